@@ -1,0 +1,324 @@
+"""TEST INFRASTRUCTURE ONLY — golden-vector generator.
+
+Runs the *unmodified* reference (``/root/reference``, imported through
+``oracle/reference_loader.py``) on seeded synthetic inputs and snapshots inputs and
+outputs as ``tests/golden/*.npz``.  ``/root/reference`` does not exist on the GPU box,
+so the fixtures (small) are committed together with this script:
+
+    python oracle/make_golden.py            # regenerates every fixture, 1 torch thread
+
+Each fixture records the reference function it came from in its ``source`` field.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reference_loader as rl  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+class RecordingLogger:
+    """Stands in for ``tonic.logger.current_logger`` to capture per-iteration infos."""
+
+    def __init__(self):
+        self.records = {}
+
+    def store(self, key, value, stats=False):
+        self.records.setdefault(key, []).append(np.array(value))
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def state_arrays(prefix, state_dict):
+    return {prefix + k: v.detach().numpy().copy() for k, v in state_dict.items()}
+
+
+# ----------------------------------------------------------------------------- cases
+
+def golden_lambda_returns(tonic):
+    """tonic/replays/utils.py:4-19 and segments.py:41-46 on edge-case shapes."""
+    rng = np.random.RandomState(0)
+    cases = {}
+    shapes = [(1, 1), (1, 7), (5, 1), (64, 8), (33, 5), (128, 3), (256, 2), (512, 4)]
+    for i, (steps, workers) in enumerate(shapes):
+        nv = rng.normal(size=(steps, workers)).astype(np.float32)
+        val = rng.normal(size=(steps, workers)).astype(np.float32)
+        rew = rng.normal(size=(steps, workers)).astype(np.float32)
+        resets = (rng.uniform(size=(steps, workers)) < 0.15)
+        terms = resets & (rng.uniform(size=(steps, workers)) < 0.5)
+        if i == 4:      # every transition is a time-out
+            resets[:] = True
+            terms[:] = False
+        if i == 5:      # every transition terminates
+            resets[:] = True
+            terms[:] = True
+        if i == 6:      # nothing ever resets (longest dependency chains)
+            resets[:] = False
+            terms[:] = False
+        resets = resets.astype(np.float32)
+        terms = terms.astype(np.float32)
+        for j, (gamma, lam) in enumerate([(0.99, 0.97), (0.9, 0.5), (1.0, 1.0), (0.99, 0.0)]):
+            ret = tonic.replays.lambda_returns(
+                values=val, next_values=nv, rewards=rew, resets=resets,
+                terminations=terms, discount_factor=gamma, trace_decay=lam)
+            seg = tonic.replays.Segment(size=steps, discount_factor=gamma, trace_decay=lam)
+            seg.initialize(0)
+            seg.buffers = dict(rewards=rew, resets=resets, terminations=terms)
+            seg.compute_returns(val.reshape(-1), nv.reshape(-1))
+            adv = seg.get_full('advantages')['advantages']
+            assert np.array_equal(seg.buffers['returns'], ret)
+            key = f'c{i}_{j}_'
+            cases.update({key + 'next_values': nv, key + 'values': val, key + 'rewards': rew,
+                          key + 'resets': resets, key + 'terminations': terms,
+                          key + 'gamma': np.float64(gamma), key + 'lambda': np.float64(lam),
+                          key + 'returns': ret, key + 'advantages': adv.reshape(steps, workers)})
+    # constant advantages -> std == 0 -> normalisation skipped (segments.py:44)
+    seg = tonic.replays.Segment(size=4)
+    seg.initialize(0)
+    ones = np.ones((4, 3), np.float32)
+    seg.buffers = dict(returns=ones * 2, values=ones)
+    cases['const_advantages'] = seg.get_full('advantages')['advantages']
+    save('lambda_returns', source='tonic/replays/utils.py:4-19; segments.py:38-48,67-78',
+         n_cases=len(shapes), **cases)
+
+
+def golden_meanstd(tonic):
+    """tonic/torch/normalizers/mean_stds.py:44-74."""
+    rng = np.random.RandomState(1)
+    norm = tonic.torch.normalizers.MeanStd()
+    norm.initialize((5,))
+    out = {}
+    for u in range(3):
+        for s in range(4):
+            batch = (rng.normal(size=(7, 5)) * (u + 1) + s).astype(np.float32)
+            norm.record(batch)
+            out[f'u{u}_s{s}_batch'] = batch
+        out[f'u{u}_sum'] = np.array(norm.new_sum)
+        out[f'u{u}_sum_sq'] = np.array(norm.new_sum_sq)
+        norm.update()
+        out[f'u{u}_mean'] = norm._mean.detach().numpy().copy()
+        out[f'u{u}_std'] = norm._std.detach().numpy().copy()
+        x = rng.normal(size=(6, 5)).astype(np.float32)
+        out[f'u{u}_x'] = x
+        out[f'u{u}_normalized'] = norm(torch.as_tensor(x)).numpy()
+    save('meanstd', source='tonic/torch/normalizers/mean_stds.py:34-74', **out)
+
+
+def golden_buffer(tonic):
+    """tonic/replays/buffers.py:28-91 (default return_steps=1)."""
+    out = {}
+    for case, (workers, size, batch) in enumerate([(1, 50, 8), (4, 64, 16), (3, 20, 5)]):
+        rng = np.random.RandomState(10 + case)
+        buf = tonic.replays.Buffer(size=size, batch_iterations=3, batch_size=batch,
+                                   steps_before_batches=0, steps_between_batches=1)
+        buf.initialize(seed=case)
+        n_store = size // workers + 5        # wraps the circular index
+        pre = f'b{case}_'
+        stored = {k: [] for k in ('observations', 'actions', 'next_observations',
+                                  'rewards', 'resets', 'terminations')}
+        for _ in range(n_store):
+            kw = dict(observations=rng.normal(size=(workers, 3)).astype(np.float32),
+                      actions=rng.uniform(-1, 1, size=(workers, 2)).astype(np.float32),
+                      next_observations=rng.normal(size=(workers, 3)).astype(np.float32),
+                      rewards=rng.normal(size=workers).astype(np.float32),
+                      resets=rng.uniform(size=workers) < 0.2,
+                      terminations=rng.uniform(size=workers) < 0.1)
+            for k in stored:
+                stored[k].append(kw[k])
+            buf.store(**kw)
+        for k in stored:
+            out[pre + 'in_' + k] = np.array(stored[k])
+        out[pre + 'index'] = np.int64(buf.index)
+        out[pre + 'size'] = np.int64(buf.size)
+        out[pre + 'max_size'] = np.int64(buf.max_size)
+        for k, v in buf.buffers.items():
+            out[pre + 'buf_' + k] = v.copy()
+        state = buf.np_random.get_state()
+        keys = ('observations', 'actions', 'next_observations', 'rewards', 'discounts')
+        for it, batch_dict in enumerate(buf.get(*keys, steps=123)):
+            for k in keys:
+                out[pre + f'get{it}_' + k] = batch_dict[k]
+        replay_rng = np.random.RandomState()
+        replay_rng.set_state(state)
+        for it in range(3):
+            out[pre + f'get{it}_indices'] = replay_rng.randint(buf.size * workers, size=batch)
+        out[pre + 'cfg'] = np.array([workers, size, batch], np.int64)
+    save('buffer', source='tonic/replays/buffers.py:28-91', **out)
+
+
+def golden_segment_minibatches(tonic):
+    """tonic/replays/segments.py:50-65 with batch_size set (index stream)."""
+    seg = tonic.replays.Segment(size=6, batch_iterations=3, batch_size=7)
+    seg.initialize(seed=3)
+    seg.num_workers = 4
+    seg.buffers = dict(idx=np.arange(24, dtype=np.float32).reshape(6, 4))
+    batches = [b['idx'].astype(np.int64) for b in seg.get('idx')]
+    save('segment_minibatch', source='tonic/replays/segments.py:50-65',
+         seed=np.int64(3), size=np.int64(24), batch_size=np.int64(7),
+         iterations=np.int64(3), lengths=np.array([len(b) for b in batches]),
+         indices=np.concatenate(batches))
+
+
+def golden_sequential(tonic):
+    """tonic/environments/distributed.py:12-58 (time-out vs termination reset logic)
+    and the Sequential(P*S) == Parallel(P, S) seed layout (:106-113)."""
+    def builder():
+        return rl.SyntheticEnvironment(3, 2, max_episode_steps=5)
+    env = tonic.environments.distribute(builder, 1, 4)
+    env.initialize(seed=7)
+    obs = [env.start()]
+    rng = np.random.RandomState(0)
+    acts, nobs, rews, rsts, terms = [], [], [], [], []
+    for _ in range(12):
+        a = rng.uniform(-1, 1, size=(4, 2)).astype(np.float32)
+        o, infos = env.step(a)
+        acts.append(a)
+        obs.append(o)
+        nobs.append(infos['observations'])
+        rews.append(infos['rewards'])
+        rsts.append(infos['resets'])
+        terms.append(infos['terminations'])
+    save('sequential', source='tonic/environments/distributed.py:12-58',
+         observations=np.array(obs), actions=np.array(acts),
+         next_observations=np.array(nobs), rewards=np.array(rews),
+         resets=np.array(rsts), terminations=np.array(terms),
+         seed=np.int64(7), max_episode_steps=np.int64(5))
+
+
+def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
+            reward_scale=1.0, updates=1):
+    """tonic/torch/agents/{a2c.py:41-73, ppo.py:20-67}: acts with the reference agent on
+    a synthetic env for `steps` time steps so the real store/record/update path runs."""
+    def builder():
+        return rl.SyntheticEnvironment(obs_dim, act_dim, max_episode_steps=7)
+    env = tonic.environments.distribute(builder, 1, workers)
+    env.initialize(seed=seed)
+    agent = tonic.torch.agents.PPO(
+        replay=tonic.replays.Segment(size=steps, batch_iterations=iterations))
+    agent.initialize(env.observation_space, env.action_space, seed=seed)
+    out = state_arrays('init/', agent.model.state_dict())
+    recorder = RecordingLogger()
+    tonic.logger.current_logger = recorder
+    observations = env.start()
+    eps_all, act_all, lp_all, obs_all = [], [], [], []
+    rng = np.random.RandomState(seed + 1)
+    for update in range(updates):
+        for t in range(steps):
+            gen_state = torch.get_rng_state()
+            actions = agent.step(observations, t * workers)
+            after = torch.get_rng_state()
+            torch.set_rng_state(gen_state)
+            eps = torch.randn(workers, act_dim).numpy()
+            torch.set_rng_state(after)
+            eps_all.append(eps)
+            act_all.append(actions.copy())
+            lp_all.append(agent.last_log_probs.copy())
+            obs_all.append(observations.copy())
+            observations, infos = env.step(actions)
+            # make rewards less trivial and add a few true terminations
+            infos['rewards'] = (infos['rewards'] * reward_scale +
+                                rng.normal(size=workers)).astype(np.float32)
+            term = rng.uniform(size=workers) < 0.05
+            infos['terminations'] = term
+            infos['resets'] = infos['resets'] | term
+            if t == steps - 1:
+                seg = {k: v.copy() for k, v in agent.replay.buffers.items()}
+                norm = agent.model.observation_normalizer
+                pre_state = state_arrays(f'pre{update}/', agent.model.state_dict())
+            agent.update(**infos, steps=t * workers)
+        # the last store happened inside update(); rebuild the full segment view
+        seg = {k: v.copy() for k, v in agent.replay.buffers.items()}
+        pre = f'u{update}/'
+        for k in ('observations', 'actions', 'next_observations', 'rewards', 'resets',
+                  'terminations', 'log_probs', 'values', 'next_values', 'returns',
+                  'advantages'):
+            out[pre + 'segment/' + k] = seg[k]
+        out.update(pre_state)
+        out.update(state_arrays(f'post{update}/', agent.model.state_dict()))
+        for k, v in recorder.records.items():
+            if k == 'critic/v':
+                out[pre + 'info/critic/v_mean'] = np.array([x.mean() for x in v])
+                out[pre + 'info/critic/v_first'] = v[0]
+            else:
+                out[pre + 'info/' + k] = np.array(v)
+        recorder.records.clear()
+        out[pre + 'norm/count'] = np.int64(norm.count)
+        if update == 0:
+            out.update(first_update_probes(tonic, builder, seed, seg, iterations))
+    out['act/observations'] = np.array(obs_all)
+    out['act/eps'] = np.array(eps_all)
+    out['act/actions'] = np.array(act_all)
+    out['act/log_probs'] = np.array(lp_all)
+    out['cfg'] = np.array([obs_dim, act_dim, workers, steps, seed, iterations, updates],
+                          np.int64)
+    save(name, source='tonic/torch/agents/a2c.py:41-99; ppo.py:20-67; '
+                      'updaters/actors.py:70-112; updaters/critics.py:18-28', **out)
+
+
+def first_update_probes(tonic, builder, seed, seg, iterations):
+    """Two extra reference runs on the first update's batch (fresh agents, same seed ->
+    same initial parameters; updaters called as ppo.py:33-46 does):
+      * ``iter1/``  parameters after exactly ONE actor+critic iteration (well conditioned:
+        the 1e-5 parameter-delta tolerance applies strictly here);
+      * ``noise/``  |delta| between the reference on the batch and the reference on a
+        sample-PERMUTED batch after all iterations.  Full-batch means are permutation
+        invariant, so this is the reference's own float32 summation-order noise after
+        `iterations` Adam steps — the floor any independent implementation can reach."""
+    flat = {k: tonic.replays.flatten_batch(v) for k, v in seg.items()}
+    n = flat['rewards'].shape[0]
+
+    def run(order, iters):
+        env = tonic.environments.distribute(builder, 1, 1)
+        agent = tonic.torch.agents.PPO()
+        agent.initialize(env.observation_space, env.action_space, seed=seed)
+        batch = {k: torch.as_tensor(flat[k][order]) for k in
+                 ('observations', 'actions', 'advantages', 'log_probs', 'returns')}
+        train_actor = True
+        for _ in range(iters):
+            if train_actor:
+                infos = agent.actor_updater(batch['observations'], batch['actions'],
+                                            batch['advantages'], batch['log_probs'])
+                train_actor = not infos['stop'].numpy()
+            agent.critic_updater(batch['observations'], batch['returns'])
+        return agent.model.state_dict()
+
+    identity = np.arange(n)
+    one = run(identity, 1)
+    full = run(identity, iterations)
+    shuffled = run(np.random.RandomState(99).permutation(n), iterations)
+    out = state_arrays('iter1/', one)
+    for k in full:
+        out['noise/' + k] = np.abs(full[k].numpy() - shuffled[k].numpy())
+        out['probe_full/' + k] = full[k].numpy().copy()
+    return out
+
+
+def main():
+    torch.set_num_threads(1)
+    tonic = rl.load_reference()
+    golden_lambda_returns(tonic)
+    golden_meanstd(tonic)
+    golden_buffer(tonic)
+    golden_segment_minibatches(tonic)
+    golden_sequential(tonic)
+    # cfg-2 shapes (HalfCheetah O=17, A=6) at N = 32*8 = 256, two consecutive updates.
+    run_ppo(tonic, 'ppo_halfcheetah_small', 17, 6, workers=8, steps=32, seed=0, updates=2)
+    # cfg-1 shapes (Pendulum O=3, A=1), W=1.
+    run_ppo(tonic, 'ppo_pendulum_small', 3, 1, workers=1, steps=64, seed=1, updates=1)
+    # cfg-5 shapes (AntBullet O=28, A=8), larger rewards so the KL stop triggers.
+    run_ppo(tonic, 'ppo_antbullet_small', 28, 8, workers=16, steps=24, seed=2,
+            reward_scale=5.0, updates=1)
+
+
+if __name__ == '__main__':
+    main()
