@@ -145,7 +145,19 @@ def test_ppo_single_iteration_deltas_strict(golden, name):
     seg = {k: g[f'u0/segment/{k}'] for k in (
         'observations', 'actions', 'next_observations', 'rewards', 'resets',
         'terminations', 'log_probs')}
-    new_actor, new_critic, _, _ = port.ppo_update(actor, critic, norm, seg, batch_iterations=1)
+    new_actor, new_critic, _, extra = port.ppo_update(actor, critic, norm, seg, batch_iterations=1)
     ref_actor, ref_critic, _ = _params(g, 'iter1/')
-    for got, want, before in zip(new_actor + new_critic, ref_actor + ref_critic, actor + critic):
-        np.testing.assert_allclose(got - before, want - before, atol=1e-5, rtol=0)
+    flat = {k: port.flatten_time_major(v) for k, v in seg.items()}
+    g_actor, _ = port.clipped_ratio_grads(actor, flat['observations'], flat['actions'],
+                                          extra['advantages'], flat['log_probs'])
+    g_critic, _ = port.value_regression_grads(critic, norm[0], norm[1], flat['observations'],
+                                              extra['returns'].reshape(-1))
+    for got, want, before, grad in zip(new_actor + new_critic, ref_actor + ref_critic,
+                                       actor + critic, g_actor + g_critic):
+        # Adam's first step is lr * g / (|g| + 1e-8): where |g| is at float32 summation-noise
+        # level the reference's own step has an arbitrary sign, so only the bound |step| <= lr
+        # can be checked there; everywhere else the 1e-5 tolerance applies strictly.
+        live = np.abs(grad) > 1e-6 * np.abs(grad).max()
+        assert live.mean() > 0.99
+        np.testing.assert_allclose((got - before)[live], (want - before)[live], atol=1e-5, rtol=0)
+        assert np.abs(got - before).max() <= 1.01e-3
