@@ -1,0 +1,178 @@
+/*
+ * libtonic_hip.so — C ABI of the MI355X (gfx950) rollout-collect + learner-update engine
+ * that sits under Tonic's duck-typed Python API (tonic.torch.agents.Agent / tonic.Trainer /
+ * tonic.environments.distribute / tonic.replays.Segment,Buffer).
+ *
+ * The reference (fabiopardo/tonic) has NO native code and NO FFI: every entry point below
+ * replaces arithmetic that the reference runs in NumPy / torch-CPU; the "replaces" line of
+ * each declaration cites that reference code (paths relative to the reference checkout).
+ * The Python binding a Tonic maintainer would add is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / HIP C++ types in signatures.
+ *     `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *   - Every pointer marked `d_` is DEVICE memory owned by the CALLER (e.g. a torch ROCm
+ *     tensor's data_ptr()); row-major contiguous float32 unless stated.  The library
+ *     allocates nothing and never synchronises: every call only enqueues kernels on
+ *     `stream` (hipGraph-capturable).  Scratch space is passed in by the caller; its size
+ *     comes from the matching *_workspace_bytes() query.
+ *   - Return value: 0 on success, negative tonic_status otherwise; tonic_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *   - Shapes: T = Segment time steps, W = workers, N = T*W samples (time-major flattening,
+ *     tonic/replays/utils.py:22-25), O = observation size, A = action size, hidden = 64.
+ *   - Parameter blocks are ONE flat float32 buffer per network in the reference's
+ *     `model.parameters()` order:
+ *       PPO actor : W1[64,O] b1[64] W2[64,64] b2[64] log_scale[1,A] W3[A,64] b3[A]
+ *       V critic  : W1[64,O] b1[64] W2[64,64] b2[64] w3[1,64] b3[1]
+ *     Gradient / Adam-moment buffers use the same layout and length.
+ */
+#ifndef TONIC_HIP_H
+#define TONIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tonic_status {
+  TONIC_OK = 0,
+  TONIC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / NULL pointer / unsupported size   */
+  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* O > 64, A > 8 or hidden != 64 for mlp64 path */
+  TONIC_ERR_LAUNCH = -3,             /* hipLaunchKernel / hipMemsetAsync failed       */
+  TONIC_ERR_WORKSPACE = -4           /* workspace too small                           */
+} tonic_status;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* tonic_last_error(void);
+/* ABI version (bumped on any signature change) and the gfx target the kernels were built for. */
+int32_t tonic_abi_version(void);
+const char* tonic_target_arch(void);
+
+/* Developer tuning knobs (process-wide; call before sizing workspaces).  Keys:
+ *   "grad_waves" = 4 | 8   waves per workgroup of the fused forward+backward kernel. */
+int tonic_set_tuning(const char* key, int32_t value);
+
+/* Sizes of the flat parameter blocks described above. */
+int64_t tonic_ppo_actor_param_count(int32_t O, int32_t A);
+int64_t tonic_v_critic_param_count(int32_t O);
+
+/* ---- GAE / lambda-returns (HBM-bound scan) --------------------------------------------
+ * replaces: tonic/replays/utils.py:4-19 (lambda_returns) + tonic/replays/segments.py:41-46
+ *           (raw advantages and their global mean / population std).
+ * Inputs  [T,W]: d_next_values, d_rewards, d_resets, d_terminations, d_values (float32; the
+ *           0/1 flags are stored as float32 exactly like Segment.store, segments.py:33).
+ * Outputs [T,W]: d_returns, d_advantages (RAW = returns - values; the normalisation
+ *           (adv-mean)/std is applied in-register by the PPO actor kernel from d_adv_stats).
+ *         d_adv_stats[4] float32 = {mean, std, all_zero_flag (1.0 if every raw advantage is
+ *           0, actors.py:71), normalise_flag (1.0 if std != 0, segments.py:44)}.
+ * `chunks` = number of time chunks the scan is split into (>=1, divides nothing required);
+ *           0 lets the library choose from (T, W).  With 1 chunk the float32 operation
+ *           order is exactly the reference's (bit-exact returns); with more, chunk carries
+ *           are composed as affine maps and returns agree to ~1e-6 relative.
+ */
+int64_t tonic_gae_workspace_bytes(int64_t T, int64_t W, int32_t chunks);
+int tonic_gae_lambda_returns(const float* d_next_values, const float* d_rewards,
+                             const float* d_resets, const float* d_terminations,
+                             const float* d_values, float* d_returns, float* d_advantages,
+                             float* d_adv_stats, int64_t T, int64_t W, double discount_factor,
+                             double trace_decay, int32_t chunks, void* d_workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* ---- acting: policy forward + sample + log-prob ----------------------------------------
+ * replaces: tonic/torch/agents/a2c.py:75-85 (A2C._step) = Actor.forward
+ *           (tonic/torch/models/actors.py:60-66,134-137; MLP utils.py:22-23) + Normal.sample
+ *           + log_prob.sum(-1).  d_eps [n,A] are standard-normal draws made by the host
+ *           torch CPU generator so the RNG stream is the reference's;
+ *           actions = loc + scale*eps.  Passing d_eps = NULL returns the mode (loc) instead.
+ * Outputs: d_actions [n,A], d_log_probs [n] (may be NULL).
+ */
+int tonic_ppo_act(const float* d_actor_params, const float* d_observations,
+                  const float* d_eps, float* d_actions, float* d_log_probs, int64_t n,
+                  int32_t O, int32_t A, void* stream);
+
+/* ---- critic forward ---------------------------------------------------------------------
+ * replaces: tonic/torch/agents/a2c.py:92-99 (A2C._evaluate) = Critic.forward
+ *           (tonic/torch/models/critics.py:15-20,87-90; encoders.py:13-16;
+ *            tonic/torch/normalizers/mean_stds.py:34-39 with clip=None).
+ * d_norm_mean / d_norm_std: [O] (the MeanStd `_mean` / `_std` parameters).
+ */
+int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
+                        const float* d_norm_std, const float* d_observations, float* d_values,
+                        int64_t n, int32_t O, void* stream);
+
+/* ---- learner: fused forward + loss + backward over the whole batch ------------------------
+ * Both calls write per-workgroup partial sums into d_workspace, then reduce them into
+ * d_grad_sums (SUMS over the n local samples, not means: the 1/N_global scaling happens in
+ * tonic_adam_step so that multi-GPU ranks can all-reduce d_grad_sums first).
+ * d_grad_sums layout: [P gradient sums | 8 statistic sums], P = param count:
+ *   actor  stats: {loss_sum, kl_sum, clipped_count, n*entropy, n*mean_sigma, n, 0, 0}
+ *   critic stats: {squared_error_sum, value_sum, 0, 0, 0, n, 0, 0}        (n = local samples)
+ * d_skip_flag (int32, may be NULL): when *d_skip_flag != 0 the kernels exit immediately
+ * and leave d_grad_sums untouched (device-side replacement of the per-iteration
+ * `stop.numpy()` host sync of tonic/torch/agents/ppo.py:45-46).
+ *
+ * tonic_ppo_actor_grad replaces: tonic/torch/updaters/actors.py:70-99 (ClippedRatio
+ *   forward, surrogate loss, entropy, backward).   d_adv_stats as produced by
+ *   tonic_gae_lambda_returns.
+ * tonic_value_regression_grad replaces: tonic/torch/updaters/critics.py:18-24 (VRegression).
+ */
+int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_count);
+int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_observations,
+                         const float* d_actions, const float* d_advantages,
+                         const float* d_adv_stats, const float* d_old_log_probs,
+                         float* d_grad_sums, int64_t n, int32_t O, int32_t A,
+                         double ratio_clip, double entropy_coeff, const int32_t* d_skip_flag,
+                         void* d_workspace, int64_t workspace_bytes, void* stream);
+int tonic_value_regression_grad(const float* d_critic_params, const float* d_norm_mean,
+                                const float* d_norm_std, const float* d_observations,
+                                const float* d_returns, float* d_grad_sums, int64_t n,
+                                int32_t O, void* d_workspace, int64_t workspace_bytes,
+                                void* stream);
+
+/* ---- optimizer ---------------------------------------------------------------------------
+ * replaces: torch.optim.Adam single-tensor path (torch/optim/adam.py:395-547) as
+ *   constructed at tonic/torch/updaters/actors.py:58-59 and critics.py:9-10, applied to the
+ *   flat parameter block: grad = d_grad_sums[i] * grad_scale (grad_scale = 1/N_global).
+ * d_state: int32[4] = {step_count, stop_flag, reserved, reserved}; step_count is
+ *   incremented on the device so the call is graph-replayable.
+ * PPO extras (pass stats_kind = 1 for the actor, 2 for the critic, 0 for none): finalises
+ *   the 8 statistic sums into d_info_row[8] and, for the actor, sets stop_flag when
+ *   kl > kl_threshold (actors.py:102-112).  Actor rows: {loss, kl, entropy, clip_fraction,
+ *   std, stop, ran(1.0), 0}; critic rows: {loss, v_mean, ...}.  When d_adv_stats says every
+ *   advantage is zero the actor step is skipped and loss=kl=clip_fraction=0 (actors.py:71-78).
+ * The whole call is skipped when d_skip_flag (may alias &d_state[1]) is non-zero.
+ */
+int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
+                    float* d_exp_avg_sq, int32_t* d_state, int64_t param_count,
+                    double grad_scale, double lr, double beta1, double beta2, double eps,
+                    int32_t stats_kind, double kl_threshold, double entropy_coeff,
+                    const float* d_adv_stats, float* d_info_row, const int32_t* d_skip_flag,
+                    void* stream);
+
+/* ---- replay: HBM-resident Segment -----------------------------------------------------------
+ * replaces: tonic/replays/segments.py:27-36 (Segment.store, one time row for all W workers)
+ *   and tonic/torch/normalizers/mean_stds.py:44-48 (MeanStd.record: sequential float32
+ *   accumulation in worker order, square then add — bit-exact by construction).
+ * d_norm_acc: float32[2*O] = {new_sum[O], new_sum_sq[O]} (may be NULL to skip recording).
+ */
+int tonic_segment_store(float* d_seg_observations, float* d_seg_actions,
+                        float* d_seg_next_observations, float* d_seg_rewards,
+                        float* d_seg_resets, float* d_seg_terminations, float* d_seg_log_probs,
+                        const float* d_observations, const float* d_actions,
+                        const float* d_next_observations, const float* d_rewards,
+                        const float* d_resets, const float* d_terminations,
+                        const float* d_log_probs, float* d_norm_acc, int64_t row, int64_t W,
+                        int32_t O, int32_t A, void* stream);
+
+/* ---- target networks (SAC / TD3) ---------------------------------------------------------------
+ * replaces: tonic/torch/models/actor_critics.py:126-130 (update_targets): per element
+ *   t = fl(fl(t*(1-coeff)) + fl(coeff*o)) — three roundings, no FMA — on flat buffers.
+ */
+int tonic_polyak_update(float* d_target, const float* d_online, int64_t n, double coeff,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TONIC_HIP_H */

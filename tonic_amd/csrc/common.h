@@ -1,0 +1,63 @@
+// Shared host/device helpers for libtonic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tonic_hip.h"
+
+namespace tonic {
+
+void set_error(const char* fmt, ...);
+
+#define TONIC_REQUIRE(cond, code, ...)      \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::tonic::set_error(__VA_ARGS__);      \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define TONIC_CHECK_LAUNCH(what)                                               \
+  do {                                                                         \
+    hipError_t err__ = hipGetLastError();                                      \
+    if (err__ != hipSuccess) {                                                 \
+      ::tonic::set_error("%s: %s", (what), hipGetErrorString(err__));          \
+      return TONIC_ERR_LAUNCH;                                                 \
+    }                                                                          \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr int kHidden = 64;       // both hidden layers of the PPO actor/critic (a2c.py:7-17)
+constexpr int kStatSlots = 8;     // statistic sums appended to every gradient block
+
+// Orders LDS traffic of ONE wave against itself: the writes of some lanes are read by other
+// lanes of the same wave.  LDS operations of a wave execute in issue order, so only the
+// compiler has to be stopped from re-ordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace tonic

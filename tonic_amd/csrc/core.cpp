@@ -1,0 +1,22 @@
+// Library-level entry points: error reporting and version queries.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/tonic_hip.h"
+
+namespace tonic {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace tonic
+
+extern "C" const char* tonic_last_error(void) { return tonic::g_error; }
+extern "C" int32_t tonic_abi_version(void) { return 1; }
+extern "C" const char* tonic_target_arch(void) { return "gfx950"; }

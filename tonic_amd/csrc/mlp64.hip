@@ -1,0 +1,831 @@
+// Fused 2x64-tanh MLP kernels for the PPO actor / V critic (gfx950, wave64, fp32 MFMA).
+//
+// Math restated from (paths relative to the reference checkout):
+//   tonic/torch/models/utils.py:12-23 (MLP), actors.py:60-66,134-137 (Gaussian head),
+//   critics.py:15-20,87-90 (value head), encoders.py:13-16, normalizers/mean_stds.py:34-39,
+//   tonic/torch/updaters/actors.py:70-112 (ClippedRatio), critics.py:18-28 (VRegression).
+//
+// Design (one wave = one 32-sample tile, no block-level barriers inside the tile loop):
+//   * "S layout": lane = (sample s = lane&31, half h = lane>>5); register q in [0,32) holds
+//     hidden feature feat(q,h).  This is exactly the C/D layout of
+//     v_mfma_f32_32x32x2_f32 when the product is formed TRANSPOSED,
+//     D[out_feature][sample] = sum_k W[out_feature][k] * X^T[k][sample]
+//     (A operand = weights streamed from LDS, B operand = activations in registers), and it
+//     is ALSO a valid B-operand layout for the next layer because the k order of an MFMA
+//     chain is free: step s contracts feature feat(s,0) from lanes 0-31 with feat(s,1) from
+//     lanes 32-63, and the LDS weight image is pre-permuted to match.  So the forward chain
+//     x -> h1 -> h2 and the backward chain dz2 -> dh1 never leave registers.
+//   * Weight gradients contract over SAMPLES, which needs "F layout" operands (lane = feature,
+//     registers = samples).  Each wave transposes S -> F through a private LDS scratch
+//     (row stride 36 floats: conflict-free ds_write_b32 / ds_read_b128), then accumulates
+//     dW2 (4 tiles), dW1 (2 tiles) with MFMA and the skinny dW3 / biases with VALU, all in
+//     registers across the wave's whole tile loop.
+//   * End of kernel: waves fold their accumulators into one LDS image in wave order
+//     (deterministic), one partial block per workgroup goes to HBM, a second tiny kernel
+//     reduces the partials in fixed order.
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace tonic {
+
+constexpr int TS = 36;  // floats per row of the per-wave transpose scratch
+
+__host__ __device__ constexpr int feat(int q, int h) {
+  return 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
+}
+
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
+constexpr float kEntropyConst = 1.41893853320467274178f; // 0.5 + 0.5*log(2*pi)
+
+template <int KS1, int AP, bool BWD, int WAVES>
+struct Lds {
+  static constexpr int W1S = 0;                                  // [2][KS1][64]
+  static constexpr int W2S = W1S + 2 * KS1 * 64;                 // [2][32][64]
+  static constexpr int W2B = W2S + 2 * 32 * 64;                  // [2][32][64] (BWD only)
+  static constexpr int B1P = W2B + (BWD ? 2 * 32 * 64 : 0);      // [2][32]
+  static constexpr int B2P = B1P + 64;                           // [2][32]
+  static constexpr int W3P = B2P + 64;                           // [AP][2][32]
+  static constexpr int HC = W3P + AP * 64;                       // [8][4] head constants
+  static constexpr int NORM = HC + 32;                           // mean[2*KS1], std[2*KS1]
+  static constexpr int WAVE0 = (NORM + 4 * KS1 + 3) / 4 * 4;     // per-wave scratch
+  static constexpr int T_FLOATS = 64 * TS;
+  static constexpr int DO_FLOATS = 32 * 8;
+  static constexpr int WAVE_FLOATS = BWD ? (T_FLOATS + DO_FLOATS) : 0;
+  static constexpr int TOTAL = WAVE0 + WAVES * WAVE_FLOATS;
+  static constexpr int BYTES = TOTAL * 4;
+};
+
+struct MlpArgs {
+  const float* params;
+  const float* obs;
+  const float* actions;     // actor grad / unused
+  const float* adv;         // raw advantages
+  const float* adv_stats;   // {mean, std, all_zero, normalise}
+  const float* old_logp;
+  const float* returns;     // critic grad
+  const float* norm_mean;   // critic
+  const float* norm_std;
+  const float* eps;         // act
+  float* out0;              // act: actions, value: values, grad: partials
+  float* out1;              // act: log_probs
+  const int32_t* skip;
+  int64_t n;
+  int O, A;
+  float clip_lo, clip_hi;
+  int pstride;
+};
+
+// ---------------------------------------------------------------------------- staging
+
+template <int KS1, int AP, bool BWD, bool ACTOR, int WAVES>
+__device__ __forceinline__ void stage_weights(float* lds, const MlpArgs& a) {
+  using L = Lds<KS1, AP, BWD, WAVES>;
+  const int tid = threadIdx.x, nth = WAVES * 64;
+  const int O = a.O, A = a.A;
+  const float* W1 = a.params;
+  const float* b1 = W1 + 64 * O;
+  const float* W2 = b1 + 64;
+  const float* b2 = W2 + 64 * 64;
+  const float* tail = b2 + 64;
+  const float* W3 = ACTOR ? tail + A : tail;
+  const float* b3 = W3 + (ACTOR ? A * 64 : 64);
+  for (int idx = tid; idx < 2 * KS1 * 64; idx += nth) {
+    const int t = idx / (KS1 * 64), rem = idx % (KS1 * 64);
+    const int st = rem >> 6, l = rem & 63, kh = l >> 5, i = l & 31, k = 2 * st + kh;
+    lds[L::W1S + idx] = k < O ? W1[(32 * t + i) * O + k] : 0.f;
+  }
+  for (int idx = tid; idx < 2 * 32 * 64; idx += nth) {
+    const int t = idx >> 11, st = (idx >> 6) & 31, l = idx & 63, kh = l >> 5, i = l & 31;
+    const int f = feat(st, kh);
+    lds[L::W2S + idx] = W2[(32 * t + i) * 64 + f];
+    if (BWD) lds[L::W2B + idx] = W2[f * 64 + 32 * t + i];
+  }
+  for (int idx = tid; idx < 64; idx += nth) {
+    const int h = idx >> 5, q = idx & 31;
+    lds[L::B1P + idx] = b1[feat(q, h)];
+    lds[L::B2P + idx] = b2[feat(q, h)];
+  }
+  for (int idx = tid; idx < AP * 64; idx += nth) {
+    const int aa = idx >> 6, h = (idx >> 5) & 1, q = idx & 31;
+    const int nout = ACTOR ? A : 1;
+    lds[L::W3P + idx] = aa < nout ? W3[aa * 64 + feat(q, h)] : 0.f;
+  }
+  for (int idx = tid; idx < 8; idx += nth) {
+    // head constants {bias, sigma, 1/(2 var), log sigma + log sqrt(2 pi)}
+    float bias = 0.f, sigma = 1.f, half_inv_var = 0.f, logc = 0.f;
+    if (ACTOR) {
+      if (idx < A) {
+        bias = b3[idx];
+        const float ls = tail[idx];
+        const float sp = ls > 20.f ? ls : log1pf(expf(ls));       // softplus, threshold 20
+        sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);            // actors.py:63-64
+        half_inv_var = 1.0f / (2.0f * (sigma * sigma));
+        logc = logf(sigma) + kLogSqrt2Pi;
+      }
+    } else if (idx == 0) {
+      bias = b3[0];
+    }
+    lds[L::HC + idx * 4 + 0] = bias;
+    lds[L::HC + idx * 4 + 1] = sigma;
+    lds[L::HC + idx * 4 + 2] = half_inv_var;
+    lds[L::HC + idx * 4 + 3] = logc;
+  }
+  if (!ACTOR) {
+    for (int idx = tid; idx < 2 * KS1; idx += nth) {
+      lds[L::NORM + idx] = idx < O ? a.norm_mean[idx] : 0.f;
+      lds[L::NORM + 2 * KS1 + idx] = idx < O ? a.norm_std[idx] : 1.f;
+    }
+  }
+}
+
+// --------------------------------------------------------------------- MFMA building blocks
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void load_bias(const float* bp, int h, f32x16& acc0, f32x16& acc1) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(bp + h * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v0 = p[j], v1 = p[4 + j];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc0[4 * j + c] = v0[c];
+      acc1[4 * j + c] = v1[c];
+    }
+  }
+}
+
+// out[q] = tanh(bias + sum_k W[feat(q,h)][k] * in[k]) for this lane's sample (S layout).
+template <int KS>
+__device__ __forceinline__ void dense_tanh(const float* w_img, const float* bias_img,
+                                           const float (&in)[KS], float (&out)[32], int lane) {
+  f32x16 acc0, acc1;
+  load_bias(bias_img, lane >> 5, acc0, acc1);
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    const float a0 = w_img[st * 64 + lane];
+    const float a1 = w_img[(KS + st) * 64 + lane];
+    acc0 = mfma32(a0, in[st], acc0);
+    acc1 = mfma32(a1, in[st], acc1);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    out[r] = tanhf(acc0[r]);
+    out[16 + r] = tanhf(acc1[r]);
+  }
+}
+
+// S-layout register file -> per-wave scratch T[feature][sample].
+__device__ __forceinline__ void scatter_S(float* T, const float (&v)[32], int s, int h) {
+#pragma unroll
+  for (int q = 0; q < 32; ++q) T[feat(q, h) * TS + s] = v[q];
+}
+
+// F layout: lane (c = lane&31, kh = lane>>5) gets feature 32*t + c, samples 16*kh .. 16*kh+15.
+__device__ __forceinline__ void gather_F(const float* T, int t, int c, int kh, float (&out)[16]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(T + (32 * t + c) * TS + 16 * kh);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = p[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[4 * j + e] = v[e];
+  }
+}
+
+template <int KS1, bool NORMALISE>
+__device__ __forceinline__ void load_obs(const MlpArgs& a, const float* norm, int64_t ns,
+                                         bool valid, int h, float (&x)[KS1]) {
+#pragma unroll
+  for (int st = 0; st < KS1; ++st) {
+    const int k = 2 * st + h;
+    float v = 0.f;
+    if (valid && k < a.O) {
+      v = a.obs[ns * a.O + k];
+      if (NORMALISE) v = (v - norm[k]) / norm[2 * KS1 + k];   // mean_stds.py:36
+    }
+    x[st] = v;
+  }
+}
+
+// Head pre-activation z[a] = b3[a] + sum_f W3[a][f] * h2[f] (both halves end with the sum).
+template <int AP, int LW3P, int LHC>
+__device__ __forceinline__ void head_linear(const float* lds, const float (&h2)[32], int h,
+                                            float (&z)[AP]) {
+  const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + LW3P);
+#pragma unroll
+  for (int aa = 0; aa < AP; ++aa) {
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 w = w3p[(aa * 2 + h) * 8 + j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], w[e], part);
+    }
+    z[aa] = part + __shfl_xor(part, 32, 64) + lds[LHC + aa * 4];
+  }
+}
+
+// ------------------------------------------------------------------------ forward kernels
+
+// Acting: a2c.py:75-85.  One wave per 32 observations.
+template <int KS1, int AP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ppo_act_kernel(MlpArgs a) {
+  using L = Lds<KS1, AP, false, WAVES>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<KS1, AP, false, true, WAVES>(lds, a);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
+       tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t ns = tile * 32 + s;
+    const bool valid = ns < a.n;
+    float x[KS1], h1[32], h2[32], z[AP];
+    load_obs<KS1, false>(a, nullptr, ns, valid, h, x);
+    dense_tanh<KS1>(lds + L::W1S, lds + L::B1P, x, h1, lane);
+    dense_tanh<32>(lds + L::W2S, lds + L::B2P, h1, h2, lane);
+    head_linear<AP, L::W3P, L::HC>(lds, h2, h, z);
+    float logp = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) {
+      if (aa < a.A) {
+        const float loc = tanhf(z[aa]);
+        const float sigma = lds[L::HC + aa * 4 + 1];
+        float act = loc;
+        if (a.eps != nullptr && valid) act = loc + sigma * a.eps[ns * a.A + aa];
+        const float d = act - loc;
+        logp += -(d * d) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
+        if (valid && h == 0) a.out0[ns * a.A + aa] = act;
+      }
+    }
+    if (valid && h == 0 && a.out1 != nullptr) a.out1[ns] = logp;
+  }
+}
+
+// Critic forward: a2c.py:92-99.
+template <int KS1, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void value_forward_kernel(MlpArgs a) {
+  using L = Lds<KS1, 1, false, WAVES>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<KS1, 1, false, false, WAVES>(lds, a);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
+       tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t ns = tile * 32 + s;
+    const bool valid = ns < a.n;
+    float x[KS1], h1[32], h2[32], z[1];
+    load_obs<KS1, true>(a, lds + L::NORM, ns, valid, h, x);
+    dense_tanh<KS1>(lds + L::W1S, lds + L::B1P, x, h1, lane);
+    dense_tanh<32>(lds + L::W2S, lds + L::B2P, h1, h2, lane);
+    head_linear<1, L::W3P, L::HC>(lds, h2, h, z);
+    if (valid && h == 0) a.out0[ns] = z[0];
+  }
+}
+
+// -------------------------------------------------------- fused forward + loss + backward
+
+template <int KS1, int AP, bool ACTOR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpArgs a) {
+  using L = Lds<KS1, AP, true, WAVES>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (a.skip != nullptr && *a.skip != 0) return;
+  stage_weights<KS1, AP, true, ACTOR, WAVES>(lds, a);
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, h = lane >> 5;
+  const int c = s, kh = h;   // names used when the lane acts in F layout
+  float* T = lds + L::WAVE0 + wave * L::WAVE_FLOATS;
+  float* DO = T + L::T_FLOATS;
+  const int O = a.O, A = a.A;
+
+  float adv_mean = 0.f, adv_std = 1.f;
+  bool adv_norm = false;
+  if (ACTOR) {
+    adv_mean = a.adv_stats[0];
+    adv_std = a.adv_stats[1];
+    adv_norm = a.adv_stats[3] != 0.f;
+  }
+
+  // accumulators that live across the whole tile loop
+  f32x16 gW2[2][2], gW1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gW2[i][0][r] = 0.f; gW2[i][1][r] = 0.f; gW1[i][r] = 0.f; }
+  }
+  float gW3[2][AP], gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gb3[AP], gsig[AP];
+#pragma unroll
+  for (int aa = 0; aa < AP; ++aa) { gW3[0][aa] = gW3[1][aa] = 0.f; gb3[aa] = 0.f; gsig[aa] = 0.f; }
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;   // loss, kl | sq err, v ; clipped ; n
+
+  const int64_t ntiles = (a.n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
+       tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t ns = tile * 32 + s;
+    const bool valid = ns < a.n;
+    const bool counted = valid && h == 0;
+    float x[KS1], h1[32], h2[32], z[AP], dzl[AP];
+    load_obs<KS1, !ACTOR>(a, lds + L::NORM, ns, valid, h, x);
+    dense_tanh<KS1>(lds + L::W1S, lds + L::B1P, x, h1, lane);
+    dense_tanh<32>(lds + L::W2S, lds + L::B2P, h1, h2, lane);
+    head_linear<AP, L::W3P, L::HC>(lds, h2, h, z);
+
+    if (ACTOR) {
+      // ---- ClippedRatio loss (updaters/actors.py:81-91) and d loss / d z
+      float logp = 0.f, loc[AP], dif[AP];
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        loc[aa] = 0.f; dif[aa] = 0.f;
+        if (aa < A) {
+          loc[aa] = tanhf(z[aa]);
+          const float act = valid ? a.actions[ns * A + aa] : loc[aa];
+          dif[aa] = act - loc[aa];
+          logp += -(dif[aa] * dif[aa]) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
+        }
+      }
+      const float old_lp = valid ? a.old_logp[ns] : logp;
+      float adv = valid ? a.adv[ns] : 0.f;
+      if (adv_norm) adv = (adv - adv_mean) / adv_std;             // segments.py:45
+      const float ratio = expf(logp - old_lp);
+      const float clipped_ratio = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+      const float surr1 = adv * ratio, surr2 = adv * clipped_ratio;
+      const bool outside = ratio > a.clip_hi || ratio < a.clip_lo;
+      const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
+      const float g = (dead || !valid) ? 0.f : -(adv * ratio);    // d(-min)/d logp, unscaled
+      if (counted) {
+        st0 += -fminf(surr1, surr2);
+        st1 += old_lp - logp;
+        st2 += outside ? 1.f : 0.f;
+        st3 += 1.f;
+      }
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        dzl[aa] = 0.f;
+        if (aa < A) {
+          const float sigma = lds[L::HC + aa * 4 + 1];
+          const float inv_var = 2.f * lds[L::HC + aa * 4 + 2];
+          const float dloc = g * dif[aa] * inv_var;                      // d logp / d loc
+          dzl[aa] = dloc * (1.f - loc[aa] * loc[aa]);
+          if (counted) {
+            gsig[aa] += g * (dif[aa] * dif[aa] * inv_var / sigma - 1.f / sigma);
+            gb3[aa] += dzl[aa];
+          }
+        }
+      }
+    } else {
+      // ---- MSE (updaters/critics.py:20-21): d/dv of (v - ret)^2, unscaled by 1/N
+      const float ret = valid ? a.returns[ns] : 0.f;
+      const float err = valid ? z[0] - ret : 0.f;
+      dzl[0] = 2.f * err;
+      if (counted) {
+        st0 += err * err;
+        st1 += z[0];
+        st3 += 1.f;
+        gb3[0] += dzl[0];
+      }
+    }
+
+    // ---- dW3 (VALU, F layout): needs h2^T and the per-sample dz of the head
+    scatter_S(T, h2, s, h);
+    if (h == 0) {
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        if (aa < 4) lo[aa] = dzl[aa]; else hi[aa - 4] = dzl[aa];
+      }
+      reinterpret_cast<f32x4*>(DO + s * 8)[0] = lo;
+      if (AP > 4) reinterpret_cast<f32x4*>(DO + s * 8)[1] = hi;
+    }
+    wave_lds_sync();
+    {
+      float hF[2][16];
+      gather_F(T, 0, c, kh, hF[0]);
+      gather_F(T, 1, c, kh, hF[1]);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const f32x4 lo = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[0];
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        if (AP > 4) hi = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[1];
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          const float d = aa < 4 ? lo[aa] : hi[aa - 4];
+          gW3[0][aa] = fmaf(hF[0][m], d, gW3[0][aa]);
+          gW3[1][aa] = fmaf(hF[1][m], d, gW3[1][aa]);
+        }
+      }
+    }
+    wave_lds_sync();
+
+    // ---- dz2 = (dzl . W3) * tanh'(h2)   (in place of h2)
+    {
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          const f32x4 w = w3p[(aa * 2 + h) * 8 + j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(dzl[aa], w[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = h2[4 * j + e];
+          h2[4 * j + e] = acc[e] * (1.f - y * y);
+        }
+      }
+    }
+    float (&dz2)[32] = h2;
+
+    // ---- dh1 = dz2 . W2 (transposed MFMA, stays in S layout); dz1 = dh1 * tanh'(h1)
+    float dz1[32];
+    {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      const float* w2b = lds + L::W2B;
+#pragma unroll
+      for (int st = 0; st < 32; ++st) {
+        acc0 = mfma32(w2b[st * 64 + lane], dz2[st], acc0);
+        acc1 = mfma32(w2b[(32 + st) * 64 + lane], dz2[st], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dz1[r] = acc0[r] * (1.f - h1[r] * h1[r]);
+        dz1[16 + r] = acc1[r] * (1.f - h1[16 + r] * h1[16 + r]);
+      }
+    }
+
+    // ---- dW2[out][in] += dz2^T . h1 over the tile's 32 samples (MFMA, F-layout operands)
+    {
+      float aF[2][16], bF[2][16];
+      scatter_S(T, dz2, s, h);
+      wave_lds_sync();
+      gather_F(T, 0, c, kh, aF[0]);
+      gather_F(T, 1, c, kh, aF[1]);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 16; ++m) { gb2[0] += aF[0][m]; gb2[1] += aF[1][m]; }
+      scatter_S(T, h1, s, h);
+      wave_lds_sync();
+      gather_F(T, 0, c, kh, bF[0]);
+      gather_F(T, 1, c, kh, bF[1]);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        gW2[0][0] = mfma32(aF[0][m], bF[0][m], gW2[0][0]);
+        gW2[0][1] = mfma32(aF[0][m], bF[1][m], gW2[0][1]);
+        gW2[1][0] = mfma32(aF[1][m], bF[0][m], gW2[1][0]);
+        gW2[1][1] = mfma32(aF[1][m], bF[1][m], gW2[1][1]);
+      }
+    }
+
+    // ---- dW1[out][in] += dz1^T . x
+    {
+      float aF[2][16], xF[16];
+      scatter_S(T, dz1, s, h);
+      wave_lds_sync();
+      gather_F(T, 0, c, kh, aF[0]);
+      gather_F(T, 1, c, kh, aF[1]);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 16; ++m) { gb1[0] += aF[0][m]; gb1[1] += aF[1][m]; }
+#pragma unroll
+      for (int st = 0; st < KS1; ++st) T[(2 * st + h) * TS + s] = x[st];
+      wave_lds_sync();
+      gather_F(T, 0, c, kh, xF);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float xv = c < 2 * KS1 ? xF[m] : 0.f;     // rows >= 2*KS1 hold stale data
+        gW1[0] = mfma32(aF[0][m], xv, gW1[0]);
+        gW1[1] = mfma32(aF[1][m], xv, gW1[1]);
+      }
+    }
+  }
+
+  // ---------------- fold the waves' accumulators into one image G (flat parameter layout)
+  const int oW1 = 0, ob1 = 64 * O, oW2 = ob1 + 64, ob2 = oW2 + 4096, oTail = ob2 + 64;
+  const int oLs = oTail, oW3 = ACTOR ? oTail + A : oTail, ob3 = oW3 + (ACTOR ? A * 64 : 64);
+  const int P = ob3 + (ACTOR ? A : 1);
+  float* G = lds + L::WAVE0;
+  __syncthreads();
+  for (int i = tid; i < P + kStatSlots; i += WAVES * 64) G[i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;
+          G[oW2 + row * 64 + s] += gW2[ti][0][r];
+          G[oW2 + row * 64 + 32 + s] += gW2[ti][1][r];
+          if (s < O) G[oW1 + row * O + s] += gW1[ti][r];
+        }
+        const float vb1 = gb1[ti] + __shfl_xor(gb1[ti], 32, 64);
+        const float vb2 = gb2[ti] + __shfl_xor(gb2[ti], 32, 64);
+        if (kh == 0) { G[ob1 + 32 * ti + c] += vb1; G[ob2 + 32 * ti + c] += vb2; }
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          const float v = gW3[ti][aa] + __shfl_xor(gW3[ti][aa], 32, 64);
+          if (kh == 0 && aa < (ACTOR ? A : 1)) G[oW3 + aa * 64 + 32 * ti + c] += v;
+        }
+      }
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        const float vb = wave_sum(gb3[aa]);
+        const float vs = wave_sum(gsig[aa]);
+        if (lane == 0 && aa < (ACTOR ? A : 1)) {
+          G[ob3 + aa] += vb;
+          if (ACTOR) G[oLs + aa] += vs;     // d loss / d sigma; chain rule in the reducer
+        }
+      }
+      const float r0 = wave_sum(st0), r1 = wave_sum(st1), r2 = wave_sum(st2), r3 = wave_sum(st3);
+      if (lane == 0) { G[P + 0] += r0; G[P + 1] += r1; G[P + 2] += r2; G[P + 5] += r3; }
+    }
+    __syncthreads();
+  }
+  float* dst = a.out0 + (int64_t)blockIdx.x * a.pstride;
+  for (int i = tid; i < P + kStatSlots; i += WAVES * 64) dst[i] = G[i];
+}
+
+// Fixed-order reduction of the per-workgroup partials (+ log_scale chain rule, entropy).
+template <bool ACTOR>
+__global__ void reduce_partials_kernel(const float* partials, int nblocks, int pstride, int P,
+                                       const float* params, float* grad_sums, int O, int A,
+                                       float entropy_coeff, const int32_t* skip) {
+  if (skip != nullptr && *skip != 0) return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P + kStatSlots) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += (double)partials[(int64_t)b * pstride + p];
+  float out = (float)acc;
+  if (ACTOR) {
+    const int oLs = 64 * O + 64 + 4096 + 64;
+    double nloc = 0.0;
+    if ((p >= oLs && p < oLs + A) || p == P + 3 || p == P + 4) {
+      for (int b = 0; b < nblocks; ++b) nloc += (double)partials[(int64_t)b * pstride + P + 5];
+    }
+    if (p >= oLs && p < oLs + A) {
+      const float ls = params[p];
+      const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+      const float raw = sp + 1e-8f;
+      const float sigma = fminf(fmaxf(raw, 1e-4f), 1.0f);
+      const bool inside = raw >= 1e-4f && raw <= 1.0f;              // clamp passes the gradient
+      const float dsig_dls = inside ? 1.f / (1.f + expf(-ls)) : 0.f; // softplus'
+      double dsig = acc;
+      if (entropy_coeff != 0.f) dsig -= (double)entropy_coeff / ((double)A * sigma) * nloc;
+      out = (float)(dsig * dsig_dls);
+    }
+    if (p == P + 3 || p == P + 4) {
+      // n-weighted entropy / std of the PRE-step distribution (actors.py:91,108)
+      double ent = 0.0, sd = 0.0;
+      for (int aa = 0; aa < A; ++aa) {
+        const float ls = params[oLs + aa];
+        const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+        const float sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);
+        ent += (double)kEntropyConst + (double)logf(sigma);
+        sd += sigma;
+      }
+      out = (float)((p == P + 3 ? ent : sd) / A * nloc);
+    }
+  }
+  grad_sums[p] = out;
+}
+
+// ------------------------------------------------------------------------------- host side
+
+namespace {
+
+constexpr int kFwdWaves = 4;
+constexpr int kMaxGradBlocks = 256;   // one workgroup per CU
+// Waves per workgroup of the fused grad kernel: 4 = one wave per SIMD with the whole
+// 512-register file (no spills), 8 = two waves per SIMD at 256 registers (spills today).
+int g_grad_waves = 4;
+
+int ks1_bucket(int O) {
+  if (O <= 4) return 2;
+  if (O <= 18) return 9;
+  if (O <= 32) return 16;
+  return -1;
+}
+int ap_bucket(int A) {
+  if (A <= 1) return 1;
+  if (A <= 6) return 6;
+  if (A <= 8) return 8;
+  return -1;
+}
+
+int grad_blocks(int64_t n) {
+  const int64_t tiles = (n + 31) / 32;
+  int64_t blocks = (tiles + g_grad_waves - 1) / g_grad_waves;
+  if (blocks > kMaxGradBlocks) blocks = kMaxGradBlocks;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename K>
+int launch(K kernel, int blocks, int threads, int lds_bytes, hipStream_t stream, MlpArgs args,
+           const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
+    return TONIC_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, args);
+  TONIC_CHECK_LAUNCH(what);
+  return TONIC_OK;
+}
+
+template <int KS1, int AP>
+int launch_act(int blocks, hipStream_t st, const MlpArgs& a) {
+  return launch(ppo_act_kernel<KS1, AP, kFwdWaves>, blocks, kFwdWaves * 64,
+                Lds<KS1, AP, false, kFwdWaves>::BYTES, st, a, "tonic_ppo_act");
+}
+template <int KS1>
+int launch_value(int blocks, hipStream_t st, const MlpArgs& a) {
+  return launch(value_forward_kernel<KS1, kFwdWaves>, blocks, kFwdWaves * 64,
+                Lds<KS1, 1, false, kFwdWaves>::BYTES, st, a, "tonic_value_forward");
+}
+template <int KS1, int AP, bool ACTOR>
+int launch_grad(int blocks, hipStream_t st, const MlpArgs& a) {
+  const char* what = ACTOR ? "tonic_ppo_actor_grad" : "tonic_value_regression_grad";
+  if (g_grad_waves == 8)
+    return launch(mlp64_grad_kernel<KS1, AP, ACTOR, 8>, blocks, 512,
+                  Lds<KS1, AP, true, 8>::BYTES, st, a, what);
+  return launch(mlp64_grad_kernel<KS1, AP, ACTOR, 4>, blocks, 256,
+                Lds<KS1, AP, true, 4>::BYTES, st, a, what);
+}
+
+template <typename F>
+int dispatch_ks1(int ks1, F&& f) {
+  switch (ks1) {
+    case 2: return f(std::integral_constant<int, 2>{});
+    case 9: return f(std::integral_constant<int, 9>{});
+    case 16: return f(std::integral_constant<int, 16>{});
+    default: break;
+  }
+  set_error("unsupported observation bucket %d", ks1);
+  return TONIC_ERR_UNSUPPORTED_SHAPE;
+}
+
+}  // namespace
+}  // namespace tonic
+
+using namespace tonic;
+
+extern "C" int tonic_set_tuning(const char* key, int32_t value) {
+  TONIC_REQUIRE(key != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_set_tuning: null key");
+  if (strcmp(key, "grad_waves") == 0) {
+    TONIC_REQUIRE(value == 4 || value == 8, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_waves must be 4 or 8, got %d", value);
+    g_grad_waves = value;
+    return TONIC_OK;
+  }
+  set_error("tonic_set_tuning: unknown key '%s'", key);
+  return TONIC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int64_t tonic_ppo_actor_param_count(int32_t O, int32_t A) {
+  return 64LL * O + 64 + 64 * 64 + 64 + A + 64LL * A + A;
+}
+
+extern "C" int64_t tonic_v_critic_param_count(int32_t O) {
+  return 64LL * O + 64 + 64 * 64 + 64 + 64 + 1;
+}
+
+static int check_shape(int32_t O, int32_t A, bool actor) {
+  TONIC_REQUIRE(O >= 1 && ks1_bucket(O) > 0, TONIC_ERR_UNSUPPORTED_SHAPE,
+                "observation size %d not supported by the mlp64 kernels (1..32)", O);
+  if (actor)
+    TONIC_REQUIRE(A >= 1 && ap_bucket(A) > 0, TONIC_ERR_UNSUPPORTED_SHAPE,
+                  "action size %d not supported by the mlp64 kernels (1..8)", A);
+  return TONIC_OK;
+}
+
+extern "C" int tonic_ppo_act(const float* d_actor_params, const float* d_observations,
+                             const float* d_eps, float* d_actions, float* d_log_probs,
+                             int64_t n, int32_t O, int32_t A, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && n >= 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_act: null pointer or negative n");
+  if (int rc = check_shape(O, A, true)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.eps = d_eps;
+  a.out0 = d_actions; a.out1 = d_log_probs; a.n = n; a.O = O; a.A = A;
+  const int64_t tiles = (n + 31) / 32;
+  int blocks = (int)((tiles + kFwdWaves - 1) / kFwdWaves);
+  if (blocks > 1024) blocks = 1024;
+  const int ap = ap_bucket(A);
+  hipStream_t st = as_stream(stream);
+  return dispatch_ks1(ks1_bucket(O), [&](auto ks) {
+    constexpr int KS1 = decltype(ks)::value;
+    if (ap == 1) return launch_act<KS1, 1>(blocks, st, a);
+    if (ap == 6) return launch_act<KS1, 6>(blocks, st, a);
+    return launch_act<KS1, 8>(blocks, st, a);
+  });
+}
+
+extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
+                                   const float* d_norm_std, const float* d_observations,
+                                   float* d_values, int64_t n, int32_t O, void* stream) {
+  TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_values &&
+                    n >= 0, TONIC_ERR_INVALID_ARGUMENT, "tonic_value_forward: bad argument");
+  if (int rc = check_shape(O, 1, false)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_critic_params; a.obs = d_observations; a.norm_mean = d_norm_mean;
+  a.norm_std = d_norm_std; a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
+  const int64_t tiles = (n + 31) / 32;
+  int blocks = (int)((tiles + kFwdWaves - 1) / kFwdWaves);
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t st = as_stream(stream);
+  return dispatch_ks1(ks1_bucket(O), [&](auto ks) {
+    return launch_value<decltype(ks)::value>(blocks, st, a);
+  });
+}
+
+extern "C" int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_count) {
+  const int64_t pstride = round_up(param_count + kStatSlots, 64);
+  return (int64_t)grad_blocks(n) * pstride * (int64_t)sizeof(float);
+}
+
+template <bool ACTOR>
+static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coeff,
+                    void* d_workspace, int64_t workspace_bytes, void* stream) {
+  const int blocks = grad_blocks(a.n);
+  const int64_t pstride = round_up(P + kStatSlots, 64);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= blocks * pstride * (int64_t)sizeof(float),
+                TONIC_ERR_WORKSPACE, "grad workspace too small: %lld < %lld",
+                (long long)workspace_bytes, (long long)(blocks * pstride * sizeof(float)));
+  a.out0 = static_cast<float*>(d_workspace);
+  a.pstride = (int)pstride;
+  const int ap = ACTOR ? ap_bucket(a.A) : 1;
+  hipStream_t st = as_stream(stream);
+  const int rc = dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
+    constexpr int KS1 = decltype(ks)::value;
+    if constexpr (!ACTOR) {
+      return launch_grad<KS1, 1, false>(blocks, st, a);
+    } else {
+      if (ap == 1) return launch_grad<KS1, 1, true>(blocks, st, a);
+      if (ap == 6) return launch_grad<KS1, 6, true>(blocks, st, a);
+      return launch_grad<KS1, 8, true>(blocks, st, a);
+    }
+  });
+  if (rc != TONIC_OK) return rc;
+  const int total = (int)P + kStatSlots;
+  hipLaunchKernelGGL(reduce_partials_kernel<ACTOR>, dim3((total + 255) / 256), dim3(256), 0,
+                     as_stream(stream), static_cast<const float*>(d_workspace), blocks,
+                     (int)pstride, (int)P, a.params, d_grad_sums, a.O, a.A, entropy_coeff,
+                     a.skip);
+  TONIC_CHECK_LAUNCH("reduce_partials_kernel");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_observations,
+                                    const float* d_actions, const float* d_advantages,
+                                    const float* d_adv_stats, const float* d_old_log_probs,
+                                    float* d_grad_sums, int64_t n, int32_t O, int32_t A,
+                                    double ratio_clip, double entropy_coeff,
+                                    const int32_t* d_skip_flag, void* d_workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && d_advantages && d_adv_stats &&
+                    d_old_log_probs && d_grad_sums && n > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_actor_grad: bad argument");
+  if (int rc = check_shape(O, A, true)) return rc;
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.actions = d_actions;
+  a.adv = d_advantages; a.adv_stats = d_adv_stats; a.old_logp = d_old_log_probs;
+  a.skip = d_skip_flag; a.n = n; a.O = O; a.A = A;
+  a.clip_lo = (float)(1.0 - ratio_clip);     // actors.py:85-86 (f64, then f32 in clamp)
+  a.clip_hi = (float)(1.0 + ratio_clip);
+  return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
+                        (float)entropy_coeff,
+                        d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int tonic_value_regression_grad(const float* d_critic_params,
+                                           const float* d_norm_mean, const float* d_norm_std,
+                                           const float* d_observations, const float* d_returns,
+                                           float* d_grad_sums, int64_t n, int32_t O,
+                                           void* d_workspace, int64_t workspace_bytes,
+                                           void* stream) {
+  TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_returns &&
+                    d_grad_sums && n > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_value_regression_grad: bad argument");
+  if (int rc = check_shape(O, 1, false)) return rc;
+  MlpArgs a{};
+  a.params = d_critic_params; a.obs = d_observations; a.returns = d_returns;
+  a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.n = n; a.O = O; a.A = 1;
+  return run_grad<false>(a, tonic_v_critic_param_count(O), d_grad_sums, 0.f, d_workspace,
+                         workspace_bytes, stream);
+}
