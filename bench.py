@@ -1,0 +1,300 @@
+"""Headline benchmark: PPO rollout-collect + learner-update on synthetic HalfCheetah shapes.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one Segment of synthetic input:
+T=4096 environment steps x W=256 workers per GPU collected (one policy forward+sample launch
+and one segment-store launch per environment step, inputs resident in HBM), then ONE learner
+update (2 critic forwards, the GAE scan, 80 x [actor fwd+loss+bwd, Adam, critic fwd+bwd,
+Adam] with the device-side KL early stop), then the statistics read-back and the
+normaliser update.  `value` = env steps/s of the whole job = (N_gpus * T * W * K) / time.
+
+Extra keys on the same JSON line: `roofline` (dominant kernel = fused actor forward+backward,
+fp32 MFMA bound), `roofline_gae` (HBM-bound scan, at the config size and at a bandwidth-bound
+sweep size), `cpu_baseline` (oracle/torch_port.py = the reference's torch-CPU path timed on
+this box's cores on a bounded sample), `learner_updates_per_sec`, phase timings and the
+host-in-the-loop (PCIe-inclusive) rate through the drop-in agent API.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+O, A, W, T, ITERATIONS = 17, 6, 256, 4096, 80          # cfg 2: HalfCheetah-v3, parallel=256
+ACTOR_FLOP_PER_SAMPLE = 31232                          # fwd 11136 + bwd 20096
+CRITIC_FLOP_PER_SAMPLE = 29312
+FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def build_agent(steps=T, iterations=ITERATIONS, seed=0):
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd.environments import Box
+    agent = tonic_amd.torch.agents.PPO(
+        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    return agent
+
+
+def time_events(fn, repeats):
+    """Average GPU duration (ms) of fn() measured with events on the launch stream."""
+    import torch
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(repeats):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / repeats
+
+
+def kernel_rooflines(agent):
+    """Live roofline measurements of the dominant kernels (HIP events, launch stream)."""
+    import torch
+    from tonic_amd import _lib, replays
+    lib, p = _lib.load(), _lib.ptr
+    replay, actor, critic = agent.replay, agent.actor_updater, agent.critic_updater
+    b = replay.buffers
+    n = T * W
+    obs = replays.flatten_batch(b['observations'])
+    act = replays.flatten_batch(b['actions'])
+    adv = replays.flatten_batch(b['advantages'])
+    logp = replays.flatten_batch(b['log_probs'])
+    ret = replays.flatten_batch(b['returns'])
+    ws = actor._workspace_for(n)
+    stream = _lib.current_stream()
+
+    def actor_grad():
+        _lib.check(lib.tonic_ppo_actor_grad(
+            p(actor.flat.flat), p(obs), p(act), p(adv), p(replay.adv_stats), p(logp),
+            p(actor.grad_sums), n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), stream), 'actor')
+
+    mean, std = critic.norm_tensors()
+    wsc = critic._workspace_for(n)
+
+    def critic_grad():
+        _lib.check(lib.tonic_value_regression_grad(
+            p(critic.flat.flat), p(mean), p(std), p(obs), p(ret), p(critic.grad_sums), n, O,
+            p(wsc), wsc.numel(), stream), 'critic')
+
+    out = {}
+    for waves in (4, 8):
+        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+        ws = actor._workspace_for(n)
+        wsc = critic._workspace_for(n)
+        ms_a, ms_c = time_events(actor_grad, 10), time_events(critic_grad, 10)
+        out[waves] = (ms_a, ms_c)
+    best = min(out, key=lambda k: out[k][0] + out[k][1])
+    _lib.check(lib.tonic_set_tuning(b'grad_waves', best), 'tuning')
+    ms_a, ms_c = out[best]
+    tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
+    tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
+    roof = dict(bound='mfma', kernel='mlp64_grad_kernel<actor> (+reduce_partials)',
+                achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                ms_per_launch=round(ms_a, 4), samples_per_launch=n,
+                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_waves=best,
+                variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
+    roof_critic = dict(bound='mfma', kernel='mlp64_grad_kernel<critic> (+reduce_partials)',
+                       achieved=round(tf_c, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                       frac=round(tf_c / FP32_MFMA_PEAK_TFLOPS, 4),
+                       ms_per_launch=round(ms_c, 4))
+
+    # GAE scan: 28 algorithmic B / transition (read nv, r, reset, term, values; write ret, adv)
+    def gae_entry(t_steps, workers, chunks):
+        dev = agent.device
+        arrays = [torch.randn(t_steps, workers, device=dev) for _ in range(3)]
+        flags = (torch.rand(t_steps, workers, device=dev) < 1e-3).float()
+        outs = [torch.empty(t_steps, workers, device=dev) for _ in range(2)]
+        stats = torch.zeros(4, device=dev)
+        wsg = torch.empty(max(lib.tonic_gae_workspace_bytes(t_steps, workers, chunks), 16),
+                          dtype=torch.uint8, device=dev)
+
+        def run():
+            _lib.check(lib.tonic_gae_lambda_returns(
+                p(arrays[0]), p(arrays[1]), p(flags), p(flags), p(arrays[2]), p(outs[0]),
+                p(outs[1]), p(stats), None, t_steps, workers, 0.99, 0.97, chunks, p(wsg),
+                wsg.numel(), stream), 'gae')
+        ms = time_events(run, 10)
+        gbs = 28.0 * t_steps * workers / (ms * 1e-3) / 1e9
+        return dict(T=t_steps, W=workers, chunks=chunks, ms=round(ms, 4),
+                    achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    sweep = [gae_entry(T, W, 0), gae_entry(T, W, 1), gae_entry(T, 4096, 0),
+             gae_entry(T, 65536, 1), gae_entry(T, 65536, 4)]
+    top = max(sweep, key=lambda e: e['achieved'])
+    roof_gae = dict(bound='hbm', kernel='gae_scan_kernel (+summary/carry/stats)',
+                    achieved=top['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=top['frac'],
+                    bytes_per_transition=28, at=dict(T=top['T'], W=top['W']), sweep=sweep,
+                    note='cfg-2 size (T=4096, W=256) moves 29 MB: launch-latency bound, '
+                         'inside the Infinity Cache; the HBM fraction is meaningful at W>=4096')
+    return roof, roof_critic, roof_gae
+
+
+def cpu_baseline():
+    """The reference's torch-CPU PPO path (oracle/torch_port.py) on this box's cores, bounded
+    sample: 64 act+store steps at W=256, the full-size evaluate + GAE, and 2 full-batch
+    actor+critic iterations at N = 4096*256; extrapolated to T=4096 steps and 80 iterations."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch
+    import torch_port
+    threads = torch.get_num_threads()
+    rng = np.random.RandomState(0)
+    agent = torch_port.TorchPPO(O, A, steps=T)
+    sample_steps, sample_iters = 64, 2
+    obs = rng.standard_normal((W, O)).astype(np.float32)
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        actions = agent.step(obs)
+        agent.store(obs, -np.square(actions).sum(-1), np.zeros(W, bool), np.zeros(W, bool))
+    t_step = (time.perf_counter() - t0) / sample_steps
+    n = T * W
+    agent.buffers = dict(
+        observations=rng.standard_normal((T, W, O)).astype(np.float32),
+        next_observations=rng.standard_normal((T, W, O)).astype(np.float32),
+        actions=np.clip(rng.standard_normal((T, W, A)), -1, 1).astype(np.float32),
+        rewards=rng.standard_normal((T, W)).astype(np.float32),
+        resets=np.zeros((T, W), np.float32), terminations=np.zeros((T, W), np.float32),
+        log_probs=(rng.standard_normal((T, W)) * 0.1 - 6).astype(np.float32))
+    t0 = time.perf_counter()
+    batch = agent.evaluate_and_returns()
+    t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(sample_iters):
+        agent.actor_update(batch['observations'], batch['actions'], batch['advantages'],
+                           batch['log_probs'])
+        agent.critic_update(batch['observations'], batch['returns'])
+    t_iter = (time.perf_counter() - t0) / sample_iters
+    cycle = T * t_step + t_eval + ITERATIONS * t_iter
+    return dict(value=round(n / cycle, 1), unit='env_steps/s', cores=threads, kind='port',
+                learner_updates_per_sec=round(ITERATIONS / (t_eval + ITERATIONS * t_iter), 3),
+                sample=f'{sample_steps} act+store steps (W={W}), full-size evaluate+GAE '
+                       f'(N={n}), {sample_iters} full-batch actor+critic iterations; '
+                       f'extrapolated to T={T} steps and {ITERATIONS} iterations',
+                seconds=dict(per_env_step=round(t_step, 6), evaluate_and_gae=round(t_eval, 4),
+                             per_iteration=round(t_iter, 4), cycle=round(cycle, 2)),
+                os_cpu_count=os.cpu_count())
+
+
+def host_loop_rate(agent, steps=512):
+    """PCIe-inclusive collect through the drop-in API (agent.step / agent.update with NumPy
+    in/out, pinned staging, vectorised synthetic environment) — never `value`."""
+    import torch
+    from tonic_amd.environments import SyntheticBatch
+    env = SyntheticBatch(W, O, A, max_episode_steps=1000)
+    env.initialize(seed=1)
+    agent.replay.index = 0
+    observations = env.start()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        actions = agent.step(observations, t * W)
+        observations, infos = env.step(actions)
+        agent.update(**infos, steps=t * W)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    agent.replay.index = 0
+    return dict(env_steps_per_sec=round(steps * W / dt, 1), ms_per_env_step=round(dt / steps * 1e3, 4),
+                steps=steps)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=3)
+    parser.add_argument('--warmup', type=int, default=1)
+    parser.add_argument('--no-graph', action='store_true', help='eager launches, no hipGraph')
+    parser.add_argument('--no-extras', action='store_true',
+                        help='skip roofline / cpu_baseline / host-loop measurements')
+    args = parser.parse_args()
+
+    import torch
+    from tonic_amd import parallel
+    from tonic_amd.rollout import DeviceRollout
+    rank, world = parallel.init_from_env()
+    assert world == max(args.gpus, 1) or world == 1, (world, args.gpus)
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local_rank)
+
+    agent = build_agent(seed=0)                      # same seed: replicated parameters
+    rollout = DeviceRollout(agent, W, T, seed=1 + rank)
+    capture = not args.no_graph
+
+    def one_step():
+        rollout.collect(capture=capture)
+        agent._update()                              # enqueue + one read-back + normaliser
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    from tonic_amd.utils import logger
+    logger.get_current_logger().store = lambda *a, **k: None      # no log accumulation here
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * T * W * args.steps / elapsed
+    actor_iters = int((agent.last_infos[0][:, 6] > 0).sum())
+
+    result = {
+        'metric': 'env steps/sec (+ learner updates/sec), PPO HalfCheetah parallel=256',
+        'value': round(value, 1), 'unit': 'env_steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'PPO HalfCheetah-v3 shapes (O=17, A=6), parallel=256 workers per '
+                               'GPU, Segment T=4096 (N=1048576 transitions per GPU per step), '
+                               '80 full-batch iterations, 1 learner update per step',
+                   'workers_per_gpu': W, 'segment_steps': T, 'batch_iterations': ITERATIONS,
+                   'global_workers': W * world, 'parallelism': f'dp{world} (worker-axis shard, '
+                   'RCCL all-reduce of flat gradient sums)', 'hip_graph': capture},
+        'learner_updates_per_sec': round(ITERATIONS * args.steps / elapsed, 2),
+        'actor_iterations_last_update': actor_iters,
+    }
+
+    if rank == 0 and not args.no_extras:
+        # phase split (untimed extras): collect-only and update-only
+        def sync_time(fn, n=2):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        if world == 1:
+            result['collect_ms'] = round(sync_time(lambda: rollout.collect(capture=capture)), 3)
+            result['update_ms'] = round(sync_time(agent._update), 3)
+            roof, roof_c, roof_g = kernel_rooflines(agent)
+            result['roofline'] = roof
+            result['roofline_critic'] = roof_c
+            result['roofline_gae'] = roof_g
+            result['host_loop'] = host_loop_rate(agent)
+            result['cpu_baseline'] = cpu_baseline()
+            result['speedup_vs_cpu_baseline'] = round(value / result['cpu_baseline']['value'], 1)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -75,9 +75,15 @@ int64_t tonic_gae_workspace_bytes(int64_t T, int64_t W, int32_t chunks);
 int tonic_gae_lambda_returns(const float* d_next_values, const float* d_rewards,
                              const float* d_resets, const float* d_terminations,
                              const float* d_values, float* d_returns, float* d_advantages,
-                             float* d_adv_stats, int64_t T, int64_t W, double discount_factor,
-                             double trace_decay, int32_t chunks, void* d_workspace,
-                             int64_t workspace_bytes, void* stream);
+                             float* d_adv_stats, double* d_adv_moments, int64_t T, int64_t W,
+                             double discount_factor, double trace_decay, int32_t chunks,
+                             void* d_workspace, int64_t workspace_bytes, void* stream);
+/* Multi-GPU: d_adv_moments (float64[5], may be NULL) receives this rank's
+ * {sum, sum_sq, -min, max, count} of the raw advantages.  Ranks all-reduce it (SUM on
+ * [0,1,4], MAX on [2,3]) and then rebuild the GLOBAL d_adv_stats with the call below, so the
+ * normalisation matches the single-process full batch (segments.py:43-46). */
+int tonic_advantage_stats_from_moments(const double* d_adv_moments, float* d_adv_stats,
+                                       void* stream);
 
 /* ---- acting: policy forward + sample + log-prob ----------------------------------------
  * replaces: tonic/torch/agents/a2c.py:75-85 (A2C._step) = Actor.forward

@@ -1,0 +1,131 @@
+"""TEST / BASELINE INFRASTRUCTURE ONLY — the reference's PPO path restated on the SAME
+torch-CPU operators the reference executes (``torch.nn.Linear``, ``torch.distributions.Normal``,
+autograd, ``torch.optim.Adam``) so it can be (a) timed on the GPU box's host cores as
+``cpu_baseline`` (kind "port": ``/root/reference`` does not exist there) and (b) used as a
+full-size float32 checker.  Pinned against the golden vectors by tests/test_oracle_golden.py.
+
+Cited reference code (relative to the reference checkout): ``tonic/torch/agents/a2c.py:41-99``,
+``ppo.py:20-67``, ``tonic/torch/updaters/actors.py:70-112``, ``critics.py:18-28``,
+``tonic/replays/segments.py:27-78``, ``tonic/torch/normalizers/mean_stds.py:34-74``.
+"""
+import numpy as np
+import torch
+
+import numpy_port as port
+
+
+class TorchPPO:
+    def __init__(self, observation_size, action_size, seed=0, steps=4096, iterations=80,
+                 actor_lr=3e-4, critic_lr=1e-3):
+        torch.manual_seed(seed)
+        O, A = observation_size, action_size
+        tanh = torch.nn.Tanh
+        # creation order = reference init order (actor torso, head, critic torso, head)
+        self.actor_torso = torch.nn.Sequential(torch.nn.Linear(O, 64), tanh(),
+                                               torch.nn.Linear(64, 64), tanh())
+        self.loc_layer = torch.nn.Sequential(torch.nn.Linear(64, A), tanh())
+        self.log_scale = torch.nn.Parameter(torch.zeros(1, A))
+        self.critic_torso = torch.nn.Sequential(torch.nn.Linear(O, 64), tanh(),
+                                                torch.nn.Linear(64, 64), tanh())
+        self.v_layer = torch.nn.Linear(64, 1)
+        self.actor_vars = [*self.actor_torso.parameters(), self.log_scale,
+                           *self.loc_layer.parameters()]
+        self.critic_vars = [*self.critic_torso.parameters(), *self.v_layer.parameters()]
+        self.actor_opt = torch.optim.Adam(self.actor_vars, lr=actor_lr)
+        self.critic_opt = torch.optim.Adam(self.critic_vars, lr=critic_lr)
+        self.normalizer = port.MeanStdPort((O,))
+        self.norm_mean = torch.zeros(O)
+        self.norm_std = torch.ones(O)
+        self.steps, self.iterations = steps, iterations
+        self.buffers, self.index = None, 0
+
+    def load(self, actor, critic, norm):
+        with torch.no_grad():
+            for p, v in zip(self.actor_vars, actor):
+                p.copy_(torch.as_tensor(v))
+            for p, v in zip(self.critic_vars, critic):
+                p.copy_(torch.as_tensor(v))
+        self.norm_mean, self.norm_std = torch.as_tensor(norm[0]), torch.as_tensor(norm[1])
+
+    def distribution(self, observations):
+        loc = self.loc_layer(self.actor_torso(observations))
+        scale = torch.nn.functional.softplus(self.log_scale) + port.FLOAT_EPSILON
+        scale = torch.clamp(scale, 1e-4, 1.).repeat(observations.shape[0], 1)
+        return torch.distributions.normal.Normal(loc, scale)
+
+    def critic(self, observations):
+        with torch.no_grad():
+            observations = (observations - self.norm_mean) / self.norm_std
+        return self.v_layer(self.critic_torso(observations)).squeeze(-1)
+
+    def step(self, observations):                                   # a2c.py:41-52,75-85
+        observations = torch.as_tensor(observations, dtype=torch.float32)
+        with torch.no_grad():
+            dist = self.distribution(observations)
+            actions = dist.sample()
+            log_probs = dist.log_prob(actions).sum(dim=-1)
+        self.last = (observations.numpy().copy(), actions.numpy().copy(), log_probs.numpy().copy())
+        return self.last[1]
+
+    def store(self, next_observations, rewards, resets, terminations):   # a2c.py:58-69
+        row = dict(observations=self.last[0], actions=self.last[1],
+                   next_observations=next_observations, rewards=rewards, resets=resets,
+                   terminations=terminations, log_probs=self.last[2])
+        if self.buffers is None:
+            self.buffers = {k: np.zeros((self.steps,) + np.array(v).shape, np.float32)
+                            for k, v in row.items()}
+        for k, v in row.items():
+            self.buffers[k][self.index] = v
+        self.index += 1
+        self.normalizer.record(self.last[0])
+
+    def actor_update(self, observations, actions, advantages, log_probs):   # actors.py:70-112
+        self.actor_opt.zero_grad()
+        dist = self.distribution(observations)
+        new_log_probs = dist.log_prob(actions).sum(dim=-1)
+        ratios = torch.exp(new_log_probs - log_probs)
+        clipped = torch.clamp(ratios, 1 - 0.2, 1 + 0.2)
+        loss = -(torch.min(advantages * ratios, advantages * clipped)).mean()
+        loss.backward()
+        self.actor_opt.step()
+        with torch.no_grad():
+            kl = (log_probs - new_log_probs).mean()
+        return dict(loss=loss.detach(), kl=kl, stop=bool(kl > 0.015))
+
+    def critic_update(self, observations, returns):                      # critics.py:18-28
+        self.critic_opt.zero_grad()
+        values = self.critic(observations)
+        loss = torch.nn.functional.mse_loss(values, returns)
+        loss.backward()
+        self.critic_opt.step()
+        return dict(loss=loss.detach(), v=values.detach())
+
+    def evaluate_and_returns(self, gamma=0.99, lam=0.97):                # ppo.py:20-24
+        b = self.buffers
+        flat = {k: port.flatten_time_major(v) for k, v in b.items()}
+        with torch.no_grad():
+            values = self.critic(torch.as_tensor(flat['observations'])).numpy()
+            next_values = self.critic(torch.as_tensor(flat['next_observations'])).numpy()
+        shape = b['rewards'].shape
+        b['values'], b['next_values'] = values.reshape(shape), next_values.reshape(shape)
+        b['returns'] = port.lambda_returns(b['next_values'], b['rewards'], b['resets'],
+                                           b['terminations'], gamma, lam)
+        b['advantages'] = port.normalized_advantages(b['returns'], b['values'])
+        self.index = 0
+        return {k: torch.as_tensor(port.flatten_time_major(b[k])) for k in
+                ('observations', 'actions', 'advantages', 'log_probs', 'returns')}
+
+    def update(self, iterations=None):                                   # ppo.py:20-59
+        batch = self.evaluate_and_returns()
+        infos, train_actor = [], True
+        for _ in range(iterations or self.iterations):
+            info = {}
+            if train_actor:
+                info['actor'] = self.actor_update(batch['observations'], batch['actions'],
+                                                  batch['advantages'], batch['log_probs'])
+                train_actor = not info['actor']['stop']
+            info['critic'] = self.critic_update(batch['observations'], batch['returns'])
+            infos.append(info)
+        mean, std = self.normalizer.update()
+        self.norm_mean, self.norm_std = torch.as_tensor(mean), torch.as_tensor(std)
+        return infos

@@ -1,0 +1,448 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle
+(oracle/numpy_port.py) and the golden vectors produced by the unmodified reference.
+
+Tolerances (north_star): index / integer work bit-exact; float32 losses and parameter
+deltas within 1e-5.  Returns from the 1-chunk GAE scan and the MeanStd sums are required to
+be BIT-exact because the kernels replay the reference's float32 operation order.
+"""
+import numpy as np
+import pytest
+
+import numpy_port as port
+from test_oracle_golden import PPO_CASES, _params
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from tonic_amd import _lib
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return _lib.load()
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda().contiguous()
+
+
+def flat(params):
+    return np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in params])
+
+
+def run_gae(lib, nv, rew, rst, term, val, gamma, lam, chunks):
+    from tonic_amd import _lib
+    T, W = rew.shape
+    d = [dev(a) for a in (nv, rew, rst, term, val)]
+    ret, adv = torch.empty(T, W).cuda(), torch.empty(T, W).cuda()
+    stats = torch.zeros(4).cuda()
+    ws = torch.empty(max(lib.tonic_gae_workspace_bytes(T, W, chunks), 16), dtype=torch.uint8).cuda()
+    _lib.check(lib.tonic_gae_lambda_returns(
+        *[t.data_ptr() for t in d], ret.data_ptr(), adv.data_ptr(), stats.data_ptr(), None, T, W,
+        float(gamma), float(lam), chunks, ws.data_ptr(), ws.numel(), None), 'gae')
+    torch.cuda.synchronize()
+    return ret.cpu().numpy(), adv.cpu().numpy(), stats.cpu().numpy()
+
+
+def normalise(adv, stats):
+    return (adv - stats[0]) / stats[1] if stats[3] else adv
+
+
+# ------------------------------------------------------------------------------- GAE
+
+def test_gae_golden_bit_exact(lib, golden):
+    g = golden('lambda_returns')
+    for i in range(int(g['n_cases'])):
+        for j in range(4):
+            k = f'c{i}_{j}_'
+            args = [g[k + n] for n in ('next_values', 'rewards', 'resets', 'terminations', 'values')]
+            gamma, lam = float(g[k + 'gamma']), float(g[k + 'lambda'])
+            ret, adv, stats = run_gae(lib, *args, gamma, lam, 1)
+            assert np.array_equal(ret, g[k + 'returns']), f'{k}: 1-chunk scan must be bit-exact'
+            np.testing.assert_allclose(normalise(adv, stats), g[k + 'advantages'],
+                                       rtol=1e-5, atol=1e-5, err_msg=k)
+            for chunks in (0, 3, 8):
+                ret_c, adv_c, stats_c = run_gae(lib, *args, gamma, lam, chunks)
+                scale = max(1.0, np.abs(g[k + 'returns']).max())
+                assert np.abs(ret_c - g[k + 'returns']).max() <= 1e-5 * scale, (k, chunks)
+                np.testing.assert_allclose(stats_c[:2], stats[:2], rtol=1e-5, atol=1e-6)
+
+
+def test_gae_constant_and_zero_advantages(lib):
+    T, W = 6, 5
+    zeros = np.zeros((T, W), np.float32)
+    # rewards 0, values == returns == 0 -> every advantage is 0 -> all_zero flag, no normalise
+    ret, adv, stats = run_gae(lib, zeros, zeros, zeros, zeros, zeros, 0.99, 0.97, 1)
+    assert stats[2] == 1.0 and stats[3] == 0.0 and not adv.any()
+    # constant non-zero advantage: std == 0 -> normalisation skipped (segments.py:44)
+    ones = np.ones((T, W), np.float32)
+    ret, adv, stats = run_gae(lib, zeros, ones, ones, ones, zeros, 0.99, 0.97, 2)
+    assert np.array_equal(ret, ones) and stats[2] == 0.0 and stats[3] == 0.0
+
+
+@pytest.mark.parametrize('T,W', [(4096, 256), (1000, 77)])
+def test_gae_full_size_bit_exact(lib, T, W):
+    rng = np.random.RandomState(T + W)
+    nv, rew, val = (rng.normal(size=(T, W)).astype(np.float32) for _ in range(3))
+    rst = (rng.uniform(size=(T, W)) < 1e-3)
+    term = (rst & (rng.uniform(size=(T, W)) < 0.5)).astype(np.float32)
+    rst = rst.astype(np.float32)
+    want = port.lambda_returns(nv, rew, rst, term, 0.99, 0.97)
+    ret, adv, stats = run_gae(lib, nv, rew, rst, term, val, 0.99, 0.97, 1)
+    assert np.array_equal(ret, want)
+    assert np.array_equal(adv, want - val)
+    ref_adv = port.normalized_advantages(want, val)
+    np.testing.assert_allclose(normalise(adv, stats), ref_adv, rtol=1e-5, atol=1e-5)
+    ret_auto, _, stats_auto = run_gae(lib, nv, rew, rst, term, val, 0.99, 0.97, 0)
+    assert np.abs(ret_auto - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # determinism: a second run is bit-identical (fixed-order reductions, no atomics)
+    ret2, adv2, stats2 = run_gae(lib, nv, rew, rst, term, val, 0.99, 0.97, 0)
+    assert np.array_equal(ret2, ret_auto) and np.array_equal(stats2, stats_auto)
+
+
+# ------------------------------------------------------------------ acting / evaluation
+
+@pytest.mark.parametrize('name', PPO_CASES)
+def test_ppo_act_golden(lib, golden, name):
+    from tonic_amd import _lib
+    g = golden(name)
+    O, A, W, steps = (int(x) for x in g['cfg'][:4])
+    actor, _, _ = _params(g, 'init/')
+    params = dev(flat(actor))
+    for t in range(steps):
+        obs, eps = dev(g['act/observations'][t]), dev(g['act/eps'][t])
+        actions, logp = torch.empty(W, A).cuda(), torch.empty(W).cuda()
+        _lib.check(lib.tonic_ppo_act(params.data_ptr(), obs.data_ptr(), eps.data_ptr(),
+                                     actions.data_ptr(), logp.data_ptr(), W, O, A, None), 'act')
+        np.testing.assert_allclose(actions.cpu().numpy(), g['act/actions'][t], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(logp.cpu().numpy(), g['act/log_probs'][t], rtol=1e-5, atol=1e-5)
+    # mode (no noise): loc itself, and log-prob pointer may be NULL
+    _lib.check(lib.tonic_ppo_act(params.data_ptr(), obs.data_ptr(), None, actions.data_ptr(),
+                                 None, W, O, A, None), 'act-mode')
+    _, _, loc, _, _ = port.ppo_actor_forward(actor, g['act/observations'][steps - 1])
+    np.testing.assert_allclose(actions.cpu().numpy(), loc, rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize('O,n', [(17, 1000), (3, 31), (28, 4097), (1, 64), (32, 65)])
+def test_value_forward_vs_oracle(lib, O, n):
+    from tonic_amd import _lib
+    rng = np.random.RandomState(O * 1000 + n)
+    params = [rng.normal(size=(64, O)) * 0.4, rng.normal(size=64) * 0.2,
+              rng.normal(size=(64, 64)) * 0.2, rng.normal(size=64) * 0.2,
+              rng.normal(size=(1, 64)) * 0.3, rng.normal(size=1)]
+    params = [p.astype(np.float32) for p in params]
+    mean = rng.normal(size=O).astype(np.float32)
+    std = (np.abs(rng.normal(size=O)) + 0.3).astype(np.float32)
+    obs = rng.normal(size=(n, O)).astype(np.float32) * 2
+    want = port.critic_forward(params, mean, std, obs)[3]
+    out = torch.empty(n).cuda()
+    keep = [dev(flat(params)), dev(mean), dev(std), dev(obs)]   # keep the tensors alive
+    _lib.check(lib.tonic_value_forward(*[t.data_ptr() for t in keep], out.data_ptr(),
+                                       n, O, None), 'value')
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------- gradients
+
+def actor_grad(lib, params, obs, actions, adv, stats, old_lp, waves=None):
+    from tonic_amd import _lib
+    if waves:
+        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+    n, O = obs.shape
+    A = actions.shape[1]
+    P = lib.tonic_ppo_actor_param_count(O, A)
+    out = torch.zeros(P + 8).cuda()
+    ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8).cuda()
+    keep = [dev(flat(params)), dev(obs), dev(actions), dev(adv), dev(stats), dev(old_lp)]
+    _lib.check(lib.tonic_ppo_actor_grad(
+        *[t.data_ptr() for t in keep], out.data_ptr(),
+        n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor_grad')
+    torch.cuda.synchronize()
+    _lib.check(lib.tonic_set_tuning(b'grad_waves', 4), 'tuning')
+    return out.cpu().numpy(), P
+
+
+def critic_grad(lib, params, mean, std, obs, returns, waves=None):
+    from tonic_amd import _lib
+    if waves:
+        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+    n, O = obs.shape
+    P = lib.tonic_v_critic_param_count(O)
+    out = torch.zeros(P + 8).cuda()
+    ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8).cuda()
+    keep = [dev(flat(params)), dev(mean), dev(std), dev(obs), dev(returns)]
+    _lib.check(lib.tonic_value_regression_grad(
+        *[t.data_ptr() for t in keep], out.data_ptr(), n, O, ws.data_ptr(),
+        ws.numel(), None), 'critic_grad')
+    torch.cuda.synchronize()
+    _lib.check(lib.tonic_set_tuning(b'grad_waves', 4), 'tuning')
+    return out.cpu().numpy(), P
+
+
+def assert_grads_close(got_sums, want_grads, n, what):
+    want = flat(want_grads).astype(np.float64)
+    got = got_sums.astype(np.float64) / n
+    err = np.abs(got - want).max()
+    scale = np.abs(want).max()
+    assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
+
+
+@pytest.mark.parametrize('waves', [4, 8])
+@pytest.mark.parametrize('name', PPO_CASES)
+def test_actor_and_critic_grads_golden_batch(lib, golden, name, waves):
+    g = golden(name)
+    actor, critic, norm = _params(g, 'pre0/')
+    seg = {k: port.flatten_time_major(g[f'u0/segment/{k}']) for k in (
+        'observations', 'actions', 'log_probs', 'returns', 'advantages', 'values')}
+    n = seg['observations'].shape[0]
+    # (a) final advantages passed directly (normalise flag 0)
+    stats = np.array([0, 1, 0, 0], np.float32)
+    got, P = actor_grad(lib, actor, seg['observations'], seg['actions'], seg['advantages'],
+                        stats, seg['log_probs'], waves)
+    want, info = port.clipped_ratio_grads(actor, seg['observations'], seg['actions'],
+                                          seg['advantages'], seg['log_probs'])
+    assert_grads_close(got[:P], want, n, f'{name} actor grads')
+    np.testing.assert_allclose(got[P + 0] / n, info['loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[P + 1] / n, info['kl'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
+    np.testing.assert_allclose(got[P + 3] / n, info['entropy'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[P + 4] / n, info['std'], rtol=1e-5, atol=1e-5)
+    assert got[P + 5] == n
+    # (b) raw advantages + in-kernel normalisation from the statistics
+    raw = seg['returns'] - seg['values']
+    stats = np.array([raw.mean(dtype=np.float64), raw.std(dtype=np.float64), 0, 1], np.float32)
+    got_b, _ = actor_grad(lib, actor, seg['observations'], seg['actions'], raw, stats,
+                          seg['log_probs'], waves)
+    assert_grads_close(got_b[:P], want, n, f'{name} actor grads (in-kernel normalisation)')
+    # critic
+    got_c, Pc = critic_grad(lib, critic, norm[0], norm[1], seg['observations'], seg['returns'], waves)
+    want_c, info_c = port.value_regression_grads(critic, norm[0], norm[1], seg['observations'],
+                                                 seg['returns'])
+    assert_grads_close(got_c[:Pc], want_c, n, f'{name} critic grads')
+    np.testing.assert_allclose(got_c[Pc + 0] / n, info_c['loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
+
+
+def test_grads_ratio_clipping_branches(lib):
+    """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
+    the still-live ones; ragged n (not a multiple of the 32-sample tile)."""
+    rng = np.random.RandomState(5)
+    O, A, n = 17, 6, 1234
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, A)) * 0.3, rng.normal(size=(A, 64)) * 0.2, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    obs = rng.normal(size=(n, O)).astype(np.float32)
+    actions = np.clip(rng.normal(size=(n, A)), -1, 1).astype(np.float32)
+    adv = rng.normal(size=n).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.4).astype(np.float32)
+    want, info = port.clipped_ratio_grads(params, obs, actions, adv, old_lp)
+    assert 0.2 < info['clip_fraction'] < 0.9
+    got, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32), old_lp)
+    assert_grads_close(got[:P], want, n, 'clipping branches')
+    np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
+
+
+def test_grads_full_size_properties(lib):
+    """BASELINE size (N = 4096 x 256): sums are additive over a split of the batch,
+    bit-reproducible run to run, and agree with the oracle on a 4096-sample slice."""
+    rng = np.random.RandomState(11)
+    O, A, n = 17, 6, 4096 * 256
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              np.zeros((1, A)), rng.normal(size=(A, 64)) * 0.1, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    old_lp = (-6 + rng.standard_normal(n) * 0.2).astype(np.float32)
+    stats = np.array([0, 1, 0, 0], np.float32)
+    full, P = actor_grad(lib, params, obs, actions, adv, stats, old_lp)
+    again, _ = actor_grad(lib, params, obs, actions, adv, stats, old_lp)
+    assert np.array_equal(full, again), 'fixed-order reductions must be bit-reproducible'
+    h = n // 2
+    a, _ = actor_grad(lib, params, obs[:h], actions[:h], adv[:h], stats, old_lp[:h])
+    b, _ = actor_grad(lib, params, obs[h:], actions[h:], adv[h:], stats, old_lp[h:])
+    both = a.astype(np.float64) + b.astype(np.float64)
+    scale = np.abs(full[:P]).max()
+    assert np.abs(both[:P] - full[:P]).max() <= 1e-5 * scale
+    m = 4096
+    want, _ = port.clipped_ratio_grads(params, obs[:m], actions[:m], adv[:m], old_lp[:m])
+    part, _ = actor_grad(lib, params, obs[:m], actions[:m], adv[:m], stats, old_lp[:m])
+    assert_grads_close(part[:P], want, m, 'slice of the full batch')
+
+
+# -------------------------------------------------------------------------------- Adam
+
+def test_adam_matches_reference_adam(lib):
+    from tonic_amd import _lib
+    rng = np.random.RandomState(3)
+    n, N = 5000, 37
+    p0 = rng.normal(size=n).astype(np.float32)
+    grads = [(rng.normal(size=n) * 10 ** rng.uniform(-6, 1, size=n)).astype(np.float32) for _ in range(5)]
+    ref = [torch.nn.Parameter(torch.tensor(p0))]
+    opt = torch.optim.Adam(ref, lr=3e-4)
+    params, m, v = dev(p0), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    state = torch.zeros(4, dtype=torch.int32).cuda()
+    for g in grads:
+        ref[0].grad = torch.tensor(g)
+        opt.step()
+        sums = dev(np.concatenate([g * N, np.zeros(8, np.float32)]))
+        _lib.check(lib.tonic_adam_step(params.data_ptr(), sums.data_ptr(), m.data_ptr(),
+                                       v.data_ptr(), state.data_ptr(), n, 1.0 / N, 3e-4, 0.9,
+                                       0.999, 1e-8, 0, 0.0, 0.0, None, None, None, None), 'adam')
+    assert int(state[0]) == len(grads)
+    delta_ref = ref[0].detach().numpy() - p0
+    delta = params.cpu().numpy() - p0
+    np.testing.assert_allclose(delta, delta_ref, rtol=0, atol=1e-7)
+
+
+# ------------------------------------------------------------------ segment + normaliser
+
+def test_segment_store_and_meanstd_record_bit_exact(lib):
+    from tonic_amd.replays import Segment
+    from tonic_amd.torch.normalizers import MeanStd
+    rng = np.random.RandomState(8)
+    T, W, O, A = 5, 37, 17, 6
+    seg = Segment(size=T)
+    seg.initialize(seed=0, device='cuda')
+    norm = MeanStd()
+    norm.initialize((O,))
+    norm.attach('cuda')
+    ref = port.MeanStdPort((O,))
+    rows = []
+    for t in range(T):
+        row = dict(observations=rng.normal(size=(W, O)) * 3 + 1, actions=rng.normal(size=(W, A)),
+                   next_observations=rng.normal(size=(W, O)), rewards=rng.normal(size=W),
+                   resets=rng.uniform(size=W) < 0.3, terminations=rng.uniform(size=W) < 0.1,
+                   log_probs=rng.normal(size=W))
+        row = {k: np.asarray(v, np.float32) for k, v in row.items()}
+        rows.append(row)
+        seg.store(normalizer=norm, **{k: dev(v) for k, v in row.items()})
+        ref.record(row['observations'])
+    assert seg.ready()
+    for k in rows[0]:
+        want = np.stack([r[k] for r in rows])
+        assert np.array_equal(seg.buffers[k].cpu().numpy(), want), k
+    sums = norm.device_sums.cpu().numpy()
+    assert np.array_equal(sums[:O], ref.new_sum) and np.array_equal(sums[O:], ref.new_sum_sq)
+    norm.update()
+    mean, std = ref.update()
+    assert np.array_equal(norm._mean.detach().cpu().numpy(), mean)
+    assert np.array_equal(norm._std.detach().cpu().numpy(), std)
+
+
+# ------------------------------------------------------------- whole update, agent level
+
+def _agent_from_golden(g, prefix, steps, iterations=80):
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd.environments import Box
+    O, A = int(g['cfg'][0]), int(g['cfg'][1])
+    agent = tonic_amd.torch.agents.PPO(
+        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=0)
+    state = {k[len(prefix):]: torch.as_tensor(g[k]) for k in g.files if k.startswith(prefix)}
+    agent.model.load_state_dict(state)
+    return agent
+
+
+def _fill_segment(agent, g, u):
+    for t in range(agent.replay.max_size):
+        row = {k: dev(g[f'u{u}/segment/{k}'][t]) for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets',
+            'terminations', 'log_probs')}
+        agent.replay.store(normalizer=None, **row)
+
+
+@pytest.mark.parametrize('name', PPO_CASES)
+def test_ppo_update_matches_reference(golden, lib, name):
+    g = golden(name)
+    steps = int(g['cfg'][3])
+    agent = _agent_from_golden(g, 'pre0/', steps)
+    before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    _fill_segment(agent, g, 0)
+    infos = agent.enqueue_update().cpu().numpy()
+    b = agent.replay.buffers
+    np.testing.assert_allclose(b['returns'].cpu().numpy(), g['u0/segment/returns'], rtol=1e-5, atol=1e-5)
+    ran = infos[0][:, 6] > 0
+    n_actor = int(g['u0/info/actor/iterations'][0])
+    assert ran.sum() == n_actor and ran[:n_actor].all(), 'device-side KL early stop'
+    for i, key in enumerate(('loss', 'kl', 'entropy', 'clip_fraction', 'std')):
+        np.testing.assert_allclose(infos[0][:n_actor, i], g[f'u0/info/actor/{key}'],
+                                   rtol=1e-5, atol=1e-5, err_msg=key)
+    assert np.array_equal(infos[0][:n_actor, 5] > 0.5, g['u0/info/actor/stop'])
+    np.testing.assert_allclose(infos[1][:, 0], g['u0/info/critic/loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(infos[1][:, 1], g['u0/info/critic/v_mean'], rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, start in before.items():
+        if 'normalizer' in key:
+            continue
+        got = after[key].detach().cpu().numpy() - start
+        want = g['post0/' + key] - start
+        tol = max(1e-5, 50 * float(g['noise/' + key].max()))
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=key)
+
+
+@pytest.mark.parametrize('name', PPO_CASES)
+def test_ppo_single_iteration_strict(golden, lib, name):
+    g = golden(name)
+    steps = int(g['cfg'][3])
+    agent = _agent_from_golden(g, 'pre0/', steps, iterations=1)
+    before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    _fill_segment(agent, g, 0)
+    agent.enqueue_update()
+    torch.cuda.synchronize()
+    actor, critic, norm = _params(g, 'pre0/')
+    flat_seg = {k: port.flatten_time_major(g[f'u0/segment/{k}']) for k in (
+        'observations', 'actions', 'log_probs', 'returns', 'advantages')}
+    g_actor, _ = port.clipped_ratio_grads(actor, flat_seg['observations'], flat_seg['actions'],
+                                          flat_seg['advantages'], flat_seg['log_probs'])
+    g_critic, _ = port.value_regression_grads(critic, norm[0], norm[1], flat_seg['observations'],
+                                              flat_seg['returns'])
+    keys = [k for k in before if 'normalizer' not in k]
+    after = agent.model.state_dict()
+    for key, grad in zip(keys, g_actor + g_critic):
+        got = after[key].detach().cpu().numpy() - before[key]
+        want = g['iter1/' + key] - before[key]
+        live = np.abs(grad) > 1e-6 * np.abs(grad).max()     # see test_oracle_golden.py
+        np.testing.assert_allclose(got[live], want[live], rtol=0, atol=1e-5, err_msg=key)
+
+
+def test_agent_drop_in_trajectory(golden, lib):
+    """The full drop-in path (agent.step / agent.update with NumPy in/out, Sequential
+    collector, host-drawn noise) replays the reference's run: same actions, same stored
+    segment, same update statistics."""
+    import tonic_amd
+    import tonic_amd.torch
+    g = golden('ppo_halfcheetah_small')
+    O, A, W, steps, seed, iterations, updates = (int(x) for x in g['cfg'])
+    env = tonic_amd.environments.distribute(
+        lambda: tonic_amd.environments.Synthetic(O, A, max_episode_steps=7), 1, W)
+    env.initialize(seed=seed)
+    agent = tonic_amd.torch.agents.PPO(
+        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations))
+    agent.initialize(env.observation_space, env.action_space, seed=seed)
+    observations = env.start()
+    rng = np.random.RandomState(seed + 1)
+    for t in range(steps):
+        np.testing.assert_allclose(observations, g['act/observations'][t], rtol=0, atol=0)
+        actions = agent.step(observations, t * W)
+        np.testing.assert_allclose(actions, g['act/actions'][t], rtol=0, atol=3e-6)
+        observations, infos = env.step(g['act/actions'][t])   # reference actions: same env path
+        infos['rewards'] = (infos['rewards'] + rng.normal(size=W)).astype(np.float32)
+        term = rng.uniform(size=W) < 0.05
+        infos['terminations'] = term
+        infos['resets'] = infos['resets'] | term
+        agent.update(**infos, steps=t * W)
+    infos = agent.last_infos
+    n_actor = int(g['u0/info/actor/iterations'][0])
+    assert (infos[0][:, 6] > 0).sum() == n_actor
+    np.testing.assert_allclose(infos[0][:n_actor, 1], g['u0/info/actor/kl'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(infos[1][:, 0], g['u0/info/critic/loss'], rtol=1e-4, atol=1e-4)
+    norm = agent.model.observation_normalizer
+    np.testing.assert_allclose(norm._mean.detach().cpu().numpy(),
+                               g['post0/observation_normalizer._mean'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(norm._std.detach().cpu().numpy(),
+                               g['post0/observation_normalizer._std'], rtol=0, atol=1e-7)

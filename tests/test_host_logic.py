@@ -1,0 +1,215 @@
+"""CPU tests of the host side: collector semantics vs the reference goldens, the C-ABI
+library's exported symbols vs include/tonic_hip.h, trainer bookkeeping, sharding helpers and
+the world_size-2 gloo path of the gradient-sum exchange."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import numpy_port as port
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tonic_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'tonic_hip.h')).read()
+    declared = set(re.findall(r'\b(tonic_[a-z0-9_]+)\s*\(', header))
+    declared -= {'tonic_status'}
+    assert {'tonic_gae_lambda_returns', 'tonic_ppo_actor_grad', 'tonic_adam_step'} <= declared
+    assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree'
+    lib = ctypes.CDLL(_lib.LIBRARY_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} missing from libtonic_hip.so'
+    loaded = _lib.load()
+    assert loaded.tonic_abi_version() == 1
+    assert loaded.tonic_target_arch() == b'gfx950'
+    assert loaded.tonic_ppo_actor_param_count(17, 6) == 5708
+    assert loaded.tonic_v_critic_param_count(17) == 5377
+    # argument validation happens before any GPU work: error codes + messages, no crash
+    assert loaded.tonic_gae_workspace_bytes(4096, 256, 0) > 0
+    status = loaded.tonic_ppo_act(None, None, None, None, None, 4, 17, 6, None)
+    assert status == -1 and b'null' in loaded.tonic_last_error()
+    status = loaded.tonic_set_tuning(b'no_such_knob', 1)
+    assert status == -1 and b'unknown key' in loaded.tonic_last_error()
+
+
+def test_agents_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import tonic_amd.torch
+    from tonic_amd import _lib
+    from tonic_amd.environments import Box
+    agent = tonic_amd.torch.agents.PPO()
+    with pytest.raises(_lib.TonicHipError, match='no CPU fallback'):
+        agent.initialize(Box(-1, 1, (3,)), Box(-1, 1, (1,)), seed=0)
+
+
+def test_sequential_matches_reference_golden(golden):
+    from tonic_amd import environments
+    g = golden('sequential')
+    env = environments.distribute(
+        lambda: environments.Synthetic(3, 2, max_episode_steps=int(g['max_episode_steps'])), 1, 4)
+    env.initialize(seed=int(g['seed']))
+    obs = env.start()
+    assert obs.dtype == np.float32 and np.array_equal(obs, g['observations'][0])
+    for t in range(g['actions'].shape[0]):
+        obs, infos = env.step(g['actions'][t])
+        assert np.array_equal(obs, g['observations'][t + 1])
+        assert np.array_equal(infos['observations'], g['next_observations'][t])
+        assert np.array_equal(infos['rewards'], g['rewards'][t])
+        assert infos['resets'].dtype == bool and np.array_equal(infos['resets'], g['resets'][t])
+        assert np.array_equal(infos['terminations'], g['terminations'][t])
+
+
+def test_parallel_equals_sequential():
+    """Sequential(P*S) == Parallel(P, S) for equal seeds (seed layout distributed.py:18-20,109)."""
+    from tonic_amd import environments
+
+    def builder():
+        return environments.Synthetic(5, 3, max_episode_steps=4)
+    seq = environments.distribute(builder, 1, 6)
+    par = environments.distribute(builder, 3, 2)
+    assert isinstance(par, environments.Parallel)
+    seq.initialize(seed=11)
+    par.initialize(seed=11)
+    a, b = seq.start(), par.start()
+    assert np.array_equal(a, b)
+    rng = np.random.RandomState(0)
+    for _ in range(9):
+        actions = rng.uniform(-1, 1, size=(6, 3)).astype(np.float32)
+        (oa, ia), (ob, ib) = seq.step(actions), par.step(actions)
+        assert np.array_equal(oa, ob)
+        for key in ia:
+            assert np.array_equal(ia[key], ib[key]), key
+
+
+def test_synthetic_batch_protocol():
+    from tonic_amd.environments import SyntheticBatch
+    env = SyntheticBatch(8, 17, 6, max_episode_steps=3, termination_probability=0.2)
+    env.initialize(seed=0)
+    obs = env.start()
+    assert obs.shape == (8, 17) and obs.dtype == np.float32
+    for t in range(7):
+        obs, infos = env.step(np.zeros((8, 6), np.float32))
+        assert (infos['resets'] | ~infos['terminations']).all()      # resets ⊇ terminations
+        assert infos['rewards'].dtype == np.float32
+        keep = ~infos['resets']
+        assert np.array_equal(obs[keep], infos['observations'][keep])
+
+
+def test_trainer_bookkeeping(tmp_path):
+    import tonic_amd
+    from tonic_amd import agents, environments, logger
+
+    class Constant(agents.Agent):
+        updates = 0
+
+        def step(self, observations, steps):
+            return np.zeros((len(observations), 2), np.float32)
+
+        test_step = step
+
+        def update(self, observations, rewards, resets, terminations, steps):
+            self.updates += 1
+            assert observations.shape == (3, 4) and resets.dtype == bool
+
+        def save(self, path):
+            self.saved = path
+
+    logger.initialize(path=str(tmp_path))
+    env = environments.distribute(lambda: environments.Synthetic(4, 2, max_episode_steps=5), 1, 3)
+    env.initialize(seed=0)
+    test_env = environments.distribute(lambda: environments.Synthetic(4, 2, max_episode_steps=5), 1, 1)
+    test_env.initialize(seed=10000)
+    agent = Constant()
+    trainer = tonic_amd.Trainer(steps=60, epoch_steps=30, save_steps=60, show_progress=False)
+    trainer.initialize(agent, env, test_env)
+    trainer.run()
+    assert agent.updates == 20 and trainer.steps == 60
+    assert agent.saved.endswith(os.path.join('checkpoints', 'step_60'))
+    rows = open(tmp_path / 'log.csv').read().strip().split('\n')
+    header = rows[0].split(',')
+    for key in ('train/steps_per_second', 'train/episode_length/mean', 'test/episode_score/mean',
+                'train/action/mean', 'train/epochs'):
+        assert key in header
+    assert len(rows) == 3
+    first = dict(zip(header, rows[1].split(',')))
+    assert float(first['train/episode_length/mean']) == 5.0       # time-outs every 5 steps
+    assert float(first['test/episode_length/mean']) == 5.0
+
+
+def test_shard_bounds_partition():
+    from tonic_amd import parallel
+    for total in (256, 10240, 7):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'oracle'))
+import numpy_port as port
+from tonic_amd import parallel
+rank, world = parallel.init_from_env(backend='gloo')
+rng = np.random.RandomState(0)
+T, W, O, A = 6, 10, 17, 6
+params = [rng.normal(size=s).astype(np.float32) * 0.2 for s in
+          [(64, O), (64,), (64, 64), (64,), (1, A), (A, 64), (A,)]]
+obs = rng.normal(size=(T, W, O)).astype(np.float32)
+act = np.clip(rng.normal(size=(T, W, A)), -1, 1).astype(np.float32)
+ret = rng.normal(size=(T, W)).astype(np.float32)
+val = rng.normal(size=(T, W)).astype(np.float32)
+old = (rng.normal(size=(T, W)) - 6).astype(np.float32)
+lo, hi = parallel.shard_bounds(W)
+raw = (ret - val)[:, lo:hi].astype(np.float64)
+mean, std, all_zero = parallel.combine_advantage_moments(
+    raw.sum(), (raw * raw).sum(), raw.min(), raw.max(), raw.size)
+adv_full = port.normalized_advantages(ret, val)
+adv = ((ret - val)[:, lo:hi] - np.float32(mean)) / np.float32(std)
+np.testing.assert_allclose(adv, adv_full[:, lo:hi], rtol=1e-5, atol=1e-5)
+f = lambda x: x[:, lo:hi].reshape((-1,) + x.shape[2:])
+n_local = T * (hi - lo)
+grads, stats = port.clipped_ratio_grads(params, f(obs), f(act), adv.reshape(-1), f(old))
+sums = torch.tensor(np.concatenate([g.reshape(-1) for g in grads] +
+                                   [[stats['loss'], stats['kl'], n_local]]).astype(np.float64))
+sums[:-1] *= n_local                       # ranks exchange SUMS, not means
+parallel.allreduce_sums(sums)
+n_global = float(sums[-1])
+assert n_global == T * W
+full_g, full_s = port.clipped_ratio_grads(
+    params, obs.reshape(-1, O), act.reshape(-1, A), adv_full.reshape(-1), old.reshape(-1))
+want = np.concatenate([g.reshape(-1) for g in full_g]).astype(np.float64)
+got = sums[:-3].numpy() / n_global
+assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-8, np.abs(got - want).max()
+assert abs(float(sums[-3]) / n_global - full_s['loss']) < 1e-5
+assert abs(float(sums[-2]) / n_global - full_s['kl']) < 1e-5
+print('rank', rank, 'ok')
+'''
+
+
+def test_two_rank_gradient_sum_exchange_gloo(tmp_path):
+    """world_size 2 over gloo: sharding the worker axis and all-reducing gradient SUMS gives
+    the single-process full-batch gradient (the protocol the RCCL path uses)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', WORLD_SIZE='2',
+               OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f'rank {r} ok' in out

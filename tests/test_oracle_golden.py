@@ -161,3 +161,56 @@ def test_ppo_single_iteration_deltas_strict(golden, name):
         assert live.mean() > 0.99
         np.testing.assert_allclose((got - before)[live], (want - before)[live], atol=1e-5, rtol=0)
         assert np.abs(got - before).max() <= 1.01e-3
+
+
+@pytest.mark.parametrize('name', ['ppo_halfcheetah_small', 'ppo_pendulum_small'])
+def test_torch_port_matches_reference(golden, name):
+    """oracle/torch_port.py (the timed CPU baseline) reproduces the reference's update."""
+    import torch
+    import torch_port
+    torch.set_num_threads(1)
+    g = golden(name)
+    O, A, W, steps = (int(x) for x in g['cfg'][:4])
+    actor, critic, norm = _params(g, 'pre0/')
+    agent = torch_port.TorchPPO(O, A, steps=steps)
+    agent.load(actor, critic, norm)
+    agent.buffers = {k: g[f'u0/segment/{k}'].copy() for k in (
+        'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+        'log_probs')}
+    agent.normalizer.new_count = 1
+    agent.normalizer.new_sum = np.zeros(O, np.float32)
+    agent.normalizer.new_sum_sq = np.zeros(O, np.float32)
+    infos = agent.update()
+    assert np.array_equal(agent.buffers['returns'], g['u0/segment/returns'])
+    kl = np.array([float(i['actor']['kl']) for i in infos if 'actor' in i])
+    np.testing.assert_allclose(kl, g['u0/info/actor/kl'], rtol=1e-6, atol=1e-7)
+    closs = np.array([float(i['critic']['loss']) for i in infos])
+    np.testing.assert_allclose(closs, g['u0/info/critic/loss'], rtol=1e-6, atol=1e-7)
+    ref_actor, ref_critic, _ = _params(g, 'post0/')
+    for got, want in zip(agent.actor_vars + agent.critic_vars, ref_actor + ref_critic):
+        np.testing.assert_allclose(got.detach().numpy(), want, rtol=0, atol=1e-6)
+
+
+def test_c_restatement_matches_golden(golden):
+    """oracle/gae_ref.c (built by __graft_entry__.build()) is bit-exact with the reference."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle',
+                        'liboracle_gae.so')
+    if not os.path.exists(path):
+        pytest.skip('oracle C checker not built (run python __graft_entry__.py build)')
+    lib = ctypes.CDLL(path)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.oracle_lambda_returns.argtypes = [fp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_double] * 2
+    g = golden('lambda_returns')
+    for i in range(int(g['n_cases'])):
+        for j in range(4):
+            k = f'c{i}_{j}_'
+            arrays = [np.ascontiguousarray(g[k + n]) for n in
+                      ('next_values', 'rewards', 'resets', 'terminations')]
+            out = np.zeros_like(arrays[0])
+            T, W = out.shape
+            lib.oracle_lambda_returns(*[a.ctypes.data_as(fp) for a in arrays],
+                                      out.ctypes.data_as(fp), T, W, float(g[k + 'gamma']),
+                                      float(g[k + 'lambda']))
+            assert np.array_equal(out, g[k + 'returns']), k

@@ -1,0 +1,82 @@
+"""ctypes binding of ``libtonic_hip.so`` (the C ABI declared in ``include/tonic_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+``TonicHipError`` is raised.  Build the library with ``python __graft_entry__.py build`` or
+``make -C tonic_amd/csrc`` (hipcc cross-compiles gfx950 without a GPU).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, 'libtonic_hip.so')
+
+c_float_p = ctypes.c_void_p   # device pointers travel as plain integers
+c_i32, c_i64, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/tonic_hip.h one to one.
+SIGNATURES = {
+    'tonic_last_error': (ctypes.c_char_p, []),
+    'tonic_abi_version': (c_i32, []),
+    'tonic_target_arch': (ctypes.c_char_p, []),
+    'tonic_set_tuning': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
+    'tonic_ppo_actor_param_count': (c_i64, [c_i32, c_i32]),
+    'tonic_v_critic_param_count': (c_i64, [c_i32]),
+    'tonic_gae_workspace_bytes': (c_i64, [c_i64, c_i64, c_i32]),
+    'tonic_gae_lambda_returns': (ctypes.c_int, [c_vp] * 9 + [c_i64, c_i64, c_f64, c_f64, c_i32,
+                                                              c_vp, c_i64, c_vp]),
+    'tonic_advantage_stats_from_moments': (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    'tonic_ppo_act': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_vp]),
+    'tonic_value_forward': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_vp]),
+    'tonic_mlp64_grad_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'tonic_ppo_actor_grad': (ctypes.c_int, [c_vp] * 7 + [c_i64, c_i32, c_i32, c_f64, c_f64,
+                                                          c_vp, c_vp, c_i64, c_vp]),
+    'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_vp, c_i64, c_vp]),
+    'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
+                                                     c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    'tonic_segment_store': (ctypes.c_int, [c_vp] * 15 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
+}
+
+
+class TonicHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and declares every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise TonicHipError(
+            f'{LIBRARY_PATH} not found: the HIP extension is required (no CPU fallback). '
+            'Build it with `python __graft_entry__.py build` or `make -C tonic_amd/csrc`.')
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().tonic_last_error().decode()
+        raise TonicHipError(f'{what} failed with status {status}: {msg}')
+
+
+def ptr(tensor):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if tensor is None:
+        return None
+    if not tensor.is_contiguous():
+        raise TonicHipError('non-contiguous tensor passed to the HIP engine')
+    return tensor.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

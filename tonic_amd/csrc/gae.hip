@@ -164,8 +164,29 @@ __global__ __launch_bounds__(kGaeThreads) void gae_scan_kernel(GaeArgs g) {
 }
 
 // {mean, std, all_zero, normalise}: segments.py:43-46 and updaters/actors.py:71.
+__device__ __forceinline__ void write_adv_stats(double s0, double s1, double mn, double mx,
+                                                double count, float* adv_stats) {
+  const double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  // numpy's std of a constant array is exactly 0 (segments.py:44 then skips the
+  // normalisation); detect that case by min == max instead of trusting var == 0.
+  const bool constant = mn == mx;
+  const float std = constant ? 0.f : (float)sqrt(var);
+  adv_stats[0] = (float)mean;
+  adv_stats[1] = std;
+  adv_stats[2] = (constant && mn == 0.0) ? 1.f : 0.f;
+  adv_stats[3] = std != 0.f ? 1.f : 0.f;
+}
+
+// moments = {sum, sum_sq, -min, max, count}: ranks SUM-reduce [0,1,4] and MAX-reduce [2,3].
+__global__ void adv_stats_from_moments_kernel(const double* moments, float* adv_stats) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    write_adv_stats(moments[0], moments[1], -moments[2], moments[3], moments[4], adv_stats);
+}
+
 __global__ void gae_stats_kernel(const double* block_sums, int nblocks, double count,
-                                 float* adv_stats) {
+                                 float* adv_stats, double* moments) {
   double s0 = 0.0, s1 = 0.0, mn = INFINITY, mx = -INFINITY;
   for (int i = threadIdx.x; i < nblocks; i += 64) {
     s0 += block_sums[4 * i];
@@ -181,17 +202,10 @@ __global__ void gae_stats_kernel(const double* block_sums, int nblocks, double c
     mx = fmax(mx, __shfl_xor(mx, off, 64));
   }
   if (threadIdx.x == 0) {
-    const double mean = s0 / count;
-    double var = s1 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    // numpy's std of a constant array is exactly 0 (segments.py:44 then skips the
-    // normalisation); detect that case by min == max instead of trusting var == 0.
-    const bool constant = mn == mx;
-    const float std = constant ? 0.f : (float)sqrt(var);
-    adv_stats[0] = (float)mean;
-    adv_stats[1] = std;
-    adv_stats[2] = (constant && mn == 0.0) ? 1.f : 0.f;
-    adv_stats[3] = std != 0.f ? 1.f : 0.f;
+    write_adv_stats(s0, s1, mn, mx, count, adv_stats);
+    if (moments != nullptr) {
+      moments[0] = s0; moments[1] = s1; moments[2] = -mn; moments[3] = mx; moments[4] = count;
+    }
   }
 }
 
@@ -241,7 +255,8 @@ extern "C" int64_t tonic_gae_workspace_bytes(int64_t T, int64_t W, int32_t chunk
 extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float* d_rewards,
                                         const float* d_resets, const float* d_terminations,
                                         const float* d_values, float* d_returns,
-                                        float* d_advantages, float* d_adv_stats, int64_t T,
+                                        float* d_advantages, float* d_adv_stats,
+                                        double* d_adv_moments, int64_t T,
                                         int64_t W, double discount_factor, double trace_decay,
                                         int32_t chunks, void* d_workspace,
                                         int64_t workspace_bytes, void* stream) {
@@ -280,7 +295,17 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
   hipLaunchKernelGGL(gae_scan_kernel, dim3((unsigned)l.col_blocks, l.chunks), dim3(kGaeThreads),
                      0, st, g);
   hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(64), 0, st, g.block_sums,
-                     (int)l.scan_blocks, (double)T * (double)W, d_adv_stats);
+                     (int)l.scan_blocks, (double)T * (double)W, d_adv_stats, d_adv_moments);
   TONIC_CHECK_LAUNCH("tonic_gae_lambda_returns");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_advantage_stats_from_moments(const double* d_adv_moments,
+                                                  float* d_adv_stats, void* stream) {
+  TONIC_REQUIRE(d_adv_moments && d_adv_stats, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_advantage_stats_from_moments: null pointer");
+  hipLaunchKernelGGL(adv_stats_from_moments_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                     d_adv_moments, d_adv_stats);
+  TONIC_CHECK_LAUNCH("tonic_advantage_stats_from_moments");
   return TONIC_OK;
 }

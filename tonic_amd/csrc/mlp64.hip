@@ -635,11 +635,20 @@ int grad_blocks(int64_t n) {
 template <typename K>
 int launch(K kernel, int blocks, int threads, int lds_bytes, hipStream_t stream, MlpArgs args,
            const char* what) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (e != hipSuccess) {
-    set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
-    return TONIC_ERR_LAUNCH;
+  // >64 KiB of dynamic LDS needs an opt-in, once per kernel (not a stream operation, so it is
+  // done outside any graph capture that may be active on later calls).
+  static thread_local const void* configured[64];
+  static thread_local int n_configured = 0;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  bool known = false;
+  for (int i = 0; i < n_configured; ++i) known |= configured[i] == fn;
+  if (!known) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
+      return TONIC_ERR_LAUNCH;
+    }
+    if (n_configured < 64) configured[n_configured++] = fn;
   }
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, args);
   TONIC_CHECK_LAUNCH(what);

@@ -1,0 +1,72 @@
+"""Single-node multi-GPU data parallelism: one process per GPU, RCCL over xGMI.
+
+The worker axis W is sharded contiguously across ranks (rank r owns workers
+[r*W/G, (r+1)*W/G), the reference's group-major order).  Rollout, store, critic evaluation and
+the lambda-return scan need no communication (worker columns are independent); the learner
+exchanges ONE flat float32 buffer per optimizer step — [gradient sums | 8 statistic sums] —
+with a sum all-reduce, after which every rank applies the identical Adam step scaled by
+1/N_global.  Advantage normalisation needs the global mean/std: ranks all-reduce
+(sum, sum of squares, min, max-as-negated-min, count) once per update.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 or dist.is_initialized():
+        return rank(), world_size()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" is RCCL on ROCm
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    dist.init_process_group(backend=backend)
+    return rank(), world_size()
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_bounds(total, r=None, world=None):
+    """Contiguous [begin, end) of `total` items owned by rank r (remainder to the low ranks)."""
+    r = rank() if r is None else r
+    world = world_size() if world is None else world
+    base, extra = divmod(total, world)
+    begin = r * base + min(r, extra)
+    return begin, begin + base + (1 if r < extra else 0)
+
+
+def allreduce_sums(buffer):
+    """In-place sum all-reduce of a flat buffer (no-op for a single process)."""
+    if world_size() > 1:
+        dist.all_reduce(buffer, op=dist.ReduceOp.SUM)
+    return buffer
+
+
+def combine_advantage_moments(total, total_sq, minimum, maximum, count):
+    """Global advantage mean / population std from per-rank float64 moments
+    (tonic/replays/segments.py:43-46 over the union of all shards)."""
+    if world_size() > 1:
+        sums = torch.tensor([total, total_sq, count], dtype=torch.float64)
+        ext = torch.tensor([-minimum, maximum], dtype=torch.float64)
+        if dist.get_backend() == 'nccl':
+            sums, ext = sums.cuda(), ext.cuda()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+        total, total_sq, count = sums.tolist()
+        minimum, maximum = -float(ext[0]), float(ext[1])
+    mean = total / count
+    var = max(total_sq / count - mean * mean, 0.0)
+    constant = minimum == maximum
+    std = 0.0 if constant else var ** 0.5
+    return mean, std, constant and minimum == 0.0

@@ -1,0 +1,139 @@
+"""HBM-resident on-policy ``Segment`` — API of ``tonic/replays/segments.py``.
+
+Layout in HBM (float32, like the reference which stores even the boolean flags as float32,
+segments.py:33): ``observations, next_observations [T, W, O]``, ``actions [T, W, A]``,
+``rewards, resets, terminations, log_probs, values, next_values, returns, advantages
+[T, W]`` — time-major so that (a) one ``store`` call writes one contiguous row per buffer,
+(b) the lambda-return scan walks T with lane = worker (coalesced), (c) the flattened batch
+``[T*W, ...]`` the learner kernels read is a free view (``flatten_batch``, utils.py:22-25).
+176 B per transition at O=17, A=6 (+16 B for the derived arrays) = 201 MB at W=256.
+
+``store`` goes through ``tonic_segment_store`` (one launch per time step, which also advances
+the observation normaliser's running sums); ``compute_returns`` through
+``tonic_gae_lambda_returns`` which also produces the raw advantages and their mean / std;
+the normalisation itself, (adv - mean) / std (segments.py:45), is applied in-register by the
+actor kernel, so ``get_full('advantages')`` materialises it only when a caller asks.
+"""
+import numpy as np
+import torch
+
+from tonic_amd import _lib, parallel
+
+STORED_KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'resets',
+               'terminations', 'log_probs')
+
+
+def flatten_batch(values):
+    shape = values.shape
+    return values.reshape((int(np.prod(shape[:2], dtype=int)),) + tuple(shape[2:]))
+
+
+class Segment:
+    def __init__(self, size=4096, batch_iterations=80, batch_size=None, discount_factor=0.99,
+                 trace_decay=0.97, gae_chunks=0):
+        self.max_size = size
+        self.batch_iterations = batch_iterations
+        self.batch_size = batch_size
+        self.discount_factor = discount_factor
+        self.trace_decay = trace_decay
+        self.gae_chunks = gae_chunks
+
+    def initialize(self, seed=None, device=None):
+        self.np_random = np.random.RandomState(seed)
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.buffers = None
+        self.index = 0
+        self.lib = _lib.load()
+
+    def ready(self):
+        return self.index == self.max_size
+
+    def _allocate(self, num_workers, observation_size, action_size):
+        T, W = self.max_size, num_workers
+        self.num_workers = W
+        self.observation_size, self.action_size = observation_size, action_size
+
+        def new(*shape):
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self.buffers = dict(
+            observations=new(T, W, observation_size), actions=new(T, W, action_size),
+            next_observations=new(T, W, observation_size), rewards=new(T, W), resets=new(T, W),
+            terminations=new(T, W), log_probs=new(T, W), values=new(T, W),
+            next_values=new(T, W), returns=new(T, W), advantages=new(T, W))
+        self.adv_stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.adv_moments = torch.zeros(5, dtype=torch.float64, device=self.device)
+        nbytes = self.lib.tonic_gae_workspace_bytes(T, W, self.gae_chunks)
+        self.gae_workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+
+    def store(self, normalizer=None, **kwargs):
+        """Writes one time row.  Values must be float32 device tensors of shape [W, ...]
+        (the agent stages host data through its pinned buffers first)."""
+        if self.buffers is None:
+            self._allocate(kwargs['observations'].shape[0], kwargs['observations'].shape[1],
+                           kwargs['actions'].shape[1])
+        if self.index >= self.max_size:
+            raise IndexError('Segment is full: call get()/get_full() before storing again')
+        b = self.buffers
+        sums = normalizer.device_sums if normalizer is not None else None
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_segment_store(
+            p(b['observations']), p(b['actions']), p(b['next_observations']), p(b['rewards']),
+            p(b['resets']), p(b['terminations']), p(b['log_probs']),
+            p(kwargs['observations']), p(kwargs['actions']), p(kwargs['next_observations']),
+            p(kwargs['rewards']), p(kwargs['resets']), p(kwargs['terminations']),
+            p(kwargs['log_probs']), p(sums), self.index, self.num_workers,
+            self.observation_size, self.action_size, _lib.current_stream()),
+            'tonic_segment_store')
+        if normalizer is not None:
+            normalizer.note_device_rows(self.num_workers)
+        self.index += 1
+
+    def compute_returns(self, values, next_values):
+        """segments.py:67-78 + the raw-advantage half of get_full (segments.py:41-46)."""
+        b = self.buffers
+        shape = b['rewards'].shape
+        if values.data_ptr() != b['values'].data_ptr():
+            b['values'].copy_(values.reshape(shape))
+        if next_values.data_ptr() != b['next_values'].data_ptr():
+            b['next_values'].copy_(next_values.reshape(shape))
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_gae_lambda_returns(
+            p(b['next_values']), p(b['rewards']), p(b['resets']), p(b['terminations']),
+            p(b['values']), p(b['returns']), p(b['advantages']), p(self.adv_stats),
+            p(self.adv_moments), shape[0], shape[1], float(self.discount_factor),
+            float(self.trace_decay), self.gae_chunks, p(self.gae_workspace),
+            self.gae_workspace.numel(), _lib.current_stream()), 'tonic_gae_lambda_returns')
+        if parallel.world_size() > 1:
+            # global advantage statistics over every rank's worker shard
+            m = self.adv_moments
+            torch.distributed.all_reduce(m[0:2])
+            torch.distributed.all_reduce(m[4:5])
+            torch.distributed.all_reduce(m[2:4], op=torch.distributed.ReduceOp.MAX)
+            _lib.check(self.lib.tonic_advantage_stats_from_moments(
+                p(m), p(self.adv_stats), _lib.current_stream()),
+                'tonic_advantage_stats_from_moments')
+
+    def get_full(self, *keys):
+        """Flattened [T*W, ...] device views.  'advantages' is returned NORMALISED like the
+        reference (materialised with stock torch ops; the fused learner path never asks for
+        it and reads the raw advantages + adv_stats instead)."""
+        self.index = 0
+        out = {}
+        for k in keys:
+            if k == 'advantages':
+                mean, std, _, flag = self.adv_stats.tolist()
+                adv = self.buffers['advantages']
+                out[k] = flatten_batch((adv - mean) / std if flag else adv)
+            else:
+                out[k] = flatten_batch(self.buffers[k])
+        return out
+
+    def get(self, *keys):
+        batch = self.get_full(*keys)
+        if self.batch_size is None:
+            for _ in range(self.batch_iterations):
+                yield batch
+        else:
+            raise NotImplementedError(
+                'Segment(batch_size=...) minibatches are not implemented yet in the HIP engine '
+                '(SURVEY.md §8f item 2); use the default full-batch mode')

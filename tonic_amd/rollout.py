@@ -1,0 +1,76 @@
+"""Device-resident synthetic rollout: the collect half of the hot path with every input
+already in HBM (the benchmark contract's "inputs resident in HBM when the timed region
+starts").  Observations, transition outcomes and the action noise of a whole Segment
+(T time steps x W workers) are pre-generated on the device; ``collect`` then issues, per
+environment step, exactly what ``PPO.step`` + ``PPO.update`` issue — one ``tonic_ppo_act``
+and one ``tonic_segment_store`` (with the normaliser record) — but without the host in the
+loop.  The per-step launches are kept (one act per time step on W observations) because in
+a real environment step t+1's observations depend on step t's actions.
+
+``capture=True`` records the T-step sequence once into a hipGraph (via
+``torch.cuda.CUDAGraph``; the C-ABI calls only enqueue kernels on the current stream, so they
+are capturable) and replays it, removing the host launch cost.
+"""
+import torch
+
+from tonic_amd import _lib
+
+
+class DeviceRollout:
+    def __init__(self, agent, workers, steps, seed=0, reset_probability=1e-3):
+        self.agent = agent
+        self.lib = _lib.load()
+        device = agent.device
+        O, A = agent.observation_size, agent.action_size
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.W, self.T = workers, steps
+        self.observations = torch.randn(steps + 1, workers, O, device=device, generator=gen)
+        self.eps = torch.randn(steps, workers, A, device=device, generator=gen)
+        self.rewards = torch.randn(steps, workers, device=device, generator=gen)
+        resets = torch.rand(steps, workers, device=device, generator=gen) < reset_probability
+        terms = resets & (torch.rand(steps, workers, device=device, generator=gen) < 0.5)
+        self.resets, self.terminations = resets.float(), terms.float()
+        self.actions = torch.empty(workers, A, device=device)
+        self.log_probs = torch.empty(workers, device=device)
+        self.graph = None
+
+    def _enqueue(self):
+        agent, lib, p = self.agent, self.lib, _lib.ptr
+        replay = agent.replay
+        if replay.buffers is None:
+            replay._allocate(self.W, agent.observation_size, agent.action_size)
+        b = replay.buffers
+        norm = agent.model.observation_normalizer
+        sums = norm.device_sums if norm is not None else None
+        stream = _lib.current_stream()
+        actor = p(agent.model.flat_actor.flat)
+        for t in range(self.T):
+            _lib.check(lib.tonic_ppo_act(
+                actor, p(self.observations[t]), p(self.eps[t]), p(self.actions),
+                p(self.log_probs), self.W, agent.observation_size, agent.action_size, stream),
+                'tonic_ppo_act')
+            _lib.check(lib.tonic_segment_store(
+                p(b['observations']), p(b['actions']), p(b['next_observations']),
+                p(b['rewards']), p(b['resets']), p(b['terminations']), p(b['log_probs']),
+                p(self.observations[t]), p(self.actions), p(self.observations[t + 1]),
+                p(self.rewards[t]), p(self.resets[t]), p(self.terminations[t]),
+                p(self.log_probs), p(sums), t, self.W, agent.observation_size,
+                agent.action_size, stream), 'tonic_segment_store')
+
+    def collect(self, capture=False):
+        """Fills the agent's Segment with T steps (asynchronous; no host sync)."""
+        if capture:
+            if self.graph is None:
+                self._enqueue()                       # warm-up: allocations, LDS opt-ins
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._enqueue()
+            self.graph.replay()
+        else:
+            self._enqueue()
+        norm = self.agent.model.observation_normalizer
+        if norm is not None:
+            norm.new_count += self.T * self.W
+        self.agent.replay.index = self.T

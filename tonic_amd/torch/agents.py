@@ -1,0 +1,245 @@
+"""PPO on the HIP engine — API of ``tonic/torch/agents/{agent,a2c,ppo}.py``.
+
+``step`` / ``update`` keep the reference signatures (NumPy in, NumPy out) so
+``tonic.Trainer`` drives the agent unchanged.  Per environment step the host does one pinned
+H2D copy (observations + pre-drawn standard-normal noise), one ``tonic_ppo_act`` launch and
+one D2H copy of the actions; ``update`` stages the transition outcome and launches
+``tonic_segment_store`` (which also advances the observation-normaliser sums).  Every
+``Segment.size`` steps ``_update`` enqueues the whole learner update
+(2 x value forward, GAE scan, ``batch_iterations`` x [actor grad+Adam, critic grad+Adam])
+without any host synchronisation — the KL early stop of ppo.py:45-46 is a device flag — and
+reads the logged statistics back once.
+
+The action noise is drawn on the host with ``torch.randn`` from the global CPU generator,
+which consumes the same stream as the reference's ``Normal.sample()``, so
+runs with equal seeds follow the reference's trajectory up to float32 rounding.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from tonic_amd import _lib, agents, logger, replays
+from tonic_amd.torch import models, normalizers, updaters
+
+
+def default_model():
+    """tonic/torch/agents/a2c.py:7-17."""
+    return models.ActorCritic(
+        actor=models.Actor(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((64, 64), torch.nn.Tanh),
+            head=models.DetachedScaleGaussianPolicyHead()),
+        critic=models.Critic(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((64, 64), torch.nn.Tanh),
+            head=models.ValueHead()),
+        observation_normalizer=normalizers.MeanStd())
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.TonicHipError(
+            'tonic_amd agents need a ROCm GPU: the learner runs in hand-written HIP kernels '
+            'and there is deliberately no CPU fallback')
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    return torch.device('cuda', local_rank if local_rank < torch.cuda.device_count() else 0)
+
+
+class Agent(agents.Agent):
+    """tonic/torch/agents/agent.py:10-26 (seeding and .pt checkpoints)."""
+
+    def initialize(self, seed=None):
+        if seed is not None:
+            np.random.seed(seed)
+            random.seed(seed)
+            torch.manual_seed(seed)
+
+    def save(self, path):
+        path = path + '.pt'
+        logger.log(f'\nSaving weights to {path}')
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        # CPU tensors with the reference's key layout: loadable by the reference and tonic.play.
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, path)
+
+    def load(self, path):
+        path = path + '.pt'
+        logger.log(f'\nLoading weights from {path}')
+        self.model.load_state_dict(torch.load(path, map_location='cpu'))
+
+
+class _Staging:
+    """Pinned host <-> device staging for one [W, ...] record per environment step."""
+
+    def __init__(self, fields, device):
+        self.offsets, total = {}, 0
+        for name, shape in fields:
+            size = int(np.prod(shape))
+            self.offsets[name] = (total, size, tuple(shape))
+            total += size
+        self.host = torch.empty(total, dtype=torch.float32).pin_memory()
+        self.device = torch.empty(total, dtype=torch.float32, device=device)
+        self.host_np = self.host.numpy()
+
+    def host_view(self, name):
+        start, size, shape = self.offsets[name]
+        return self.host_np[start:start + size].reshape(shape)
+
+    def device_view(self, name):
+        start, size, shape = self.offsets[name]
+        return self.device[start:start + size].view(shape)
+
+    def upload(self):
+        self.device.copy_(self.host, non_blocking=True)
+
+    def download(self):
+        self.host.copy_(self.device, non_blocking=True)
+
+
+class A2C(Agent):
+    """Acting / storing half shared by the on-policy agents (a2c.py:20-99)."""
+
+    def __init__(self, model=None, replay=None, actor_updater=None, critic_updater=None):
+        self.model = model or default_model()
+        self.replay = replay or replays.Segment()
+        self.actor_updater = actor_updater
+        self.critic_updater = critic_updater or updaters.VRegression()
+        if self.actor_updater is None:
+            raise NotImplementedError(
+                'A2C (StochasticPolicyGradient) is outside the accelerated path; use PPO')
+
+    def initialize(self, observation_space, action_space, seed=None):
+        super().initialize(seed=seed)
+        self.device = _device()
+        self.lib = _lib.load()
+        self.model.initialize(observation_space, action_space)       # CPU init: seed parity
+        self.model.pack(self.device)
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.attach(self.device)
+        self.replay.initialize(seed, device=self.device)
+        self.actor_updater.initialize(self.model)
+        self.critic_updater.initialize(self.model)
+        self.observation_size = observation_space.shape[0]
+        self.action_size = action_space.shape[0]
+        self._workers = None
+
+    # ------------------------------------------------------------------ acting
+    def _io(self, workers):
+        W, O, A = workers, self.observation_size, self.action_size
+        return (_Staging([('observations', (W, O)), ('eps', (W, A))], self.device),
+                _Staging([('actions', (W, A)), ('log_probs', (W,))], self.device))
+
+    def _act(self, observations, stage_in, stage_out, want_log_probs):
+        W, A = observations.shape[0], self.action_size
+        stage_in.host_view('observations')[:] = observations
+        # Same generator draw as Normal.sample() in the reference (a2c.py:81).
+        stage_in.host_view('eps')[:] = torch.randn(W, A).numpy()
+        stage_in.upload()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_ppo_act(
+            p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
+            p(stage_in.device_view('eps')), p(stage_out.device_view('actions')),
+            p(stage_out.device_view('log_probs')) if want_log_probs else None,
+            W, self.observation_size, A, _lib.current_stream()), 'tonic_ppo_act')
+        stage_out.download()
+        torch.cuda.current_stream().synchronize()
+        return stage_out.host_view('actions').copy()
+
+    def step(self, observations, steps):
+        observations = np.asarray(observations, np.float32)
+        if self._workers != observations.shape[0]:
+            W, O = observations.shape[0], self.observation_size
+            self._workers = W
+            self._in, self._out = self._io(W)
+            self._outcome = _Staging([('next_observations', (W, O)), ('rewards', (W,)),
+                                      ('resets', (W,)), ('terminations', (W,))], self.device)
+        actions = self._act(observations, self._in, self._out, True)
+        self.last_observations = observations.copy()
+        self.last_actions = actions
+        self.last_log_probs = self._out.host_view('log_probs').copy()
+        return actions
+
+    def test_step(self, observations, steps):
+        observations = np.asarray(observations, np.float32)
+        if getattr(self, '_test_workers', None) != observations.shape[0]:
+            self._test_workers = observations.shape[0]
+            self._test_in, self._test_out = self._io(observations.shape[0])
+        return self._act(observations, self._test_in, self._test_out, False)
+
+    # ---------------------------------------------------------------- learning
+    def update(self, observations, rewards, resets, terminations, steps):
+        stage = self._outcome
+        stage.host_view('next_observations')[:] = observations
+        stage.host_view('rewards')[:] = rewards
+        stage.host_view('resets')[:] = resets                 # bool -> float32 (segments.py:33)
+        stage.host_view('terminations')[:] = terminations
+        stage.upload()
+        self.replay.store(
+            normalizer=self.model.observation_normalizer,
+            observations=self._in.device_view('observations'),
+            actions=self._out.device_view('actions'),
+            next_observations=stage.device_view('next_observations'),
+            rewards=stage.device_view('rewards'), resets=stage.device_view('resets'),
+            terminations=stage.device_view('terminations'),
+            log_probs=self._out.device_view('log_probs'))
+        if self.model.return_normalizer:
+            raise NotImplementedError('return normalisers are not supported (never enabled by '
+                                      'the reference defaults)')
+        if self.replay.ready():
+            self._update()
+
+    def _evaluate(self):
+        """a2c.py:92-99 on the HBM-resident segment: fills values / next_values in place."""
+        b = self.replay.buffers
+        critic = self.critic_updater
+        critic.forward_values(replays.flatten_batch(b['observations']), b['values'].view(-1))
+        critic.forward_values(replays.flatten_batch(b['next_observations']),
+                              b['next_values'].view(-1))
+        return b['values'], b['next_values']
+
+
+class PPO(A2C):
+    """tonic/torch/agents/ppo.py:7-67."""
+
+    def __init__(self, model=None, replay=None, actor_updater=None, critic_updater=None):
+        super().__init__(model=model, replay=replay,
+                         actor_updater=actor_updater or updaters.ClippedRatio(),
+                         critic_updater=critic_updater)
+
+    def enqueue_update(self):
+        """Enqueues one whole learner update on the current stream (no host sync)."""
+        replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
+        values, next_values = self._evaluate()
+        replay.compute_returns(values, next_values)
+        batch = replay.get_full('observations', 'actions', 'log_probs', 'returns')
+        raw_advantages = replays.flatten_batch(replay.buffers['advantages'])
+        iterations = replay.batch_iterations
+        if getattr(self, '_infos', None) is None or self._infos.shape[1] != iterations:
+            self._infos = torch.zeros(2, iterations, updaters.INFO_WIDTH, device=self.device)
+        self._infos.zero_()
+        actor.reset_stop()
+        for it in range(iterations):
+            actor.enqueue(batch['observations'], batch['actions'], raw_advantages,
+                          replay.adv_stats, batch['log_probs'], self._infos[0, it])
+            critic.enqueue(batch['observations'], batch['returns'], self._infos[1, it])
+        return self._infos
+
+    def _update(self):
+        if self.replay.batch_size is not None:
+            raise NotImplementedError('PPO minibatches (Segment(batch_size=...)) are not '
+                                      'implemented in the HIP engine yet')
+        infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+        actor_rows = infos[0][infos[0][:, 6] > 0]
+        for row in actor_rows:
+            for i, key in enumerate(updaters.ACTOR_INFO):
+                value = row[i] > 0.5 if key == 'stop' else row[i]
+                logger.store('actor/' + key, value)
+        for row in infos[1]:
+            logger.store('critic/loss', row[0])
+            logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
+        logger.store('actor/iterations', len(actor_rows))
+        logger.store('critic/iterations', len(infos[1]))
+        self.last_infos = infos
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.update()

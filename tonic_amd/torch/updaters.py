@@ -1,0 +1,188 @@
+"""Learner updaters on the HIP engine — API of ``tonic/torch/updaters/{actors,critics}.py``.
+
+``ClippedRatio`` (actors.py:53-112) and ``VRegression`` (critics.py:6-28) keep their
+constructor arguments, ``initialize(model)`` and ``__call__`` returning a dict whose values
+expose ``.numpy()``.  Internally one update is three asynchronous launches on the current
+stream, with no host synchronisation:
+
+    tonic_ppo_actor_grad / tonic_value_regression_grad   fused forward + loss + backward
+    [all-reduce of the flat gradient-sum buffer over RCCL when world_size > 1]
+    tonic_adam_step                                       flat Adam + logged statistics
+
+The PPO agent drives them through ``enqueue`` for all 80 iterations and reads the
+statistics back once; ``__call__`` (enqueue + read back) exists for drop-in compatibility.
+"""
+import numpy as np
+import torch
+
+from tonic_amd import _lib
+
+INFO_WIDTH = 8
+ACTOR_INFO = ('loss', 'kl', 'entropy', 'clip_fraction', 'std', 'stop')
+
+
+def adam_hyperparameters(factory, default_lr):
+    """Reads lr / betas / eps from the reference-style ``optimizer=lambda params: Adam(...)``
+    factory (actors.py:58-59) so user configs keep working; only plain Adam is fused."""
+    if factory is None:
+        return dict(lr=default_lr, betas=(0.9, 0.999), eps=1e-8)
+    probe = factory([torch.nn.Parameter(torch.zeros(1))])
+    if not isinstance(probe, torch.optim.Adam) or isinstance(probe, torch.optim.AdamW):
+        raise NotImplementedError(f'only torch.optim.Adam is fused on the HIP engine, got {type(probe)}')
+    d = probe.defaults
+    if d.get('weight_decay', 0) != 0 or d.get('amsgrad', False) or d.get('maximize', False):
+        raise NotImplementedError('Adam with weight_decay / amsgrad / maximize is not fused')
+    return dict(lr=float(d['lr']), betas=tuple(float(b) for b in d['betas']), eps=float(d['eps']))
+
+
+class _FlatUpdater:
+    stats_kind = 0
+
+    def _setup(self, flat, hyper):
+        self.lib = _lib.load()
+        self.flat = flat
+        self.hyper = hyper
+        device = flat.flat.device
+        self.count = flat.count
+        self.grad_sums = torch.zeros(self.count + INFO_WIDTH, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(self.count, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.count, dtype=torch.float32, device=device)
+        self.state = torch.zeros(4, dtype=torch.int32, device=device)   # {step, stop, -, -}
+        self.workspace = None
+        self.scratch_info = torch.zeros(INFO_WIDTH, dtype=torch.float32, device=device)
+        self.world_size = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world_size = torch.distributed.get_world_size()
+
+    def _workspace_for(self, n):
+        need = self.lib.tonic_mlp64_grad_workspace_bytes(n, self.count)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
+        return self.workspace
+
+    def _step(self, n_global, info_row, adv_stats=None, skip=None, kl_threshold=0.0,
+              entropy_coeff=0.0):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
+        h = self.hyper
+        _lib.check(self.lib.tonic_adam_step(
+            _lib.ptr(self.flat.flat), _lib.ptr(self.grad_sums), _lib.ptr(self.exp_avg),
+            _lib.ptr(self.exp_avg_sq), _lib.ptr(self.state), self.count, 1.0 / n_global,
+            h['lr'], h['betas'][0], h['betas'][1], h['eps'], self.stats_kind,
+            float(kl_threshold), float(entropy_coeff), _lib.ptr(adv_stats),
+            _lib.ptr(info_row), skip, _lib.current_stream()), 'tonic_adam_step')
+
+
+class ClippedRatio(_FlatUpdater):
+    stats_kind = 1
+
+    def __init__(self, optimizer=None, ratio_clip=0.2, kl_threshold=0.015, entropy_coeff=0,
+                 gradient_clip=0):
+        self.optimizer = optimizer
+        self.ratio_clip = ratio_clip
+        self.kl_threshold = kl_threshold
+        self.entropy_coeff = entropy_coeff
+        self.gradient_clip = gradient_clip
+        if gradient_clip > 0:
+            raise NotImplementedError('gradient_clip > 0 is not implemented in the fused PPO path')
+
+    def initialize(self, model):
+        self.model = model
+        self._setup(model.flat_actor, adam_hyperparameters(self.optimizer, 3e-4))
+        self.variables = model.flat_actor.params
+        self.observation_size = model.actor.torso.model[0].in_features
+        self.action_size = model.actor.head.log_scale.shape[1]
+        if tuple(model.actor.torso.sizes) != (64, 64):
+            raise NotImplementedError('the fused PPO kernels need a (64, 64) tanh torso')
+
+    def stop_flag_ptr(self):
+        return self.state.data_ptr() + 4
+
+    def reset_stop(self):
+        self.state[1:2].zero_()
+
+    def enqueue(self, observations, actions, advantages, adv_stats, log_probs, info_row,
+                n_global=None):
+        n = observations.shape[0]
+        ws = self._workspace_for(n)
+        p = _lib.ptr
+        skip = self.stop_flag_ptr()
+        _lib.check(self.lib.tonic_ppo_actor_grad(
+            p(self.flat.flat), p(observations), p(actions), p(advantages), p(adv_stats),
+            p(log_probs), p(self.grad_sums), n, self.observation_size, self.action_size,
+            float(self.ratio_clip), float(self.entropy_coeff), skip, p(ws), ws.numel(),
+            _lib.current_stream()), 'tonic_ppo_actor_grad')
+        self._step(n_global or n * self.world_size, info_row, adv_stats, skip,
+                   self.kl_threshold, self.entropy_coeff)
+
+    def __call__(self, observations, actions, advantages, log_probs):
+        """Drop-in form (actors.py:70-112): `advantages` are final (already normalised)."""
+        all_zero = bool((advantages == 0).all())
+        adv_stats = torch.tensor([0., 1., float(all_zero), 0.], device=advantages.device)
+        self.reset_stop()
+        self.scratch_info.zero_()
+        self.enqueue(observations, actions, advantages, adv_stats, log_probs, self.scratch_info)
+        row = self.scratch_info.cpu()
+        self.reset_stop()
+        out = {k: row[i].clone() for i, k in enumerate(ACTOR_INFO)}
+        out['stop'] = out['stop'] > 0.5
+        return out
+
+
+class VRegression(_FlatUpdater):
+    stats_kind = 2
+
+    def __init__(self, loss=None, optimizer=None, gradient_clip=0):
+        if loss is not None and not isinstance(loss, torch.nn.MSELoss):
+            raise NotImplementedError('only the default MSE loss is fused')
+        if gradient_clip > 0:
+            raise NotImplementedError('gradient_clip > 0 is not implemented in the fused PPO path')
+        self.loss = loss
+        self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
+
+    def initialize(self, model):
+        self.model = model
+        self._setup(model.flat_critic, adam_hyperparameters(self.optimizer, 1e-3))
+        self.variables = model.flat_critic.params
+        self.observation_size = model.critic.torso.model[0].in_features
+        self.normalizer = model.observation_normalizer
+        if tuple(model.critic.torso.sizes) != (64, 64):
+            raise NotImplementedError('the fused PPO kernels need a (64, 64) tanh torso')
+        if self.normalizer is None:
+            device = self.grad_sums.device
+            self._unit_mean = torch.zeros(self.observation_size, device=device)
+            self._unit_std = torch.ones(self.observation_size, device=device)
+
+    def norm_tensors(self):
+        if self.normalizer is None:
+            return self._unit_mean, self._unit_std
+        return self.normalizer._mean.data, self.normalizer._std.data
+
+    def forward_values(self, observations, out):
+        mean, std = self.norm_tensors()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_value_forward(
+            p(self.flat.flat), p(mean), p(std), p(observations), p(out), observations.shape[0],
+            self.observation_size, _lib.current_stream()), 'tonic_value_forward')
+        return out
+
+    def enqueue(self, observations, returns, info_row, n_global=None):
+        n = observations.shape[0]
+        ws = self._workspace_for(n)
+        mean, std = self.norm_tensors()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_value_regression_grad(
+            p(self.flat.flat), p(mean), p(std), p(observations), p(returns), p(self.grad_sums),
+            n, self.observation_size, p(ws), ws.numel(), _lib.current_stream()),
+            'tonic_value_regression_grad')
+        self._step(n_global or n * self.world_size, info_row)
+
+    def __call__(self, observations, returns):
+        """Drop-in form (critics.py:18-28).  `v` is the pre-step value vector."""
+        values = torch.empty(observations.shape[0], device=observations.device)
+        self.forward_values(observations, values)
+        self.scratch_info.zero_()
+        self.enqueue(observations, returns, self.scratch_info)
+        row = self.scratch_info.cpu()
+        return dict(loss=row[0].clone(), v=values.cpu())

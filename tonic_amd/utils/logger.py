@@ -1,0 +1,179 @@
+"""Epoch logger with the key names and CSV semantics of ``tonic/utils/logger.py``.
+
+The key names (``train/steps_per_second``, ``actor/kl`` ...) are part of the drop-in contract:
+``tonic.plot`` and downstream tooling read ``log.csv`` / ``config.yaml`` written here.
+``termcolor`` is optional (not installed in the ROCm image): plain text is used without it.
+"""
+import datetime
+import os
+import time
+
+import numpy as np
+
+try:
+    import termcolor
+except ImportError:          # pragma: no cover - depends on the image
+    termcolor = None
+
+current_logger = None
+
+
+def _paint(text, color=None, on_color=None, attrs=None):
+    if termcolor is None:
+        return text
+    return termcolor.colored(text, color, on_color, attrs=attrs)
+
+
+class Logger:
+    def __init__(self, path=None, width=60, script_path=None, config=None):
+        self.path = path or str(time.time())
+        self.log_file_path = os.path.join(self.path, 'log.csv')
+        if script_path:
+            with open(script_path) as source:
+                text = source.read()
+            os.makedirs(self.path, exist_ok=True)
+            target = os.path.join(self.path, 'script.py')
+            with open(target, 'w') as out:
+                out.write(text)
+            log(f'Script file saved to {target}')
+        if config:
+            import yaml
+            os.makedirs(self.path, exist_ok=True)
+            target = os.path.join(self.path, 'config.yaml')
+            with open(target, 'w') as out:
+                yaml.dump(config, out)
+            log(f'Config file saved to {target}')
+        self.known_keys = set()
+        self.stat_keys = set()
+        self.epoch_dict = {}
+        self.width = width
+        self.last_epoch_progress = None
+        self.start_time = time.time()
+
+    def store(self, key, value, stats=False):
+        """Keeps named values during an epoch (logger.py:51-59)."""
+        bucket = self.epoch_dict.get(key)
+        if bucket is None:
+            self.epoch_dict[key] = [value]
+            if stats:
+                self.stat_keys.add(key)
+        else:
+            bucket.append(value)
+
+    def _reduce(self):
+        for key in list(self.epoch_dict):
+            values = self.epoch_dict[key]
+            if key in self.stat_keys:
+                del self.epoch_dict[key]
+                flat = np.concatenate([np.ravel(v) for v in values]) if len(values) else values
+                # same reductions as logger.py:66-71 (np.mean/std/min/max over the stored list)
+                self.epoch_dict[key + '/mean'] = np.mean(flat)
+                self.epoch_dict[key + '/std'] = np.std(flat)
+                self.epoch_dict[key + '/min'] = np.min(flat)
+                self.epoch_dict[key + '/max'] = np.max(flat)
+                self.epoch_dict[key + '/size'] = len(values)
+            else:
+                self.epoch_dict[key] = np.mean(values)
+
+    def dump(self):
+        """Prints the epoch table and appends a row to log.csv (rewritten when new keys appear)."""
+        self._reduce()
+        new_keys = [k for k in self.epoch_dict if k not in self.known_keys]
+        first_row = not self.known_keys
+        if new_keys:
+            if not first_row:
+                warning(f'Logging new keys {new_keys}')
+            self.known_keys.update(new_keys)
+            self.final_keys = sorted(self.known_keys)
+        print()
+        shown = set()
+        for key in self.final_keys:
+            *groups, leaf = key.split('/')
+            for depth in range(len(groups)):
+                prefix = '/'.join(groups[:depth + 1])
+                if prefix not in shown:
+                    shown.add(prefix)
+                    print('  ' * depth + groups[depth].replace('_', ' '))
+            value = self.epoch_dict.get(key)
+            if isinstance(value, (float, np.floating)):
+                text = f'{value:8.3g}'
+            elif isinstance(value, (int, np.integer)):
+                text = f'{value:,}'
+            else:
+                text = str(value)
+            left = '  ' * len(groups) + leaf.replace('_', ' ')
+            print(left + ' ' * max(1, self.width - len(left) - len(text)) + text)
+        print()
+        values = [self.epoch_dict.get(k) for k in self.final_keys]
+        os.makedirs(self.path, exist_ok=True)
+        if new_keys and not first_row:
+            with open(self.log_file_path) as old:
+                old_header = old.readline().strip().split(',')
+                old_rows = [line.strip().split(',') for line in old if line.strip()]
+            with open(self.log_file_path, 'w') as out:
+                out.write(','.join(self.final_keys) + '\n')
+                for row in old_rows:
+                    by_key = dict(zip(old_header, row))
+                    out.write(','.join(by_key.get(k, 'None') for k in self.final_keys) + '\n')
+                out.write(','.join(map(str, values)) + '\n')
+        else:
+            with open(self.log_file_path, 'a') as out:
+                if first_row:
+                    out.write(','.join(self.final_keys) + '\n')
+                out.write(','.join(map(str, values)) + '\n')
+        self.epoch_dict.clear()
+        self.last_epoch_progress = None
+
+    def show_progress(self, steps, num_epoch_steps, num_steps, color='white', on_color='on_blue'):
+        epoch_steps = (steps - 1) % num_epoch_steps + 1
+        progress = int(self.width * epoch_steps / num_epoch_steps)
+        if progress == self.last_epoch_progress:
+            return
+        per_step = (time.time() - self.start_time) / steps
+        left_epoch = datetime.timedelta(seconds=int(max((num_epoch_steps - epoch_steps) * per_step, 0)))
+        left_total = datetime.timedelta(seconds=int(max((num_steps - steps) * per_step, 0)))
+        msg = f'Time left:  epoch {left_epoch}  total {left_total}'.center(self.width)
+        print(_paint('\r' + msg[:progress], color, on_color), end='')
+        print(msg[progress:], sep='', end='', flush=True)
+        self.last_epoch_progress = progress
+
+
+def initialize(*args, **kwargs):
+    global current_logger
+    current_logger = Logger(*args, **kwargs)
+    return current_logger
+
+
+def get_current_logger():
+    global current_logger
+    if current_logger is None:
+        current_logger = Logger()
+    return current_logger
+
+
+def store(*args, **kwargs):
+    return get_current_logger().store(*args, **kwargs)
+
+
+def dump(*args, **kwargs):
+    return get_current_logger().dump(*args, **kwargs)
+
+
+def show_progress(*args, **kwargs):
+    return get_current_logger().show_progress(*args, **kwargs)
+
+
+def get_path():
+    return get_current_logger().path
+
+
+def log(msg, color='green'):
+    print(_paint(msg, color, attrs=['bold']))
+
+
+def warning(msg, color='yellow'):
+    print(_paint('Warning: ' + msg, color, attrs=['bold']))
+
+
+def error(msg, color='red'):
+    print(_paint('Error: ' + msg, color, attrs=['bold']))
