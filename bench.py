@@ -113,7 +113,8 @@ def kernel_rooflines(agent):
     def gae_entry(t_steps, workers, chunks):
         dev = agent.device
         arrays = [torch.randn(t_steps, workers, device=dev) for _ in range(3)]
-        flags = (torch.rand(t_steps, workers, device=dev) < 1e-3).float()
+        resets = (torch.rand(t_steps, workers, device=dev) < 1e-3).float()
+        terms = resets * (torch.rand(t_steps, workers, device=dev) < 0.5).float()
         outs = [torch.empty(t_steps, workers, device=dev) for _ in range(2)]
         stats = torch.zeros(4, device=dev)
         wsg = torch.empty(max(lib.tonic_gae_workspace_bytes(t_steps, workers, chunks), 16),
@@ -121,7 +122,7 @@ def kernel_rooflines(agent):
 
         def run():
             _lib.check(lib.tonic_gae_lambda_returns(
-                p(arrays[0]), p(arrays[1]), p(flags), p(flags), p(arrays[2]), p(outs[0]),
+                p(arrays[0]), p(arrays[1]), p(resets), p(terms), p(arrays[2]), p(outs[0]),
                 p(outs[1]), p(stats), None, t_steps, workers, 0.99, 0.97, chunks, p(wsg),
                 wsg.numel(), stream), 'gae')
         ms = time_events(run, 10)

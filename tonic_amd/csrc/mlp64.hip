@@ -92,16 +92,28 @@ __device__ __forceinline__ void stage_weights(float* lds, const MlpArgs& a) {
   const float* tail = b2 + 64;
   const float* W3 = ACTOR ? tail + A : tail;
   const float* b3 = W3 + (ACTOR ? A * 64 : 64);
-  for (int idx = tid; idx < 2 * KS1 * 64; idx += nth) {
-    const int t = idx / (KS1 * 64), rem = idx % (KS1 * 64);
-    const int st = rem >> 6, l = rem & 63, kh = l >> 5, i = l & 31, k = 2 * st + kh;
-    lds[L::W1S + idx] = k < O ? W1[(32 * t + i) * O + k] : 0.f;
+  // Global reads in memory order (coalesced); the permutation is applied on the LDS side.
+  // Inverse of feat(): feature f sits at step q = (f>>5)<<4 | ((f>>3)&3)<<2 | (f&3), half (f>>2)&1.
+  for (int idx = tid; idx < 2 * KS1 * 64; idx += nth) lds[L::W1S + idx] = 0.f;
+  __syncthreads();
+  for (int g = tid; g < 64 * O; g += nth) {
+    const int row = g / O, k = g - row * O;
+    const int t = row >> 5, i = row & 31, st = k >> 1, kh = k & 1;
+    lds[L::W1S + (t * KS1 + st) * 64 + kh * 32 + i] = W1[g];
   }
-  for (int idx = tid; idx < 2 * 32 * 64; idx += nth) {
-    const int t = idx >> 11, st = (idx >> 6) & 31, l = idx & 63, kh = l >> 5, i = l & 31;
-    const int f = feat(st, kh);
-    lds[L::W2S + idx] = W2[(32 * t + i) * 64 + f];
-    if (BWD) lds[L::W2B + idx] = W2[f * 64 + 32 * t + i];
+  for (int g = tid; g < 64 * 64; g += nth) {
+    const int row = g >> 6, col = g & 63;
+    const float w = W2[g];
+    {  // forward image: A operand row = output feature, k = input feature `col`
+      const int t = row >> 5, i = row & 31;
+      const int st = ((col >> 5) << 4) | (((col >> 3) & 3) << 2) | (col & 3), kh = (col >> 2) & 1;
+      lds[L::W2S + (t * 32 + st) * 64 + kh * 32 + i] = w;
+    }
+    if (BWD) {  // backward image: A operand row = input feature `col`, k = output feature `row`
+      const int t = col >> 5, i = col & 31;
+      const int st = ((row >> 5) << 4) | (((row >> 3) & 3) << 2) | (row & 3), kh = (row >> 2) & 1;
+      lds[L::W2B + (t * 32 + st) * 64 + kh * 32 + i] = w;
+    }
   }
   for (int idx = tid; idx < 64; idx += nth) {
     const int h = idx >> 5, q = idx & 31;
@@ -143,6 +155,15 @@ __device__ __forceinline__ void stage_weights(float* lds, const MlpArgs& a) {
 
 // --------------------------------------------------------------------- MFMA building blocks
 
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): one v_exp_f32 + one v_rcp_f32, no
+// branches (the libm tanhf is ~40 instructions with a divergent branch).  Absolute error
+// <= ~2e-7 over the whole range, i.e. float32 rounding level of the surrounding dot products.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.8853900817779268f);   // 2*log2(e)
+  const float y = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+  return copysignf(y, x);
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -175,8 +196,8 @@ __device__ __forceinline__ void dense_tanh(const float* w_img, const float* bias
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    out[r] = tanhf(acc0[r]);
-    out[16 + r] = tanhf(acc1[r]);
+    out[r] = tanh_fast(acc0[r]);
+    out[16 + r] = tanh_fast(acc1[r]);
   }
 }
 
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void ppo_act_kernel(MlpArgs a) {
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       if (aa < a.A) {
-        const float loc = tanhf(z[aa]);
+        const float loc = tanh_fast(z[aa]);
         const float sigma = lds[L::HC + aa * 4 + 1];
         float act = loc;
         if (a.eps != nullptr && valid) act = loc + sigma * a.eps[ns * a.A + aa];
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       for (int aa = 0; aa < AP; ++aa) {
         loc[aa] = 0.f; dif[aa] = 0.f;
         if (aa < A) {
-          loc[aa] = tanhf(z[aa]);
+          loc[aa] = tanh_fast(z[aa]);
           const float act = valid ? a.actions[ns * A + aa] : loc[aa];
           dif[aa] = act - loc[aa];
           logp += -(dif[aa] * dif[aa]) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
@@ -558,22 +579,42 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
 }
 
 // Fixed-order reduction of the per-workgroup partials (+ log_scale chain rule, entropy).
+// One workgroup of 16 waves per 64 consecutive outputs: wave w sums a contiguous slice of the
+// partial rows (independent loads, 8 in flight), the slices are combined in wave order.
+constexpr int kReduceWaves = 16;
+
 template <bool ACTOR>
-__global__ void reduce_partials_kernel(const float* partials, int nblocks, int pstride, int P,
-                                       const float* params, float* grad_sums, int O, int A,
-                                       float entropy_coeff, const int32_t* skip) {
+__global__ __launch_bounds__(kReduceWaves * 64) void reduce_partials_kernel(
+    const float* partials, int nblocks, int pstride, int P, const float* params,
+    float* grad_sums, int O, int A, float entropy_coeff, double nloc, const int32_t* skip) {
   if (skip != nullptr && *skip != 0) return;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P + kStatSlots) return;
+  __shared__ double slices[kReduceWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const bool active = p < P + kStatSlots;
+  const int per = (nblocks + kReduceWaves - 1) / kReduceWaves;
+  const int b0 = wave * per, b1 = min(b0 + per, nblocks);
   double acc = 0.0;
-  for (int b = 0; b < nblocks; ++b) acc += (double)partials[(int64_t)b * pstride + p];
+  if (active) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partials[(int64_t)(b + u) * pstride + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < b1; ++b) acc += (double)partials[(int64_t)b * pstride + p];
+  }
+  slices[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0 || !active) return;
+  acc = 0.0;
+#pragma unroll
+  for (int w = 0; w < kReduceWaves; ++w) acc += slices[w][lane];
   float out = (float)acc;
   if (ACTOR) {
     const int oLs = 64 * O + 64 + 4096 + 64;
-    double nloc = 0.0;
-    if ((p >= oLs && p < oLs + A) || p == P + 3 || p == P + 4) {
-      for (int b = 0; b < nblocks; ++b) nloc += (double)partials[(int64_t)b * pstride + P + 5];
-    }
     if (p >= oLs && p < oLs + A) {
       const float ls = params[p];
       const float sp = ls > 20.f ? ls : log1pf(expf(ls));
@@ -792,10 +833,10 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
   });
   if (rc != TONIC_OK) return rc;
   const int total = (int)P + kStatSlots;
-  hipLaunchKernelGGL(reduce_partials_kernel<ACTOR>, dim3((total + 255) / 256), dim3(256), 0,
-                     as_stream(stream), static_cast<const float*>(d_workspace), blocks,
-                     (int)pstride, (int)P, a.params, d_grad_sums, a.O, a.A, entropy_coeff,
-                     a.skip);
+  hipLaunchKernelGGL(reduce_partials_kernel<ACTOR>, dim3((total + 63) / 64),
+                     dim3(kReduceWaves * 64), 0, as_stream(stream),
+                     static_cast<const float*>(d_workspace), blocks, (int)pstride, (int)P,
+                     a.params, d_grad_sums, a.O, a.A, entropy_coeff, (double)a.n, a.skip);
   TONIC_CHECK_LAUNCH("reduce_partials_kernel");
   return TONIC_OK;
 }

@@ -20,7 +20,11 @@ struct StoreArgs {
   int O, A;
 };
 
-__global__ __launch_bounds__(256) void segment_store_kernel(StoreArgs a) {
+constexpr int kStoreThreads = 1024;
+constexpr int kRecordLdsFloats = 16384;     // 64 KiB staging tile for MeanStd.record
+
+__global__ __launch_bounds__(kStoreThreads) void segment_store_kernel(StoreArgs a) {
+  __shared__ float tile[kRecordLdsFloats];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n_obs = a.W * a.O, n_act = a.W * a.A;
@@ -35,19 +39,29 @@ __global__ __launch_bounds__(256) void segment_store_kernel(StoreArgs a) {
     a.seg_term[a.row * a.W + i] = a.term[i];
     a.seg_lp[a.row * a.W + i] = a.lp[i];
   }
-  // MeanStd.record on the LAST block so it overlaps the copies of the others.
-  if (a.norm_acc != nullptr && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < a.O) {
-    const int k = threadIdx.x;
-    float sum = a.norm_acc[k], sum_sq = a.norm_acc[a.O + k];
-    for (int64_t w = 0; w < a.W; ++w) {
-      const float v = a.obs[w * a.O + k];
-      sum = sum + v;                 // mean_stds.py:46
-      const float sq = v * v;        // np.square, then a separate add (:47)
-      sum_sq = sum_sq + sq;
+  // MeanStd.record (mean_stds.py:44-48) on the LAST workgroup: rows are staged through LDS with
+  // coalesced loads, then lane k walks feature k over the rows IN ORDER with float32 adds —
+  // the reference's exact operation sequence, without a dependent global load per row.
+  if (a.norm_acc == nullptr || blockIdx.x != gridDim.x - 1) return;
+  const int k = threadIdx.x;
+  float sum = 0.f, sum_sq = 0.f;
+  if (k < a.O) { sum = a.norm_acc[k]; sum_sq = a.norm_acc[a.O + k]; }
+  const int64_t rows_per_chunk = kRecordLdsFloats / a.O;
+  for (int64_t w0 = 0; w0 < a.W; w0 += rows_per_chunk) {
+    const int64_t rows = min(rows_per_chunk, a.W - w0);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < rows * a.O; i += blockDim.x) tile[i] = a.obs[w0 * a.O + i];
+    __syncthreads();
+    if (k < a.O) {
+      for (int64_t w = 0; w < rows; ++w) {
+        const float v = tile[w * a.O + k];
+        sum = sum + v;                 // mean_stds.py:46
+        const float sq = v * v;        // np.square, then a separately rounded add (:47)
+        sum_sq = sum_sq + sq;
+      }
     }
-    a.norm_acc[k] = sum;
-    a.norm_acc[a.O + k] = sum_sq;
   }
+  if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }
 }
 
 }  // namespace tonic
@@ -68,7 +82,7 @@ extern "C" int tonic_segment_store(float* d_seg_observations, float* d_seg_actio
                     d_observations && d_actions && d_next_observations && d_rewards &&
                     d_resets && d_terminations && d_log_probs,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_segment_store: null pointer");
-  TONIC_REQUIRE(row >= 0 && W > 0 && O > 0 && O <= 256 && A > 0, TONIC_ERR_INVALID_ARGUMENT,
+  TONIC_REQUIRE(row >= 0 && W > 0 && O > 0 && O <= 1024 && A > 0, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_segment_store: row=%lld W=%lld O=%d A=%d", (long long)row,
                 (long long)W, O, A);
   StoreArgs a;
@@ -77,9 +91,9 @@ extern "C" int tonic_segment_store(float* d_seg_observations, float* d_seg_actio
   a.seg_lp = d_seg_log_probs; a.obs = d_observations; a.act = d_actions;
   a.next = d_next_observations; a.rew = d_rewards; a.rst = d_resets; a.term = d_terminations;
   a.lp = d_log_probs; a.norm_acc = d_norm_acc; a.row = row; a.W = W; a.O = O; a.A = A;
-  int64_t blocks = (W * O + 255) / 256 + 1;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(segment_store_kernel, dim3((unsigned)blocks), dim3(256), 0,
+  int64_t blocks = (W * (2 * O + A + 4) + 8 * kStoreThreads - 1) / (8 * kStoreThreads);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(segment_store_kernel, dim3((unsigned)blocks), dim3(kStoreThreads), 0,
                      as_stream(stream), a);
   TONIC_CHECK_LAUNCH("tonic_segment_store");
   return TONIC_OK;
