@@ -87,7 +87,7 @@ def kernel_rooflines(agent):
             p(wsc), wsc.numel(), stream), 'critic')
 
     out = {}
-    for waves in (4, 8):
+    for waves in (4,):
         _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
         ws = actor._workspace_for(n)
         wsc = critic._workspace_for(n)

@@ -50,7 +50,7 @@ int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
 /* Developer tuning knobs (process-wide; call before sizing workspaces).  Keys:
- *   "grad_waves" = 4 | 8   waves per workgroup of the fused forward+backward kernel. */
+ *   "grad_waves" = 4       waves per workgroup of the fused forward+backward kernel. */
 int tonic_set_tuning(const char* key, int32_t value);
 
 /* Sizes of the flat parameter blocks described above. */
@@ -170,6 +170,22 @@ int tonic_segment_store(float* d_seg_observations, float* d_seg_actions,
                         const float* d_resets, const float* d_terminations,
                         const float* d_log_probs, float* d_norm_acc, int64_t row, int64_t W,
                         int32_t O, int32_t A, void* stream);
+
+/* ---- fused on-policy collect step (device-resident collectors) ---------------------------------
+ * replaces: tonic/torch/agents/a2c.py:41-52 (A2C.step: forward + sample + log-prob) and
+ *   a2c.py:58-69 (Segment.store + MeanStd.record) for ONE environment step in ONE launch:
+ *   tonic_ppo_act + tonic_segment_store fused, actions / log-probs written straight into row
+ *   `row` of the Segment.  d_actions_out [W,A] (may be NULL) receives a copy of the actions for
+ *   the environment.  d_eps / d_norm_acc may be NULL as in the unfused calls.
+ */
+int tonic_ppo_collect_step(const float* d_actor_params, const float* d_observations,
+                           const float* d_eps, const float* d_next_observations,
+                           const float* d_rewards, const float* d_resets,
+                           const float* d_terminations, float* d_seg_observations,
+                           float* d_seg_actions, float* d_seg_next_observations,
+                           float* d_seg_rewards, float* d_seg_resets, float* d_seg_terminations,
+                           float* d_seg_log_probs, float* d_norm_acc, float* d_actions_out,
+                           int64_t row, int64_t W, int32_t O, int32_t A, void* stream);
 
 /* ---- target networks (SAC / TD3) ---------------------------------------------------------------
  * replaces: tonic/torch/models/actor_critics.py:126-130 (update_targets): per element

@@ -53,7 +53,7 @@ struct Lds {
   static constexpr int WAVE0 = (NORM + 4 * KS1 + 3) / 4 * 4;     // per-wave scratch
   static constexpr int T_FLOATS = 64 * TS;
   static constexpr int DO_FLOATS = 32 * 8;
-  static constexpr int WAVE_FLOATS = BWD ? (T_FLOATS + DO_FLOATS) : 0;
+  static constexpr int WAVE_FLOATS = BWD ? (2 * T_FLOATS + DO_FLOATS) : 0;
   static constexpr int TOTAL = WAVE0 + WAVES * WAVE_FLOATS;
   static constexpr int BYTES = TOTAL * 4;
 };
@@ -194,11 +194,21 @@ __device__ __forceinline__ void dense_tanh(const float* w_img, const float* bias
     acc0 = mfma32(a0, in[st], acc0);
     acc1 = mfma32(a1, in[st], acc1);
   }
+  // tanh in three batched sweeps (exp2, rcp, combine): 32 independent transcendental ops
+  // back to back instead of 32 dependent exp->rcp chains, so one wave per SIMD still has ILP.
+  float t[32];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    out[r] = tanh_fast(acc0[r]);
-    out[16 + r] = tanh_fast(acc1[r]);
+    out[r] = acc0[r];
+    out[16 + r] = acc1[r];
   }
+#pragma unroll
+  for (int r = 0; r < 32; ++r) t[r] = __builtin_amdgcn_exp2f(fabsf(out[r]) * -2.8853900817779268f);
+  float d[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) d[r] = __builtin_amdgcn_rcpf(1.f + t[r]);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) out[r] = copysignf((1.f - t[r]) * d[r], out[r]);
 }
 
 // S-layout register file -> per-wave scratch T[feature][sample].
@@ -288,6 +298,99 @@ __global__ __launch_bounds__(WAVES * 64) void ppo_act_kernel(MlpArgs a) {
   }
 }
 
+// One environment step of the on-policy collect loop in ONE launch (device-resident
+// collectors): a2c.py:41-52 (act: forward + sample + log-prob) + a2c.py:58-69 (Segment.store of
+// the whole transition + MeanStd.record).  Workgroups [0, act_blocks) run the policy on 32
+// observations per wave and write actions / log-probs / observations straight into row `row`
+// of the HBM-resident Segment; the LAST workgroup copies the transition outcome
+// (next observations, rewards, resets, terminations) and replays MeanStd.record's sequential
+// float32 accumulation from an LDS-staged copy of the observation block.
+struct CollectArgs {
+  MlpArgs act;                 // params, obs, eps, n = W, O, A; out0 = optional actions copy
+  const float* next_obs; const float* rewards; const float* resets; const float* terminations;
+  float* seg_obs; float* seg_act; float* seg_next; float* seg_rew; float* seg_rst;
+  float* seg_term; float* seg_lp;
+  float* norm_acc;
+  int64_t row;
+  int record_floats;           // LDS floats available to the record tile
+};
+
+template <int KS1, int AP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ppo_collect_kernel(CollectArgs c) {
+  using L = Lds<KS1, AP, false, WAVES>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MlpArgs& a = c.act;
+  const int64_t W = a.n;
+  const int O = a.O, A = a.A;
+  if (blockIdx.x == gridDim.x - 1) {
+    // ---- transition outcome + MeanStd.record (segments.py:27-36, mean_stds.py:44-48)
+    const int nth = WAVES * 64, tid = threadIdx.x;
+    for (int64_t i = tid; i < W * O; i += nth) c.seg_next[c.row * W * O + i] = c.next_obs[i];
+    for (int64_t i = tid; i < W; i += nth) {
+      c.seg_rew[c.row * W + i] = c.rewards[i];
+      c.seg_rst[c.row * W + i] = c.resets[i];
+      c.seg_term[c.row * W + i] = c.terminations[i];
+    }
+    if (c.norm_acc == nullptr) return;
+    float sum = 0.f, sum_sq = 0.f;
+    if (tid < O) { sum = c.norm_acc[tid]; sum_sq = c.norm_acc[O + tid]; }
+    const int64_t rows_per_chunk = c.record_floats / O;
+    for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
+      const int64_t rows = min(rows_per_chunk, W - w0);
+      __syncthreads();
+      for (int64_t i = tid; i < rows * O; i += nth) lds[i] = a.obs[w0 * O + i];
+      __syncthreads();
+      if (tid < O) {
+        for (int64_t w = 0; w < rows; ++w) {
+          const float v = lds[w * O + tid];
+          sum = sum + v;
+          const float sq = v * v;
+          sum_sq = sum_sq + sq;
+        }
+      }
+    }
+    if (tid < O) { c.norm_acc[tid] = sum; c.norm_acc[O + tid] = sum_sq; }
+    return;
+  }
+  stage_weights<KS1, AP, false, true, WAVES>(lds, a);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (W + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
+       tile += (int64_t)(gridDim.x - 1) * WAVES) {
+    const int64_t ns = tile * 32 + s;
+    const bool valid = ns < W;
+    float x[KS1], h1[32], h2[32], z[AP];
+    load_obs<KS1, false>(a, nullptr, ns, valid, h, x);
+    // this wave's 32 observation rows -> Segment row (contiguous block, coalesced)
+    {
+      const int64_t first = tile * 32 * O, count = min<int64_t>(32, W - tile * 32) * O;
+      for (int64_t i = lane; i < count; i += 64)
+        c.seg_obs[c.row * W * O + first + i] = a.obs[first + i];
+    }
+    dense_tanh<KS1>(lds + L::W1S, lds + L::B1P, x, h1, lane);
+    dense_tanh<32>(lds + L::W2S, lds + L::B2P, h1, h2, lane);
+    head_linear<AP, L::W3P, L::HC>(lds, h2, h, z);
+    float logp = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) {
+      if (aa < A) {
+        const float loc = tanh_fast(z[aa]);
+        const float sigma = lds[L::HC + aa * 4 + 1];
+        float act = loc;
+        if (a.eps != nullptr && valid) act = loc + sigma * a.eps[ns * A + aa];
+        const float d = act - loc;
+        logp += -(d * d) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
+        if (valid && h == 0) {
+          c.seg_act[(c.row * W + ns) * A + aa] = act;
+          if (a.out0 != nullptr) a.out0[ns * A + aa] = act;
+        }
+      }
+    }
+    if (valid && h == 0) c.seg_lp[c.row * W + ns] = logp;
+  }
+}
+
 // Critic forward: a2c.py:92-99.
 template <int KS1, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void value_forward_kernel(MlpArgs a) {
@@ -322,8 +425,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, h = lane >> 5;
   const int c = s, kh = h;   // names used when the lane acts in F layout
-  float* T = lds + L::WAVE0 + wave * L::WAVE_FLOATS;
-  float* DO = T + L::T_FLOATS;
+  float* TA = lds + L::WAVE0 + wave * L::WAVE_FLOATS;
+  float* TB = TA + L::T_FLOATS;
+  float* DO = TB + L::T_FLOATS;
   const int O = a.O, A = a.A;
 
   float adv_mean = 0.f, adv_std = 1.f;
@@ -346,14 +450,45 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
   for (int aa = 0; aa < AP; ++aa) { gW3[0][aa] = gW3[1][aa] = 0.f; gb3[aa] = 0.f; gsig[aa] = 0.f; }
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;   // loss, kl | sq err, v ; clipped ; n
 
-  const int64_t ntiles = (a.n + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
-       tile += (int64_t)gridDim.x * WAVES) {
+  // Per-sample inputs of one tile, loaded one iteration ahead so that the global-load latency
+  // hides under the previous tile's MFMA/VALU work (one wave per SIMD: nothing else would).
+  struct TileIn {
+    float x[KS1];
+    float act[AP];
+    float adv, old_lp, ret;
+    bool valid;
+  };
+  auto load_tile = [&](int64_t tile, TileIn& in) {
     const int64_t ns = tile * 32 + s;
-    const bool valid = ns < a.n;
+    in.valid = ns < a.n;
+    load_obs<KS1, !ACTOR>(a, lds + L::NORM, ns, in.valid, h, in.x);
+    in.adv = 0.f; in.old_lp = 0.f; in.ret = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) in.act[aa] = 0.f;
+    if (in.valid) {
+      if (ACTOR) {
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa)
+          if (aa < A) in.act[aa] = a.actions[ns * A + aa];
+        in.adv = a.adv[ns];
+        in.old_lp = a.old_logp[ns];
+      } else {
+        in.ret = a.returns[ns];
+      }
+    }
+  };
+
+  const int64_t ntiles = (a.n + 31) / 32;
+  const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  TileIn cur, nxt;
+  if (tile < ntiles) load_tile(tile, cur);
+  for (; tile < ntiles; tile += tile_stride) {
+    if (tile + tile_stride < ntiles) load_tile(tile + tile_stride, nxt);
+    const bool valid = cur.valid;
     const bool counted = valid && h == 0;
-    float x[KS1], h1[32], h2[32], z[AP], dzl[AP];
-    load_obs<KS1, !ACTOR>(a, lds + L::NORM, ns, valid, h, x);
+    float h1[32], h2[32], z[AP], dzl[AP];
+    float (&x)[KS1] = cur.x;
     dense_tanh<KS1>(lds + L::W1S, lds + L::B1P, x, h1, lane);
     dense_tanh<32>(lds + L::W2S, lds + L::B2P, h1, h2, lane);
     head_linear<AP, L::W3P, L::HC>(lds, h2, h, z);
@@ -366,13 +501,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
         loc[aa] = 0.f; dif[aa] = 0.f;
         if (aa < A) {
           loc[aa] = tanh_fast(z[aa]);
-          const float act = valid ? a.actions[ns * A + aa] : loc[aa];
+          const float act = valid ? cur.act[aa] : loc[aa];
           dif[aa] = act - loc[aa];
           logp += -(dif[aa] * dif[aa]) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
         }
       }
-      const float old_lp = valid ? a.old_logp[ns] : logp;
-      float adv = valid ? a.adv[ns] : 0.f;
+      const float old_lp = valid ? cur.old_lp : logp;
+      float adv = cur.adv;
       if (adv_norm) adv = (adv - adv_mean) / adv_std;             // segments.py:45
       const float ratio = expf(logp - old_lp);
       const float clipped_ratio = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
@@ -402,8 +537,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       }
     } else {
       // ---- MSE (updaters/critics.py:20-21): d/dv of (v - ret)^2, unscaled by 1/N
-      const float ret = valid ? a.returns[ns] : 0.f;
-      const float err = valid ? z[0] - ret : 0.f;
+      const float err = valid ? z[0] - cur.ret : 0.f;
       dzl[0] = 2.f * err;
       if (counted) {
         st0 += err * err;
@@ -413,8 +547,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       }
     }
 
-    // ---- dW3 (VALU, F layout): needs h2^T and the per-sample dz of the head
-    scatter_S(T, h2, s, h);
+    // ---- backward.  Two private LDS scratch tiles (TA, TB) so that every S->F transpose is
+    // in flight while an independent MFMA chain or VALU block runs.
+    scatter_S(TA, h2, s, h);                         // h2^T for dW3
     if (h == 0) {
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -424,27 +559,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       reinterpret_cast<f32x4*>(DO + s * 8)[0] = lo;
       if (AP > 4) reinterpret_cast<f32x4*>(DO + s * 8)[1] = hi;
     }
-    wave_lds_sync();
-    {
-      float hF[2][16];
-      gather_F(T, 0, c, kh, hF[0]);
-      gather_F(T, 1, c, kh, hF[1]);
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const f32x4 lo = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[0];
-        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
-        if (AP > 4) hi = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[1];
-#pragma unroll
-        for (int aa = 0; aa < AP; ++aa) {
-          const float d = aa < 4 ? lo[aa] : hi[aa - 4];
-          gW3[0][aa] = fmaf(hF[0][m], d, gW3[0][aa]);
-          gW3[1][aa] = fmaf(hF[1][m], d, gW3[1][aa]);
-        }
-      }
-    }
-    wave_lds_sync();
-
-    // ---- dz2 = (dzl . W3) * tanh'(h2)   (in place of h2)
+    // dz2 = (dzl . W3) * tanh'(h2), in place of h2 (its LDS copy is already issued)
     {
       const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
 #pragma unroll
@@ -464,41 +579,62 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       }
     }
     float (&dz2)[32] = h2;
+    scatter_S(TB, dz2, s, h);                        // dz2^T for dW2 / db2
+    wave_lds_sync();
 
-    // ---- dh1 = dz2 . W2 (transposed MFMA, stays in S layout); dz1 = dh1 * tanh'(h1)
-    float dz1[32];
-    {
-      f32x16 acc0, acc1;
+    // dh1 = dz2 . W2 (transposed MFMA, stays in S layout) — covers the two transposes above
+    f32x16 dacc0, dacc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { dacc0[r] = 0.f; dacc1[r] = 0.f; }
+    {
       const float* w2b = lds + L::W2B;
 #pragma unroll
       for (int st = 0; st < 32; ++st) {
-        acc0 = mfma32(w2b[st * 64 + lane], dz2[st], acc0);
-        acc1 = mfma32(w2b[(32 + st) * 64 + lane], dz2[st], acc1);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dz1[r] = acc0[r] * (1.f - h1[r] * h1[r]);
-        dz1[16 + r] = acc1[r] * (1.f - h1[16 + r] * h1[16 + r]);
+        dacc0 = mfma32(w2b[st * 64 + lane], dz2[st], dacc0);
+        dacc1 = mfma32(w2b[(32 + st) * 64 + lane], dz2[st], dacc1);
       }
     }
 
-    // ---- dW2[out][in] += dz2^T . h1 over the tile's 32 samples (MFMA, F-layout operands)
+    // dW3 (VALU, F layout) from TA / DO while the dh1 chain drains
     {
-      float aF[2][16], bF[2][16];
-      scatter_S(T, dz2, s, h);
-      wave_lds_sync();
-      gather_F(T, 0, c, kh, aF[0]);
-      gather_F(T, 1, c, kh, aF[1]);
-      wave_lds_sync();
+      float hF[2][16];
+      gather_F(TA, 0, c, kh, hF[0]);
+      gather_F(TA, 1, c, kh, hF[1]);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) { gb2[0] += aF[0][m]; gb2[1] += aF[1][m]; }
-      scatter_S(T, h1, s, h);
-      wave_lds_sync();
-      gather_F(T, 0, c, kh, bF[0]);
-      gather_F(T, 1, c, kh, bF[1]);
-      wave_lds_sync();
+      for (int m = 0; m < 16; ++m) {
+        const f32x4 lo = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[0];
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        if (AP > 4) hi = reinterpret_cast<const f32x4*>(DO + (16 * kh + m) * 8)[1];
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          const float d = aa < 4 ? lo[aa] : hi[aa - 4];
+          gW3[0][aa] = fmaf(hF[0][m], d, gW3[0][aa]);
+          gW3[1][aa] = fmaf(hF[1][m], d, gW3[1][aa]);
+        }
+      }
+    }
+    float aF[2][16];
+    gather_F(TB, 0, c, kh, aF[0]);
+    gather_F(TB, 1, c, kh, aF[1]);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { gb2[0] += aF[0][m]; gb2[1] += aF[1][m]; }
+
+    float dz1[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dz1[r] = dacc0[r] * (1.f - h1[r] * h1[r]);
+      dz1[16 + r] = dacc1[r] * (1.f - h1[16 + r] * h1[16 + r]);
+    }
+    wave_lds_sync();                                 // TA / TB reads done
+    scatter_S(TA, h1, s, h);
+    scatter_S(TB, dz1, s, h);
+    wave_lds_sync();
+
+    // dW2[out][in] += dz2^T . h1 over the tile's 32 samples (MFMA, F-layout operands)
+    {
+      float bF[2][16];
+      gather_F(TA, 0, c, kh, bF[0]);
+      gather_F(TA, 1, c, kh, bF[1]);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         gW2[0][0] = mfma32(aF[0][m], bF[0][m], gW2[0][0]);
@@ -508,28 +644,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       }
     }
 
-    // ---- dW1[out][in] += dz1^T . x
+    // dW1[out][in] += dz1^T . x
     {
-      float aF[2][16], xF[16];
-      scatter_S(T, dz1, s, h);
-      wave_lds_sync();
-      gather_F(T, 0, c, kh, aF[0]);
-      gather_F(T, 1, c, kh, aF[1]);
-      wave_lds_sync();
+      float cF[2][16], xF[16];
+      gather_F(TB, 0, c, kh, cF[0]);
+      gather_F(TB, 1, c, kh, cF[1]);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) { gb1[0] += aF[0][m]; gb1[1] += aF[1][m]; }
+      for (int m = 0; m < 16; ++m) { gb1[0] += cF[0][m]; gb1[1] += cF[1][m]; }
+      wave_lds_sync();                               // h1^T (TA) has been read
 #pragma unroll
-      for (int st = 0; st < KS1; ++st) T[(2 * st + h) * TS + s] = x[st];
+      for (int st = 0; st < KS1; ++st) TA[(2 * st + h) * TS + s] = x[st];
       wave_lds_sync();
-      gather_F(T, 0, c, kh, xF);
-      wave_lds_sync();
+      gather_F(TA, 0, c, kh, xF);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const float xv = c < 2 * KS1 ? xF[m] : 0.f;     // rows >= 2*KS1 hold stale data
-        gW1[0] = mfma32(aF[0][m], xv, gW1[0]);
-        gW1[1] = mfma32(aF[1][m], xv, gW1[1]);
+        gW1[0] = mfma32(cF[0][m], xv, gW1[0]);
+        gW1[1] = mfma32(cF[1][m], xv, gW1[1]);
       }
+      wave_lds_sync();                               // before the next tile rewrites TA / TB
     }
+    cur = nxt;
   }
 
   // ---------------- fold the waves' accumulators into one image G (flat parameter layout)
@@ -648,8 +783,8 @@ namespace {
 
 constexpr int kFwdWaves = 4;
 constexpr int kMaxGradBlocks = 256;   // one workgroup per CU
-// Waves per workgroup of the fused grad kernel: 4 = one wave per SIMD with the whole
-// 512-register file (no spills), 8 = two waves per SIMD at 256 registers (spills today).
+// Waves per workgroup of the fused grad kernel: one wave per SIMD with the whole 512-register
+// file (a two-waves-per-SIMD build spilled >100 registers and measured no faster).
 int g_grad_waves = 4;
 
 int ks1_bucket(int O) {
@@ -709,9 +844,6 @@ int launch_value(int blocks, hipStream_t st, const MlpArgs& a) {
 template <int KS1, int AP, bool ACTOR>
 int launch_grad(int blocks, hipStream_t st, const MlpArgs& a) {
   const char* what = ACTOR ? "tonic_ppo_actor_grad" : "tonic_value_regression_grad";
-  if (g_grad_waves == 8)
-    return launch(mlp64_grad_kernel<KS1, AP, ACTOR, 8>, blocks, 512,
-                  Lds<KS1, AP, true, 8>::BYTES, st, a, what);
   return launch(mlp64_grad_kernel<KS1, AP, ACTOR, 4>, blocks, 256,
                 Lds<KS1, AP, true, 4>::BYTES, st, a, what);
 }
@@ -736,8 +868,8 @@ using namespace tonic;
 extern "C" int tonic_set_tuning(const char* key, int32_t value) {
   TONIC_REQUIRE(key != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_set_tuning: null key");
   if (strcmp(key, "grad_waves") == 0) {
-    TONIC_REQUIRE(value == 4 || value == 8, TONIC_ERR_INVALID_ARGUMENT,
-                  "grad_waves must be 4 or 8, got %d", value);
+    TONIC_REQUIRE(value == 4, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_waves must be 4 (the only variant built), got %d", value);
     g_grad_waves = value;
     return TONIC_OK;
   }
@@ -782,6 +914,68 @@ extern "C" int tonic_ppo_act(const float* d_actor_params, const float* d_observa
     if (ap == 1) return launch_act<KS1, 1>(blocks, st, a);
     if (ap == 6) return launch_act<KS1, 6>(blocks, st, a);
     return launch_act<KS1, 8>(blocks, st, a);
+  });
+}
+
+extern "C" int tonic_ppo_collect_step(
+    const float* d_actor_params, const float* d_observations, const float* d_eps,
+    const float* d_next_observations, const float* d_rewards, const float* d_resets,
+    const float* d_terminations, float* d_seg_observations, float* d_seg_actions,
+    float* d_seg_next_observations, float* d_seg_rewards, float* d_seg_resets,
+    float* d_seg_terminations, float* d_seg_log_probs, float* d_norm_acc, float* d_actions_out,
+    int64_t row, int64_t W, int32_t O, int32_t A, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_next_observations && d_rewards &&
+                    d_resets && d_terminations && d_seg_observations && d_seg_actions &&
+                    d_seg_next_observations && d_seg_rewards && d_seg_resets &&
+                    d_seg_terminations && d_seg_log_probs,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_collect_step: null pointer");
+  TONIC_REQUIRE(row >= 0 && W > 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_ppo_collect_step: row=%lld W=%lld", (long long)row, (long long)W);
+  if (int rc = check_shape(O, A, true)) return rc;
+  CollectArgs c{};
+  c.act.params = d_actor_params; c.act.obs = d_observations; c.act.eps = d_eps;
+  c.act.out0 = d_actions_out; c.act.n = W; c.act.O = O; c.act.A = A;
+  c.next_obs = d_next_observations; c.rewards = d_rewards; c.resets = d_resets;
+  c.terminations = d_terminations; c.seg_obs = d_seg_observations; c.seg_act = d_seg_actions;
+  c.seg_next = d_seg_next_observations; c.seg_rew = d_seg_rewards; c.seg_rst = d_seg_resets;
+  c.seg_term = d_seg_terminations; c.seg_lp = d_seg_log_probs; c.norm_acc = d_norm_acc;
+  c.row = row;
+  const int64_t tiles = (W + 31) / 32;
+  int act_blocks = (int)((tiles + kFwdWaves - 1) / kFwdWaves);
+  if (act_blocks > 1024) act_blocks = 1024;
+  const int ap = ap_bucket(A);
+  hipStream_t st = as_stream(stream);
+  return dispatch_ks1(ks1_bucket(O), [&](auto ks) -> int {
+    constexpr int KS1 = decltype(ks)::value;
+    auto go = [&](auto kernel, int act_lds) -> int {
+      const int lds_bytes = act_lds > 65536 ? act_lds : 65536;
+      c.record_floats = lds_bytes / 4;
+      static thread_local const void* configured[16];
+      static thread_local int n_configured = 0;
+      const void* fn = reinterpret_cast<const void*>(kernel);
+      bool known = false;
+      for (int i = 0; i < n_configured; ++i) known |= configured[i] == fn;
+      if (!known) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) {
+          set_error("tonic_ppo_collect_step: hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return (int)TONIC_ERR_LAUNCH;
+        }
+        if (n_configured < 16) configured[n_configured++] = fn;
+      }
+      hipLaunchKernelGGL(kernel, dim3(act_blocks + 1), dim3(kFwdWaves * 64), lds_bytes, st, c);
+      {
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+          set_error("tonic_ppo_collect_step: %s", hipGetErrorString(e2));
+          return (int)TONIC_ERR_LAUNCH;
+        }
+      }
+      return (int)TONIC_OK;
+    };
+    if (ap == 1) return go(ppo_collect_kernel<KS1, 1, kFwdWaves>, Lds<KS1, 1, false, kFwdWaves>::BYTES);
+    if (ap == 6) return go(ppo_collect_kernel<KS1, 6, kFwdWaves>, Lds<KS1, 6, false, kFwdWaves>::BYTES);
+    return go(ppo_collect_kernel<KS1, 8, kFwdWaves>, Lds<KS1, 8, false, kFwdWaves>::BYTES);
   });
 }
 

@@ -2,9 +2,10 @@
 already in HBM (the benchmark contract's "inputs resident in HBM when the timed region
 starts").  Observations, transition outcomes and the action noise of a whole Segment
 (T time steps x W workers) are pre-generated on the device; ``collect`` then issues, per
-environment step, exactly what ``PPO.step`` + ``PPO.update`` issue — one ``tonic_ppo_act``
-and one ``tonic_segment_store`` (with the normaliser record) — but without the host in the
-loop.  The per-step launches are kept (one act per time step on W observations) because in
+environment step, exactly what ``PPO.step`` + ``PPO.update`` issue — policy forward + sample, Segment store and normaliser record — as ONE fused
+``tonic_ppo_collect_step`` launch per environment step (``fused=False``: the separate
+``tonic_ppo_act`` + ``tonic_segment_store`` launches the host-in-the-loop agent uses), without
+the host in the loop.  The per-step launches are kept (one act per time step on W observations) because in
 a real environment step t+1's observations depend on step t's actions.
 
 ``capture=True`` records the T-step sequence once into a hipGraph (via
@@ -17,7 +18,8 @@ from tonic_amd import _lib
 
 
 class DeviceRollout:
-    def __init__(self, agent, workers, steps, seed=0, reset_probability=1e-3):
+    def __init__(self, agent, workers, steps, seed=0, reset_probability=1e-3, fused=True):
+        self.fused = fused
         self.agent = agent
         self.lib = _lib.load()
         device = agent.device
@@ -45,24 +47,37 @@ class DeviceRollout:
         sums = norm.device_sums if norm is not None else None
         stream = _lib.current_stream()
         actor = p(agent.model.flat_actor.flat)
+        O, A = agent.observation_size, agent.action_size
         for t in range(self.T):
+            if self.fused:
+                _lib.check(lib.tonic_ppo_collect_step(
+                    actor, p(self.observations[t]), p(self.eps[t]), p(self.observations[t + 1]),
+                    p(self.rewards[t]), p(self.resets[t]), p(self.terminations[t]),
+                    p(b['observations']), p(b['actions']), p(b['next_observations']),
+                    p(b['rewards']), p(b['resets']), p(b['terminations']), p(b['log_probs']),
+                    p(sums), None, t, self.W, O, A, stream), 'tonic_ppo_collect_step')
+                continue
             _lib.check(lib.tonic_ppo_act(
                 actor, p(self.observations[t]), p(self.eps[t]), p(self.actions),
-                p(self.log_probs), self.W, agent.observation_size, agent.action_size, stream),
-                'tonic_ppo_act')
+                p(self.log_probs), self.W, O, A, stream), 'tonic_ppo_act')
             _lib.check(lib.tonic_segment_store(
                 p(b['observations']), p(b['actions']), p(b['next_observations']),
                 p(b['rewards']), p(b['resets']), p(b['terminations']), p(b['log_probs']),
                 p(self.observations[t]), p(self.actions), p(self.observations[t + 1]),
                 p(self.rewards[t]), p(self.resets[t]), p(self.terminations[t]),
-                p(self.log_probs), p(sums), t, self.W, agent.observation_size,
-                agent.action_size, stream), 'tonic_segment_store')
+                p(self.log_probs), p(sums), t, self.W, O, A, stream), 'tonic_segment_store')
 
     def collect(self, capture=False):
         """Fills the agent's Segment with T steps (asynchronous; no host sync)."""
         if capture:
             if self.graph is None:
-                self._enqueue()                       # warm-up: allocations, LDS opt-ins
+                # Warm-up outside the capture (buffer allocation, LDS opt-ins).  It runs the
+                # rollout once, so undo its only cumulative side effect — the normaliser sums.
+                norm = self.agent.model.observation_normalizer
+                saved = norm.device_sums.clone() if norm is not None else None
+                self._enqueue()
+                if saved is not None:
+                    norm.device_sums.copy_(saved)
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
