@@ -142,7 +142,8 @@ int tonic_value_regression_grad(const float* d_critic_params, const float* d_nor
  *   flat parameter block: grad = d_grad_sums[i] * grad_scale (grad_scale = 1/N_global).
  * d_state: int32[4] = {step_count, stop_flag, reserved, reserved}; step_count is
  *   incremented on the device so the call is graph-replayable.
- * PPO extras (pass stats_kind = 1 for the actor, 2 for the critic, 0 for none): finalises
+ * Statistic extras (stats_kind: 0 none, 1 PPO actor, 2 V critic, 3 twin Q critics
+ *   {loss, q1 mean, q2 mean}, 4 Q-gradient actor {loss}): finalises
  *   the 8 statistic sums into d_info_row[8] and, for the actor, sets stop_flag when
  *   kl > kl_threshold (actors.py:102-112).  Actor rows: {loss, kl, entropy, clip_fraction,
  *   std, stop, ran(1.0), 0}; critic rows: {loss, v_mean, ...}.  When d_adv_stats says every
@@ -193,6 +194,80 @@ int tonic_ppo_collect_step(const float* d_actor_params, const float* d_observati
  */
 int tonic_polyak_update(float* d_target, const float* d_online, int64_t n, double coeff,
                         void* stream);
+
+/* ======================= off-policy path: SAC / TD3 (2 hidden ReLU layers of width H) =========
+ * Flat parameter blocks (reference `parameters()` order):
+ *   deterministic actor (TD3): W1[H,O] b1[H] W2[H,H] b2[H] Wa[A,H] ba[A]              (heads = 1)
+ *   Gaussian actor (SAC)     : W1 b1 W2 b2 Wloc[A,H] bloc[A] Wscale[A,H] bscale[A]    (heads = 2)
+ *   Q critic                 : W1[H,O+A] b1[H] W2[H,H] b2[H] w3[1,H] b3[1]
+ *   twin critics             : [critic_1 | critic_2] contiguous (one Adam over both, as
+ *                              tonic/torch/updaters/critics.py:148-153,195-200 build it).
+ * All scratch comes from ONE caller-provided workspace (tonic_offpolicy_workspace_bytes).
+ */
+int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);
+int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads);
+int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H);
+
+/* replaces: tonic/replays/buffers.py:33-56 (Buffer.store: one row of the circular buffers incl.
+ *   discounts = float32(1 - terminations) * discount_factor) + mean_stds.py:44-48 (record). */
+int tonic_buffer_store(float* d_buf_observations, float* d_buf_actions,
+                       float* d_buf_next_observations, float* d_buf_rewards, float* d_buf_resets,
+                       float* d_buf_terminations, float* d_buf_discounts,
+                       const float* d_observations, const float* d_actions,
+                       const float* d_next_observations, const float* d_rewards,
+                       const float* d_resets, const float* d_terminations, float* d_norm_acc,
+                       int64_t row, int64_t W, int32_t O, int32_t A, double discount_factor,
+                       void* stream);
+
+/* replaces: tonic/replays/buffers.py:84-91 (Buffer.get: rows = idx // W, cols = idx % W, fancy-
+ *   index gather of 5 keys).  d_indices: int64[B] drawn by the host RandomState (bit-exact
+ *   stream); one wavefront copies one sampled transition. */
+int tonic_buffer_gather(const int64_t* d_indices, const float* d_buf_observations,
+                        const float* d_buf_actions, const float* d_buf_next_observations,
+                        const float* d_buf_rewards, const float* d_buf_discounts,
+                        float* d_observations, float* d_actions, float* d_next_observations,
+                        float* d_rewards, float* d_discounts, int64_t W, int32_t B, int32_t O,
+                        int32_t A, void* stream);
+
+/* replaces: DDPG._greedy_actions (tonic/torch/agents/ddpg.py:78-81; kind 0 = tanh head,
+ *   models/actors.py:113-115) and SAC._stochastic_actions / _greedy_actions
+ *   (tonic/torch/agents/sac.py:40-51; kind 1 = tanh(loc + sigma * eps), eps NULL -> tanh(loc)). */
+int tonic_policy_forward(const float* d_actor_params, const float* d_observations,
+                         const float* d_eps, float* d_actions, int32_t kind, int32_t B, int32_t O,
+                         int32_t H, int32_t A, void* d_workspace, int64_t workspace_bytes,
+                         void* stream);
+
+/* replaces: kind 0 TwinCriticDeterministicQLearning.__call__ (tonic/torch/updaters/
+ *   critics.py:156-175, TargetActionNoise :125-134; d_policy_params = TARGET actor),
+ *   kind 1 TwinCriticSoftQLearning.__call__ (critics.py:202-227; d_policy_params = ONLINE
+ *   actor, quirk Q9).  d_eps [B,A]: host-drawn standard normals (torch CPU generator order).
+ *   Output: gradient SUMS over the batch for [critic_1 | critic_2] + 8 statistics
+ *   {sq_err_sum (both critics), q1_sum, q2_sum, 0, 0, B, 0, 0}; follow with
+ *   tonic_adam_step(grad_scale = 1/B). */
+int tonic_twin_q_grad(int32_t kind, const float* d_policy_params, const float* d_target_critics,
+                      const float* d_critics, const float* d_norm_mean, const float* d_norm_std,
+                      const float* d_observations, const float* d_actions,
+                      const float* d_next_observations, const float* d_rewards,
+                      const float* d_discounts, const float* d_eps, float* d_grad_sums, int32_t B,
+                      int32_t O, int32_t H, int32_t A, double entropy_coeff, double noise_scale,
+                      double noise_clip, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* replaces: kind 0 DeterministicPolicyGradient.__call__ on critic_1 (tonic/torch/updaters/
+ *   actors.py:170-189, td3.py:36), kind 1 TwinCriticSoftDeterministicPolicyGradient.__call__
+ *   (actors.py:238-267).  Critics are frozen (no weight gradients).  Output: gradient SUMS for
+ *   the actor + 8 statistics {loss_sum, 0, 0, 0, 0, B, 0, 0}. */
+int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d_critics,
+                       const float* d_norm_mean, const float* d_norm_std,
+                       const float* d_observations, const float* d_eps, float* d_grad_sums,
+                       int32_t B, int32_t O, int32_t H, int32_t A, double entropy_coeff,
+                       void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* Developer / test entry: one GEMM of the small-batch fp32 MFMA building block
+ * (mode "NT" | "NN" | "TN"; act 0 none, 1 relu, 2 tanh; d_mask multiplies by (mask > 0)). */
+int tonic_gemm_f32(const char* mode, const float* d_a, const float* d_b, float* d_c,
+                   const float* d_bias, const float* d_mask, float* d_colsum, int32_t M,
+                   int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t act,
+                   int32_t accumulate, double alpha, void* stream);
 
 #ifdef __cplusplus
 }

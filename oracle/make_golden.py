@@ -303,6 +303,114 @@ def first_update_probes(tonic, builder, seed, seg, iterations):
     return out
 
 
+def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32, batch=24,
+                  iterations=6, seed=0, loop_steps=16):
+    """tonic/torch/agents/{ddpg.py:45-112, td3.py:38-55, sac.py:40-51} driven through the
+    reference agent on a synthetic env (small custom torso so the fixture stays small).  The
+    first learner update is captured completely: buffer contents, the index stream of
+    Buffer.get, the standard-normal draws of the updaters (regenerated from the saved torch
+    generator state and checked), per-iteration infos, parameters before / after."""
+    models, updaters = tonic.torch.models, tonic.torch.updaters
+    relu = torch.nn.ReLU
+
+    def builder():
+        return rl.SyntheticEnvironment(obs_dim, act_dim, max_episode_steps=5)
+    env = tonic.environments.distribute(builder, 1, workers)
+    env.initialize(seed=seed)
+    critic = models.Critic(encoder=models.ObservationActionEncoder(),
+                           torso=models.MLP((hidden, hidden), relu), head=models.ValueHead())
+    if kind == 'sac':
+        head = models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
+                                         distribution=models.SquashedMultivariateNormalDiag)
+    else:
+        head = models.DeterministicPolicyHead()
+    model = models.ActorTwinCriticWithTargets(
+        actor=models.Actor(encoder=models.ObservationEncoder(),
+                           torso=models.MLP((hidden, hidden), relu), head=head),
+        critic=critic, observation_normalizer=tonic.torch.normalizers.MeanStd())
+    replay = tonic.replays.Buffer(size=400, batch_iterations=iterations, batch_size=batch,
+                                  steps_before_batches=workers * 10, steps_between_batches=workers * 10)
+    if kind == 'sac':
+        agent = tonic.torch.agents.SAC(
+            model=model, replay=replay,
+            exploration=tonic.explorations.NoActionNoise(start_steps=workers * 5))
+    else:
+        agent = tonic.torch.agents.TD3(
+            model=model, replay=replay,
+            exploration=tonic.explorations.NormalActionNoise(start_steps=workers * 5))
+    agent.initialize(env.observation_space, env.action_space, seed=seed)
+    out = state_arrays('init/', agent.model.state_dict())
+    recorder = RecordingLogger()
+    tonic.logger.current_logger = recorder
+    rng = np.random.RandomState(seed + 1)
+    observations = env.start()
+    obs_all, act_all, policy_eps = [], [], []
+    captured = {}
+    original_update = agent._update
+
+    def capturing_update(steps):
+        if not captured:
+            captured['torch_state'] = torch.get_rng_state()
+            captured['np_state'] = agent.replay.np_random.get_state()
+            captured['size'] = agent.replay.size
+            captured['buffers'] = {k: v.copy() for k, v in agent.replay.buffers.items()}
+            captured['pre'] = state_arrays('pre/', agent.model.state_dict())
+            original_update(steps)
+            captured['post'] = state_arrays('post/', agent.model.state_dict())
+            captured['infos'] = {k: np.array(v) for k, v in recorder.records.items()}
+        else:
+            original_update(steps)
+    agent._update = capturing_update
+    for t in range(loop_steps):
+        gen_state = torch.get_rng_state()
+        actions = agent.step(observations, t * workers)
+        after = torch.get_rng_state()
+        torch.set_rng_state(gen_state)
+        policy_eps.append(torch.randn(workers, act_dim).numpy())      # consumed only by SAC policy
+        torch.set_rng_state(after)
+        obs_all.append(observations.copy())
+        act_all.append(np.array(actions, np.float64))
+        observations, infos = env.step(actions)
+        infos['rewards'] = (infos['rewards'] + rng.normal(size=workers)).astype(np.float32)
+        term = rng.uniform(size=workers) < 0.1
+        infos['terminations'] = term
+        infos['resets'] = infos['resets'] | term
+        agent.update(**infos, steps=t * workers)
+    assert captured, 'the learner update never ran'
+    # regenerate the index stream and the updaters' normal draws, then verify them by replaying
+    # the reference updaters on a fresh agent (see the consistency check below)
+    index_rng = np.random.RandomState()
+    index_rng.set_state(captured['np_state'])
+    indices = np.array([index_rng.randint(captured['size'] * workers, size=batch)
+                        for _ in range(iterations)])
+    saved = torch.get_rng_state()
+    torch.set_rng_state(captured['torch_state'])
+    draws = 2 if kind == 'sac' else 1
+    eps = np.array([[torch.randn(batch, act_dim).numpy() for _ in range(draws)]
+                    for _ in range(iterations)])
+    torch.set_rng_state(saved)
+    out.update(captured['pre'])
+    out.update(captured['post'])
+    for k, v in captured['buffers'].items():
+        out['buffer/' + k] = v
+    for k, v in captured['infos'].items():
+        if v.ndim == 2:
+            out['info/' + k + '_mean'] = v.mean(axis=1)
+        else:
+            out['info/' + k] = v
+    out['indices'] = indices
+    out['eps'] = eps
+    out['act/observations'] = np.array(obs_all)
+    out['act/actions'] = np.array(act_all)
+    out['act/policy_eps'] = np.array(policy_eps)
+    out['buffer_size'] = np.int64(captured['size'])
+    out['cfg'] = np.array([obs_dim, act_dim, workers, hidden, batch, iterations, seed,
+                           loop_steps], np.int64)
+    save(name, source='tonic/torch/agents/ddpg.py:45-112; td3.py:38-55; sac.py:40-51; '
+                      'updaters/critics.py:125-235; updaters/actors.py:159-267; '
+                      'replays/buffers.py:28-91', **out)
+
+
 def main():
     torch.set_num_threads(1)
     tonic = rl.load_reference()
@@ -318,6 +426,8 @@ def main():
     # cfg-5 shapes (AntBullet O=28, A=8), larger rewards so the KL stop triggers.
     run_ppo(tonic, 'ppo_antbullet_small', 28, 8, workers=16, steps=24, seed=2,
             reward_scale=5.0, updates=1)
+    run_offpolicy(tonic, 'sac_small', 'sac')
+    run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
 
 
 if __name__ == '__main__':

@@ -129,3 +129,134 @@ class TorchPPO:
         mean, std = self.normalizer.update()
         self.norm_mean, self.norm_std = torch.as_tensor(mean), torch.as_tensor(std)
         return infos
+
+
+# ------------------------------------------------------------------- off-policy (SAC / TD3)
+
+ACTOR_KEYS = {'sac': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
+                      'torso.model.2.bias', 'head.loc_layer.0.weight', 'head.loc_layer.0.bias',
+                      'head.scale_layer.0.weight', 'head.scale_layer.0.bias'),
+              'td3': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
+                      'torso.model.2.bias', 'head.action_layer.0.weight',
+                      'head.action_layer.0.bias')}
+CRITIC_KEYS = ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
+               'torso.model.2.bias', 'head.v_layer.weight', 'head.v_layer.bias')
+
+
+class OffPolicyPort:
+    """SAC / TD3 learner restated with torch-CPU autograd:
+    ``tonic/torch/updaters/critics.py:125-134,156-182,202-235``,
+    ``tonic/torch/updaters/actors.py:170-189,238-267``,
+    ``tonic/torch/models/actors.py:7-34,94-98,113-115``, ``models/encoders.py:28-31``,
+    ``models/actor_critics.py:126-130`` (polyak), ``tonic/replays/buffers.py:84-91`` (gather)
+    and the iteration schedule of ``agents/ddpg.py:105-112`` / ``td3.py:38-47``."""
+
+    def __init__(self, kind, state, prefix, delay_steps=2, entropy_coeff=0.2, target_coeff=0.005):
+        self.kind, self.delay, self.alpha, self.tau = kind, delay_steps, entropy_coeff, target_coeff
+
+        def grab(net, keys, grad):
+            return [torch.tensor(state[f'{prefix}{net}.{k}'], requires_grad=grad) for k in keys]
+        self.actor = grab('actor', ACTOR_KEYS[kind], True)
+        self.critics = [grab('critic_1', CRITIC_KEYS, True), grab('critic_2', CRITIC_KEYS, True)]
+        self.target_actor = grab('target_actor', ACTOR_KEYS[kind], False)
+        self.target_critics = [grab('target_critic_1', CRITIC_KEYS, False),
+                               grab('target_critic_2', CRITIC_KEYS, False)]
+        self.mean = torch.tensor(state[prefix + 'observation_normalizer._mean'])
+        self.std = torch.tensor(state[prefix + 'observation_normalizer._std'])
+        lr_actor, lr_critic = (3e-4, 3e-4) if kind == 'sac' else (1e-3, 1e-3)
+        self.actor_opt = torch.optim.Adam(self.actor, lr=lr_actor)
+        self.critic_opt = torch.optim.Adam(self.critics[0] + self.critics[1], lr=lr_critic)
+
+    @staticmethod
+    def torso(p, x):
+        h = torch.relu(torch.nn.functional.linear(x, p[0], p[1]))
+        return torch.relu(torch.nn.functional.linear(h, p[2], p[3]))
+
+    def q(self, p, observations, actions):
+        x = torch.cat([(observations - self.mean) / self.std, actions], dim=-1)
+        return torch.nn.functional.linear(self.torso(p, x), p[4], p[5]).squeeze(-1)
+
+    def policy(self, p, observations, eps):
+        """Returns (actions, log_probs) — log_probs None for the deterministic head."""
+        h = self.torso(p, observations)
+        if self.kind == 'td3':
+            return torch.tanh(torch.nn.functional.linear(h, p[4], p[5])), None
+        loc = torch.nn.functional.linear(h, p[4], p[5])
+        scale = torch.clamp(torch.nn.functional.softplus(
+            torch.nn.functional.linear(h, p[6], p[7])), 1e-4, 1)
+        raw = loc + eps * scale
+        normal = torch.distributions.normal.Normal(loc, scale)
+        squashed = torch.tanh(raw)
+        log_probs = normal.log_prob(raw) - torch.log(1 - squashed ** 2 + 1e-6)
+        return squashed, log_probs.sum(dim=-1)
+
+    def critic_step(self, b, eps):
+        with torch.no_grad():
+            if self.kind == 'td3':
+                next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
+                noise = torch.clamp(0.2 * eps, -0.5, 0.5)
+                next_actions = torch.clamp(next_actions + noise, -1, 1)
+                bonus = 0
+            else:
+                next_actions, next_lp = self.policy(self.actor, b['next_observations'], eps)
+                bonus = -self.alpha * next_lp
+            next_q = torch.min(self.q(self.target_critics[0], b['next_observations'], next_actions),
+                               self.q(self.target_critics[1], b['next_observations'], next_actions))
+            returns = b['rewards'] + b['discounts'] * (next_q + bonus)
+        self.critic_opt.zero_grad()
+        q1 = self.q(self.critics[0], b['observations'], b['actions'])
+        q2 = self.q(self.critics[1], b['observations'], b['actions'])
+        loss = torch.nn.functional.mse_loss(q1, returns) + torch.nn.functional.mse_loss(q2, returns)
+        loss.backward()
+        self.critic_opt.step()
+        return dict(loss=float(loss), q1=float(q1.mean()), q2=float(q2.mean()))
+
+    def actor_step(self, b, eps):
+        self.actor_opt.zero_grad()
+        actions, lp = self.policy(self.actor, b['observations'], eps)
+        if self.kind == 'td3':
+            loss = -self.q(self.critics[0], b['observations'], actions).mean()
+        else:
+            q = torch.min(self.q(self.critics[0], b['observations'], actions),
+                          self.q(self.critics[1], b['observations'], actions))
+            loss = (self.alpha * lp - q).mean()
+        loss.backward()
+        self.actor_opt.step()
+        for p in self.critics[0] + self.critics[1]:
+            p.grad = None
+        return dict(loss=float(loss))
+
+    def update_targets(self):
+        online = self.actor + self.critics[0] + self.critics[1]
+        target = self.target_actor + self.target_critics[0] + self.target_critics[1]
+        with torch.no_grad():
+            for o, t in zip(online, target):
+                t.mul_(1 - self.tau)
+                t.add_(self.tau * o)
+
+    def update(self, buffers, workers, indices, eps):
+        """indices [iterations, B]; eps [iterations, draws, B, A] (draw 0 = critic step)."""
+        infos = []
+        for it in range(indices.shape[0]):
+            rows, cols = indices[it] // workers, indices[it] % workers
+            b = {k: torch.as_tensor(buffers[k][rows, cols]) for k in (
+                'observations', 'actions', 'next_observations', 'rewards', 'discounts')}
+            info = dict(critic=self.critic_step(b, torch.as_tensor(eps[it, 0])))
+            if self.kind == 'sac' or (it + 1) % self.delay == 0:
+                actor_eps = torch.as_tensor(eps[it, 1]) if self.kind == 'sac' else None
+                info['actor'] = self.actor_step(b, actor_eps)
+                self.update_targets()
+            infos.append(info)
+        return infos
+
+    def state(self):
+        out = {}
+        for net, params, keys in (
+                ('actor', self.actor, ACTOR_KEYS[self.kind]),
+                ('critic_1', self.critics[0], CRITIC_KEYS), ('critic_2', self.critics[1], CRITIC_KEYS),
+                ('target_actor', self.target_actor, ACTOR_KEYS[self.kind]),
+                ('target_critic_1', self.target_critics[0], CRITIC_KEYS),
+                ('target_critic_2', self.target_critics[1], CRITIC_KEYS)):
+            for k, p in zip(keys, params):
+                out[f'{net}.{k}'] = p.detach().numpy()
+        return out

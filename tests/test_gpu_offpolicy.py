@@ -1,0 +1,176 @@
+"""GPU parity tests of the off-policy path (SAC / TD3): gemm16 building block, HBM Buffer
+store / gather (bit-exact), policy forward, and whole learner updates against the reference
+goldens (oracle/make_golden.py run_offpolicy) — through the C ABI / the drop-in agents."""
+import numpy as np
+import pytest
+
+import numpy_port as port
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from tonic_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib.load()
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda().contiguous()
+
+
+@pytest.mark.parametrize('mode', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('M,N,K', [(1024, 256, 256), (100, 256, 119), (24, 1, 32), (37, 21, 88),
+                                   (16, 32, 16), (1, 256, 1024)])
+def test_gemm16_vs_numpy(lib, mode, M, N, K):
+    from tonic_amd import _lib
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    a_shape = (M, K) if mode[0] == 'N' else (K, M)
+    b_shape = (N, K) if mode[1] == 'T' else (K, N)
+    a = rng.normal(size=a_shape).astype(np.float32)
+    b = rng.normal(size=b_shape).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    mask = rng.normal(size=(M, N)).astype(np.float32)
+    c0 = rng.normal(size=(M, N)).astype(np.float32)
+    al = a if mode[0] == 'N' else a.T
+    bl = b.T if mode[1] == 'T' else b
+    ref = al.astype(np.float64) @ bl.astype(np.float64)
+    tol = 2e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    da, db, dbias, dmask = dev(a), dev(b), dev(bias), dev(mask)
+    out = torch.zeros(M, N).cuda()
+    colsum = torch.zeros(M).cuda()
+    _lib.check(lib.tonic_gemm_f32(mode.encode(), da.data_ptr(), db.data_ptr(), out.data_ptr(),
+                                  None, None, colsum.data_ptr() if mode == 'TN' else None,
+                                  M, N, K, a_shape[1], b_shape[1], N, 0, 0, 1.0, None), 'gemm')
+    assert np.abs(out.cpu().numpy() - ref).max() <= tol
+    if mode == 'TN':
+        np.testing.assert_allclose(colsum.cpu().numpy(), a.sum(0), rtol=1e-5, atol=1e-4)
+    # fused epilogue: bias + relu, relu-mask, accumulate, alpha
+    out = dev(c0)
+    _lib.check(lib.tonic_gemm_f32(mode.encode(), da.data_ptr(), db.data_ptr(), out.data_ptr(),
+                                  dbias.data_ptr(), dmask.data_ptr(), None, M, N, K, a_shape[1],
+                                  b_shape[1], N, 1, 1, 0.5, None), 'gemm-epilogue')
+    want = c0 + np.where(mask > 0, np.maximum(0.5 * ref + bias, 0), 0)
+    assert np.abs(out.cpu().numpy() - want).max() <= tol + 1e-6
+
+
+@pytest.mark.parametrize('name', ['sac_small', 'td3_small'])
+def test_buffer_store_gather_bit_exact(lib, golden, name):
+    """Replays the reference run's stores into the HBM Buffer and gathers with the reference's
+    index stream: contents, discounts, NaN padding and batches are bit-identical."""
+    from tonic_amd.replays import Buffer
+    g = golden(name)
+    O, A, W, hidden, B, iterations, seed, loop_steps = (int(x) for x in g['cfg'])
+    size = int(g['buffer_size'])
+    buf = Buffer(size=400, batch_iterations=iterations, batch_size=B, steps_before_batches=W * 10,
+                 steps_between_batches=W * 10)
+    buf.initialize(seed=seed, device='cuda')
+    ref = {k[len('buffer/'):]: g[k] for k in g.files if k.startswith('buffer/')}
+    for t in range(size):
+        buf.store(**{k: dev(ref[k][t]) for k in ('observations', 'actions', 'next_observations',
+                                                 'rewards', 'resets', 'terminations')})
+    assert buf.size == size and buf.max_size == ref['rewards'].shape[0]
+    for k, want in ref.items():
+        assert np.array_equal(buf.buffers[k].cpu().numpy(), want, equal_nan=True), k
+    indices = buf.sample_indices()
+    assert np.array_equal(indices, g['indices']), 'index stream must be bit-exact'
+    for it in range(iterations):
+        batch = buf.gather(dev(indices[it], torch.int64))
+        rows, cols = indices[it] // W, indices[it] % W
+        for k in ('observations', 'actions', 'next_observations', 'rewards', 'discounts'):
+            assert np.array_equal(batch[k].cpu().numpy(), ref[k][rows, cols]), k
+
+
+def _agent_from_golden(g, kind):
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    O, A, W, hidden, B, iterations, seed, loop_steps = (int(x) for x in g['cfg'])
+    relu = torch.nn.ReLU
+    critic = tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
+                              torso=tt.models.MLP((hidden, hidden), relu),
+                              head=tt.models.ValueHead())
+    if kind == 'sac':
+        head = tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
+                                            distribution=tt.models.SquashedMultivariateNormalDiag)
+    else:
+        head = tt.models.DeterministicPolicyHead()
+    model = tt.models.ActorTwinCriticWithTargets(
+        actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
+                              torso=tt.models.MLP((hidden, hidden), relu), head=head),
+        critic=critic, observation_normalizer=tt.normalizers.MeanStd())
+    replay = tonic_amd.replays.Buffer(size=400, batch_iterations=iterations, batch_size=B,
+                                      steps_before_batches=W * 10, steps_between_batches=W * 10)
+    if kind == 'sac':
+        agent = tt.agents.SAC(model=model, replay=replay,
+                              exploration=tonic_amd.explorations.NoActionNoise(start_steps=W * 5))
+    else:
+        agent = tt.agents.TD3(model=model, replay=replay,
+                              exploration=tonic_amd.explorations.NormalActionNoise(start_steps=W * 5))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    return agent
+
+
+@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3')])
+def test_offpolicy_update_matches_reference(lib, golden, name, kind):
+    g = golden(name)
+    agent = _agent_from_golden(g, kind)
+    state = agent.model.state_dict()
+    for key in state:       # identical initialisation from the same seed (CPU init parity)
+        np.testing.assert_array_equal(state[key].cpu().numpy(), g['init/' + key], err_msg=key)
+    agent.model.load_state_dict({k[len('pre/'):]: torch.as_tensor(g[k]) for k in g.files
+                                 if k.startswith('pre/')})
+    before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    ref = {k[len('buffer/'):]: g[k] for k in g.files if k.startswith('buffer/')}
+    for t in range(int(g['buffer_size'])):
+        agent.replay.store(**{k: dev(ref[k][t]) for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations')})
+    infos = agent.enqueue_update(g['indices'], g['eps']).cpu().numpy()
+    np.testing.assert_allclose(infos[0][:, 0], g['info/critic/loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q1_mean'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(infos[0][:, 2], g['info/critic/q2_mean'], rtol=1e-5, atol=1e-5)
+    ran = infos[1][:, 6] > 0
+    assert ran.sum() == len(g['info/actor/loss'])
+    np.testing.assert_allclose(infos[1][ran, 0], g['info/actor/loss'], rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, start in before.items():
+        if 'normalizer' in key:
+            continue
+        got = after[key].detach().cpu().numpy() - start
+        want = g['post/' + key] - start
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg=key)
+
+
+@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3')])
+def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
+    """agent.step / agent.update with NumPy in/out replays the reference run: warm-up actions
+    from the NumPy stream, policy actions (+ exploration noise / sampled noise) after it, the
+    learner update triggered at the same step, same statistics."""
+    import tonic_amd
+    g = golden(name)
+    O, A, W, hidden, B, iterations, seed, loop_steps = (int(x) for x in g['cfg'])
+    agent = _agent_from_golden(g, kind)
+    env = tonic_amd.environments.distribute(
+        lambda: tonic_amd.environments.Synthetic(O, A, max_episode_steps=5), 1, W)
+    env.initialize(seed=seed)
+    observations = env.start()
+    rng = np.random.RandomState(seed + 1)
+    updated = False
+    for t in range(loop_steps):
+        np.testing.assert_array_equal(observations, g['act/observations'][t])
+        actions = agent.step(observations, t * W)
+        if not updated:          # after the first update parameters differ at rounding level
+            np.testing.assert_allclose(actions, g['act/actions'][t], rtol=0, atol=5e-6)
+        observations, infos = env.step(g['act/actions'][t])
+        infos['rewards'] = (infos['rewards'] + rng.normal(size=W)).astype(np.float32)
+        term = rng.uniform(size=W) < 0.1
+        infos['terminations'] = term
+        infos['resets'] = infos['resets'] | term
+        agent.update(**infos, steps=t * W)
+        if hasattr(agent, 'last_infos') and not updated:
+            updated = True
+            infos_dev = agent.last_infos
+            np.testing.assert_allclose(infos_dev[0][:, 0], g['info/critic/loss'], rtol=1e-4, atol=1e-5)
+    assert updated

@@ -36,6 +36,17 @@ SIGNATURES = {
     'tonic_segment_store': (ctypes.c_int, [c_vp] * 15 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_ppo_collect_step': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
+    'tonic_offpolicy_workspace_bytes': (c_i64, [c_i32] * 4),
+    'tonic_mlp_actor_param_count': (c_i64, [c_i32] * 4),
+    'tonic_q_critic_param_count': (c_i64, [c_i32] * 3),
+    'tonic_buffer_store': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i32, c_i32, c_f64, c_vp]),
+    'tonic_buffer_gather': (ctypes.c_int, [c_vp] * 11 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'tonic_policy_forward': (ctypes.c_int, [c_vp] * 4 + [c_i32] * 5 + [c_vp, c_i64, c_vp]),
+    'tonic_twin_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 12 + [c_i32] * 4 + [c_f64] * 3 +
+                          [c_vp, c_i64, c_vp]),
+    'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 7 + [c_i32] * 4 + [c_f64] +
+                           [c_vp, c_i64, c_vp]),
+    'tonic_gemm_f32': (ctypes.c_int, [ctypes.c_char_p] + [c_vp] * 6 + [c_i32] * 8 + [c_f64, c_vp]),
 }
 
 

@@ -1,0 +1,627 @@
+// Off-policy learner path (SAC / TD3) for 2-hidden-layer ReLU networks, gfx950.
+//
+// Restates (paths relative to the reference checkout):
+//   tonic/torch/updaters/critics.py:125-134 (TargetActionNoise), :156-182
+//     (TwinCriticDeterministicQLearning), :202-235 (TwinCriticSoftQLearning),
+//   tonic/torch/updaters/actors.py:170-189 (DeterministicPolicyGradient), :238-267
+//     (TwinCriticSoftDeterministicPolicyGradient),
+//   tonic/torch/models/actors.py:7-34 (SquashedMultivariateNormalDiag), :94-98
+//     (GaussianPolicyHead.forward), :113-115 (DeterministicPolicyHead), critics.py:15-20,
+//     encoders.py:28-31 (ObservationActionEncoder), normalizers/mean_stds.py:34-39,
+//   tonic/replays/buffers.py:33-56 (store), :81-91 (get: rows = idx // W, cols = idx % W).
+//
+// Every dense layer is one gemm16 launch (gemm16.h) with bias / ReLU / ReLU-mask / bias-
+// gradient fused in its epilogue; the twin critics run as batch-2 launches over a flat
+// [critic_1 | critic_2] parameter block.  The glue (sampling, squashing, targets, loss
+// gradients) is a handful of tiny element-wise kernels.  Gradients are written as SUMS over the
+// batch straight into the flat gradient buffer (same layout as the parameters), so
+// tonic_adam_step / an RCCL all-reduce consume them exactly like the PPO path.
+#include "gemm16.h"
+
+namespace tonic {
+
+constexpr float kSacLogEps = 1e-6f;            // actors.py:15
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+struct ActorShape { int O, H, A, heads; };      // heads: 1 = deterministic (TD3), 2 = loc+scale (SAC)
+struct CriticShape { int O, A, H; };
+
+__host__ __device__ inline int64_t actor_count(ActorShape s) {
+  return (int64_t)s.H * s.O + s.H + (int64_t)s.H * s.H + s.H + (int64_t)s.heads * (s.A * s.H + s.A);
+}
+__host__ __device__ inline int64_t critic_count(CriticShape s) {
+  return (int64_t)s.H * (s.O + s.A) + s.H + (int64_t)s.H * s.H + s.H + s.H + 1;
+}
+
+// ------------------------------------------------------------------ element-wise kernels
+
+// X[m] = [ (obs[m] - mean) / std , actions[m] ]   (encoders.py:28-31 + mean_stds.py:36)
+__global__ void encode_kernel(const float* obs, const float* act, const float* mean,
+                              const float* std, float* X, int B, int O, int A, int ldx) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * (O + A)) return;
+  const int m = idx / (O + A), c = idx - m * (O + A);
+  X[(int64_t)m * ldx + c] = c < O ? (obs[(int64_t)m * O + c] - mean[c]) / std[c]
+                                  : act[(int64_t)m * A + (c - O)];
+}
+
+// SAC: u = loc + sigma * eps, a = tanh(u), logp = sum_a [N(u; loc, sigma) - log(1 - a^2 + 1e-6)]
+// with sigma = clamp(softplus(spre), 1e-4, 1) (actors.py:11-16,94-98).  One thread per sample.
+__global__ void sac_sample_kernel(const float* loc, const float* spre, const float* eps, int ld,
+                                  float* act, float* logp, float* sigma_out, int B, int A) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= B) return;
+  float lp = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float raw = softplus_f(spre[(int64_t)m * ld + a]);
+    const float sigma = fminf(fmaxf(raw, 1e-4f), 1.0f);
+    const float l = loc[(int64_t)m * ld + a];
+    const float u = eps ? l + eps[(int64_t)m * A + a] * sigma : l;   // rsample: loc + eps * scale
+    const float t = tanhf(u);
+    const float d = u - l;
+    const float normal = -(d * d) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
+    lp += normal - logf(1.f - t * t + kSacLogEps);
+    act[(int64_t)m * A + a] = t;
+    if (sigma_out) sigma_out[(int64_t)m * A + a] = sigma;
+  }
+  if (logp) logp[m] = lp;
+}
+
+// TD3 target actions: clamp(a + clamp(scale * eps, -clip, clip), -1, 1)  (critics.py:130-134)
+__global__ void td3_target_action_kernel(const float* loc, int ld, const float* eps, float* act,
+                                         int B, int A, float scale, float clip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  const int m = idx / A, a = idx - m * A;
+  float noise = scale * eps[idx];
+  noise = fminf(fmaxf(noise, -clip), clip);
+  act[idx] = fminf(fmaxf(loc[(int64_t)m * ld + a] + noise, -1.f), 1.f);
+}
+
+// dense actions out of a padded head buffer (deterministic policy: tanh already applied)
+__global__ void copy_actions_kernel(const float* loc, int ld, float* act, int B, int A) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  act[idx] = loc[(int64_t)(idx / A) * ld + (idx % A)];
+}
+
+// y = r + disc * (min(q1', q2') - alpha * logp')  (critics.py:219-221; alpha = 0 and logp = null
+// give TD3's critics.py:166-167), then dq_z = 2 (q_z - y) and the statistics.
+__global__ void critic_loss_kernel(const float* rewards, const float* discounts,
+                                   const float* tq, const float* logp_next, float alpha,
+                                   const float* q, float* dq, float* stats, int B, int Bp) {
+  __shared__ float red[3][256];
+  float s_loss = 0.f, s_q1 = 0.f, s_q2 = 0.f;
+  for (int m = threadIdx.x; m < B; m += blockDim.x) {
+    float next = fminf(tq[m], tq[Bp + m]);
+    if (logp_next) next = next - alpha * logp_next[m];
+    const float y = rewards[m] + discounts[m] * next;
+    const float e1 = q[m] - y, e2 = q[Bp + m] - y;
+    dq[m] = 2.f * e1;
+    dq[Bp + m] = 2.f * e2;
+    s_loss += e1 * e1 + e2 * e2;
+    s_q1 += q[m];
+    s_q2 += q[Bp + m];
+  }
+  red[0][threadIdx.x] = s_loss; red[1][threadIdx.x] = s_q1; red[2][threadIdx.x] = s_q2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int i = 0; i < (int)blockDim.x; ++i) { a += red[0][i]; b += red[1][i]; c += red[2][i]; }
+    stats[0] = (float)a; stats[1] = (float)b; stats[2] = (float)c; stats[3] = 0.f;
+    stats[4] = 0.f; stats[5] = (float)B; stats[6] = 0.f; stats[7] = 0.f;
+  }
+}
+
+// Actor objective: SAC  loss = mean(alpha * logp - min(q1, q2))  (actors.py:254-257)
+//                  TD3  loss = -mean(q1)                          (actors.py:177-179)
+// d loss / d q_z (unscaled by 1/B): -1 on the smaller critic, -1/2 each on ties.
+__global__ void actor_loss_kernel(const float* q, const float* logp, float alpha, int twin,
+                                  float* dq, float* stats, int B, int Bp) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int m = threadIdx.x; m < B; m += blockDim.x) {
+    const float q1 = q[m];
+    if (twin) {
+      const float q2 = q[Bp + m];
+      dq[m] = q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
+      dq[Bp + m] = q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
+      s += alpha * logp[m] - fminf(q1, q2);
+    } else {
+      dq[m] = -1.f;
+      s += -q1;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0;
+    for (int i = 0; i < (int)blockDim.x; ++i) a += red[i];
+    stats[0] = (float)a;
+    for (int i = 1; i < 8; ++i) stats[i] = i == 5 ? (float)B : 0.f;
+  }
+}
+
+// Back through the squashed Gaussian head (SAC) or the tanh head (TD3).
+//   da[m][a] = d loss / d action (from the critics' input gradient, columns O..O+A)
+// SAC: u = loc + sigma eps, a = tanh(u):
+//   d loss/d u   = da (1 - a^2) + alpha * 2 a (1 - a^2) / (1 - a^2 + 1e-6)
+//   d loss/d loc = d loss/d u ;  d loss/d sigma = d loss/d u * eps - alpha / sigma
+//   d sigma/d spre = sigmoid(spre) inside the clamp, else 0.
+// TD3: a = tanh(z):  d loss/d z = da (1 - a^2).
+__global__ void actor_head_backward_kernel(const float* dx, int lddx, int O, const float* act,
+                                           const float* eps, const float* sigma,
+                                           const float* spre, int ld, float alpha, int sac,
+                                           float* dloc, float* dspre, int B, int A) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  const int m = idx / A, a = idx - m * A;
+  const float da = dx[(int64_t)m * lddx + O + a];
+  const float t = act[idx];
+  const float one_m = 1.f - t * t;
+  if (!sac) {
+    dloc[(int64_t)m * ld + a] = da * one_m;
+    return;
+  }
+  const float du = da * one_m + alpha * (2.f * t * one_m / (one_m + kSacLogEps));
+  const float sg = sigma[idx];
+  const float dsigma = du * eps[idx] - alpha / sg;
+  const float pre = spre[(int64_t)m * ld + a];
+  const float raw = softplus_f(pre);
+  const bool inside = raw >= 1e-4f && raw <= 1.0f;
+  dloc[(int64_t)m * ld + a] = du;
+  dspre[(int64_t)m * ld + a] = inside ? dsigma / (1.f + expf(-pre)) : 0.f;
+}
+
+// Buffer.get gather (buffers.py:84-91): one wave per sampled transition.
+struct GatherArgs {
+  const int64_t* indices;
+  const float* obs; const float* act; const float* next; const float* rew; const float* disc;
+  float* o_obs; float* o_act; float* o_next; float* o_rew; float* o_disc;
+  int64_t W;
+  int B, O, A;
+};
+
+__global__ __launch_bounds__(256) void buffer_gather_kernel(GatherArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= g.B) return;
+  const int64_t idx = g.indices[b];
+  const int64_t row = idx / g.W, col = idx - row * g.W;       // rows = idx // W, cols = idx % W
+  const int64_t t = row * g.W + col;
+  for (int k = lane; k < g.O; k += 64) {
+    g.o_obs[(int64_t)b * g.O + k] = g.obs[t * g.O + k];
+    g.o_next[(int64_t)b * g.O + k] = g.next[t * g.O + k];
+  }
+  for (int k = lane; k < g.A; k += 64) g.o_act[(int64_t)b * g.A + k] = g.act[t * g.A + k];
+  if (lane == 0) { g.o_rew[b] = g.rew[t]; g.o_disc[b] = g.disc[t]; }
+}
+
+// Buffer.store row write (buffers.py:33-52) + MeanStd.record (mean_stds.py:44-48).
+struct BufferStoreArgs {
+  float* b_obs; float* b_act; float* b_next; float* b_rew; float* b_rst; float* b_term; float* b_disc;
+  const float* obs; const float* act; const float* next; const float* rew; const float* rst;
+  const float* term;
+  float* norm_acc;
+  int64_t row, W;
+  int O, A;
+  float discount;
+};
+
+__global__ __launch_bounds__(1024) void buffer_store_kernel(BufferStoreArgs a) {
+  __shared__ float tile[16384];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_obs = a.W * a.O, n_act = a.W * a.A;
+  for (int64_t i = tid; i < n_obs; i += stride) {
+    a.b_obs[a.row * n_obs + i] = a.obs[i];
+    a.b_next[a.row * n_obs + i] = a.next[i];
+  }
+  for (int64_t i = tid; i < n_act; i += stride) a.b_act[a.row * n_act + i] = a.act[i];
+  for (int64_t i = tid; i < a.W; i += stride) {
+    a.b_rew[a.row * a.W + i] = a.rew[i];
+    a.b_rst[a.row * a.W + i] = a.rst[i];
+    a.b_term[a.row * a.W + i] = a.term[i];
+    a.b_disc[a.row * a.W + i] = (1.f - a.term[i]) * a.discount;     // buffers.py:34-36
+  }
+  if (a.norm_acc == nullptr || blockIdx.x != gridDim.x - 1) return;
+  const int k = threadIdx.x;
+  float sum = 0.f, sum_sq = 0.f;
+  if (k < a.O) { sum = a.norm_acc[k]; sum_sq = a.norm_acc[a.O + k]; }
+  const int64_t rows_per_chunk = 16384 / a.O;
+  for (int64_t w0 = 0; w0 < a.W; w0 += rows_per_chunk) {
+    const int64_t rows = min(rows_per_chunk, a.W - w0);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < rows * a.O; i += blockDim.x) tile[i] = a.obs[w0 * a.O + i];
+    __syncthreads();
+    if (k < a.O) {
+      for (int64_t w = 0; w < rows; ++w) {
+        const float v = tile[w * a.O + k];
+        sum = sum + v;
+        const float sq = v * v;
+        sum_sq = sum_sq + sq;
+      }
+    }
+  }
+  if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }
+}
+
+// --------------------------------------------------------------------------- host helpers
+
+namespace {
+
+inline int pad16(int x) { return (x + 15) / 16 * 16; }
+
+struct ActorParams {
+  const float *W1, *b1, *W2, *b2, *Wh, *bh;     // Wh/bh: first head; second head follows at +A*H+A
+  ActorShape s;
+  explicit ActorParams(const float* p, ActorShape sh) : s(sh) {
+    W1 = p; b1 = W1 + (int64_t)s.H * s.O; W2 = b1 + s.H; b2 = W2 + (int64_t)s.H * s.H;
+    Wh = b2 + s.H; bh = Wh + (int64_t)s.A * s.H;
+  }
+  const float* head_w(int h) const { return Wh + (int64_t)h * (s.A * s.H + s.A); }
+  const float* head_b(int h) const { return head_w(h) + (int64_t)s.A * s.H; }
+};
+
+struct CriticOffsets {
+  int64_t W1, b1, W2, b2, w3, b3, count;
+  explicit CriticOffsets(CriticShape s) {
+    W1 = 0; b1 = W1 + (int64_t)s.H * (s.O + s.A); W2 = b1 + s.H; b2 = W2 + (int64_t)s.H * s.H;
+    w3 = b2 + s.H; b3 = w3 + s.H; count = b3 + 1;
+  }
+};
+
+GemmArgs gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+              int K) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.alpha = 1.f;
+  return g;
+}
+
+#define TRY(expr)                    \
+  do {                               \
+    const int rc__ = (expr);         \
+    if (rc__ != TONIC_OK) return rc__; \
+  } while (0)
+
+// actor torso + heads: h1, h2 [Bp, H]; head h -> out_h [Bp, ldh] (pre-activation unless `tanh_head`)
+int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
+                  float* h2, float* head0, float* head1, int ldh, bool tanh_head,
+                  hipStream_t st) {
+  ActorParams p(params, s);
+  GemmArgs g = gemm(obs, s.O, p.W1, s.O, h1, s.H, B, s.H, s.O);
+  g.bias = p.b1; g.act = ACT_RELU;
+  TRY(launch_gemm('c', 'c', g, 1, st));
+  g = gemm(h1, s.H, p.W2, s.H, h2, s.H, B, s.H, s.H);
+  g.bias = p.b2; g.act = ACT_RELU;
+  TRY(launch_gemm('c', 'c', g, 1, st));
+  g = gemm(h2, s.H, p.head_w(0), s.H, head0, ldh, B, s.A, s.H);
+  g.bias = p.head_b(0); g.act = tanh_head ? ACT_TANH : ACT_NONE;
+  TRY(launch_gemm('c', 'c', g, 1, st));
+  if (s.heads == 2) {
+    g = gemm(h2, s.H, p.head_w(1), s.H, head1, ldh, B, s.A, s.H);
+    g.bias = p.head_b(1);
+    TRY(launch_gemm('c', 'c', g, 1, st));
+  }
+  return TONIC_OK;
+}
+
+// `nets` critics batched over blockIdx.z; X shared ([Bp, ldx]); h1/h2 [nets][Bp][H]; q [nets][Bp]
+int critics_forward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
+                    int Bp, float* h1, float* h2, float* q, hipStream_t st) {
+  const CriticOffsets o(s);
+  const int in = s.O + s.A;
+  const int64_t hs = (int64_t)Bp * s.H;
+  GemmArgs g = gemm(X, ldx, params + o.W1, in, h1, s.H, B, s.H, in);
+  g.bias = params + o.b1; g.act = ACT_RELU;
+  g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
+  TRY(launch_gemm('c', 'c', g, nets, st));
+  g = gemm(h1, s.H, params + o.W2, s.H, h2, s.H, B, s.H, s.H);
+  g.bias = params + o.b2; g.act = ACT_RELU;
+  g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
+  TRY(launch_gemm('c', 'c', g, nets, st));
+  g = gemm(h2, s.H, params + o.w3, s.H, q, 1, B, 1, s.H);
+  g.bias = params + o.b3;
+  g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = Bp;
+  TRY(launch_gemm('c', 'c', g, nets, st));
+  return TONIC_OK;
+}
+
+// Backward of `nets` critics from dq [nets][Bp].  grads != null: weight/bias gradient SUMS into
+// the flat layout (stride = critic param count).  dX != null: input gradient [nets][Bp][lddx].
+int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
+                     int Bp, const float* h1, const float* h2, const float* dq, float* dh2,
+                     float* dh1, float* grads, float* dX, int lddx, hipStream_t st) {
+  const CriticOffsets o(s);
+  const int in = s.O + s.A;
+  const int64_t hs = (int64_t)Bp * s.H;
+  GemmArgs g;
+  if (grads) {   // dw3[1,H] = dq^T h2 ; db3 = sum dq
+    g = gemm(dq, 1, h2, s.H, grads + o.w3, s.H, 1, s.H, B);
+    g.colsum = grads + o.b3; g.strideColsum = o.count;
+    g.strideA = Bp; g.strideB = hs; g.strideC = o.count;
+    TRY(launch_gemm('s', 's', g, nets, st));
+  }
+  // dz2 = (dq w3) * relu'(h2)
+  g = gemm(dq, 1, params + o.w3, s.H, dh2, s.H, B, s.H, 1);
+  g.mask = h2; g.ldmask = s.H;
+  g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
+  TRY(launch_gemm('c', 's', g, nets, st));
+  if (grads) {   // dW2[H,H] = dz2^T h1 ; db2
+    g = gemm(dh2, s.H, h1, s.H, grads + o.W2, s.H, s.H, s.H, B);
+    g.colsum = grads + o.b2; g.strideColsum = o.count;
+    g.strideA = hs; g.strideB = hs; g.strideC = o.count;
+    TRY(launch_gemm('s', 's', g, nets, st));
+  }
+  // dz1 = (dz2 W2) * relu'(h1)
+  g = gemm(dh2, s.H, params + o.W2, s.H, dh1, s.H, B, s.H, s.H);
+  g.mask = h1; g.ldmask = s.H;
+  g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
+  TRY(launch_gemm('c', 's', g, nets, st));
+  if (grads) {   // dW1[H,in] = dz1^T X ; db1
+    g = gemm(dh1, s.H, X, ldx, grads + o.W1, in, s.H, in, B);
+    g.colsum = grads + o.b1; g.strideColsum = o.count;
+    g.strideA = hs; g.strideC = o.count;
+    TRY(launch_gemm('s', 's', g, nets, st));
+  }
+  if (dX) {      // dX = dz1 W1  (summed over the critics: second one accumulates)
+    for (int z = 0; z < nets; ++z) {
+      g = gemm(dh1 + z * hs, s.H, params + z * o.count + o.W1, in, dX, lddx, B, in, s.H);
+      g.accumulate = z > 0;
+      TRY(launch_gemm('c', 's', g, 1, st));
+    }
+  }
+  return TONIC_OK;
+}
+
+struct Workspace {
+  char* base;
+  int64_t used, capacity;
+  float* take(int64_t floats) {
+    float* p = reinterpret_cast<float*>(base + used);
+    used += round_up(floats * 4, 256);
+    return p;
+  }
+};
+
+int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
+  const int64_t Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A);
+  // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
+  return 2 * Bp * H + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * H + 2 * Bp) +
+         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 64 * 16;
+}
+
+}  // namespace
+}  // namespace tonic
+
+using namespace tonic;
+
+extern "C" int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H) {
+  return (offpolicy_workspace_floats(B, O, A, H) + 64 * 30) * 4;
+}
+
+extern "C" int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads) {
+  return actor_count(ActorShape{O, H, A, heads});
+}
+extern "C" int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H) {
+  return critic_count(CriticShape{O, A, H});
+}
+
+// Policy forward for acting / evaluation.  kind: 0 = deterministic tanh head (TD3,
+// actors.py:113-115), 1 = squashed Gaussian sample tanh(loc + sigma * eps) (SAC
+// `_stochastic_actions`, sac.py:40-43; eps = NULL gives the greedy `loc` of sac.py:48-51).
+extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_observations,
+                                    const float* d_eps, float* d_actions, int32_t kind, int32_t B,
+                                    int32_t O, int32_t H, int32_t A, void* d_workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && d_workspace && B > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_policy_forward: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
+                TONIC_ERR_WORKSPACE, "tonic_policy_forward: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldh = pad16(A);
+  Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
+  float* h1 = ws.take((int64_t)Bp * H); float* h2 = ws.take((int64_t)Bp * H);
+  float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
+  const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
+  TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st));
+  const int threads = 256;
+  if (kind == 0) {
+    hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, head0, ldh, d_actions, B, A);
+  } else {
+    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, d_actions, (float*)nullptr, (float*)nullptr, B, A);
+  }
+  TONIC_CHECK_LAUNCH("tonic_policy_forward");
+  return TONIC_OK;
+}
+
+// Twin-critic Q-learning gradients.  kind 0 = TD3 (critics.py:156-175: target actor + clipped
+// noise), 1 = SAC (critics.py:202-227: online actor sample, entropy term).  Writes gradient SUMS
+// for [critic_1 | critic_2] + 8 statistics {sq_err_sum(both), q1_sum, q2_sum, 0, 0, B, 0, 0}
+// into d_grad_sums; the caller follows with tonic_adam_step(grad_scale = 1/B).
+extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
+                                 const float* d_target_critics, const float* d_critics,
+                                 const float* d_norm_mean, const float* d_norm_std,
+                                 const float* d_observations, const float* d_actions,
+                                 const float* d_next_observations, const float* d_rewards,
+                                 const float* d_discounts, const float* d_eps,
+                                 float* d_grad_sums, int32_t B, int32_t O, int32_t H, int32_t A,
+                                 double entropy_coeff, double noise_scale, double noise_clip,
+                                 void* d_workspace, int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_policy_params && d_target_critics && d_critics && d_norm_mean && d_norm_std &&
+                    d_observations && d_actions && d_next_observations && d_rewards &&
+                    d_discounts && d_eps && d_grad_sums && d_workspace && B > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_twin_q_grad: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
+                TONIC_ERR_WORKSPACE, "tonic_twin_q_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A), threads = 256;
+  const CriticShape cs{O, A, H};
+  const int64_t Pc = critic_count(cs);
+  Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
+  float* a_h1 = ws.take((int64_t)Bp * H); float* a_h2 = ws.take((int64_t)Bp * H);
+  float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
+  float* next_act = ws.take((int64_t)Bp * A); float* logp = ws.take(Bp);
+  float* X = ws.take((int64_t)Bp * ldx);
+  float* c_h1 = ws.take(2LL * Bp * H); float* c_h2 = ws.take(2LL * Bp * H);
+  float* tq = ws.take(2LL * Bp); float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
+  float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
+
+  // ---- targets (no grad)
+  const ActorShape as{O, H, A, kind == 0 ? 1 : 2};
+  TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
+                    kind == 0, st));
+  if (kind == 0) {
+    hipLaunchKernelGGL(td3_target_action_kernel, dim3((B * A + threads - 1) / threads),
+                       dim3(threads), 0, st, head0, ldh, d_eps, next_act, B, A,
+                       (float)noise_scale, (float)noise_clip);
+  } else {
+    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, next_act, logp, (float*)nullptr, B, A);
+  }
+  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
+                     st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+  TRY(critics_forward(d_target_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, tq, st));
+  // ---- online critics on (obs, actions)
+  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
+                     st, d_observations, d_actions, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+  TRY(critics_forward(d_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, q, st));
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, st, d_rewards, d_discounts, tq,
+                     kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
+                     d_grad_sums + 2 * Pc, B, Bp);
+  TRY(critics_backward(d_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
+                       nullptr, 0, st));
+  TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
+  return TONIC_OK;
+}
+
+// Actor gradient through the (frozen) critics.  kind 0 = DeterministicPolicyGradient on
+// critic_1 only (actors.py:170-189 with td3.py:36), 1 = TwinCriticSoftDeterministicPolicyGradient
+// (actors.py:238-267).  Gradient SUMS for the actor + 8 statistics {loss_sum, 0.., B, ..}.
+extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
+                                  const float* d_critics, const float* d_norm_mean,
+                                  const float* d_norm_std, const float* d_observations,
+                                  const float* d_eps, float* d_grad_sums, int32_t B, int32_t O,
+                                  int32_t H, int32_t A, double entropy_coeff, void* d_workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_critics && d_norm_mean && d_norm_std && d_observations &&
+                    d_grad_sums && d_workspace && B > 0 && (kind == 0 || d_eps),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_actor_q_grad: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
+                TONIC_ERR_WORKSPACE, "tonic_actor_q_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A), threads = 256;
+  const int nets = kind == 0 ? 1 : 2;
+  const CriticShape cs{O, A, H};
+  const ActorShape as{O, H, A, kind == 0 ? 1 : 2};
+  const int64_t Pa = actor_count(as);
+  Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
+  float* a_h1 = ws.take((int64_t)Bp * H); float* a_h2 = ws.take((int64_t)Bp * H);
+  float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
+  float* act = ws.take((int64_t)Bp * A); float* sigma = ws.take((int64_t)Bp * A);
+  float* logp = ws.take(Bp);
+  float* X = ws.take((int64_t)Bp * ldx);
+  float* c_h1 = ws.take(2LL * Bp * H); float* c_h2 = ws.take(2LL * Bp * H);
+  float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
+  float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
+  float* dX = ws.take((int64_t)Bp * ldx);
+  float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
+  float* da_h2 = ws.take((int64_t)Bp * H); float* da_h1 = ws.take((int64_t)Bp * H);
+
+  TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
+                    kind == 0, st));
+  if (kind == 0) {
+    hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, head0, ldh, act, B, A);
+  } else {
+    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, act, logp, sigma, B, A);
+  }
+  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
+                     st, d_observations, act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+  TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, st, q, logp, (float)entropy_coeff,
+                     nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
+  TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dX,
+                       ldx, st));
+  hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
+                     dim3(threads), 0, st, dX, ldx, O, act, d_eps, sigma, head1, ldh,
+                     (float)entropy_coeff, kind == 1 ? 1 : 0, dloc, dspre, B, A);
+  // ---- actor backward (weight-gradient sums into the flat layout)
+  ActorParams p(d_actor_params, as);
+  float* g_W1 = d_grad_sums; float* g_b1 = g_W1 + (int64_t)H * O; float* g_W2 = g_b1 + H;
+  float* g_b2 = g_W2 + (int64_t)H * H; float* g_Wh = g_b2 + H;
+  GemmArgs g;
+  for (int h = 0; h < as.heads; ++h) {
+    const float* dhead = h == 0 ? dloc : dspre;
+    float* gw = g_Wh + (int64_t)h * (A * H + A);
+    g = gemm(dhead, ldh, a_h2, H, gw, H, A, H, B);          // dWh[A,H] = dhead^T h2 ; dbh
+    g.colsum = gw + (int64_t)A * H;
+    TRY(launch_gemm('s', 's', g, 1, st));
+    g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A); // dz2 (+)= (dhead Wh) * relu'(h2)
+    g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
+    TRY(launch_gemm('c', 's', g, 1, st));
+  }
+  g = gemm(da_h2, H, a_h1, H, g_W2, H, H, H, B);
+  g.colsum = g_b2;
+  TRY(launch_gemm('s', 's', g, 1, st));
+  g = gemm(da_h2, H, p.W2, H, da_h1, H, B, H, H);
+  g.mask = a_h1; g.ldmask = H;
+  TRY(launch_gemm('c', 's', g, 1, st));
+  g = gemm(da_h1, H, d_observations, O, g_W1, O, H, O, B);
+  g.colsum = g_b1;
+  TRY(launch_gemm('s', 's', g, 1, st));
+  TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_buffer_gather(const int64_t* d_indices, const float* d_buf_observations,
+                                   const float* d_buf_actions,
+                                   const float* d_buf_next_observations,
+                                   const float* d_buf_rewards, const float* d_buf_discounts,
+                                   float* d_observations, float* d_actions,
+                                   float* d_next_observations, float* d_rewards,
+                                   float* d_discounts, int64_t W, int32_t B, int32_t O, int32_t A,
+                                   void* stream) {
+  TONIC_REQUIRE(d_indices && d_buf_observations && d_buf_actions && d_buf_next_observations &&
+                    d_buf_rewards && d_buf_discounts && d_observations && d_actions &&
+                    d_next_observations && d_rewards && d_discounts && W > 0 && B > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_buffer_gather: bad argument");
+  GatherArgs g{d_indices, d_buf_observations, d_buf_actions, d_buf_next_observations,
+               d_buf_rewards, d_buf_discounts, d_observations, d_actions, d_next_observations,
+               d_rewards, d_discounts, W, B, O, A};
+  hipLaunchKernelGGL(buffer_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), g);
+  TONIC_CHECK_LAUNCH("tonic_buffer_gather");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_buffer_store(float* d_buf_observations, float* d_buf_actions,
+                                  float* d_buf_next_observations, float* d_buf_rewards,
+                                  float* d_buf_resets, float* d_buf_terminations,
+                                  float* d_buf_discounts, const float* d_observations,
+                                  const float* d_actions, const float* d_next_observations,
+                                  const float* d_rewards, const float* d_resets,
+                                  const float* d_terminations, float* d_norm_acc, int64_t row,
+                                  int64_t W, int32_t O, int32_t A, double discount_factor,
+                                  void* stream) {
+  TONIC_REQUIRE(d_buf_observations && d_buf_actions && d_buf_next_observations &&
+                    d_buf_rewards && d_buf_resets && d_buf_terminations && d_buf_discounts &&
+                    d_observations && d_actions && d_next_observations && d_rewards && d_resets &&
+                    d_terminations && row >= 0 && W > 0 && O > 0 && O <= 1024 && A > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_buffer_store: bad argument");
+  BufferStoreArgs a{d_buf_observations, d_buf_actions, d_buf_next_observations, d_buf_rewards,
+                    d_buf_resets, d_buf_terminations, d_buf_discounts, d_observations, d_actions,
+                    d_next_observations, d_rewards, d_resets, d_terminations, d_norm_acc, row, W,
+                    O, A, (float)discount_factor};
+  int64_t blocks = (W * (2 * O + A + 4) + 8 * 1024 - 1) / (8 * 1024);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(buffer_store_kernel, dim3((unsigned)blocks), dim3(1024), 0,
+                     as_stream(stream), a);
+  TONIC_CHECK_LAUNCH("tonic_buffer_store");
+  return TONIC_OK;
+}

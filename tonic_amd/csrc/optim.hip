@@ -20,7 +20,7 @@ struct AdamArgs {
   int64_t n;
   float grad_scale, lr, beta1, beta2, eps;
   double beta1_d, beta2_d, lr_d;
-  int stats_kind;            // 0 none, 1 PPO actor, 2 V critic
+  int stats_kind;            // 0 none, 1 PPO actor, 2 V critic, 3 twin Q critics, 4 Q actor
   float kl_threshold, entropy_coeff;
   const float* adv_stats;
   float* info_row;
@@ -76,6 +76,14 @@ __global__ void adam_finalize_kernel(AdamArgs a) {
     a.info_row[0] = st[0] * a.grad_scale;      // MSE loss
     a.info_row[1] = st[1] * a.grad_scale;      // mean of the pre-step values ('v')
     a.info_row[6] = 1.f;
+  } else if (a.stats_kind == 3 && a.info_row != nullptr) {
+    a.info_row[0] = st[0] * a.grad_scale;      // loss_1 + loss_2 (critics.py:172,224)
+    a.info_row[1] = st[1] * a.grad_scale;      // mean q1
+    a.info_row[2] = st[2] * a.grad_scale;      // mean q2
+    a.info_row[6] = 1.f;
+  } else if (a.stats_kind == 4 && a.info_row != nullptr) {
+    a.info_row[0] = st[0] * a.grad_scale;      // actor loss (actors.py:179,257)
+    a.info_row[6] = 1.f;
   }
 }
 
@@ -104,7 +112,7 @@ extern "C" int tonic_adam_step(float* d_params, const float* d_grad_sums, float*
   TONIC_REQUIRE(d_params && d_grad_sums && d_exp_avg && d_exp_avg_sq && d_state &&
                     param_count > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_adam_step: bad argument");
-  TONIC_REQUIRE(stats_kind >= 0 && stats_kind <= 2, TONIC_ERR_INVALID_ARGUMENT,
+  TONIC_REQUIRE(stats_kind >= 0 && stats_kind <= 4, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_adam_step: stats_kind %d", stats_kind);
   AdamArgs a;
   a.params = d_params; a.grad_sums = d_grad_sums; a.exp_avg = d_exp_avg;

@@ -1,3 +1,4 @@
+from .buffers import Buffer
 from .segments import Segment, flatten_batch
 
-__all__ = ['Segment', 'flatten_batch']
+__all__ = ['Buffer', 'Segment', 'flatten_batch']

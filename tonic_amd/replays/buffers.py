@@ -1,0 +1,115 @@
+"""HBM-resident off-policy ``Buffer`` — API of ``tonic/replays/buffers.py``.
+
+Circular float32 store ``[max_size = size // W, W, ...]`` for ``observations, actions,
+next_observations, rewards, resets, terminations, discounts``, NaN-initialised like the
+reference (buffers.py:45), 936 B per transition at O=111, A=8 (0.94 GB for 1 M transitions).
+``store`` is one ``tonic_buffer_store`` launch (row write, ``discounts = float32(1 -
+terminations) * discount_factor``, observation-normaliser record); ``get`` draws the indices
+with the host ``RandomState`` exactly like buffers.py:86 (bit-exact stream) and gathers the
+batch with ``tonic_buffer_gather`` (one wavefront per sampled transition,
+``rows = idx // W``, ``cols = idx % W``).
+"""
+import numpy as np
+import torch
+
+from tonic_amd import _lib
+
+KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+        'discounts')
+BATCH_KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'discounts')
+
+
+class Buffer:
+    def __init__(self, size=int(1e6), return_steps=1, batch_iterations=50, batch_size=100,
+                 discount_factor=0.99, steps_before_batches=int(1e4), steps_between_batches=50):
+        if return_steps != 1:
+            raise NotImplementedError('n-step returns (return_steps > 1) are not implemented in '
+                                      'the HIP engine yet (SURVEY.md §8f item 3)')
+        self.full_max_size = size
+        self.return_steps = return_steps
+        self.batch_iterations = batch_iterations
+        self.batch_size = batch_size
+        self.discount_factor = discount_factor
+        self.steps_before_batches = steps_before_batches
+        self.steps_between_batches = steps_between_batches
+
+    def initialize(self, seed=None, device=None):
+        self.np_random = np.random.RandomState(seed)
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.buffers = None
+        self.index = 0
+        self.size = 0
+        self.last_steps = 0
+        self.lib = _lib.load()
+
+    def ready(self, steps):
+        if steps < self.steps_before_batches:
+            return False
+        return (steps - self.last_steps) >= self.steps_between_batches
+
+    def _allocate(self, num_workers, observation_size, action_size):
+        self.num_workers = num_workers
+        self.max_size = self.full_max_size // num_workers
+        self.observation_size, self.action_size = observation_size, action_size
+        R, W = self.max_size, num_workers
+
+        def new(*shape):
+            return torch.full(shape, float('nan'), dtype=torch.float32, device=self.device)
+        self.buffers = dict(
+            observations=new(R, W, observation_size), actions=new(R, W, action_size),
+            next_observations=new(R, W, observation_size), rewards=new(R, W), resets=new(R, W),
+            terminations=new(R, W), discounts=new(R, W))
+        B = self.batch_size
+        self.batch = dict(
+            observations=torch.empty(B, observation_size, device=self.device),
+            actions=torch.empty(B, action_size, device=self.device),
+            next_observations=torch.empty(B, observation_size, device=self.device),
+            rewards=torch.empty(B, device=self.device), discounts=torch.empty(B, device=self.device))
+
+    def store(self, normalizer=None, **kwargs):
+        """One time row from float32 device tensors [W, ...] (buffers.py:33-56)."""
+        if self.buffers is None:
+            self._allocate(kwargs['observations'].shape[0], kwargs['observations'].shape[1],
+                           kwargs['actions'].shape[1])
+        b, p = self.buffers, _lib.ptr
+        sums = normalizer.device_sums if normalizer is not None else None
+        _lib.check(self.lib.tonic_buffer_store(
+            p(b['observations']), p(b['actions']), p(b['next_observations']), p(b['rewards']),
+            p(b['resets']), p(b['terminations']), p(b['discounts']), p(kwargs['observations']),
+            p(kwargs['actions']), p(kwargs['next_observations']), p(kwargs['rewards']),
+            p(kwargs['resets']), p(kwargs['terminations']), p(sums), self.index,
+            self.num_workers, self.observation_size, self.action_size,
+            float(self.discount_factor), _lib.current_stream()), 'tonic_buffer_store')
+        if normalizer is not None:
+            normalizer.note_device_rows(self.num_workers)
+        self.index = (self.index + 1) % self.max_size
+        self.size = min(self.size + 1, self.max_size)
+
+    def sample_indices(self, iterations=None):
+        """The index stream of `iterations` successive Buffer.get draws (buffers.py:85-86)."""
+        total = self.size * self.num_workers
+        count = self.batch_iterations if iterations is None else iterations
+        return np.stack([self.np_random.randint(total, size=self.batch_size)
+                         for _ in range(count)])
+
+    def gather(self, device_indices, out=None):
+        """Gathers one batch (int64 device indices [B]) into `out` (default: the reusable batch)."""
+        out = out or self.batch
+        b, p = self.buffers, _lib.ptr
+        _lib.check(self.lib.tonic_buffer_gather(
+            p(device_indices), p(b['observations']), p(b['actions']), p(b['next_observations']),
+            p(b['rewards']), p(b['discounts']), p(out['observations']), p(out['actions']),
+            p(out['next_observations']), p(out['rewards']), p(out['discounts']),
+            self.num_workers, device_indices.shape[0], self.observation_size, self.action_size,
+            _lib.current_stream()), 'tonic_buffer_gather')
+        return out
+
+    def get(self, *keys, steps):
+        """Generator form of the reference API: yields device-tensor batches."""
+        for _ in range(self.batch_iterations):
+            indices = self.sample_indices(1)[0]
+            device_indices = torch.as_tensor(indices, device=self.device)
+            out = {k: torch.empty_like(v) for k, v in self.batch.items()}
+            self.gather(device_indices, out)
+            yield {k: out[k] for k in keys}
+        self.last_steps = steps

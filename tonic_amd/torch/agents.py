@@ -20,7 +20,7 @@ import random
 import numpy as np
 import torch
 
-from tonic_amd import _lib, agents, logger, replays
+from tonic_amd import _lib, agents, explorations, logger, replays
 from tonic_amd.torch import models, normalizers, updaters
 
 
@@ -243,3 +243,214 @@ class PPO(A2C):
         self.last_infos = infos
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
+
+
+# ----------------------------------------------------------------- off-policy (SAC / TD3)
+
+def _twin_model(head):
+    return models.ActorTwinCriticWithTargets(
+        actor=models.Actor(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=head),
+        critic=models.Critic(
+            encoder=models.ObservationActionEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.ValueHead()),
+        observation_normalizer=normalizers.MeanStd())
+
+
+class DDPG(Agent):
+    """Acting / storing / update scheduling shared by the off-policy agents
+    (tonic/torch/agents/ddpg.py:20-112).  Plain DDPG (single critic, DeterministicQLearning) is
+    outside the accelerated path; TD3 and SAC build on this class like in the reference."""
+
+    policy_kind = 0          # tonic_policy_forward kind used by `_policy`
+
+    def __init__(self, model=None, replay=None, exploration=None, actor_updater=None,
+                 critic_updater=None):
+        if model is None or critic_updater is None or actor_updater is None:
+            raise NotImplementedError(
+                'plain DDPG (single critic) is outside the accelerated path; use TD3 or SAC')
+        self.model = model
+        self.replay = replay or replays.Buffer()
+        self.exploration = exploration or explorations.NormalActionNoise()
+        self.actor_updater = actor_updater
+        self.critic_updater = critic_updater
+
+    def initialize(self, observation_space, action_space, seed=None):
+        super().initialize(seed=seed)
+        self.device = _device()
+        self.lib = _lib.load()
+        self.model.initialize(observation_space, action_space)      # CPU init: seed parity
+        self.model.pack(self.device)
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.attach(self.device)
+        self.replay.initialize(seed, device=self.device)
+        self.exploration.initialize(self._policy, action_space, seed)
+        self.actor_updater.initialize(self.model)
+        self.critic_updater.initialize(self.model)
+        self.observation_size = observation_space.shape[0]
+        self.action_size = action_space.shape[0]
+        self.hidden = self.critic_updater.hidden
+        self._workers = None
+        self._policy_io = {}
+
+    # ------------------------------------------------------------------ acting
+    def _forward_policy(self, observations, kind, stochastic):
+        observations = np.asarray(observations, np.float32)
+        W = observations.shape[0]
+        io = self._policy_io.get(W)
+        if io is None:
+            need = self.lib.tonic_offpolicy_workspace_bytes(W, self.observation_size,
+                                                            self.action_size, self.hidden)
+            io = (_Staging([('observations', (W, self.observation_size)),
+                            ('eps', (W, self.action_size))], self.device),
+                  _Staging([('actions', (W, self.action_size))], self.device),
+                  torch.empty(need, dtype=torch.uint8, device=self.device))
+            self._policy_io[W] = io
+        stage_in, stage_out, workspace = io
+        stage_in.host_view('observations')[:] = observations
+        if stochastic:      # Normal.sample() of sac.py:43 == loc + scale * randn (SURVEY A.7)
+            stage_in.host_view('eps')[:] = torch.randn(W, self.action_size).numpy()
+        stage_in.upload()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_policy_forward(
+            p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
+            p(stage_in.device_view('eps')) if stochastic else None,
+            p(stage_out.device_view('actions')), kind, W, self.observation_size, self.hidden,
+            self.action_size, p(workspace), workspace.numel(), _lib.current_stream()),
+            'tonic_policy_forward')
+        stage_out.download()
+        torch.cuda.current_stream().synchronize()
+        return stage_out.host_view('actions').copy()
+
+    def _greedy_actions(self, observations):
+        return self._forward_policy(observations, self.policy_kind, False)
+
+    def _policy(self, observations):
+        return self._greedy_actions(observations)
+
+    def step(self, observations, steps):
+        actions = self.exploration(observations, steps)
+        self.last_observations = observations.copy()
+        self.last_actions = actions.copy()
+        return actions
+
+    def test_step(self, observations, steps):
+        return self._greedy_actions(observations)
+
+    # ---------------------------------------------------------------- learning
+    def update(self, observations, rewards, resets, terminations, steps):
+        W = len(rewards)
+        if self._workers != W:
+            self._workers = W
+            O, A = self.observation_size, self.action_size
+            self._transition = _Staging(
+                [('observations', (W, O)), ('actions', (W, A)), ('next_observations', (W, O)),
+                 ('rewards', (W,)), ('resets', (W,)), ('terminations', (W,))], self.device)
+        stage = self._transition
+        stage.host_view('observations')[:] = self.last_observations
+        stage.host_view('actions')[:] = self.last_actions          # float64 warm-up -> float32
+        stage.host_view('next_observations')[:] = observations
+        stage.host_view('rewards')[:] = rewards
+        stage.host_view('resets')[:] = resets
+        stage.host_view('terminations')[:] = terminations
+        stage.upload()
+        self.replay.store(
+            normalizer=self.model.observation_normalizer,
+            **{k: stage.device_view(k) for k in ('observations', 'actions', 'next_observations',
+                                                 'rewards', 'resets', 'terminations')})
+        if self.model.return_normalizer:
+            raise NotImplementedError('return normalisers are not supported')
+        if self.replay.ready(steps):
+            self._update(steps)
+        self.exploration.update(resets)
+
+    def _actor_due(self, iteration):
+        return True                       # ddpg.py:105-112: actor + targets every iteration
+
+    def enqueue_update(self, indices, eps):
+        """Enqueues `indices.shape[0]` learner iterations (no host sync).  indices: int64
+        [iterations, B] host array; eps: float32 [iterations, draws, B, A] host array with the
+        standard-normal draws in the order the reference consumes them."""
+        iterations = indices.shape[0]
+        device_indices = torch.as_tensor(indices).to(self.device, non_blocking=True)
+        device_eps = torch.as_tensor(eps).to(self.device, non_blocking=True)
+        if getattr(self, '_infos', None) is None or self._infos.shape[1] != iterations:
+            self._infos = torch.zeros(2, iterations, updaters.INFO_WIDTH, device=self.device)
+        self._infos.zero_()
+        for it in range(iterations):
+            batch = self.replay.gather(device_indices[it])
+            self.critic_updater.enqueue(batch, device_eps[it, 0], self._infos[0, it])
+            if self._actor_due(it):
+                actor_eps = device_eps[it, 1] if device_eps.shape[1] > 1 else None
+                self.actor_updater.enqueue(batch['observations'], actor_eps, self._infos[1, it])
+                self.model.update_targets()
+        return self._infos
+
+    def _draw_noise(self, iterations):
+        raise NotImplementedError
+
+    def _update(self, steps):
+        replay = self.replay
+        indices = replay.sample_indices()
+        eps = self._draw_noise(indices.shape[0])
+        infos = self.enqueue_update(indices, eps).cpu().numpy()
+        replay.last_steps = steps
+        for row in infos[0]:
+            logger.store('critic/loss', row[0])
+            logger.store('critic/q1', row[1])        # batch means (log-equivalent)
+            logger.store('critic/q2', row[2])
+        for row in infos[1][infos[1][:, 6] > 0]:
+            logger.store('actor/loss', row[0])
+        self.last_infos = infos
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.update()
+
+
+class TD3(DDPG):
+    """tonic/torch/agents/td3.py:20-55."""
+
+    policy_kind = 0
+
+    def __init__(self, model=None, replay=None, exploration=None, actor_updater=None,
+                 critic_updater=None, delay_steps=2):
+        super().__init__(
+            model=model or _twin_model(models.DeterministicPolicyHead()), replay=replay,
+            exploration=exploration,
+            actor_updater=actor_updater or updaters.DeterministicPolicyGradient(),
+            critic_updater=critic_updater or updaters.TwinCriticDeterministicQLearning())
+        self.delay_steps = delay_steps
+        self.model.critic = self.model.critic_1        # td3.py:36 (also a checkpoint alias)
+
+    def _actor_due(self, iteration):
+        return (iteration + 1) % self.delay_steps == 0     # td3.py:43-46 (quirk Q8)
+
+    def _draw_noise(self, iterations):
+        # TargetActionNoise: one torch.randn_like(actions) per critic update (critics.py:131)
+        B, A = self.replay.batch_size, self.action_size
+        return np.stack([torch.randn(B, A).numpy()[None] for _ in range(iterations)])
+
+
+class SAC(DDPG):
+    """tonic/torch/agents/sac.py:22-51."""
+
+    policy_kind = 1
+
+    def __init__(self, model=None, replay=None, exploration=None, actor_updater=None,
+                 critic_updater=None):
+        head = models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
+                                         distribution=models.SquashedMultivariateNormalDiag)
+        super().__init__(
+            model=model or _twin_model(head), replay=replay,
+            exploration=exploration or explorations.NoActionNoise(),
+            actor_updater=actor_updater or updaters.TwinCriticSoftDeterministicPolicyGradient(),
+            critic_updater=critic_updater or updaters.TwinCriticSoftQLearning())
+
+    def _policy(self, observations):
+        return self._forward_policy(observations, 1, True)        # sac.py:40-46
+
+    def _draw_noise(self, iterations):
+        # per iteration: rsample of the critic step, then rsample of the actor step
+        B, A = self.replay.batch_size, self.action_size
+        return np.stack([np.stack([torch.randn(B, A).numpy(), torch.randn(B, A).numpy()])
+                         for _ in range(iterations)])

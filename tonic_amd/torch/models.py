@@ -215,16 +215,27 @@ class Critic(_Network):
         self.head.initialize(size, return_normalizer)
 
 
-class FlatNetwork:
-    """One network's parameters packed into a single contiguous device buffer, in
-    ``parameters()`` order (the layout the C ABI documents); every ``nn.Parameter`` of the
-    module becomes a view of it, so ``state_dict`` / ``load_state_dict`` keep working and the
-    kernels see one flat pointer."""
+def network_variables(module):
+    """Weights / biases of a network in ``parameters()`` order, WITHOUT the shared normaliser
+    statistics (non-trainable ``_mean`` / ``_std``) — target networks included even though
+    their ``requires_grad`` is False."""
+    return [p for name, p in module.named_parameters() if 'normalizer' not in name]
 
-    def __init__(self, module, device):
-        params = trainable_variables(module)
+
+class FlatNetwork:
+    """One or several networks' parameters packed into a single contiguous device buffer, in
+    ``parameters()`` order (the layout the C ABI documents); every ``nn.Parameter`` becomes a
+    view of it, so ``state_dict`` / ``load_state_dict`` keep working and the kernels see one
+    flat pointer.  ``out`` packs into an existing buffer region instead of allocating."""
+
+    def __init__(self, modules, device, out=None):
+        if isinstance(modules, torch.nn.Module):
+            modules = [modules]
+        params = [p for module in modules for p in network_variables(module)]
         self.count = sum(p.numel() for p in params)
-        self.flat = torch.empty(self.count, dtype=torch.float32, device=device)
+        self.flat = out if out is not None else torch.empty(
+            self.count, dtype=torch.float32, device=device)
+        assert self.flat.numel() == self.count
         offset = 0
         for p in params:
             n = p.numel()
@@ -321,3 +332,32 @@ class ActorTwinCriticWithTargets(ActorCriticWithTargets):
         return [(self.actor, False), (self.critic_1, True), (self.critic_2, True),
                 (self.target_actor, False), (self.target_critic_1, True),
                 (self.target_critic_2, True)]
+
+    def pack(self, device):
+        """Moves the model to `device`; online networks share one flat buffer
+        [actor | critic_1 | critic_2] and the targets another with the same layout, so
+        ``update_targets`` is one polyak launch and both critics are one Adam block."""
+        self.to(device)
+        online = [self.actor, self.critic_1, self.critic_2]
+        target = [self.target_actor, self.target_critic_1, self.target_critic_2]
+        total = sum(p.numel() for m in online for p in network_variables(m))
+        self.flat_online = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_target = torch.empty(total, dtype=torch.float32, device=device)
+        n_actor = sum(p.numel() for p in network_variables(self.actor))
+        self.flat_actor = FlatNetwork(self.actor, device, self.flat_online[:n_actor])
+        self.flat_critics = FlatNetwork([self.critic_1, self.critic_2], device,
+                                        self.flat_online[n_actor:])
+        self.flat_target_actor = FlatNetwork(self.target_actor, device,
+                                             self.flat_target[:n_actor])
+        self.flat_target_critics = FlatNetwork([self.target_critic_1, self.target_critic_2],
+                                               device, self.flat_target[n_actor:])
+        return self
+
+    def update_targets(self):
+        """actor_critics.py:126-130 as ONE launch over the flat online / target buffers."""
+        from tonic_amd import _lib
+        if getattr(self, 'flat_online', None) is None:
+            return super().update_targets()
+        _lib.check(_lib.load().tonic_polyak_update(
+            _lib.ptr(self.flat_target), _lib.ptr(self.flat_online), self.flat_online.numel(),
+            float(self.target_coeff), _lib.current_stream()), 'tonic_polyak_update')

@@ -186,3 +186,177 @@ class VRegression(_FlatUpdater):
         self.enqueue(observations, returns, self.scratch_info)
         row = self.scratch_info.cpu()
         return dict(loss=row[0].clone(), v=values.cpu())
+
+
+# ----------------------------------------------------------------- off-policy (SAC / TD3)
+
+def _torso_width(torso):
+    sizes = tuple(torso.sizes)
+    if len(sizes) != 2 or sizes[0] != sizes[1] or torso.activation is not torch.nn.ReLU:
+        raise NotImplementedError('the fused off-policy kernels need a two-layer ReLU torso of '
+                                  f'equal widths, got {sizes} / {torso.activation}')
+    return sizes[0]
+
+
+class _QUpdater(_FlatUpdater):
+    """Shared plumbing of the four off-policy updaters: shapes, normaliser tensors, workspace."""
+
+    def _shapes(self, model):
+        self.model = model
+        self.observation_size = model.actor.torso.model[0].in_features
+        self.hidden = _torso_width(model.actor.torso)
+        if _torso_width(model.critic_1.torso) != self.hidden:
+            raise NotImplementedError('actor and critic torsos must have the same width')
+        head = model.actor.head
+        self.sac = hasattr(head, 'scale_layer')
+        layer = head.loc_layer if self.sac else head.action_layer
+        self.action_size = layer[0].out_features
+        self.normalizer = model.observation_normalizer
+        device = model.flat_online.device
+        if self.normalizer is None:
+            self._unit = (torch.zeros(self.observation_size, device=device),
+                          torch.ones(self.observation_size, device=device))
+
+    def norm_tensors(self):
+        if self.normalizer is None:
+            return self._unit
+        return self.normalizer._mean.data, self.normalizer._std.data
+
+    def _offpolicy_workspace(self, batch):
+        need = self.lib.tonic_offpolicy_workspace_bytes(batch, self.observation_size,
+                                                        self.action_size, self.hidden)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
+        return self.workspace
+
+    def _info(self, fn, keys):
+        self.scratch_info.zero_()
+        fn(self.scratch_info)
+        row = self.scratch_info.cpu()
+        return {k: row[i].clone() for i, k in enumerate(keys)}
+
+
+class TargetActionNoise:
+    """critics.py:125-134 (parameters only: the clipping runs inside tonic_twin_q_grad)."""
+
+    def __init__(self, scale=0.2, clip=0.5):
+        self.scale, self.clip = scale, clip
+
+
+class _TwinCriticQLearning(_QUpdater):
+    stats_kind = 3          # {loss, q1 mean, q2 mean}
+    default_lr = 1e-3
+    kind = 0
+
+    def initialize(self, model):
+        self._shapes(model)
+        self._setup(model.flat_critics, adam_hyperparameters(self.optimizer, self.default_lr))
+        self.variables = model.flat_critics.params
+
+    def _policy_params(self):
+        raise NotImplementedError
+
+    def enqueue(self, batch, eps, info_row):
+        B = batch['observations'].shape[0]
+        ws = self._offpolicy_workspace(B)
+        mean, std = self.norm_tensors()
+        noise = getattr(self, 'target_action_noise', None)
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_twin_q_grad(
+            self.kind, p(self._policy_params()), p(self.model.flat_target_critics.flat),
+            p(self.flat.flat), p(mean), p(std), p(batch['observations']), p(batch['actions']),
+            p(batch['next_observations']), p(batch['rewards']), p(batch['discounts']), p(eps),
+            p(self.grad_sums), B, self.observation_size, self.hidden, self.action_size,
+            float(getattr(self, 'entropy_coeff', 0.0)), float(noise.scale if noise else 0.0),
+            float(noise.clip if noise else 0.0), p(ws), ws.numel(), _lib.current_stream()),
+            'tonic_twin_q_grad')
+        self._step(B * self.world_size, info_row)
+
+    def __call__(self, observations, actions, next_observations, rewards, discounts):
+        """Drop-in form: draws its own noise from the torch CPU generator like the reference."""
+        batch = dict(observations=observations, actions=actions,
+                     next_observations=next_observations, rewards=rewards, discounts=discounts)
+        eps = torch.randn(actions.shape).to(actions.device)
+        out = self._info(lambda row: self.enqueue(batch, eps, row), ('loss', 'q1', 'q2'))
+        return out
+
+
+class TwinCriticDeterministicQLearning(_TwinCriticQLearning):
+    """critics.py:137-182 (TD3): target actor + clipped target-action noise."""
+    kind, default_lr = 0, 1e-3
+
+    def __init__(self, loss=None, optimizer=None, target_action_noise=None, gradient_clip=0):
+        _check_plain(loss, gradient_clip)
+        self.optimizer = optimizer
+        self.target_action_noise = target_action_noise or TargetActionNoise(scale=0.2, clip=0.5)
+
+    def _policy_params(self):
+        return self.model.flat_target_actor.flat
+
+
+class TwinCriticSoftQLearning(_TwinCriticQLearning):
+    """critics.py:185-235 (SAC): online-actor sample and entropy bonus in the target."""
+    kind, default_lr = 1, 3e-4
+
+    def __init__(self, loss=None, optimizer=None, entropy_coeff=0.2, gradient_clip=0):
+        _check_plain(loss, gradient_clip)
+        self.optimizer = optimizer
+        self.entropy_coeff = entropy_coeff
+
+    def _policy_params(self):
+        return self.model.flat_actor.flat
+
+
+class _ActorQGradient(_QUpdater):
+    stats_kind = 4          # {loss}
+    default_lr = 1e-3
+    kind = 0
+
+    def initialize(self, model):
+        self._shapes(model)
+        self._setup(model.flat_actor, adam_hyperparameters(self.optimizer, self.default_lr))
+        self.variables = model.flat_actor.params
+
+    def enqueue(self, observations, eps, info_row):
+        B = observations.shape[0]
+        ws = self._offpolicy_workspace(B)
+        mean, std = self.norm_tensors()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_actor_q_grad(
+            self.kind, p(self.flat.flat), p(self.model.flat_critics.flat), p(mean), p(std),
+            p(observations), p(eps), p(self.grad_sums), B, self.observation_size, self.hidden,
+            self.action_size, float(getattr(self, 'entropy_coeff', 0.0)), p(ws), ws.numel(),
+            _lib.current_stream()), 'tonic_actor_q_grad')
+        self._step(B * self.world_size, info_row)
+
+    def __call__(self, observations):
+        eps = None
+        if self.kind == 1:
+            eps = torch.randn(observations.shape[0], self.action_size).to(observations.device)
+        return self._info(lambda row: self.enqueue(observations, eps, row), ('loss',))
+
+
+class DeterministicPolicyGradient(_ActorQGradient):
+    """actors.py:159-189 on `model.critic` (= critic_1 for TD3, td3.py:36)."""
+    kind, default_lr = 0, 1e-3
+
+    def __init__(self, optimizer=None, gradient_clip=0):
+        _check_plain(None, gradient_clip)
+        self.optimizer = optimizer
+
+
+class TwinCriticSoftDeterministicPolicyGradient(_ActorQGradient):
+    """actors.py:226-267 (SAC)."""
+    kind, default_lr = 1, 3e-4
+
+    def __init__(self, optimizer=None, entropy_coeff=0.2, gradient_clip=0):
+        _check_plain(None, gradient_clip)
+        self.optimizer = optimizer
+        self.entropy_coeff = entropy_coeff
+
+
+def _check_plain(loss, gradient_clip):
+    if loss is not None and not isinstance(loss, torch.nn.MSELoss):
+        raise NotImplementedError('only the default MSE loss is fused')
+    if gradient_clip > 0:
+        raise NotImplementedError('gradient_clip > 0 is not implemented in the fused path')
