@@ -185,6 +185,77 @@ def cpu_baseline():
                 os_cpu_count=os.cpu_count())
 
 
+def offpolicy_rates():
+    """cfg 3 of BASELINE.json (not the headline metric): SAC, O=111, A=8, default 256-wide
+    networks, 1 M-transition HBM Buffer, B=1024, 50 iterations per update call.  Reports learner
+    updates (batch iterations) per second on the GPU, eager and hipGraph-replayed, and the
+    reference's torch-CPU path (oracle/torch_port.OffPolicyPort) on a 5-iteration sample."""
+    import torch
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch_port
+    o_dim, a_dim, batch, iterations, rows = 111, 8, 1024, 50, 1000000
+    replay = tonic_amd.replays.Buffer(size=rows, batch_iterations=iterations, batch_size=batch)
+    agent = tt.agents.SAC(replay=replay)
+    agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=0)
+    replay._allocate(1, o_dim, a_dim)
+    gen = torch.Generator(device=agent.device)
+    gen.manual_seed(0)
+    for key, buf in replay.buffers.items():
+        if key in ('resets', 'terminations'):
+            buf.copy_((torch.rand(buf.shape, device=agent.device, generator=gen) < 1e-3).float())
+        elif key == 'discounts':
+            buf.copy_((1 - replay.buffers['terminations']) * 0.99)
+        elif key == 'actions':
+            buf.copy_(torch.rand(buf.shape, device=agent.device, generator=gen) * 2 - 1)
+        else:
+            buf.copy_(torch.randn(buf.shape, device=agent.device, generator=gen))
+    replay.size, replay.index = rows, 0
+
+    def one_update(graph):
+        indices = replay.sample_indices()
+        eps = agent._draw_noise(iterations)
+        return agent.enqueue_update(indices, eps, graph=graph)
+
+    out = {'workload': f'SAC O={o_dim} A={a_dim} hidden=256 B={batch}, {iterations} iterations '
+                       f'per update, {rows} transitions resident in HBM '
+                       f'({sum(b.numel() for b in replay.buffers.values()) * 4 / 1e9:.2f} GB)'}
+    for label, graph in (('eager', False), ('hip_graph', True)):
+        one_update(graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            infos = one_update(graph)
+        infos.cpu()
+        dt = (time.perf_counter() - t0) / reps
+        out[label] = {'learner_updates_per_sec': round(iterations / dt, 1),
+                      'ms_per_update_call': round(dt * 1e3, 3)}
+    # CPU baseline: same path on torch-CPU, bounded sample
+    state = {'pre/' + k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
+    port_ = torch_port.OffPolicyPort('sac', state, 'pre/')
+    rng = np.random.RandomState(0)
+    sample_rows = 4096
+    host = dict(observations=rng.standard_normal((sample_rows, 1, o_dim)),
+                actions=rng.uniform(-1, 1, (sample_rows, 1, a_dim)),
+                next_observations=rng.standard_normal((sample_rows, 1, o_dim)),
+                rewards=rng.standard_normal((sample_rows, 1)),
+                discounts=np.full((sample_rows, 1), 0.99))
+    host = {k: v.astype(np.float32) for k, v in host.items()}
+    idx = rng.randint(sample_rows, size=(6, batch))
+    eps = rng.standard_normal((6, 2, batch, a_dim)).astype(np.float32)
+    port_.update(host, 1, idx[:1], eps[:1])
+    t0 = time.perf_counter()
+    port_.update(host, 1, idx[1:], eps[1:])
+    dt = (time.perf_counter() - t0) / 5
+    out['cpu_baseline'] = {'learner_updates_per_sec': round(1 / dt, 2), 'kind': 'port',
+                           'cores': torch.get_num_threads(),
+                           'sample': '5 SAC iterations (critic + actor + polyak) at B=1024'}
+    return out
+
+
 def host_loop_rate(agent, steps=512):
     """PCIe-inclusive collect through the drop-in API (agent.step / agent.update with NumPy
     in/out, pinned staging, vectorised synthetic environment) — never `value`."""
@@ -223,7 +294,7 @@ def main():
     rank, world = parallel.init_from_env()
     assert world == max(args.gpus, 1) or world == 1, (world, args.gpus)
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
     agent = build_agent(seed=0)                      # same seed: replicated parameters
     rollout = DeviceRollout(agent, W, T, seed=1 + rank)
@@ -289,6 +360,7 @@ def main():
             result['roofline_gae'] = roof_g
             result['host_loop'] = host_loop_rate(agent)
             result['cpu_baseline'] = cpu_baseline()
+            result['offpolicy_sac'] = offpolicy_rates()
             result['speedup_vs_cpu_baseline'] = round(value / result['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(result))

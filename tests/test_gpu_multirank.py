@@ -1,0 +1,40 @@
+"""The N-rank learner path on one GPU box: two processes (gloo all-reduce of the flat gradient-sum
+buffers, advantage moments and normaliser sums; both ranks share cuda:0) must reproduce the
+single-process full-batch PPO update — the property the RCCL run over 2/4/8 GPUs relies on."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'mp_ppo_worker.py')
+
+
+def launch(world, out, port):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               TONIC_AMD_BACKEND='gloo')
+    procs = [subprocess.Popen([sys.executable, WORKER, out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    for p in procs:
+        output = p.communicate(timeout=300)[0]
+        assert p.returncode == 0, output[-3000:]
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    single, double = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    launch(1, single, 29631)
+    launch(2, double, 29632)
+    a, b = np.load(single), np.load(double)
+    np.testing.assert_allclose(b['adv_stats'], a['adv_stats'], rtol=1e-5, atol=1e-6)
+    ran = a['infos'][0][:, 6] > 0
+    assert np.array_equal(ran, b['infos'][0][:, 6] > 0)
+    np.testing.assert_allclose(b['infos'][0][ran, :5], a['infos'][0][ran, :5], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b['infos'][1][:, :2], a['infos'][1][:, :2], rtol=1e-4, atol=1e-5)
+    for key in a.files:
+        if key in ('infos', 'adv_stats'):
+            continue
+        np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)

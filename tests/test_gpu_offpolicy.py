@@ -174,3 +174,47 @@ def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
             infos_dev = agent.last_infos
             np.testing.assert_allclose(infos_dev[0][:, 0], g['info/critic/loss'], rtol=1e-4, atol=1e-5)
     assert updated
+
+
+@pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100)])
+def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
+    """cfg-3 (SAC, O=111, A=8, B=1024) and cfg-4 per-GPU (TD3, O=67, A=21, 64 workers, the
+    reference's default B=100) shapes with the default 256-wide networks: two learner iterations
+    on the HIP path vs the torch-CPU oracle from identical parameters, buffer, indices, noise."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    import torch_port
+    from tonic_amd.environments import Box
+    torch.set_num_threads(8)
+    rng = np.random.RandomState(7)
+    rows = 64
+    replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
+    agent = (tt.agents.SAC if kind == 'sac' else tt.agents.TD3)(replay=replay)
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+    # make the normaliser non-trivial
+    norm = agent.model.observation_normalizer
+    norm._mean.data.copy_(dev(rng.normal(size=O) * 0.3))
+    norm._std.data.copy_(dev(np.abs(rng.normal(size=O)) + 0.5))
+    state = {'pre/' + k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    for t in range(rows):
+        replay.store(**{k: dev(v[t]) for k, v in host.items()})
+    host['discounts'] = port.buffer_discounts(host['terminations'] != 0, 0.99)
+    indices = replay.sample_indices()
+    draws = 2 if kind == 'sac' else 1
+    eps = rng.normal(size=(2, draws, B, A)).astype(np.float32)
+    oracle = torch_port.OffPolicyPort(kind, state, 'pre/')
+    want = oracle.update(host, W, indices, eps)
+    infos = agent.enqueue_update(indices, eps).cpu().numpy()
+    np.testing.assert_allclose(infos[0][:, 0], [i['critic']['loss'] for i in want], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(infos[0][:, 1], [i['critic']['q1'] for i in want], rtol=1e-5, atol=1e-5)
+    ran = infos[1][:, 6] > 0
+    np.testing.assert_allclose(infos[1][ran, 0], [i['actor']['loss'] for i in want if 'actor' in i],
+                               rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, value in oracle.state().items():
+        got = after[key].detach().cpu().numpy() - state['pre/' + key]
+        np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)

@@ -29,13 +29,17 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ P, int ld
   }
 }
 
-template <bool A_KC, bool B_KC>
+// SPLITK = false: each of the 4 waves of a workgroup owns its own 16 x 32 output tile.
+// SPLITK = true : the 4 waves share ONE tile and interleave the k-chunks (long contractions such
+//                 as the weight gradients, K = batch size); partial tiles are combined through
+//                 LDS in wave order (deterministic).
+template <bool A_KC, bool B_KC, bool SPLITK>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int tiles_n = (g.N + 31) / 32, tiles_m = (g.M + 15) / 16;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_n) return;
+  const int tile = SPLITK ? blockIdx.x : blockIdx.x * 4 + wave;
+  if (tile >= tiles_m * tiles_n) return;          // uniform per workgroup when SPLITK
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * 16, n0 = tn * 32;
   const int z = blockIdx.z;
@@ -47,19 +51,49 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs g) {
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
-#pragma unroll 2
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
-    const int kbase = k0 + 4 * kg;
-    float a[4], b0[4], b1[4];
-    load_operand<A_KC>(A, g.lda, m0 + i, g.M, kbase, g.K, vec_a, a);
-    load_operand<B_KC>(B, g.ldb, n0 + i, g.N, kbase, g.K, vec_b, b0);
-    load_operand<B_KC>(B, g.ldb, n0 + 16 + i, g.N, kbase, g.K, vec_b, b1);
+  const int kstep = SPLITK ? 64 : 16;
+  int k0 = SPLITK ? 16 * wave : 0;
+  // register double buffering: chunk c+1 is in flight while chunk c feeds the MFMAs
+  float a[4], b0[4], b1[4], an[4], b0n[4], b1n[4];
+  if (k0 < g.K) {
+    load_operand<A_KC>(A, g.lda, m0 + i, g.M, k0 + 4 * kg, g.K, vec_a, a);
+    load_operand<B_KC>(B, g.ldb, n0 + i, g.N, k0 + 4 * kg, g.K, vec_b, b0);
+    load_operand<B_KC>(B, g.ldb, n0 + 16 + i, g.N, k0 + 4 * kg, g.K, vec_b, b1);
+  }
+  for (; k0 < g.K; k0 += kstep) {
+    const int kn = k0 + kstep + 4 * kg;
+    const bool more = k0 + kstep < g.K;
+    if (more) {
+      load_operand<A_KC>(A, g.lda, m0 + i, g.M, kn, g.K, vec_a, an);
+      load_operand<B_KC>(B, g.ldb, n0 + i, g.N, kn, g.K, vec_b, b0n);
+      load_operand<B_KC>(B, g.ldb, n0 + 16 + i, g.N, kn, g.K, vec_b, b1n);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       acc0 = mfma16(a[t], b0[t], acc0);
       acc1 = mfma16(a[t], b1[t], acc1);
     }
     if (!A_KC) colsum += (a[0] + a[1]) + (a[2] + a[3]);
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a[t] = an[t]; b0[t] = b0n[t]; b1[t] = b1n[t]; }
+    }
+  }
+
+  if (SPLITK) {
+    __shared__ float part[4][64][9];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[wave][lane][r] = acc0[r]; part[wave][lane][4 + r] = acc1[r]; }
+    part[wave][lane][8] = colsum;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc0[r] = (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
+      acc1[r] = (part[0][lane][4 + r] + part[1][lane][4 + r]) +
+                (part[2][lane][4 + r] + part[3][lane][4 + r]);
+    }
+    colsum = (part[0][lane][8] + part[1][lane][8]) + (part[2][lane][8] + part[3][lane][8]);
   }
 
   if (!A_KC && g.colsum != nullptr && tn == 0) {
@@ -93,17 +127,21 @@ int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStrea
   TONIC_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && batch > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "gemm: bad argument (M=%d N=%d K=%d)", g.M, g.N, g.K);
   const int tiles = ((g.M + 15) / 16) * ((g.N + 31) / 32);
-  const dim3 grid((tiles + 3) / 4, 1, batch), block(256);
-  if (mode_a == 'c' && mode_b == 'c')
-    hipLaunchKernelGGL((gemm16_kernel<true, true>), grid, block, 0, stream, g);
-  else if (mode_a == 'c' && mode_b == 's')
-    hipLaunchKernelGGL((gemm16_kernel<true, false>), grid, block, 0, stream, g);
-  else if (mode_a == 's' && mode_b == 's')
-    hipLaunchKernelGGL((gemm16_kernel<false, false>), grid, block, 0, stream, g);
+  const bool splitk = g.K >= 256 && tiles <= 1024;      // long contraction, few tiles
+  const dim3 grid(splitk ? tiles : (tiles + 3) / 4, 1, batch), block(256);
+#define TONIC_GEMM_LAUNCH(AKC, BKC)                                                          \
+  do {                                                                                       \
+    if (splitk) hipLaunchKernelGGL((gemm16_kernel<AKC, BKC, true>), grid, block, 0, stream, g);  \
+    else hipLaunchKernelGGL((gemm16_kernel<AKC, BKC, false>), grid, block, 0, stream, g);       \
+  } while (0)
+  if (mode_a == 'c' && mode_b == 'c') TONIC_GEMM_LAUNCH(true, true);
+  else if (mode_a == 'c' && mode_b == 's') TONIC_GEMM_LAUNCH(true, false);
+  else if (mode_a == 's' && mode_b == 's') TONIC_GEMM_LAUNCH(false, false);
   else {
     set_error("gemm: unsupported operand layouts '%c%c'", mode_a, mode_b);
     return TONIC_ERR_INVALID_ARGUMENT;
   }
+#undef TONIC_GEMM_LAUNCH
   TONIC_CHECK_LAUNCH("gemm16");
   return TONIC_OK;
 }

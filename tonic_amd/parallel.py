@@ -22,9 +22,10 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" is RCCL on ROCm
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        backend = os.environ.get('TONIC_AMD_BACKEND') or (
+            'nccl' if torch.cuda.is_available() else 'gloo')           # "nccl" is RCCL on ROCm
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     dist.init_process_group(backend=backend)
     return rank(), world_size()
 
