@@ -115,7 +115,7 @@ int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
  *   actor  stats: {loss_sum, kl_sum, clipped_count, n*entropy, n*mean_sigma, n, 0, 0}
  *   critic stats: {squared_error_sum, value_sum, 0, 0, 0, n, 0, 0}        (n = local samples)
  * d_skip_flag (int32, may be NULL): when *d_skip_flag != 0 the kernels exit immediately
- * and leave d_grad_sums untouched (device-side replacement of the per-iteration
+ * and d_grad_sums is zero-filled (device-side replacement of the per-iteration
  * `stop.numpy()` host sync of tonic/torch/agents/ppo.py:45-46).
  *
  * tonic_ppo_actor_grad replaces: tonic/torch/updaters/actors.py:70-99 (ClippedRatio

@@ -722,11 +722,15 @@ template <bool ACTOR>
 __global__ __launch_bounds__(kReduceWaves * 64) void reduce_partials_kernel(
     const float* partials, int nblocks, int pstride, int P, const float* params,
     float* grad_sums, int O, int A, float entropy_coeff, double nloc, const int32_t* skip) {
-  if (skip != nullptr && *skip != 0) return;
   __shared__ double slices[kReduceWaves][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   const bool active = p < P + kStatSlots;
+  if (skip != nullptr && *skip != 0) {
+    // Skipped step: publish zeros, so a multi-GPU all-reduce of the (ignored) buffer stays finite.
+    if (wave == 0 && active) grad_sums[p] = 0.f;
+    return;
+  }
   const int per = (nblocks + kReduceWaves - 1) / kReduceWaves;
   const int b0 = wave * per, b1 = min(b0 + per, nblocks);
   double acc = 0.0;

@@ -219,10 +219,24 @@ class PPO(A2C):
             self._infos = torch.zeros(2, iterations, updaters.INFO_WIDTH, device=self.device)
         self._infos.zero_()
         actor.reset_stop()
+        world = actor.world_size
+        if world > 1 and getattr(self, '_joint_grads', None) is None:
+            # one all-reduce per iteration for BOTH networks: [actor sums|8 stats|critic sums|8 stats]
+            na, nc = actor.count + updaters.INFO_WIDTH, critic.count + updaters.INFO_WIDTH
+            self._joint_grads = torch.zeros(na + nc, device=self.device)
+            actor.share_gradient_buffer(self._joint_grads[:na])
+            critic.share_gradient_buffer(self._joint_grads[na:])
+        n = batch['observations'].shape[0]
         for it in range(iterations):
-            actor.enqueue(batch['observations'], batch['actions'], raw_advantages,
-                          replay.adv_stats, batch['log_probs'], self._infos[0, it])
-            critic.enqueue(batch['observations'], batch['returns'], self._infos[1, it])
+            actor.enqueue_grad(batch['observations'], batch['actions'], raw_advantages,
+                               replay.adv_stats, batch['log_probs'])
+            critic.enqueue_grad(batch['observations'], batch['returns'])
+            if world > 1:
+                # After the KL stop the actor half is stale on every rank alike and ignored
+                # (tonic_adam_step is skipped by the same device flag on all ranks).
+                torch.distributed.all_reduce(self._joint_grads)          # RCCL over xGMI
+            actor.enqueue_step(n, replay.adv_stats, self._infos[0, it], allreduce=False)
+            critic.enqueue_step(n, self._infos[1, it], allreduce=False)
         return self._infos
 
     def _update(self):

@@ -60,9 +60,15 @@ class _FlatUpdater:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
         return self.workspace
 
+    def share_gradient_buffer(self, buffer):
+        """Makes `grad_sums` a view of a caller-owned buffer so that several updaters' gradient
+        sums travel in ONE all-reduce (the caller then passes allreduce=False to enqueue)."""
+        assert buffer.numel() == self.count + INFO_WIDTH
+        self.grad_sums = buffer
+
     def _step(self, n_global, info_row, adv_stats=None, skip=None, kl_threshold=0.0,
-              entropy_coeff=0.0):
-        if self.world_size > 1:
+              entropy_coeff=0.0, allreduce=True):
+        if self.world_size > 1 and allreduce:
             torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
         h = self.hyper
         _lib.check(self.lib.tonic_adam_step(
@@ -101,19 +107,23 @@ class ClippedRatio(_FlatUpdater):
     def reset_stop(self):
         self.state[1:2].zero_()
 
-    def enqueue(self, observations, actions, advantages, adv_stats, log_probs, info_row,
-                n_global=None):
+    def enqueue_grad(self, observations, actions, advantages, adv_stats, log_probs):
         n = observations.shape[0]
         ws = self._workspace_for(n)
         p = _lib.ptr
-        skip = self.stop_flag_ptr()
         _lib.check(self.lib.tonic_ppo_actor_grad(
             p(self.flat.flat), p(observations), p(actions), p(advantages), p(adv_stats),
             p(log_probs), p(self.grad_sums), n, self.observation_size, self.action_size,
-            float(self.ratio_clip), float(self.entropy_coeff), skip, p(ws), ws.numel(),
-            _lib.current_stream()), 'tonic_ppo_actor_grad')
-        self._step(n_global or n * self.world_size, info_row, adv_stats, skip,
-                   self.kl_threshold, self.entropy_coeff)
+            float(self.ratio_clip), float(self.entropy_coeff), self.stop_flag_ptr(), p(ws),
+            ws.numel(), _lib.current_stream()), 'tonic_ppo_actor_grad')
+
+    def enqueue_step(self, n_local, adv_stats, info_row, allreduce=True):
+        self._step(n_local * self.world_size, info_row, adv_stats, self.stop_flag_ptr(),
+                   self.kl_threshold, self.entropy_coeff, allreduce)
+
+    def enqueue(self, observations, actions, advantages, adv_stats, log_probs, info_row):
+        self.enqueue_grad(observations, actions, advantages, adv_stats, log_probs)
+        self.enqueue_step(observations.shape[0], adv_stats, info_row)
 
     def __call__(self, observations, actions, advantages, log_probs):
         """Drop-in form (actors.py:70-112): `advantages` are final (already normalised)."""
@@ -167,7 +177,7 @@ class VRegression(_FlatUpdater):
             self.observation_size, _lib.current_stream()), 'tonic_value_forward')
         return out
 
-    def enqueue(self, observations, returns, info_row, n_global=None):
+    def enqueue_grad(self, observations, returns):
         n = observations.shape[0]
         ws = self._workspace_for(n)
         mean, std = self.norm_tensors()
@@ -176,7 +186,13 @@ class VRegression(_FlatUpdater):
             p(self.flat.flat), p(mean), p(std), p(observations), p(returns), p(self.grad_sums),
             n, self.observation_size, p(ws), ws.numel(), _lib.current_stream()),
             'tonic_value_regression_grad')
-        self._step(n_global or n * self.world_size, info_row)
+
+    def enqueue_step(self, n_local, info_row, allreduce=True):
+        self._step(n_local * self.world_size, info_row, allreduce=allreduce)
+
+    def enqueue(self, observations, returns, info_row):
+        self.enqueue_grad(observations, returns)
+        self.enqueue_step(observations.shape[0], info_row)
 
     def __call__(self, observations, returns):
         """Drop-in form (critics.py:18-28).  `v` is the pre-step value vector."""
