@@ -87,22 +87,22 @@ def kernel_rooflines(agent):
             p(wsc), wsc.numel(), stream), 'critic')
 
     out = {}
-    for waves in (4,):
-        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+    for waves in (0, 1):          # grad_variant: 0 = 32x32x2 / 1 wave per SIMD, 1 = 16x16x4 / 2 waves
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', waves), 'tuning')
         ws = actor._workspace_for(n)
         wsc = critic._workspace_for(n)
         ms_a, ms_c = time_events(actor_grad, 10), time_events(critic_grad, 10)
         out[waves] = (ms_a, ms_c)
     best = min(out, key=lambda k: out[k][0] + out[k][1])
-    _lib.check(lib.tonic_set_tuning(b'grad_waves', best), 'tuning')
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
     ms_a, ms_c = out[best]
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
-    roof = dict(bound='mfma', kernel='mlp64_grad_kernel<actor> (+reduce_partials)',
+    roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> / mlp64_grad_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                 ms_per_launch=round(ms_a, 4), samples_per_launch=n,
-                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_waves=best,
+                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=best,
                 variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
     roof_critic = dict(bound='mfma', kernel='mlp64_grad_kernel<critic> (+reduce_partials)',
                        achieved=round(tf_c, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',

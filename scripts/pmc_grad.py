@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tonic_amd import _lib
 
 lib = _lib.load()
-waves = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+waves = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-_lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+_lib.check(lib.tonic_set_tuning(b'grad_variant', waves), 'tuning')
 O, A, n = 17, 6, 4096 * 256
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 P = lib.tonic_ppo_actor_param_count(O, A)

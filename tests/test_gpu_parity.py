@@ -144,10 +144,10 @@ def test_value_forward_vs_oracle(lib, O, n):
 
 # ---------------------------------------------------------------------------- gradients
 
-def actor_grad(lib, params, obs, actions, adv, stats, old_lp, waves=None):
+def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
     from tonic_amd import _lib
-    if waves:
-        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+    if variant is not None:
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
     n, O = obs.shape
     A = actions.shape[1]
     P = lib.tonic_ppo_actor_param_count(O, A)
@@ -158,14 +158,14 @@ def actor_grad(lib, params, obs, actions, adv, stats, old_lp, waves=None):
         *[t.data_ptr() for t in keep], out.data_ptr(),
         n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor_grad')
     torch.cuda.synchronize()
-    _lib.check(lib.tonic_set_tuning(b'grad_waves', 4), 'tuning')
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
     return out.cpu().numpy(), P
 
 
-def critic_grad(lib, params, mean, std, obs, returns, waves=None):
+def critic_grad(lib, params, mean, std, obs, returns, variant=None):
     from tonic_amd import _lib
-    if waves:
-        _lib.check(lib.tonic_set_tuning(b'grad_waves', waves), 'tuning')
+    if variant is not None:
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
     n, O = obs.shape
     P = lib.tonic_v_critic_param_count(O)
     out = torch.zeros(P + 8).cuda()
@@ -175,7 +175,7 @@ def critic_grad(lib, params, mean, std, obs, returns, waves=None):
         *[t.data_ptr() for t in keep], out.data_ptr(), n, O, ws.data_ptr(),
         ws.numel(), None), 'critic_grad')
     torch.cuda.synchronize()
-    _lib.check(lib.tonic_set_tuning(b'grad_waves', 4), 'tuning')
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
     return out.cpu().numpy(), P
 
 
@@ -187,9 +187,9 @@ def assert_grads_close(got_sums, want_grads, n, what):
     assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
 
 
-@pytest.mark.parametrize('waves', [4])
+@pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('name', PPO_CASES)
-def test_actor_and_critic_grads_golden_batch(lib, golden, name, waves):
+def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     g = golden(name)
     actor, critic, norm = _params(g, 'pre0/')
     seg = {k: port.flatten_time_major(g[f'u0/segment/{k}']) for k in (
@@ -198,7 +198,7 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, waves):
     # (a) final advantages passed directly (normalise flag 0)
     stats = np.array([0, 1, 0, 0], np.float32)
     got, P = actor_grad(lib, actor, seg['observations'], seg['actions'], seg['advantages'],
-                        stats, seg['log_probs'], waves)
+                        stats, seg['log_probs'], variant)
     want, info = port.clipped_ratio_grads(actor, seg['observations'], seg['actions'],
                                           seg['advantages'], seg['log_probs'])
     assert_grads_close(got[:P], want, n, f'{name} actor grads')
@@ -212,10 +212,10 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, waves):
     raw = seg['returns'] - seg['values']
     stats = np.array([raw.mean(dtype=np.float64), raw.std(dtype=np.float64), 0, 1], np.float32)
     got_b, _ = actor_grad(lib, actor, seg['observations'], seg['actions'], raw, stats,
-                          seg['log_probs'], waves)
+                          seg['log_probs'], variant)
     assert_grads_close(got_b[:P], want, n, f'{name} actor grads (in-kernel normalisation)')
     # critic
-    got_c, Pc = critic_grad(lib, critic, norm[0], norm[1], seg['observations'], seg['returns'], waves)
+    got_c, Pc = critic_grad(lib, critic, norm[0], norm[1], seg['observations'], seg['returns'], variant)
     want_c, info_c = port.value_regression_grads(critic, norm[0], norm[1], seg['observations'],
                                                  seg['returns'])
     assert_grads_close(got_c[:Pc], want_c, n, f'{name} critic grads')
@@ -223,7 +223,8 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, waves):
     np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
 
 
-def test_grads_ratio_clipping_branches(lib):
+@pytest.mark.parametrize('variant', [0, 1])
+def test_grads_ratio_clipping_branches(lib, variant):
     """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
     the still-live ones; ragged n (not a multiple of the 32-sample tile)."""
     rng = np.random.RandomState(5)
@@ -239,12 +240,14 @@ def test_grads_ratio_clipping_branches(lib):
     old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.4).astype(np.float32)
     want, info = port.clipped_ratio_grads(params, obs, actions, adv, old_lp)
     assert 0.2 < info['clip_fraction'] < 0.9
-    got, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32), old_lp)
+    got, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32), old_lp,
+                        variant)
     assert_grads_close(got[:P], want, n, 'clipping branches')
     np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
 
 
-def test_grads_full_size_properties(lib):
+@pytest.mark.parametrize('variant', [0, 1])
+def test_grads_full_size_properties(lib, variant):
     """BASELINE size (N = 4096 x 256): sums are additive over a split of the batch,
     bit-reproducible run to run, and agree with the oracle on a 4096-sample slice."""
     rng = np.random.RandomState(11)
@@ -258,18 +261,18 @@ def test_grads_full_size_properties(lib):
     adv = rng.standard_normal(n).astype(np.float32)
     old_lp = (-6 + rng.standard_normal(n) * 0.2).astype(np.float32)
     stats = np.array([0, 1, 0, 0], np.float32)
-    full, P = actor_grad(lib, params, obs, actions, adv, stats, old_lp)
-    again, _ = actor_grad(lib, params, obs, actions, adv, stats, old_lp)
+    full, P = actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant)
+    again, _ = actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant)
     assert np.array_equal(full, again), 'fixed-order reductions must be bit-reproducible'
     h = n // 2
-    a, _ = actor_grad(lib, params, obs[:h], actions[:h], adv[:h], stats, old_lp[:h])
-    b, _ = actor_grad(lib, params, obs[h:], actions[h:], adv[h:], stats, old_lp[h:])
+    a, _ = actor_grad(lib, params, obs[:h], actions[:h], adv[:h], stats, old_lp[:h], variant)
+    b, _ = actor_grad(lib, params, obs[h:], actions[h:], adv[h:], stats, old_lp[h:], variant)
     both = a.astype(np.float64) + b.astype(np.float64)
     scale = np.abs(full[:P]).max()
     assert np.abs(both[:P] - full[:P]).max() <= 1e-5 * scale
     m = 4096
     want, _ = port.clipped_ratio_grads(params, obs[:m], actions[:m], adv[:m], old_lp[:m])
-    part, _ = actor_grad(lib, params, obs[:m], actions[:m], adv[:m], stats, old_lp[:m])
+    part, _ = actor_grad(lib, params, obs[:m], actions[:m], adv[:m], stats, old_lp[:m], variant)
     assert_grads_close(part[:P], want, m, 'slice of the full batch')
 
 

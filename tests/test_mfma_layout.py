@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import mfma_emulator as emu
+import mfma_emulator16 as emu16
 import numpy_port as port
 
 
@@ -14,8 +15,12 @@ def _random_actor(rng, O, A):
             rng.normal(size=A) * 0.1]
 
 
+EMULATORS = {'32x32x2': emu.emulate_grad, '16x16x4': emu16.emulate_grad16}
+
+
+@pytest.mark.parametrize('variant', list(EMULATORS))
 @pytest.mark.parametrize('O,A,n', [(17, 6, 70), (3, 1, 33), (28, 8, 64)])
-def test_actor_grad_layout(O, A, n):
+def test_actor_grad_layout(O, A, n, variant):
     rng = np.random.RandomState(O)
     params = [p.astype(np.float32) for p in _random_actor(rng, O, A)]
     obs = rng.normal(size=(n, O)).astype(np.float32)
@@ -26,7 +31,7 @@ def test_actor_grad_layout(O, A, n):
     grads, stats = port.clipped_ratio_grads(params, obs, actions, adv, old_lp)
     data = dict(observations=obs, actions=actions, advantages=adv, log_probs=old_lp,
                 clip=(np.float32(0.8), np.float32(1.2)))
-    G, P = emu.emulate_grad([p.astype(np.float64) for p in params], O, A, True, data, n)
+    G, P = EMULATORS[variant]([p.astype(np.float64) for p in params], O, A, True, data, n)
     assert P == sum(g.size for g in grads)
     # the kernel leaves d loss / d sigma in the log_scale slot (chain rule in the reducer)
     _, dscale_dls = port.gaussian_scale(params[4])
@@ -41,8 +46,9 @@ def test_actor_grad_layout(O, A, n):
     assert G[P + 5] == n
 
 
+@pytest.mark.parametrize('variant', list(EMULATORS))
 @pytest.mark.parametrize('O,n', [(17, 70), (3, 5), (28, 96)])
-def test_critic_grad_layout(O, n):
+def test_critic_grad_layout(O, n, variant):
     rng = np.random.RandomState(100 + O)
     params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
               rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
@@ -54,8 +60,8 @@ def test_critic_grad_layout(O, n):
     returns = rng.normal(size=n).astype(np.float32)
     grads, stats = port.value_regression_grads(params, mean, std, obs, returns)
     data = dict(observations=obs, returns=returns)
-    G, P = emu.emulate_grad([p.astype(np.float64) for p in params], O, 1, False, data, n,
-                            norm=(mean.astype(np.float64), std.astype(np.float64)))
+    G, P = EMULATORS[variant]([p.astype(np.float64) for p in params], O, 1, False, data, n,
+                              norm=(mean.astype(np.float64), std.astype(np.float64)))
     want = np.concatenate([g.reshape(-1) for g in grads]).astype(np.float64) * n
     np.testing.assert_allclose(G[:P], want, rtol=2e-4, atol=2e-4 * np.abs(want).max())
     np.testing.assert_allclose(G[P + 0] / n, stats['loss'], rtol=1e-4)

@@ -46,6 +46,7 @@ SIGNATURES = {
                           [c_vp, c_i64, c_vp]),
     'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 7 + [c_i32] * 4 + [c_f64] +
                            [c_vp, c_i64, c_vp]),
+    'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_gemm_f32': (ctypes.c_int, [ctypes.c_char_p] + [c_vp] * 6 + [c_i32] * 8 + [c_f64, c_vp]),
 }
 

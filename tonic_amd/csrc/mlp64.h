@@ -1,0 +1,47 @@
+// Declarations shared by the two fused-MLP kernel families (mlp64.hip: 32x32x2 tiles, one
+// wave per SIMD; mlp64x16.hip: 16x16x4 tiles, two waves per SIMD).
+#pragma once
+#include "common.h"
+
+namespace tonic {
+
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
+constexpr float kEntropyConst = 1.41893853320467274178f; // 0.5 + 0.5*log(2*pi)
+
+struct MlpArgs {
+  const float* params;
+  const float* obs;
+  const float* actions;     // actor grad / unused
+  const float* adv;         // raw advantages
+  const float* adv_stats;   // {mean, std, all_zero, normalise}
+  const float* old_logp;
+  const float* returns;     // critic grad
+  const float* norm_mean;   // critic
+  const float* norm_std;
+  const float* eps;         // act
+  float* out0;              // act: actions, value: values, grad: partials
+  float* out1;              // act: log_probs
+  const int32_t* skip;
+  int64_t n;
+  int O, A;
+  float clip_lo, clip_hi;
+  int pstride;
+  int skew;                 // initial phase offset (x ~8k cycles) of the second wave per SIMD
+};
+
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): one v_exp_f32 + one v_rcp_f32, no
+// branches (the libm tanhf is ~40 instructions with a divergent branch).  Absolute error
+// <= ~2e-7 over the whole range, i.e. float32 rounding level of the surrounding dot products.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.8853900817779268f);   // 2*log2(e)
+  const float y = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+  return copysignf(y, x);
+}
+
+// mlp64x16.hip
+bool grad16_supported(int O, int A, bool actor);
+int grad16_blocks(int64_t n);
+int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args);
+int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args);
+
+}  // namespace tonic

@@ -27,7 +27,7 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "mlp64.h"
 
 namespace tonic {
 
@@ -36,9 +36,6 @@ constexpr int TS = 36;  // floats per row of the per-wave transpose scratch
 __host__ __device__ constexpr int feat(int q, int h) {
   return 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
 }
-
-constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
-constexpr float kEntropyConst = 1.41893853320467274178f; // 0.5 + 0.5*log(2*pi)
 
 template <int KS1, int AP, bool BWD, int WAVES>
 struct Lds {
@@ -56,26 +53,6 @@ struct Lds {
   static constexpr int WAVE_FLOATS = BWD ? (2 * T_FLOATS + DO_FLOATS) : 0;
   static constexpr int TOTAL = WAVE0 + WAVES * WAVE_FLOATS;
   static constexpr int BYTES = TOTAL * 4;
-};
-
-struct MlpArgs {
-  const float* params;
-  const float* obs;
-  const float* actions;     // actor grad / unused
-  const float* adv;         // raw advantages
-  const float* adv_stats;   // {mean, std, all_zero, normalise}
-  const float* old_logp;
-  const float* returns;     // critic grad
-  const float* norm_mean;   // critic
-  const float* norm_std;
-  const float* eps;         // act
-  float* out0;              // act: actions, value: values, grad: partials
-  float* out1;              // act: log_probs
-  const int32_t* skip;
-  int64_t n;
-  int O, A;
-  float clip_lo, clip_hi;
-  int pstride;
 };
 
 // ---------------------------------------------------------------------------- staging
@@ -155,15 +132,6 @@ __device__ __forceinline__ void stage_weights(float* lds, const MlpArgs& a) {
 
 // --------------------------------------------------------------------- MFMA building blocks
 
-// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): one v_exp_f32 + one v_rcp_f32, no
-// branches (the libm tanhf is ~40 instructions with a divergent branch).  Absolute error
-// <= ~2e-7 over the whole range, i.e. float32 rounding level of the surrounding dot products.
-__device__ __forceinline__ float tanh_fast(float x) {
-  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.8853900817779268f);   // 2*log2(e)
-  const float y = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
-  return copysignf(y, x);
-}
-
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -228,18 +196,18 @@ __device__ __forceinline__ void gather_F(const float* T, int t, int c, int kh, f
   }
 }
 
+// Branch-free (see mlp64x16.hip): clamped addresses + select, never a load under a lane branch.
 template <int KS1, bool NORMALISE>
 __device__ __forceinline__ void load_obs(const MlpArgs& a, const float* norm, int64_t ns,
                                          bool valid, int h, float (&x)[KS1]) {
+  const int64_t nc = valid ? ns : a.n - 1;
 #pragma unroll
   for (int st = 0; st < KS1; ++st) {
     const int k = 2 * st + h;
-    float v = 0.f;
-    if (valid && k < a.O) {
-      v = a.obs[ns * a.O + k];
-      if (NORMALISE) v = (v - norm[k]) / norm[2 * KS1 + k];   // mean_stds.py:36
-    }
-    x[st] = v;
+    const int kc = k < a.O ? k : a.O - 1;
+    float v = a.obs[nc * a.O + kc];
+    if (NORMALISE) v = (v - norm[kc]) / norm[2 * KS1 + kc];   // mean_stds.py:36
+    x[st] = v * ((valid && k < a.O) ? 1.f : 0.f);   // mask-multiply: a select lets the load sink into a branch
   }
 }
 
@@ -288,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void ppo_act_kernel(MlpArgs a) {
         const float loc = tanh_fast(z[aa]);
         const float sigma = lds[L::HC + aa * 4 + 1];
         float act = loc;
-        if (a.eps != nullptr && valid) act = loc + sigma * a.eps[ns * a.A + aa];
+        if (a.eps != nullptr) act = loc + sigma * a.eps[(valid ? ns : a.n - 1) * a.A + aa];
         const float d = act - loc;
         logp += -(d * d) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
         if (valid && h == 0) a.out0[ns * a.A + aa] = act;
@@ -378,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void ppo_collect_kernel(CollectArgs c) 
         const float loc = tanh_fast(z[aa]);
         const float sigma = lds[L::HC + aa * 4 + 1];
         float act = loc;
-        if (a.eps != nullptr && valid) act = loc + sigma * a.eps[ns * A + aa];
+        if (a.eps != nullptr) act = loc + sigma * a.eps[(valid ? ns : W - 1) * A + aa];
         const float d = act - loc;
         logp += -(d * d) * lds[L::HC + aa * 4 + 2] - lds[L::HC + aa * 4 + 3];
         if (valid && h == 0) {
@@ -462,19 +430,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
     const int64_t ns = tile * 32 + s;
     in.valid = ns < a.n;
     load_obs<KS1, !ACTOR>(a, lds + L::NORM, ns, in.valid, h, in.x);
+    const int64_t nc = in.valid ? ns : a.n - 1;
     in.adv = 0.f; in.old_lp = 0.f; in.ret = 0.f;
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) in.act[aa] = 0.f;
-    if (in.valid) {
-      if (ACTOR) {
+    if (ACTOR) {
 #pragma unroll
-        for (int aa = 0; aa < AP; ++aa)
-          if (aa < A) in.act[aa] = a.actions[ns * A + aa];
-        in.adv = a.adv[ns];
-        in.old_lp = a.old_logp[ns];
-      } else {
-        in.ret = a.returns[ns];
-      }
+      for (int aa = 0; aa < AP; ++aa) in.act[aa] = a.actions[nc * A + (aa < A ? aa : A - 1)];
+      in.adv = a.adv[nc];
+      in.old_lp = a.old_logp[nc];
+    } else {
+      in.ret = a.returns[nc];
     }
   };
 
@@ -507,7 +473,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
         }
       }
       const float old_lp = valid ? cur.old_lp : logp;
-      float adv = cur.adv;
+      float adv = valid ? cur.adv : 0.f;
       if (adv_norm) adv = (adv - adv_mean) / adv_std;             // segments.py:45
       const float ratio = expf(logp - old_lp);
       const float clipped_ratio = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
@@ -790,6 +756,10 @@ constexpr int kMaxGradBlocks = 256;   // one workgroup per CU
 // Waves per workgroup of the fused grad kernel: one wave per SIMD with the whole 512-register
 // file (a two-waves-per-SIMD build spilled >100 registers and measured no faster).
 int g_grad_waves = 4;
+// 0 = 32x32x2 tiles, one wave per SIMD (mlp64_grad_kernel); 1 = 16x16x4 tiles, two waves per
+// SIMD (mlp64x16.hip).
+int g_grad_variant = 1;
+int g_grad_skew = 1;       // mlp64x16: phase skew of waves 4-7, in units of s_sleep(127) (~8k cycles)
 
 int ks1_bucket(int O) {
   if (O <= 4) return 2;
@@ -875,6 +845,18 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     TONIC_REQUIRE(value == 4, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_waves must be 4 (the only variant built), got %d", value);
     g_grad_waves = value;
+    return TONIC_OK;
+  }
+  if (strcmp(key, "grad_skew") == 0) {
+    TONIC_REQUIRE(value >= 0 && value <= 64, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_skew must be in [0, 64], got %d", value);
+    g_grad_skew = value;
+    return TONIC_OK;
+  }
+  if (strcmp(key, "grad_variant") == 0) {
+    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_variant must be 0 or 1, got %d", value);
+    g_grad_variant = value;
     return TONIC_OK;
   }
   set_error("tonic_set_tuning: unknown key '%s'", key);
@@ -1004,22 +986,25 @@ extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_
 
 extern "C" int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_count) {
   const int64_t pstride = round_up(param_count + kStatSlots, 64);
-  return (int64_t)grad_blocks(n) * pstride * (int64_t)sizeof(float);
+  const int blocks = grad_blocks(n) > grad16_blocks(n) ? grad_blocks(n) : grad16_blocks(n);
+  return (int64_t)blocks * pstride * (int64_t)sizeof(float);
 }
 
 template <bool ACTOR>
 static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coeff,
                     void* d_workspace, int64_t workspace_bytes, void* stream) {
-  const int blocks = grad_blocks(a.n);
+  const bool use16 = g_grad_variant == 1 && grad16_supported(a.O, a.A, ACTOR);
+  const int blocks = use16 ? grad16_blocks(a.n) : grad_blocks(a.n);
   const int64_t pstride = round_up(P + kStatSlots, 64);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= blocks * pstride * (int64_t)sizeof(float),
                 TONIC_ERR_WORKSPACE, "grad workspace too small: %lld < %lld",
                 (long long)workspace_bytes, (long long)(blocks * pstride * sizeof(float)));
   a.out0 = static_cast<float*>(d_workspace);
   a.pstride = (int)pstride;
+  a.skew = g_grad_skew;
   const int ap = ACTOR ? ap_bucket(a.A) : 1;
   hipStream_t st = as_stream(stream);
-  const int rc = dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
+  const int rc = use16 ? launch_grad16(ACTOR, blocks, st, a) : dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
     constexpr int KS1 = decltype(ks)::value;
     if constexpr (!ACTOR) {
       return launch_grad<KS1, 1, false>(blocks, st, a);
@@ -1059,6 +1044,29 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
   return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
                         (float)entropy_coeff,
                         d_workspace, workspace_bytes, stream);
+}
+
+// Developer tool: per-phase s_memtime totals of the 8 waves of workgroup 0 of the 16x16x4 actor
+// grad kernel (O <= 20, A <= 6 build).  d_phase_cycles: uint64[8 waves][12 phases].
+extern "C" int tonic_debug_grad16_phases(const float* d_actor_params, const float* d_observations,
+                                         const float* d_actions, const float* d_advantages,
+                                         const float* d_adv_stats, const float* d_old_log_probs,
+                                         int64_t n, int32_t O, int32_t A, void* d_workspace,
+                                         int64_t workspace_bytes, uint64_t* d_phase_cycles,
+                                         void* stream) {
+  TONIC_REQUIRE(O == 17 && A == 6 && d_phase_cycles && d_workspace,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_debug_grad16_phases: unsupported shape");
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.actions = d_actions;
+  a.adv = d_advantages; a.adv_stats = d_adv_stats; a.old_logp = d_old_log_probs;
+  a.n = n; a.O = O; a.A = A; a.clip_lo = 0.8f; a.clip_hi = 1.2f;
+  a.out0 = static_cast<float*>(d_workspace);
+  a.out1 = reinterpret_cast<float*>(d_phase_cycles);
+  a.pstride = (int)round_up(tonic_ppo_actor_param_count(O, A) + kStatSlots, 64);
+  a.skew = 0;
+  TONIC_REQUIRE(workspace_bytes >= (int64_t)grad16_blocks(n) * a.pstride * 4, TONIC_ERR_WORKSPACE,
+                "tonic_debug_grad16_phases: workspace too small");
+  return launch_grad16_probe(grad16_blocks(n), as_stream(stream), a);
 }
 
 extern "C" int tonic_value_regression_grad(const float* d_critic_params,

@@ -1,0 +1,640 @@
+// Fused forward + loss + backward of the 2x64-tanh PPO networks on 16x16x4 fp32 MFMA tiles,
+// TWO waves per SIMD (8 waves / workgroup, <= 256 registers per wave).
+//
+// Same mathematics and the same flat gradient image as mlp64.hip's mlp64_grad_kernel (see the
+// reference citations there); what changes is the tiling.  PMC on the 32x32x2 version
+// (profiles/r01_pmc_grad.md) showed the MFMA pipe busy only 42 % of the time: with one wave per
+// SIMD the VALU phases (tanh, Gaussian head, PPO loss) and the LDS transposes of a tile cannot
+// overlap its MFMA phases.  A 16-sample tile halves every per-wave register array
+// (activations 16 instead of 32 registers, F-layout operands 4 per feature tile), which lets two
+// waves share a SIMD so that one wave's MFMA chain runs under the other's VALU / LDS / HBM work.
+//
+// Layouts (v_mfma_f32_16x16x4_f32: A lane l -> A[i = l&15][k = l>>4], B lane l -> B[k = l>>4][j = l&15],
+// D lane l, reg r -> D[row = 4*(l>>4) + r][col = l&15]):
+//   S layout: lane = (sample s = lane&15, group g = lane>>4); register q in [0,16) holds hidden
+//             feature feat16(q, g) = 16*(q>>2) + 4*g + (q&3).  Transposed products
+//             D[out][sample] = sum_k W[out][k] X^T[k][sample] keep the chains x->h1->h2 and
+//             dz2->dh1 in registers: MFMA step q contracts feature feat16(q, g) from group g.
+//   F layout: lane = (feature i = lane&15 of a 16-feature tile, g); 4 registers = samples 4g..4g+3.
+//             Operands of the weight-gradient MFMAs (contraction over the tile's 16 samples),
+//             produced by a transpose through a private LDS tile (row stride 24 floats:
+//             conflict-free ds_read_b128).
+#include "mlp64.h"
+
+namespace tonic {
+
+constexpr int TS16 = 24;
+constexpr int kWaves16 = 8;
+
+__host__ __device__ constexpr int feat16(int q, int g) { return 16 * (q >> 2) + 4 * g + (q & 3); }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int KS1, int AP>
+struct Lds16 {
+  static constexpr int W1I = 0;                          // [4][KS1][64]       (b32 per step)
+  static constexpr int W2S = W1I + 4 * KS1 * 64;         // [4][4][64][4]      (b128 per 4 steps)
+  static constexpr int W2B = W2S + 4096;                 // [4][4][64][4]
+  static constexpr int B1P = W2B + 4096;                 // [4 groups][16]
+  static constexpr int B2P = B1P + 64;
+  static constexpr int W3P = B2P + 64;                   // [AP][4 groups][16]
+  static constexpr int HC = W3P + AP * 64;               // [8][8] head constants
+  static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
+  static constexpr int WAVE0 = (NORM + 8 * KS1 + 3) / 4 * 4;
+  static constexpr int T_FLOATS = 64 * TS16;
+  static constexpr int DO_FLOATS = 16 * 16;
+  static constexpr int WAVE_FLOATS = 2 * T_FLOATS + DO_FLOATS;
+  static constexpr int TOTAL = WAVE0 + kWaves16 * WAVE_FLOATS;
+  static constexpr int BYTES = TOTAL * 4;
+};
+
+template <int KS1, int AP, bool ACTOR>
+__device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
+  using L = Lds16<KS1, AP>;
+  const int tid = threadIdx.x, nth = kWaves16 * 64;
+  const int O = a.O, A = a.A;
+  const float* W1 = a.params;
+  const float* b1 = W1 + 64 * O;
+  const float* W2 = b1 + 64;
+  const float* b2 = W2 + 64 * 64;
+  const float* tail = b2 + 64;
+  const float* W3 = ACTOR ? tail + A : tail;
+  const float* b3 = W3 + (ACTOR ? A * 64 : 64);
+  for (int idx = tid; idx < 4 * KS1 * 64; idx += nth) lds[L::W1I + idx] = 0.f;
+  __syncthreads();
+  for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
+    const int row = gi / O, k = gi - row * O;
+    const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
+    lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi];
+  }
+  for (int gi = tid; gi < 64 * 64; gi += nth) {
+    const int row = gi >> 6, col = gi & 63;
+    const float w = W2[gi];
+    {  // forward image: A row = output feature `row`, k = input feature `col`
+      const int T = row >> 4, i = row & 15;
+      const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
+      lds[L::W2S + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+    }
+    {  // backward image: A row = input feature `col`, k = output feature `row`
+      const int T = col >> 4, i = col & 15;
+      const int st = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
+      lds[L::W2B + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+    }
+  }
+  for (int idx = tid; idx < 64; idx += nth) {
+    const int g = idx >> 4, q = idx & 15;
+    lds[L::B1P + idx] = b1[feat16(q, g)];
+    lds[L::B2P + idx] = b2[feat16(q, g)];
+  }
+  for (int idx = tid; idx < AP * 64; idx += nth) {
+    const int aa = idx >> 6, g = (idx >> 4) & 3, q = idx & 15;
+    const int nout = ACTOR ? A : 1;
+    lds[L::W3P + idx] = aa < nout ? W3[aa * 64 + feat16(q, g)] : 0.f;
+  }
+  for (int idx = tid; idx < 8; idx += nth) {
+    float bias = 0.f, sigma = 1.f, half_inv_var = 0.f, logc = 0.f;
+    if (ACTOR) {
+      if (idx < A) {
+        bias = b3[idx];
+        const float ls = tail[idx];
+        const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+        sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);
+        half_inv_var = 1.0f / (2.0f * (sigma * sigma));
+        logc = logf(sigma) + kLogSqrt2Pi;
+      }
+    } else if (idx == 0) {
+      bias = b3[0];
+    }
+    lds[L::HC + idx * 8 + 0] = bias;
+    lds[L::HC + idx * 8 + 1] = sigma;
+    lds[L::HC + idx * 8 + 2] = half_inv_var;
+    lds[L::HC + idx * 8 + 3] = logc;
+    lds[L::HC + idx * 8 + 4] = 1.0f / sigma;
+    lds[L::HC + idx * 8 + 5] = 2.0f * half_inv_var;
+    lds[L::HC + idx * 8 + 6] = 0.f;
+    lds[L::HC + idx * 8 + 7] = 0.f;
+  }
+  if (!ACTOR) {
+    for (int idx = tid; idx < 4 * KS1; idx += nth) {
+      lds[L::NORM + idx] = idx < O ? a.norm_mean[idx] : 0.f;
+      lds[L::NORM + 4 * KS1 + idx] = idx < O ? a.norm_std[idx] : 1.f;
+    }
+  }
+}
+
+// v + (the same lane of the other three 16-lane groups): two v_permlane*_swap, no LDS round trip.
+__device__ __forceinline__ float sum_groups(float v) {
+  const unsigned bits = __float_as_uint(v);
+  auto p16 = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+  v = __uint_as_float(p16[0]) + __uint_as_float(p16[1]);
+  const unsigned b2 = __float_as_uint(v);
+  auto p32 = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+  return __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
+}
+
+__device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16]) {
+  float t[16], d[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out[q] = acc[q >> 2][q & 3];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(fabsf(out[q]) * -2.8853900817779268f);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) d[q] = __builtin_amdgcn_rcpf(1.f + t[q]);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out[q] = copysignf((1.f - t[q]) * d[q], out[q]);
+}
+
+// acc[T] (+)= sum over 16 steps of W-image chunk x in[]: 64 in-features, 64 out-features.
+__device__ __forceinline__ void chain64(const float* wimg, const float (&in)[16], int lane,
+                                        f32x4 (&acc)[4]) {
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(wimg);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x4 w[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) w[T] = w4[(T * 4 + c) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int T = 0; T < 4; ++T) acc[T] = mfma16(w[T][e], in[4 * c + e], acc[T]);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_bias16(const float* bimg, int g, f32x4 (&acc)[4]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(bimg + g * 16);
+#pragma unroll
+  for (int T = 0; T < 4; ++T) acc[T] = p[T];
+}
+
+__device__ __forceinline__ void scatter_S16(float* T, const float (&v)[16], int s, int g) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) T[feat16(q, g) * TS16 + s] = v[q];
+}
+
+__device__ __forceinline__ f32x4 gather_F16(const float* T, int tile, int i, int g) {
+  return *reinterpret_cast<const f32x4*>(T + (16 * tile + i) * TS16 + 4 * g);
+}
+
+// PROBE builds (developer tool, tonic_debug_grad16_phases) stamp s_memtime at phase boundaries of
+// the tile loop and dump per-phase cycle totals of every wave of workgroup 0.
+__device__ __forceinline__ unsigned long long probe_clock() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);      // pin the stamp: nothing may be scheduled across it
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PHASE(k)                                              \
+  do {                                                        \
+    if (PROBE) {                                              \
+      const unsigned long long now__ = probe_clock();         \
+      ph[k] += now__ - last;                                  \
+      last = now__;                                           \
+    }                                                         \
+  } while (0)
+
+template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, bool PROBE = false>
+__global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs a) {
+  using L = Lds16<KS1, AP>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (a.skip != nullptr && *a.skip != 0) return;
+  stage_weights16<KS1, AP, ACTOR>(lds, a);
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
+  const int i = s;   // feature index inside a 16-feature tile when the lane acts in F layout
+  float* TA = lds + L::WAVE0 + wave * L::WAVE_FLOATS;
+  float* TB = TA + L::T_FLOATS;
+  float* DO = TB + L::T_FLOATS;
+  const int O = a.O;
+  const int A = EXACT ? AP : a.A;      // EXACT: the action count is the template bucket
+
+  float adv_mean = 0.f, adv_std = 1.f;
+  bool adv_norm = false;
+  if (ACTOR) {
+    adv_mean = a.adv_stats[0];
+    adv_std = a.adv_stats[1];
+    adv_norm = a.adv_stats[3] != 0.f;
+  }
+
+  // dW1: XT full 16-column tiles on MFMA + XR (<= 4) remainder columns on VALU (O = 17 would
+  // otherwise pay a whole padded tile — 16 registers and 16 MFMAs per tile — for one column).
+  f32x4 gW2[4][4], gW1[4][XT], gW3[4];
+  float gW1r[4][XR > 0 ? XR : 1];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    gW3[x] = zero4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) gW2[x][y] = zero4;
+#pragma unroll
+    for (int y = 0; y < XT; ++y) gW1[x][y] = zero4;
+#pragma unroll
+    for (int y = 0; y < (XR > 0 ? XR : 1); ++y) gW1r[x][y] = 0.f;
+  }
+  float gb1[4] = {0.f, 0.f, 0.f, 0.f}, gb2[4] = {0.f, 0.f, 0.f, 0.f};
+  // Column sums of the per-sample head gradients (db3 = sum dz, d loss/d sigma) ride on the dW3
+  // MFMAs: one more chain against a B operand of ones (rows 0..7 -> db3[a], rows 8..15 -> dsigma[a]).
+  f32x4 gHead = {0.f, 0.f, 0.f, 0.f};
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
+
+  // Two waves share a SIMD and run the same MFMA / VALU phase sequence.  Started together they
+  // convoy (both in an MFMA phase, then both in a VALU phase: the matrix pipe idles > 50 %), and
+  // fair arbitration preserves the offset between them — so give the second-dispatched half of
+  // the workgroup an initial phase skew of about half a tile.
+  if (__builtin_amdgcn_readfirstlane(wave) >= kWaves16 / 2) {
+    for (int k = 0; k < a.skew; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // Per-sample inputs, branch-free: out-of-range lanes read a clamped (valid) address and the
+  // value is discarded by a select.  (A load under `if (valid)` becomes an exec-masked branch
+  // with its own s_waitcnt vmcnt(0): eight serialised HBM round trips per tile.)
+  struct TileIn {
+    float x[KS1];
+    float act[AP];
+    float adv, lp, ret;
+  };
+  auto load_tile = [&](int64_t t, TileIn& in) {
+    const int64_t nsl = t * 16 + s;
+    const bool ok = nsl < a.n;
+    const int64_t nc = ok ? nsl : a.n - 1;
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) {
+      const int k = 4 * st + g;
+      const int kc = k < O ? k : O - 1;
+      in.x[st] = a.obs[nc * O + kc];      // RAW: any arithmetic here would wait for the load now
+    }
+    in.adv = 0.f; in.lp = 0.f; in.ret = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) in.act[aa] = 0.f;
+    if (ACTOR) {
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) in.act[aa] = a.actions[nc * A + (aa < A ? aa : A - 1)];
+      in.adv = a.adv[nc];
+      in.lp = a.old_logp[nc];
+    } else {
+      in.ret = a.returns[nc];
+    }
+  };
+
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last = PROBE ? probe_clock() : 0ull;
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int64_t tile_stride = (int64_t)gridDim.x * kWaves16;
+  TileIn cur, nxt;
+  int64_t tile = (int64_t)blockIdx.x * kWaves16 + wave;
+  if (tile < ntiles) load_tile(tile, cur);
+  for (; tile < ntiles; tile += tile_stride) {
+    PHASE(11);                                       // loop overhead / previous tail
+    const int64_t ns = tile * 16 + s;
+    const bool valid = ns < a.n;
+    const bool counted = valid && g == 0;
+
+    // consume the prefetched raw inputs: normalise (critic) and zero the padding with a 0/1
+    // multiply (a select would let the compiler sink the load into an exec-masked branch)
+    float x[KS1];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) {
+      const int k = 4 * st + g;
+      const int kc = k < O ? k : O - 1;
+      float v = cur.x[st];
+      if (!ACTOR) v = (v - lds[L::NORM + kc]) / lds[L::NORM + 4 * KS1 + kc];
+      x[st] = v * ((valid && k < O) ? 1.f : 0.f);
+    }
+    float (&in_act)[AP] = cur.act;
+    const float in_adv = cur.adv, in_lp = cur.lp, in_ret = cur.ret;
+    // next tile's inputs are requested now and consumed one iteration later: ~6k cycles of HBM
+    // latency per tile (measured with the phase probes) disappear behind this tile's work
+    if (tile + tile_stride < ntiles) load_tile(tile + tile_stride, nxt);
+
+    // ---- forward
+    float h1[16], h2[16], z[AP], dzl[AP];
+    {
+      f32x4 acc[4];
+      load_bias16(lds + L::B1P, g, acc);
+#pragma unroll
+      for (int st = 0; st < KS1; ++st) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+          acc[T] = mfma16(lds[L::W1I + (T * KS1 + st) * 64 + lane], x[st], acc[T]);
+      }
+      PHASE(0);                                      // input loads + layer-1 chain issued
+      tanh16(acc, h1);
+      PHASE(1);
+      load_bias16(lds + L::B2P, g, acc);
+      chain64(lds + L::W2S, h1, lane, acc);
+      PHASE(2);
+      tanh16(acc, h2);
+      PHASE(3);
+    }
+    {
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 w = w3p[(aa * 4 + g) * 4 + j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], w[e], part);
+        }
+        z[aa] = sum_groups(part) + lds[L::HC + aa * 8];
+      }
+    }
+
+    const float cw = counted ? 1.f : 0.f;            // arithmetic mask: no lane branches below
+    if (ACTOR) {
+      float logp = 0.f, loc[AP], dif[AP], dsg[AP];
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        const f32x4 hc = *reinterpret_cast<const f32x4*>(lds + L::HC + aa * 8);
+        loc[aa] = tanh_fast(z[aa]);
+        const float act = valid ? in_act[aa] : loc[aa];
+        dif[aa] = act - loc[aa];
+        const float term = -(dif[aa] * dif[aa]) * hc[2] - hc[3];
+        logp += (EXACT || aa < A) ? term : 0.f;
+      }
+      const float old_lp = valid ? in_lp : logp;
+      float adv = valid ? in_adv : 0.f;
+      if (adv_norm) adv = (adv - adv_mean) / adv_std;
+      const float ratio = __expf(logp - old_lp);
+      const float clipped_ratio = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+      const float surr1 = adv * ratio, surr2 = adv * clipped_ratio;
+      const bool outside = ratio > a.clip_hi || ratio < a.clip_lo;
+      const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
+      const float gl = (dead || !valid) ? 0.f : -(adv * ratio);
+      st0 += cw * -fminf(surr1, surr2);
+      st1 += cw * (old_lp - logp);
+      st2 += (counted && outside) ? 1.f : 0.f;
+      st3 += cw;
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        const f32x2 hs = *reinterpret_cast<const f32x2*>(lds + L::HC + aa * 8 + 4);   // 1/sigma, 1/var
+        const float dloc = gl * dif[aa] * hs[1];
+        const float live = (EXACT || aa < A) ? 1.f : 0.f;
+        dzl[aa] = live * dloc * (1.f - loc[aa] * loc[aa]);
+        dsg[aa] = live * gl * (dif[aa] * dif[aa] * hs[1] * hs[0] - hs[0]);
+      }
+      if (g == 0) {
+        f32x4 lo = zero4, hi = zero4;
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          if (aa < 4) lo[aa] = dsg[aa]; else hi[aa - 4] = dsg[aa];
+        }
+        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = lo;
+        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = hi;
+      }
+    } else {
+      const float err = valid ? z[0] - in_ret : 0.f;
+      dzl[0] = 2.f * err;
+      st0 += cw * err * err;
+      st1 += cw * z[0];
+      st3 += cw;
+      if (g == 0) {
+        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = zero4;
+        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = zero4;
+      }
+    }
+
+    PHASE(4);                                        // head + loss
+    // ---- backward
+    scatter_S16(TA, h2, s, g);                       // h2^T for dW3
+    if (g == 0) {
+      f32x4 lo = zero4, hi = zero4;
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        if (aa < 4) lo[aa] = dzl[aa]; else hi[aa - 4] = dzl[aa];
+      }
+      reinterpret_cast<f32x4*>(DO + s * 16)[0] = lo;
+      reinterpret_cast<f32x4*>(DO + s * 16)[1] = hi;
+    }
+    {
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          const f32x4 w = w3p[(aa * 4 + g) * 4 + j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(dzl[aa], w[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = h2[4 * j + e];
+          h2[4 * j + e] = acc[e] * (1.f - y * y);
+        }
+      }
+    }
+    float (&dz2)[16] = h2;
+    scatter_S16(TB, dz2, s, g);
+    wave_lds_sync();
+    PHASE(5);                                        // dz2 + scatters
+
+    f32x4 dacc[4] = {zero4, zero4, zero4, zero4};
+    chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
+    PHASE(6);
+
+    // dW3[a][f] += dO^T . h2  (MFMA: rows = action index, padded to 16)
+    {
+      float aop[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) aop[e] = DO[(4 * g + e) * 16 + i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gHead = mfma16(aop[e], 1.f, gHead);
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const f32x4 hF = gather_F16(TA, T, i, g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gW3[T] = mfma16(aop[e], hF[e], gW3[T]);
+      }
+    }
+    f32x4 aF[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      aF[T] = gather_F16(TB, T, i, g);
+      gb2[T] += (aF[T][0] + aF[T][1]) + (aF[T][2] + aF[T][3]);
+    }
+    PHASE(7);                                        // dW3 + dz2^T gathers
+    float dz1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dz1[q] = dacc[q >> 2][q & 3] * (1.f - h1[q] * h1[q]);
+    wave_lds_sync();
+    scatter_S16(TA, h1, s, g);
+    scatter_S16(TB, dz1, s, g);
+    wave_lds_sync();
+    PHASE(8);                                        // dz1 + scatters
+
+    // dW2[out][in] += dz2^T . h1
+#pragma unroll
+    for (int Tj = 0; Tj < 4; ++Tj) {
+      const f32x4 bF = gather_F16(TA, Tj, i, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) gW2[Ti][Tj] = mfma16(aF[Ti][e], bF[e], gW2[Ti][Tj]);
+      }
+    }
+    PHASE(9);                                        // dW2
+    // dW1[out][in] += dz1^T . x
+    f32x4 cF[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      cF[T] = gather_F16(TB, T, i, g);
+      gb1[T] += (cF[T][0] + cF[T][1]) + (cF[T][2] + cF[T][3]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) TA[(4 * st + g) * TS16 + s] = x[st];
+    wave_lds_sync();
+#pragma unroll
+    for (int Tj = 0; Tj < XT; ++Tj) {
+      f32x4 xF = gather_F16(TA, Tj, i, g);
+      if (16 * Tj + i >= 4 * KS1) xF = zero4;          // rows beyond the staged x hold stale data
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int Ti = 0; Ti < 4; ++Ti) gW1[Ti][Tj] = mfma16(cF[Ti][e], xF[e], gW1[Ti][Tj]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < XR; ++c) {                      // remainder columns 16*XT + c on VALU
+      const f32x4 xr = *reinterpret_cast<const f32x4*>(TA + (16 * XT + c) * TS16 + 4 * g);
+#pragma unroll
+      for (int Ti = 0; Ti < 4; ++Ti) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gW1r[Ti][c] = fmaf(cF[Ti][e], xr[e], gW1r[Ti][c]);
+      }
+    }
+    wave_lds_sync();
+    cur = nxt;
+    PHASE(10);                                       // dW1
+  }
+  if (PROBE && blockIdx.x == 0 && lane == 0) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out1) + wave * 12;
+    for (int k = 0; k < 12; ++k) dst[k] = ph[k];
+  }
+
+  // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
+  const int oW1 = 0, ob1 = 64 * O, oW2 = ob1 + 64, ob2 = oW2 + 4096, oTail = ob2 + 64;
+  const int oLs = oTail, oW3 = ACTOR ? oTail + A : oTail, ob3 = oW3 + (ACTOR ? A * 64 : 64);
+  const int nout = ACTOR ? A : 1;
+  const int P = ob3 + nout;
+  float* G = lds + L::WAVE0;
+  __syncthreads();
+  for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) G[idx] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < kWaves16; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int Ti = 0; Ti < 4; ++Ti) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * Ti + 4 * g + r;
+#pragma unroll
+          for (int Tj = 0; Tj < 4; ++Tj) G[oW2 + row * 64 + 16 * Tj + s] += gW2[Ti][Tj][r];
+#pragma unroll
+          for (int Tj = 0; Tj < XT; ++Tj)
+            if (16 * Tj + s < O) G[oW1 + row * O + 16 * Tj + s] += gW1[Ti][Tj][r];
+        }
+        const float v1 = sum_groups(gb1[Ti]), v2 = sum_groups(gb2[Ti]);
+        if (g == 0) { G[ob1 + 16 * Ti + i] += v1; G[ob2 + 16 * Ti + i] += v2; }
+#pragma unroll
+        for (int c = 0; c < XR; ++c) {                  // lane (i, g): feature 16*Ti + i, 4 samples
+          const float vr = sum_groups(gW1r[Ti][c]);
+          if (g == 0 && 16 * XT + c < O) G[oW1 + (16 * Ti + i) * O + 16 * XT + c] += vr;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int aa = 4 * g + r;                    // gW3[T] rows are action indices
+          if (aa < nout) G[oW3 + aa * 64 + 16 * Ti + s] += gW3[Ti][r];
+        }
+      }
+      // gHead rows: lane (j, g), reg r -> row 4g + r (every column j holds the same sum)
+      if (s == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * g + r;
+          if (row < 8 && row < nout) G[ob3 + row] += gHead[r];
+          if (ACTOR && row >= 8 && row - 8 < nout) G[oLs + row - 8] += gHead[r];
+        }
+      }
+      const float r0 = wave_sum(st0), r1 = wave_sum(st1), r2 = wave_sum(st2), r3 = wave_sum(st3);
+      if (lane == 0) { G[P + 0] += r0; G[P + 1] += r1; G[P + 2] += r2; G[P + 5] += r3; }
+    }
+    __syncthreads();
+  }
+  float* dst = a.out0 + (int64_t)blockIdx.x * a.pstride;
+  for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) dst[idx] = G[idx];
+}
+
+// ------------------------------------------------------------------------------- host side
+
+bool grad16_supported(int O, int A, bool actor) {
+  return O >= 1 && O <= 32 && (!actor || (A >= 1 && A <= 8));
+}
+
+int grad16_blocks(int64_t n) {
+  const int64_t tiles = (n + 15) / 16;
+  int64_t blocks = (tiles + kWaves16 - 1) / kWaves16;
+  if (blocks > 256) blocks = 256;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+namespace {
+
+template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT>
+int go16(int blocks, hipStream_t stream, const MlpArgs& args) {
+  auto kernel = mlp64_grad16_kernel<KS1, XT, XR, AP, ACTOR, EXACT>;
+  constexpr int lds_bytes = Lds16<KS1, AP>::BYTES;
+  static thread_local bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      set_error("mlp64_grad16: hipFuncSetAttribute(%d B LDS): %s", lds_bytes, hipGetErrorString(e));
+      return TONIC_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWaves16 * 64), lds_bytes, stream, args);
+  TONIC_CHECK_LAUNCH("mlp64_grad16_kernel");
+  return TONIC_OK;
+}
+
+template <int KS1, int XT, int XR>
+int by_heads(bool actor, int blocks, hipStream_t st, const MlpArgs& a) {
+  if (!actor) return go16<KS1, XT, XR, 1, false, true>(blocks, st, a);
+  if (a.A == 1) return go16<KS1, XT, XR, 1, true, true>(blocks, st, a);
+  if (a.A == 6) return go16<KS1, XT, XR, 6, true, true>(blocks, st, a);
+  if (a.A == 8) return go16<KS1, XT, XR, 8, true, true>(blocks, st, a);
+  if (a.A < 6) return go16<KS1, XT, XR, 6, true, false>(blocks, st, a);
+  return go16<KS1, XT, XR, 8, true, false>(blocks, st, a);
+}
+
+}  // namespace
+
+int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
+  auto kernel = mlp64_grad16_kernel<5, 1, 1, 6, true, true, true>;
+  constexpr int lds_bytes = Lds16<5, 6>::BYTES;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) { set_error("probe: %s", hipGetErrorString(e)); return TONIC_ERR_LAUNCH; }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWaves16 * 64), lds_bytes, stream, args);
+  TONIC_CHECK_LAUNCH("mlp64_grad16_kernel<probe>");
+  return TONIC_OK;
+}
+
+int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args) {
+  // (x steps KS1 = ceil(O/4), full 16-column dW1 tiles, remainder columns)
+  if (args.O <= 4) return by_heads<1, 0, 4>(actor, blocks, stream, args);
+  if (args.O <= 16) return by_heads<4, 1, 0>(actor, blocks, stream, args);
+  if (args.O == 17) return by_heads<5, 1, 1>(actor, blocks, stream, args);     // HalfCheetah
+  if (args.O <= 20) return by_heads<5, 1, 4>(actor, blocks, stream, args);
+  return by_heads<8, 2, 0>(actor, blocks, stream, args);
+}
+
+}  // namespace tonic
