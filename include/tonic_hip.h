@@ -190,6 +190,24 @@ int tonic_ppo_collect_step(const float* d_actor_params, const float* d_observati
                            float* d_seg_log_probs, float* d_norm_acc, float* d_actions_out,
                            int64_t row, int64_t W, int32_t O, int32_t A, void* stream);
 
+/* Latency-optimised form of tonic_ppo_collect_step for device-resident collectors: the actor's
+ * MFMA operand images are packed ONCE per learner update (tonic_ppo_pack_actor, a float32 buffer
+ * of tonic_ppo_packed_actor_floats(O, A) elements) and every per-step launch streams them from
+ * L2 instead of re-staging 21 KB of weights through LDS.  Same mathematics on 16x16x4 tiles
+ * (results equal tonic_ppo_collect_step's up to float32 summation order). */
+int64_t tonic_ppo_packed_actor_floats(int32_t O, int32_t A);
+int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed, int32_t O, int32_t A,
+                         void* stream);
+int tonic_ppo_collect_step_packed(const float* d_packed_actor, const float* d_observations,
+                                  const float* d_eps, const float* d_next_observations,
+                                  const float* d_rewards, const float* d_resets,
+                                  const float* d_terminations, float* d_seg_observations,
+                                  float* d_seg_actions, float* d_seg_next_observations,
+                                  float* d_seg_rewards, float* d_seg_resets,
+                                  float* d_seg_terminations, float* d_seg_log_probs,
+                                  float* d_norm_acc, float* d_actions_out, int64_t row,
+                                  int64_t W, int32_t O, int32_t A, void* stream);
+
 /* ---- target networks (SAC / TD3) ---------------------------------------------------------------
  * replaces: tonic/torch/models/actor_critics.py:126-130 (update_targets): per element
  *   t = fl(fl(t*(1-coeff)) + fl(coeff*o)) — three roundings, no FMA — on flat buffers.

@@ -461,10 +461,12 @@ def test_fused_collect_step_equals_act_plus_store(lib, O, A, W):
     from tonic_amd.rollout import DeviceRollout
     T = 6
     results = []
-    for fused, capture in ((False, False), (True, False), (True, True)):
+    for fused, capture, packed in ((False, False, False), (True, False, False), (True, True, False),
+                                   (True, False, True), (True, True, True)):
         agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T))
         agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=3)
-        rollout = DeviceRollout(agent, W, T, seed=5, reset_probability=0.2, fused=fused)
+        rollout = DeviceRollout(agent, W, T, seed=5, reset_probability=0.2, fused=fused,
+                                packed=packed)
         rollout.collect(capture=capture)
         torch.cuda.synchronize()
         out = {k: agent.replay.buffers[k].cpu().numpy().copy() for k in (
@@ -472,8 +474,15 @@ def test_fused_collect_step_equals_act_plus_store(lib, O, A, W):
             'terminations', 'log_probs')}
         out['sums'] = agent.model.observation_normalizer.device_sums.cpu().numpy().copy()
         results.append(out)
-    for other in results[1:]:
+    for other in results[1:3]:
         for key, want in results[0].items():
             assert np.array_equal(other[key], want), key
+    # packed-weight 16x16x4 kernel: same mathematics, different float32 summation order
+    assert all(np.array_equal(results[4][k], results[3][k]) for k in results[3])
+    for key, want in results[0].items():
+        if key in ('actions', 'log_probs'):
+            np.testing.assert_allclose(results[3][key], want, rtol=0, atol=2e-5 if key == 'log_probs' else 3e-6)
+        else:
+            assert np.array_equal(results[3][key], want), key
     assert np.array_equal(results[0]['observations'], rollout.observations[:T].cpu().numpy())
     assert np.abs(results[0]['actions']).max() > 0 and np.isfinite(results[0]['log_probs']).all()

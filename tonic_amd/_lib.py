@@ -35,6 +35,9 @@ SIGNATURES = {
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'tonic_segment_store': (ctypes.c_int, [c_vp] * 15 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_ppo_collect_step': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'tonic_ppo_packed_actor_floats': (c_i64, [c_i32, c_i32]),
+    'tonic_ppo_pack_actor': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    'tonic_ppo_collect_step_packed': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
     'tonic_offpolicy_workspace_bytes': (c_i64, [c_i32] * 4),
     'tonic_mlp_actor_param_count': (c_i64, [c_i32] * 4),

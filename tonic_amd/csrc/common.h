@@ -56,6 +56,32 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// MeanStd.record's inner loop (mean_stds.py:44-48) for one observation feature: float32 running
+// sums advanced one worker row at a time, IN ORDER, `sum_sq += v * v` as two rounded operations.
+// Rows are read from an LDS tile [rows][stride] sixteen at a time (independent loads in flight)
+// so that only the two add chains are serial, not an LDS round trip per row.
+__device__ __forceinline__ void record_rows(const float* column, int stride, int rows, float& sum,
+                                            float& sum_sq) {
+  int w = 0;
+  for (; w + 16 <= rows; w += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = column[(w + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      sum = sum + v[u];
+      const float sq = v[u] * v[u];
+      sum_sq = sum_sq + sq;
+    }
+  }
+  for (; w < rows; ++w) {
+    const float v = column[w * stride];
+    sum = sum + v;
+    const float sq = v * v;
+    sum_sq = sum_sq + sq;
+  }
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -309,12 +309,7 @@ __global__ __launch_bounds__(WAVES * 64) void ppo_collect_kernel(CollectArgs c) 
       for (int64_t i = tid; i < rows * O; i += nth) lds[i] = a.obs[w0 * O + i];
       __syncthreads();
       if (tid < O) {
-        for (int64_t w = 0; w < rows; ++w) {
-          const float v = lds[w * O + tid];
-          sum = sum + v;
-          const float sq = v * v;
-          sum_sq = sum_sq + sq;
-        }
+        record_rows(lds + tid, O, (int)rows, sum, sum_sq);
       }
     }
     if (tid < O) { c.norm_acc[tid] = sum; c.norm_acc[O + tid] = sum_sq; }

@@ -571,6 +571,200 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) dst[idx] = G[idx];
 }
 
+// ------------------------------------------------- packed-weight acting (device-resident collect)
+//
+// The per-environment-step collect kernel is latency-bound (W = 256 observations = 16 tiles):
+// staging 21 KB of weights through LDS at every launch cost more than the MFMA chain itself.
+// `actor_pack_kernel` therefore writes the pre-permuted operand images ONCE per learner update
+// into HBM (L2-resident afterwards) and `ppo_collect16_kernel` streams its MFMA A operands
+// straight from that image (lane-linear, coalesced) — no LDS, no workgroup barrier.
+struct PackedActor {
+  int W1I, W2S, B1P, B2P, W3P, HC, total;
+  __host__ __device__ PackedActor(int ks1, int ap) {
+    W1I = 0; W2S = W1I + 4 * ks1 * 64; B1P = W2S + 4096; B2P = B1P + 64; W3P = B2P + 64;
+    HC = W3P + ap * 64; total = HC + 64;
+  }
+};
+
+__global__ void actor_pack_kernel(const float* params, float* packed, int O, int A, int ks1,
+                                  int ap) {
+  const PackedActor L(ks1, ap);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  const float* W1 = params;
+  const float* b1 = W1 + 64 * O;
+  const float* W2 = b1 + 64;
+  const float* b2 = W2 + 64 * 64;
+  const float* tail = b2 + 64;
+  const float* W3 = tail + A;
+  const float* b3 = W3 + A * 64;
+  for (int idx = tid; idx < 4 * ks1 * 64; idx += nth) {
+    const int T = idx / (ks1 * 64), rem = idx - T * ks1 * 64, st = rem >> 6, l = rem & 63;
+    const int k = 4 * st + (l >> 4);
+    packed[L.W1I + idx] = k < O ? W1[(16 * T + (l & 15)) * O + k] : 0.f;
+  }
+  for (int idx = tid; idx < 4096; idx += nth) {
+    const int e = idx & 3, l = (idx >> 2) & 63, c = (idx >> 8) & 3, T = idx >> 10;
+    packed[L.W2S + idx] = W2[(16 * T + (l & 15)) * 64 + feat16(4 * c + e, l >> 4)];
+  }
+  for (int idx = tid; idx < 64; idx += nth) {
+    packed[L.B1P + idx] = b1[feat16(idx & 15, idx >> 4)];
+    packed[L.B2P + idx] = b2[feat16(idx & 15, idx >> 4)];
+  }
+  for (int idx = tid; idx < ap * 64; idx += nth) {
+    const int aa = idx >> 6, g = (idx >> 4) & 3, q = idx & 15;
+    packed[L.W3P + idx] = aa < A ? W3[aa * 64 + feat16(q, g)] : 0.f;
+  }
+  for (int idx = tid; idx < 8; idx += nth) {
+    float bias = 0.f, sigma = 1.f, half_inv_var = 0.f, logc = 0.f;
+    if (idx < A) {
+      bias = b3[idx];
+      const float ls = tail[idx];
+      const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+      sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);
+      half_inv_var = 1.0f / (2.0f * (sigma * sigma));
+      logc = logf(sigma) + kLogSqrt2Pi;
+    }
+    float* hc = packed + L.HC + idx * 8;
+    hc[0] = bias; hc[1] = sigma; hc[2] = half_inv_var; hc[3] = logc;
+    hc[4] = 1.f / sigma; hc[5] = 2.f * half_inv_var; hc[6] = 0.f; hc[7] = 0.f;
+  }
+}
+
+struct Collect16Args {
+  const float* packed; const float* obs; const float* eps;
+  const float* next_obs; const float* rewards; const float* resets; const float* terminations;
+  float* seg_obs; float* seg_act; float* seg_next; float* seg_rew; float* seg_rst;
+  float* seg_term; float* seg_lp;
+  float* norm_acc; float* actions_out;
+  int64_t row, W;
+  int O, A;
+};
+
+constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
+
+template <int KS1, int AP>
+__global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
+  __shared__ float tile[kCollectLds];
+  const int64_t W = c.W;
+  const int O = c.O, A = c.A;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {
+    // transition outcome + MeanStd.record (segments.py:27-36, mean_stds.py:44-48)
+    for (int64_t i = tid; i < W * O; i += 256) c.seg_next[c.row * W * O + i] = c.next_obs[i];
+    for (int64_t i = tid; i < W; i += 256) {
+      c.seg_rew[c.row * W + i] = c.rewards[i];
+      c.seg_rst[c.row * W + i] = c.resets[i];
+      c.seg_term[c.row * W + i] = c.terminations[i];
+    }
+    if (c.norm_acc == nullptr) return;
+    float sum = 0.f, sum_sq = 0.f;
+    if (tid < O) { sum = c.norm_acc[tid]; sum_sq = c.norm_acc[O + tid]; }
+    const int64_t rows_per_chunk = kCollectLds / O;
+    for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
+      const int64_t rows = min(rows_per_chunk, W - w0);
+      __syncthreads();
+      for (int64_t i = tid; i < rows * O; i += 256) tile[i] = c.obs[w0 * O + i];
+      __syncthreads();
+      if (tid < O) {
+        record_rows(tile + tid, O, (int)rows, sum, sum_sq);
+      }
+    }
+    if (tid < O) { c.norm_acc[tid] = sum; c.norm_acc[O + tid] = sum_sq; }
+    return;
+  }
+  const PackedActor L(KS1, AP);
+  const float* P = c.packed;
+  const int lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
+  const int64_t ntiles = (W + 15) / 16;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)(gridDim.x - 1) * 4) {
+    const int64_t ns = t * 16 + s;
+    const bool valid = ns < W;
+    const int64_t nc = valid ? ns : W - 1;
+    float xr[KS1], ep[AP];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) {
+      const int k = 4 * st + g;
+      xr[st] = c.obs[nc * O + (k < O ? k : O - 1)];
+    }
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa)
+      ep[aa] = c.eps != nullptr ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
+    {  // this wave's 16 observation rows -> Segment row (contiguous, coalesced)
+      const int64_t first = t * 16 * O, count = min<int64_t>(16, W - t * 16) * O;
+      for (int64_t i = lane; i < count; i += 64)
+        c.seg_obs[c.row * W * O + first + i] = c.obs[first + i];
+    }
+    // Every weight operand is requested up front (about 220 registers of loads in flight), so
+    // the L2 latency is paid once per launch instead of once per dependent stage.
+    f32x4 bias1[4], bias2[4], w2[4][4], w3[AP][4], hcA[AP], hcB[AP];
+    float wl[4][KS1];
+    {
+      const f32x4* b1p = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16);
+      const f32x4* b2p = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16);
+      const f32x4* w2p = reinterpret_cast<const f32x4*>(P + L.W2S);
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(P + L.W3P);
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        bias1[T] = b1p[T];
+        bias2[T] = b2p[T];
+#pragma unroll
+        for (int st = 0; st < KS1; ++st) wl[T][st] = P[L.W1I + (T * KS1 + st) * 64 + lane];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) w2[T][cc] = w2p[(T * 4 + cc) * 64 + lane];
+      }
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w3[aa][j] = w3p[(aa * 4 + g) * 4 + j];
+        hcA[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8);
+        hcB[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8 + 4);
+      }
+    }
+    f32x4 acc[4];
+    float h1[16], h2[16];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) acc[T] = bias1[T];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) {
+      const float xv = xr[st] * ((valid && 4 * st + g < O) ? 1.f : 0.f);
+#pragma unroll
+      for (int T = 0; T < 4; ++T) acc[T] = mfma16(wl[T][st], xv, acc[T]);
+    }
+    tanh16(acc, h1);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) acc[T] = bias2[T];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mfma16(w2[T][cc][e], h1[4 * cc + e], acc[T]);
+      }
+    }
+    tanh16(acc, h2);
+    float logp = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) {
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], w3[aa][j][e], part);
+      }
+      const f32x4 hc = hcA[aa];
+      const float loc = tanh_fast(sum_groups(part) + hc[0]);
+      const float act = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
+      const float d = act - loc;
+      logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
+      if (valid && g == 0 && aa < A) {
+        c.seg_act[(c.row * W + ns) * A + aa] = act;
+        if (c.actions_out != nullptr) c.actions_out[ns * A + aa] = act;
+      }
+    }
+    if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
 
 bool grad16_supported(int O, int A, bool actor) {
@@ -638,3 +832,57 @@ int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& arg
 }
 
 }  // namespace tonic
+
+using namespace tonic;
+
+static int collect16_ks1(int O) { return O <= 4 ? 1 : O <= 20 ? 5 : 8; }
+static int collect16_ap(int A) { return A <= 1 ? 1 : A <= 6 ? 6 : 8; }
+
+extern "C" int64_t tonic_ppo_packed_actor_floats(int32_t O, int32_t A) {
+  return PackedActor(collect16_ks1(O), collect16_ap(A)).total;
+}
+
+extern "C" int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed, int32_t O,
+                                    int32_t A, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_packed && O >= 1 && O <= 32 && A >= 1 && A <= 8,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_pack_actor: bad argument");
+  hipLaunchKernelGGL(actor_pack_kernel, dim3(8), dim3(256), 0, as_stream(stream),
+                     d_actor_params, d_packed, O, A, collect16_ks1(O), collect16_ap(A));
+  TONIC_CHECK_LAUNCH("tonic_ppo_pack_actor");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_ppo_collect_step_packed(
+    const float* d_packed_actor, const float* d_observations, const float* d_eps,
+    const float* d_next_observations, const float* d_rewards, const float* d_resets,
+    const float* d_terminations, float* d_seg_observations, float* d_seg_actions,
+    float* d_seg_next_observations, float* d_seg_rewards, float* d_seg_resets,
+    float* d_seg_terminations, float* d_seg_log_probs, float* d_norm_acc, float* d_actions_out,
+    int64_t row, int64_t W, int32_t O, int32_t A, void* stream) {
+  TONIC_REQUIRE(d_packed_actor && d_observations && d_next_observations && d_rewards &&
+                    d_resets && d_terminations && d_seg_observations && d_seg_actions &&
+                    d_seg_next_observations && d_seg_rewards && d_seg_resets &&
+                    d_seg_terminations && d_seg_log_probs && row >= 0 && W > 0 && O >= 1 &&
+                    O <= 32 && A >= 1 && A <= 8,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_collect_step_packed: bad argument");
+  Collect16Args c{d_packed_actor, d_observations, d_eps, d_next_observations, d_rewards,
+                  d_resets, d_terminations, d_seg_observations, d_seg_actions,
+                  d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
+                  d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A};
+  const int64_t tiles = (W + 15) / 16;
+  int act_blocks = (int)((tiles + 3) / 4);
+  if (act_blocks > 2048) act_blocks = 2048;
+  const dim3 grid(act_blocks + 1), block(256);
+  hipStream_t st = as_stream(stream);
+  const int ks1 = collect16_ks1(O), ap = collect16_ap(A);
+#define TONIC_COLLECT16(K, P_)                                                        \
+  if (ks1 == K && ap == P_) {                                                         \
+    hipLaunchKernelGGL((ppo_collect16_kernel<K, P_>), grid, block, 0, st, c);         \
+  } else
+  TONIC_COLLECT16(1, 1) TONIC_COLLECT16(1, 6) TONIC_COLLECT16(1, 8)
+  TONIC_COLLECT16(5, 1) TONIC_COLLECT16(5, 6) TONIC_COLLECT16(5, 8)
+  TONIC_COLLECT16(8, 1) TONIC_COLLECT16(8, 6) TONIC_COLLECT16(8, 8) {}
+#undef TONIC_COLLECT16
+  TONIC_CHECK_LAUNCH("tonic_ppo_collect_step_packed");
+  return TONIC_OK;
+}

@@ -53,12 +53,7 @@ __global__ __launch_bounds__(kStoreThreads) void segment_store_kernel(StoreArgs 
     for (int64_t i = threadIdx.x; i < rows * a.O; i += blockDim.x) tile[i] = a.obs[w0 * a.O + i];
     __syncthreads();
     if (k < a.O) {
-      for (int64_t w = 0; w < rows; ++w) {
-        const float v = tile[w * a.O + k];
-        sum = sum + v;                 // mean_stds.py:46
-        const float sq = v * v;        // np.square, then a separately rounded add (:47)
-        sum_sq = sum_sq + sq;
-      }
+      record_rows(tile + k, a.O, (int)rows, sum, sum_sq);
     }
   }
   if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }

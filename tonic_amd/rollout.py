@@ -18,8 +18,10 @@ from tonic_amd import _lib
 
 
 class DeviceRollout:
-    def __init__(self, agent, workers, steps, seed=0, reset_probability=1e-3, fused=True):
+    def __init__(self, agent, workers, steps, seed=0, reset_probability=1e-3, fused=True,
+                 packed=True):
         self.fused = fused
+        self.packed = packed and fused
         self.agent = agent
         self.lib = _lib.load()
         device = agent.device
@@ -48,7 +50,23 @@ class DeviceRollout:
         stream = _lib.current_stream()
         actor = p(agent.model.flat_actor.flat)
         O, A = agent.observation_size, agent.action_size
+        if self.packed:
+            if getattr(self, 'packed_actor', None) is None:
+                self.packed_actor = torch.empty(lib.tonic_ppo_packed_actor_floats(O, A),
+                                                device=agent.device)
+            # once per collect (the parameters change at every learner update)
+            _lib.check(lib.tonic_ppo_pack_actor(actor, p(self.packed_actor), O, A, stream),
+                       'tonic_ppo_pack_actor')
         for t in range(self.T):
+            if self.packed:
+                _lib.check(lib.tonic_ppo_collect_step_packed(
+                    p(self.packed_actor), p(self.observations[t]), p(self.eps[t]),
+                    p(self.observations[t + 1]), p(self.rewards[t]), p(self.resets[t]),
+                    p(self.terminations[t]), p(b['observations']), p(b['actions']),
+                    p(b['next_observations']), p(b['rewards']), p(b['resets']),
+                    p(b['terminations']), p(b['log_probs']), p(sums), None, t, self.W, O, A,
+                    stream), 'tonic_ppo_collect_step_packed')
+                continue
             if self.fused:
                 _lib.check(lib.tonic_ppo_collect_step(
                     actor, p(self.observations[t]), p(self.eps[t]), p(self.observations[t + 1]),
@@ -71,6 +89,11 @@ class DeviceRollout:
         """Fills the agent's Segment with T steps (asynchronous; no host sync)."""
         if capture:
             if self.graph is None:
+                if self.packed and getattr(self, 'packed_actor', None) is None:
+                    self.packed_actor = torch.empty(
+                        self.lib.tonic_ppo_packed_actor_floats(self.agent.observation_size,
+                                                               self.agent.action_size),
+                        device=self.agent.device)
                 # Warm-up outside the capture (buffer allocation, LDS opt-ins).  It runs the
                 # rollout once, so undo its only cumulative side effect — the normaliser sums.
                 norm = self.agent.model.observation_normalizer
