@@ -174,6 +174,19 @@ int tonic_segment_store(float* d_seg_observations, float* d_seg_actions,
                         const float* d_log_probs, float* d_norm_acc, int64_t row, int64_t W,
                         int32_t O, int32_t A, void* stream);
 
+/* replaces: tonic/replays/segments.py:58-65 (Segment.get with batch_size: fancy-index every
+ *   learner input by a shuffled index vector).  Gathers `count` flattened transitions
+ *   d_indices[i] in [0, segment_rows) of observations [N,O], actions [N,A], raw advantages,
+ *   log-probs and returns [N] into contiguous outputs; one call per shuffled epoch, the
+ *   minibatches are then [start, start + batch_size) slices of the outputs.  Bit-exact copy.
+ */
+int tonic_segment_gather(const int64_t* d_indices, const float* d_seg_observations,
+                         const float* d_seg_actions, const float* d_seg_advantages,
+                         const float* d_seg_log_probs, const float* d_seg_returns,
+                         float* d_observations, float* d_actions, float* d_advantages,
+                         float* d_log_probs, float* d_returns, int64_t count,
+                         int64_t segment_rows, int32_t O, int32_t A, void* stream);
+
 /* ---- fused on-policy collect step (device-resident collectors) ---------------------------------
  * replaces: tonic/torch/agents/a2c.py:41-52 (A2C.step: forward + sample + log-prob) and
  *   a2c.py:58-69 (Segment.store + MeanStd.record) for ONE environment step in ONE launch:

@@ -196,7 +196,7 @@ def golden_sequential(tonic):
 
 
 def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
-            reward_scale=1.0, updates=1):
+            reward_scale=1.0, updates=1, batch_size=None):
     """tonic/torch/agents/{a2c.py:41-73, ppo.py:20-67}: acts with the reference agent on
     a synthetic env for `steps` time steps so the real store/record/update path runs."""
     def builder():
@@ -204,9 +204,11 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
     env = tonic.environments.distribute(builder, 1, workers)
     env.initialize(seed=seed)
     agent = tonic.torch.agents.PPO(
-        replay=tonic.replays.Segment(size=steps, batch_iterations=iterations))
+        replay=tonic.replays.Segment(size=steps, batch_iterations=iterations,
+                                     batch_size=batch_size))
     agent.initialize(env.observation_space, env.action_space, seed=seed)
     out = state_arrays('init/', agent.model.state_dict())
+    out['batch_size'] = np.int64(batch_size or 0)
     recorder = RecordingLogger()
     tonic.logger.current_logger = recorder
     observations = env.start()
@@ -253,7 +255,7 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 out[pre + 'info/' + k] = np.array(v)
         recorder.records.clear()
         out[pre + 'norm/count'] = np.int64(norm.count)
-        if update == 0:
+        if update == 0 and batch_size is None:
             out.update(first_update_probes(tonic, builder, seed, seg, iterations))
     out['act/observations'] = np.array(obs_all)
     out['act/eps'] = np.array(eps_all)
@@ -426,6 +428,9 @@ def main():
     # cfg-5 shapes (AntBullet O=28, A=8), larger rewards so the KL stop triggers.
     run_ppo(tonic, 'ppo_antbullet_small', 28, 8, workers=16, steps=24, seed=2,
             reward_scale=5.0, updates=1)
+    # minibatch mode (segments.py:58-65): N = 20*12 = 240 samples, ragged last minibatch of 48
+    run_ppo(tonic, 'ppo_minibatch_small', 17, 6, workers=12, steps=20, seed=4, iterations=5,
+            batch_size=64)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
 

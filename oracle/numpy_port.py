@@ -316,7 +316,7 @@ def polyak(targets, onlines, coeff=0.005):
 
 def ppo_update(actor_params, critic_params, normalizer, segment, batch_iterations=80,
                discount_factor=0.99, trace_decay=0.97, actor_lr=3e-4, critic_lr=1e-3,
-               actor_adam=None, critic_adam=None):
+               actor_adam=None, critic_adam=None, batch_size=None, np_random=None):
     """``PPO._update`` — ``tonic/torch/agents/ppo.py:20-59`` (default full-batch path,
     ``Segment.batch_size=None``).  ``segment`` maps the seven stored keys to ``[T, W,
     ...]`` float32 arrays.  Returns new params, per-iteration infos and the returns."""
@@ -332,23 +332,29 @@ def ppo_update(actor_params, critic_params, normalizer, segment, batch_iteration
     actor_adam = actor_adam or AdamPort(actor_params, actor_lr)
     critic_adam = critic_adam or AdamPort(critic_params, critic_lr)
     infos, train_actor = [], True
-    for _ in range(batch_iterations):
+    n = advantages.shape[0]
+    if batch_size is None:                      # segments.py:55-57: the same full batch each time
+        schedule = [None] * batch_iterations
+    else:                                       # segments.py:58-65: shuffled minibatches
+        schedule = list(segment_minibatch_indices(np_random, n, batch_size, batch_iterations))
+    flat_returns = returns.reshape(-1)
+    for idx in schedule:
+        pick = (lambda v: v) if idx is None else (lambda v: v[idx])
+        obs_b, act_b, adv_b = pick(flat['observations']), pick(flat['actions']), pick(advantages)
+        lp_b, ret_b = pick(flat['log_probs']), pick(flat_returns)
         info = {}
         if train_actor:
-            if np.all(advantages == 0):                        # actors.py:71-78
-                _, _, _, scale, _ = ppo_actor_forward(actor_params, flat['observations'])
+            if np.all(adv_b == 0):                             # actors.py:71-78
+                _, _, _, scale, _ = ppo_actor_forward(actor_params, obs_b)
                 ent = F32(np.mean(0.5 + 0.5 * math.log(2 * math.pi) + np.log(scale)))
                 info['actor'] = dict(loss=F32(0), kl=F32(0), entropy=ent,
                                      clip_fraction=F32(0), std=F32(scale.mean()), stop=False)
             else:
-                grads, stats = clipped_ratio_grads(
-                    actor_params, flat['observations'], flat['actions'], advantages,
-                    flat['log_probs'])
+                grads, stats = clipped_ratio_grads(actor_params, obs_b, act_b, adv_b, lp_b)
                 actor_params = actor_adam.step(actor_params, grads)
                 info['actor'] = stats
             train_actor = not info['actor']['stop']
-        grads, stats = value_regression_grads(
-            critic_params, mean, std, flat['observations'], returns.reshape(-1))
+        grads, stats = value_regression_grads(critic_params, mean, std, obs_b, ret_b)
         critic_params = critic_adam.step(critic_params, grads)
         info['critic'] = dict(loss=stats['loss'], v=stats['v'])
         infos.append(info)

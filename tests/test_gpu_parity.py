@@ -338,14 +338,15 @@ def test_segment_store_and_meanstd_record_bit_exact(lib):
 
 # ------------------------------------------------------------- whole update, agent level
 
-def _agent_from_golden(g, prefix, steps, iterations=80):
+def _agent_from_golden(g, prefix, steps, iterations=80, batch_size=None, seed=0):
     import tonic_amd
     import tonic_amd.torch
     from tonic_amd.environments import Box
     O, A = int(g['cfg'][0]), int(g['cfg'][1])
     agent = tonic_amd.torch.agents.PPO(
-        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations))
-    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=0)
+        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations,
+                                         batch_size=batch_size))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
     state = {k[len(prefix):]: torch.as_tensor(g[k]) for k in g.files if k.startswith(prefix)}
     agent.model.load_state_dict(state)
     return agent
@@ -386,6 +387,68 @@ def test_ppo_update_matches_reference(golden, lib, name):
         want = g['post0/' + key] - start
         tol = max(1e-5, 50 * float(g['noise/' + key].max()))
         np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=key)
+
+
+def test_segment_gather_bit_exact(lib):
+    """tonic_segment_gather == fancy indexing (segments.py:64), ragged row count."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(5)
+    N, n, O, A = 1003, 517, 17, 6
+    src = [rng.randn(N, O), rng.randn(N, A), rng.randn(N), rng.randn(N), rng.randn(N)]
+    src = [x.astype(np.float32) for x in src]
+    idx = rng.permutation(N)[:n].astype(np.int64)
+    d_src = [dev(x) for x in src]
+    d_out = [torch.full((n,) + x.shape[1:], np.nan, device='cuda') for x in src]
+    d_idx = torch.as_tensor(idx, device='cuda')
+    _lib.check(lib.tonic_segment_gather(
+        d_idx.data_ptr(), *[t.data_ptr() for t in d_src], *[t.data_ptr() for t in d_out], n, N,
+        O, A, None), 'tonic_segment_gather')
+    torch.cuda.synchronize()
+    for got, want in zip(d_out, src):
+        assert np.array_equal(got.cpu().numpy(), want[idx])
+
+
+def test_ppo_minibatch_update_matches_reference(golden, lib):
+    """Segment(batch_size=64): 5 shuffled epochs of 64/64/64/48 minibatches, KL stop inside an
+    epoch (ppo.py:40-47 over segments.py:58-65)."""
+    g = golden('ppo_minibatch_small')
+    steps, seed, iterations = int(g['cfg'][3]), int(g['cfg'][4]), int(g['cfg'][5])
+    agent = _agent_from_golden(g, 'pre0/', steps, iterations=iterations,
+                               batch_size=int(g['batch_size']), seed=seed)
+    before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    _fill_segment(agent, g, 0)
+    infos = agent.enqueue_update().cpu().numpy()
+    assert infos.shape[1] == int(g['u0/info/critic/iterations'][0])
+    ran = infos[0][:, 6] > 0
+    n_actor = int(g['u0/info/actor/iterations'][0])
+    assert ran.sum() == n_actor and ran[:n_actor].all(), 'device-side KL early stop'
+    for i, key in enumerate(('loss', 'kl', 'entropy', 'clip_fraction', 'std')):
+        np.testing.assert_allclose(infos[0][:n_actor, i], g[f'u0/info/actor/{key}'],
+                                   rtol=1e-5, atol=1e-5, err_msg=key)
+    assert np.array_equal(infos[0][:n_actor, 5] > 0.5, g['u0/info/actor/stop'])
+    np.testing.assert_allclose(infos[1][:, 0], g['u0/info/critic/loss'], rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, start in before.items():
+        if 'normalizer' in key:
+            continue
+        got = after[key].detach().cpu().numpy() - start
+        np.testing.assert_allclose(got, g['post0/' + key] - start, rtol=0, atol=2e-5, err_msg=key)
+
+    # drop-in generator: same index stream, normalised advantages
+    agent2 = _agent_from_golden(g, 'pre0/', steps, iterations=iterations,
+                                batch_size=int(g['batch_size']), seed=seed)
+    _fill_segment(agent2, g, 0)
+    agent2.replay.compute_returns(*agent2._evaluate())
+    want_idx = port.segment_minibatch_indices(np.random.RandomState(seed), steps * int(g['cfg'][2]),
+                                              int(g['batch_size']), iterations)
+    flat_obs = port.flatten_time_major(g['u0/segment/observations'])
+    adv = port.normalized_advantages(g['u0/segment/returns'], g['u0/segment/values']).reshape(-1)
+    count = 0
+    for batch, idx in zip(agent2.replay.get('observations', 'advantages'), want_idx):
+        assert np.array_equal(batch['observations'].cpu().numpy(), flat_obs[idx])
+        np.testing.assert_allclose(batch['advantages'].cpu().numpy(), adv[idx], atol=2e-5)
+        count += 1
+    assert count == agent2.replay.updates_per_get()
 
 
 @pytest.mark.parametrize('name', PPO_CASES)

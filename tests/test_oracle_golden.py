@@ -241,3 +241,26 @@ def test_offpolicy_port_matches_reference(golden, name, kind):
                                g['info/actor/loss'], rtol=1e-5, atol=1e-7)
     for key, value in port_.state().items():
         np.testing.assert_allclose(value, g['post/' + key], rtol=0, atol=1e-7, err_msg=key)
+
+
+def test_ppo_minibatch_update_matches_reference(golden):
+    """Segment(batch_size=64): shuffled minibatches (segments.py:58-65), ragged last batch, KL stop
+    in the middle of an iteration."""
+    g = golden('ppo_minibatch_small')
+    seed, iterations, bs = int(g['cfg'][4]), int(g['cfg'][5]), int(g['batch_size'])
+    actor, critic, norm = _params(g, 'pre0/')
+    seg = {k: g[f'u0/segment/{k}'] for k in (
+        'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+        'log_probs')}
+    new_actor, new_critic, infos, _ = port.ppo_update(
+        actor, critic, norm, seg, batch_iterations=iterations, batch_size=bs,
+        np_random=np.random.RandomState(seed))
+    assert len(infos) == int(g['u0/info/critic/iterations'][0])
+    kl = np.array([i['actor']['kl'] for i in infos if 'actor' in i])
+    np.testing.assert_allclose(kl, g['u0/info/actor/kl'], rtol=1e-5, atol=1e-5)
+    assert np.array_equal([i['actor']['stop'] for i in infos if 'actor' in i], g['u0/info/actor/stop'])
+    np.testing.assert_allclose([i['critic']['loss'] for i in infos], g['u0/info/critic/loss'],
+                               rtol=1e-5, atol=1e-5)
+    ref_actor, ref_critic, _ = _params(g, 'post0/')
+    for got, want, before in zip(new_actor + new_critic, ref_actor + ref_critic, actor + critic):
+        np.testing.assert_allclose(got - before, want - before, atol=2e-5, rtol=0)

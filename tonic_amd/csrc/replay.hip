@@ -59,9 +59,54 @@ __global__ __launch_bounds__(kStoreThreads) void segment_store_kernel(StoreArgs 
   if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }
 }
 
+// Segment.get minibatch fetch (segments.py:58-65: `{k: v[indices] for k, v in batch.items()}`)
+// for one whole shuffled epoch: wave b copies flattened transition indices[b] of every learner
+// input into row b of the contiguous epoch image, so that the minibatches of the epoch are plain
+// [start, start + batch_size) slices of it.
+struct SegGatherArgs {
+  const int64_t* indices;
+  const float* obs; const float* act; const float* adv; const float* lp; const float* ret;
+  float* o_obs; float* o_act; float* o_adv; float* o_lp; float* o_ret;
+  int64_t n, N;
+  int O, A;
+};
+
+__global__ __launch_bounds__(256) void segment_gather_kernel(SegGatherArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= g.n) return;
+  const int64_t t = g.indices[b];
+  if (t < 0 || t >= g.N) return;                       // caller validated; never read outside
+  for (int k = lane; k < g.O; k += 64) g.o_obs[b * g.O + k] = g.obs[t * g.O + k];
+  for (int k = lane; k < g.A; k += 64) g.o_act[b * g.A + k] = g.act[t * g.A + k];
+  if (lane == 0) { g.o_adv[b] = g.adv[t]; g.o_lp[b] = g.lp[t]; g.o_ret[b] = g.ret[t]; }
+}
+
 }  // namespace tonic
 
 using namespace tonic;
+
+extern "C" int tonic_segment_gather(const int64_t* d_indices, const float* d_seg_observations,
+                                    const float* d_seg_actions, const float* d_seg_advantages,
+                                    const float* d_seg_log_probs, const float* d_seg_returns,
+                                    float* d_observations, float* d_actions, float* d_advantages,
+                                    float* d_log_probs, float* d_returns, int64_t count,
+                                    int64_t segment_rows, int32_t O, int32_t A, void* stream) {
+  TONIC_REQUIRE(d_indices && d_seg_observations && d_seg_actions && d_seg_advantages &&
+                    d_seg_log_probs && d_seg_returns && d_observations && d_actions &&
+                    d_advantages && d_log_probs && d_returns,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_segment_gather: null pointer");
+  TONIC_REQUIRE(count > 0 && segment_rows > 0 && O > 0 && A > 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_segment_gather: count=%lld rows=%lld O=%d A=%d", (long long)count,
+                (long long)segment_rows, O, A);
+  SegGatherArgs g{d_indices, d_seg_observations, d_seg_actions, d_seg_advantages,
+                  d_seg_log_probs, d_seg_returns, d_observations, d_actions, d_advantages,
+                  d_log_probs, d_returns, count, segment_rows, O, A};
+  hipLaunchKernelGGL(segment_gather_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0,
+                     as_stream(stream), g);
+  TONIC_CHECK_LAUNCH("tonic_segment_gather");
+  return TONIC_OK;
+}
 
 extern "C" int tonic_segment_store(float* d_seg_observations, float* d_seg_actions,
                                    float* d_seg_next_observations, float* d_seg_rewards,

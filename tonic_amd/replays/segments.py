@@ -23,6 +23,9 @@ STORED_KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'reset
                'terminations', 'log_probs')
 
 
+LEARNER_KEYS = ('observations', 'actions', 'advantages', 'log_probs', 'returns')
+
+
 def flatten_batch(values):
     shape = values.shape
     return values.reshape((int(np.prod(shape[:2], dtype=int)),) + tuple(shape[2:]))
@@ -128,12 +131,59 @@ class Segment:
                 out[k] = flatten_batch(self.buffers[k])
         return out
 
-    def get(self, *keys):
-        batch = self.get_full(*keys)
+    def updates_per_get(self):
+        """Number of batches one ``get`` / ``learner_batches`` pass yields."""
+        if self.batch_size is None:
+            return self.batch_iterations
+        n = self.max_size * self.num_workers
+        return self.batch_iterations * ((n + self.batch_size - 1) // self.batch_size)
+
+    def learner_batches(self):
+        """What the fused learner consumes: tuples ``(observations, actions, RAW advantages,
+        log_probs, returns)`` of device tensors — the full flattened segment ``batch_iterations``
+        times (segments.py:55-57), or shuffled minibatches (segments.py:58-65).
+
+        Minibatch mode keeps the reference's index stream (one persistent ``arange`` shuffled
+        in place by the replay's ``RandomState`` once per epoch) on the host, uploads the epoch's
+        permutation and gathers the whole epoch with ONE ``tonic_segment_gather`` launch; the
+        minibatches are then contiguous slices of that epoch image."""
+        self.index = 0
+        b = self.buffers
+        full = tuple(flatten_batch(b[k]) for k in LEARNER_KEYS)
         if self.batch_size is None:
             for _ in range(self.batch_iterations):
+                yield full
+            return
+        n, bs = full[0].shape[0], int(self.batch_size)
+        if getattr(self, '_epoch', None) is None or self._epoch[0].shape[0] != n:
+            self._epoch = tuple(torch.empty_like(v) for v in full)
+            self._epoch_indices = torch.empty(n, dtype=torch.int64, device=self.device)
+        order = np.arange(n)                                   # segments.py:59
+        p = _lib.ptr
+        for _ in range(self.batch_iterations):
+            self.np_random.shuffle(order)                      # segments.py:61
+            self._epoch_indices.copy_(torch.from_numpy(order))   # blocking H2D: `order` is reused
+            _lib.check(self.lib.tonic_segment_gather(
+                p(self._epoch_indices), *[p(v) for v in full], *[p(v) for v in self._epoch],
+                n, n, self.observation_size, self.action_size, _lib.current_stream()),
+                'tonic_segment_gather')
+            for start in range(0, n, bs):                      # segments.py:62-65, ragged tail
+                yield tuple(v[start:start + bs] for v in self._epoch)
+
+    def get(self, *keys):
+        """Drop-in generator (segments.py:49-65).  'advantages' come out normalised."""
+        if self.batch_size is None:
+            batch = self.get_full(*keys)
+            for _ in range(self.batch_iterations):
                 yield batch
-        else:
-            raise NotImplementedError(
-                'Segment(batch_size=...) minibatches are not implemented yet in the HIP engine '
-                '(SURVEY.md §8f item 2); use the default full-batch mode')
+            return
+        unknown = [k for k in keys if k not in LEARNER_KEYS]
+        if unknown:
+            raise NotImplementedError(f'minibatches of {unknown} are outside the learner path; '
+                                      f'the gather kernel serves {LEARNER_KEYS}')
+        mean, std, _, flag = self.adv_stats.tolist()
+        for parts in self.learner_batches():
+            batch = dict(zip(LEARNER_KEYS, parts))
+            if 'advantages' in keys and flag:
+                batch['advantages'] = (batch['advantages'] - mean) / std      # segments.py:45
+            yield {k: batch[k] for k in keys}

@@ -212,11 +212,9 @@ class PPO(A2C):
         replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
         values, next_values = self._evaluate()
         replay.compute_returns(values, next_values)
-        batch = replay.get_full('observations', 'actions', 'log_probs', 'returns')
-        raw_advantages = replays.flatten_batch(replay.buffers['advantages'])
-        iterations = replay.batch_iterations
-        if getattr(self, '_infos', None) is None or self._infos.shape[1] != iterations:
-            self._infos = torch.zeros(2, iterations, updaters.INFO_WIDTH, device=self.device)
+        updates = replay.updates_per_get()
+        if getattr(self, '_infos', None) is None or self._infos.shape[1] != updates:
+            self._infos = torch.zeros(2, updates, updaters.INFO_WIDTH, device=self.device)
         self._infos.zero_()
         actor.reset_stop()
         world = actor.world_size
@@ -226,11 +224,13 @@ class PPO(A2C):
             self._joint_grads = torch.zeros(na + nc, device=self.device)
             actor.share_gradient_buffer(self._joint_grads[:na])
             critic.share_gradient_buffer(self._joint_grads[na:])
-        n = batch['observations'].shape[0]
-        for it in range(iterations):
-            actor.enqueue_grad(batch['observations'], batch['actions'], raw_advantages,
-                               replay.adv_stats, batch['log_probs'])
-            critic.enqueue_grad(batch['observations'], batch['returns'])
+        # Full batch (ppo.py:40-47 over segments.py:55-57) or shuffled minibatches
+        # (segments.py:58-65); the advantages stay raw and are normalised in-register with the
+        # GLOBAL statistics, exactly what get_full computes before the reference slices.
+        for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
+            n = obs.shape[0]
+            actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+            critic.enqueue_grad(obs, returns)
             if world > 1:
                 # After the KL stop the actor half is stale on every rank alike and ignored
                 # (tonic_adam_step is skipped by the same device flag on all ranks).
@@ -240,9 +240,6 @@ class PPO(A2C):
         return self._infos
 
     def _update(self):
-        if self.replay.batch_size is not None:
-            raise NotImplementedError('PPO minibatches (Segment(batch_size=...)) are not '
-                                      'implemented in the HIP engine yet')
         infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
         actor_rows = infos[0][infos[0][:, 6] > 0]
         for row in actor_rows:
