@@ -57,6 +57,21 @@ def time_events(fn, repeats):
     return start.elapsed_time(end) / repeats
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected separately, gfx950 read correction applied) — PMC counters cannot be
+    collected from inside the timed run, so the summary of the same kernels is quoted."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+    try:
+        with open(path) as f:
+            table = json.load(f)['kernels']
+        entry = next(v for k, v in table.items() if k.startswith(prefix))
+    except (OSError, StopIteration, KeyError, ValueError):
+        return dict(traffic=None)
+    return dict(traffic=entry['read_bytes'] + entry['write_bytes'], traffic_unit='B/launch',
+                traffic_source='profiles/r01_traffic.json')
+
+
 def kernel_rooflines(agent):
     """Live roofline measurements of the dominant kernels (HIP events, launch stream)."""
     import torch
@@ -100,7 +115,7 @@ def kernel_rooflines(agent):
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
     roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> / mlp64_grad_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
                 ms_per_launch=round(ms_a, 4), samples_per_launch=n,
                 flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=best,
                 variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
@@ -135,6 +150,7 @@ def kernel_rooflines(agent):
     roof_gae = dict(bound='hbm', kernel='gae_scan_kernel (+summary/carry/stats)',
                     achieved=top['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=top['frac'],
                     bytes_per_transition=28, at=dict(T=top['T'], W=top['W']), sweep=sweep,
+                    **pmc_traffic('gae_scan_kernel'),
                     note='cfg-2 size (T=4096, W=256) moves 29 MB: launch-latency bound, '
                          'inside the Infinity Cache; the HBM fraction is meaningful at W>=4096')
     return roof, roof_critic, roof_gae
@@ -357,16 +373,20 @@ def main():
 
     if rank == 0 and not args.no_extras:
         # phase split (untimed extras): collect-only and update-only
-        def sync_time(fn, n=2):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n * 1e3
         if world == 1:
-            result['collect_ms'] = round(sync_time(lambda: rollout.collect(capture=capture)), 3)
-            result['update_ms'] = round(sync_time(agent._update), 3)
+            collect_s = update_s = 0.0                   # phase split of two more whole steps
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rollout.collect(capture=capture)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                agent._update()
+                torch.cuda.synchronize()
+                collect_s += t1 - t0
+                update_s += time.perf_counter() - t1
+            result['collect_ms'] = round(collect_s / 2 * 1e3, 3)
+            result['update_ms'] = round(update_s / 2 * 1e3, 3)
             roof, roof_c, roof_g = kernel_rooflines(agent)
             result['roofline'] = roof
             result['roofline_critic'] = roof_c

@@ -12,7 +12,7 @@ batch with ``tonic_buffer_gather`` (one wavefront per sampled transition,
 import numpy as np
 import torch
 
-from tonic_amd import _lib
+from tonic_amd import _lib, parallel
 
 KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
         'discounts')
@@ -48,8 +48,12 @@ class Buffer:
         return (steps - self.last_steps) >= self.steps_between_batches
 
     def _allocate(self, num_workers, observation_size, action_size):
+        # Multi-GPU: this rank holds a contiguous shard of the GLOBAL worker axis (equal shards);
+        # capacity and the index stream are those of the global [max_size, W_global] buffer.
         self.num_workers = num_workers
-        self.max_size = self.full_max_size // num_workers
+        self.rank, self.world = parallel.rank(), parallel.world_size()
+        self.global_workers = num_workers * self.world
+        self.max_size = self.full_max_size // self.global_workers
         self.observation_size, self.action_size = observation_size, action_size
         R, W = self.max_size, num_workers
 
@@ -87,10 +91,29 @@ class Buffer:
 
     def sample_indices(self, iterations=None):
         """The index stream of `iterations` successive Buffer.get draws (buffers.py:85-86)."""
-        total = self.size * self.num_workers
+        total = self.size * self.global_workers
         count = self.batch_iterations if iterations is None else iterations
         return np.stack([self.np_random.randint(total, size=self.batch_size)
                          for _ in range(count)])
+
+    def shard_indices(self, indices):
+        """Splits GLOBAL flat indices [iterations, B] (rows = idx // W_global, cols = idx %
+        W_global, buffers.py:87-88) into this rank's part: returns (local flat indices into the
+        [max_size, W_local] shard, positions inside the global batch, counts), the first two
+        zero-padded to B per iteration.  Every rank draws the same global stream (same seed), so
+        the union over ranks is exactly the single-process batch."""
+        iterations, B = indices.shape
+        rows, cols = indices // self.global_workers, indices % self.global_workers
+        mine = (cols // self.num_workers) == self.rank
+        local = np.zeros((iterations, B), np.int64)
+        positions = np.zeros((iterations, B), np.int64)
+        counts = mine.sum(axis=1)
+        for it in range(iterations):
+            pos = np.flatnonzero(mine[it])
+            positions[it, :len(pos)] = pos
+            local[it, :len(pos)] = (rows[it, pos] * self.num_workers
+                                    + cols[it, pos] - self.rank * self.num_workers)
+        return local, positions, counts
 
     def gather(self, device_indices, out=None):
         """Gathers one batch (int64 device indices [B]) into `out` (default: the reusable batch)."""
@@ -102,13 +125,19 @@ class Buffer:
             p(out['next_observations']), p(out['rewards']), p(out['discounts']),
             self.num_workers, device_indices.shape[0], self.observation_size, self.action_size,
             _lib.current_stream()), 'tonic_buffer_gather')
+        count = device_indices.shape[0]
+        if count != out['rewards'].shape[0]:
+            return {k: v[:count] for k, v in out.items()}
         return out
 
     def get(self, *keys, steps):
         """Generator form of the reference API: yields device-tensor batches."""
         for _ in range(self.batch_iterations):
-            indices = self.sample_indices(1)[0]
-            device_indices = torch.as_tensor(indices, device=self.device)
+            indices = self.sample_indices(1)
+            if self.world > 1:                 # this rank's part of the global batch
+                local, _, counts = self.shard_indices(indices)
+                indices = local[:, :counts[0]]
+            device_indices = torch.as_tensor(indices[0], device=self.device)
             out = {k: torch.empty_like(v) for k, v in self.batch.items()}
             self.gather(device_indices, out)
             yield {k: out[k] for k in keys}

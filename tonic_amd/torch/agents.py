@@ -386,7 +386,20 @@ class DDPG(Agent):
         on unless TONIC_AMD_NO_GRAPH=1) the launch sequence — gather, ~45 small GEMM /
         element-wise launches per iteration, Adam, polyak — is captured once into a hipGraph
         reading fixed index / noise buffers and replayed on later calls."""
-        iterations = indices.shape[0]
+        iterations, global_batch = indices.shape
+        world = self.critic_updater.world_size
+        counts = None
+        if world > 1:
+            # SURVEY §8e: every rank draws the same GLOBAL index / noise stream and keeps the
+            # samples whose worker column lives in its shard (binomial split, mean B / world);
+            # gradient SUMS are all-reduced and scaled by 1 / B_global, so the update equals the
+            # single-process one on the global buffer.
+            indices, positions, counts = self.replay.shard_indices(indices)
+            local_eps = np.zeros_like(eps)
+            for it in range(iterations):
+                c = counts[it]
+                local_eps[it, :, :c] = eps[it][:, positions[it, :c]]
+            eps = local_eps
         key = (iterations, tuple(eps.shape))
         if getattr(self, '_static_key', None) != key:
             self._static_key = key
@@ -401,17 +414,26 @@ class DDPG(Agent):
 
         def enqueue():
             self._infos.zero_()
+            draws = self._static_eps.shape[1]
             for it in range(iterations):
-                batch = self.replay.gather(self._static_indices[it])
-                self.critic_updater.enqueue(batch, self._static_eps[it, 0], self._infos[0, it])
+                c = global_batch if counts is None else int(counts[it])
+                n_global = None if counts is None else global_batch
+                if c > 0:
+                    batch = self.replay.gather(self._static_indices[it, :c])
+                    self.critic_updater.enqueue(batch, self._static_eps[it, 0, :c],
+                                                self._infos[0, it], n_global)
+                else:
+                    self.critic_updater.enqueue_empty(self._infos[0, it], n_global)
                 if self._actor_due(it):
-                    draws = self._static_eps.shape[1]
-                    actor_eps = self._static_eps[it, 1] if draws > 1 else None
-                    self.actor_updater.enqueue(batch['observations'], actor_eps,
-                                               self._infos[1, it])
+                    actor_eps = self._static_eps[it, 1, :c] if draws > 1 else None
+                    if c > 0:
+                        self.actor_updater.enqueue(batch['observations'], actor_eps,
+                                                   self._infos[1, it], n_global)
+                    else:
+                        self.actor_updater.enqueue_empty(self._infos[1, it], n_global)
                     self.model.update_targets()
 
-        if not graph or self.critic_updater.world_size > 1:
+        if not graph or world > 1:
             enqueue()
             return self._infos
         if self._graph is None:

@@ -65,6 +65,9 @@ class MeanStd(torch.nn.Module):
         self.new_count += rows
 
     def update(self):
+        if self.new_count == 0:
+            # mean_stds.py:52 divides the integer 0 by the integer 0 here: same error, no NaNs
+            raise ZeroDivisionError('MeanStd.update() without any recorded values')
         if self.device_sums is not None:
             if torch.distributed.is_available() and torch.distributed.is_initialized() \
                     and torch.distributed.get_world_size() > 1:

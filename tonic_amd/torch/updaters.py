@@ -245,6 +245,11 @@ class _QUpdater(_FlatUpdater):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
         return self.workspace
 
+    def enqueue_empty(self, info_row, n_global):
+        """This rank drew none of the global batch: contribute zero sums, take the same step."""
+        self.grad_sums.zero_()
+        self._step(n_global, info_row)
+
     def _info(self, fn, keys):
         self.scratch_info.zero_()
         fn(self.scratch_info)
@@ -272,7 +277,7 @@ class _TwinCriticQLearning(_QUpdater):
     def _policy_params(self):
         raise NotImplementedError
 
-    def enqueue(self, batch, eps, info_row):
+    def enqueue(self, batch, eps, info_row, n_global=None):
         B = batch['observations'].shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -286,7 +291,7 @@ class _TwinCriticQLearning(_QUpdater):
             float(getattr(self, 'entropy_coeff', 0.0)), float(noise.scale if noise else 0.0),
             float(noise.clip if noise else 0.0), p(ws), ws.numel(), _lib.current_stream()),
             'tonic_twin_q_grad')
-        self._step(B * self.world_size, info_row)
+        self._step(n_global or B * self.world_size, info_row)
 
     def __call__(self, observations, actions, next_observations, rewards, discounts):
         """Drop-in form: draws its own noise from the torch CPU generator like the reference."""
@@ -333,7 +338,7 @@ class _ActorQGradient(_QUpdater):
         self._setup(model.flat_actor, adam_hyperparameters(self.optimizer, self.default_lr))
         self.variables = model.flat_actor.params
 
-    def enqueue(self, observations, eps, info_row):
+    def enqueue(self, observations, eps, info_row, n_global=None):
         B = observations.shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -343,7 +348,7 @@ class _ActorQGradient(_QUpdater):
             p(observations), p(eps), p(self.grad_sums), B, self.observation_size, self.hidden,
             self.action_size, float(getattr(self, 'entropy_coeff', 0.0)), p(ws), ws.numel(),
             _lib.current_stream()), 'tonic_actor_q_grad')
-        self._step(B * self.world_size, info_row)
+        self._step(n_global or B * self.world_size, info_row)
 
     def __call__(self, observations):
         eps = None
