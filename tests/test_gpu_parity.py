@@ -23,6 +23,8 @@ def lib():
 
 
 def dev(x, dtype=torch.float32):
+    if isinstance(x, torch.Tensor):
+        return x.to(device='cuda', dtype=dtype).contiguous()
     return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda().contiguous()
 
 
@@ -274,6 +276,61 @@ def test_grads_full_size_properties(lib, variant):
     want, _ = port.clipped_ratio_grads(params, obs[:m], actions[:m], adv[:m], old_lp[:m])
     part, _ = actor_grad(lib, params, obs[:m], actions[:m], adv[:m], stats, old_lp[:m], variant)
     assert_grads_close(part[:P], want, m, 'slice of the full batch')
+
+
+def test_config5_size_properties(lib):
+    """BASELINE config 5 at its single-GPU maximum (AntBullet shapes O=28, A=8, W=10240, T=4096:
+    N = 41.9 M transitions, 4.7 GB of observations): 64-bit indexing end to end.  The gradient
+    sums are additive over a split of the batch, the tail slice agrees with the oracle, and the
+    lambda-return scan over [4096, 10240] is bit-exact."""
+    O, A, T, W = 28, 8, 4096, 10240
+    n = T * W
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    rng = np.random.RandomState(5)
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              np.zeros((1, A)), rng.normal(size=(A, 64)) * 0.1, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    obs = torch.randn(n, O, device='cuda', generator=g)
+    actions = torch.randn(n, A, device='cuda', generator=g).clamp_(-1, 1)
+    adv = torch.randn(n, device='cuda', generator=g)
+    old_lp = torch.randn(n, device='cuda', generator=g) * 0.2 - 8
+    returns = torch.randn(n, device='cuda', generator=g)
+    stats = np.array([0, 1, 0, 0], np.float32)
+    mean, std = rng.normal(size=O).astype(np.float32), (0.5 + rng.uniform(size=O)).astype(np.float32)
+    h = n // 2 + 12345                                   # uneven split, second half starts > 2^31 B in
+    full, P = actor_grad(lib, params, obs, actions, adv, stats, old_lp)
+    a, _ = actor_grad(lib, params, obs[:h], actions[:h], adv[:h], stats, old_lp[:h])
+    b, _ = actor_grad(lib, params, obs[h:], actions[h:], adv[h:], stats, old_lp[h:])
+    both = a.astype(np.float64) + b.astype(np.float64)
+    assert np.abs(both[:P] - full[:P]).max() <= 2e-5 * np.abs(full[:P]).max()
+    assert full[P + 5] == n and abs(both[P + 5] - n) <= 4, 'sample count statistic (float32)'
+    cfull, Pc = critic_grad(lib, cparams, mean, std, obs, returns)
+    ca, _ = critic_grad(lib, cparams, mean, std, obs[:h], returns[:h])
+    cb, _ = critic_grad(lib, cparams, mean, std, obs[h:], returns[h:])
+    cboth = ca.astype(np.float64) + cb.astype(np.float64)
+    assert np.abs(cboth[:Pc] - cfull[:Pc]).max() <= 2e-5 * np.abs(cfull[:Pc]).max()
+    m = 4096                                             # the LAST rows: highest addresses
+    tail = [t[n - m:].cpu().numpy() for t in (obs, actions, adv, old_lp, returns)]
+    want, _ = port.clipped_ratio_grads(params, tail[0], tail[1], tail[2], tail[3])
+    part, _ = actor_grad(lib, params, obs[n - m:], actions[n - m:], adv[n - m:], stats, old_lp[n - m:])
+    assert_grads_close(part[:P], want, m, 'tail slice, actor')
+    want, _ = port.value_regression_grads(cparams, mean, std, tail[0], tail[4])
+    part, _ = critic_grad(lib, cparams, mean, std, obs[n - m:], returns[n - m:])
+    assert_grads_close(part[:Pc], want, m, 'tail slice, critic')
+    del obs, actions, full, a, b
+
+    nv, rew, val = (torch.randn(T, W, device='cuda', generator=g).cpu().numpy() for _ in range(3))
+    rst = rng.uniform(size=(T, W)) < 1e-3
+    term = (rst & (rng.uniform(size=(T, W)) < 0.5)).astype(np.float32)
+    rst = rst.astype(np.float32)
+    want = port.lambda_returns(nv, rew, rst, term, 0.99, 0.97)
+    ret, adv_out, _ = run_gae(lib, nv, rew, rst, term, val, 0.99, 0.97, 1)
+    assert np.array_equal(ret, want) and np.array_equal(adv_out, want - val)
+    ret_auto, _, _ = run_gae(lib, nv, rew, rst, term, val, 0.99, 0.97, 0)
+    assert np.abs(ret_auto - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
 
 
 # -------------------------------------------------------------------------------- Adam
