@@ -252,6 +252,17 @@ int tonic_buffer_store(float* d_buf_observations, float* d_buf_actions,
                        int64_t row, int64_t W, int32_t O, int32_t A, double discount_factor,
                        void* stream);
 
+/* replaces: tonic/replays/buffers.py:58-79 (Buffer.accumulate_n_steps, return_steps > 1): call
+ *   right after tonic_buffer_store wrote row `row`, with `size` = the number of filled rows
+ *   BEFORE this store.  Folds the new reward / discount / next observation into the previous
+ *   min(size, return_steps - 1) rows until a stored reset cuts the chain.  Bit-exact. */
+int tonic_buffer_accumulate_n_steps(float* d_buf_next_observations, float* d_buf_rewards,
+                                    float* d_buf_discounts, const float* d_buf_resets,
+                                    const float* d_next_observations, const float* d_rewards,
+                                    const float* d_terminations, int64_t row, int64_t size,
+                                    int64_t max_size, int64_t W, int32_t O, int32_t return_steps,
+                                    double discount_factor, void* stream);
+
 /* replaces: tonic/replays/buffers.py:84-91 (Buffer.get: rows = idx // W, cols = idx % W, fancy-
  *   index gather of 5 keys).  d_indices: int64[B] drawn by the host RandomState (bit-exact
  *   stream); one wavefront copies one sampled transition. */

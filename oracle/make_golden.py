@@ -156,6 +156,39 @@ def golden_buffer(tonic):
     save('buffer', source='tonic/replays/buffers.py:28-91', **out)
 
 
+def golden_buffer_nstep(tonic):
+    """tonic/replays/buffers.py:33-79 with return_steps > 1 (accumulate_n_steps)."""
+    out = {}
+    for case, (workers, size, steps) in enumerate([(4, 48, 3), (1, 9, 5), (5, 40, 2)]):
+        rng = np.random.RandomState(40 + case)
+        buf = tonic.replays.Buffer(size=size, return_steps=steps)
+        buf.initialize(seed=case)
+        n_store = size // workers + 7        # wraps the circular index
+        pre = f'n{case}_'
+        names = ('observations', 'actions', 'next_observations', 'rewards', 'resets',
+                 'terminations')
+        stored = {k: [] for k in names}
+        for t in range(n_store):
+            kw = dict(observations=rng.normal(size=(workers, 3)).astype(np.float32),
+                      actions=rng.uniform(-1, 1, size=(workers, 2)).astype(np.float32),
+                      next_observations=rng.normal(size=(workers, 3)).astype(np.float32),
+                      rewards=rng.normal(size=workers).astype(np.float32),
+                      resets=rng.uniform(size=workers) < 0.25,
+                      terminations=rng.uniform(size=workers) < 0.15)
+            for k in names:
+                stored[k].append(kw[k])
+            buf.store(**kw)
+            if t == 3:                       # early snapshot: fewer stored rows than return_steps
+                for k, v in buf.buffers.items():
+                    out[pre + 'early_' + k] = v.copy()
+        for k in names:
+            out[pre + 'in_' + k] = np.array(stored[k])
+        for k, v in buf.buffers.items():
+            out[pre + 'buf_' + k] = v.copy()
+        out[pre + 'cfg'] = np.array([workers, size, steps, buf.index, buf.size], np.int64)
+    save('buffer_nstep', source='tonic/replays/buffers.py:33-79', **out)
+
+
 def golden_segment_minibatches(tonic):
     """tonic/replays/segments.py:50-65 with batch_size set (index stream)."""
     seg = tonic.replays.Segment(size=6, batch_iterations=3, batch_size=7)
@@ -416,6 +449,11 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
 def main():
     torch.set_num_threads(1)
     tonic = rl.load_reference()
+    if len(sys.argv) > 1:                    # regenerate only the named pure-replay goldens
+        for name in sys.argv[1:]:
+            globals()['golden_' + name](tonic)
+        return
+    golden_buffer_nstep(tonic)
     golden_lambda_returns(tonic)
     golden_meanstd(tonic)
     golden_buffer(tonic)

@@ -95,6 +95,48 @@ def buffer_discounts(terminations, discount_factor):
     return np.float32(1 - terminations) * discount_factor
 
 
+class BufferPort:
+    """``Buffer.store`` incl. ``accumulate_n_steps`` — ``tonic/replays/buffers.py:33-79``: circular
+    float32 rows; with ``return_steps > 1`` every store folds the new reward / discount /
+    next observation into the previous ``return_steps - 1`` rows until a reset cuts the chain."""
+
+    KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+            'discounts')
+
+    def __init__(self, size, num_workers, return_steps=1, discount_factor=0.99):
+        self.max_size = size // num_workers
+        self.num_workers = num_workers
+        self.return_steps = return_steps
+        self.discount_factor = discount_factor
+        self.buffers = None
+        self.index = 0
+        self.size = 0
+
+    def store(self, **kw):
+        kw = dict(kw, discounts=buffer_discounts(kw['terminations'], self.discount_factor))  # :34-36
+        if self.buffers is None:                                                   # :39-45
+            self.buffers = {k: np.full((self.max_size,) + np.array(kw[k]).shape, np.nan, F32)
+                            for k in self.KEYS}
+        for k in self.KEYS:                                                        # :48-49
+            self.buffers[k][self.index] = kw[k]
+        if self.return_steps > 1:                                                  # :52-53
+            b = self.buffers
+            rewards, next_obs, discounts = kw['rewards'], kw['next_observations'], kw['discounts']
+            masks = np.ones(self.num_workers, F32)
+            for i in range(min(self.size, self.return_steps - 1)):                 # :64-79
+                index = (self.index - i - 1) % self.max_size
+                masks = masks * (1 - b['resets'][index])
+                new_rewards = b['rewards'][index] + b['discounts'][index] * rewards
+                b['rewards'][index] = (1 - masks) * b['rewards'][index] + masks * new_rewards
+                new_discounts = b['discounts'][index] * discounts
+                b['discounts'][index] = (1 - masks) * b['discounts'][index] + masks * new_discounts
+                b['next_observations'][index] = (
+                    (1 - masks)[:, None] * b['next_observations'][index]
+                    + masks[:, None] * next_obs)
+        self.index = (self.index + 1) % self.max_size                              # :55-56
+        self.size = min(self.size + 1, self.max_size)
+
+
 def buffer_sample_indices(np_random, size, num_workers, batch_size):
     """``Buffer.get`` index math — ``tonic/replays/buffers.py:84-88`` (int64)."""
     flat = np_random.randint(size * num_workers, size=batch_size)

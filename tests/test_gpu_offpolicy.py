@@ -56,6 +56,25 @@ def test_gemm16_vs_numpy(lib, mode, M, N, K):
     assert np.abs(out.cpu().numpy() - want).max() <= tol + 1e-6
 
 
+def test_buffer_n_step_returns_bit_exact(lib, golden):
+    """Buffer(return_steps > 1) on the GPU == the reference's accumulate_n_steps (buffers.py:58-79),
+    bit for bit, incl. the early steps and the circular wrap."""
+    import tonic_amd
+    from test_oracle_golden import nstep_cases
+    g = golden('buffer_nstep')
+    for pre, workers, size, steps, index, filled, rows in nstep_cases(g):
+        buf = tonic_amd.replays.Buffer(size=size, return_steps=steps)
+        buf.initialize(seed=0)
+        for t, row in enumerate(rows):
+            buf.store(**{k: dev(v) for k, v in row.items()})
+            if t == 3:
+                for k, v in buf.buffers.items():
+                    assert np.array_equal(v.cpu().numpy(), g[pre + 'early_' + k], equal_nan=True), k
+        assert (buf.index, buf.size) == (index, filled)
+        for k, v in buf.buffers.items():
+            assert np.array_equal(v.cpu().numpy(), g[pre + 'buf_' + k], equal_nan=True), (pre, k)
+
+
 @pytest.mark.parametrize('name', ['sac_small', 'td3_small'])
 def test_buffer_store_gather_bit_exact(lib, golden, name):
     """Replays the reference run's stores into the HBM Buffer and gathers with the reference's

@@ -65,6 +65,31 @@ def test_buffer_index_math_bit_exact(golden):
                                       g[pre + f'get{it}_' + key], equal_nan=True)
 
 
+def nstep_cases(g):
+    for case in range(3):
+        pre = f'n{case}_'
+        workers, size, steps, index, filled = (int(x) for x in g[pre + 'cfg'])
+        rows = [{k: g[pre + 'in_' + k][t] for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations')}
+            for t in range(g[pre + 'in_rewards'].shape[0])]
+        yield pre, workers, size, steps, index, filled, rows
+
+
+def test_buffer_n_step_accumulation_bit_exact(golden):
+    """Buffer(return_steps > 1): store + accumulate_n_steps (buffers.py:33-79)."""
+    g = golden('buffer_nstep')
+    for pre, workers, size, steps, index, filled, rows in nstep_cases(g):
+        buf = port.BufferPort(size, workers, return_steps=steps)
+        for t, row in enumerate(rows):
+            buf.store(**row)
+            if t == 3:
+                for k in buf.KEYS:
+                    assert np.array_equal(buf.buffers[k], g[pre + 'early_' + k], equal_nan=True), k
+        assert (buf.index, buf.size) == (index, filled)
+        for k in buf.KEYS:
+            assert np.array_equal(buf.buffers[k], g[pre + 'buf_' + k], equal_nan=True), k
+
+
 def test_segment_minibatch_indices_bit_exact(golden):
     g = golden('segment_minibatch')
     rng = np.random.RandomState(int(g['seed']))

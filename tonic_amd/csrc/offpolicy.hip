@@ -199,6 +199,49 @@ __global__ __launch_bounds__(256) void buffer_gather_kernel(GatherArgs g) {
   if (lane == 0) { g.o_rew[b] = g.rew[t]; g.o_disc[b] = g.disc[t]; }
 }
 
+// Buffer.accumulate_n_steps (buffers.py:58-79) after the row write of one store: thread = one
+// (worker, next-observation feature) element; the reset mask chain of a worker is recomputed per
+// thread (at most return_steps - 1 reads).  Every expression keeps the reference's separate
+// float32 roundings — `(1 - m) * old + m * new` is NOT replaced by a select, so that even the
+// sign of a zero comes out as in NumPy.
+struct NStepArgs {
+  float* b_next; float* b_rew; float* b_disc; const float* b_rst;
+  const float* next; const float* rew; const float* term;
+  int64_t row, size, max_size, W;
+  int O, back;
+  float discount;
+};
+
+__global__ __launch_bounds__(256) void buffer_nstep_kernel(NStepArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.W * a.O) return;
+  const int64_t w = e / a.O;
+  const int k = (int)(e - w * a.O);
+  const float reward = a.rew[w];
+  const float discount = (1.f - a.term[w]) * a.discount;             // buffers.py:34-36
+  const float next = a.next[e];
+  float mask = 1.f;
+  for (int i = 0; i < a.back; ++i) {
+    int64_t index = (a.row - i - 1) % a.max_size;
+    if (index < 0) index += a.max_size;                              // Python modulo
+    const int64_t at = index * a.W + w;
+    mask = mask * (1.f - a.b_rst[at]);
+    const float keep = 1.f - mask;
+    if (k == 0) {
+      const float r_old = a.b_rew[at], d_old = a.b_disc[at];
+      const float scaled = d_old * reward;
+      const float new_reward = r_old + scaled;
+      const float r_keep = keep * r_old, r_take = mask * new_reward;
+      a.b_rew[at] = r_keep + r_take;
+      const float new_discount = d_old * discount;
+      const float d_keep = keep * d_old, d_take = mask * new_discount;
+      a.b_disc[at] = d_keep + d_take;
+    }
+    const float o_keep = keep * a.b_next[at * a.O + k], o_take = mask * next;
+    a.b_next[at * a.O + k] = o_keep + o_take;
+  }
+}
+
 // Buffer.store row write (buffers.py:33-52) + MeanStd.record (mean_stds.py:44-48).
 struct BufferStoreArgs {
   float* b_obs; float* b_act; float* b_next; float* b_rew; float* b_rst; float* b_term; float* b_disc;
@@ -592,6 +635,35 @@ extern "C" int tonic_buffer_gather(const int64_t* d_indices, const float* d_buf_
                d_rewards, d_discounts, W, B, O, A};
   hipLaunchKernelGGL(buffer_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), g);
   TONIC_CHECK_LAUNCH("tonic_buffer_gather");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_buffer_accumulate_n_steps(float* d_buf_next_observations,
+                                               float* d_buf_rewards, float* d_buf_discounts,
+                                               const float* d_buf_resets,
+                                               const float* d_next_observations,
+                                               const float* d_rewards,
+                                               const float* d_terminations, int64_t row,
+                                               int64_t size, int64_t max_size, int64_t W,
+                                               int32_t O, int32_t return_steps,
+                                               double discount_factor, void* stream) {
+  TONIC_REQUIRE(d_buf_next_observations && d_buf_rewards && d_buf_discounts && d_buf_resets &&
+                    d_next_observations && d_rewards && d_terminations,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_buffer_accumulate_n_steps: null pointer");
+  TONIC_REQUIRE(row >= 0 && row < max_size && size >= 0 && size <= max_size && W > 0 && O > 0 &&
+                    return_steps >= 1,
+                TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_buffer_accumulate_n_steps: row=%lld size=%lld max_size=%lld W=%lld O=%d "
+                "return_steps=%d", (long long)row, (long long)size, (long long)max_size,
+                (long long)W, O, return_steps);
+  const int64_t back = size < return_steps - 1 ? size : return_steps - 1;      // buffers.py:64
+  if (back == 0) return TONIC_OK;
+  NStepArgs a{d_buf_next_observations, d_buf_rewards, d_buf_discounts, d_buf_resets,
+              d_next_observations, d_rewards, d_terminations, row, size, max_size, W, O,
+              (int)back, (float)discount_factor};
+  const int64_t blocks = (W * O + 255) / 256;
+  hipLaunchKernelGGL(buffer_nstep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+  TONIC_CHECK_LAUNCH("tonic_buffer_accumulate_n_steps");
   return TONIC_OK;
 }
 

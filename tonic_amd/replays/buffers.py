@@ -4,7 +4,8 @@ Circular float32 store ``[max_size = size // W, W, ...]`` for ``observations, ac
 next_observations, rewards, resets, terminations, discounts``, NaN-initialised like the
 reference (buffers.py:45), 936 B per transition at O=111, A=8 (0.94 GB for 1 M transitions).
 ``store`` is one ``tonic_buffer_store`` launch (row write, ``discounts = float32(1 -
-terminations) * discount_factor``, observation-normaliser record); ``get`` draws the indices
+terminations) * discount_factor``, observation-normaliser record) plus, for ``return_steps > 1``,
+one ``tonic_buffer_accumulate_n_steps`` launch (buffers.py:58-79, bit-exact); ``get`` draws the indices
 with the host ``RandomState`` exactly like buffers.py:86 (bit-exact stream) and gathers the
 batch with ``tonic_buffer_gather`` (one wavefront per sampled transition,
 ``rows = idx // W``, ``cols = idx % W``).
@@ -22,9 +23,6 @@ BATCH_KEYS = ('observations', 'actions', 'next_observations', 'rewards', 'discou
 class Buffer:
     def __init__(self, size=int(1e6), return_steps=1, batch_iterations=50, batch_size=100,
                  discount_factor=0.99, steps_before_batches=int(1e4), steps_between_batches=50):
-        if return_steps != 1:
-            raise NotImplementedError('n-step returns (return_steps > 1) are not implemented in '
-                                      'the HIP engine yet (SURVEY.md §8f item 3)')
         self.full_max_size = size
         self.return_steps = return_steps
         self.batch_iterations = batch_iterations
@@ -86,6 +84,13 @@ class Buffer:
             float(self.discount_factor), _lib.current_stream()), 'tonic_buffer_store')
         if normalizer is not None:
             normalizer.note_device_rows(self.num_workers)
+        if self.return_steps > 1:                                    # buffers.py:52-53
+            _lib.check(self.lib.tonic_buffer_accumulate_n_steps(
+                p(b['next_observations']), p(b['rewards']), p(b['discounts']), p(b['resets']),
+                p(kwargs['next_observations']), p(kwargs['rewards']), p(kwargs['terminations']),
+                self.index, self.size, self.max_size, self.num_workers, self.observation_size,
+                self.return_steps, float(self.discount_factor), _lib.current_stream()),
+                'tonic_buffer_accumulate_n_steps')
         self.index = (self.index + 1) % self.max_size
         self.size = min(self.size + 1, self.max_size)
 

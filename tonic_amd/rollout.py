@@ -87,7 +87,7 @@ class DeviceRollout:
 
     def collect(self, capture=False):
         """Fills the agent's Segment with T steps (asynchronous; no host sync)."""
-        if capture:
+        if capture and not getattr(self, 'capture_failed', False):
             if self.graph is None:
                 if self.packed and getattr(self, 'packed_actor', None) is None:
                     self.packed_actor = torch.empty(
@@ -102,10 +102,23 @@ class DeviceRollout:
                 if saved is not None:
                     norm.device_sums.copy_(saved)
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._enqueue()
-            self.graph.replay()
+                # thread_local: API calls of OTHER threads (e.g. the RCCL watchdog of a multi-GPU
+                # run polling its events) must not invalidate this thread's capture.
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                        self._enqueue()
+                    self.graph = graph
+                except RuntimeError as error:       # still the HIP path, just launched eagerly
+                    import sys
+                    print(f'tonic_amd: hipGraph capture of the rollout failed ({error}); '
+                          'falling back to eager kernel launches', file=sys.stderr)
+                    self.capture_failed = True
+                    torch.cuda.synchronize()
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._enqueue()
         else:
             self._enqueue()
         norm = self.agent.model.observation_normalizer
