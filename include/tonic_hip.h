@@ -284,7 +284,10 @@ int tonic_policy_forward(const float* d_actor_params, const float* d_observation
 /* replaces: kind 0 TwinCriticDeterministicQLearning.__call__ (tonic/torch/updaters/
  *   critics.py:156-175, TargetActionNoise :125-134; d_policy_params = TARGET actor),
  *   kind 1 TwinCriticSoftQLearning.__call__ (critics.py:202-227; d_policy_params = ONLINE
- *   actor, quirk Q9).  d_eps [B,A]: host-drawn standard normals (torch CPU generator order).
+ *   actor, quirk Q9), kind 2 DeterministicQLearning.__call__ (critics.py:68-86, DDPG: ONE critic
+ *   block in d_target_critics / d_critics, target actor, no noise, d_eps may be NULL; output
+ *   [critic sums | 8 statistics {sq_err_sum, q_sum, 0, ...}]).
+ *   d_eps [B,A]: host-drawn standard normals (torch CPU generator order).
  *   Output: gradient SUMS over the batch for [critic_1 | critic_2] + 8 statistics
  *   {sq_err_sum (both critics), q1_sum, q2_sum, 0, 0, B, 0, 0}; follow with
  *   tonic_adam_step(grad_scale = 1/B). */

@@ -359,7 +359,9 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
                                          distribution=models.SquashedMultivariateNormalDiag)
     else:
         head = models.DeterministicPolicyHead()
-    model = models.ActorTwinCriticWithTargets(
+    container = (models.ActorCriticWithTargets if kind == 'ddpg'
+                 else models.ActorTwinCriticWithTargets)
+    model = container(
         actor=models.Actor(encoder=models.ObservationEncoder(),
                            torso=models.MLP((hidden, hidden), relu), head=head),
         critic=critic, observation_normalizer=tonic.torch.normalizers.MeanStd())
@@ -370,7 +372,8 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
             model=model, replay=replay,
             exploration=tonic.explorations.NoActionNoise(start_steps=workers * 5))
     else:
-        agent = tonic.torch.agents.TD3(
+        cls = tonic.torch.agents.DDPG if kind == 'ddpg' else tonic.torch.agents.TD3
+        agent = cls(
             model=model, replay=replay,
             exploration=tonic.explorations.NormalActionNoise(start_steps=workers * 5))
     agent.initialize(env.observation_space, env.action_space, seed=seed)
@@ -449,9 +452,13 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
 def main():
     torch.set_num_threads(1)
     tonic = rl.load_reference()
-    if len(sys.argv) > 1:                    # regenerate only the named pure-replay goldens
+    if len(sys.argv) > 1:                    # regenerate only the named goldens
         for name in sys.argv[1:]:
-            globals()['golden_' + name](tonic)
+            if name == 'ddpg_small':
+                run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2,
+                              batch=16, seed=5)
+            else:
+                globals()['golden_' + name](tonic)
         return
     golden_buffer_nstep(tonic)
     golden_lambda_returns(tonic)
@@ -471,6 +478,7 @@ def main():
             batch_size=64)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
+    run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)
 
 
 if __name__ == '__main__':

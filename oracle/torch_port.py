@@ -139,12 +139,13 @@ ACTOR_KEYS = {'sac': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model
               'td3': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
                       'torso.model.2.bias', 'head.action_layer.0.weight',
                       'head.action_layer.0.bias')}
+ACTOR_KEYS['ddpg'] = ACTOR_KEYS['td3']
 CRITIC_KEYS = ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
                'torso.model.2.bias', 'head.v_layer.weight', 'head.v_layer.bias')
 
 
 class OffPolicyPort:
-    """SAC / TD3 learner restated with torch-CPU autograd:
+    """SAC / TD3 / DDPG learner restated with torch-CPU autograd:
     ``tonic/torch/updaters/critics.py:125-134,156-182,202-235``,
     ``tonic/torch/updaters/actors.py:170-189,238-267``,
     ``tonic/torch/models/actors.py:7-34,94-98,113-115``, ``models/encoders.py:28-31``,
@@ -156,16 +157,17 @@ class OffPolicyPort:
 
         def grab(net, keys, grad):
             return [torch.tensor(state[f'{prefix}{net}.{k}'], requires_grad=grad) for k in keys]
+        # DDPG (agents/ddpg.py, critics.py:56-86): ONE critic named `critic` / `target_critic`
+        self.critic_names = ('critic',) if kind == 'ddpg' else ('critic_1', 'critic_2')
         self.actor = grab('actor', ACTOR_KEYS[kind], True)
-        self.critics = [grab('critic_1', CRITIC_KEYS, True), grab('critic_2', CRITIC_KEYS, True)]
+        self.critics = [grab(n, CRITIC_KEYS, True) for n in self.critic_names]
         self.target_actor = grab('target_actor', ACTOR_KEYS[kind], False)
-        self.target_critics = [grab('target_critic_1', CRITIC_KEYS, False),
-                               grab('target_critic_2', CRITIC_KEYS, False)]
+        self.target_critics = [grab('target_' + n, CRITIC_KEYS, False) for n in self.critic_names]
         self.mean = torch.tensor(state[prefix + 'observation_normalizer._mean'])
         self.std = torch.tensor(state[prefix + 'observation_normalizer._std'])
         lr_actor, lr_critic = (3e-4, 3e-4) if kind == 'sac' else (1e-3, 1e-3)
         self.actor_opt = torch.optim.Adam(self.actor, lr=lr_actor)
-        self.critic_opt = torch.optim.Adam(self.critics[0] + self.critics[1], lr=lr_critic)
+        self.critic_opt = torch.optim.Adam(sum(self.critics, []), lr=lr_critic)
 
     @staticmethod
     def torso(p, x):
@@ -179,7 +181,7 @@ class OffPolicyPort:
     def policy(self, p, observations, eps):
         """Returns (actions, log_probs) — log_probs None for the deterministic head."""
         h = self.torso(p, observations)
-        if self.kind == 'td3':
+        if self.kind != 'sac':
             return torch.tanh(torch.nn.functional.linear(h, p[4], p[5])), None
         loc = torch.nn.functional.linear(h, p[4], p[5])
         scale = torch.clamp(torch.nn.functional.softplus(
@@ -191,6 +193,17 @@ class OffPolicyPort:
         return squashed, log_probs.sum(dim=-1)
 
     def critic_step(self, b, eps):
+        if self.kind == 'ddpg':                                    # critics.py:68-86
+            with torch.no_grad():
+                next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
+                returns = b['rewards'] + b['discounts'] * self.q(
+                    self.target_critics[0], b['next_observations'], next_actions)
+            self.critic_opt.zero_grad()
+            q = self.q(self.critics[0], b['observations'], b['actions'])
+            loss = torch.nn.functional.mse_loss(q, returns)
+            loss.backward()
+            self.critic_opt.step()
+            return dict(loss=float(loss.detach()), q1=float(q.detach().mean()), q2=0.0)
         with torch.no_grad():
             if self.kind == 'td3':
                 next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
@@ -209,12 +222,13 @@ class OffPolicyPort:
         loss = torch.nn.functional.mse_loss(q1, returns) + torch.nn.functional.mse_loss(q2, returns)
         loss.backward()
         self.critic_opt.step()
-        return dict(loss=float(loss), q1=float(q1.mean()), q2=float(q2.mean()))
+        return dict(loss=float(loss.detach()), q1=float(q1.detach().mean()),
+                    q2=float(q2.detach().mean()))
 
     def actor_step(self, b, eps):
         self.actor_opt.zero_grad()
         actions, lp = self.policy(self.actor, b['observations'], eps)
-        if self.kind == 'td3':
+        if self.kind != 'sac':
             loss = -self.q(self.critics[0], b['observations'], actions).mean()
         else:
             q = torch.min(self.q(self.critics[0], b['observations'], actions),
@@ -222,13 +236,13 @@ class OffPolicyPort:
             loss = (self.alpha * lp - q).mean()
         loss.backward()
         self.actor_opt.step()
-        for p in self.critics[0] + self.critics[1]:
+        for p in sum(self.critics, []):
             p.grad = None
-        return dict(loss=float(loss))
+        return dict(loss=float(loss.detach()))
 
     def update_targets(self):
-        online = self.actor + self.critics[0] + self.critics[1]
-        target = self.target_actor + self.target_critics[0] + self.target_critics[1]
+        online = self.actor + sum(self.critics, [])
+        target = self.target_actor + sum(self.target_critics, [])
         with torch.no_grad():
             for o, t in zip(online, target):
                 t.mul_(1 - self.tau)
@@ -242,7 +256,7 @@ class OffPolicyPort:
             b = {k: torch.as_tensor(buffers[k][rows, cols]) for k in (
                 'observations', 'actions', 'next_observations', 'rewards', 'discounts')}
             info = dict(critic=self.critic_step(b, torch.as_tensor(eps[it, 0])))
-            if self.kind == 'sac' or (it + 1) % self.delay == 0:
+            if self.kind != 'td3' or (it + 1) % self.delay == 0:
                 actor_eps = torch.as_tensor(eps[it, 1]) if self.kind == 'sac' else None
                 info['actor'] = self.actor_step(b, actor_eps)
                 self.update_targets()
@@ -251,12 +265,11 @@ class OffPolicyPort:
 
     def state(self):
         out = {}
-        for net, params, keys in (
-                ('actor', self.actor, ACTOR_KEYS[self.kind]),
-                ('critic_1', self.critics[0], CRITIC_KEYS), ('critic_2', self.critics[1], CRITIC_KEYS),
-                ('target_actor', self.target_actor, ACTOR_KEYS[self.kind]),
-                ('target_critic_1', self.target_critics[0], CRITIC_KEYS),
-                ('target_critic_2', self.target_critics[1], CRITIC_KEYS)):
+        nets = [('actor', self.actor, ACTOR_KEYS[self.kind]),
+                ('target_actor', self.target_actor, ACTOR_KEYS[self.kind])]
+        for n, online, target in zip(self.critic_names, self.critics, self.target_critics):
+            nets += [(n, online, CRITIC_KEYS), ('target_' + n, target, CRITIC_KEYS)]
+        for net, params, keys in nets:
             for k, p in zip(keys, params):
                 out[f'{net}.{k}'] = p.detach().numpy()
         return out

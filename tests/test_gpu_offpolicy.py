@@ -116,7 +116,9 @@ def _agent_from_golden(g, kind):
                                             distribution=tt.models.SquashedMultivariateNormalDiag)
     else:
         head = tt.models.DeterministicPolicyHead()
-    model = tt.models.ActorTwinCriticWithTargets(
+    container = (tt.models.ActorCriticWithTargets if kind == 'ddpg'
+                 else tt.models.ActorTwinCriticWithTargets)
+    model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
                               torso=tt.models.MLP((hidden, hidden), relu), head=head),
         critic=critic, observation_normalizer=tt.normalizers.MeanStd())
@@ -126,13 +128,17 @@ def _agent_from_golden(g, kind):
         agent = tt.agents.SAC(model=model, replay=replay,
                               exploration=tonic_amd.explorations.NoActionNoise(start_steps=W * 5))
     else:
-        agent = tt.agents.TD3(model=model, replay=replay,
-                              exploration=tonic_amd.explorations.NormalActionNoise(start_steps=W * 5))
+        cls = tt.agents.DDPG if kind == 'ddpg' else tt.agents.TD3
+        agent = cls(model=model, replay=replay,
+                    exploration=tonic_amd.explorations.NormalActionNoise(start_steps=W * 5))
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
     return agent
 
 
-@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3')])
+OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg')]
+
+
+@pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
 def test_offpolicy_update_matches_reference(lib, golden, name, kind):
     g = golden(name)
     agent = _agent_from_golden(g, kind)
@@ -148,8 +154,11 @@ def test_offpolicy_update_matches_reference(lib, golden, name, kind):
             'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations')})
     infos = agent.enqueue_update(g['indices'], g['eps']).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], g['info/critic/loss'], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q1_mean'], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(infos[0][:, 2], g['info/critic/q2_mean'], rtol=1e-5, atol=1e-5)
+    if kind == 'ddpg':
+        np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q_mean'], rtol=1e-5, atol=1e-5)
+    else:
+        np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q1_mean'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(infos[0][:, 2], g['info/critic/q2_mean'], rtol=1e-5, atol=1e-5)
     ran = infos[1][:, 6] > 0
     assert ran.sum() == len(g['info/actor/loss'])
     np.testing.assert_allclose(infos[1][ran, 0], g['info/actor/loss'], rtol=1e-5, atol=1e-5)
@@ -162,7 +171,7 @@ def test_offpolicy_update_matches_reference(lib, golden, name, kind):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg=key)
 
 
-@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3')])
+@pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
 def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
     """agent.step / agent.update with NumPy in/out replays the reference run: warm-up actions
     from the NumPy stream, policy actions (+ exploration noise / sampled noise) after it, the
@@ -195,7 +204,8 @@ def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
     assert updated
 
 
-@pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100)])
+@pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100),
+                                          ('ddpg', 17, 6, 4, 100)])
 def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     """cfg-3 (SAC, O=111, A=8, B=1024) and cfg-4 per-GPU (TD3, O=67, A=21, 64 workers, the
     reference's default B=100) shapes with the default 256-wide networks: two learner iterations
@@ -208,7 +218,7 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     rng = np.random.RandomState(7)
     rows = 64
     replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
-    agent = (tt.agents.SAC if kind == 'sac' else tt.agents.TD3)(replay=replay)
+    agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG)[kind](replay=replay)
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
     # make the normaliser non-trivial
     norm = agent.model.observation_normalizer

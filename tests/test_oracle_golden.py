@@ -241,7 +241,8 @@ def test_c_restatement_matches_golden(golden):
             assert np.array_equal(out, g[k + 'returns']), k
 
 
-@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3')])
+@pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3'),
+                                       ('ddpg_small', 'ddpg')])
 def test_offpolicy_port_matches_reference(golden, name, kind):
     """oracle/torch_port.OffPolicyPort replays the reference's first SAC / TD3 update from the
     golden buffer, index stream and normal draws (this also pins the RNG bookkeeping)."""
@@ -260,8 +261,8 @@ def test_offpolicy_port_matches_reference(golden, name, kind):
     assert np.isnan(buffers['rewards'][size:]).all()
     infos = port_.update(buffers, workers, g['indices'], g['eps'])
     np.testing.assert_allclose([i['critic']['loss'] for i in infos], g['info/critic/loss'], rtol=1e-6)
-    np.testing.assert_allclose([i['critic']['q1'] for i in infos], g['info/critic/q1_mean'],
-                               rtol=1e-5, atol=1e-7)
+    q_key = 'info/critic/q_mean' if kind == 'ddpg' else 'info/critic/q1_mean'
+    np.testing.assert_allclose([i['critic']['q1'] for i in infos], g[q_key], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose([i['actor']['loss'] for i in infos if 'actor' in i],
                                g['info/actor/loss'], rtol=1e-5, atol=1e-7)
     for key, value in port_.state().items():

@@ -89,12 +89,22 @@ __global__ void copy_actions_kernel(const float* loc, int ld, float* act, int B,
 
 // y = r + disc * (min(q1', q2') - alpha * logp')  (critics.py:219-221; alpha = 0 and logp = null
 // give TD3's critics.py:166-167), then dq_z = 2 (q_z - y) and the statistics.
+// nets == 1 (DDPG, critics.py:72-79): y = r + disc * q', one critic, statistics {sq_err, q, 0}.
 __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
                                    const float* tq, const float* logp_next, float alpha,
-                                   const float* q, float* dq, float* stats, int B, int Bp) {
+                                   const float* q, float* dq, float* stats, int B, int Bp,
+                                   int nets) {
   __shared__ float red[3][256];
   float s_loss = 0.f, s_q1 = 0.f, s_q2 = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
+    if (nets == 1) {
+      const float y = rewards[m] + discounts[m] * tq[m];
+      const float e1 = q[m] - y;
+      dq[m] = 2.f * e1;
+      s_loss += e1 * e1;
+      s_q1 += q[m];
+      continue;
+    }
     float next = fminf(tq[m], tq[Bp + m]);
     if (logp_next) next = next - alpha * logp_next[m];
     const float y = rewards[m] + discounts[m] * next;
@@ -478,8 +488,9 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   return TONIC_OK;
 }
 
-// Twin-critic Q-learning gradients.  kind 0 = TD3 (critics.py:156-175: target actor + clipped
-// noise), 1 = SAC (critics.py:202-227: online actor sample, entropy term).  Writes gradient SUMS
+// Q-learning gradients.  kind 0 = TD3 (critics.py:156-175: target actor + clipped noise),
+// 1 = SAC (critics.py:202-227: online actor sample, entropy term), 2 = DDPG (critics.py:68-86:
+// ONE critic, target actor, no noise; gradient sums for [critic] + 8 statistics).  Writes gradient SUMS
 // for [critic_1 | critic_2] + 8 statistics {sq_err_sum(both), q1_sum, q2_sum, 0, 0, B, 0, 0}
 // into d_grad_sums; the caller follows with tonic_adam_step(grad_scale = 1/B).
 extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
@@ -493,7 +504,8 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
                                  void* d_workspace, int64_t workspace_bytes, void* stream) {
   TONIC_REQUIRE(d_policy_params && d_target_critics && d_critics && d_norm_mean && d_norm_std &&
                     d_observations && d_actions && d_next_observations && d_rewards &&
-                    d_discounts && d_eps && d_grad_sums && d_workspace && B > 0,
+                    d_discounts && (d_eps || kind == 2) && d_grad_sums && d_workspace && B > 0 &&
+                    kind >= 0 && kind <= 2,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_twin_q_grad: bad argument");
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_twin_q_grad: workspace too small");
@@ -511,28 +523,32 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
 
   // ---- targets (no grad)
-  const ActorShape as{O, H, A, kind == 0 ? 1 : 2};
+  const int nets = kind == 2 ? 1 : 2;
+  const ActorShape as{O, H, A, kind == 1 ? 2 : 1};
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
-                    kind == 0, st));
+                    kind != 1, st));
   if (kind == 0) {
     hipLaunchKernelGGL(td3_target_action_kernel, dim3((B * A + threads - 1) / threads),
                        dim3(threads), 0, st, head0, ldh, d_eps, next_act, B, A,
                        (float)noise_scale, (float)noise_clip);
+  } else if (kind == 2) {
+    hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, head0, ldh, next_act, B, A);
   } else {
     hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
                        head0, head1, d_eps, ldh, next_act, logp, (float*)nullptr, B, A);
   }
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
-  TRY(critics_forward(d_target_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, tq, st));
+  TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, tq, st));
   // ---- online critics on (obs, actions)
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_observations, d_actions, d_norm_mean, d_norm_std, X, B, O, A, ldx);
-  TRY(critics_forward(d_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, q, st));
+  TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
   hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, st, d_rewards, d_discounts, tq,
                      kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
-                     d_grad_sums + 2 * Pc, B, Bp);
-  TRY(critics_backward(d_critics, cs, 2, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
+                     d_grad_sums + nets * Pc, B, Bp, nets);
+  TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
                        nullptr, 0, st));
   TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
   return TONIC_OK;

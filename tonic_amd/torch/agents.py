@@ -269,23 +269,31 @@ def _twin_model(head):
         observation_normalizer=normalizers.MeanStd())
 
 
+def _ddpg_model():
+    """tonic/torch/agents/ddpg.py:7-17."""
+    return models.ActorCriticWithTargets(
+        actor=models.Actor(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.DeterministicPolicyHead()),
+        critic=models.Critic(
+            encoder=models.ObservationActionEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.ValueHead()),
+        observation_normalizer=normalizers.MeanStd())
+
+
 class DDPG(Agent):
-    """Acting / storing / update scheduling shared by the off-policy agents
-    (tonic/torch/agents/ddpg.py:20-112).  Plain DDPG (single critic, DeterministicQLearning) is
-    outside the accelerated path; TD3 and SAC build on this class like in the reference."""
+    """tonic/torch/agents/ddpg.py:20-112: acting / storing / update scheduling; TD3 and SAC build
+    on this class like in the reference."""
 
     policy_kind = 0          # tonic_policy_forward kind used by `_policy`
 
     def __init__(self, model=None, replay=None, exploration=None, actor_updater=None,
                  critic_updater=None):
-        if model is None or critic_updater is None or actor_updater is None:
-            raise NotImplementedError(
-                'plain DDPG (single critic) is outside the accelerated path; use TD3 or SAC')
-        self.model = model
+        self.model = model or _ddpg_model()
         self.replay = replay or replays.Buffer()
         self.exploration = exploration or explorations.NormalActionNoise()
-        self.actor_updater = actor_updater
-        self.critic_updater = critic_updater
+        self.actor_updater = actor_updater or updaters.DeterministicPolicyGradient()
+        self.critic_updater = critic_updater or updaters.DeterministicQLearning()
 
     def initialize(self, observation_space, action_space, seed=None):
         super().initialize(seed=seed)
@@ -448,7 +456,8 @@ class DDPG(Agent):
         return self._infos
 
     def _draw_noise(self, iterations):
-        raise NotImplementedError
+        # DeterministicQLearning / DeterministicPolicyGradient draw nothing (one unused slot)
+        return np.zeros((iterations, 1, self.replay.batch_size, self.action_size), np.float32)
 
     def _update(self, steps):
         replay = self.replay
@@ -456,10 +465,14 @@ class DDPG(Agent):
         eps = self._draw_noise(indices.shape[0])
         infos = self.enqueue_update(indices, eps).cpu().numpy()
         replay.last_steps = steps
+        twin = hasattr(self.model, 'critic_2')
         for row in infos[0]:
             logger.store('critic/loss', row[0])
-            logger.store('critic/q1', row[1])        # batch means (log-equivalent)
-            logger.store('critic/q2', row[2])
+            if twin:
+                logger.store('critic/q1', row[1])    # batch means (log-equivalent)
+                logger.store('critic/q2', row[2])
+            else:
+                logger.store('critic/q', row[1])
         for row in infos[1][infos[1][:, 6] > 0]:
             logger.store('actor/loss', row[0])
         self.last_infos = infos

@@ -307,11 +307,36 @@ class ActorCriticWithTargets(torch.nn.Module):
         for o, t in zip(self.online_variables, self.target_variables):
             t.data.copy_(o.data)
 
+    def pack(self, device):
+        """Moves the model to `device`; the online networks share one flat buffer
+        [actor | critic(s)] and the targets another with the same layout, so ``update_targets``
+        is one polyak launch and all critics are one Adam block."""
+        self.to(device)
+        nets = [n for n, _ in self._networks()]
+        online, target = nets[:len(nets) // 2], nets[len(nets) // 2:]
+        total = sum(p.numel() for m in online for p in network_variables(m))
+        self.flat_online = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_target = torch.empty(total, dtype=torch.float32, device=device)
+        n_actor = sum(p.numel() for p in network_variables(online[0]))
+        self.flat_actor = FlatNetwork(online[0], device, self.flat_online[:n_actor])
+        self.flat_critics = FlatNetwork(online[1:], device, self.flat_online[n_actor:])
+        self.flat_target_actor = FlatNetwork(target[0], device, self.flat_target[:n_actor])
+        self.flat_target_critics = FlatNetwork(target[1:], device, self.flat_target[n_actor:])
+        return self
+
     def update_targets(self):
-        with torch.no_grad():
-            for o, t in zip(self.online_variables, self.target_variables):
-                t.data.mul_(1 - self.target_coeff)
-                t.data.add_(self.target_coeff * o.data)
+        """actor_critics.py:68-72 / 126-130 as ONE launch over the flat online / target buffers
+        (the per-parameter host loop only before ``pack``)."""
+        if getattr(self, 'flat_online', None) is None:
+            with torch.no_grad():
+                for o, t in zip(self.online_variables, self.target_variables):
+                    t.data.mul_(1 - self.target_coeff)
+                    t.data.add_(self.target_coeff * o.data)
+            return
+        from tonic_amd import _lib
+        _lib.check(_lib.load().tonic_polyak_update(
+            _lib.ptr(self.flat_target), _lib.ptr(self.flat_online), self.flat_online.numel(),
+            float(self.target_coeff), _lib.current_stream()), 'tonic_polyak_update')
 
 
 class ActorTwinCriticWithTargets(ActorCriticWithTargets):
@@ -333,31 +358,3 @@ class ActorTwinCriticWithTargets(ActorCriticWithTargets):
                 (self.target_actor, False), (self.target_critic_1, True),
                 (self.target_critic_2, True)]
 
-    def pack(self, device):
-        """Moves the model to `device`; online networks share one flat buffer
-        [actor | critic_1 | critic_2] and the targets another with the same layout, so
-        ``update_targets`` is one polyak launch and both critics are one Adam block."""
-        self.to(device)
-        online = [self.actor, self.critic_1, self.critic_2]
-        target = [self.target_actor, self.target_critic_1, self.target_critic_2]
-        total = sum(p.numel() for m in online for p in network_variables(m))
-        self.flat_online = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_target = torch.empty(total, dtype=torch.float32, device=device)
-        n_actor = sum(p.numel() for p in network_variables(self.actor))
-        self.flat_actor = FlatNetwork(self.actor, device, self.flat_online[:n_actor])
-        self.flat_critics = FlatNetwork([self.critic_1, self.critic_2], device,
-                                        self.flat_online[n_actor:])
-        self.flat_target_actor = FlatNetwork(self.target_actor, device,
-                                             self.flat_target[:n_actor])
-        self.flat_target_critics = FlatNetwork([self.target_critic_1, self.target_critic_2],
-                                               device, self.flat_target[n_actor:])
-        return self
-
-    def update_targets(self):
-        """actor_critics.py:126-130 as ONE launch over the flat online / target buffers."""
-        from tonic_amd import _lib
-        if getattr(self, 'flat_online', None) is None:
-            return super().update_targets()
-        _lib.check(_lib.load().tonic_polyak_update(
-            _lib.ptr(self.flat_target), _lib.ptr(self.flat_online), self.flat_online.numel(),
-            float(self.target_coeff), _lib.current_stream()), 'tonic_polyak_update')

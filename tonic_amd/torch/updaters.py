@@ -221,7 +221,8 @@ class _QUpdater(_FlatUpdater):
         self.model = model
         self.observation_size = model.actor.torso.model[0].in_features
         self.hidden = _torso_width(model.actor.torso)
-        if _torso_width(model.critic_1.torso) != self.hidden:
+        critic = model.critic_1 if hasattr(model, 'critic_1') else model.critic
+        if _torso_width(critic.torso) != self.hidden:
             raise NotImplementedError('actor and critic torsos must have the same width')
         head = model.actor.head
         self.sac = hasattr(head, 'scale_layer')
@@ -299,6 +300,24 @@ class _TwinCriticQLearning(_QUpdater):
                      next_observations=next_observations, rewards=rewards, discounts=discounts)
         eps = torch.randn(actions.shape).to(actions.device)
         out = self._info(lambda row: self.enqueue(batch, eps, row), ('loss', 'q1', 'q2'))
+        return out
+
+
+class DeterministicQLearning(_TwinCriticQLearning):
+    """critics.py:56-86 (DDPG): ONE critic, target actor, no target noise."""
+    kind, default_lr = 2, 1e-3
+
+    def __init__(self, loss=None, optimizer=None, gradient_clip=0):
+        _check_plain(loss, gradient_clip)
+        self.optimizer = optimizer
+
+    def _policy_params(self):
+        return self.model.flat_target_actor.flat
+
+    def __call__(self, observations, actions, next_observations, rewards, discounts):
+        batch = dict(observations=observations, actions=actions,
+                     next_observations=next_observations, rewards=rewards, discounts=discounts)
+        out = self._info(lambda row: self.enqueue(batch, None, row), ('loss', 'q'))
         return out
 
 
