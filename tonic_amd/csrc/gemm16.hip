@@ -7,40 +7,45 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Four k-values (k = k0 + 4*kg + t) of one operand row/column `idx` for this lane.
+// Four k-values (k = kbase + t) of one operand row/column `idx` for this lane.  Branch-free:
+// `idx` and k are clamped to valid addresses by the caller / here, and whatever was read beyond K
+// is zeroed by a 0/1 multiply at the consumer.  (A load under a lane-predicated branch gets its
+// own `s_waitcnt vmcnt(0)`: three serialised memory round trips per k-chunk.)
 template <bool KC>
 __device__ __forceinline__ void load_operand(const float* __restrict__ P, int ld, int idx,
-                                             int idx_limit, int kbase, int K, bool vec_ok,
-                                             float (&v)[4]) {
-  const bool in = idx < idx_limit;
+                                             int kbase, int K, bool vec, float (&v)[4]) {
   if (KC) {
-    const float* p = P + (int64_t)idx * ld + kbase;
-    if (in && vec_ok && kbase + 4 <= K) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+    const float* p = P + (int64_t)idx * ld;
+    if (vec) {                                     // wave-uniform: aligned rows, chunk inside K
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p + kbase);
       v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] = (in && kbase + t < K) ? p[t] : 0.f;
+      for (int t = 0; t < 4; ++t) v[t] = p[min(kbase + t, K - 1)];
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      v[t] = (in && kbase + t < K) ? P[(int64_t)(kbase + t) * ld + idx] : 0.f;
+    for (int t = 0; t < 4; ++t) v[t] = P[(int64_t)min(kbase + t, K - 1) * ld + idx];
   }
 }
 
-// SPLITK = false: each of the 4 waves of a workgroup owns its own 16 x 32 output tile.
-// SPLITK = true : the 4 waves share ONE tile and interleave the k-chunks (long contractions such
-//                 as the weight gradients, K = batch size); partial tiles are combined through
-//                 LDS in wave order (deterministic).
-template <bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs g) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One 16 x 32 output tile is owned by S = blockDim.y waves which interleave the 16-wide k-chunks
+// (S = 1: no exchange; S up to 16 for the weight gradients, K = batch size) so that no wave walks
+// more than a few chunks: the operands of up to four chunks are requested back to back and the
+// MFMAs start when the first arrives.  Partial tiles are combined through LDS in wave order
+// (deterministic).  blockDim = (64, S, tiles per workgroup).
+constexpr int kGemmGroup = 4;                      // chunks in flight per wave
+constexpr int kGemmMaxWaves = 16;
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_kernel(GemmArgs g) {
+  extern __shared__ float part[];                  // [waves][64][9] when S > 1
+  const int lane = threadIdx.x, part_of = threadIdx.y, S = blockDim.y;
   const int i = lane & 15, kg = lane >> 4;
   const int tiles_n = (g.N + 31) / 32, tiles_m = (g.M + 15) / 16;
-  const int tile = SPLITK ? blockIdx.x : blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_n) return;          // uniform per workgroup when SPLITK
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int tile = blockIdx.x * blockDim.z + threadIdx.z;
+  const bool live = tile < tiles_m * tiles_n;      // uniform per wave
+  const int tm = live ? tile / tiles_n : 0, tn = live ? tile - tm * tiles_n : 0;
   const int m0 = tm * 16, n0 = tn * 32;
   const int z = blockIdx.z;
   const float* A = g.A + z * g.strideA;
@@ -48,52 +53,54 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs g) {
   float* C = g.C + z * g.strideC;
   const bool vec_a = A_KC && (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const bool vec_b = B_KC && (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  const int ia = min(m0 + i, g.M - 1), ib0 = min(n0 + i, g.N - 1), ib1 = min(n0 + 16 + i, g.N - 1);
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
-  const int kstep = SPLITK ? 64 : 16;
-  int k0 = SPLITK ? 16 * wave : 0;
-  // register double buffering: chunk c+1 is in flight while chunk c feeds the MFMAs
-  float a[4], b0[4], b1[4], an[4], b0n[4], b1n[4];
-  if (k0 < g.K) {
-    load_operand<A_KC>(A, g.lda, m0 + i, g.M, k0 + 4 * kg, g.K, vec_a, a);
-    load_operand<B_KC>(B, g.ldb, n0 + i, g.N, k0 + 4 * kg, g.K, vec_b, b0);
-    load_operand<B_KC>(B, g.ldb, n0 + 16 + i, g.N, k0 + 4 * kg, g.K, vec_b, b1);
-  }
-  for (; k0 < g.K; k0 += kstep) {
-    const int kn = k0 + kstep + 4 * kg;
-    const bool more = k0 + kstep < g.K;
-    if (more) {
-      load_operand<A_KC>(A, g.lda, m0 + i, g.M, kn, g.K, vec_a, an);
-      load_operand<B_KC>(B, g.ldb, n0 + i, g.N, kn, g.K, vec_b, b0n);
-      load_operand<B_KC>(B, g.ldb, n0 + 16 + i, g.N, kn, g.K, vec_b, b1n);
+  const int chunks = (g.K + 15) / 16;
+  for (int first = part_of; live && first < chunks; first += kGemmGroup * S) {
+    float a[kGemmGroup][4], b0[kGemmGroup][4], b1[kGemmGroup][4];
+#pragma unroll
+    for (int j = 0; j < kGemmGroup; ++j) {         // all requests first (clamped, never skipped)
+      const int k0 = 16 * min(first + j * S, chunks - 1);
+      const bool inside = k0 + 16 <= g.K;
+      load_operand<A_KC>(A, g.lda, ia, k0 + 4 * kg, g.K, vec_a && inside, a[j]);
+      load_operand<B_KC>(B, g.ldb, ib0, k0 + 4 * kg, g.K, vec_b && inside, b0[j]);
+      load_operand<B_KC>(B, g.ldb, ib1, k0 + 4 * kg, g.K, vec_b && inside, b1[j]);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc0 = mfma16(a[t], b0[t], acc0);
-      acc1 = mfma16(a[t], b1[t], acc1);
-    }
-    if (!A_KC) colsum += (a[0] + a[1]) + (a[2] + a[3]);
-    if (more) {
+    for (int j = 0; j < kGemmGroup; ++j) {
+      const int c = first + j * S;
+      if (c >= chunks) break;                      // wave-uniform
+      const int kbase = 16 * c + 4 * kg;
+      if (16 * c + 16 > g.K) {                     // ragged last chunk: zero what lies beyond K
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { a[t] = an[t]; b0[t] = b0n[t]; b1[t] = b1n[t]; }
+        for (int t = 0; t < 4; ++t) a[j][t] *= (kbase + t < g.K) ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma16(a[j][t], b0[j][t], acc0);
+        acc1 = mfma16(a[j][t], b1[j][t], acc1);
+      }
+      if (!A_KC) colsum += (a[j][0] + a[j][1]) + (a[j][2] + a[j][3]);
     }
   }
 
-  if (SPLITK) {
-    __shared__ float part[4][64][9];
+  if (S > 1) {
+    float* mine = part + ((threadIdx.z * S + part_of) * 64 + lane) * 9;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { part[wave][lane][r] = acc0[r]; part[wave][lane][4 + r] = acc1[r]; }
-    part[wave][lane][8] = colsum;
+    for (int r = 0; r < 4; ++r) { mine[r] = acc0[r]; mine[4 + r] = acc1[r]; }
+    mine[8] = colsum;
     __syncthreads();
-    if (wave != 0) return;
+    if (part_of != 0 || !live) return;
+    for (int w = 1; w < S; ++w) {                  // fixed order: bit-reproducible
+      const float* other = part + ((threadIdx.z * S + w) * 64 + lane) * 9;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc0[r] = (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
-      acc1[r] = (part[0][lane][4 + r] + part[1][lane][4 + r]) +
-                (part[2][lane][4 + r] + part[3][lane][4 + r]);
+      for (int r = 0; r < 4; ++r) { acc0[r] += other[r]; acc1[r] += other[4 + r]; }
+      colsum += other[8];
     }
-    colsum = (part[0][lane][8] + part[1][lane][8]) + (part[2][lane][8] + part[3][lane][8]);
+  } else if (!live) {
+    return;
   }
 
   if (!A_KC && g.colsum != nullptr && tn == 0) {
@@ -127,13 +134,16 @@ int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStrea
   TONIC_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && batch > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "gemm: bad argument (M=%d N=%d K=%d)", g.M, g.N, g.K);
   const int tiles = ((g.M + 15) / 16) * ((g.N + 31) / 32);
-  const bool splitk = g.K >= 256 && tiles <= 1024;      // long contraction, few tiles
-  const dim3 grid(splitk ? tiles : (tiles + 3) / 4, 1, batch), block(256);
-#define TONIC_GEMM_LAUNCH(AKC, BKC)                                                          \
-  do {                                                                                       \
-    if (splitk) hipLaunchKernelGGL((gemm16_kernel<AKC, BKC, true>), grid, block, 0, stream, g);  \
-    else hipLaunchKernelGGL((gemm16_kernel<AKC, BKC, false>), grid, block, 0, stream, g);       \
-  } while (0)
+  const int chunks = (g.K + 15) / 16;
+  // waves per tile: at most kGemmGroup chunks per wave, then more while the chip is not full
+  int S = 1;
+  while (S < kGemmMaxWaves && S * kGemmGroup < chunks) S *= 2;
+  while (S < kGemmMaxWaves && S < chunks && (int64_t)tiles * batch * S < 2048) S *= 2;
+  const int per_block = S >= 4 ? 1 : 4 / S;         // tiles per workgroup (>= 4 waves each)
+  const dim3 grid((tiles + per_block - 1) / per_block, 1, batch), block(64, S, per_block);
+  const size_t lds = S > 1 ? (size_t)per_block * S * 64 * 9 * sizeof(float) : 0;
+#define TONIC_GEMM_LAUNCH(AKC, BKC) \
+  hipLaunchKernelGGL((gemm16_kernel<AKC, BKC>), grid, block, lds, stream, g)
   if (mode_a == 'c' && mode_b == 'c') TONIC_GEMM_LAUNCH(true, true);
   else if (mode_a == 'c' && mode_b == 's') TONIC_GEMM_LAUNCH(true, false);
   else if (mode_a == 's' && mode_b == 's') TONIC_GEMM_LAUNCH(false, false);

@@ -48,13 +48,18 @@ __global__ void encode_kernel(const float* obs, const float* act, const float* m
 }
 
 // SAC: u = loc + sigma * eps, a = tanh(u), logp = sum_a [N(u; loc, sigma) - log(1 - a^2 + 1e-6)]
-// with sigma = clamp(softplus(spre), 1e-4, 1) (actors.py:11-16,94-98).  One thread per sample.
+// with sigma = clamp(softplus(spre), 1e-4, 1) (actors.py:11-16,94-98).  A group of G = 2^k >= A
+// lanes (G <= 32; wider heads loop) owns one sample and folds the log-probability terms with a
+// fixed xor tree, so the dozen transcendental calls per action run in parallel, not in a loop.
 __global__ void sac_sample_kernel(const float* loc, const float* spre, const float* eps, int ld,
-                                  float* act, float* logp, float* sigma_out, int B, int A) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= B) return;
+                                  float* act, float* logp, float* sigma_out, int B, int A,
+                                  int G) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = tid / G, lane_a = tid - m * G;
+  const bool sample_ok = m < B;
   float lp = 0.f;
-  for (int a = 0; a < A; ++a) {
+  for (int a = lane_a; a < A; a += G) {
+    if (!sample_ok) break;
     const float raw = softplus_f(spre[(int64_t)m * ld + a]);
     const float sigma = fminf(fmaxf(raw, 1e-4f), 1.0f);
     const float l = loc[(int64_t)m * ld + a];
@@ -66,8 +71,11 @@ __global__ void sac_sample_kernel(const float* loc, const float* spre, const flo
     act[(int64_t)m * A + a] = t;
     if (sigma_out) sigma_out[(int64_t)m * A + a] = sigma;
   }
-  if (logp) logp[m] = lp;
+  for (int off = G >> 1; off >= 1; off >>= 1) lp += __shfl_xor(lp, off, 64);
+  if (logp && sample_ok && lane_a == 0) logp[m] = lp;
 }
+
+inline int sample_group(int A) { int g = 1; while (g < A && g < 32) g *= 2; return g; }
 
 // TD3 target actions: clamp(a + clamp(scale * eps, -clip, clip), -1, 1)  (critics.py:130-134)
 __global__ void td3_target_action_kernel(const float* loc, int ld, const float* eps, float* act,
@@ -87,6 +95,23 @@ __global__ void copy_actions_kernel(const float* loc, int ld, float* act, int B,
   act[idx] = loc[(int64_t)(idx / A) * ld + (idx % A)];
 }
 
+// Sum of up to three per-thread values over a workgroup of whole waves: float64 xor tree inside
+// each wave, then the wave partials in wave order by thread 0 (deterministic).  Result valid on
+// thread 0 only.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
+  __shared__ double wave_part[3][16];
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { wave_part[0][wave] = a; wave_part[1][wave] = b; wave_part[2][wave] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      a += wave_part[0][w]; b += wave_part[1][w]; c += wave_part[2][w];
+    }
+  }
+}
+
 // y = r + disc * (min(q1', q2') - alpha * logp')  (critics.py:219-221; alpha = 0 and logp = null
 // give TD3's critics.py:166-167), then dq_z = 2 (q_z - y) and the statistics.
 // nets == 1 (DDPG, critics.py:72-79): y = r + disc * q', one critic, statistics {sq_err, q, 0}.
@@ -94,7 +119,6 @@ __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
                                    const float* tq, const float* logp_next, float alpha,
                                    const float* q, float* dq, float* stats, int B, int Bp,
                                    int nets) {
-  __shared__ float red[3][256];
   float s_loss = 0.f, s_q1 = 0.f, s_q2 = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
     if (nets == 1) {
@@ -115,11 +139,9 @@ __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
     s_q1 += q[m];
     s_q2 += q[Bp + m];
   }
-  red[0][threadIdx.x] = s_loss; red[1][threadIdx.x] = s_q1; red[2][threadIdx.x] = s_q2;
-  __syncthreads();
+  double a = s_loss, b = s_q1, c = s_q2;
+  block_sum3(a, b, c);
   if (threadIdx.x == 0) {
-    double a = 0, b = 0, c = 0;
-    for (int i = 0; i < (int)blockDim.x; ++i) { a += red[0][i]; b += red[1][i]; c += red[2][i]; }
     stats[0] = (float)a; stats[1] = (float)b; stats[2] = (float)c; stats[3] = 0.f;
     stats[4] = 0.f; stats[5] = (float)B; stats[6] = 0.f; stats[7] = 0.f;
   }
@@ -130,7 +152,6 @@ __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
 // d loss / d q_z (unscaled by 1/B): -1 on the smaller critic, -1/2 each on ties.
 __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha, int twin,
                                   float* dq, float* stats, int B, int Bp) {
-  __shared__ float red[256];
   float s = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
     const float q1 = q[m];
@@ -144,11 +165,9 @@ __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha
       s += -q1;
     }
   }
-  red[threadIdx.x] = s;
-  __syncthreads();
+  double a = s, unused1 = 0, unused2 = 0;
+  block_sum3(a, unused1, unused2);
   if (threadIdx.x == 0) {
-    double a = 0;
-    for (int i = 0; i < (int)blockDim.x; ++i) a += red[i];
     stats[0] = (float)a;
     for (int i = 1; i < 8; ++i) stats[i] = i == 5 ? (float)B : 0.f;
   }
@@ -481,8 +500,10 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
                        0, st, head0, ldh, d_actions, B, A);
   } else {
-    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
-                       head0, head1, d_eps, ldh, d_actions, (float*)nullptr, (float*)nullptr, B, A);
+    hipLaunchKernelGGL(sac_sample_kernel,
+                       dim3((B * sample_group(A) + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, d_actions, (float*)nullptr, (float*)nullptr, B, A,
+                       sample_group(A));
   }
   TONIC_CHECK_LAUNCH("tonic_policy_forward");
   return TONIC_OK;
@@ -535,8 +556,10 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
                        0, st, head0, ldh, next_act, B, A);
   } else {
-    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
-                       head0, head1, d_eps, ldh, next_act, logp, (float*)nullptr, B, A);
+    hipLaunchKernelGGL(sac_sample_kernel,
+                       dim3((B * sample_group(A) + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, next_act, logp, (float*)nullptr, B, A,
+                       sample_group(A));
   }
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
@@ -545,7 +568,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_observations, d_actions, d_norm_mean, d_norm_std, X, B, O, A, ldx);
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, st, d_rewards, d_discounts, tq,
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts, tq,
                      kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
                      d_grad_sums + nets * Pc, B, Bp, nets);
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
@@ -593,13 +616,15 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
                        0, st, head0, ldh, act, B, A);
   } else {
-    hipLaunchKernelGGL(sac_sample_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
-                       head0, head1, d_eps, ldh, act, logp, sigma, B, A);
+    hipLaunchKernelGGL(sac_sample_kernel,
+                       dim3((B * sample_group(A) + threads - 1) / threads), dim3(threads), 0, st,
+                       head0, head1, d_eps, ldh, act, logp, sigma, B, A,
+                       sample_group(A));
   }
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_observations, act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
-  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, st, q, logp, (float)entropy_coeff,
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,
                      nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dX,
                        ldx, st));
