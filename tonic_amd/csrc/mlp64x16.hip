@@ -641,6 +641,7 @@ struct Collect16Args {
 };
 
 constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
+constexpr int kCollectCopyBlocks = 4;  // workgroups that copy the transition outcome
 
 template <int KS1, int AP>
 __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
@@ -648,14 +649,24 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   const int64_t W = c.W;
   const int O = c.O, A = c.A;
   const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {
-    // transition outcome + MeanStd.record (segments.py:27-36, mean_stds.py:44-48)
-    for (int64_t i = tid; i < W * O; i += 256) c.seg_next[c.row * W * O + i] = c.next_obs[i];
-    for (int64_t i = tid; i < W; i += 256) {
+  // Workgroup roles: [0, act_blocks) actor tiles | kCollectCopyBlocks outcome-copy blocks | one
+  // MeanStd.record block.  The three run side by side on different CUs, so a step costs the
+  // longest of {actor chain, cold outcome copy, sequential record} instead of their sum.
+  const int act_blocks = (int)gridDim.x - 1 - kCollectCopyBlocks;
+  if ((int)blockIdx.x >= act_blocks && (int)blockIdx.x < act_blocks + kCollectCopyBlocks) {
+    // transition outcome (segments.py:27-36): next observations, rewards, resets, terminations
+    const int64_t part = (int)blockIdx.x - act_blocks, stride = 256 * kCollectCopyBlocks;
+    for (int64_t i = part * 256 + tid; i < W * O; i += stride)
+      c.seg_next[c.row * W * O + i] = c.next_obs[i];
+    for (int64_t i = part * 256 + tid; i < W; i += stride) {
       c.seg_rew[c.row * W + i] = c.rewards[i];
       c.seg_rst[c.row * W + i] = c.resets[i];
       c.seg_term[c.row * W + i] = c.terminations[i];
     }
+    return;
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    // MeanStd.record (mean_stds.py:44-48)
     if (c.norm_acc == nullptr) return;
     float sum = 0.f, sum_sq = 0.f;
     if (tid < O) { sum = c.norm_acc[tid]; sum_sq = c.norm_acc[O + tid]; }
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   const float* P = c.packed;
   const int lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
   const int64_t ntiles = (W + 15) / 16;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)(gridDim.x - 1) * 4) {
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)act_blocks * 4) {
     const int64_t ns = t * 16 + s;
     const bool valid = ns < W;
     const int64_t nc = valid ? ns : W - 1;
@@ -872,7 +883,7 @@ extern "C" int tonic_ppo_collect_step_packed(
   const int64_t tiles = (W + 15) / 16;
   int act_blocks = (int)((tiles + 3) / 4);
   if (act_blocks > 2048) act_blocks = 2048;
-  const dim3 grid(act_blocks + 1), block(256);
+  const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
   hipStream_t st = as_stream(stream);
   const int ks1 = collect16_ks1(O), ap = collect16_ap(A);
 #define TONIC_COLLECT16(K, P_)                                                        \
