@@ -174,6 +174,13 @@ int tonic_segment_store(float* d_seg_observations, float* d_seg_actions,
                         const float* d_log_probs, float* d_norm_acc, int64_t row, int64_t W,
                         int32_t O, int32_t A, void* stream);
 
+/* replaces: tonic/torch/normalizers/mean_stds.py:44-48 (MeanStd.record) on its own: advances
+ *   d_norm_acc = {new_sum[size], new_sum_sq[size]} by `rows` rows of d_values [rows, size] in row
+ *   order with the reference's float32 operation sequence (bit-exact).  For callers that keep
+ *   the record off the critical path of their step kernel (side stream / hipGraph branch). */
+int tonic_meanstd_record(const float* d_values, float* d_norm_acc, int64_t rows, int32_t size,
+                         void* stream);
+
 /* replaces: tonic/replays/segments.py:58-65 (Segment.get with batch_size: fancy-index every
  *   learner input by a shuffled index vector).  Gathers `count` flattened transitions
  *   d_indices[i] in [0, segment_rows) of observations [N,O], actions [N,A], raw advantages,

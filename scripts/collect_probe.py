@@ -31,3 +31,24 @@ def run(use_sums, Wn=W):
 print('us per step, with record   :', run(True))
 print('us per step, without record:', run(False))
 print('us per step, W=16 no record:', run(False, 16))
+
+
+def empty_node_floor():
+    """A graph of T dependent near-empty launches (tonic_polyak_update on 64 floats)."""
+    a, b = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+
+    def f():
+        for _ in range(T):
+            _lib.check(lib.tonic_polyak_update(p(a), p(b), 64, 0.5, _lib.current_stream()), 'p')
+    f(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g): f()
+    g.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): g.replay()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / 10 / T * 1e3
+
+
+print('us per node, near-empty kernel chain:', empty_node_floor())

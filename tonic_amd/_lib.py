@@ -34,6 +34,7 @@ SIGNATURES = {
     'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'tonic_segment_store': (ctypes.c_int, [c_vp] * 15 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'tonic_meanstd_record': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     'tonic_segment_gather': (ctypes.c_int, [c_vp] * 11 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_ppo_collect_step': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_ppo_packed_actor_floats': (c_i64, [c_i32, c_i32]),

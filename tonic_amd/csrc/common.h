@@ -82,6 +82,22 @@ __device__ __forceinline__ void record_rows(const float* column, int stride, int
   }
 }
 
+// One of the two chains of MeanStd.record on its own: acc += column[w * stride] for w in order.
+// Callers stage v and v * v (rounded, as mean_stds.py:47 computes it) side by side and walk the
+// two chains on two different waves, i.e. two SIMDs: one dependent float32 add per row and wave
+// instead of add + multiply + add — the chain is VALU-issue bound, 4 cycles per instruction.
+__device__ __forceinline__ void add_rows(const float* column, int stride, int rows, float& acc) {
+  int w = 0;
+  for (; w + 16 <= rows; w += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = column[(w + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = acc + v[u];
+  }
+  for (; w < rows; ++w) acc = acc + column[w * stride];
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

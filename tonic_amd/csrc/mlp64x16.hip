@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 // staging 21 KB of weights through LDS at every launch cost more than the MFMA chain itself.
 // `actor_pack_kernel` therefore writes the pre-permuted operand images ONCE per learner update
 // into HBM (L2-resident afterwards) and `ppo_collect16_kernel` streams its MFMA A operands
-// straight from that image (lane-linear, coalesced) — no LDS, no workgroup barrier.
+// straight from that image (lane-linear, coalesced) — no weight staging through LDS.
 struct PackedActor {
   int W1I, W2S, B1P, B2P, W3P, HC, total;
   __host__ __device__ PackedActor(int ks1, int ap) {
@@ -666,28 +666,39 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     return;
   }
   if (blockIdx.x == gridDim.x - 1) {
-    // MeanStd.record (mean_stds.py:44-48)
+    // MeanStd.record (mean_stds.py:44-48): values and their squares staged side by side, the sum
+    // chain on wave 0 and the sum-of-squares chain on wave 1
     if (c.norm_acc == nullptr) return;
-    float sum = 0.f, sum_sq = 0.f;
-    if (tid < O) { sum = c.norm_acc[tid]; sum_sq = c.norm_acc[O + tid]; }
-    const int64_t rows_per_chunk = kCollectLds / O;
+    constexpr int kHalf = kCollectLds / 2;
+    const int lane = tid & 63, wave = tid >> 6;
+    float acc = 0.f;
+    if (wave < 2 && lane < O) acc = c.norm_acc[wave * O + lane];
+    const int64_t rows_per_chunk = kHalf / O;
     for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
       const int64_t rows = min(rows_per_chunk, W - w0);
       __syncthreads();
-      for (int64_t i = tid; i < rows * O; i += 256) tile[i] = c.obs[w0 * O + i];
-      __syncthreads();
-      if (tid < O) {
-        record_rows(tile + tid, O, (int)rows, sum, sum_sq);
+      for (int64_t i = tid; i < rows * O; i += 256) {
+        const float v = c.obs[w0 * O + i];
+        tile[i] = v;
+        tile[kHalf + i] = v * v;
       }
+      __syncthreads();
+      if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
     }
-    if (tid < O) { c.norm_acc[tid] = sum; c.norm_acc[O + tid] = sum_sq; }
+    if (wave < 2 && lane < O) c.norm_acc[wave * O + lane] = acc;
     return;
   }
+  // Actor: ONE 16-sample tile per workgroup; wave w owns output-feature tile w (16 of the 64
+  // features) of both hidden layers, so the dependent chain per launch is 5 + 8 MFMAs and four
+  // tanh per lane instead of 20 + 64 and 32.  h1 is exchanged through LDS (one b128 per lane),
+  // the head is a per-wave partial dot product folded by wave 0.
   const PackedActor L(KS1, AP);
   const float* P = c.packed;
   const int lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
   const int64_t ntiles = (W + 15) / 16;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)act_blocks * 4) {
+  f32x4* X1 = reinterpret_cast<f32x4*>(tile);                  // [4 tiles][64 lanes] h1 values
+  float* ZP = tile + 1024;                                     // [4 waves][AP][16 samples]
+  for (int64_t t = blockIdx.x; t < ntiles; t += act_blocks) {
     const int64_t ns = t * 16 + s;
     const bool valid = ns < W;
     const int64_t nc = valid ? ns : W - 1;
@@ -700,79 +711,79 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa)
       ep[aa] = c.eps != nullptr ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
-    {  // this wave's 16 observation rows -> Segment row (contiguous, coalesced)
+    // this tile's weight operands, all requested up front
+    const f32x4 bias1 = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16)[wave];
+    const f32x4 bias2 = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16)[wave];
+    float wl[KS1];
+    f32x4 w2[4], w3[AP], hcA[AP];
+#pragma unroll
+    for (int st = 0; st < KS1; ++st) wl[st] = P[L.W1I + (wave * KS1 + st) * 64 + lane];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      w2[cc] = reinterpret_cast<const f32x4*>(P + L.W2S)[(wave * 4 + cc) * 64 + lane];
+#pragma unroll
+    for (int aa = 0; aa < AP; ++aa) {
+      w3[aa] = reinterpret_cast<const f32x4*>(P + L.W3P)[(aa * 4 + g) * 4 + wave];
+      hcA[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8);
+    }
+    {  // the tile's 16 observation rows -> Segment row (contiguous, coalesced)
       const int64_t first = t * 16 * O, count = min<int64_t>(16, W - t * 16) * O;
-      for (int64_t i = lane; i < count; i += 64)
+      for (int64_t i = tid; i < count; i += 256)
         c.seg_obs[c.row * W * O + first + i] = c.obs[first + i];
     }
-    // Every weight operand is requested up front (about 220 registers of loads in flight), so
-    // the L2 latency is paid once per launch instead of once per dependent stage.
-    f32x4 bias1[4], bias2[4], w2[4][4], w3[AP][4], hcA[AP], hcB[AP];
-    float wl[4][KS1];
-    {
-      const f32x4* b1p = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16);
-      const f32x4* b2p = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16);
-      const f32x4* w2p = reinterpret_cast<const f32x4*>(P + L.W2S);
-      const f32x4* w3p = reinterpret_cast<const f32x4*>(P + L.W3P);
-#pragma unroll
-      for (int T = 0; T < 4; ++T) {
-        bias1[T] = b1p[T];
-        bias2[T] = b2p[T];
-#pragma unroll
-        for (int st = 0; st < KS1; ++st) wl[T][st] = P[L.W1I + (T * KS1 + st) * 64 + lane];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) w2[T][cc] = w2p[(T * 4 + cc) * 64 + lane];
-      }
-#pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w3[aa][j] = w3p[(aa * 4 + g) * 4 + j];
-        hcA[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8);
-        hcB[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8 + 4);
-      }
-    }
-    f32x4 acc[4];
-    float h1[16], h2[16];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) acc[T] = bias1[T];
+    f32x4 acc = bias1;
 #pragma unroll
     for (int st = 0; st < KS1; ++st) {
       const float xv = xr[st] * ((valid && 4 * st + g < O) ? 1.f : 0.f);
-#pragma unroll
-      for (int T = 0; T < 4; ++T) acc[T] = mfma16(wl[T][st], xv, acc[T]);
+      acc = mfma16(wl[st], xv, acc);
     }
-    tanh16(acc, h1);
+    f32x4 h;
 #pragma unroll
-    for (int T = 0; T < 4; ++T) acc[T] = bias2[T];
+    for (int e = 0; e < 4; ++e) h[e] = tanh_fast(acc[e]);
+    X1[wave * 64 + lane] = h;
+    __syncthreads();
+    f32x4 h1[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) h1[cc] = X1[cc * 64 + lane];
+    f32x4 even = bias2, odd = {0.f, 0.f, 0.f, 0.f};            // two chains: half the latency
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mfma16(w2[T][cc][e], h1[4 * cc + e], acc[T]);
+        if (e & 1) odd = mfma16(w2[cc][e], h1[cc][e], odd);
+        else even = mfma16(w2[cc][e], h1[cc][e], even);
       }
     }
-    tanh16(acc, h2);
-    float logp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = tanh_fast(even[e] + odd[e]);
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       float part = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], w3[aa][j][e], part);
-      }
-      const f32x4 hc = hcA[aa];
-      const float loc = tanh_fast(sum_groups(part) + hc[0]);
-      const float act = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
-      const float d = act - loc;
-      logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
-      if (valid && g == 0 && aa < A) {
-        c.seg_act[(c.row * W + ns) * A + aa] = act;
-        if (c.actions_out != nullptr) c.actions_out[ns * A + aa] = act;
-      }
+      for (int e = 0; e < 4; ++e) part = fmaf(h[e], w3[aa][e], part);
+      part = sum_groups(part);
+      if (g == 0) ZP[(wave * AP + aa) * 16 + s] = part;
     }
-    if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
+    __syncthreads();
+    if (wave == 0) {
+      float logp = 0.f;
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+        const float z = (ZP[aa * 16 + s] + ZP[(AP + aa) * 16 + s]) +
+                        (ZP[(2 * AP + aa) * 16 + s] + ZP[(3 * AP + aa) * 16 + s]);
+        const f32x4 hc = hcA[aa];
+        const float loc = tanh_fast(z + hc[0]);
+        const float act = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
+        const float d = act - loc;
+        logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
+        if (valid && g == 0 && aa < A) {
+          c.seg_act[(c.row * W + ns) * A + aa] = act;
+          if (c.actions_out != nullptr) c.actions_out[ns * A + aa] = act;
+        }
+      }
+      if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
+    }
+    __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
 }
 
@@ -881,8 +892,7 @@ extern "C" int tonic_ppo_collect_step_packed(
                   d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
                   d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A};
   const int64_t tiles = (W + 15) / 16;
-  int act_blocks = (int)((tiles + 3) / 4);
-  if (act_blocks > 2048) act_blocks = 2048;
+  const int act_blocks = (int)(tiles < 4096 ? tiles : 4096);       // one tile per workgroup
   const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
   hipStream_t st = as_stream(stream);
   const int ks1 = collect16_ks1(O), ap = collect16_ap(A);

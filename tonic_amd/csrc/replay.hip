@@ -59,6 +59,43 @@ __global__ __launch_bounds__(kStoreThreads) void segment_store_kernel(StoreArgs 
   if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }
 }
 
+// MeanStd.record alone (mean_stds.py:44-48) for callers that keep it off the critical path of
+// their step kernel (a side stream / parallel hipGraph branch): one workgroup, rows staged
+// through LDS, lane k walks feature k over the rows IN ORDER — the same float32 sums as the
+// reference's Python loop.
+__global__ __launch_bounds__(256) void meanstd_record_kernel(const float* values, float* acc,
+                                                             int64_t rows, int size) {
+  // Two half tiles of {v, v * v}: waves 2..3 stage chunk c+1 while wave 0 walks the sum chain and
+  // wave 1 the sum-of-squares chain of chunk c (one dependent add per row and wave).
+  constexpr int kQuarter = kRecordLdsFloats / 4;
+  __shared__ float tile[2][2][kQuarter];              // [buffer][v | v*v][...]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float chain = 0.f;
+  if (wave < 2 && lane < size) chain = acc[wave * size + lane];
+  const int64_t per_chunk = kQuarter / size;
+  const int64_t chunks = (rows + per_chunk - 1) / per_chunk;
+  auto fetch = [&](int64_t c, int first_thread, int threads) {
+    const int64_t r0 = c * per_chunk, n = min(per_chunk, rows - r0);
+    for (int64_t i = (int)threadIdx.x - first_thread; i < n * size; i += threads) {
+      const float v = values[r0 * size + i];
+      tile[c & 1][0][i] = v;
+      tile[c & 1][1][i] = v * v;
+    }
+  };
+  fetch(0, 0, 256);
+  __syncthreads();
+  for (int64_t c = 0; c < chunks; ++c) {
+    if (wave >= 2) {
+      if (c + 1 < chunks) fetch(c + 1, 128, 128);
+    } else if (lane < size) {
+      const int64_t n = min(per_chunk, rows - c * per_chunk);
+      add_rows(tile[c & 1][wave] + lane, size, (int)n, chain);
+    }
+    __syncthreads();
+  }
+  if (wave < 2 && lane < size) acc[wave * size + lane] = chain;
+}
+
 // Segment.get minibatch fetch (segments.py:58-65: `{k: v[indices] for k, v in batch.items()}`)
 // for one whole shuffled epoch: wave b copies flattened transition indices[b] of every learner
 // input into row b of the contiguous epoch image, so that the minibatches of the epoch are plain
@@ -85,6 +122,17 @@ __global__ __launch_bounds__(256) void segment_gather_kernel(SegGatherArgs g) {
 }  // namespace tonic
 
 using namespace tonic;
+
+extern "C" int tonic_meanstd_record(const float* d_values, float* d_norm_acc, int64_t rows,
+                                    int32_t size, void* stream) {
+  TONIC_REQUIRE(d_values && d_norm_acc && rows > 0 && size > 0 && size <= 64,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_meanstd_record: rows=%lld size=%d",
+                (long long)rows, size);
+  hipLaunchKernelGGL(meanstd_record_kernel, dim3(1), dim3(256), 0, as_stream(stream), d_values,
+                     d_norm_acc, rows, size);
+  TONIC_CHECK_LAUNCH("tonic_meanstd_record");
+  return TONIC_OK;
+}
 
 extern "C" int tonic_segment_gather(const int64_t* d_indices, const float* d_seg_observations,
                                     const float* d_seg_actions, const float* d_seg_advantages,
