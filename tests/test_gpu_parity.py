@@ -412,6 +412,25 @@ def test_meanstd_record_standalone_bit_exact(lib, rows, size):
     assert np.array_equal(got[:size], ref.new_sum) and np.array_equal(got[size:], ref.new_sum_sq)
 
 
+@pytest.mark.parametrize('rows,size', [(3000, 17), (1, 3), (482, 17), (5000, 32)])
+def test_meanstd_record_standalone_bit_exact(lib, rows, size):
+    """tonic_meanstd_record (several double-buffered LDS chunks) == MeanStd.record's Python loop
+    (mean_stds.py:44-48), continuing from non-zero running sums."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(rows + size)
+    values = (rng.standard_normal((rows, size)) * 3 + 1).astype(np.float32)
+    ref = port.MeanStdPort((size,))
+    ref.record(values[:1])                                   # non-zero starting sums
+    start = np.concatenate([ref.new_sum, ref.new_sum_sq]).astype(np.float32)
+    ref.record(values)
+    acc, d_values = dev(start), dev(values)
+    _lib.check(lib.tonic_meanstd_record(d_values.data_ptr(), acc.data_ptr(), rows, size, None),
+               'tonic_meanstd_record')
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    assert np.array_equal(got[:size], ref.new_sum) and np.array_equal(got[size:], ref.new_sum_sq)
+
+
 # ------------------------------------------------------------- whole update, agent level
 
 def _agent_from_golden(g, prefix, steps, iterations=80, batch_size=None, seed=0):

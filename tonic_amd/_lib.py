@@ -40,6 +40,8 @@ SIGNATURES = {
     'tonic_ppo_packed_actor_floats': (c_i64, [c_i32, c_i32]),
     'tonic_ppo_pack_actor': (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     'tonic_ppo_collect_step_packed': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'tonic_ppo_collect_steps_packed': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i64, c_i32, c_i32,
+                                                                    c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
     'tonic_buffer_accumulate_n_steps': (ctypes.c_int, [c_vp] * 7 + [c_i64] * 4 + [c_i32, c_i32, c_f64,
                                                                       c_vp]),

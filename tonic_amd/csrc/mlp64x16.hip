@@ -638,7 +638,22 @@ struct Collect16Args {
   float* norm_acc; float* actions_out;
   int64_t row, W;
   int O, A;
+  // inputs of the NEXT step (null: none): touched early so that the next launch finds them in
+  // L2 / Infinity Cache instead of paying an HBM round trip on its critical path
+  const float* pf_eps; const float* pf_next_obs; const float* pf_rewards;
+  const float* pf_resets; const float* pf_terminations;
 };
+
+// Loads whose values are needed by nobody: the addresses are touched and the results only fold
+// into `sink`, which `retire_touches` consumes at the END of the workgroup's work (a store that
+// never executes for real data) — so the loads stay in flight behind everything else instead of
+// being waited for one by one.
+__device__ __forceinline__ void touch(const float* p, float& sink) {
+  sink += __builtin_nontemporal_load(p);
+}
+__device__ __forceinline__ void retire_touches(float sink, float* never_written) {
+  if (sink == 1.2345e-38f) *never_written = sink;
+}
 
 constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
 constexpr int kCollectCopyBlocks = 4;  // workgroups that copy the transition outcome
@@ -656,13 +671,35 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   if ((int)blockIdx.x >= act_blocks && (int)blockIdx.x < act_blocks + kCollectCopyBlocks) {
     // transition outcome (segments.py:27-36): next observations, rewards, resets, terminations
     const int64_t part = (int)blockIdx.x - act_blocks, stride = 256 * kCollectCopyBlocks;
-    for (int64_t i = part * 256 + tid; i < W * O; i += stride)
-      c.seg_next[c.row * W * O + i] = c.next_obs[i];
-    for (int64_t i = part * 256 + tid; i < W; i += stride) {
-      c.seg_rew[c.row * W + i] = c.rewards[i];
-      c.seg_rst[c.row * W + i] = c.resets[i];
-      c.seg_term[c.row * W + i] = c.terminations[i];
+    float sink = 0.f;
+    if (c.pf_next_obs != nullptr) {               // one touch per 64-byte line of the next step
+      for (int64_t i = (part * 256 + tid) * 16; i < W * O; i += stride * 16)
+        touch(c.pf_next_obs + i, sink);
+      for (int64_t i = (part * 256 + tid) * 16; i < W; i += stride * 16) {
+        touch(c.pf_rewards + i, sink);
+        touch(c.pf_resets + i, sink);
+        touch(c.pf_terminations + i, sink);
+      }
     }
+    {  // all of this thread's loads first, then the stores (a plain copy loop waits per element)
+      float* dst = c.seg_next + c.row * W * O;
+      int64_t i = part * 256 + tid;
+      for (; i + 7 * stride < W * O; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c.next_obs[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[i + u * stride] = v[u];
+      }
+      for (; i < W * O; i += stride) dst[i] = c.next_obs[i];
+    }
+    for (int64_t i = part * 256 + tid; i < W; i += stride) {
+      const float rew = c.rewards[i], rst = c.resets[i], term = c.terminations[i];
+      c.seg_rew[c.row * W + i] = rew;
+      c.seg_rst[c.row * W + i] = rst;
+      c.seg_term[c.row * W + i] = term;
+    }
+    retire_touches(sink, c.seg_next);
     return;
   }
   if (blockIdx.x == gridDim.x - 1) {
@@ -671,21 +708,39 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     if (c.norm_acc == nullptr) return;
     constexpr int kHalf = kCollectLds / 2;
     const int lane = tid & 63, wave = tid >> 6;
+    // The next launch's record reads this step's next observations (trainer.py:44-56 hands them
+    // back as the observations of step t + 1): touch them now, from the workgroup slot that will
+    // need them, so that the sequential chain does not start behind an HBM round trip.
+    float sink = 0.f;
+    for (int64_t i = (int64_t)tid * 16; i < W * O; i += 256 * 16) touch(c.next_obs + i, sink);
     float acc = 0.f;
     if (wave < 2 && lane < O) acc = c.norm_acc[wave * O + lane];
     const int64_t rows_per_chunk = kHalf / O;
     for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
       const int64_t rows = min(rows_per_chunk, W - w0);
       __syncthreads();
-      for (int64_t i = tid; i < rows * O; i += 256) {
-        const float v = c.obs[w0 * O + i];
-        tile[i] = v;
-        tile[kHalf + i] = v * v;
+      {  // staging with eight loads in flight per thread (a plain loop waits for every load)
+        const float* src = c.obs + w0 * O;
+        const int64_t count = rows * O;
+        int64_t i = tid;
+        for (; i + 7 * 256 < count; i += 8 * 256) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = src[i + u * 256];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { tile[i + u * 256] = v[u]; tile[kHalf + i + u * 256] = v[u] * v[u]; }
+        }
+        for (; i < count; i += 256) {
+          const float v = src[i];
+          tile[i] = v;
+          tile[kHalf + i] = v * v;
+        }
       }
       __syncthreads();
       if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
     }
     if (wave < 2 && lane < O) c.norm_acc[wave * O + lane] = acc;
+    retire_touches(sink, c.norm_acc);
     return;
   }
   // Actor: ONE 16-sample tile per workgroup; wave w owns output-feature tile w (16 of the 64
@@ -698,6 +753,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   const int64_t ntiles = (W + 15) / 16;
   f32x4* X1 = reinterpret_cast<f32x4*>(tile);                  // [4 tiles][64 lanes] h1 values
   float* ZP = tile + 1024;                                     // [4 waves][AP][16 samples]
+  float eps_sink = 0.f;
   for (int64_t t = blockIdx.x; t < ntiles; t += act_blocks) {
     const int64_t ns = t * 16 + s;
     const bool valid = ns < W;
@@ -730,6 +786,11 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
       const int64_t first = t * 16 * O, count = min<int64_t>(16, W - t * 16) * O;
       for (int64_t i = tid; i < count; i += 256)
         c.seg_obs[c.row * W * O + first + i] = c.obs[first + i];
+      if (c.pf_eps != nullptr) {                  // next step's noise rows of this tile
+        const int64_t e_first = t * 16 * A, e_count = min<int64_t>(16, W - t * 16) * A;
+        for (int64_t i = (int64_t)tid * 16; i < e_count; i += 256 * 16)
+          touch(c.pf_eps + e_first + i, eps_sink);
+      }
     }
     f32x4 acc = bias1;
 #pragma unroll
@@ -785,6 +846,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
+  retire_touches(eps_sink, c.seg_lp);
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -874,6 +936,59 @@ extern "C" int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed
   return TONIC_OK;
 }
 
+namespace {
+
+int launch_collect16(const Collect16Args& c, hipStream_t st) {
+  const int64_t tiles = (c.W + 15) / 16;
+  const int act_blocks = (int)(tiles < 4096 ? tiles : 4096);       // one tile per workgroup
+  const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
+  const int ks1 = collect16_ks1(c.O), ap = collect16_ap(c.A);
+#define TONIC_COLLECT16(K, P_)                                                        \
+  if (ks1 == K && ap == P_) {                                                         \
+    hipLaunchKernelGGL((ppo_collect16_kernel<K, P_>), grid, block, 0, st, c);         \
+  } else
+  TONIC_COLLECT16(1, 1) TONIC_COLLECT16(1, 6) TONIC_COLLECT16(1, 8)
+  TONIC_COLLECT16(5, 1) TONIC_COLLECT16(5, 6) TONIC_COLLECT16(5, 8)
+  TONIC_COLLECT16(8, 1) TONIC_COLLECT16(8, 6) TONIC_COLLECT16(8, 8) {}
+#undef TONIC_COLLECT16
+  return TONIC_OK;
+}
+
+}  // namespace
+
+extern "C" int tonic_ppo_collect_steps_packed(
+    const float* d_packed_actor, const float* d_observations, const float* d_eps,
+    const float* d_rewards, const float* d_resets, const float* d_terminations,
+    float* d_seg_observations, float* d_seg_actions, float* d_seg_next_observations,
+    float* d_seg_rewards, float* d_seg_resets, float* d_seg_terminations,
+    float* d_seg_log_probs, float* d_norm_acc, int64_t row0, int64_t steps, int64_t W,
+    int32_t O, int32_t A, void* stream) {
+  TONIC_REQUIRE(d_packed_actor && d_observations && d_rewards && d_resets && d_terminations &&
+                    d_seg_observations && d_seg_actions && d_seg_next_observations &&
+                    d_seg_rewards && d_seg_resets && d_seg_terminations && d_seg_log_probs &&
+                    row0 >= 0 && steps > 0 && W > 0 && O >= 1 && O <= 32 && A >= 1 && A <= 8,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_collect_steps_packed: bad argument");
+  hipStream_t st = as_stream(stream);
+  for (int64_t t = 0; t < steps; ++t) {
+    const float* obs = d_observations + t * W * O;
+    Collect16Args c{d_packed_actor, obs, d_eps ? d_eps + t * W * A : nullptr, obs + W * O,
+                    d_rewards + t * W, d_resets + t * W, d_terminations + t * W,
+                    d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
+                    d_seg_resets, d_seg_terminations, d_seg_log_probs, d_norm_acc, nullptr,
+                    row0 + t, W, O, A, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (t + 1 < steps) {                         // the next step's inputs exist: touch them early
+      c.pf_eps = d_eps ? d_eps + (t + 1) * W * A : nullptr;
+      c.pf_next_obs = obs + 2 * W * O;
+      c.pf_rewards = d_rewards + (t + 1) * W;
+      c.pf_resets = d_resets + (t + 1) * W;
+      c.pf_terminations = d_terminations + (t + 1) * W;
+    }
+    launch_collect16(c, st);
+    TONIC_CHECK_LAUNCH("tonic_ppo_collect_steps_packed");
+  }
+  return TONIC_OK;
+}
+
 extern "C" int tonic_ppo_collect_step_packed(
     const float* d_packed_actor, const float* d_observations, const float* d_eps,
     const float* d_next_observations, const float* d_rewards, const float* d_resets,
@@ -890,20 +1005,9 @@ extern "C" int tonic_ppo_collect_step_packed(
   Collect16Args c{d_packed_actor, d_observations, d_eps, d_next_observations, d_rewards,
                   d_resets, d_terminations, d_seg_observations, d_seg_actions,
                   d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
-                  d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A};
-  const int64_t tiles = (W + 15) / 16;
-  const int act_blocks = (int)(tiles < 4096 ? tiles : 4096);       // one tile per workgroup
-  const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
-  hipStream_t st = as_stream(stream);
-  const int ks1 = collect16_ks1(O), ap = collect16_ap(A);
-#define TONIC_COLLECT16(K, P_)                                                        \
-  if (ks1 == K && ap == P_) {                                                         \
-    hipLaunchKernelGGL((ppo_collect16_kernel<K, P_>), grid, block, 0, st, c);         \
-  } else
-  TONIC_COLLECT16(1, 1) TONIC_COLLECT16(1, 6) TONIC_COLLECT16(1, 8)
-  TONIC_COLLECT16(5, 1) TONIC_COLLECT16(5, 6) TONIC_COLLECT16(5, 8)
-  TONIC_COLLECT16(8, 1) TONIC_COLLECT16(8, 6) TONIC_COLLECT16(8, 8) {}
-#undef TONIC_COLLECT16
+                  d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A,
+                  nullptr, nullptr, nullptr, nullptr, nullptr};
+  launch_collect16(c, as_stream(stream));
   TONIC_CHECK_LAUNCH("tonic_ppo_collect_step_packed");
   return TONIC_OK;
 }

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(kStoreThreads) void segment_store_kernel(StoreArgs 
 }
 
 // MeanStd.record alone (mean_stds.py:44-48) for callers that keep it off the critical path of
-// their step kernel (a side stream / parallel hipGraph branch): one workgroup, rows staged
-// through LDS, lane k walks feature k over the rows IN ORDER — the same float32 sums as the
+// their step kernel (one launch over all the rows of a rollout): one workgroup, {v, v * v}
+// staged through LDS, the two chains on two waves IN ROW ORDER — the same float32 sums as the
 // reference's Python loop.
 __global__ __launch_bounds__(256) void meanstd_record_kernel(const float* values, float* acc,
                                                              int64_t rows, int size) {
@@ -76,8 +76,23 @@ __global__ __launch_bounds__(256) void meanstd_record_kernel(const float* values
   const int64_t chunks = (rows + per_chunk - 1) / per_chunk;
   auto fetch = [&](int64_t c, int first_thread, int threads) {
     const int64_t r0 = c * per_chunk, n = min(per_chunk, rows - r0);
-    for (int64_t i = (int)threadIdx.x - first_thread; i < n * size; i += threads) {
-      const float v = values[r0 * size + i];
+    const float* src = values + r0 * size;
+    const int64_t count = n * size;
+    // eight loads in flight per thread before the first LDS store: the staging must keep up with
+    // a chain that consumes a row every ~5 cycles
+    int64_t i = (int)threadIdx.x - first_thread;
+    for (; i + 7 * threads < count; i += 8 * threads) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * threads);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        tile[c & 1][0][i + u * threads] = v[u];
+        tile[c & 1][1][i + u * threads] = v[u] * v[u];
+      }
+    }
+    for (; i < count; i += threads) {
+      const float v = src[i];
       tile[c & 1][0][i] = v;
       tile[c & 1][1][i] = v * v;
     }

@@ -57,16 +57,16 @@ class DeviceRollout:
             # once per collect (the parameters change at every learner update)
             _lib.check(lib.tonic_ppo_pack_actor(actor, p(self.packed_actor), O, A, stream),
                        'tonic_ppo_pack_actor')
+        if self.packed:
+            # one C call enqueues the T per-step launches (inputs are step-major and contiguous)
+            _lib.check(lib.tonic_ppo_collect_steps_packed(
+                p(self.packed_actor), p(self.observations), p(self.eps), p(self.rewards),
+                p(self.resets), p(self.terminations), p(b['observations']), p(b['actions']),
+                p(b['next_observations']), p(b['rewards']), p(b['resets']), p(b['terminations']),
+                p(b['log_probs']), p(sums), 0, self.T, self.W, O, A, stream),
+                'tonic_ppo_collect_steps_packed')
+            return
         for t in range(self.T):
-            if self.packed:
-                _lib.check(lib.tonic_ppo_collect_step_packed(
-                    p(self.packed_actor), p(self.observations[t]), p(self.eps[t]),
-                    p(self.observations[t + 1]), p(self.rewards[t]), p(self.resets[t]),
-                    p(self.terminations[t]), p(b['observations']), p(b['actions']),
-                    p(b['next_observations']), p(b['rewards']), p(b['resets']),
-                    p(b['terminations']), p(b['log_probs']), p(sums), None, t, self.W, O, A,
-                    stream), 'tonic_ppo_collect_step_packed')
-                continue
             if self.fused:
                 _lib.check(lib.tonic_ppo_collect_step(
                     actor, p(self.observations[t]), p(self.eps[t]), p(self.observations[t + 1]),
