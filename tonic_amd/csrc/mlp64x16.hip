@@ -69,18 +69,27 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
     const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
     lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi];
   }
-  for (int gi = tid; gi < 64 * 64; gi += nth) {
-    const int row = gi >> 6, col = gi & 63;
-    const float w = W2[gi];
-    {  // forward image: A row = output feature `row`, k = input feature `col`
-      const int T = row >> 4, i = row & 15;
-      const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
-      lds[L::W2S + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
-    }
-    {  // backward image: A row = input feature `col`, k = output feature `row`
-      const int T = col >> 4, i = col & 15;
-      const int st = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
-      lds[L::W2B + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+  {
+    // all eight W2 values of this thread are requested before the first LDS scatter (a load in a
+    // plain copy loop is waited for before the next one is issued)
+    constexpr int kPer = 64 * 64 / (kWaves16 * 64);
+    float w2v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) w2v[u] = W2[tid + u * nth];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int gi = tid + u * nth, row = gi >> 6, col = gi & 63;
+      const float w = w2v[u];
+      {  // forward image: A row = output feature `row`, k = input feature `col`
+        const int T = row >> 4, i = row & 15;
+        const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
+        lds[L::W2S + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+      }
+      {  // backward image: A row = input feature `col`, k = output feature `row`
+        const int T = col >> 4, i = col & 15;
+        const int st = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
+        lds[L::W2B + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+      }
     }
   }
   for (int idx = tid; idx < 64; idx += nth) {
@@ -519,38 +528,45 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   }
 
   // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
+  // `G[i] += v` per wave in turn would be a dependent LDS read-modify-write per element (the
+  // compiler must assume the addresses alias): ~100 serialised round trips per wave and turn,
+  // 40 us per launch — and ds_add_f32 is slower still.  Instead four waves at a time STORE their
+  // accumulators into four private images (plain, pipelined ds_write), then all 512 threads add
+  // the images element-wise onto image 0 in wave order: 0 + w0 + w1 + ... + w7 left to right,
+  // bit-identical to the serial fold, in two short rounds.  The images overlay the weight and
+  // tile areas, which are dead by now.
   const int oW1 = 0, ob1 = 64 * O, oW2 = ob1 + 64, ob2 = oW2 + 4096, oTail = ob2 + 64;
   const int oLs = oTail, oW3 = ACTOR ? oTail + A : oTail, ob3 = oW3 + (ACTOR ? A * 64 : 64);
   const int nout = ACTOR ? A : 1;
   const int P = ob3 + nout;
-  float* G = lds + L::WAVE0;
-  __syncthreads();
-  for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) G[idx] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < kWaves16; ++w) {
-    if (wave == w) {
+  const int image = (P + kStatSlots + 63) / 64 * 64;
+  float* G = lds;
+  for (int round = 0; round < kWaves16 / 4; ++round) {
+    __syncthreads();
+    if ((wave >> 2) == round) {
+      float* IMG = lds + (1 + (wave & 3)) * image;
 #pragma unroll
       for (int Ti = 0; Ti < 4; ++Ti) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * Ti + 4 * g + r;
 #pragma unroll
-          for (int Tj = 0; Tj < 4; ++Tj) G[oW2 + row * 64 + 16 * Tj + s] += gW2[Ti][Tj][r];
+          for (int Tj = 0; Tj < 4; ++Tj) IMG[oW2 + row * 64 + 16 * Tj + s] = gW2[Ti][Tj][r];
 #pragma unroll
           for (int Tj = 0; Tj < XT; ++Tj)
-            if (16 * Tj + s < O) G[oW1 + row * O + 16 * Tj + s] += gW1[Ti][Tj][r];
+            if (16 * Tj + s < O) IMG[oW1 + row * O + 16 * Tj + s] = gW1[Ti][Tj][r];
         }
         const float v1 = sum_groups(gb1[Ti]), v2 = sum_groups(gb2[Ti]);
-        if (g == 0) { G[ob1 + 16 * Ti + i] += v1; G[ob2 + 16 * Ti + i] += v2; }
+        if (g == 0) { IMG[ob1 + 16 * Ti + i] = v1; IMG[ob2 + 16 * Ti + i] = v2; }
 #pragma unroll
         for (int c = 0; c < XR; ++c) {                  // lane (i, g): feature 16*Ti + i, 4 samples
           const float vr = sum_groups(gW1r[Ti][c]);
-          if (g == 0 && 16 * XT + c < O) G[oW1 + (16 * Ti + i) * O + 16 * XT + c] += vr;
+          if (g == 0 && 16 * XT + c < O) IMG[oW1 + (16 * Ti + i) * O + 16 * XT + c] = vr;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int aa = 4 * g + r;                    // gW3[T] rows are action indices
-          if (aa < nout) G[oW3 + aa * 64 + 16 * Ti + s] += gW3[Ti][r];
+          if (aa < nout) IMG[oW3 + aa * 64 + 16 * Ti + s] = gW3[Ti][r];
         }
       }
       // gHead rows: lane (j, g), reg r -> row 4g + r (every column j holds the same sum)
@@ -558,15 +574,23 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * g + r;
-          if (row < 8 && row < nout) G[ob3 + row] += gHead[r];
-          if (ACTOR && row >= 8 && row - 8 < nout) G[oLs + row - 8] += gHead[r];
+          if (row < 8 && row < nout) IMG[ob3 + row] = gHead[r];
+          if (ACTOR && row >= 8 && row - 8 < nout) IMG[oLs + row - 8] = gHead[r];
         }
       }
       const float r0 = wave_sum(st0), r1 = wave_sum(st1), r2 = wave_sum(st2), r3 = wave_sum(st3);
-      if (lane == 0) { G[P + 0] += r0; G[P + 1] += r1; G[P + 2] += r2; G[P + 5] += r3; }
+      if (lane == 0) { IMG[P + 0] = r0; IMG[P + 1] = r1; IMG[P + 2] = r2; IMG[P + 5] = r3; }
+      if (lane == 0) { IMG[P + 3] = 0.f; IMG[P + 4] = 0.f; IMG[P + 6] = 0.f; IMG[P + 7] = 0.f; }
     }
     __syncthreads();
+    for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) {
+      float acc = round == 0 ? 0.f : G[idx];
+#pragma unroll
+      for (int w = 1; w <= 4; ++w) acc += lds[w * image + idx];
+      G[idx] = acc;
+    }
   }
+  __syncthreads();
   float* dst = a.out0 + (int64_t)blockIdx.x * a.pstride;
   for (int idx = tid; idx < P + kStatSlots; idx += kWaves16 * 64) dst[idx] = G[idx];
 }
@@ -878,6 +902,11 @@ int go16(int blocks, hipStream_t stream, const MlpArgs& args) {
     }
     configured = true;
   }
+  // the epilogue overlays five gradient images on the weight / tile areas
+  const int P = ACTOR ? 64 * args.O + 64 + 4096 + 64 + args.A + 64 * args.A + args.A
+                      : 64 * args.O + 64 + 4096 + 64 + 64 + 1;
+  TONIC_REQUIRE(5 * ((P + kStatSlots + 63) / 64 * 64) * 4 <= lds_bytes, TONIC_ERR_INVALID_ARGUMENT,
+                "mlp64_grad16: gradient images do not fit the %d B of LDS", lds_bytes);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWaves16 * 64), lds_bytes, stream, args);
   TONIC_CHECK_LAUNCH("mlp64_grad16_kernel");
   return TONIC_OK;
