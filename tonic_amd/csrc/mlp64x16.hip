@@ -208,6 +208,8 @@ __device__ __forceinline__ unsigned long long probe_clock() {
 template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, bool PROBE = false>
 __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs a) {
   using L = Lds16<KS1, AP>;
+  // LDS reads of head weights kept in flight (4 registers each); the widest bucket has none to spare
+  constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (a.skip != nullptr && *a.skip != 0) return;
   stage_weights16<KS1, AP, ACTOR>(lds, a);
@@ -340,17 +342,25 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       PHASE(3);
     }
     {
-      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
+      // W3 operands through a rolling window of kW3Window LDS reads in flight: the plain loop
+      // (read 16 bytes, wait, four FMAs, next) exposed 24 LDS round trips per tile
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P) + g * 4;
+      constexpr int kReads = AP * 4;
+      f32x4 win[kW3Window];
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
-        float part = 0.f;
+      for (int u = 0; u < kW3Window && u < kReads; ++u) win[u] = w3p[(u >> 2) * 16 + (u & 3)];
+      float part = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 w = w3p[(aa * 4 + g) * 4 + j];
+      for (int t = 0; t < kReads; ++t) {
+        const int aa = t >> 2, j = t & 3;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], w[e], part);
+        for (int e = 0; e < 4; ++e) part = fmaf(h2[4 * j + e], win[t % kW3Window][e], part);
+        if (t + kW3Window < kReads)
+          win[t % kW3Window] = w3p[((t + kW3Window) >> 2) * 16 + ((t + kW3Window) & 3)];
+        if (j == 3) {
+          z[aa] = sum_groups(part) + lds[L::HC + aa * 8];
+          part = 0.f;
         }
-        z[aa] = sum_groups(part) + lds[L::HC + aa * 8];
       }
     }
 
@@ -421,20 +431,26 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       reinterpret_cast<f32x4*>(DO + s * 16)[1] = hi;
     }
     {
-      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P);
+      const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P) + g * 4;
+      constexpr int kReads = AP * 4;                 // t -> (j = t / AP, aa = t % AP)
+      f32x4 win[kW3Window];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 acc = zero4;
+      for (int u = 0; u < kW3Window && u < kReads; ++u) win[u] = w3p[(u % AP) * 16 + u / AP];
+      f32x4 acc = zero4;
 #pragma unroll
-        for (int aa = 0; aa < AP; ++aa) {
-          const f32x4 w = w3p[(aa * 4 + g) * 4 + j];
+      for (int t = 0; t < kReads; ++t) {
+        const int j = t / AP, aa = t % AP;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(dzl[aa], w[e], acc[e]);
-        }
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(dzl[aa], win[t % kW3Window][e], acc[e]);
+        if (t + kW3Window < kReads)
+          win[t % kW3Window] = w3p[((t + kW3Window) % AP) * 16 + (t + kW3Window) / AP];
+        if (aa == AP - 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float y = h2[4 * j + e];
-          h2[4 * j + e] = acc[e] * (1.f - y * y);
+          for (int e = 0; e < 4; ++e) {
+            const float y = h2[4 * j + e];
+            h2[4 * j + e] = acc[e] * (1.f - y * y);
+          }
+          acc = zero4;
         }
       }
     }
