@@ -689,7 +689,7 @@ struct Collect16Args {
 // never executes for real data) — so the loads stay in flight behind everything else instead of
 // being waited for one by one.
 __device__ __forceinline__ void touch(const float* p, float& sink) {
-  sink += __builtin_nontemporal_load(p);
+  sink += *p;            // a plain load: it must ALLOCATE in L2 (a nontemporal one streams through)
 }
 __device__ __forceinline__ void retire_touches(float sink, float* never_written) {
   if (sink == 1.2345e-38f) *never_written = sink;
