@@ -52,7 +52,8 @@ const char* tonic_target_arch(void);
 /* Developer tuning knobs (process-wide; call before sizing workspaces).  Keys:
  *   "grad_waves" = 4       waves per workgroup of the 32x32x2-tile fused grad kernel;
  *   "grad_variant" = 0 | 1 fused grad kernel: 0 = 32x32x2 tiles, 1 wave/SIMD; 1 = 16x16x4
- *                          tiles, 2 waves/SIMD (default). */
+ *                          tiles, 2 waves/SIMD (default);
+ *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0). */
 int tonic_set_tuning(const char* key, int32_t value);
 
 /* Sizes of the flat parameter blocks described above. */

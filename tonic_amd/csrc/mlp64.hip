@@ -754,7 +754,8 @@ int g_grad_waves = 4;
 // 0 = 32x32x2 tiles, one wave per SIMD (mlp64_grad_kernel); 1 = 16x16x4 tiles, two waves per
 // SIMD (mlp64x16.hip).
 int g_grad_variant = 1;
-int g_grad_skew = 1;       // mlp64x16: phase skew of waves 4-7, in units of s_sleep(127) (~8k cycles)
+int g_grad_skew = 0;       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
+                           // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
 int ks1_bucket(int O) {
   if (O <= 4) return 2;

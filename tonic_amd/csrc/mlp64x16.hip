@@ -252,10 +252,10 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   f32x4 gHead = {0.f, 0.f, 0.f, 0.f};
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
-  // Two waves share a SIMD and run the same MFMA / VALU phase sequence.  Started together they
-  // convoy (both in an MFMA phase, then both in a VALU phase: the matrix pipe idles > 50 %), and
-  // fair arbitration preserves the offset between them — so give the second-dispatched half of
-  // the workgroup an initial phase skew of about half a tile.
+  // Experiment knob (tonic_set_tuning "grad_skew", default 0): delays the second-dispatched half of
+  // the workgroup.  It was meant to put the two waves of a SIMD into opposite MFMA / VALU phases;
+  // micro-benchmarks (scripts/ubench) then showed that fp32 MFMA and VALU instructions never
+  // overlap on gfx950, so there is nothing to gain from it.
   if (__builtin_amdgcn_readfirstlane(wave) >= kWaves16 / 2) {
     for (int k = 0; k < a.skew; ++k) __builtin_amdgcn_s_sleep(127);
   }
