@@ -16,8 +16,11 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ P, int ld
                                              int kbase, int K, bool vec, float (&v)[4]) {
   if (KC) {
     const float* p = P + (int64_t)idx * ld;
-    if (vec) {                                     // wave-uniform: aligned rows, chunk inside K
-      const f32x4 q = *reinterpret_cast<const f32x4*>(p + kbase);
+    if (vec) {                                     // wave-uniform: the chunk lies inside K
+      // one global_load_dwordx4 per lane; gfx950 global loads only need dword alignment, so rows
+      // of odd length (K = 111, 119: the first layers) take this path too
+      typedef float f32x4_dword __attribute__((ext_vector_type(4), aligned(4)));
+      const f32x4_dword q = *reinterpret_cast<const f32x4_dword*>(p + kbase);
       v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     } else {
 #pragma unroll
@@ -51,8 +54,7 @@ __global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_kernel(GemmArgs g) 
   const float* A = g.A + z * g.strideA;
   const float* B = g.B + z * g.strideB;
   float* C = g.C + z * g.strideC;
-  const bool vec_a = A_KC && (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
-  const bool vec_b = B_KC && (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  const bool vec_a = A_KC, vec_b = B_KC;
   const int ia = min(m0 + i, g.M - 1), ib0 = min(n0 + i, g.N - 1), ib1 = min(n0 + 16 + i, g.N - 1);
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
