@@ -1,0 +1,267 @@
+// Fused forward of a two-hidden-layer ReLU MLP with up to two narrow heads (gfx950) — the
+// networks of the off-policy path: Actor / Critic of tonic/torch/models/{actors,critics}.py with
+// the MLP torso of models/utils.py:12-23 (x -> relu(W1 x + b1) -> relu(W2 h1 + b2) -> heads).
+//
+// At batch 1024 and width 256 one layer is 134 MFLOP: as separate GEMM launches every layer pays
+// the ~5 us a dependent launch costs (first loads of a fresh kernel + store + launch), three to
+// four times per network pass.  Here one workgroup of four waves carries 16 batch rows through all
+// layers: wave w owns the 16-feature output tiles w, w+4, w+8, w+12 of both hidden layers
+// (v_mfma_f32_16x16x4_f32, product formed as D[feature][row] so that the result is already in
+// the lane = row layout the next layer wants as B operand), hidden activations are exchanged
+// through LDS, weights stream from L2 as one 16-byte load per lane and k-chunk, and the hidden
+// activations are also written to HBM because the backward pass needs them.
+#include "mlpfwd.h"
+
+namespace tonic {
+
+namespace {
+
+typedef float f32x4_dword __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Four consecutive k of one row as one dwordx4 load (dword alignment is enough on gfx950).
+__device__ __forceinline__ f32x4 load_k4(const float* row, int k) {
+  const f32x4_dword q = *reinterpret_cast<const f32x4_dword*>(row + k);
+  return f32x4{q[0], q[1], q[2], q[3]};
+}
+
+// The ragged last chunk (K % 16 != 0): clamped scalar loads, k >= K zeroed by the caller's mask.
+__device__ __forceinline__ f32x4 load_k4_tail(const float* row, int k, int K) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = row[min(k + e, K - 1)];
+  return v;
+}
+
+constexpr int kRows = 16;          // batch rows per workgroup
+constexpr int kMaxTiles = 4;       // 16-feature tiles per wave: H <= 256
+
+// One layer for the TILES 16-feature tiles a wave owns (rows wrow[j] of W), contraction over K.
+//   acc[j] += W[tile j rows][0 .. K) . B operand
+// bfull(k) / btail(k) give the B operand of this lane: four consecutive k of its input row.
+// Only one wave lives on a SIMD here, so latency is hidden by software: two operand sets of
+// kHalf k-chunks each; the loads of one set are issued, THEN the MFMAs of the other set run (the
+// sched_barriers pin that order — left alone the scheduler sinks every load next to its use and
+// the loop becomes "wait for everything, compute, load everything").  The loop has no branch but
+// its back edge: chunks past the end re-read the last chunk and are multiplied by zero.  The
+// weight half of the first set and the ragged tail are requested by `start`, which the caller
+// runs BEFORE the barrier that publishes the previous layer's activations.
+constexpr int kHalf = 2;
+
+template <int TILES>
+struct Layer {
+  const float* wrow[TILES];
+  int K, nfull;
+  f32x4 a0[kHalf][TILES];        // weight operands of the first set
+  f32x4 at[TILES];               // weight operands of the ragged last chunk (K % 16 != 0)
+
+  __device__ __forceinline__ void start(const float* const (&rows)[TILES], int K_, int kg) {
+    K = K_; nfull = K / 16;
+#pragma unroll
+    for (int j = 0; j < TILES; ++j) wrow[j] = rows[j];
+#pragma unroll
+    for (int q = 0; q < kHalf; ++q) {
+      const int k = 16 * min(q, max(nfull - 1, 0)) + 4 * kg;
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) a0[q][j] = nfull > 0 ? load_k4(wrow[j], k) : f32x4{0, 0, 0, 0};
+    }
+    if (K % 16 != 0) {
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) at[j] = load_k4_tail(wrow[j], 16 * nfull + 4 * kg, K);
+    }
+  }
+
+  template <typename BFull, typename BTail>
+  __device__ __forceinline__ void run(int kg, f32x4 (&acc)[TILES], BFull bfull, BTail btail) {
+    if (nfull > 0) {
+      f32x4 aA[kHalf][TILES], aB[kHalf][TILES], bA[kHalf], bB[kHalf];
+      auto fill_a = [&](f32x4 (&a)[kHalf][TILES], int first) {
+#pragma unroll
+        for (int q = 0; q < kHalf; ++q) {
+          const int k = 16 * min(first + q, nfull - 1) + 4 * kg;
+#pragma unroll
+          for (int j = 0; j < TILES; ++j) a[q][j] = load_k4(wrow[j], k);
+        }
+      };
+      auto fill_b = [&](f32x4 (&b)[kHalf], int first) {
+#pragma unroll
+        for (int q = 0; q < kHalf; ++q) b[q] = bfull(16 * min(first + q, nfull - 1) + 4 * kg);
+      };
+      auto compute = [&](const f32x4 (&a)[kHalf][TILES], const f32x4 (&b)[kHalf], int first) {
+#pragma unroll
+        for (int q = 0; q < kHalf; ++q) {
+          const float live = first + q < nfull ? 1.f : 0.f;
+          f32x4 bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[e] = b[q][e] * live;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {               // e outer: the tiles are independent chains
+#pragma unroll
+            for (int j = 0; j < TILES; ++j) acc[j] = mfma16(a[q][j][e], bb[e], acc[j]);
+          }
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) {
+#pragma unroll
+        for (int j = 0; j < TILES; ++j) aA[q][j] = a0[q][j];
+      }
+      fill_b(bA, 0);
+      const int rounds = (nfull + 2 * kHalf - 1) / (2 * kHalf);
+      for (int r = 0; r < rounds; ++r) {
+        const int c = 2 * kHalf * r;
+        fill_a(aB, c + kHalf); fill_b(bB, c + kHalf);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(aA, bA, c);
+        __builtin_amdgcn_sched_barrier(0);
+        fill_a(aA, c + 2 * kHalf); fill_b(bA, c + 2 * kHalf);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(aB, bB, c + kHalf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (K % 16 != 0) {                                // ragged last chunk
+      const int k = 16 * nfull + 4 * kg;
+      f32x4 b = btail(k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = (k + e < K) ? b[e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int j = 0; j < TILES; ++j) acc[j] = mfma16(at[j][e], b[e], acc[j]);
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: uniform branches
+  const int m = lane & 15, kg = lane >> 4;            // A operand row / D column; k group
+  const int H = a.H, pitch = H + 4, tiles = H / 16;
+  const int net = blockIdx.y;
+  const int r0 = blockIdx.x * kRows;
+  const int row = min(r0 + m, a.B - 1);               // batch row of this lane (clamped)
+  const bool row_ok = r0 + m < a.B;
+  const float* W1 = a.W1 + net * a.stride_params;
+  const float* b1 = a.b1 + net * a.stride_params;
+  const float* W2 = a.W2 + net * a.stride_params;
+  const float* b2 = a.b2 + net * a.stride_params;
+  float* h1g = a.h1 + net * a.stride_hidden;
+  float* h2g = a.h2 + net * a.stride_hidden;
+  float* hx = lds;
+  float* hy = lds + kRows * pitch;
+  // wave w owns tiles w, w + 4, w + 8, w + 12; an index beyond the layer is clamped (the wave
+  // then recomputes the last tile and drops it: no branch around an MFMA)
+  int tile_of[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) tile_of[j] = min(wave + 4 * j, tiles - 1);
+
+  // everything that does not depend on activations is requested up front
+  f32x4 bias1[kMaxTiles], bias2[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
+    const f32x4_dword q1 = *reinterpret_cast<const f32x4_dword*>(b1 + 16 * tile_of[j] + 4 * kg);
+    const f32x4_dword q2 = *reinterpret_cast<const f32x4_dword*>(b2 + 16 * tile_of[j] + 4 * kg);
+    bias1[j] = f32x4{q1[0], q1[1], q1[2], q1[3]};
+    bias2[j] = f32x4{q2[0], q2[1], q2[2], q2[3]};
+  }
+  const bool head_wave = wave < a.heads;
+  // (selects, not array indexing: a runtime index into the kernel arguments would go to scratch)
+  const float* Wh = (wave == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
+  const float* bh = (wave == 0 ? a.bh[0] : a.bh[1]) + net * a.stride_params;
+  float hbias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hbias[e] = bh[min(4 * kg + e, a.NH - 1)];
+
+  // hidden layer epilogue: bias + ReLU, to HBM (for the backward) and to an LDS image [row][feature]
+  auto finish = [&](f32x4 (&acc)[kMaxTiles], const f32x4 (&bias)[kMaxTiles], float* global,
+                    float* image) {
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+      if (wave + 4 * j >= tiles) break;               // scalar condition
+      const int f = 16 * tile_of[j] + 4 * kg;         // D rows 4*kg + e of the tile, column m
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = fmaxf(acc[j][e] + bias[j][e], 0.f);
+      *reinterpret_cast<f32x4*>(image + m * pitch + f) = h;
+      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * H + f) =
+          f32x4_dword{h[0], h[1], h[2], h[3]};
+    }
+  };
+
+  const float* rows1[kMaxTiles];
+  const float* rows2[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
+    rows1[j] = W1 + (int64_t)(16 * tile_of[j] + m) * a.K1;
+    rows2[j] = W2 + (int64_t)(16 * tile_of[j] + m) * H;
+  }
+  f32x4 acc[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xrow = a.X + (int64_t)row * a.ldx;
+  Layer<kMaxTiles> l1;
+  l1.start(rows1, a.K1, kg);
+  l1.run(kg, acc, [&](int k) { return load_k4(xrow, k); },
+         [&](int k) { return load_k4_tail(xrow, k, a.K1); });
+  Layer<kMaxTiles> l2;
+  l2.start(rows2, H, kg);                             // W2's first operands fly over the epilogue
+  finish(acc, bias1, h1g, hx);
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
+  l2.run(kg, acc, from_hx, from_hx);
+  Layer<1> lh;
+  const float* rowsh[1] = {Wh + (int64_t)min(m, a.NH - 1) * H};
+  if (head_wave) lh.start(rowsh, H, kg);
+  finish(acc, bias2, h2g, hy);
+  __syncthreads();
+
+  // heads: wave h < heads forms the [16 outputs][16 rows] tile of head h
+  if (head_wave) {
+    f32x4 out[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto from_hy = [&](int k) { return *reinterpret_cast<const f32x4*>(hy + m * pitch + k); };
+    lh.run(kg, out, from_hy, from_hy);
+    float* out_base = wave == 0 ? a.out[0] : a.out[1];
+    const int act = wave == 0 ? a.act[0] : a.act[1];
+    if (row_ok) {
+      float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = 4 * kg + e;
+        if (o < a.NH) {
+          float v = out[0][e] + hbias[e];
+          if (act == ACT_TANH) v = tanhf(v);
+          dst[o] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool mlp_forward_supported(int H, int NH, int heads) {
+  return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && NH >= 1 && NH <= 16 && heads >= 1 &&
+         heads <= 2;
+}
+
+int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
+  TONIC_REQUIRE(mlp_forward_supported(a.H, a.NH, a.heads) && a.B > 0 && a.K1 > 0 && nets > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: H=%d NH=%d heads=%d B=%d K1=%d", a.H,
+                a.NH, a.heads, a.B, a.K1);
+  const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
+                     stream, a);
+  TONIC_CHECK_LAUNCH("mlp_forward_kernel");
+  return TONIC_OK;
+}
+
+}  // namespace tonic

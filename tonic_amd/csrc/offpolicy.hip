@@ -17,6 +17,7 @@
 // batch straight into the flat gradient buffer (same layout as the parameters), so
 // tonic_adam_step / an RCCL all-reduce consume them exactly like the PPO path.
 #include "gemm16.h"
+#include "mlpfwd.h"
 
 namespace tonic {
 
@@ -359,6 +360,18 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
                   hipStream_t st) {
   ActorParams p(params, s);
+  if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
+    MlpFwdArgs f{};
+    f.X = obs; f.ldx = s.O; f.K1 = s.O;
+    f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2;
+    f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
+    f.Wh[1] = p.head_w(s.heads - 1); f.bh[1] = p.head_b(s.heads - 1);
+    f.heads = s.heads; f.NH = s.A;
+    f.h1 = h1; f.h2 = h2; f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
+    f.act[0] = tanh_head ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
+    f.B = B; f.H = s.H;
+    return launch_mlp_forward(f, 1, st);
+  }
   GemmArgs g = gemm(obs, s.O, p.W1, s.O, h1, s.H, B, s.H, s.O);
   g.bias = p.b1; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
@@ -382,6 +395,18 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
   const CriticOffsets o(s);
   const int in = s.O + s.A;
   const int64_t hs = (int64_t)Bp * s.H;
+  if (mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
+    MlpFwdArgs f{};
+    f.X = X; f.ldx = ldx; f.K1 = in;
+    f.W1 = params + o.W1; f.b1 = params + o.b1; f.W2 = params + o.W2; f.b2 = params + o.b2;
+    f.Wh[0] = f.Wh[1] = params + o.w3; f.bh[0] = f.bh[1] = params + o.b3;
+    f.heads = 1; f.NH = 1;
+    f.h1 = h1; f.h2 = h2; f.out[0] = f.out[1] = q; f.ldo = 1;
+    f.act[0] = f.act[1] = ACT_NONE;
+    f.B = B; f.H = s.H;
+    f.stride_params = o.count; f.stride_hidden = hs; f.stride_out = Bp;
+    return launch_mlp_forward(f, nets, st);
+  }
   GemmArgs g = gemm(X, ldx, params + o.W1, in, h1, s.H, B, s.H, in);
   g.bias = params + o.b1; g.act = ACT_RELU;
   g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
