@@ -214,22 +214,22 @@ def cpu_baseline():
                 runs=runs, os_cpu_count=os.cpu_count())
 
 
-def offpolicy_rates():
-    """cfg 3 of BASELINE.json (not the headline metric): SAC, O=111, A=8, default 256-wide
-    networks, 1 M-transition HBM Buffer, B=1024, 50 iterations per update call.  Reports learner
-    updates (batch iterations) per second on the GPU, eager and hipGraph-replayed, and the
-    reference's torch-CPU path (oracle/torch_port.OffPolicyPort) on a 5-iteration sample."""
+def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=True):
+    """cfg 3 / cfg 4 of BASELINE.json (not the headline metric).  Default: SAC, O=111, A=8, default
+    256-wide networks, 1 M-transition HBM Buffer, B=1024, 50 iterations per update call.  Reports
+    learner updates (batch iterations) per second on the GPU, eager and hipGraph-replayed, and
+    the reference's torch-CPU path (oracle/torch_port.OffPolicyPort) on a 5-iteration sample."""
     import torch
     import tonic_amd
     import tonic_amd.torch as tt
     from tonic_amd.environments import Box
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import torch_port
-    o_dim, a_dim, batch, iterations, rows = 111, 8, 1024, 50, 1000000
+    iterations, rows = 50, 1000000
     replay = tonic_amd.replays.Buffer(size=rows, batch_iterations=iterations, batch_size=batch)
-    agent = tt.agents.SAC(replay=replay)
+    agent = (tt.agents.SAC if kind == 'sac' else tt.agents.TD3)(replay=replay)
     agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=0)
-    replay._allocate(1, o_dim, a_dim)
+    replay._allocate(workers, o_dim, a_dim)
     gen = torch.Generator(device=agent.device)
     gen.manual_seed(0)
     for key, buf in replay.buffers.items():
@@ -241,14 +241,14 @@ def offpolicy_rates():
             buf.copy_(torch.rand(buf.shape, device=agent.device, generator=gen) * 2 - 1)
         else:
             buf.copy_(torch.randn(buf.shape, device=agent.device, generator=gen))
-    replay.size, replay.index = rows, 0
+    replay.size, replay.index = replay.max_size, 0
 
     def one_update(graph):
         indices = replay.sample_indices()
         eps = agent._draw_noise(iterations)
         return agent.enqueue_update(indices, eps, graph=graph)
 
-    out = {'workload': f'SAC O={o_dim} A={a_dim} hidden=256 B={batch}, {iterations} iterations '
+    out = {'workload': f'{kind.upper()} O={o_dim} A={a_dim} workers={workers} hidden=256 B={batch}, {iterations} iterations '
                        f'per update, {rows} transitions resident in HBM '
                        f'({sum(b.numel() for b in replay.buffers.values()) * 4 / 1e9:.2f} GB)'}
     for label, graph in (('eager', False), ('hip_graph', True)):
@@ -262,9 +262,11 @@ def offpolicy_rates():
         dt = (time.perf_counter() - t0) / reps
         out[label] = {'learner_updates_per_sec': round(iterations / dt, 1),
                       'ms_per_update_call': round(dt * 1e3, 3)}
+    if not cpu:
+        return out
     # CPU baseline: same path on torch-CPU, bounded sample
     state = {'pre/' + k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
-    port_ = torch_port.OffPolicyPort('sac', state, 'pre/')
+    port_ = torch_port.OffPolicyPort(kind, state, 'pre/')
     rng = np.random.RandomState(0)
     sample_rows = 4096
     host = dict(observations=rng.standard_normal((sample_rows, 1, o_dim)),
@@ -274,14 +276,14 @@ def offpolicy_rates():
                 discounts=np.full((sample_rows, 1), 0.99))
     host = {k: v.astype(np.float32) for k, v in host.items()}
     idx = rng.randint(sample_rows, size=(6, batch))
-    eps = rng.standard_normal((6, 2, batch, a_dim)).astype(np.float32)
+    eps = rng.standard_normal((6, 2 if kind == 'sac' else 1, batch, a_dim)).astype(np.float32)
     port_.update(host, 1, idx[:1], eps[:1])
     t0 = time.perf_counter()
     port_.update(host, 1, idx[1:], eps[1:])
     dt = (time.perf_counter() - t0) / 5
     out['cpu_baseline'] = {'learner_updates_per_sec': round(1 / dt, 2), 'kind': 'port',
                            'cores': torch.get_num_threads(),
-                           'sample': '5 SAC iterations (critic + actor + polyak) at B=1024'}
+                           'sample': f'5 {kind.upper()} iterations (critic + actor + polyak) at B={batch}'}
     return out
 
 
@@ -315,7 +317,15 @@ def main():
     parser.add_argument('--no-graph', action='store_true', help='eager launches, no hipGraph')
     parser.add_argument('--no-extras', action='store_true',
                         help='skip roofline / cpu_baseline / host-loop measurements')
+    parser.add_argument('--workload', default='cfg2', choices=('cfg2', 'cfg5'),
+                        help='cfg2 (default, the headline metric): HalfCheetah shapes, 256 workers '
+                             'per GPU; cfg5: AntBullet shapes (O=28, A=8), 1280 workers per GPU, '
+                             'i.e. BASELINE config 5 at 8 GPUs — a scaling data point, no extras')
     args = parser.parse_args()
+    if args.workload == 'cfg5':
+        global O, A, W
+        O, A, W = 28, 8, 1280
+        args.no_extras = True
 
     import torch
     from tonic_amd import parallel
@@ -357,12 +367,15 @@ def main():
     actor_iters = int((agent.last_infos[0][:, 6] > 0).sum())
 
     result = {
-        'metric': 'env steps/sec (+ learner updates/sec), PPO HalfCheetah parallel=256',
+        'metric': 'env steps/sec (+ learner updates/sec), PPO HalfCheetah parallel=256'
+                  if args.workload == 'cfg2' else
+                  'env steps/sec (+ learner updates/sec), PPO AntBullet parallel=1280 per GPU',
         'value': round(value, 1), 'unit': 'env_steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'PPO HalfCheetah-v3 shapes (O=17, A=6), parallel=256 workers per '
-                               'GPU, Segment T=4096 (N=1048576 transitions per GPU per step), '
+        'config': {'workload': f'PPO {"HalfCheetah-v3" if args.workload == "cfg2" else "AntBulletEnv-v0"} '
+                               f'shapes (O={O}, A={A}), parallel={W} workers per GPU, Segment T={T} '
+                               f'(N={T * W} transitions per GPU per step), '
                                '80 full-batch iterations, 1 learner update per step',
                    'workers_per_gpu': W, 'segment_steps': T, 'batch_iterations': ITERATIONS,
                    'global_workers': W * world, 'parallelism': f'dp{world} (worker-axis shard, '
@@ -394,6 +407,11 @@ def main():
             result['host_loop'] = host_loop_rate(agent)
             result['cpu_baseline'] = cpu_baseline()
             result['offpolicy_sac'] = offpolicy_rates()
+            # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
+            # reference's default batch of 100 and the batch of cfg 3
+            result['offpolicy_td3'] = {
+                f'B={b}': offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)['hip_graph']
+                for b in (100, 1024)}
             result['speedup_vs_cpu_baseline'] = round(value / result['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(result))
