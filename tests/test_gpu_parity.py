@@ -412,25 +412,6 @@ def test_meanstd_record_standalone_bit_exact(lib, rows, size):
     assert np.array_equal(got[:size], ref.new_sum) and np.array_equal(got[size:], ref.new_sum_sq)
 
 
-@pytest.mark.parametrize('rows,size', [(3000, 17), (1, 3), (482, 17), (5000, 32)])
-def test_meanstd_record_standalone_bit_exact(lib, rows, size):
-    """tonic_meanstd_record (several double-buffered LDS chunks) == MeanStd.record's Python loop
-    (mean_stds.py:44-48), continuing from non-zero running sums."""
-    from tonic_amd import _lib
-    rng = np.random.RandomState(rows + size)
-    values = (rng.standard_normal((rows, size)) * 3 + 1).astype(np.float32)
-    ref = port.MeanStdPort((size,))
-    ref.record(values[:1])                                   # non-zero starting sums
-    start = np.concatenate([ref.new_sum, ref.new_sum_sq]).astype(np.float32)
-    ref.record(values)
-    acc, d_values = dev(start), dev(values)
-    _lib.check(lib.tonic_meanstd_record(d_values.data_ptr(), acc.data_ptr(), rows, size, None),
-               'tonic_meanstd_record')
-    torch.cuda.synchronize()
-    got = acc.cpu().numpy()
-    assert np.array_equal(got[:size], ref.new_sum) and np.array_equal(got[size:], ref.new_sum_sq)
-
-
 # ------------------------------------------------------------- whole update, agent level
 
 def _agent_from_golden(g, prefix, steps, iterations=80, batch_size=None, seed=0):
@@ -644,3 +625,57 @@ def test_fused_collect_step_equals_act_plus_store(lib, O, A, W):
             assert np.array_equal(results[3][key], want), key
     assert np.array_equal(results[0]['observations'], rollout.observations[:T].cpu().numpy())
     assert np.abs(results[0]['actions']).max() > 0 and np.isfinite(results[0]['log_probs']).all()
+
+
+# ------------------------------------------------------------- drop-in plumbing end to end
+
+def test_trainer_runs_ppo_end_to_end_and_checkpoints_interchange(lib, tmp_path):
+    """`tonic_amd.Trainer` drives the PPO agent through the distributed collector like
+    `python -m tonic.train` does (trainer.py:28-146): learner updates happen, the reference's log
+    keys appear, and the `.pt` checkpoint has the reference's `state_dict` layout
+    and restores the exact parameters."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments, logger
+
+    def make_agent():
+        return tonic_amd.torch.agents.PPO(
+            replay=tonic_amd.replays.Segment(size=16, batch_iterations=3))
+
+    logger.initialize(path=str(tmp_path))
+    env = environments.distribute(lambda: environments.Synthetic(5, 2, max_episode_steps=7), 1, 4)
+    env.initialize(seed=0)
+    test_env = environments.distribute(lambda: environments.Synthetic(5, 2, max_episode_steps=7), 1, 1)
+    test_env.initialize(seed=10000)
+    agent = make_agent()
+    agent.initialize(env.observation_space, env.action_space, seed=3)
+    before = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+    trainer = tonic_amd.Trainer(steps=160, epoch_steps=80, save_steps=160, show_progress=False)
+    trainer.initialize(agent, env, test_env)
+    trainer.run()
+    header = open(tmp_path / 'log.csv').read().split('\n')[0].split(',')
+    for key in ('actor/loss', 'actor/kl', 'actor/entropy', 'actor/clip_fraction', 'actor/std',
+                'actor/stop', 'actor/iterations', 'critic/loss', 'critic/v', 'critic/iterations',
+                'train/episode_score/mean', 'test/episode_score/mean', 'train/steps_per_second'):
+        assert any(h == key or h.startswith(key + '/') for h in header), key
+    after = agent.model.state_dict()
+    assert any(not torch.equal(after[k].cpu(), before[k]) for k in before), 'no learner update ran'
+
+    checkpoint = tmp_path / 'checkpoints' / 'step_160.pt'
+    saved = torch.load(checkpoint, map_location='cpu')
+    expected_keys = {
+        'actor.torso.model.0.weight', 'actor.torso.model.0.bias', 'actor.torso.model.2.weight',
+        'actor.torso.model.2.bias', 'actor.head.log_scale', 'actor.head.loc_layer.0.weight',
+        'actor.head.loc_layer.0.bias', 'critic.torso.model.0.weight', 'critic.torso.model.0.bias',
+        'critic.torso.model.2.weight', 'critic.torso.model.2.bias', 'critic.head.v_layer.weight',
+        'critic.head.v_layer.bias', 'observation_normalizer._mean', 'observation_normalizer._std'}
+    assert expected_keys <= set(saved)
+    fresh = make_agent()
+    fresh.initialize(env.observation_space, env.action_space, seed=99)
+    fresh.load(str(checkpoint)[:-3])
+    for key, value in fresh.model.state_dict().items():
+        assert torch.equal(value.cpu(), after[key].cpu()), key
+    # the flat device buffers the kernels read follow the loaded parameters
+    flat = fresh.model.flat_actor.flat.cpu()
+    first = fresh.model.state_dict()['actor.torso.model.0.weight'].cpu().reshape(-1)
+    assert torch.equal(flat[:first.numel()], first)
