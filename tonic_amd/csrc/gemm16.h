@@ -37,6 +37,17 @@ struct GemmArgs {
   float alpha;           // result scale (applied before bias)
 };
 
+constexpr int kGemmGroupMax = 4;
+
+struct GemmGroup {
+  GemmArgs problem[kGemmGroupMax];
+  int first[kGemmGroupMax + 1];      // workgroup ranges of the problems
+  int count;
+};
+
 int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStream_t stream);
+// `count` (<= kGemmGroupMax) GEMMs of the same layout and K in one launch (see gemm16.hip).
+int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count, int batch,
+                      hipStream_t stream);
 
 }  // namespace tonic

@@ -41,12 +41,11 @@ constexpr int kGemmGroup = 4;                      // chunks in flight per wave
 constexpr int kGemmMaxWaves = 16;
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_kernel(GemmArgs g) {
-  extern __shared__ float part[];                  // [waves][64][9] when S > 1
+__device__ __forceinline__ void gemm16_tiles(const GemmArgs& g, int block_index, float* part) {
   const int lane = threadIdx.x, part_of = threadIdx.y, S = blockDim.y;
   const int i = lane & 15, kg = lane >> 4;
   const int tiles_n = (g.N + 31) / 32, tiles_m = (g.M + 15) / 16;
-  const int tile = blockIdx.x * blockDim.z + threadIdx.z;
+  const int tile = block_index * blockDim.z + threadIdx.z;
   const bool live = tile < tiles_m * tiles_n;      // uniform per wave
   const int tm = live ? tile / tiles_n : 0, tn = live ? tile - tm * tiles_n : 0;
   const int m0 = tm * 16, n0 = tn * 32;
@@ -132,15 +131,82 @@ __global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_kernel(GemmArgs g) 
   }
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_kernel(GemmArgs g) {
+  extern __shared__ float part[];                  // [waves][64][9] when S > 1
+  gemm16_tiles<A_KC, B_KC>(g, blockIdx.x, part);
+}
+
+// Several independent GEMMs of the same operand layout and contraction length in ONE launch (the
+// weight gradients of one network: dW1, dW2, dW3 ... all contract over the batch): workgroup
+// ranges [first[p], first[p + 1]) belong to problem p.  A launch costs ~5 us whatever it computes.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_group_kernel(GemmGroup G) {
+  extern __shared__ float part[];
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kGemmGroupMax; ++q) p += (q < G.count && (int)blockIdx.x >= G.first[q]) ? 1 : 0;
+  gemm16_tiles<A_KC, B_KC>(G.problem[p], (int)blockIdx.x - G.first[p], part);
+}
+
+namespace {
+
+// waves per tile: at most kGemmGroup chunks per wave, then more while the chip is not full
+int waves_per_tile(int K, int64_t tiles_total) {
+  const int chunks = (K + 15) / 16;
+  int S = 1;
+  while (S < kGemmMaxWaves && S * kGemmGroup < chunks) S *= 2;
+  while (S < kGemmMaxWaves && S < chunks && tiles_total * S < 2048) S *= 2;
+  return S;
+}
+
+}  // namespace
+
+int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count, int batch,
+                      hipStream_t stream) {
+  TONIC_REQUIRE(list && count >= 1 && count <= kGemmGroupMax && batch > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "gemm group: %d problems", count);
+  GemmGroup G{};
+  G.count = count;
+  int64_t tiles_total = 0;
+  for (int p = 0; p < count; ++p) {
+    const GemmArgs& g = list[p];
+    TONIC_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K == list[0].K && g.K > 0,
+                  TONIC_ERR_INVALID_ARGUMENT, "gemm group: problem %d (M=%d N=%d K=%d)", p, g.M,
+                  g.N, g.K);
+    G.problem[p] = g;
+    tiles_total += (int64_t)((g.M + 15) / 16) * ((g.N + 31) / 32);
+  }
+  const int S = waves_per_tile(list[0].K, tiles_total * batch);
+  const int per_block = S >= 4 ? 1 : 4 / S;
+  int blocks = 0;
+  for (int p = 0; p < count; ++p) {
+    G.first[p] = blocks;
+    const int tiles = ((list[p].M + 15) / 16) * ((list[p].N + 31) / 32);
+    blocks += (tiles + per_block - 1) / per_block;
+  }
+  G.first[count] = blocks;
+  const dim3 grid(blocks, 1, batch), block(64, S, per_block);
+  const size_t lds = S > 1 ? (size_t)per_block * S * 64 * 9 * sizeof(float) : 0;
+#define TONIC_GEMM_LAUNCH(AKC, BKC) \
+  hipLaunchKernelGGL((gemm16_group_kernel<AKC, BKC>), grid, block, lds, stream, G)
+  if (mode_a == 'c' && mode_b == 'c') TONIC_GEMM_LAUNCH(true, true);
+  else if (mode_a == 'c' && mode_b == 's') TONIC_GEMM_LAUNCH(true, false);
+  else if (mode_a == 's' && mode_b == 's') TONIC_GEMM_LAUNCH(false, false);
+  else {
+    set_error("gemm group: unsupported operand layouts '%c%c'", mode_a, mode_b);
+    return TONIC_ERR_INVALID_ARGUMENT;
+  }
+#undef TONIC_GEMM_LAUNCH
+  TONIC_CHECK_LAUNCH("gemm16_group");
+  return TONIC_OK;
+}
+
 int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStream_t stream) {
   TONIC_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && batch > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "gemm: bad argument (M=%d N=%d K=%d)", g.M, g.N, g.K);
   const int tiles = ((g.M + 15) / 16) * ((g.N + 31) / 32);
-  const int chunks = (g.K + 15) / 16;
-  // waves per tile: at most kGemmGroup chunks per wave, then more while the chip is not full
-  int S = 1;
-  while (S < kGemmMaxWaves && S * kGemmGroup < chunks) S *= 2;
-  while (S < kGemmMaxWaves && S < chunks && (int64_t)tiles * batch * S < 2048) S *= 2;
+  const int S = waves_per_tile(g.K, (int64_t)tiles * batch);
   const int per_block = S >= 4 ? 1 : 4 / S;         // tiles per workgroup (>= 4 waves each)
   const dim3 grid((tiles + per_block - 1) / per_block, 1, batch), block(64, S, per_block);
   const size_t lds = S > 1 ? (size_t)per_block * S * 64 * 9 * sizeof(float) : 0;

@@ -431,33 +431,31 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
   const int in = s.O + s.A;
   const int64_t hs = (int64_t)Bp * s.H;
   GemmArgs g;
-  if (grads) {   // dw3[1,H] = dq^T h2 ; db3 = sum dq
-    g = gemm(dq, 1, h2, s.H, grads + o.w3, s.H, 1, s.H, B);
-    g.colsum = grads + o.b3; g.strideColsum = o.count;
-    g.strideA = Bp; g.strideB = hs; g.strideC = o.count;
-    TRY(launch_gemm('s', 's', g, nets, st));
-  }
+  // the input-gradient chain first ...
   // dz2 = (dq w3) * relu'(h2)
   g = gemm(dq, 1, params + o.w3, s.H, dh2, s.H, B, s.H, 1);
   g.mask = h2; g.ldmask = s.H;
   g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
   TRY(launch_gemm('c', 's', g, nets, st));
-  if (grads) {   // dW2[H,H] = dz2^T h1 ; db2
-    g = gemm(dh2, s.H, h1, s.H, grads + o.W2, s.H, s.H, s.H, B);
-    g.colsum = grads + o.b2; g.strideColsum = o.count;
-    g.strideA = hs; g.strideB = hs; g.strideC = o.count;
-    TRY(launch_gemm('s', 's', g, nets, st));
-  }
   // dz1 = (dz2 W2) * relu'(h1)
   g = gemm(dh2, s.H, params + o.W2, s.H, dh1, s.H, B, s.H, s.H);
   g.mask = h1; g.ldmask = s.H;
   g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
   TRY(launch_gemm('c', 's', g, nets, st));
-  if (grads) {   // dW1[H,in] = dz1^T X ; db1
-    g = gemm(dh1, s.H, X, ldx, grads + o.W1, in, s.H, in, B);
-    g.colsum = grads + o.b1; g.strideColsum = o.count;
-    g.strideA = hs; g.strideC = o.count;
-    TRY(launch_gemm('s', 's', g, nets, st));
+  if (grads) {
+    // ... then the three weight gradients (all contract over the batch) in ONE launch:
+    //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
+    GemmArgs w[3];
+    w[0] = gemm(dq, 1, h2, s.H, grads + o.w3, s.H, 1, s.H, B);
+    w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
+    w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
+    w[1] = gemm(dh2, s.H, h1, s.H, grads + o.W2, s.H, s.H, s.H, B);
+    w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
+    w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
+    w[2] = gemm(dh1, s.H, X, ldx, grads + o.W1, in, s.H, in, B);
+    w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
+    w[2].strideA = hs; w[2].strideC = o.count;
+    TRY(launch_gemm_group('s', 's', w, 3, nets, st));
   }
   if (dX) {      // dX = dz1 W1  (summed over the critics: second one accumulates)
     for (int z = 0; z < nets; ++z) {
@@ -661,25 +659,31 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* g_W1 = d_grad_sums; float* g_b1 = g_W1 + (int64_t)H * O; float* g_W2 = g_b1 + H;
   float* g_b2 = g_W2 + (int64_t)H * H; float* g_Wh = g_b2 + H;
   GemmArgs g;
+  // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
   for (int h = 0; h < as.heads; ++h) {
     const float* dhead = h == 0 ? dloc : dspre;
-    float* gw = g_Wh + (int64_t)h * (A * H + A);
-    g = gemm(dhead, ldh, a_h2, H, gw, H, A, H, B);          // dWh[A,H] = dhead^T h2 ; dbh
-    g.colsum = gw + (int64_t)A * H;
-    TRY(launch_gemm('s', 's', g, 1, st));
-    g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A); // dz2 (+)= (dhead Wh) * relu'(h2)
+    g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A);
     g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
     TRY(launch_gemm('c', 's', g, 1, st));
   }
-  g = gemm(da_h2, H, a_h1, H, g_W2, H, H, H, B);
-  g.colsum = g_b2;
-  TRY(launch_gemm('s', 's', g, 1, st));
   g = gemm(da_h2, H, p.W2, H, da_h1, H, B, H, H);
   g.mask = a_h1; g.ldmask = H;
   TRY(launch_gemm('c', 's', g, 1, st));
-  g = gemm(da_h1, H, d_observations, O, g_W1, O, H, O, B);
-  g.colsum = g_b1;
-  TRY(launch_gemm('s', 's', g, 1, st));
+  // ... then all weight gradients (they contract over the batch) in ONE launch:
+  //   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T obs, db1
+  GemmArgs w[4];
+  int count = 0;
+  for (int h = 0; h < as.heads; ++h) {
+    const float* dhead = h == 0 ? dloc : dspre;
+    float* gw = g_Wh + (int64_t)h * (A * H + A);
+    w[count] = gemm(dhead, ldh, a_h2, H, gw, H, A, H, B);
+    w[count++].colsum = gw + (int64_t)A * H;
+  }
+  w[count] = gemm(da_h2, H, a_h1, H, g_W2, H, H, H, B);
+  w[count++].colsum = g_b2;
+  w[count] = gemm(da_h1, H, d_observations, O, g_W1, O, H, O, B);
+  w[count++].colsum = g_b1;
+  TRY(launch_gemm_group('s', 's', w, count, 1, st));
   TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
   return TONIC_OK;
 }
