@@ -213,3 +213,28 @@ def test_two_rank_gradient_sum_exchange_gloo(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f'rank {r} ok' in out
+
+
+def test_buffer_shard_indices_partition_the_global_batch():
+    """SURVEY §8e, off-policy: every rank draws the same GLOBAL index stream and keeps the samples
+    whose worker column it owns.  The per-rank parts must partition the batch, and the local
+    flat index must address the same transition in the rank's [rows, W_local] shard."""
+    import tonic_amd
+    rng = np.random.RandomState(0)
+    world, w_local, rows, batch, iterations = 4, 3, 50, 64, 5
+    w_global = world * w_local
+    indices = rng.randint(rows * w_global, size=(iterations, batch))
+    global_ids = np.arange(rows * w_global).reshape(rows, w_global)       # a "transition id" buffer
+    seen = np.zeros((iterations, batch), int)
+    for rank in range(world):
+        buf = tonic_amd.replays.Buffer(size=rows * w_global, batch_size=batch)
+        buf.num_workers, buf.global_workers, buf.rank, buf.world = w_local, w_global, rank, world
+        local, positions, counts = buf.shard_indices(indices)
+        shard = global_ids[:, rank * w_local:(rank + 1) * w_local]        # this rank's columns
+        for it in range(iterations):
+            c = counts[it]
+            pos = positions[it, :c]
+            assert np.array_equal(shard.reshape(-1)[local[it, :c]], indices[it, pos])
+            assert np.all(np.diff(pos) > 0), 'batch order is kept inside a shard'
+            seen[it, pos] += 1
+    assert np.all(seen == 1), 'every sample of the global batch is owned by exactly one rank'
