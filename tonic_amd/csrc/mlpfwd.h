@@ -20,7 +20,28 @@ struct MlpFwdArgs {
   int64_t stride_params, stride_hidden, stride_out;
 };
 
+// Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).
+struct MlpBwdArgs {
+  int heads;                 // 0: critic (dq, w3); 1..2: actor heads (dhead, Wh)
+  const float* dq;           // [B] per network            (heads == 0)
+  const float* w3;           // [H]                        (heads == 0)
+  const float* dhead[2];     // [B, ldh] gradients at the head outputs
+  const float* Wh[2];        // [NH, H]
+  int NH, ldh;
+  const float* W2;           // [H, H]
+  const float* W1;           // [H, K1]  (only for dxa)
+  int K1, xa_first, xa_count;   // dxa = columns [xa_first, xa_first + xa_count) of dz1 . W1
+  const float* h1; const float* h2;   // [B, H] forward activations (ReLU masks)
+  float* dz2; float* dz1;    // [B, H] outputs
+  float* dxa;                // [B, ldxa]
+  int ldxa;
+  int B, H;
+  int64_t stride_params, stride_hidden, stride_dq, stride_dxa;
+};
+
 bool mlp_forward_supported(int H, int NH, int heads);
+bool mlp_backward_supported(int H, int NH, int heads, int xa_count);
+int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream);
 int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream);
 
 }  // namespace tonic

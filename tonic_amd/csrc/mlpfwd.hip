@@ -51,26 +51,45 @@ constexpr int kMaxTiles = 4;       // 16-feature tiles per wave: H <= 256
 // runs BEFORE the barrier that publishes the previous layer's activations.
 constexpr int kHalf = 2;
 
-template <int TILES>
+// KS = false: the weight rows are k-contiguous (forward: W[out][k]); KS = true: k-strided
+// (backward through W^T: element (out, k) lives at W[k][out], i.e. base + k * ld + out).
+template <int TILES, bool KS = false>
 struct Layer {
-  const float* wrow[TILES];
-  int K, nfull;
+  const float* wrow[TILES];      // KS: column pointers W + out
+  int K, nfull, ld;
+
+  __device__ __forceinline__ f32x4 weights(const float* w, int k) const {
+    if (!KS) return load_k4(w, k);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)(k + e) * ld];
+    return v;
+  }
+  __device__ __forceinline__ f32x4 weights_tail(const float* w, int k) const {
+    if (!KS) return load_k4_tail(w, k, K);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)min(k + e, K - 1) * ld];
+    return v;
+  }
+
   f32x4 a0[kHalf][TILES];        // weight operands of the first set
   f32x4 at[TILES];               // weight operands of the ragged last chunk (K % 16 != 0)
 
-  __device__ __forceinline__ void start(const float* const (&rows)[TILES], int K_, int kg) {
-    K = K_; nfull = K / 16;
+  __device__ __forceinline__ void start(const float* const (&rows)[TILES], int K_, int kg,
+                                        int ld_ = 0) {
+    K = K_; nfull = K / 16; ld = ld_;
 #pragma unroll
     for (int j = 0; j < TILES; ++j) wrow[j] = rows[j];
 #pragma unroll
     for (int q = 0; q < kHalf; ++q) {
       const int k = 16 * min(q, max(nfull - 1, 0)) + 4 * kg;
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) a0[q][j] = nfull > 0 ? load_k4(wrow[j], k) : f32x4{0, 0, 0, 0};
+      for (int j = 0; j < TILES; ++j) a0[q][j] = nfull > 0 ? weights(wrow[j], k) : f32x4{0, 0, 0, 0};
     }
     if (K % 16 != 0) {
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) at[j] = load_k4_tail(wrow[j], 16 * nfull + 4 * kg, K);
+      for (int j = 0; j < TILES; ++j) at[j] = weights_tail(wrow[j], 16 * nfull + 4 * kg);
     }
   }
 
@@ -83,7 +102,7 @@ struct Layer {
         for (int q = 0; q < kHalf; ++q) {
           const int k = 16 * min(first + q, nfull - 1) + 4 * kg;
 #pragma unroll
-          for (int j = 0; j < TILES; ++j) a[q][j] = load_k4(wrow[j], k);
+          for (int j = 0; j < TILES; ++j) a[q][j] = weights(wrow[j], k);
         }
       };
       auto fill_b = [&](f32x4 (&b)[kHalf], int first) {
@@ -246,6 +265,121 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   }
 }
 
+// Fused input-gradient chain of the same networks (the backward of mlp_forward_kernel without the
+// weight gradients, which contract over the batch and go out as one grouped GEMM launch):
+//   dz2 = dOut . W_out   * relu'(h2)      critic: dOut = dq [B], W_out = w3 [H]   (outer product)
+//                                          actor : dOut = d head(s) [B, ldh], W_out = Wh [NH, H]
+//   dz1 = dz2 . W2       * relu'(h1)
+//   dxa = (dz1 . W1)[:, first : first + count]      optional: the action columns of the critic's
+//                                                    input gradient, all the actor step needs
+// Same decomposition as the forward: 16 batch rows per workgroup, wave w owns feature tiles w,
+// w+4, ..., D[feature][row] products, LDS exchange between the layers; the weights are walked
+// along their rows (W^T), i.e. k-strided loads.  dz2 / dz1 are written to HBM for the weight
+// gradients.
+__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+  const int H = a.H, pitch = H + 4, tiles = H / 16;
+  const int net = blockIdx.y;
+  const int r0 = blockIdx.x * kRows;
+  const int row = min(r0 + m, a.B - 1);
+  const bool row_ok = r0 + m < a.B;
+  const float* W2 = a.W2 + net * a.stride_params;
+  const float* h1g = a.h1 + net * a.stride_hidden;
+  const float* h2g = a.h2 + net * a.stride_hidden;
+  float* dz2g = a.dz2 + net * a.stride_hidden;
+  float* dz1g = a.dz1 + net * a.stride_hidden;
+  float* hx = lds;
+  float* hy = lds + kRows * pitch;
+  int tile_of[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) tile_of[j] = min(wave + 4 * j, tiles - 1);
+
+  // ReLU masks of both layers (forward activations of this lane's rows / features), up front
+  f32x4 mask2[kMaxTiles], mask1[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
+    const int f = 16 * tile_of[j] + 4 * kg;
+    mask2[j] = load_k4(h2g + (int64_t)row * H, f);
+    mask1[j] = load_k4(h1g + (int64_t)row * H, f);
+  }
+  // masked gradient of a hidden layer: to HBM (weight gradients) and to an LDS image [row][feature]
+  auto finish = [&](const f32x4 (&acc)[kMaxTiles], const f32x4 (&mask)[kMaxTiles], float* global,
+                    float* image) {
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+      if (wave + 4 * j >= tiles) break;
+      const int f = 16 * tile_of[j] + 4 * kg;
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = mask[j][e] > 0.f ? acc[j][e] : 0.f;
+      *reinterpret_cast<f32x4*>(image + m * pitch + f) = d;
+      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * H + f) =
+          f32x4_dword{d[0], d[1], d[2], d[3]};
+    }
+  };
+
+  const float* cols2[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) cols2[j] = W2 + 16 * tile_of[j] + m;
+  Layer<kMaxTiles, true> l1;                          // dz1 = W2^T dz2: requested before dz2 exists
+  l1.start(cols2, H, kg, H);
+
+  f32x4 acc[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.heads == 0) {                                 // critic: dq[row] * w3[feature]
+    const float dq = a.dq[net * a.stride_dq + row];
+    const float* w3 = a.w3 + net * a.stride_params;
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+      const f32x4 w = load_k4(w3, 16 * tile_of[j] + 4 * kg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] = dq * w[e];
+    }
+  } else {                                            // actor: sum over the heads of dhead . Wh
+    for (int h = 0; h < a.heads; ++h) {
+      const float* Wh = (h == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
+      const float* dh = (h == 0 ? a.dhead[0] : a.dhead[1]) + (int64_t)row * a.ldh;
+      const float* colsh[kMaxTiles];
+#pragma unroll
+      for (int j = 0; j < kMaxTiles; ++j) colsh[j] = Wh + 16 * tile_of[j] + m;
+      Layer<kMaxTiles, true> lh;
+      lh.start(colsh, a.NH, kg, H);
+      auto from_dh = [&](int k) { return load_k4(dh, k); };       // rows are padded to ldh >= 16
+      lh.run(kg, acc, from_dh, from_dh);
+    }
+  }
+  finish(acc, mask2, dz2g, hx);
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
+  l1.run(kg, acc, from_hx, from_hx);
+  Layer<1, true> lx;
+  const bool xa_wave = a.xa_count > 0 && wave == 0;
+  const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first + min(m, max(a.xa_count - 1, 0))};
+  if (xa_wave) lx.start(colsx, H, kg, a.K1);
+  finish(acc, mask1, dz1g, hy);
+  __syncthreads();
+
+  if (xa_wave) {                                      // [16 action columns][16 rows] of dz1 . W1
+    f32x4 out[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto from_hy = [&](int k) { return *reinterpret_cast<const f32x4*>(hy + m * pitch + k); };
+    lx.run(kg, out, from_hy, from_hy);
+    if (row_ok) {
+      float* dst = a.dxa + net * a.stride_dxa + (int64_t)(r0 + m) * a.ldxa;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (4 * kg + e < a.xa_count) dst[4 * kg + e] = out[0][e];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool mlp_forward_supported(int H, int NH, int heads) {
@@ -261,6 +395,22 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);
   TONIC_CHECK_LAUNCH("mlp_forward_kernel");
+  return TONIC_OK;
+}
+
+bool mlp_backward_supported(int H, int NH, int heads, int xa_count) {
+  return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && heads >= 0 && heads <= 2 &&
+         (heads == 0 || (NH >= 1 && NH <= 16)) && xa_count >= 0 && xa_count <= 16;
+}
+
+int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
+  TONIC_REQUIRE(mlp_backward_supported(a.H, a.NH, a.heads, a.xa_count) && a.B > 0 && nets > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_backward: H=%d NH=%d heads=%d B=%d", a.H, a.NH,
+                a.heads, a.B);
+  const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
+                     stream, a);
+  TONIC_CHECK_LAUNCH("mlp_backward_kernel");
   return TONIC_OK;
 }
 

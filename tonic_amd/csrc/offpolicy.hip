@@ -175,20 +175,23 @@ __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha
 }
 
 // Back through the squashed Gaussian head (SAC) or the tanh head (TD3).
-//   da[m][a] = d loss / d action (from the critics' input gradient, columns O..O+A)
+//   da[m][a] = d loss / d action (the action columns of the critics' input gradients, [B, pad16(A)])
 // SAC: u = loc + sigma eps, a = tanh(u):
 //   d loss/d u   = da (1 - a^2) + alpha * 2 a (1 - a^2) / (1 - a^2 + 1e-6)
 //   d loss/d loc = d loss/d u ;  d loss/d sigma = d loss/d u * eps - alpha / sigma
 //   d sigma/d spre = sigmoid(spre) inside the clamp, else 0.
 // TD3: a = tanh(z):  d loss/d z = da (1 - a^2).
-__global__ void actor_head_backward_kernel(const float* dx, int lddx, int O, const float* act,
+__global__ void actor_head_backward_kernel(const float* dxa0, const float* dxa1, int ldxa,
+                                           const float* act,
                                            const float* eps, const float* sigma,
                                            const float* spre, int ld, float alpha, int sac,
                                            float* dloc, float* dspre, int B, int A) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * A) return;
   const int m = idx / A, a = idx - m * A;
-  const float da = dx[(int64_t)m * lddx + O + a];
+  // d loss / d action = sum over the critics of the action columns of their input gradient
+  float da = dxa0[(int64_t)m * ldxa + a];
+  if (dxa1 != nullptr) da = da + dxa1[(int64_t)m * ldxa + a];
   const float t = act[idx];
   const float one_m = 1.f - t * t;
   if (!sac) {
@@ -423,25 +426,44 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
 }
 
 // Backward of `nets` critics from dq [nets][Bp].  grads != null: weight/bias gradient SUMS into
-// the flat layout (stride = critic param count).  dX != null: input gradient [nets][Bp][lddx].
+// the flat layout (stride = critic param count).  dxa != null: the ACTION columns of the input
+// gradient, [nets][Bp][pad16(A)] (all the actor step needs of dX; the caller adds the critics).
 int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                      int Bp, const float* h1, const float* h2, const float* dq, float* dh2,
-                     float* dh1, float* grads, float* dX, int lddx, hipStream_t st) {
+                     float* dh1, float* grads, float* dxa, hipStream_t st) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
   const int64_t hs = (int64_t)Bp * s.H;
+  const int ldxa = pad16(s.A);
   GemmArgs g;
   // the input-gradient chain first ...
-  // dz2 = (dq w3) * relu'(h2)
-  g = gemm(dq, 1, params + o.w3, s.H, dh2, s.H, B, s.H, 1);
-  g.mask = h2; g.ldmask = s.H;
-  g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
-  TRY(launch_gemm('c', 's', g, nets, st));
-  // dz1 = (dz2 W2) * relu'(h1)
-  g = gemm(dh2, s.H, params + o.W2, s.H, dh1, s.H, B, s.H, s.H);
-  g.mask = h1; g.ldmask = s.H;
-  g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
-  TRY(launch_gemm('c', 's', g, nets, st));
+  if (mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0)) {        // ... in ONE launch
+    MlpBwdArgs b{};
+    b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
+    b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in;
+    b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
+    b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa;
+    b.B = B; b.H = s.H;
+    b.ldxa = ldxa;
+    b.stride_params = o.count; b.stride_hidden = hs; b.stride_dq = Bp; b.stride_dxa = (int64_t)Bp * ldxa;
+    TRY(launch_mlp_backward(b, nets, st));
+  } else {
+    // dz2 = (dq w3) * relu'(h2)
+    g = gemm(dq, 1, params + o.w3, s.H, dh2, s.H, B, s.H, 1);
+    g.mask = h2; g.ldmask = s.H;
+    g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
+    TRY(launch_gemm('c', 's', g, nets, st));
+    // dz1 = (dz2 W2) * relu'(h1)
+    g = gemm(dh2, s.H, params + o.W2, s.H, dh1, s.H, B, s.H, s.H);
+    g.mask = h1; g.ldmask = s.H;
+    g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
+    TRY(launch_gemm('c', 's', g, nets, st));
+    if (dxa) {     // dxa = dz1 W1[:, O : O + A]
+      g = gemm(dh1, s.H, params + o.W1 + s.O, in, dxa, ldxa, B, s.A, s.H);
+      g.strideA = hs; g.strideB = o.count; g.strideC = (int64_t)Bp * ldxa;
+      TRY(launch_gemm('c', 's', g, nets, st));
+    }
+  }
   if (grads) {
     // ... then the three weight gradients (all contract over the batch) in ONE launch:
     //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
@@ -456,13 +478,6 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
     w[2].strideA = hs; w[2].strideC = o.count;
     TRY(launch_gemm_group('s', 's', w, 3, nets, st));
-  }
-  if (dX) {      // dX = dz1 W1  (summed over the critics: second one accumulates)
-    for (int z = 0; z < nets; ++z) {
-      g = gemm(dh1 + z * hs, s.H, params + z * o.count + o.W1, in, dX, lddx, B, in, s.H);
-      g.accumulate = z > 0;
-      TRY(launch_gemm('c', 's', g, 1, st));
-    }
   }
   return TONIC_OK;
 }
@@ -481,7 +496,7 @@ int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A);
   // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
   return 2 * Bp * H + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * H + 2 * Bp) +
-         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 64 * 16;
+         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 2 * Bp * ldh + 64 * 16;
 }
 
 }  // namespace
@@ -595,7 +610,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
                      kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
                      d_grad_sums + nets * Pc, B, Bp, nets);
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
-                       nullptr, 0, st));
+                       nullptr, st));
   TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
   return TONIC_OK;
 }
@@ -629,7 +644,8 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* c_h1 = ws.take(2LL * Bp * H); float* c_h2 = ws.take(2LL * Bp * H);
   float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
   float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
-  float* dX = ws.take((int64_t)Bp * ldx);
+  float* dX = ws.take((int64_t)Bp * ldx);      // (kept: workspace layout)
+  float* dxa = ws.take(2LL * Bp * ldh);         // action columns of the critics' input gradients
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take((int64_t)Bp * H); float* da_h1 = ws.take((int64_t)Bp * H);
 
@@ -649,10 +665,12 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
   hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,
                      nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
-  TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dX,
-                       ldx, st));
+  (void)dX;
+  TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dxa,
+                       st));
   hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
-                     dim3(threads), 0, st, dX, ldx, O, act, d_eps, sigma, head1, ldh,
+                     dim3(threads), 0, st, dxa, nets == 2 ? dxa + (int64_t)Bp * ldh : (float*)nullptr,
+                     ldh, act, d_eps, sigma, head1, ldh,
                      (float)entropy_coeff, kind == 1 ? 1 : 0, dloc, dspre, B, A);
   // ---- actor backward (weight-gradient sums into the flat layout)
   ActorParams p(d_actor_params, as);
@@ -660,15 +678,26 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* g_b2 = g_W2 + (int64_t)H * H; float* g_Wh = g_b2 + H;
   GemmArgs g;
   // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
-  for (int h = 0; h < as.heads; ++h) {
-    const float* dhead = h == 0 ? dloc : dspre;
-    g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A);
-    g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
+  if (mlp_backward_supported(H, A, as.heads, 0)) {
+    MlpBwdArgs b{};
+    b.heads = as.heads; b.NH = A; b.ldh = ldh;
+    b.dhead[0] = dloc; b.dhead[1] = dspre;
+    b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
+    b.W2 = p.W2; b.W1 = p.W1; b.K1 = O; b.xa_first = 0; b.xa_count = 0;
+    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = nullptr;
+    b.B = B; b.H = H;
+    TRY(launch_mlp_backward(b, 1, st));
+  } else {
+    for (int h = 0; h < as.heads; ++h) {
+      const float* dhead = h == 0 ? dloc : dspre;
+      g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A);
+      g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
+      TRY(launch_gemm('c', 's', g, 1, st));
+    }
+    g = gemm(da_h2, H, p.W2, H, da_h1, H, B, H, H);
+    g.mask = a_h1; g.ldmask = H;
     TRY(launch_gemm('c', 's', g, 1, st));
   }
-  g = gemm(da_h2, H, p.W2, H, da_h1, H, B, H, H);
-  g.mask = a_h1; g.ldmask = H;
-  TRY(launch_gemm('c', 's', g, 1, st));
   // ... then all weight gradients (they contract over the batch) in ONE launch:
   //   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T obs, db1
   GemmArgs w[4];
