@@ -189,13 +189,17 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
     bias1[j] = f32x4{q1[0], q1[1], q1[2], q1[3]};
     bias2[j] = f32x4{q2[0], q2[1], q2[2], q2[3]};
   }
-  const bool head_wave = wave < a.heads;
+  // head tiles: wave w forms rows [16 * tile, 16 * tile + 16) of head w / tiles_per_head
+  const int tiles_per_head = (a.NH + 15) / 16;
+  const bool head_wave = wave < a.heads * tiles_per_head;
+  const int head = head_wave ? wave / tiles_per_head : 0;
+  const int head_tile = head_wave ? wave - head * tiles_per_head : 0;
   // (selects, not array indexing: a runtime index into the kernel arguments would go to scratch)
-  const float* Wh = (wave == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
-  const float* bh = (wave == 0 ? a.bh[0] : a.bh[1]) + net * a.stride_params;
+  const float* Wh = (head == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
+  const float* bh = (head == 0 ? a.bh[0] : a.bh[1]) + net * a.stride_params;
   float hbias[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) hbias[e] = bh[min(4 * kg + e, a.NH - 1)];
+  for (int e = 0; e < 4; ++e) hbias[e] = bh[min(16 * head_tile + 4 * kg + e, a.NH - 1)];
 
   // hidden layer epilogue: bias + ReLU, to HBM (for the backward) and to an LDS image [row][feature]
   auto finish = [&](f32x4 (&acc)[kMaxTiles], const f32x4 (&bias)[kMaxTiles], float* global,
@@ -238,23 +242,23 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
   l2.run(kg, acc, from_hx, from_hx);
   Layer<1> lh;
-  const float* rowsh[1] = {Wh + (int64_t)min(m, a.NH - 1) * H};
+  const float* rowsh[1] = {Wh + (int64_t)min(16 * head_tile + m, a.NH - 1) * H};
   if (head_wave) lh.start(rowsh, H, kg);
   finish(acc, bias2, h2g, hy);
   __syncthreads();
 
-  // heads: wave h < heads forms the [16 outputs][16 rows] tile of head h
+  // heads: one [16 outputs][16 rows] tile per head wave
   if (head_wave) {
     f32x4 out[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
     auto from_hy = [&](int k) { return *reinterpret_cast<const f32x4*>(hy + m * pitch + k); };
     lh.run(kg, out, from_hy, from_hy);
-    float* out_base = wave == 0 ? a.out[0] : a.out[1];
-    const int act = wave == 0 ? a.act[0] : a.act[1];
+    float* out_base = head == 0 ? a.out[0] : a.out[1];
+    const int act = head == 0 ? a.act[0] : a.act[1];
     if (row_ok) {
       float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int o = 4 * kg + e;
+        const int o = 16 * head_tile + 4 * kg + e;
         if (o < a.NH) {
           float v = out[0][e] + hbias[e];
           if (act == ACT_TANH) v = tanhf(v);
@@ -360,8 +364,9 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
   l1.run(kg, acc, from_hx, from_hx);
   Layer<1, true> lx;
-  const bool xa_wave = a.xa_count > 0 && wave == 0;
-  const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first + min(m, max(a.xa_count - 1, 0))};
+  const bool xa_wave = 16 * wave < a.xa_count;      // one 16-column tile per wave
+  const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first +
+                           min(16 * wave + m, max(a.xa_count - 1, 0))};
   if (xa_wave) lx.start(colsx, H, kg, a.K1);
   finish(acc, mask1, dz1g, hy);
   __syncthreads();
@@ -374,7 +379,8 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
       float* dst = a.dxa + net * a.stride_dxa + (int64_t)(r0 + m) * a.ldxa;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (4 * kg + e < a.xa_count) dst[4 * kg + e] = out[0][e];
+        const int o = 16 * wave + 4 * kg + e;
+        if (o < a.xa_count) dst[o] = out[0][e];
       }
     }
   }
@@ -383,8 +389,8 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 }  // namespace
 
 bool mlp_forward_supported(int H, int NH, int heads) {
-  return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && NH >= 1 && NH <= 16 && heads >= 1 &&
-         heads <= 2;
+  return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && NH >= 1 && heads >= 1 && heads <= 2 &&
+         heads * ((NH + 15) / 16) <= 4;
 }
 
 int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
@@ -400,7 +406,7 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
 
 bool mlp_backward_supported(int H, int NH, int heads, int xa_count) {
   return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && heads >= 0 && heads <= 2 &&
-         (heads == 0 || (NH >= 1 && NH <= 16)) && xa_count >= 0 && xa_count <= 16;
+         (heads == 0 || (NH >= 1 && NH <= 64)) && xa_count >= 0 && xa_count <= 64;
 }
 
 int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
