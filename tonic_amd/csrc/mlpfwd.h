@@ -18,6 +18,12 @@ struct MlpFwdArgs {
   int B, H;
   // batch of networks over blockIdx.y: element strides between consecutive networks
   int64_t stride_params, stride_hidden, stride_out;
+  // networks >= split read a second parameter set and a second input (target critics on
+  // (s', a') and online critics on (s, a) in one launch): parameter pointers move by
+  // second_params ELEMENTS on top of the linear stride, the input is X2.  split >= nets: unused.
+  int split;
+  int64_t second_params;
+  const float* X2;
 };
 
 // Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).

@@ -166,10 +166,12 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const int r0 = blockIdx.x * kRows;
   const int row = min(r0 + m, a.B - 1);               // batch row of this lane (clamped)
   const bool row_ok = r0 + m < a.B;
-  const float* W1 = a.W1 + net * a.stride_params;
-  const float* b1 = a.b1 + net * a.stride_params;
-  const float* W2 = a.W2 + net * a.stride_params;
-  const float* b2 = a.b2 + net * a.stride_params;
+  const bool second = net >= a.split;                 // scalar
+  const int64_t poff = net * a.stride_params + (second ? a.second_params : 0);
+  const float* W1 = a.W1 + poff;
+  const float* b1 = a.b1 + poff;
+  const float* W2 = a.W2 + poff;
+  const float* b2 = a.b2 + poff;
   float* h1g = a.h1 + net * a.stride_hidden;
   float* h2g = a.h2 + net * a.stride_hidden;
   float* hx = lds;
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const int head = head_wave ? wave / tiles_per_head : 0;
   const int head_tile = head_wave ? wave - head * tiles_per_head : 0;
   // (selects, not array indexing: a runtime index into the kernel arguments would go to scratch)
-  const float* Wh = (head == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
-  const float* bh = (head == 0 ? a.bh[0] : a.bh[1]) + net * a.stride_params;
+  const float* Wh = (head == 0 ? a.Wh[0] : a.Wh[1]) + poff;
+  const float* bh = (head == 0 ? a.bh[0] : a.bh[1]) + poff;
   float hbias[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) hbias[e] = bh[min(16 * head_tile + 4 * kg + e, a.NH - 1)];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   f32x4 acc[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* xrow = a.X + (int64_t)row * a.ldx;
+  const float* xrow = (second ? a.X2 : a.X) + (int64_t)row * a.ldx;
   Layer<kMaxTiles> l1;
   l1.start(rows1, a.K1, kg);
   l1.run(kg, acc, [&](int k) { return load_k4(xrow, k); },
@@ -397,6 +399,8 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_forward_supported(a.H, a.NH, a.heads) && a.B > 0 && a.K1 > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: H=%d NH=%d heads=%d B=%d K1=%d", a.H,
                 a.NH, a.heads, a.B, a.K1);
+  TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
   const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);

@@ -372,7 +372,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.heads = s.heads; f.NH = s.A;
     f.h1 = h1; f.h2 = h2; f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
     f.act[0] = tanh_head ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
-    f.B = B; f.H = s.H;
+    f.B = B; f.H = s.H; f.split = 1 << 30;
     return launch_mlp_forward(f, 1, st);
   }
   GemmArgs g = gemm(obs, s.O, p.W1, s.O, h1, s.H, B, s.H, s.O);
@@ -393,8 +393,11 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
 }
 
 // `nets` critics batched over blockIdx.z; X shared ([Bp, ldx]); h1/h2 [nets][Bp][H]; q [nets][Bp]
+// params2 / X2 != null: `nets` more critics (e.g. the online ones next to the targets) with their
+// own input, appended to the same launch: h1/h2 [2 nets][Bp][H], q [2 nets][Bp].
 int critics_forward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
-                    int Bp, float* h1, float* h2, float* q, hipStream_t st) {
+                    int Bp, float* h1, float* h2, float* q, hipStream_t st,
+                    const float* params2 = nullptr, const float* X2 = nullptr) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
   const int64_t hs = (int64_t)Bp * s.H;
@@ -406,9 +409,20 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
     f.heads = 1; f.NH = 1;
     f.h1 = h1; f.h2 = h2; f.out[0] = f.out[1] = q; f.ldo = 1;
     f.act[0] = f.act[1] = ACT_NONE;
-    f.B = B; f.H = s.H;
+    f.B = B; f.H = s.H; f.split = 1 << 30;
     f.stride_params = o.count; f.stride_hidden = hs; f.stride_out = Bp;
+    if (params2 != nullptr) {          // a second set of `nets` critics on a second input
+      f.split = nets;
+      f.second_params = (params2 - params) - (int64_t)nets * o.count;
+      f.X2 = X2;
+      return launch_mlp_forward(f, 2 * nets, st);
+    }
     return launch_mlp_forward(f, nets, st);
+  }
+  if (params2 != nullptr) {            // unfused path: one pass per parameter set
+    TRY(critics_forward(params, s, nets, X, ldx, B, Bp, h1, h2, q, st));
+    return critics_forward(params2, s, nets, X2, ldx, B, Bp, h1 + nets * hs, h2 + nets * hs,
+                           q + (int64_t)nets * Bp, st);
   }
   GemmArgs g = gemm(X, ldx, params + o.W1, in, h1, s.H, B, s.H, in);
   g.bias = params + o.b1; g.act = ACT_RELU;
@@ -496,7 +510,8 @@ int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A);
   // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
   return 2 * Bp * H + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * H + 2 * Bp) +
-         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 2 * Bp * ldh + 64 * 16;
+         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 2 * Bp * ldh + 64 * 16 +
+         4 * Bp * H + Bp * ldx + 4 * Bp;                 // second input + four-network forward
 }
 
 }  // namespace
@@ -576,13 +591,19 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   float* a_h1 = ws.take((int64_t)Bp * H); float* a_h2 = ws.take((int64_t)Bp * H);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   float* next_act = ws.take((int64_t)Bp * A); float* logp = ws.take(Bp);
-  float* X = ws.take((int64_t)Bp * ldx);
-  float* c_h1 = ws.take(2LL * Bp * H); float* c_h2 = ws.take(2LL * Bp * H);
-  float* tq = ws.take(2LL * Bp); float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
-  float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
+  const int nets = kind == 2 ? 1 : 2;
+  const int64_t hs = (int64_t)Bp * H;
+  // target critics on (s', a') and online critics on (s, a) share ONE forward launch: inputs X /
+  // X2, activations and values laid out [targets | online]
+  float* X = ws.take((int64_t)Bp * ldx); float* X2 = ws.take((int64_t)Bp * ldx);
+  float* h1_all = ws.take(4 * hs); float* h2_all = ws.take(4 * hs);
+  float* q_all = ws.take(4LL * Bp);
+  float* c_h1 = h1_all + nets * hs; float* c_h2 = h2_all + nets * hs;
+  float* tq = q_all; float* q = q_all + (int64_t)nets * Bp;
+  float* dq = ws.take(2LL * Bp);
+  float* dh2 = ws.take(2 * hs); float* dh1 = ws.take(2 * hs);
 
   // ---- targets (no grad)
-  const int nets = kind == 2 ? 1 : 2;
   const ActorShape as{O, H, A, kind == 1 ? 2 : 1};
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
                     kind != 1, st));
@@ -601,15 +622,15 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   }
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
                      st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
-  TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, tq, st));
-  // ---- online critics on (obs, actions)
+  // ---- online critics on (obs, actions), in the same launch as the targets
   hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
-                     st, d_observations, d_actions, d_norm_mean, d_norm_std, X, B, O, A, ldx);
-  TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
+                     st, d_observations, d_actions, d_norm_mean, d_norm_std, X2, B, O, A, ldx);
+  TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
+                      d_critics, X2));
   hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts, tq,
                      kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
                      d_grad_sums + nets * Pc, B, Bp, nets);
-  TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
+  TRY(critics_backward(d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
                        nullptr, st));
   TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
   return TONIC_OK;
