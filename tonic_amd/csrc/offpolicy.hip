@@ -39,10 +39,14 @@ __host__ __device__ inline int64_t critic_count(CriticShape s) {
 // ------------------------------------------------------------------ element-wise kernels
 
 // X[m] = [ (obs[m] - mean) / std , actions[m] ]   (encoders.py:28-31 + mean_stds.py:36)
+// blockIdx.y == 1 encodes a second (obs, act) pair into X2 in the same launch.
 __global__ void encode_kernel(const float* obs, const float* act, const float* mean,
-                              const float* std, float* X, int B, int O, int A, int ldx) {
+                              const float* std, float* X, int B, int O, int A, int ldx,
+                              const float* obs2 = nullptr, const float* act2 = nullptr,
+                              float* X2 = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * (O + A)) return;
+  if (blockIdx.y == 1) { obs = obs2; act = act2; X = X2; }
   const int m = idx / (O + A), c = idx - m * (O + A);
   X[(int64_t)m * ldx + c] = c < O ? (obs[(int64_t)m * O + c] - mean[c]) / std[c]
                                   : act[(int64_t)m * A + (c - O)];
@@ -620,11 +624,11 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
                        head0, head1, d_eps, ldh, next_act, logp, (float*)nullptr, B, A,
                        sample_group(A));
   }
-  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
-                     st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
-  // ---- online critics on (obs, actions), in the same launch as the targets
-  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
-                     st, d_observations, d_actions, d_norm_mean, d_norm_std, X2, B, O, A, ldx);
+  // ---- inputs of the targets (s', a') and of the online critics (s, a): one launch each for
+  //      the encoding and for the four-network forward
+  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads, 2), dim3(threads),
+                     0, st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx,
+                     d_observations, d_actions, X2);
   TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                       d_critics, X2));
   hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts, tq,
