@@ -144,15 +144,16 @@ __device__ __forceinline__ float sum_groups(float v) {
 }
 
 __device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16]) {
+  // tanh(x) = 1 - 2 / (1 + e^{2x}): five instructions per element (mul, exp, add, rcp, fma)
+  // against seven for the odd-symmetric form; absolute error <= 2e-7 over the whole range
+  // (e^{2x} = inf gives exactly 1, e^{2x} = 0 exactly -1).
   float t[16], d[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) out[q] = acc[q >> 2][q & 3];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(fabsf(out[q]) * -2.8853900817779268f);
+  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(acc[q >> 2][q & 3] * 2.8853900817779268f);
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = __builtin_amdgcn_rcpf(1.f + t[q]);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) out[q] = copysignf((1.f - t[q]) * d[q], out[q]);
+  for (int q = 0; q < 16; ++q) out[q] = fmaf(-2.f, d[q], 1.f);
 }
 
 // acc[T] (+)= sum over 16 steps of W-image chunk x in[]: 64 in-features, 64 out-features.
