@@ -20,7 +20,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r['Kernel_Name'].split('(')[0][-60:]
-    if 'grad_kernel' not in k: continue
+    if 'grad' not in k: continue
     agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k)
