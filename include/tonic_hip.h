@@ -260,9 +260,20 @@ int tonic_polyak_update(float* d_target, const float* d_online, int64_t n, doubl
  *   Q critic                 : W1[H,O+A] b1[H] W2[H,H] b2[H] w3[1,H] b3[1]
  *   twin critics             : [critic_1 | critic_2] contiguous (one Adam over both, as
  *                              tonic/torch/updaters/critics.py:148-153,195-200 build it).
+ * Off-policy parameter layout (these blocks only; the PPO blocks above are dense): tensors in
+ *   that order, every tensor starts on a 16-byte boundary (a 1-D tensor of n floats occupies
+ *   ceil(n/4)*4), and the rows of a [rows, cols] weight are tonic_mlp_weight_stride(cols) floats
+ *   apart — cols rounded up to a multiple of 4, plus 4 if that is a multiple of 32 (256 -> 260,
+ *   111 -> 112, 119 -> 120).  The kernels stream weight rows straight from L2 into MFMA
+ *   operands, one row per lane: 16-byte aligned rows keep every load one request, and a stride
+ *   that is not a multiple of 128 bytes doubles the stream rate (38 -> 70-84 B/ns per CU,
+ *   profiles/r01_ubench_row_stride.md).  Padding floats must be zero; they stay zero under
+ *   tonic_adam_step (zero gradient) and tonic_polyak_update.  The *_param_count queries return the
+ *   padded block length; gradient / Adam-moment buffers use the same layout and length.
  * All scratch comes from ONE caller-provided workspace (tonic_offpolicy_workspace_bytes).
  */
 int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);
+int32_t tonic_mlp_weight_stride(int32_t cols);
 int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads);
 int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H);
 

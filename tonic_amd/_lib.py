@@ -46,6 +46,7 @@ SIGNATURES = {
     'tonic_buffer_accumulate_n_steps': (ctypes.c_int, [c_vp] * 7 + [c_i64] * 4 + [c_i32, c_i32, c_f64,
                                                                       c_vp]),
     'tonic_offpolicy_workspace_bytes': (c_i64, [c_i32] * 4),
+    'tonic_mlp_weight_stride': (c_i32, [c_i32]),
     'tonic_mlp_actor_param_count': (c_i64, [c_i32] * 4),
     'tonic_q_critic_param_count': (c_i64, [c_i32] * 3),
     'tonic_buffer_store': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i32, c_i32, c_f64, c_vp]),

@@ -8,7 +8,8 @@
 // layers: wave w owns the 16-feature output tiles w, w+4, w+8, w+12 of both hidden layers
 // (v_mfma_f32_16x16x4_f32, product formed as D[feature][row] so that the result is already in
 // the lane = row layout the next layer wants as B operand), hidden activations are exchanged
-// through LDS, weights stream from L2 as one 16-byte load per lane and k-chunk, and the hidden
+// through LDS, weights stream from L2 as one aligned 16-byte load per lane and k-chunk (rows are
+// weight_ld floats apart, see mlpfwd.h), and the hidden
 // activations are also written to HBM because the backward pass needs them.
 #include "mlpfwd.h"
 
@@ -26,6 +27,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 load_k4(const float* row, int k) {
   const f32x4_dword q = *reinterpret_cast<const f32x4_dword*>(row + k);
   return f32x4{q[0], q[1], q[2], q[3]};
+}
+
+// Weight rows are 16-byte aligned (weight_ld).
+__device__ __forceinline__ f32x4 load_w4(const float* row, int k) {
+  return *reinterpret_cast<const f32x4*>(row + k);
 }
 
 // The ragged last chunk (K % 16 != 0): clamped scalar loads, k >= K zeroed by the caller's mask.
@@ -59,14 +65,16 @@ struct Layer {
   int K, nfull, ld;
 
   __device__ __forceinline__ f32x4 weights(const float* w, int k) const {
-    if (!KS) return load_k4(w, k);
+    if (!KS) return load_w4(w, k);
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)(k + e) * ld];
     return v;
   }
   __device__ __forceinline__ f32x4 weights_tail(const float* w, int k) const {
-    if (!KS) return load_k4_tail(w, k, K);
+    // (k-contiguous rows are padded to a multiple of 4 floats: the chunk is clamped into the
+    //  row, whatever lies at k >= K meets a zeroed B operand)
+    if (!KS) return load_w4(w, min(k, (K + 3) / 4 * 4 - 4));
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)min(k + e, K - 1) * ld];
@@ -193,12 +201,19 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   }
   // head tiles: wave w forms rows [16 * tile, 16 * tile + 16) of head w / tiles_per_head
   const int tiles_per_head = (a.NH + 15) / 16;
-  const bool head_wave = wave < a.heads * tiles_per_head;
+  // A single output (the value of a critic) is no MFMA tile: it is folded into the epilogue of
+  // the second layer as a dot product (below).
+  const bool value_head = a.heads == 1 && a.NH == 1 && a.act[0] == ACT_NONE;       // scalar
+  const bool head_wave = !value_head && wave < a.heads * tiles_per_head;
   const int head = head_wave ? wave / tiles_per_head : 0;
   const int head_tile = head_wave ? wave - head * tiles_per_head : 0;
   // (selects, not array indexing: a runtime index into the kernel arguments would go to scratch)
   const float* Wh = (head == 0 ? a.Wh[0] : a.Wh[1]) + poff;
   const float* bh = (head == 0 ? a.bh[0] : a.bh[1]) + poff;
+  f32x4 wvalue[kMaxTiles];                            // value head: w3 of this lane's features
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j)
+    wvalue[j] = value_head ? load_w4(Wh, 16 * tile_of[j] + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
   float hbias[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) hbias[e] = bh[min(16 * head_tile + 4 * kg + e, a.NH - 1)];
@@ -223,8 +238,8 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const float* rows2[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) {
-    rows1[j] = W1 + (int64_t)(16 * tile_of[j] + m) * a.K1;
-    rows2[j] = W2 + (int64_t)(16 * tile_of[j] + m) * H;
+    rows1[j] = W1 + (int64_t)(16 * tile_of[j] + m) * a.ldw1;
+    rows2[j] = W2 + (int64_t)(16 * tile_of[j] + m) * a.ldw2;
   }
   f32x4 acc[kMaxTiles];
 #pragma unroll
@@ -244,10 +259,33 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
   l2.run(kg, acc, from_hx, from_hx);
   Layer<1> lh;
-  const float* rowsh[1] = {Wh + (int64_t)min(16 * head_tile + m, a.NH - 1) * H};
+  const float* rowsh[1] = {Wh + (int64_t)min(16 * head_tile + m, a.NH - 1) * a.ldw2};
   if (head_wave) lh.start(rowsh, H, kg);
+  float* partial = lds + 2 * kRows * pitch;           // [4 waves][16 rows]
+  if (value_head) {
+    // q[row] = b3 + sum_f h2[row][f] * w3[f]: this lane's 16 features, then the four k groups
+    // of the row (lanes m, m + 16, m + 32, m + 48), then the four waves through LDS
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxTiles; ++j) {
+      if (wave + 4 * j >= tiles) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part += fmaxf(acc[j][e] + bias2[j][e], 0.f) * wvalue[j][e];
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (kg == 0) partial[16 * wave + m] = part;
+  }
   finish(acc, bias2, h2g, hy);
   __syncthreads();
+  if (value_head) {
+    if (wave == 0 && kg == 0 && row_ok) {
+      float* out_base = a.out[0];
+      out_base[net * a.stride_out + (int64_t)(r0 + m) * a.ldo] =
+          ((partial[m] + partial[16 + m]) + (partial[32 + m] + partial[48 + m])) + hbias[0];
+    }
+    return;
+  }
 
   // heads: one [16 outputs][16 rows] tile per head wave
   if (head_wave) {
@@ -331,7 +369,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) cols2[j] = W2 + 16 * tile_of[j] + m;
   Layer<kMaxTiles, true> l1;                          // dz1 = W2^T dz2: requested before dz2 exists
-  l1.start(cols2, H, kg, H);
+  l1.start(cols2, H, kg, a.ldw2);
 
   f32x4 acc[kMaxTiles];
 #pragma unroll
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
     const float* w3 = a.w3 + net * a.stride_params;
 #pragma unroll
     for (int j = 0; j < kMaxTiles; ++j) {
-      const f32x4 w = load_k4(w3, 16 * tile_of[j] + 4 * kg);
+      const f32x4 w = load_w4(w3, 16 * tile_of[j] + 4 * kg);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[j][e] = dq * w[e];
     }
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
       for (int j = 0; j < kMaxTiles; ++j) colsh[j] = Wh + 16 * tile_of[j] + m;
       Layer<kMaxTiles, true> lh;
-      lh.start(colsh, a.NH, kg, H);
+      lh.start(colsh, a.NH, kg, a.ldw2);
       auto from_dh = [&](int k) { return load_k4(dh, k); };       // rows are padded to ldh >= 16
       lh.run(kg, acc, from_dh, from_dh);
     }
@@ -369,7 +407,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
   const bool xa_wave = 16 * wave < a.xa_count;      // one 16-column tile per wave
   const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first +
                            min(16 * wave + m, max(a.xa_count - 1, 0))};
-  if (xa_wave) lx.start(colsx, H, kg, a.K1);
+  if (xa_wave) lx.start(colsx, H, kg, a.ldw1);
   finish(acc, mask1, dz1g, hy);
   __syncthreads();
 
@@ -399,9 +437,11 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_forward_supported(a.H, a.NH, a.heads) && a.B > 0 && a.K1 > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: H=%d NH=%d heads=%d B=%d K1=%d", a.H,
                 a.NH, a.heads, a.B, a.K1);
+  TONIC_REQUIRE(a.ldw1 >= a.K1 && a.ldw1 % 4 == 0 && a.ldw2 >= a.H && a.ldw2 % 4 == 0,
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: weight strides %d / %d", a.ldw1, a.ldw2);
   TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
-  const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
+  const size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);
   TONIC_CHECK_LAUNCH("mlp_forward_kernel");
@@ -417,6 +457,8 @@ int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_backward_supported(a.H, a.NH, a.heads, a.xa_count) && a.B > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_backward: H=%d NH=%d heads=%d B=%d", a.H, a.NH,
                 a.heads, a.B);
+  TONIC_REQUIRE(a.ldw2 >= a.H && (a.xa_count == 0 || a.ldw1 >= a.K1), TONIC_ERR_INVALID_ARGUMENT,
+                "mlp_backward: weight strides %d / %d", a.ldw1, a.ldw2);
   const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
   hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);

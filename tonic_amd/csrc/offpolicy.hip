@@ -29,11 +29,16 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log
 struct ActorShape { int O, H, A, heads; };      // heads: 1 = deterministic (TD3), 2 = loc+scale (SAC)
 struct CriticShape { int O, A, H; };
 
+// Floats of one network in the padded layout (mlpfwd.h: weight_ld / slot4):
+//   actor : W1 [H, O] b1 [H] W2 [H, H] b2 [H] then per head Wh [A, H] bh [A]
+//   critic: W1 [H, O + A] b1 [H] W2 [H, H] b2 [H] w3 [1, H] b3 [1]
 __host__ __device__ inline int64_t actor_count(ActorShape s) {
-  return (int64_t)s.H * s.O + s.H + (int64_t)s.H * s.H + s.H + (int64_t)s.heads * (s.A * s.H + s.A);
+  return (int64_t)s.H * weight_ld(s.O) + slot4(s.H) + (int64_t)s.H * weight_ld(s.H) + slot4(s.H) +
+         (int64_t)s.heads * ((int64_t)s.A * weight_ld(s.H) + slot4(s.A));
 }
 __host__ __device__ inline int64_t critic_count(CriticShape s) {
-  return (int64_t)s.H * (s.O + s.A) + s.H + (int64_t)s.H * s.H + s.H + s.H + 1;
+  return (int64_t)s.H * weight_ld(s.O + s.A) + slot4(s.H) + (int64_t)s.H * weight_ld(s.H) +
+         slot4(s.H) + weight_ld(s.H) + slot4(1);
 }
 
 // ------------------------------------------------------------------ element-wise kernels
@@ -329,22 +334,30 @@ namespace {
 
 inline int pad16(int x) { return (x + 15) / 16 * 16; }
 
-struct ActorParams {
-  const float *W1, *b1, *W2, *b2, *Wh, *bh;     // Wh/bh: first head; second head follows at +A*H+A
+// Pointers into one actor's block of a flat buffer (parameters, or the gradient sums of the same
+// layout); ld1 / ldH: row strides of W1 and of the H-column weights.
+template <typename T>
+struct ActorBlock {
+  T *W1, *b1, *W2, *b2, *Wh;                    // Wh: first head; the second follows head_stride on
   ActorShape s;
-  explicit ActorParams(const float* p, ActorShape sh) : s(sh) {
-    W1 = p; b1 = W1 + (int64_t)s.H * s.O; W2 = b1 + s.H; b2 = W2 + (int64_t)s.H * s.H;
-    Wh = b2 + s.H; bh = Wh + (int64_t)s.A * s.H;
+  int ld1, ldH;
+  int64_t head_stride;
+  ActorBlock(T* p, ActorShape sh) : s(sh), ld1(weight_ld(sh.O)), ldH(weight_ld(sh.H)) {
+    W1 = p; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.H * ldH;
+    Wh = b2 + slot4(s.H);
+    head_stride = (int64_t)s.A * ldH + slot4(s.A);
   }
-  const float* head_w(int h) const { return Wh + (int64_t)h * (s.A * s.H + s.A); }
-  const float* head_b(int h) const { return head_w(h) + (int64_t)s.A * s.H; }
+  T* head_w(int h) const { return Wh + h * head_stride; }
+  T* head_b(int h) const { return head_w(h) + (int64_t)s.A * ldH; }
 };
+using ActorParams = ActorBlock<const float>;
 
 struct CriticOffsets {
   int64_t W1, b1, W2, b2, w3, b3, count;
-  explicit CriticOffsets(CriticShape s) {
-    W1 = 0; b1 = W1 + (int64_t)s.H * (s.O + s.A); W2 = b1 + s.H; b2 = W2 + (int64_t)s.H * s.H;
-    w3 = b2 + s.H; b3 = w3 + s.H; count = b3 + 1;
+  int ld1, ldH;
+  explicit CriticOffsets(CriticShape s) : ld1(weight_ld(s.O + s.A)), ldH(weight_ld(s.H)) {
+    W1 = 0; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.H * ldH;
+    w3 = b2 + slot4(s.H); b3 = w3 + ldH; count = b3 + slot4(1);
   }
 };
 
@@ -370,7 +383,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
   if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
     MlpFwdArgs f{};
     f.X = obs; f.ldx = s.O; f.K1 = s.O;
-    f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2;
+    f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2; f.ldw1 = p.ld1; f.ldw2 = p.ldH;
     f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
     f.Wh[1] = p.head_w(s.heads - 1); f.bh[1] = p.head_b(s.heads - 1);
     f.heads = s.heads; f.NH = s.A;
@@ -379,17 +392,17 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.B = B; f.H = s.H; f.split = 1 << 30;
     return launch_mlp_forward(f, 1, st);
   }
-  GemmArgs g = gemm(obs, s.O, p.W1, s.O, h1, s.H, B, s.H, s.O);
+  GemmArgs g = gemm(obs, s.O, p.W1, p.ld1, h1, s.H, B, s.H, s.O);
   g.bias = p.b1; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h1, s.H, p.W2, s.H, h2, s.H, B, s.H, s.H);
+  g = gemm(h1, s.H, p.W2, p.ldH, h2, s.H, B, s.H, s.H);
   g.bias = p.b2; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h2, s.H, p.head_w(0), s.H, head0, ldh, B, s.A, s.H);
+  g = gemm(h2, s.H, p.head_w(0), p.ldH, head0, ldh, B, s.A, s.H);
   g.bias = p.head_b(0); g.act = tanh_head ? ACT_TANH : ACT_NONE;
   TRY(launch_gemm('c', 'c', g, 1, st));
   if (s.heads == 2) {
-    g = gemm(h2, s.H, p.head_w(1), s.H, head1, ldh, B, s.A, s.H);
+    g = gemm(h2, s.H, p.head_w(1), p.ldH, head1, ldh, B, s.A, s.H);
     g.bias = p.head_b(1);
     TRY(launch_gemm('c', 'c', g, 1, st));
   }
@@ -409,6 +422,7 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
     MlpFwdArgs f{};
     f.X = X; f.ldx = ldx; f.K1 = in;
     f.W1 = params + o.W1; f.b1 = params + o.b1; f.W2 = params + o.W2; f.b2 = params + o.b2;
+    f.ldw1 = o.ld1; f.ldw2 = o.ldH;
     f.Wh[0] = f.Wh[1] = params + o.w3; f.bh[0] = f.bh[1] = params + o.b3;
     f.heads = 1; f.NH = 1;
     f.h1 = h1; f.h2 = h2; f.out[0] = f.out[1] = q; f.ldo = 1;
@@ -428,15 +442,15 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
     return critics_forward(params2, s, nets, X2, ldx, B, Bp, h1 + nets * hs, h2 + nets * hs,
                            q + (int64_t)nets * Bp, st);
   }
-  GemmArgs g = gemm(X, ldx, params + o.W1, in, h1, s.H, B, s.H, in);
+  GemmArgs g = gemm(X, ldx, params + o.W1, o.ld1, h1, s.H, B, s.H, in);
   g.bias = params + o.b1; g.act = ACT_RELU;
   g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h1, s.H, params + o.W2, s.H, h2, s.H, B, s.H, s.H);
+  g = gemm(h1, s.H, params + o.W2, o.ldH, h2, s.H, B, s.H, s.H);
   g.bias = params + o.b2; g.act = ACT_RELU;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h2, s.H, params + o.w3, s.H, q, 1, B, 1, s.H);
+  g = gemm(h2, s.H, params + o.w3, o.ldH, q, 1, B, 1, s.H);
   g.bias = params + o.b3;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = Bp;
   TRY(launch_gemm('c', 'c', g, nets, st));
@@ -458,7 +472,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
   if (mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0)) {        // ... in ONE launch
     MlpBwdArgs b{};
     b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
-    b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in;
+    b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
     b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
     b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa;
     b.B = B; b.H = s.H;
@@ -467,17 +481,17 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
-    g = gemm(dq, 1, params + o.w3, s.H, dh2, s.H, B, s.H, 1);
+    g = gemm(dq, 1, params + o.w3, o.ldH, dh2, s.H, B, s.H, 1);
     g.mask = h2; g.ldmask = s.H;
     g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
     // dz1 = (dz2 W2) * relu'(h1)
-    g = gemm(dh2, s.H, params + o.W2, s.H, dh1, s.H, B, s.H, s.H);
+    g = gemm(dh2, s.H, params + o.W2, o.ldH, dh1, s.H, B, s.H, s.H);
     g.mask = h1; g.ldmask = s.H;
     g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
     if (dxa) {     // dxa = dz1 W1[:, O : O + A]
-      g = gemm(dh1, s.H, params + o.W1 + s.O, in, dxa, ldxa, B, s.A, s.H);
+      g = gemm(dh1, s.H, params + o.W1 + s.O, o.ld1, dxa, ldxa, B, s.A, s.H);
       g.strideA = hs; g.strideB = o.count; g.strideC = (int64_t)Bp * ldxa;
       TRY(launch_gemm('c', 's', g, nets, st));
     }
@@ -486,13 +500,13 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     // ... then the three weight gradients (all contract over the batch) in ONE launch:
     //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
     GemmArgs w[3];
-    w[0] = gemm(dq, 1, h2, s.H, grads + o.w3, s.H, 1, s.H, B);
+    w[0] = gemm(dq, 1, h2, s.H, grads + o.w3, o.ldH, 1, s.H, B);
     w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
     w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
-    w[1] = gemm(dh2, s.H, h1, s.H, grads + o.W2, s.H, s.H, s.H, B);
+    w[1] = gemm(dh2, s.H, h1, s.H, grads + o.W2, o.ldH, s.H, s.H, B);
     w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
     w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
-    w[2] = gemm(dh1, s.H, X, ldx, grads + o.W1, in, s.H, in, B);
+    w[2] = gemm(dh1, s.H, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
     w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
     w[2].strideA = hs; w[2].strideC = o.count;
     TRY(launch_gemm_group('s', 's', w, 3, nets, st));
@@ -526,6 +540,8 @@ using namespace tonic;
 extern "C" int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H) {
   return (offpolicy_workspace_floats(B, O, A, H) + 64 * 30) * 4;
 }
+
+extern "C" int32_t tonic_mlp_weight_stride(int32_t cols) { return weight_ld(cols); }
 
 extern "C" int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads) {
   return actor_count(ActorShape{O, H, A, heads});
@@ -699,8 +715,7 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                      (float)entropy_coeff, kind == 1 ? 1 : 0, dloc, dspre, B, A);
   // ---- actor backward (weight-gradient sums into the flat layout)
   ActorParams p(d_actor_params, as);
-  float* g_W1 = d_grad_sums; float* g_b1 = g_W1 + (int64_t)H * O; float* g_W2 = g_b1 + H;
-  float* g_b2 = g_W2 + (int64_t)H * H; float* g_Wh = g_b2 + H;
+  const ActorBlock<float> gp(d_grad_sums, as);         // the gradient sums share the layout
   GemmArgs g;
   // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
   if (mlp_backward_supported(H, A, as.heads, 0)) {
@@ -708,18 +723,18 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
     b.heads = as.heads; b.NH = A; b.ldh = ldh;
     b.dhead[0] = dloc; b.dhead[1] = dspre;
     b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
-    b.W2 = p.W2; b.W1 = p.W1; b.K1 = O; b.xa_first = 0; b.xa_count = 0;
+    b.W2 = p.W2; b.W1 = p.W1; b.K1 = O; b.ldw1 = p.ld1; b.ldw2 = p.ldH; b.xa_first = 0; b.xa_count = 0;
     b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = nullptr;
     b.B = B; b.H = H;
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
       const float* dhead = h == 0 ? dloc : dspre;
-      g = gemm(dhead, ldh, p.head_w(h), H, da_h2, H, B, H, A);
+      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, H, B, H, A);
       g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
       TRY(launch_gemm('c', 's', g, 1, st));
     }
-    g = gemm(da_h2, H, p.W2, H, da_h1, H, B, H, H);
+    g = gemm(da_h2, H, p.W2, p.ldH, da_h1, H, B, H, H);
     g.mask = a_h1; g.ldmask = H;
     TRY(launch_gemm('c', 's', g, 1, st));
   }
@@ -729,14 +744,13 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   int count = 0;
   for (int h = 0; h < as.heads; ++h) {
     const float* dhead = h == 0 ? dloc : dspre;
-    float* gw = g_Wh + (int64_t)h * (A * H + A);
-    w[count] = gemm(dhead, ldh, a_h2, H, gw, H, A, H, B);
-    w[count++].colsum = gw + (int64_t)A * H;
+    w[count] = gemm(dhead, ldh, a_h2, H, gp.head_w(h), gp.ldH, A, H, B);
+    w[count++].colsum = gp.head_b(h);
   }
-  w[count] = gemm(da_h2, H, a_h1, H, g_W2, H, H, H, B);
-  w[count++].colsum = g_b2;
-  w[count] = gemm(da_h1, H, d_observations, O, g_W1, O, H, O, B);
-  w[count++].colsum = g_b1;
+  w[count] = gemm(da_h2, H, a_h1, H, gp.W2, gp.ldH, H, H, B);
+  w[count++].colsum = gp.b2;
+  w[count] = gemm(da_h1, H, d_observations, O, gp.W1, gp.ld1, H, O, B);
+  w[count++].colsum = gp.b1;
   TRY(launch_gemm_group('s', 's', w, count, 1, st));
   TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
   return TONIC_OK;

@@ -226,24 +226,51 @@ class FlatNetwork:
     """One or several networks' parameters packed into a single contiguous device buffer, in
     ``parameters()`` order (the layout the C ABI documents); every ``nn.Parameter`` becomes a
     view of it, so ``state_dict`` / ``load_state_dict`` keep working and the kernels see one
-    flat pointer.  ``out`` packs into an existing buffer region instead of allocating."""
+    flat pointer.  ``out`` packs into an existing (zeroed) buffer region instead of allocating.
 
-    def __init__(self, modules, device, out=None):
+    ``padded`` selects the off-policy parameter layout of include/tonic_hip.h: every tensor on a
+    16-byte boundary, weight rows ``tonic_mlp_weight_stride(cols)`` floats apart (the weight
+    parameters are then strided views; the padding stays zero)."""
+
+    @staticmethod
+    def slots(modules, padded):
+        """[(parameter, floats in the buffer, row stride or None)] in buffer order."""
         if isinstance(modules, torch.nn.Module):
             modules = [modules]
         params = [p for module in modules for p in network_variables(module)]
-        self.count = sum(p.numel() for p in params)
-        self.flat = out if out is not None else torch.empty(
+        if not padded:
+            return [(p, p.numel(), None) for p in params]
+        from tonic_amd import _lib
+        stride = _lib.load().tonic_mlp_weight_stride
+        out = []
+        for p in params:
+            if p.dim() == 2:
+                ld = int(stride(p.shape[1]))
+                out.append((p, p.shape[0] * ld, ld))
+            else:
+                out.append((p, (p.numel() + 3) // 4 * 4, None))
+        return out
+
+    @staticmethod
+    def length(modules, padded=False):
+        return sum(n for _, n, _ in FlatNetwork.slots(modules, padded))
+
+    def __init__(self, modules, device, out=None, padded=False):
+        slots = self.slots(modules, padded)
+        self.count = sum(n for _, n, _ in slots)
+        self.flat = out if out is not None else torch.zeros(
             self.count, dtype=torch.float32, device=device)
         assert self.flat.numel() == self.count
         offset = 0
-        for p in params:
-            n = p.numel()
-            view = self.flat[offset:offset + n].view(p.shape)
+        for p, n, ld in slots:
+            if ld is None:
+                view = self.flat[offset:offset + p.numel()].view(p.shape)
+            else:
+                view = self.flat[offset:offset + n].view(p.shape[0], ld)[:, :p.shape[1]]
             view.copy_(p.data)
             p.data = view
             offset += n
-        self.params = params
+        self.params = [p for p, _, _ in slots]
 
     def shapes(self):
         return [tuple(p.shape) for p in self.params]
@@ -309,19 +336,20 @@ class ActorCriticWithTargets(torch.nn.Module):
 
     def pack(self, device):
         """Moves the model to `device`; the online networks share one flat buffer
-        [actor | critic(s)] and the targets another with the same layout, so ``update_targets``
-        is one polyak launch and all critics are one Adam block."""
+        [actor | critic(s)] (off-policy parameter layout: padded weight rows) and the targets
+        another with the same layout, so ``update_targets`` is one polyak launch and all
+        critics are one Adam block."""
         self.to(device)
         nets = [n for n, _ in self._networks()]
         online, target = nets[:len(nets) // 2], nets[len(nets) // 2:]
-        total = sum(p.numel() for m in online for p in network_variables(m))
-        self.flat_online = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_target = torch.empty(total, dtype=torch.float32, device=device)
-        n_actor = sum(p.numel() for p in network_variables(online[0]))
-        self.flat_actor = FlatNetwork(online[0], device, self.flat_online[:n_actor])
-        self.flat_critics = FlatNetwork(online[1:], device, self.flat_online[n_actor:])
-        self.flat_target_actor = FlatNetwork(target[0], device, self.flat_target[:n_actor])
-        self.flat_target_critics = FlatNetwork(target[1:], device, self.flat_target[n_actor:])
+        total = FlatNetwork.length(online, padded=True)
+        self.flat_online = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_target = torch.zeros(total, dtype=torch.float32, device=device)
+        n_actor = FlatNetwork.length(online[0], padded=True)
+        self.flat_actor = FlatNetwork(online[0], device, self.flat_online[:n_actor], True)
+        self.flat_critics = FlatNetwork(online[1:], device, self.flat_online[n_actor:], True)
+        self.flat_target_actor = FlatNetwork(target[0], device, self.flat_target[:n_actor], True)
+        self.flat_target_critics = FlatNetwork(target[1:], device, self.flat_target[n_actor:], True)
         return self
 
     def update_targets(self):

@@ -230,6 +230,20 @@ class _QUpdater(_FlatUpdater):
         self.action_size = layer[0].out_features
         self.normalizer = model.observation_normalizer
         device = model.flat_online.device
+        # the C side walks the flat blocks by its own offsets: both must agree on the layout
+        heads = 2 if self.sac else 1
+        lib = _lib.load()
+        want_actor = lib.tonic_mlp_actor_param_count(
+            self.observation_size, self.hidden, self.action_size, heads)
+        want_critic = lib.tonic_q_critic_param_count(
+            self.observation_size, self.action_size, self.hidden)
+        n_critics = 2 if hasattr(model, 'critic_1') else 1
+        if (model.flat_actor.count, model.flat_critics.count) != (want_actor,
+                                                                   n_critics * want_critic):
+            raise NotImplementedError(
+                f'network shapes outside the packed off-policy layout: actor '
+                f'{model.flat_actor.count} vs {want_actor}, critics {model.flat_critics.count} '
+                f'vs {n_critics} x {want_critic}')
         if self.normalizer is None:
             self._unit = (torch.zeros(self.observation_size, device=device),
                           torch.ones(self.observation_size, device=device))
