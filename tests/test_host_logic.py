@@ -238,3 +238,40 @@ def test_buffer_shard_indices_partition_the_global_batch():
             assert np.all(np.diff(pos) > 0), 'batch order is kept inside a shard'
             seen[it, pos] += 1
     assert np.all(seen == 1), 'every sample of the global batch is owned by exactly one rank'
+
+
+def test_offpolicy_padded_parameter_layout_keeps_state_dict():
+    """Off-policy blocks: padded weight rows (include/tonic_hip.h), parameters are strided views,
+    state_dict / checkpoints keep the reference's shapes, the C side agrees on the block lengths."""
+    import io
+    import torch
+    import tonic_amd.torch as tt
+    from tonic_amd import _lib
+    from tonic_amd.environments import Box
+    lib = _lib.load()
+    assert [lib.tonic_mlp_weight_stride(c) for c in (256, 111, 119, 88, 96, 64, 1)] == \
+        [260, 112, 120, 88, 100, 68, 4]
+
+    def packed():
+        model = tt.agents.SAC().model
+        model.initialize(Box(-np.inf, np.inf, (111,)), Box(-1, 1, (8,)))
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        return model.pack('cpu'), before
+
+    torch.manual_seed(0)
+    model, before = packed()
+    after = model.state_dict()
+    assert all(torch.equal(before[k], after[k]) and before[k].shape == after[k].shape for k in before)
+    assert model.actor.torso.model[2].weight.stride() == (260, 1)
+    assert model.flat_actor.count == lib.tonic_mlp_actor_param_count(111, 256, 8, 2)
+    assert model.flat_critics.count == 2 * lib.tonic_q_critic_param_count(111, 8, 256)
+    assert model.flat_online.numel() == model.flat_actor.count + model.flat_critics.count
+    live = sum(int((p != 0).sum()) for p in model.online_variables)
+    assert int((model.flat_online != 0).sum()) == live            # the padding is zero
+    blob = io.BytesIO()
+    torch.save(model.state_dict(), blob)
+    blob.seek(0)
+    other, _ = packed()
+    other.load_state_dict(torch.load(blob))
+    assert all(torch.equal(other.state_dict()[k], before[k]) for k in before)
+    assert int((other.flat_online != 0).sum()) == live
