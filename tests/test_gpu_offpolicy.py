@@ -23,7 +23,8 @@ def dev(x, dtype=torch.float32):
 
 @pytest.mark.parametrize('mode', ['NT', 'NN', 'TN'])
 @pytest.mark.parametrize('M,N,K', [(1024, 256, 256), (100, 256, 119), (24, 1, 32), (37, 21, 88),
-                                   (16, 32, 16), (1, 256, 1024)])
+                                   (16, 32, 16), (1, 256, 1024), (256, 119, 1024), (256, 256, 100),
+                                   (21, 256, 100)])
 def test_gemm16_vs_numpy(lib, mode, M, N, K):
     from tonic_amd import _lib
     rng = np.random.RandomState(M * 7 + N * 3 + K)

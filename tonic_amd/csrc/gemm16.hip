@@ -149,6 +149,190 @@ __global__ __launch_bounds__(64 * kGemmMaxWaves) void gemm16_group_kernel(GemmGr
   gemm16_tiles<A_KC, B_KC>(G.problem[p], (int)blockIdx.x - G.first[p], part);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients: C[M,N] = A[K,M]^T . B[K,N] with K = batch size (TN), bias gradient = column
+// sums of A.  Both operands are k-strided, i.e. contiguous ALONG the output index, so one lane can
+// fetch two neighbouring output columns with one 8-byte load: a wave owns a 32 x 32 output tile
+// made of 2 x 2 INTERLEAVED 16 x 16 MFMA tiles (tile jm holds rows m0 + 2 i + jm, tile jn columns
+// n0 + 2 i + jn), 8 loads feed 16 MFMAs per 16-k chunk (the generic kernel above: 12 dword loads
+// and ~70 address instructions per 8 MFMAs).  Four waves share a tile and interleave the chunks;
+// each keeps kTnDepth chunks in flight.  Partial tiles and column sums are folded through LDS in
+// wave order.
+constexpr int kTnWaves = 4, kTnDepth = 4, kTnPart = 18;      // floats per lane in the exchange
+
+typedef float f32x2_dword __attribute__((ext_vector_type(2), aligned(4)));
+
+// Two neighbouring columns of one operand row.  `base` is wave-uniform (the chunk's first row),
+// `offset` the lane's UNSIGNED 32-bit element offset from it (scalar base + zero-extended vector
+// offset is an addressing mode of global_load): the load needs no vector address arithmetic.
+// EDGE (compile-time: a run-time flag, even a wave-uniform one, puts a branch around every
+// load): tiles that reach past the last row / column of C take clamped scalar loads.
+template <bool EDGE>
+__device__ __forceinline__ void tn_load(const float* __restrict__ base, unsigned offset, int col,
+                                        int cols, float (&v)[2]) {
+  if (!EDGE) {                              // (byte offset: the addressing mode takes bytes)
+    const f32x2_dword q = *reinterpret_cast<const f32x2_dword*>(
+        reinterpret_cast<const char*>(base) + 4u * offset);
+    v[0] = q[0]; v[1] = q[1];
+  } else {                                  // offset = row offset + col: re-clamp the two columns
+    const float* row = base + (offset - col);
+    v[0] = row[min(col, cols - 1)];
+    v[1] = row[min(col + 1, cols - 1)];
+  }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, float* part) {
+  const int lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);       // scalar: uniform control flow
+  const int i = lane & 15, kg = lane >> 4;
+  const int m0 = 32 * tm, n0 = 32 * tn;
+  const int z = blockIdx.z;
+  const float* A = g.A + z * g.strideA;
+  const float* B = g.B + z * g.strideB;
+  float* C = g.C + z * g.strideC;
+  const int ca = m0 + 2 * i, cb = n0 + 2 * i;
+  const int full = g.K / 16;                // full 16-k chunks; a ragged one may follow
+  const int mine = full > w ? (full - w + kTnWaves - 1) / kTnWaves : 0;       // chunks w, w+4, ...
+  unsigned offa[4], offb[4];                // rows 4 kg + t of a chunk
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    offa[t] = (4 * kg + t) * g.lda + ca;
+    offb[t] = (4 * kg + t) * g.ldb + cb;
+  }
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int jm = 0; jm < 2; ++jm)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float colsum[2] = {0.f, 0.f};
+
+  auto multiply = [&](const float (&a)[4][2], const float (&b)[4][2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int jm = 0; jm < 2; ++jm) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[jm][jn] = mfma16(a[t][jm], b[t][jn], acc[jm][jn]);
+      }
+    }
+#pragma unroll
+    for (int jm = 0; jm < 2; ++jm) colsum[jm] += (a[0][jm] + a[1][jm]) + (a[2][jm] + a[3][jm]);
+  };
+
+  // ---- full chunks: kTnDepth chunks in flight in rotating register slots; the loads that
+  //      refill a slot are issued right after the MFMAs that drained it, so that load issue
+  //      (~7 ns of the CU's memory pipe per instruction, four waves sharing it) and MFMA issue
+  //      interleave instead of alternating in bursts (profiles/r01_ubench_row_stride.md)
+  float a[kTnDepth][4][2], b[kTnDepth][4][2];
+  auto request = [&](int slot, int index) {
+    const int c = min(w + kTnWaves * index, full - 1);           // past the end: re-read, unused
+    const float* Ac = A + (int64_t)16 * c * g.lda;               // scalar arithmetic
+    const float* Bc = B + (int64_t)16 * c * g.ldb;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      tn_load<EDGE>(Ac, offa[t], ca, g.M, a[slot][t]);
+      tn_load<EDGE>(Bc, offb[t], cb, g.N, b[slot][t]);
+    }
+  };
+  if (mine > 0) {
+#pragma unroll
+    for (int d = 0; d < kTnDepth; ++d) request(d, d);
+  }
+  for (int first = 0; first < mine; first += kTnDepth) {
+#pragma unroll
+    for (int d = 0; d < kTnDepth; ++d) {
+      if (first + d < mine) multiply(a[d], b[d]);                // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);
+      request(d, first + d + kTnDepth);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the ragged last chunk (K % 16 rows) belongs to the wave whose turn it is
+  if (g.K % 16 != 0 && full % kTnWaves == w) {
+    const float* Ac = A + (int64_t)16 * full * g.lda;
+    const float* Bc = B + (int64_t)16 * full * g.ldb;
+    const int last = g.K - 1 - 16 * full;
+    float a[4][2], b[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = min(4 * kg + t, last);                       // clamp the row, zero it below
+      tn_load<EDGE>(Ac, (unsigned)(r * g.lda + ca), ca, g.M, a[t]);
+      tn_load<EDGE>(Bc, (unsigned)(r * g.ldb + cb), cb, g.N, b[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool keep = 4 * kg + t <= last;
+      a[t][0] = keep ? a[t][0] : 0.f; a[t][1] = keep ? a[t][1] : 0.f;
+    }
+    multiply(a, b);
+  }
+
+  float* slot = part + (w * 64 + lane) * kTnPart;
+#pragma unroll
+  for (int jm = 0; jm < 2; ++jm)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot[(2 * jm + jn) * 4 + r] = acc[jm][jn][r];
+  slot[16] = colsum[0]; slot[17] = colsum[1];
+  __syncthreads();
+  if (w != 0) return;
+  for (int o = 1; o < kTnWaves; ++o) {                           // fixed order: bit-reproducible
+    const float* other = part + (o * 64 + lane) * kTnPart;
+#pragma unroll
+    for (int jm = 0; jm < 2; ++jm)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jm][jn][r] += other[(2 * jm + jn) * 4 + r];
+    colsum[0] += other[16]; colsum[1] += other[17];
+  }
+
+  if (g.colsum != nullptr && tn == 0) {
+#pragma unroll
+    for (int jm = 0; jm < 2; ++jm) {
+      float v = colsum[jm];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (kg == 0 && ca + jm < g.M) g.colsum[z * g.strideColsum + ca + jm] = v;
+    }
+  }
+  // D layout: lane (column index i, group kg), register r <-> row index 4 kg + r of the MFMA tile
+#pragma unroll
+  for (int jm = 0; jm < 2; ++jm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 2 * (4 * kg + r) + jm;
+      if (m >= g.M) continue;
+      float* dst = C + (int64_t)m * g.ldc + cb;
+      float v0 = acc[jm][0][r] * g.alpha, v1 = acc[jm][1][r] * g.alpha;
+      if (cb + 1 < g.N) {
+        if (g.accumulate) {
+          const f32x2_dword old = *reinterpret_cast<const f32x2_dword*>(dst);
+          v0 += old[0]; v1 += old[1];
+        }
+        *reinterpret_cast<f32x2_dword*>(dst) = f32x2_dword{v0, v1};
+      } else if (cb < g.N) {
+        dst[0] = g.accumulate ? dst[0] + v0 : v0;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup G) {
+  __shared__ float part[kTnWaves * 64 * kTnPart];
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kGemmGroupMax; ++q) p += (q < G.count && (int)blockIdx.x >= G.first[q]) ? 1 : 0;
+  const GemmArgs& g = G.problem[p];
+  const int tile = (int)blockIdx.x - G.first[p], tiles_n = (g.N + 31) / 32;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  if (32 * tm + 32 > g.M || 32 * tn + 32 > g.N) gemm_tn_tile<true>(g, tm, tn, part);   // uniform
+  else gemm_tn_tile<false>(g, tm, tn, part);
+}
+
 namespace {
 
 // waves per tile: at most kGemmGroup chunks per wave, then more while the chip is not full
@@ -176,6 +360,23 @@ int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count,
                   g.N, g.K);
     G.problem[p] = g;
     tiles_total += (int64_t)((g.M + 15) / 16) * ((g.N + 31) / 32);
+  }
+  if (mode_a == 's' && mode_b == 's') {                // weight gradients: the interleaved TN kernel
+    bool plain = true;
+    for (int p = 0; p < count; ++p)
+      plain = plain && !list[p].bias && !list[p].mask && list[p].act == ACT_NONE;
+    if (plain) {
+      int blocks = 0;
+      for (int p = 0; p < count; ++p) {
+        G.first[p] = blocks;
+        blocks += ((list[p].M + 31) / 32) * ((list[p].N + 31) / 32);
+      }
+      G.first[count] = blocks;
+      hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks, 1, batch), dim3(64, kTnWaves), 0,
+                         stream, G);
+      TONIC_CHECK_LAUNCH("gemm_tn_group");
+      return TONIC_OK;
+    }
   }
   const int S = waves_per_tile(list[0].K, tiles_total * batch);
   const int per_block = S >= 4 ? 1 : 4 / S;
@@ -205,6 +406,8 @@ int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count,
 int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStream_t stream) {
   TONIC_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && batch > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "gemm: bad argument (M=%d N=%d K=%d)", g.M, g.N, g.K);
+  if (mode_a == 's' && mode_b == 's' && !g.bias && !g.mask && g.act == ACT_NONE)
+    return launch_gemm_group(mode_a, mode_b, &g, 1, batch, stream);
   const int tiles = ((g.M + 15) / 16) * ((g.N + 31) / 32);
   const int S = waves_per_tile(g.K, (int64_t)tiles * batch);
   const int per_block = S >= 4 ? 1 : 4 / S;         // tiles per workgroup (>= 4 waves each)

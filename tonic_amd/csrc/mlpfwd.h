@@ -26,7 +26,8 @@ struct MlpFwdArgs {
   const float* Wh[2]; const float* bh[2];   // heads: [NH, H] rows ldw2 apart, [NH]
   int ldw1, ldw2;            // weight row strides (weight_ld): multiples of 4, 16-byte aligned rows
   int heads, NH;
-  float* h1; float* h2;      // [B, H] hidden activations (written: the backward needs them)
+  float* h1; float* h2;      // [B, H] hidden activations, rows ldh apart (written: the backward needs them)
+  int ldh;                   // >= H, multiple of 4 (weight_ld(H): the weight-gradient GEMMs walk these rows)
   float* out[2];             // head outputs [B, ldo]
   int ldo;
   int act[2];                // GemmAct per head (ACT_NONE | ACT_TANH)
@@ -53,8 +54,9 @@ struct MlpBwdArgs {
   const float* W1;           // [H, K1] rows ldw1 apart (only for dxa)
   int ldw1, ldw2;
   int K1, xa_first, xa_count;   // dxa = columns [xa_first, xa_first + xa_count) of dz1 . W1
-  const float* h1; const float* h2;   // [B, H] forward activations (ReLU masks)
-  float* dz2; float* dz1;    // [B, H] outputs
+  const float* h1; const float* h2;   // [B, H] forward activations (ReLU masks), rows ldhid apart
+  float* dz2; float* dz1;    // [B, H] outputs, rows ldhid apart
+  int ldhid;
   float* dxa;                // [B, ldxa]
   int ldxa;
   int B, H;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) h[e] = fmaxf(acc[j][e] + bias[j][e], 0.f);
       *reinterpret_cast<f32x4*>(image + m * pitch + f) = h;
-      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * H + f) =
+      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * a.ldh + f) =
           f32x4_dword{h[0], h[1], h[2], h[3]};
     }
   };
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) {
     const int f = 16 * tile_of[j] + 4 * kg;
-    mask2[j] = load_k4(h2g + (int64_t)row * H, f);
-    mask1[j] = load_k4(h1g + (int64_t)row * H, f);
+    mask2[j] = load_k4(h2g + (int64_t)row * a.ldhid, f);
+    mask1[j] = load_k4(h1g + (int64_t)row * a.ldhid, f);
   }
   // masked gradient of a hidden layer: to HBM (weight gradients) and to an LDS image [row][feature]
   auto finish = [&](const f32x4 (&acc)[kMaxTiles], const f32x4 (&mask)[kMaxTiles], float* global,
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = mask[j][e] > 0.f ? acc[j][e] : 0.f;
       *reinterpret_cast<f32x4*>(image + m * pitch + f) = d;
-      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * H + f) =
+      if (row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(r0 + m) * a.ldhid + f) =
           f32x4_dword{d[0], d[1], d[2], d[3]};
     }
   };
@@ -437,8 +437,9 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_forward_supported(a.H, a.NH, a.heads) && a.B > 0 && a.K1 > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: H=%d NH=%d heads=%d B=%d K1=%d", a.H,
                 a.NH, a.heads, a.B, a.K1);
-  TONIC_REQUIRE(a.ldw1 >= a.K1 && a.ldw1 % 4 == 0 && a.ldw2 >= a.H && a.ldw2 % 4 == 0,
-                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: weight strides %d / %d", a.ldw1, a.ldw2);
+  TONIC_REQUIRE(a.ldw1 >= a.K1 && a.ldw1 % 4 == 0 && a.ldw2 >= a.H && a.ldw2 % 4 == 0 &&
+                    a.ldh >= a.H && a.ldh % 4 == 0,
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: strides %d / %d / %d", a.ldw1, a.ldw2, a.ldh);
   TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
   const size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);
@@ -457,8 +458,9 @@ int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_backward_supported(a.H, a.NH, a.heads, a.xa_count) && a.B > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_backward: H=%d NH=%d heads=%d B=%d", a.H, a.NH,
                 a.heads, a.B);
-  TONIC_REQUIRE(a.ldw2 >= a.H && (a.xa_count == 0 || a.ldw1 >= a.K1), TONIC_ERR_INVALID_ARGUMENT,
-                "mlp_backward: weight strides %d / %d", a.ldw1, a.ldw2);
+  TONIC_REQUIRE(a.ldw2 >= a.H && (a.xa_count == 0 || a.ldw1 >= a.K1) && a.ldhid >= a.H &&
+                    a.ldhid % 4 == 0, TONIC_ERR_INVALID_ARGUMENT,
+                "mlp_backward: strides %d / %d / %d", a.ldw1, a.ldw2, a.ldhid);
   const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
   hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);

@@ -333,6 +333,10 @@ __global__ __launch_bounds__(1024) void buffer_store_kernel(BufferStoreArgs a) {
 namespace {
 
 inline int pad16(int x) { return (x + 15) / 16 * 16; }
+// Row pitch of the batch-major scratch matrices the weight-gradient GEMMs walk along the batch
+// (hidden activations, their gradients, the critics' input): never a multiple of 128 bytes
+// (profiles/r01_ubench_row_stride.md).
+inline int pitch16(int x) { return weight_ld(pad16(x)); }
 
 // Pointers into one actor's block of a flat buffer (parameters, or the gradient sums of the same
 // layout); ld1 / ldH: row strides of W1 and of the H-column weights.
@@ -380,6 +384,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
                   hipStream_t st) {
   ActorParams p(params, s);
+  const int HP = weight_ld(s.H);
   if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
     MlpFwdArgs f{};
     f.X = obs; f.ldx = s.O; f.K1 = s.O;
@@ -387,22 +392,23 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
     f.Wh[1] = p.head_w(s.heads - 1); f.bh[1] = p.head_b(s.heads - 1);
     f.heads = s.heads; f.NH = s.A;
-    f.h1 = h1; f.h2 = h2; f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
+    f.h1 = h1; f.h2 = h2; f.ldh = HP;
+    f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
     f.act[0] = tanh_head ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
     f.B = B; f.H = s.H; f.split = 1 << 30;
     return launch_mlp_forward(f, 1, st);
   }
-  GemmArgs g = gemm(obs, s.O, p.W1, p.ld1, h1, s.H, B, s.H, s.O);
+  GemmArgs g = gemm(obs, s.O, p.W1, p.ld1, h1, HP, B, s.H, s.O);
   g.bias = p.b1; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h1, s.H, p.W2, p.ldH, h2, s.H, B, s.H, s.H);
+  g = gemm(h1, HP, p.W2, p.ldH, h2, HP, B, s.H, s.H);
   g.bias = p.b2; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h2, s.H, p.head_w(0), p.ldH, head0, ldh, B, s.A, s.H);
+  g = gemm(h2, HP, p.head_w(0), p.ldH, head0, ldh, B, s.A, s.H);
   g.bias = p.head_b(0); g.act = tanh_head ? ACT_TANH : ACT_NONE;
   TRY(launch_gemm('c', 'c', g, 1, st));
   if (s.heads == 2) {
-    g = gemm(h2, s.H, p.head_w(1), p.ldH, head1, ldh, B, s.A, s.H);
+    g = gemm(h2, HP, p.head_w(1), p.ldH, head1, ldh, B, s.A, s.H);
     g.bias = p.head_b(1);
     TRY(launch_gemm('c', 'c', g, 1, st));
   }
@@ -417,7 +423,8 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
                     const float* params2 = nullptr, const float* X2 = nullptr) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
-  const int64_t hs = (int64_t)Bp * s.H;
+  const int HP = weight_ld(s.H);
+  const int64_t hs = (int64_t)Bp * HP;
   if (mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
     MlpFwdArgs f{};
     f.X = X; f.ldx = ldx; f.K1 = in;
@@ -425,7 +432,7 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
     f.ldw1 = o.ld1; f.ldw2 = o.ldH;
     f.Wh[0] = f.Wh[1] = params + o.w3; f.bh[0] = f.bh[1] = params + o.b3;
     f.heads = 1; f.NH = 1;
-    f.h1 = h1; f.h2 = h2; f.out[0] = f.out[1] = q; f.ldo = 1;
+    f.h1 = h1; f.h2 = h2; f.ldh = HP; f.out[0] = f.out[1] = q; f.ldo = 1;
     f.act[0] = f.act[1] = ACT_NONE;
     f.B = B; f.H = s.H; f.split = 1 << 30;
     f.stride_params = o.count; f.stride_hidden = hs; f.stride_out = Bp;
@@ -442,15 +449,15 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
     return critics_forward(params2, s, nets, X2, ldx, B, Bp, h1 + nets * hs, h2 + nets * hs,
                            q + (int64_t)nets * Bp, st);
   }
-  GemmArgs g = gemm(X, ldx, params + o.W1, o.ld1, h1, s.H, B, s.H, in);
+  GemmArgs g = gemm(X, ldx, params + o.W1, o.ld1, h1, HP, B, s.H, in);
   g.bias = params + o.b1; g.act = ACT_RELU;
   g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h1, s.H, params + o.W2, o.ldH, h2, s.H, B, s.H, s.H);
+  g = gemm(h1, HP, params + o.W2, o.ldH, h2, HP, B, s.H, s.H);
   g.bias = params + o.b2; g.act = ACT_RELU;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h2, s.H, params + o.w3, o.ldH, q, 1, B, 1, s.H);
+  g = gemm(h2, HP, params + o.w3, o.ldH, q, 1, B, 1, s.H);
   g.bias = params + o.b3;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = Bp;
   TRY(launch_gemm('c', 'c', g, nets, st));
@@ -465,7 +472,8 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
                      float* dh1, float* grads, float* dxa, hipStream_t st) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
-  const int64_t hs = (int64_t)Bp * s.H;
+  const int HP = weight_ld(s.H);
+  const int64_t hs = (int64_t)Bp * HP;
   const int ldxa = pad16(s.A);
   GemmArgs g;
   // the input-gradient chain first ...
@@ -474,24 +482,24 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
     b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
     b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
-    b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa;
+    b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa; b.ldhid = HP;
     b.B = B; b.H = s.H;
     b.ldxa = ldxa;
     b.stride_params = o.count; b.stride_hidden = hs; b.stride_dq = Bp; b.stride_dxa = (int64_t)Bp * ldxa;
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
-    g = gemm(dq, 1, params + o.w3, o.ldH, dh2, s.H, B, s.H, 1);
-    g.mask = h2; g.ldmask = s.H;
+    g = gemm(dq, 1, params + o.w3, o.ldH, dh2, HP, B, s.H, 1);
+    g.mask = h2; g.ldmask = HP;
     g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
     // dz1 = (dz2 W2) * relu'(h1)
-    g = gemm(dh2, s.H, params + o.W2, o.ldH, dh1, s.H, B, s.H, s.H);
-    g.mask = h1; g.ldmask = s.H;
+    g = gemm(dh2, HP, params + o.W2, o.ldH, dh1, HP, B, s.H, s.H);
+    g.mask = h1; g.ldmask = HP;
     g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
     if (dxa) {     // dxa = dz1 W1[:, O : O + A]
-      g = gemm(dh1, s.H, params + o.W1 + s.O, o.ld1, dxa, ldxa, B, s.A, s.H);
+      g = gemm(dh1, HP, params + o.W1 + s.O, o.ld1, dxa, ldxa, B, s.A, s.H);
       g.strideA = hs; g.strideB = o.count; g.strideC = (int64_t)Bp * ldxa;
       TRY(launch_gemm('c', 's', g, nets, st));
     }
@@ -500,13 +508,13 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     // ... then the three weight gradients (all contract over the batch) in ONE launch:
     //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
     GemmArgs w[3];
-    w[0] = gemm(dq, 1, h2, s.H, grads + o.w3, o.ldH, 1, s.H, B);
+    w[0] = gemm(dq, 1, h2, HP, grads + o.w3, o.ldH, 1, s.H, B);
     w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
     w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
-    w[1] = gemm(dh2, s.H, h1, s.H, grads + o.W2, o.ldH, s.H, s.H, B);
+    w[1] = gemm(dh2, HP, h1, HP, grads + o.W2, o.ldH, s.H, s.H, B);
     w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
     w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
-    w[2] = gemm(dh1, s.H, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
+    w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
     w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
     w[2].strideA = hs; w[2].strideC = o.count;
     TRY(launch_gemm_group('s', 's', w, 3, nets, st));
@@ -525,11 +533,11 @@ struct Workspace {
 };
 
 int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
-  const int64_t Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A);
+  const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
   // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
-  return 2 * Bp * H + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * H + 2 * Bp) +
-         Bp * ldx + 2 * Bp * ldh + 2 * Bp * H + 2 * Bp * ldh + 64 * 16 +
-         4 * Bp * H + Bp * ldx + 4 * Bp;                 // second input + four-network forward
+  return 2 * Bp * HP + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * HP + 2 * Bp) +
+         Bp * ldx + 2 * Bp * ldh + 2 * Bp * HP + 2 * Bp * ldh + 64 * 16 +
+         4 * Bp * HP + Bp * ldx + 4 * Bp;                 // second input + four-network forward
 }
 
 }  // namespace
@@ -562,9 +570,9 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_policy_forward: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldh = pad16(A);
+  const int Bp = pad16(B), ldh = pad16(A), HP = weight_ld(H);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
-  float* h1 = ws.take((int64_t)Bp * H); float* h2 = ws.take((int64_t)Bp * H);
+  float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
   TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st));
@@ -604,15 +612,15 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_twin_q_grad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A), threads = 256;
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = weight_ld(H);
   const CriticShape cs{O, A, H};
   const int64_t Pc = critic_count(cs);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
-  float* a_h1 = ws.take((int64_t)Bp * H); float* a_h2 = ws.take((int64_t)Bp * H);
+  float* a_h1 = ws.take((int64_t)Bp * HP); float* a_h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   float* next_act = ws.take((int64_t)Bp * A); float* logp = ws.take(Bp);
   const int nets = kind == 2 ? 1 : 2;
-  const int64_t hs = (int64_t)Bp * H;
+  const int64_t hs = (int64_t)Bp * HP;
   // target critics on (s', a') and online critics on (s, a) share ONE forward launch: inputs X /
   // X2, activations and values laid out [targets | online]
   float* X = ws.take((int64_t)Bp * ldx); float* X2 = ws.take((int64_t)Bp * ldx);
@@ -671,24 +679,24 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_actor_q_grad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldx = pad16(O + A), ldh = pad16(A), threads = 256;
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = weight_ld(H);
   const int nets = kind == 0 ? 1 : 2;
   const CriticShape cs{O, A, H};
   const ActorShape as{O, H, A, kind == 0 ? 1 : 2};
   const int64_t Pa = actor_count(as);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
-  float* a_h1 = ws.take((int64_t)Bp * H); float* a_h2 = ws.take((int64_t)Bp * H);
+  float* a_h1 = ws.take((int64_t)Bp * HP); float* a_h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   float* act = ws.take((int64_t)Bp * A); float* sigma = ws.take((int64_t)Bp * A);
   float* logp = ws.take(Bp);
   float* X = ws.take((int64_t)Bp * ldx);
-  float* c_h1 = ws.take(2LL * Bp * H); float* c_h2 = ws.take(2LL * Bp * H);
+  float* c_h1 = ws.take(2LL * Bp * HP); float* c_h2 = ws.take(2LL * Bp * HP);
   float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
-  float* dh2 = ws.take(2LL * Bp * H); float* dh1 = ws.take(2LL * Bp * H);
+  float* dh2 = ws.take(2LL * Bp * HP); float* dh1 = ws.take(2LL * Bp * HP);
   float* dX = ws.take((int64_t)Bp * ldx);      // (kept: workspace layout)
   float* dxa = ws.take(2LL * Bp * ldh);         // action columns of the critics' input gradients
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
-  float* da_h2 = ws.take((int64_t)Bp * H); float* da_h1 = ws.take((int64_t)Bp * H);
+  float* da_h2 = ws.take((int64_t)Bp * HP); float* da_h1 = ws.take((int64_t)Bp * HP);
 
   TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
                     kind == 0, st));
@@ -724,18 +732,18 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
     b.dhead[0] = dloc; b.dhead[1] = dspre;
     b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
     b.W2 = p.W2; b.W1 = p.W1; b.K1 = O; b.ldw1 = p.ld1; b.ldw2 = p.ldH; b.xa_first = 0; b.xa_count = 0;
-    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = nullptr;
+    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = nullptr; b.ldhid = HP;
     b.B = B; b.H = H;
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
       const float* dhead = h == 0 ? dloc : dspre;
-      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, H, B, H, A);
-      g.mask = a_h2; g.ldmask = H; g.accumulate = h > 0;
+      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, HP, B, H, A);
+      g.mask = a_h2; g.ldmask = HP; g.accumulate = h > 0;
       TRY(launch_gemm('c', 's', g, 1, st));
     }
-    g = gemm(da_h2, H, p.W2, p.ldH, da_h1, H, B, H, H);
-    g.mask = a_h1; g.ldmask = H;
+    g = gemm(da_h2, HP, p.W2, p.ldH, da_h1, HP, B, H, H);
+    g.mask = a_h1; g.ldmask = HP;
     TRY(launch_gemm('c', 's', g, 1, st));
   }
   // ... then all weight gradients (they contract over the batch) in ONE launch:
@@ -744,12 +752,12 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   int count = 0;
   for (int h = 0; h < as.heads; ++h) {
     const float* dhead = h == 0 ? dloc : dspre;
-    w[count] = gemm(dhead, ldh, a_h2, H, gp.head_w(h), gp.ldH, A, H, B);
+    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
     w[count++].colsum = gp.head_b(h);
   }
-  w[count] = gemm(da_h2, H, a_h1, H, gp.W2, gp.ldH, H, H, B);
+  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
   w[count++].colsum = gp.b2;
-  w[count] = gemm(da_h1, H, d_observations, O, gp.W1, gp.ld1, H, O, B);
+  w[count] = gemm(da_h1, HP, d_observations, O, gp.W1, gp.ld1, H, O, B);
   w[count++].colsum = gp.b1;
   TRY(launch_gemm_group('s', 's', w, count, 1, st));
   TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
