@@ -15,6 +15,11 @@
 //   NT  C[M,N] = A[M,K]  . B[N,K]^T   forward            (A k-contig, B k-contig)
 //   NN  C[M,N] = A[M,K]  . B[K,N]     backward to input  (A k-contig, B k-strided)
 //   TN  C[M,N] = A[K,M]^T. B[K,N]     weight gradient    (A k-strided, B k-strided)
+//
+// The weight gradients (TN without bias / mask / activation) have their own kernel
+// (gemm_tn_group_kernel): both operands are contiguous along the OUTPUT index there, so a lane
+// fetches two neighbouring output columns per load and a wave owns a 32 x 32 tile of 2 x 2
+// interleaved MFMA tiles, four waves splitting K.
 #pragma once
 #include "common.h"
 
