@@ -790,7 +790,8 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   // the head is a per-wave partial dot product folded by wave 0.
   const PackedActor L(KS1, AP);
   const float* P = c.packed;
-  const int lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
+  const int lane = tid & 63, s = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: uniform branches
   const int64_t ntiles = (W + 15) / 16;
   f32x4* X1 = reinterpret_cast<f32x4*>(tile);                  // [4 tiles][64 lanes] h1 values
   float* ZP = tile + 1024;                                     // [4 waves][AP][16 samples]
@@ -805,9 +806,11 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
       const int k = 4 * st + g;
       xr[st] = c.obs[nc * O + (k < O ? k : O - 1)];
     }
+    // (noise and head constants are wave 0's alone: every load instruction costs the CU's
+    //  memory pipe 5 - 10 ns, and the four waves share it)
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa)
-      ep[aa] = c.eps != nullptr ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
+      ep[aa] = (wave == 0 && c.eps != nullptr) ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
     // this tile's weight operands, all requested up front
     const f32x4 bias1 = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16)[wave];
     const f32x4 bias2 = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16)[wave];
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       w3[aa] = reinterpret_cast<const f32x4*>(P + L.W3P)[(aa * 4 + g) * 4 + wave];
-      hcA[aa] = *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8);
+      hcA[aa] = wave == 0 ? *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     {  // the tile's 16 observation rows -> Segment row (contiguous, coalesced)
       const int64_t first = t * 16 * O, count = min<int64_t>(16, W - t * 16) * O;
