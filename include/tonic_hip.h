@@ -252,6 +252,17 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
  */
 int tonic_polyak_update(float* d_target, const float* d_online, int64_t n, double coeff,
                         void* stream);
+/* replaces: the optimizer step of the actor followed by update_targets() (ddpg.py:105-112,
+ *   td3.py:43-46, sac via ddpg.py) in ONE launch: Adam (as tonic_adam_step, stats_kind 0 / 4, no
+ *   skip flag) on the block [block_offset, block_offset + param_count) of the online buffer, then
+ *   the polyak update of ALL total_count target entries — each thread updates the target of the
+ *   entry it just stepped, extra workgroups cover the entries outside the block (whose online
+ *   values are final: their optimizer ran in an earlier launch).  Same roundings as the two calls. */
+int tonic_adam_polyak_step(float* d_online, const float* d_grad_sums, float* d_exp_avg,
+                           float* d_exp_avg_sq, int32_t* d_state, int64_t block_offset,
+                           int64_t param_count, int64_t total_count, double grad_scale, double lr,
+                           double beta1, double beta2, double eps, int32_t stats_kind,
+                           float* d_info_row, float* d_target, double coeff, void* stream);
 
 /* ======================= off-policy path: SAC / TD3 (2 hidden ReLU layers of width H) =========
  * Flat parameter blocks (reference `parameters()` order):

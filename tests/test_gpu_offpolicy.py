@@ -248,3 +248,37 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     for key, value in oracle.state().items():
         got = after[key].detach().cpu().numpy() - state['pre/' + key]
         np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)
+
+
+def test_adam_polyak_step_equals_the_two_calls(lib):
+    """tonic_adam_polyak_step == tonic_adam_step on the block followed by tonic_polyak_update of
+    the whole target buffer, bit for bit (block at the start, in the middle, at the end)."""
+    from tonic_amd import _lib
+    p = _lib.ptr
+    total, coeff = 70_000, 0.005
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for offset, n in ((0, 20_003), (12_345, 33_333), (50_000, 20_000)):
+        online = torch.randn(total, device='cuda', generator=gen)
+        target = torch.randn(total, device='cuda', generator=gen)
+        grads = torch.randn(n + 8, device='cuda', generator=gen)
+        results = []
+        for fused in (False, True):
+            on, tg = online.clone(), target.clone()
+            m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+            state = torch.zeros(4, dtype=torch.int32, device='cuda')
+            info = torch.zeros(8, device='cuda')
+            for _ in range(3):
+                if fused:
+                    _lib.check(lib.tonic_adam_polyak_step(
+                        p(on), p(grads), p(m), p(v), p(state), offset, n, total, 1 / 64, 3e-4, 0.9,
+                        0.999, 1e-8, 4, p(info), p(tg), coeff, None), 'fused')
+                else:
+                    block = on[offset:offset + n]
+                    _lib.check(lib.tonic_adam_step(
+                        p(block), p(grads), p(m), p(v), p(state), n, 1 / 64, 3e-4, 0.9, 0.999, 1e-8,
+                        4, 0.0, 0.0, None, p(info), None, None), 'adam')
+                    _lib.check(lib.tonic_polyak_update(p(tg), p(on), total, coeff, None), 'polyak')
+            torch.cuda.synchronize()
+            results.append((on.cpu(), tg.cpu(), m.cpu(), v.cpu(), state.cpu(), info.cpu()))
+        for a, b in zip(*results):
+            assert torch.equal(a, b)

@@ -43,6 +43,8 @@ SIGNATURES = {
     'tonic_ppo_collect_steps_packed': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i64, c_i32, c_i32,
                                                                     c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
+    'tonic_adam_polyak_step': (ctypes.c_int, [c_vp] * 5 + [c_i64] * 3 + [c_f64] * 5 + [c_i32, c_vp, c_vp,
+                                                                               c_f64, c_vp]),
     'tonic_buffer_accumulate_n_steps': (ctypes.c_int, [c_vp] * 7 + [c_i64] * 4 + [c_i32, c_i32, c_f64,
                                                                       c_vp]),
     'tonic_offpolicy_workspace_bytes': (c_i64, [c_i32] * 4),

@@ -25,9 +25,33 @@ struct AdamArgs {
   const float* adv_stats;
   float* info_row;
   const int32_t* skip;
+  // optional target-network update in the same launch (tonic_adam_polyak_step): `params` is the
+  // block [polyak_offset, polyak_offset + n) of the online buffer `polyak_online`
+  float* polyak_target;
+  const float* polyak_online;
+  int64_t polyak_total, polyak_offset;
+  float polyak_keep, polyak_mix;
+  int adam_blocks;
 };
 
+// t = t*(1-c) + c*o with three roundings (actor_critics.py:126-130); used by SAC / TD3 / DDPG.
+__device__ __forceinline__ float polyak(float target, float online, float keep, float mix) {
+  const float scaled = target * keep;
+  const float add = mix * online;
+  return scaled + add;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  if (a.polyak_target != nullptr && (int)blockIdx.x >= a.adam_blocks) {
+    // the target entries OUTSIDE this optimizer block: their online values are final already
+    const int64_t first = (int64_t)((int)blockIdx.x - a.adam_blocks) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)((int)gridDim.x - a.adam_blocks) * blockDim.x;
+    for (int64_t i = first; i < a.polyak_total; i += stride) {
+      if (i >= a.polyak_offset && i < a.polyak_offset + a.n) continue;
+      a.polyak_target[i] = polyak(a.polyak_target[i], a.polyak_online[i], a.polyak_keep, a.polyak_mix);
+    }
+    return;
+  }
   if (a.skip != nullptr && *a.skip != 0) return;
   if (a.stats_kind == 1 && a.adv_stats != nullptr && a.adv_stats[2] != 0.f) return;  // actors.py:71
   const int step = a.state[0] + 1;
@@ -36,16 +60,21 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   const float step_size = (float)(a.lr_d / bias1);                 // adam.py:533
   const float bias2_sqrt = (float)sqrt(bias2);                     // adam.py:535
   const float w1 = (float)(1.0 - a.beta1_d), w2 = (float)(1.0 - a.beta2_d);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t grid = a.polyak_target != nullptr ? a.adam_blocks : (int64_t)gridDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += grid * blockDim.x) {
     const float g = a.grad_sums[i] * a.grad_scale;
     float m = a.exp_avg[i], v = a.exp_avg_sq[i];
     m = m + w1 * (g - m);                                          // lerp_, adam.py:457
     v = v * a.beta2 + w2 * (g * g);                                // mul_().addcmul_(), :476
     const float denom = sqrtf(v) / bias2_sqrt + a.eps;             // :545
-    a.params[i] = a.params[i] - step_size * (m / denom);           // addcdiv_, :547
+    const float p = a.params[i] - step_size * (m / denom);         // addcdiv_, :547
+    a.params[i] = p;
     a.exp_avg[i] = m;
     a.exp_avg_sq[i] = v;
+    if (a.polyak_target != nullptr) {                               // this entry's target, same thread
+      float* t = a.polyak_target + a.polyak_offset + i;
+      *t = polyak(*t, p, a.polyak_keep, a.polyak_mix);
+    }
   }
 }
 
@@ -87,34 +116,31 @@ __global__ void adam_finalize_kernel(AdamArgs a) {
   }
 }
 
-// t = t*(1-c) + c*o with three roundings (actor_critics.py:126-130); used by SAC/TD3.
 __global__ __launch_bounds__(256) void polyak_kernel(float* target, const float* online,
                                                      int64_t n, float keep, float mix) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float scaled = target[i] * keep;
-    const float add = mix * online[i];
-    target[i] = scaled + add;
-  }
+       i += (int64_t)gridDim.x * blockDim.x)
+    target[i] = polyak(target[i], online[i], keep, mix);
 }
 
 }  // namespace tonic
 
 using namespace tonic;
 
-extern "C" int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
-                               float* d_exp_avg_sq, int32_t* d_state, int64_t param_count,
-                               double grad_scale, double lr, double beta1, double beta2,
-                               double eps, int32_t stats_kind, double kl_threshold,
-                               double entropy_coeff,
-                               const float* d_adv_stats, float* d_info_row,
-                               const int32_t* d_skip_flag, void* stream) {
+namespace {
+
+int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, float* d_exp_avg_sq,
+                int32_t* d_state, int64_t param_count, double grad_scale, double lr, double beta1,
+                double beta2, double eps, int32_t stats_kind, double kl_threshold,
+                double entropy_coeff, const float* d_adv_stats, float* d_info_row,
+                const int32_t* d_skip_flag, float* d_target, const float* d_online,
+                int64_t total, int64_t offset, double coeff, void* stream, const char* what) {
   TONIC_REQUIRE(d_params && d_grad_sums && d_exp_avg && d_exp_avg_sq && d_state &&
                     param_count > 0,
-                TONIC_ERR_INVALID_ARGUMENT, "tonic_adam_step: bad argument");
+                TONIC_ERR_INVALID_ARGUMENT, "%s: bad argument", what);
   TONIC_REQUIRE(stats_kind >= 0 && stats_kind <= 4, TONIC_ERR_INVALID_ARGUMENT,
-                "tonic_adam_step: stats_kind %d", stats_kind);
-  AdamArgs a;
+                "%s: stats_kind %d", what, stats_kind);
+  AdamArgs a{};
   a.params = d_params; a.grad_sums = d_grad_sums; a.exp_avg = d_exp_avg;
   a.exp_avg_sq = d_exp_avg_sq; a.state = d_state; a.n = param_count;
   // Hyper-parameters are Python floats in the reference: bias corrections and step size are
@@ -127,11 +153,50 @@ extern "C" int tonic_adam_step(float* d_params, const float* d_grad_sums, float*
   a.adv_stats = d_adv_stats; a.info_row = d_info_row; a.skip = d_skip_flag;
   int64_t blocks = (param_count + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  int64_t extra = 0;
+  if (d_target != nullptr) {
+    a.polyak_target = d_target; a.polyak_online = d_online; a.polyak_total = total;
+    a.polyak_offset = offset; a.polyak_keep = (float)(1.0 - coeff); a.polyak_mix = (float)coeff;
+    a.adam_blocks = (int)blocks;
+    extra = (total - param_count + 255) / 256;
+    if (extra > 2048) extra = 2048;
+  }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(64), 0, st, a);
-  TONIC_CHECK_LAUNCH("tonic_adam_step");
+  TONIC_CHECK_LAUNCH(what);
   return TONIC_OK;
+}
+
+}  // namespace
+
+extern "C" int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
+                               float* d_exp_avg_sq, int32_t* d_state, int64_t param_count,
+                               double grad_scale, double lr, double beta1, double beta2,
+                               double eps, int32_t stats_kind, double kl_threshold,
+                               double entropy_coeff,
+                               const float* d_adv_stats, float* d_info_row,
+                               const int32_t* d_skip_flag, void* stream) {
+  return adam_launch(d_params, d_grad_sums, d_exp_avg, d_exp_avg_sq, d_state, param_count,
+                     grad_scale, lr, beta1, beta2, eps, stats_kind, kl_threshold, entropy_coeff,
+                     d_adv_stats, d_info_row, d_skip_flag, nullptr, nullptr, 0, 0, 0.0, stream,
+                     "tonic_adam_step");
+}
+
+extern "C" int tonic_adam_polyak_step(float* d_online, const float* d_grad_sums, float* d_exp_avg,
+                                      float* d_exp_avg_sq, int32_t* d_state, int64_t block_offset,
+                                      int64_t param_count, int64_t total_count, double grad_scale,
+                                      double lr, double beta1, double beta2, double eps,
+                                      int32_t stats_kind, float* d_info_row, float* d_target,
+                                      double coeff, void* stream) {
+  TONIC_REQUIRE(d_online && d_target && block_offset >= 0 && param_count > 0 &&
+                    block_offset + param_count <= total_count,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_adam_polyak_step: block [%lld, +%lld) of %lld",
+                (long long)block_offset, (long long)param_count, (long long)total_count);
+  return adam_launch(d_online + block_offset, d_grad_sums, d_exp_avg, d_exp_avg_sq, d_state,
+                     param_count, grad_scale, lr, beta1, beta2, eps, stats_kind, 0.0, 0.0, nullptr,
+                     d_info_row, nullptr, d_target, d_online, total_count, block_offset, coeff,
+                     stream, "tonic_adam_polyak_step");
 }
 
 extern "C" int tonic_polyak_update(float* d_target, const float* d_online, int64_t n,

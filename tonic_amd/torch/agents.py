@@ -434,12 +434,14 @@ class DDPG(Agent):
                     self.critic_updater.enqueue_empty(self._infos[0, it], n_global)
                 if self._actor_due(it):
                     actor_eps = self._static_eps[it, 1, :c] if draws > 1 else None
+                    # update_targets() (ddpg.py:112) rides in the actor's optimizer launch
+                    targets = (self.model.flat_target, self.model.flat_online, 0,
+                               self.model.target_coeff)
                     if c > 0:
                         self.actor_updater.enqueue(batch['observations'], actor_eps,
-                                                   self._infos[1, it], n_global)
+                                                   self._infos[1, it], n_global, targets)
                     else:
-                        self.actor_updater.enqueue_empty(self._infos[1, it], n_global)
-                    self.model.update_targets()
+                        self.actor_updater.enqueue_empty(self._infos[1, it], n_global, targets)
 
         if not graph or world > 1:
             enqueue()

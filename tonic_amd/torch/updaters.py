@@ -67,10 +67,24 @@ class _FlatUpdater:
         self.grad_sums = buffer
 
     def _step(self, n_global, info_row, adv_stats=None, skip=None, kl_threshold=0.0,
-              entropy_coeff=0.0, allreduce=True):
+              entropy_coeff=0.0, allreduce=True, targets=None):
+        """All-reduce of the gradient sums (world > 1) + Adam + statistics.  `targets` =
+        (flat target buffer, flat online buffer, offset of this block in them, coeff): the
+        polyak update of ALL targets rides in the same launch (update_targets right after the
+        step, as ddpg.py:105-112 orders them)."""
         if self.world_size > 1 and allreduce:
             torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
         h = self.hyper
+        if targets is not None:
+            target, online, offset, coeff = targets
+            assert online.data_ptr() + 4 * offset == self.flat.flat.data_ptr()
+            _lib.check(self.lib.tonic_adam_polyak_step(
+                _lib.ptr(online), _lib.ptr(self.grad_sums), _lib.ptr(self.exp_avg),
+                _lib.ptr(self.exp_avg_sq), _lib.ptr(self.state), offset, self.count,
+                online.numel(), 1.0 / n_global, h['lr'], h['betas'][0], h['betas'][1], h['eps'],
+                self.stats_kind, _lib.ptr(info_row), _lib.ptr(target), float(coeff),
+                _lib.current_stream()), 'tonic_adam_polyak_step')
+            return
         _lib.check(self.lib.tonic_adam_step(
             _lib.ptr(self.flat.flat), _lib.ptr(self.grad_sums), _lib.ptr(self.exp_avg),
             _lib.ptr(self.exp_avg_sq), _lib.ptr(self.state), self.count, 1.0 / n_global,
@@ -260,10 +274,10 @@ class _QUpdater(_FlatUpdater):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
         return self.workspace
 
-    def enqueue_empty(self, info_row, n_global):
+    def enqueue_empty(self, info_row, n_global, targets=None):
         """This rank drew none of the global batch: contribute zero sums, take the same step."""
         self.grad_sums.zero_()
-        self._step(n_global, info_row)
+        self._step(n_global, info_row, targets=targets)
 
     def _info(self, fn, keys):
         self.scratch_info.zero_()
@@ -371,7 +385,7 @@ class _ActorQGradient(_QUpdater):
         self._setup(model.flat_actor, adam_hyperparameters(self.optimizer, self.default_lr))
         self.variables = model.flat_actor.params
 
-    def enqueue(self, observations, eps, info_row, n_global=None):
+    def enqueue(self, observations, eps, info_row, n_global=None, targets=None):
         B = observations.shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -381,7 +395,7 @@ class _ActorQGradient(_QUpdater):
             p(observations), p(eps), p(self.grad_sums), B, self.observation_size, self.hidden,
             self.action_size, float(getattr(self, 'entropy_coeff', 0.0)), p(ws), ws.numel(),
             _lib.current_stream()), 'tonic_actor_q_grad')
-        self._step(n_global or B * self.world_size, info_row)
+        self._step(n_global or B * self.world_size, info_row, targets=targets)
 
     def __call__(self, observations):
         eps = None
