@@ -53,7 +53,9 @@ const char* tonic_target_arch(void);
  *   "grad_waves" = 4       waves per workgroup of the 32x32x2-tile fused grad kernel;
  *   "grad_variant" = 0 | 1 fused grad kernel: 0 = 32x32x2 tiles, 1 wave/SIMD; 1 = 16x16x4
  *                          tiles, 2 waves/SIMD (default);
- *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0). */
+ *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0);
+ *   "policy_tail" = 0 | 1  off-policy actors: sampling / target noise / dense copy in the tail of
+ *                          the forward launch (1, default) or in their own launches (0); same bits. */
 int tonic_set_tuning(const char* key, int32_t value);
 
 /* Sizes of the flat parameter blocks described above. */

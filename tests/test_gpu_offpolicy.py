@@ -282,3 +282,53 @@ def test_adam_polyak_step_equals_the_two_calls(lib):
             results.append((on.cpu(), tg.cpu(), m.cpu(), v.cpu(), state.cpu(), info.cpu()))
         for a, b in zip(*results):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind,o_dim,a_dim', [('sac', 111, 8), ('sac', 11, 3), ('td3', 67, 21),
+                                              ('ddpg', 17, 6), ('sac', 9, 40)])
+def test_policy_tail_in_the_forward_launch_is_bit_identical(lib, kind, o_dim, a_dim):
+    """Sampling / target noise / dense copy folded into the actor's forward launch (tuning key
+    policy_tail = 1, the default) against their own launches (0): same parameters, bit for bit,
+    after whole learner iterations; same actions from tonic_policy_forward."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd import _lib
+    from tonic_amd.environments import Box
+    iters, rows, B = 3, 512, 96
+    results, actions = [], []
+    try:
+        for tail in (1, 0):
+            _lib.check(lib.tonic_set_tuning(b'policy_tail', tail), 'tuning')
+            torch.manual_seed(0)
+            np.random.seed(0)
+            replay = tonic_amd.replays.Buffer(size=rows, batch_iterations=iters, batch_size=B)
+            agent = {'sac': tt.agents.SAC, 'td3': tt.agents.TD3, 'ddpg': tt.agents.DDPG}[kind](
+                replay=replay)
+            agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=0)
+            replay._allocate(1, o_dim, a_dim)
+            gen = torch.Generator(device='cuda').manual_seed(1)
+            for k, b in replay.buffers.items():
+                b.copy_(torch.randn(b.shape, device='cuda', generator=gen) *
+                        (0.0 if k in ('resets', 'terminations') else 1.0))
+            replay.buffers['discounts'].fill_(0.99)
+            replay.size = rows
+            agent.enqueue_update(replay.sample_indices(), agent._draw_noise(iters), graph=False)
+            torch.cuda.synchronize()
+            results.append({k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()})
+            obs = torch.randn(33, o_dim, device='cuda', generator=gen)
+            out = torch.zeros(33, a_dim, device='cuda')
+            eps = torch.randn(33, a_dim, device='cuda', generator=gen)
+            ws = torch.empty(lib.tonic_offpolicy_workspace_bytes(33, o_dim, a_dim, 256),
+                             dtype=torch.uint8, device='cuda')
+            for with_eps in (True, False):
+                _lib.check(lib.tonic_policy_forward(
+                    _lib.ptr(agent.model.flat_actor.flat), _lib.ptr(obs),
+                    _lib.ptr(eps) if with_eps else None, _lib.ptr(out), 1 if kind == 'sac' else 0,
+                    33, o_dim, 256, a_dim, _lib.ptr(ws), ws.numel(), None), 'policy')
+                actions.append(out.cpu().clone())
+    finally:
+        _lib.check(lib.tonic_set_tuning(b'policy_tail', 1), 'tuning')
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
+    assert torch.equal(actions[0], actions[2]) and torch.equal(actions[1], actions[3])
+    assert all(torch.isfinite(v).all() for v in results[0].values())

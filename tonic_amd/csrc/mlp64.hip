@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "mlp64.h"
+#include "mlpfwd.h"
 
 namespace tonic {
 
@@ -853,6 +854,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_variant must be 0 or 1, got %d", value);
     g_grad_variant = value;
+    return TONIC_OK;
+  }
+  if (strcmp(key, "policy_tail") == 0) {
+    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
+                  "policy_tail must be 0 or 1, got %d", value);
+    g_policy_tail = value;
     return TONIC_OK;
   }
   set_error("tonic_set_tuning: unknown key '%s'", key);

@@ -18,6 +18,44 @@ __host__ __device__ inline int weight_ld(int cols) {
 }
 __host__ __device__ inline int64_t slot4(int64_t floats) { return (floats + 3) / 4 * 4; }
 
+// ---- what follows a policy's heads (shared by the stand-alone kernels of offpolicy.hip and the
+//      tail of mlp_forward_kernel, so that both give the same bits)
+constexpr float kSacLogEps = 1e-6f;            // actors.py:15
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// One action of SquashedMultivariateNormalDiag.rsample_with_log_prob (actors.py:11-16,94-98):
+// sigma = clamp(softplus(spre), 1e-4, 1), u = loc + eps * sigma, a = tanh(u),
+// term = N(u; loc, sigma).log_prob - log(1 - a^2 + 1e-6).
+struct SquashedSample { float action, sigma, logp_term; };
+__device__ __forceinline__ SquashedSample squashed_sample(float loc, float spre, float eps,
+                                                          bool has_eps) {
+  SquashedSample r;
+  const float raw = softplus_f(spre);
+  r.sigma = fminf(fmaxf(raw, 1e-4f), 1.0f);
+  const float u = has_eps ? loc + eps * r.sigma : loc;             // rsample: loc + eps * scale
+  r.action = tanhf(u);
+  const float d = u - loc;
+  const float normal = -(d * d) / (2.f * (r.sigma * r.sigma)) - logf(r.sigma) - kHalfLog2Pi;
+  r.logp_term = normal - logf(1.f - r.action * r.action + kSacLogEps);
+  return r;
+}
+
+// TD3 target action: clamp(a + clamp(scale * eps, -clip, clip), -1, 1)  (critics.py:130-134)
+__device__ __forceinline__ float noisy_target_action(float action, float eps, float scale,
+                                                     float clip) {
+  float noise = scale * eps;
+  noise = fminf(fmaxf(noise, -clip), clip);
+  return fminf(fmaxf(action + noise, -1.f), 1.f);
+}
+
+// lanes that share one sample in sac_sample_kernel: the log-probability terms are folded by a
+// xor tree over them, which the fused tail re-plays in the same order
+__host__ __device__ inline int sample_group(int A) { int g = 1; while (g < A && g < 32) g *= 2; return g; }
+
+enum PolicyPost : int { POST_NONE = 0, POST_SQUASHED_SAMPLE = 1, POST_TARGET_NOISE = 2, POST_COPY = 3 };
+
 struct MlpFwdArgs {
   const float* X;            // [B, ldx] inputs, K1 columns used
   int ldx, K1;
@@ -40,6 +78,16 @@ struct MlpFwdArgs {
   int split;
   int64_t second_params;
   const float* X2;
+  // post != POST_NONE (single network, NH <= 64): what follows the heads runs in the same launch.
+  //   POST_SQUASHED_SAMPLE (heads = 2): actions / sigma [B, NH] dense, log-probabilities [B]
+  //   POST_TARGET_NOISE    (heads = 1, tanh head): actions = noisy_target_action(head, eps)
+  //   POST_COPY            (heads = 1): dense actions out of the padded head buffer
+  int post;
+  const float* post_eps;     // [B, NH] standard-normal draws (SAMPLE: may be null = greedy)
+  float* post_actions;       // [B, NH]
+  float* post_sigma;         // [B, NH] or null
+  float* post_logp;          // [B] or null
+  float noise_scale, noise_clip;
 };
 
 // Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).
@@ -64,6 +112,8 @@ struct MlpBwdArgs {
 };
 
 bool mlp_forward_supported(int H, int NH, int heads);
+bool mlp_policy_tail_supported(int H, int NH);
+extern int g_policy_tail;      // tuning key "policy_tail": 0 keeps sampling / noise / copy in their own launches
 bool mlp_backward_supported(int H, int NH, int heads, int xa_count);
 int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream);
 int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream);

@@ -43,6 +43,7 @@ __device__ __forceinline__ f32x4 load_k4_tail(const float* row, int k, int K) {
 }
 
 constexpr int kRows = 16;          // batch rows per workgroup
+constexpr int kPostPitch = 64;     // head outputs per row in the policy tail (NH <= 64)
 constexpr int kMaxTiles = 4;       // 16-feature tiles per wave: H <= 256
 
 // One layer for the TILES 16-feature tiles a wave owns (rows wrow[j] of W), contraction over K.
@@ -294,18 +295,62 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
     lh.run(kg, out, from_hy, from_hy);
     float* out_base = head == 0 ? a.out[0] : a.out[1];
     const int act = head == 0 ? a.act[0] : a.act[1];
-    if (row_ok) {
-      float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
+    float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int o = 16 * head_tile + 4 * kg + e;
-        if (o < a.NH) {
-          float v = out[0][e] + hbias[e];
-          if (act == ACT_TANH) v = tanhf(v);
-          dst[o] = v;
-        }
+    for (int e = 0; e < 4; ++e) {
+      const int o = 16 * head_tile + 4 * kg + e;
+      if (o < a.NH) {
+        float v = out[0][e] + hbias[e];
+        if (act == ACT_TANH) v = tanhf(v);
+        if (row_ok) dst[o] = v;
+        if (a.post != POST_NONE) lds[(head * kRows + m) * kPostPitch + o] = v;   // hx is free now
       }
     }
+  }
+  if (a.post == POST_NONE) return;                    // scalar
+
+  // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
+  __syncthreads();
+  const float* headbuf = lds;                         // [2 heads][16 rows][kPostPitch]
+  float* terms = lds + 2 * kRows * kPostPitch;        // [16 rows][kPostPitch] log-prob terms
+  const int prow = tid >> 4, slot = tid & 15, A = a.NH;
+  const int64_t grow = r0 + prow;
+  const bool ok = grow < a.B;
+  const int padded = (A + 15) / 16 * 16;
+  for (int aa = slot; aa < padded; aa += 16) {
+    float term = 0.f;
+    if (aa < A) {
+      const float first = headbuf[prow * kPostPitch + aa];
+      if (a.post == POST_SQUASHED_SAMPLE) {
+        const bool has_eps = a.post_eps != nullptr;
+        const float eps = (has_eps && ok) ? a.post_eps[grow * A + aa] : 0.f;
+        const SquashedSample sm =
+            squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
+        term = sm.logp_term;
+        if (ok) {
+          a.post_actions[grow * A + aa] = sm.action;
+          if (a.post_sigma != nullptr) a.post_sigma[grow * A + aa] = sm.sigma;
+        }
+      } else if (ok) {
+        a.post_actions[grow * A + aa] =
+            a.post == POST_TARGET_NOISE
+                ? noisy_target_action(first, a.post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
+                : first;
+      }
+    }
+    terms[prow * kPostPitch + aa] = term;
+  }
+  if (a.post != POST_SQUASHED_SAMPLE || a.post_logp == nullptr) return;
+  __syncthreads();
+  if (tid < kRows && r0 + tid < a.B) {
+    // the fold of sac_sample_kernel, re-played: G lanes, lane j summing terms j, j + G, ...
+    // in turn, then a xor tree (lane j adds lane j ^ off)
+    float* v = terms + tid * kPostPitch;
+    const int G = sample_group(A);
+    for (int aa = G; aa < A; ++aa) v[aa % G] += v[aa];
+    for (int off = G >> 1; off >= 1; off >>= 1)
+      for (int j = 0; j < off; ++j) v[j] += v[j + off];
+    a.post_logp[r0 + tid] = v[0];
   }
 }
 
@@ -428,6 +473,13 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 
 }  // namespace
 
+int g_policy_tail = 1;
+
+// the tail's three [16][kPostPitch] images live in the first hidden image (the second is being read)
+bool mlp_policy_tail_supported(int H, int NH) {
+  return NH <= kPostPitch && 3 * kRows * kPostPitch <= kRows * (H + 4);
+}
+
 bool mlp_forward_supported(int H, int NH, int heads) {
   return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && NH >= 1 && heads >= 1 && heads <= 2 &&
          heads * ((NH + 15) / 16) <= 4;
@@ -440,6 +492,13 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(a.ldw1 >= a.K1 && a.ldw1 % 4 == 0 && a.ldw2 >= a.H && a.ldw2 % 4 == 0 &&
                     a.ldh >= a.H && a.ldh % 4 == 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: strides %d / %d / %d", a.ldw1, a.ldw2, a.ldh);
+  TONIC_REQUIRE(a.post == POST_NONE ||
+                    (nets == 1 && a.NH <= kPostPitch && a.post_actions != nullptr &&
+                     mlp_policy_tail_supported(a.H, a.NH) &&
+                     (a.post == POST_SQUASHED_SAMPLE ? a.heads == 2
+                                                     : a.heads == 1 && (a.post == POST_COPY || a.post_eps))),
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: policy tail %d with heads=%d NH=%d H=%d",
+                a.post, a.heads, a.NH, a.H);
   TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
   const size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);

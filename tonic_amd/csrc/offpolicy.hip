@@ -21,11 +21,6 @@
 
 namespace tonic {
 
-constexpr float kSacLogEps = 1e-6f;            // actors.py:15
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
-
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
 struct ActorShape { int O, H, A, heads; };      // heads: 1 = deterministic (TD3), 2 = loc+scale (SAC)
 struct CriticShape { int O, A, H; };
 
@@ -70,22 +65,15 @@ __global__ void sac_sample_kernel(const float* loc, const float* spre, const flo
   float lp = 0.f;
   for (int a = lane_a; a < A; a += G) {
     if (!sample_ok) break;
-    const float raw = softplus_f(spre[(int64_t)m * ld + a]);
-    const float sigma = fminf(fmaxf(raw, 1e-4f), 1.0f);
-    const float l = loc[(int64_t)m * ld + a];
-    const float u = eps ? l + eps[(int64_t)m * A + a] * sigma : l;   // rsample: loc + eps * scale
-    const float t = tanhf(u);
-    const float d = u - l;
-    const float normal = -(d * d) / (2.f * (sigma * sigma)) - logf(sigma) - kHalfLog2Pi;
-    lp += normal - logf(1.f - t * t + kSacLogEps);
-    act[(int64_t)m * A + a] = t;
-    if (sigma_out) sigma_out[(int64_t)m * A + a] = sigma;
+    const SquashedSample sm = squashed_sample(loc[(int64_t)m * ld + a], spre[(int64_t)m * ld + a],
+                                              eps ? eps[(int64_t)m * A + a] : 0.f, eps != nullptr);
+    lp += sm.logp_term;
+    act[(int64_t)m * A + a] = sm.action;
+    if (sigma_out) sigma_out[(int64_t)m * A + a] = sm.sigma;
   }
   for (int off = G >> 1; off >= 1; off >>= 1) lp += __shfl_xor(lp, off, 64);
   if (logp && sample_ok && lane_a == 0) logp[m] = lp;
 }
-
-inline int sample_group(int A) { int g = 1; while (g < A && g < 32) g *= 2; return g; }
 
 // TD3 target actions: clamp(a + clamp(scale * eps, -clip, clip), -1, 1)  (critics.py:130-134)
 __global__ void td3_target_action_kernel(const float* loc, int ld, const float* eps, float* act,
@@ -93,9 +81,7 @@ __global__ void td3_target_action_kernel(const float* loc, int ld, const float* 
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * A) return;
   const int m = idx / A, a = idx - m * A;
-  float noise = scale * eps[idx];
-  noise = fminf(fmaxf(noise, -clip), clip);
-  act[idx] = fminf(fmaxf(loc[(int64_t)m * ld + a] + noise, -1.f), 1.f);
+  act[idx] = noisy_target_action(loc[(int64_t)m * ld + a], eps[idx], scale, clip);
 }
 
 // dense actions out of a padded head buffer (deterministic policy: tanh already applied)
@@ -380,10 +366,20 @@ GemmArgs gemm(const float* A, int lda, const float* B, int ldb, float* C, int ld
   } while (0)
 
 // actor torso + heads: h1, h2 [Bp, H]; head h -> out_h [Bp, ldh] (pre-activation unless `tanh_head`)
+// What follows the heads (sampling / target noise / dense copy); folded into the forward launch
+// when the fused kernel can (then *tail_done = true), else the caller launches its own kernel.
+struct PolicyTail {
+  int post;                    // PolicyPost
+  const float* eps;
+  float* actions; float* sigma; float* logp;
+  float noise_scale, noise_clip;
+};
+
 int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
-                  hipStream_t st) {
+                  hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr) {
   ActorParams p(params, s);
+  if (tail_done != nullptr) *tail_done = false;
   const int HP = weight_ld(s.H);
   if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
     MlpFwdArgs f{};
@@ -396,6 +392,12 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
     f.act[0] = tanh_head ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
     f.B = B; f.H = s.H; f.split = 1 << 30;
+    if (tail != nullptr && g_policy_tail != 0 && mlp_policy_tail_supported(s.H, s.A)) {
+      f.post = tail->post; f.post_eps = tail->eps; f.post_actions = tail->actions;
+      f.post_sigma = tail->sigma; f.post_logp = tail->logp;
+      f.noise_scale = tail->noise_scale; f.noise_clip = tail->noise_clip;
+      if (tail_done != nullptr) *tail_done = true;
+    }
     return launch_mlp_forward(f, 1, st);
   }
   GemmArgs g = gemm(obs, s.O, p.W1, p.ld1, h1, HP, B, s.H, s.O);
@@ -575,9 +577,14 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
-  TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st));
+  const PolicyTail tail{kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE, d_eps, d_actions, nullptr,
+                        nullptr, 0.f, 0.f};
+  bool tail_done = false;
+  TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st,
+                    &tail, &tail_done));
   const int threads = 256;
-  if (kind == 0) {
+  if (tail_done) {
+  } else if (kind == 0) {
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
                        0, st, head0, ldh, d_actions, B, A);
   } else {
@@ -633,9 +640,14 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
 
   // ---- targets (no grad)
   const ActorShape as{O, H, A, kind == 1 ? 2 : 1};
+  const PolicyTail tail{kind == 0 ? POST_TARGET_NOISE : kind == 2 ? POST_COPY : POST_SQUASHED_SAMPLE,
+                        d_eps, next_act, nullptr, kind == 1 ? logp : nullptr, (float)noise_scale,
+                        (float)noise_clip};
+  bool tail_done = false;
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
-                    kind != 1, st));
-  if (kind == 0) {
+                    kind != 1, st, &tail, &tail_done));
+  if (tail_done) {
+  } else if (kind == 0) {
     hipLaunchKernelGGL(td3_target_action_kernel, dim3((B * A + threads - 1) / threads),
                        dim3(threads), 0, st, head0, ldh, d_eps, next_act, B, A,
                        (float)noise_scale, (float)noise_clip);
@@ -698,9 +710,13 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take((int64_t)Bp * HP); float* da_h1 = ws.take((int64_t)Bp * HP);
 
+  const PolicyTail tail{kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE, d_eps, act,
+                        kind == 0 ? nullptr : sigma, kind == 0 ? nullptr : logp, 0.f, 0.f};
+  bool tail_done = false;
   TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
-                    kind == 0, st));
-  if (kind == 0) {
+                    kind == 0, st, &tail, &tail_done));
+  if (tail_done) {
+  } else if (kind == 0) {
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
                        0, st, head0, ldh, act, B, A);
   } else {
