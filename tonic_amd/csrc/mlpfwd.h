@@ -88,6 +88,14 @@ struct MlpFwdArgs {
   float* post_sigma;         // [B, NH] or null
   float* post_logp;          // [B] or null
   float noise_scale, noise_clip;
+  // enc_out != null: the tail also writes the critics' input rows (ObservationActionEncoder,
+  // encoders.py:28-31)  enc_out[row] = [ (enc_obs[row] - mean) / std , post_actions[row] ],
+  // rows enc_ld apart, and — enc_out2 != null — a second pair built from stored actions,
+  // enc_out2[row] = [ (enc_obs2[row] - mean) / std , enc_act2[row] ].
+  const float* enc_obs; const float* enc_obs2; const float* enc_act2;   // [B, enc_O], [B, NH]
+  const float* enc_mean; const float* enc_std;                          // [enc_O]
+  float* enc_out; float* enc_out2;
+  int enc_O, enc_ld;
 };
 
 // Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).

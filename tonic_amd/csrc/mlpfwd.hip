@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const bool ok = grow < a.B;
   const int padded = (A + 15) / 16 * 16;
   for (int aa = slot; aa < padded; aa += 16) {
-    float term = 0.f;
+    float term = 0.f, action = 0.f;
     if (aa < A) {
       const float first = headbuf[prow * kPostPitch + aa];
       if (a.post == POST_SQUASHED_SAMPLE) {
@@ -331,14 +331,46 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
           a.post_actions[grow * A + aa] = sm.action;
           if (a.post_sigma != nullptr) a.post_sigma[grow * A + aa] = sm.sigma;
         }
+        action = sm.action;
       } else if (ok) {
-        a.post_actions[grow * A + aa] =
-            a.post == POST_TARGET_NOISE
-                ? noisy_target_action(first, a.post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
-                : first;
+        action = a.post == POST_TARGET_NOISE
+                     ? noisy_target_action(first, a.post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
+                     : first;
+        a.post_actions[grow * A + aa] = action;
+      }
+      if (ok && a.enc_out != nullptr) {               // the critics' input: action columns
+        a.enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
+        if (a.enc_out2 != nullptr)
+          a.enc_out2[grow * a.enc_ld + a.enc_O + aa] = a.enc_act2[grow * A + aa];
       }
     }
     terms[prow * kPostPitch + aa] = term;
+  }
+  if (a.enc_out != nullptr) {
+    // ... and the normalised observation columns, eight 16-column strips at a time: all loads
+    // first, through clamped addresses (a load under a lane-predicated branch waits for itself)
+    const int O = a.enc_O;
+    const int64_t src = min(grow, (int64_t)a.B - 1);
+    const bool second = a.enc_out2 != nullptr;
+    for (int c0 = 0; c0 < O; c0 += 8 * 16) {
+      float x[8], y[8], mean[8], sdev[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = min(c0 + 16 * u + slot, O - 1);
+        x[u] = a.enc_obs[src * O + c];
+        y[u] = second ? a.enc_obs2[src * O + c] : 0.f;
+        mean[u] = a.enc_mean[c];
+        sdev[u] = a.enc_std[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 16 * u + slot;
+        if (ok && c < O) {
+          a.enc_out[grow * a.enc_ld + c] = (x[u] - mean[u]) / sdev[u];
+          if (second) a.enc_out2[grow * a.enc_ld + c] = (y[u] - mean[u]) / sdev[u];
+        }
+      }
+    }
   }
   if (a.post != POST_SQUASHED_SAMPLE || a.post_logp == nullptr) return;
   __syncthreads();
@@ -492,6 +524,11 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(a.ldw1 >= a.K1 && a.ldw1 % 4 == 0 && a.ldw2 >= a.H && a.ldw2 % 4 == 0 &&
                     a.ldh >= a.H && a.ldh % 4 == 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: strides %d / %d / %d", a.ldw1, a.ldw2, a.ldh);
+  TONIC_REQUIRE(a.enc_out == nullptr ||
+                    (a.post != POST_NONE && a.enc_obs && a.enc_mean && a.enc_std && a.enc_O > 0 &&
+                     a.enc_ld >= a.enc_O + a.NH && (a.enc_out2 == nullptr || (a.enc_obs2 && a.enc_act2))),
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: encoder in the policy tail (O=%d ld=%d)",
+                a.enc_O, a.enc_ld);
   TONIC_REQUIRE(a.post == POST_NONE ||
                     (nets == 1 && a.NH <= kPostPitch && a.post_actions != nullptr &&
                      mlp_policy_tail_supported(a.H, a.NH) &&

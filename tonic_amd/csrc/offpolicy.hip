@@ -373,6 +373,12 @@ struct PolicyTail {
   const float* eps;
   float* actions; float* sigma; float* logp;
   float noise_scale, noise_clip;
+  // optional: the critics' input rows [normalised observations | these actions] -> enc_out, and a
+  // second pair from stored actions -> enc_out2 (see MlpFwdArgs)
+  const float* enc_obs; const float* enc_obs2; const float* enc_act2;
+  const float* enc_mean; const float* enc_std;
+  float* enc_out; float* enc_out2;
+  int enc_ld;
 };
 
 int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
@@ -396,6 +402,9 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
       f.post = tail->post; f.post_eps = tail->eps; f.post_actions = tail->actions;
       f.post_sigma = tail->sigma; f.post_logp = tail->logp;
       f.noise_scale = tail->noise_scale; f.noise_clip = tail->noise_clip;
+      f.enc_obs = tail->enc_obs; f.enc_obs2 = tail->enc_obs2; f.enc_act2 = tail->enc_act2;
+      f.enc_mean = tail->enc_mean; f.enc_std = tail->enc_std;
+      f.enc_out = tail->enc_out; f.enc_out2 = tail->enc_out2; f.enc_O = s.O; f.enc_ld = tail->enc_ld;
       if (tail_done != nullptr) *tail_done = true;
     }
     return launch_mlp_forward(f, 1, st);
@@ -577,8 +586,8 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
-  const PolicyTail tail{kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE, d_eps, d_actions, nullptr,
-                        nullptr, 0.f, 0.f};
+  PolicyTail tail{};
+  tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = d_eps; tail.actions = d_actions;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st,
                     &tail, &tail_done));
@@ -640,9 +649,15 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
 
   // ---- targets (no grad)
   const ActorShape as{O, H, A, kind == 1 ? 2 : 1};
-  const PolicyTail tail{kind == 0 ? POST_TARGET_NOISE : kind == 2 ? POST_COPY : POST_SQUASHED_SAMPLE,
-                        d_eps, next_act, nullptr, kind == 1 ? logp : nullptr, (float)noise_scale,
-                        (float)noise_clip};
+  // the policy's tail also encodes both critic inputs: (s', a') from its own actions -> X, the
+  // stored (s, a) -> X2
+  PolicyTail tail{};
+  tail.post = kind == 0 ? POST_TARGET_NOISE : kind == 2 ? POST_COPY : POST_SQUASHED_SAMPLE;
+  tail.eps = d_eps; tail.actions = next_act; tail.logp = kind == 1 ? logp : nullptr;
+  tail.noise_scale = (float)noise_scale; tail.noise_clip = (float)noise_clip;
+  tail.enc_obs = d_next_observations; tail.enc_obs2 = d_observations; tail.enc_act2 = d_actions;
+  tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std;
+  tail.enc_out = X; tail.enc_out2 = X2; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
                     kind != 1, st, &tail, &tail_done));
@@ -662,9 +677,11 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   }
   // ---- inputs of the targets (s', a') and of the online critics (s, a): one launch each for
   //      the encoding and for the four-network forward
-  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads, 2), dim3(threads),
-                     0, st, d_next_observations, next_act, d_norm_mean, d_norm_std, X, B, O, A, ldx,
-                     d_observations, d_actions, X2);
+  if (!tail_done) {
+    hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads, 2),
+                       dim3(threads), 0, st, d_next_observations, next_act, d_norm_mean, d_norm_std,
+                       X, B, O, A, ldx, d_observations, d_actions, X2);
+  }
   TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                       d_critics, X2));
   hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts, tq,
@@ -710,8 +727,11 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take((int64_t)Bp * HP); float* da_h1 = ws.take((int64_t)Bp * HP);
 
-  const PolicyTail tail{kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE, d_eps, act,
-                        kind == 0 ? nullptr : sigma, kind == 0 ? nullptr : logp, 0.f, 0.f};
+  PolicyTail tail{};                             // the tail also encodes the critics' input (s, a)
+  tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = d_eps; tail.actions = act;
+  tail.sigma = kind == 0 ? nullptr : sigma; tail.logp = kind == 0 ? nullptr : logp;
+  tail.enc_obs = d_observations; tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std;
+  tail.enc_out = X; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
                     kind == 0, st, &tail, &tail_done));
@@ -725,8 +745,10 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                        head0, head1, d_eps, ldh, act, logp, sigma, B, A,
                        sample_group(A));
   }
-  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
-                     st, d_observations, act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+  if (!tail_done) {
+    hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads),
+                       0, st, d_observations, act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+  }
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
   hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,
                      nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
