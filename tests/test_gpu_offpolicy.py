@@ -285,7 +285,8 @@ def test_adam_polyak_step_equals_the_two_calls(lib):
 
 
 @pytest.mark.parametrize('kind,o_dim,a_dim', [('sac', 111, 8), ('sac', 11, 3), ('td3', 67, 21),
-                                              ('ddpg', 17, 6), ('sac', 9, 40)])
+                                              ('ddpg', 17, 6), ('sac', 9, 40), ('sac', 23, 20),
+                                              ('td3', 5, 1)])
 def test_policy_tail_in_the_forward_launch_is_bit_identical(lib, kind, o_dim, a_dim):
     """Sampling / target noise / dense copy folded into the actor's forward launch (tuning key
     policy_tail = 1, the default) against their own launches (0): same parameters, bit for bit,
