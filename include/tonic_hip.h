@@ -161,6 +161,18 @@ int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
                     int32_t stats_kind, double kl_threshold, double entropy_coeff,
                     const float* d_adv_stats, float* d_info_row, const int32_t* d_skip_flag,
                     void* stream);
+/* Two independent optimizer steps in ONE launch pair (PPO: actor, with its KL early-stop flag and
+ * statistics, and critic — ppo.py:33-46 steps them back to back); same arithmetic as two
+ * tonic_adam_step calls sharing grad_scale / betas / eps. */
+int tonic_adam_step_pair(
+    float* d_params_a, const float* d_grad_sums_a, float* d_exp_avg_a, float* d_exp_avg_sq_a,
+    int32_t* d_state_a, int64_t param_count_a, double lr_a, int32_t stats_kind_a,
+    double kl_threshold, double entropy_coeff, const float* d_adv_stats, float* d_info_row_a,
+    const int32_t* d_skip_flag_a,
+    float* d_params_b, const float* d_grad_sums_b, float* d_exp_avg_b, float* d_exp_avg_sq_b,
+    int32_t* d_state_b, int64_t param_count_b, double lr_b, int32_t stats_kind_b,
+    float* d_info_row_b,
+    double grad_scale, double beta1, double beta2, double eps, void* stream);
 
 /* ---- replay: HBM-resident Segment -----------------------------------------------------------
  * replaces: tonic/replays/segments.py:27-36 (Segment.store, one time row for all W workers)

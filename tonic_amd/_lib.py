@@ -33,6 +33,9 @@ SIGNATURES = {
     'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_vp, c_i64, c_vp]),
     'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    'tonic_adam_step_pair': (ctypes.c_int,
+                             [c_vp] * 5 + [c_i64, c_f64, c_i32, c_f64, c_f64, c_vp, c_vp, c_vp] +
+                             [c_vp] * 5 + [c_i64, c_f64, c_i32, c_vp] + [c_f64] * 4 + [c_vp]),
     'tonic_segment_store': (ctypes.c_int, [c_vp] * 15 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_meanstd_record': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     'tonic_segment_gather': (ctypes.c_int, [c_vp] * 11 + [c_i64, c_i64, c_i32, c_i32, c_vp]),

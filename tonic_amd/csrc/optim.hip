@@ -41,7 +41,12 @@ __device__ __forceinline__ float polyak(float target, float online, float keep, 
   return scaled + add;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+// Up to two independent optimizer steps in one launch (blockIdx.y): PPO steps its actor and its
+// critic together.
+struct AdamPair { AdamArgs net[2]; };
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamPair pair) {
+  const AdamArgs& a = blockIdx.y == 0 ? pair.net[0] : pair.net[1];
   if (a.polyak_target != nullptr && (int)blockIdx.x >= a.adam_blocks) {
     // the target entries OUTSIDE this optimizer block: their online values are final already
     const int64_t first = (int64_t)((int)blockIdx.x - a.adam_blocks) * blockDim.x + threadIdx.x;
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 }
 
 // One thread: bump the step counter, turn the statistic sums into the logged values.
-__global__ void adam_finalize_kernel(AdamArgs a) {
+__global__ void adam_finalize_kernel(AdamPair pair) {
+  const AdamArgs& a = blockIdx.y == 0 ? pair.net[0] : pair.net[1];
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (a.skip != nullptr && *a.skip != 0) return;
   const float* st = a.grad_sums + a.n;
@@ -129,18 +135,17 @@ using namespace tonic;
 
 namespace {
 
-int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, float* d_exp_avg_sq,
-                int32_t* d_state, int64_t param_count, double grad_scale, double lr, double beta1,
-                double beta2, double eps, int32_t stats_kind, double kl_threshold,
-                double entropy_coeff, const float* d_adv_stats, float* d_info_row,
-                const int32_t* d_skip_flag, float* d_target, const float* d_online,
-                int64_t total, int64_t offset, double coeff, void* stream, const char* what) {
+int adam_fill(AdamArgs& a, const char* what, float* d_params, const float* d_grad_sums,
+              float* d_exp_avg, float* d_exp_avg_sq, int32_t* d_state, int64_t param_count,
+              double grad_scale, double lr, double beta1, double beta2, double eps,
+              int32_t stats_kind, double kl_threshold, double entropy_coeff,
+              const float* d_adv_stats, float* d_info_row, const int32_t* d_skip_flag) {
   TONIC_REQUIRE(d_params && d_grad_sums && d_exp_avg && d_exp_avg_sq && d_state &&
                     param_count > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "%s: bad argument", what);
   TONIC_REQUIRE(stats_kind >= 0 && stats_kind <= 4, TONIC_ERR_INVALID_ARGUMENT,
                 "%s: stats_kind %d", what, stats_kind);
-  AdamArgs a{};
+  a = AdamArgs{};
   a.params = d_params; a.grad_sums = d_grad_sums; a.exp_avg = d_exp_avg;
   a.exp_avg_sq = d_exp_avg_sq; a.state = d_state; a.n = param_count;
   // Hyper-parameters are Python floats in the reference: bias corrections and step size are
@@ -151,24 +156,70 @@ int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, flo
   a.stats_kind = stats_kind; a.kl_threshold = (float)kl_threshold;
   a.entropy_coeff = (float)entropy_coeff;
   a.adv_stats = d_adv_stats; a.info_row = d_info_row; a.skip = d_skip_flag;
-  int64_t blocks = (param_count + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  return TONIC_OK;
+}
+
+int adam_blocks_for(int64_t param_count) {
+  const int64_t blocks = (param_count + 255) / 256;
+  return (int)(blocks > 2048 ? 2048 : blocks);
+}
+
+int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, float* d_exp_avg_sq,
+                int32_t* d_state, int64_t param_count, double grad_scale, double lr, double beta1,
+                double beta2, double eps, int32_t stats_kind, double kl_threshold,
+                double entropy_coeff, const float* d_adv_stats, float* d_info_row,
+                const int32_t* d_skip_flag, float* d_target, const float* d_online,
+                int64_t total, int64_t offset, double coeff, void* stream, const char* what) {
+  AdamPair pair{};
+  AdamArgs& a = pair.net[0];
+  if (int rc = adam_fill(a, what, d_params, d_grad_sums, d_exp_avg, d_exp_avg_sq, d_state,
+                         param_count, grad_scale, lr, beta1, beta2, eps, stats_kind, kl_threshold,
+                         entropy_coeff, d_adv_stats, d_info_row, d_skip_flag))
+    return rc;
+  const int blocks = adam_blocks_for(param_count);
   int64_t extra = 0;
   if (d_target != nullptr) {
     a.polyak_target = d_target; a.polyak_online = d_online; a.polyak_total = total;
     a.polyak_offset = offset; a.polyak_keep = (float)(1.0 - coeff); a.polyak_mix = (float)coeff;
-    a.adam_blocks = (int)blocks;
+    a.adam_blocks = blocks;
     extra = (total - param_count + 255) / 256;
     if (extra > 2048) extra = 2048;
   }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, pair);
+  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(64), 0, st, pair);
   TONIC_CHECK_LAUNCH(what);
   return TONIC_OK;
 }
 
 }  // namespace
+
+extern "C" int tonic_adam_step_pair(
+    float* d_params_a, const float* d_grad_sums_a, float* d_exp_avg_a, float* d_exp_avg_sq_a,
+    int32_t* d_state_a, int64_t param_count_a, double lr_a, int32_t stats_kind_a,
+    double kl_threshold, double entropy_coeff, const float* d_adv_stats, float* d_info_row_a,
+    const int32_t* d_skip_flag_a,
+    float* d_params_b, const float* d_grad_sums_b, float* d_exp_avg_b, float* d_exp_avg_sq_b,
+    int32_t* d_state_b, int64_t param_count_b, double lr_b, int32_t stats_kind_b,
+    float* d_info_row_b,
+    double grad_scale, double beta1, double beta2, double eps, void* stream) {
+  AdamPair pair{};
+  if (int rc = adam_fill(pair.net[0], "tonic_adam_step_pair (first)", d_params_a, d_grad_sums_a,
+                         d_exp_avg_a, d_exp_avg_sq_a, d_state_a, param_count_a, grad_scale, lr_a,
+                         beta1, beta2, eps, stats_kind_a, kl_threshold, entropy_coeff, d_adv_stats,
+                         d_info_row_a, d_skip_flag_a))
+    return rc;
+  if (int rc = adam_fill(pair.net[1], "tonic_adam_step_pair (second)", d_params_b, d_grad_sums_b,
+                         d_exp_avg_b, d_exp_avg_sq_b, d_state_b, param_count_b, grad_scale, lr_b,
+                         beta1, beta2, eps, stats_kind_b, 0.0, 0.0, nullptr, d_info_row_b, nullptr))
+    return rc;
+  const int blocks = adam_blocks_for(param_count_a > param_count_b ? param_count_a : param_count_b);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks, 2), dim3(256), 0, st, pair);
+  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1, 2), dim3(64), 0, st, pair);
+  TONIC_CHECK_LAUNCH("tonic_adam_step_pair");
+  return TONIC_OK;
+}
 
 extern "C" int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
                                float* d_exp_avg_sq, int32_t* d_state, int64_t param_count,

@@ -235,8 +235,8 @@ class PPO(A2C):
                 # After the KL stop the actor half is stale on every rank alike and ignored
                 # (tonic_adam_step is skipped by the same device flag on all ranks).
                 torch.distributed.all_reduce(self._joint_grads)          # RCCL over xGMI
-            actor.enqueue_step(n, replay.adv_stats, self._infos[0, it], allreduce=False)
-            critic.enqueue_step(n, self._infos[1, it], allreduce=False)
+            updaters.enqueue_step_pair(actor, critic, n, replay.adv_stats, self._infos[0, it],
+                                       self._infos[1, it])
         return self._infos
 
     def _update(self):

@@ -93,6 +93,25 @@ class _FlatUpdater:
             _lib.ptr(info_row), skip, _lib.current_stream()), 'tonic_adam_step')
 
 
+def enqueue_step_pair(actor, critic, n_local, adv_stats, actor_info, critic_info):
+    """The optimizer steps of a PPO iteration (ppo.py:33-46: actor, then critic) as ONE launch
+    pair.  The gradient sums are final (all-reduced by the caller when world > 1)."""
+    ha, hc = actor.hyper, critic.hyper
+    if (ha['betas'], ha['eps']) != (hc['betas'], hc['eps']):        # separate launches then
+        actor.enqueue_step(n_local, adv_stats, actor_info, allreduce=False)
+        critic.enqueue_step(n_local, critic_info, allreduce=False)
+        return
+    p = _lib.ptr
+    _lib.check(actor.lib.tonic_adam_step_pair(
+        p(actor.flat.flat), p(actor.grad_sums), p(actor.exp_avg), p(actor.exp_avg_sq),
+        p(actor.state), actor.count, ha['lr'], actor.stats_kind, float(actor.kl_threshold),
+        float(actor.entropy_coeff), p(adv_stats), p(actor_info), actor.stop_flag_ptr(),
+        p(critic.flat.flat), p(critic.grad_sums), p(critic.exp_avg), p(critic.exp_avg_sq),
+        p(critic.state), critic.count, hc['lr'], critic.stats_kind, p(critic_info),
+        1.0 / (n_local * actor.world_size), ha['betas'][0], ha['betas'][1], ha['eps'],
+        _lib.current_stream()), 'tonic_adam_step_pair')
+
+
 class ClippedRatio(_FlatUpdater):
     stats_kind = 1
 
