@@ -86,16 +86,33 @@ __device__ __forceinline__ void record_rows(const float* column, int stride, int
 // Callers stage v and v * v (rounded, as mean_stds.py:47 computes it) side by side and walk the
 // two chains on two different waves, i.e. two SIMDs: one dependent float32 add per row and wave
 // instead of add + multiply + add — the chain is VALU-issue bound, 4 cycles per instruction.
+// The LDS reads of the NEXT 16 rows are issued before the adds of the current 16 (two register
+// sets, order pinned): otherwise every batch starts with an exposed LDS round trip, which costs as
+// much as the 16 dependent adds themselves.
 __device__ __forceinline__ void add_rows(const float* column, int stride, int rows, float& acc) {
-  int w = 0;
-  for (; w + 16 <= rows; w += 16) {
-    float v[16];
+  const int full = rows / 16;                       // batches of 16 rows
+  float a[16], b[16];
+  auto fetch = [&](float (&v)[16], int batch) {
+    const int first = 16 * min(batch, max(full - 1, 0));            // past the end: re-read, unused
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = column[(w + u) * stride];
+    for (int u = 0; u < 16; ++u) v[u] = column[(first + u) * stride];
+  };
+  auto fold = [&](const float (&v)[16]) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc = acc + v[u];
+  };
+  if (full > 0) fetch(a, 0);
+  for (int batch = 0; batch < full; batch += 2) {
+    fetch(b, batch + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fold(a);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(a, batch + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (batch + 1 < full) fold(b);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  for (; w < rows; ++w) acc = acc + column[w * stride];
+  for (int w = 16 * full; w < rows; ++w) acc = acc + column[w * stride];
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
