@@ -722,7 +722,6 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* c_h1 = ws.take(2LL * Bp * HP); float* c_h2 = ws.take(2LL * Bp * HP);
   float* q = ws.take(2LL * Bp); float* dq = ws.take(2LL * Bp);
   float* dh2 = ws.take(2LL * Bp * HP); float* dh1 = ws.take(2LL * Bp * HP);
-  float* dX = ws.take((int64_t)Bp * ldx);      // (kept: workspace layout)
   float* dxa = ws.take(2LL * Bp * ldh);         // action columns of the critics' input gradients
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take((int64_t)Bp * HP); float* da_h1 = ws.take((int64_t)Bp * HP);
@@ -752,7 +751,6 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
   hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,
                      nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
-  (void)dX;
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dxa,
                        st));
   hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
