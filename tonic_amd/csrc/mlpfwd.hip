@@ -419,12 +419,18 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
   for (int j = 0; j < kMaxTiles; ++j) tile_of[j] = min(wave + 4 * j, tiles - 1);
 
   // ReLU masks of both layers (forward activations of this lane's rows / features), up front
+  // H = 256: the dz1 product runs on INTERLEAVED tiles — wave w owns features [64 w, 64 w + 64),
+  // tile j of them the features 64 w + 4 i + j — because W2^T is contiguous along the OUTPUT
+  // index there: one 16-byte load per lane and k feeds all four tiles (4 loads per 16-k chunk
+  // instead of 16 dword loads; the walk is bound by load instructions, ~6 ns of the CU's memory
+  // pipe each).  In that layout register e of tile j is feature 64 w + 16 kg + 4 e + j.
+  const bool wide = tiles == 4 * kMaxTiles;           // scalar
   f32x4 mask2[kMaxTiles], mask1[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) {
     const int f = 16 * tile_of[j] + 4 * kg;
     mask2[j] = load_k4(h2g + (int64_t)row * a.ldhid, f);
-    mask1[j] = load_k4(h1g + (int64_t)row * a.ldhid, f);
+    mask1[j] = load_k4(h1g + (int64_t)row * a.ldhid, wide ? 64 * wave + 16 * kg + 4 * j : f);
   }
   // masked gradient of a hidden layer: to HBM (weight gradients) and to an LDS image [row][feature]
   auto finish = [&](const f32x4 (&acc)[kMaxTiles], const f32x4 (&mask)[kMaxTiles], float* global,
@@ -446,7 +452,18 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) cols2[j] = W2 + 16 * tile_of[j] + m;
   Layer<kMaxTiles, true> l1;                          // dz1 = W2^T dz2: requested before dz2 exists
-  l1.start(cols2, H, kg, a.ldw2);
+  const float* wcol = W2 + 64 * wave + 4 * m;         // wide: this lane's four output columns
+  f32x4 wa[kHalf][4], wb[kHalf][4];                   // wide operand sets: [chunk][e] -> tiles 0..3
+  auto wfill = [&](f32x4 (&w)[kHalf][4], int first) {
+#pragma unroll
+    for (int q = 0; q < kHalf; ++q) {
+      const int k = 16 * min(first + q, tiles - 1) + 4 * kg;      // past the end: re-read, unused
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[q][e] = load_w4(wcol + (int64_t)(k + e) * a.ldw2, 0);
+    }
+  };
+  if (wide) wfill(wa, 0);
+  else l1.start(cols2, H, kg, a.ldw2);
 
   f32x4 acc[kMaxTiles];
 #pragma unroll
@@ -479,13 +496,55 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
-  l1.run(kg, acc, from_hx, from_hx);
+  if (wide) {
+    f32x4 bA[kHalf], bB[kHalf];
+    auto bfill = [&](f32x4 (&b)[kHalf], int first) {
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) b[q] = from_hx(16 * min(first + q, tiles - 1) + 4 * kg);
+    };
+    auto compute = [&](const f32x4 (&w)[kHalf][4], const f32x4 (&b)[kHalf]) {
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int j = 0; j < kMaxTiles; ++j) acc[j] = mfma16(w[q][e][j], b[q][e], acc[j]);
+        }
+      }
+    };
+    bfill(bA, 0);
+    for (int c = 0; c < tiles; c += 2 * kHalf) {      // 16 chunks: four rounds of two sets
+      wfill(wb, c + kHalf); bfill(bB, c + kHalf);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(wa, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      wfill(wa, c + 2 * kHalf); bfill(bA, c + 2 * kHalf);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(wb, bB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    l1.run(kg, acc, from_hx, from_hx);
+  }
   Layer<1, true> lx;
   const bool xa_wave = 16 * wave < a.xa_count;      // one 16-column tile per wave
   const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first +
                            min(16 * wave + m, max(a.xa_count - 1, 0))};
   if (xa_wave) lx.start(colsx, H, kg, a.ldw1);
-  finish(acc, mask1, dz1g, hy);
+  if (wide) {                                         // register e of tile j: feature .. + 4 e + j
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = 64 * wave + 16 * kg + 4 * e;
+      f32x4 d;
+#pragma unroll
+      for (int j = 0; j < kMaxTiles; ++j) d[j] = mask1[e][j] > 0.f ? acc[j][e] : 0.f;
+      *reinterpret_cast<f32x4*>(hy + m * pitch + f) = d;
+      if (row_ok) *reinterpret_cast<f32x4_dword*>(dz1g + (int64_t)(r0 + m) * a.ldhid + f) =
+          f32x4_dword{d[0], d[1], d[2], d[3]};
+    }
+  } else {
+    finish(acc, mask1, dz1g, hy);
+  }
   __syncthreads();
 
   if (xa_wave) {                                      // [16 action columns][16 rows] of dz1 . W1
