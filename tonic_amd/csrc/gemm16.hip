@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup 
   const GemmArgs& g = G.problem[p];
   const int tile = (int)blockIdx.x - G.first[p], tiles_n = (g.N + 31) / 32;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  if (32 * tm + 32 > g.M || 32 * tn + 32 > g.N) gemm_tn_tile<true>(g, tm, tn, part);   // uniform
+  // Tiles that reach past the last row / column of C still take the vector loads when the
+  // operand ROWS are long enough (padded pitch: what is read beyond M / N only feeds outputs that
+  // are never stored); clamped scalar loads only where a load would leave the row.
+  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part);   // uniform
   else gemm_tn_tile<false>(g, tm, tn, part);
 }
 
