@@ -259,9 +259,18 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
   l2.run(kg, acc, from_hx, from_hx);
-  Layer<1> lh;
-  const float* rowsh[1] = {Wh + (int64_t)min(16 * head_tile + m, a.NH - 1) * a.ldw2};
-  if (head_wave) lh.start(rowsh, H, kg);
+  // A head tile is one dependent chain of H / 4 MFMAs on one wave with nothing to hide a load
+  // behind: its whole weight row (H <= 256: 16 loads per lane) is requested here, over the
+  // second layer's epilogue and barrier.
+  constexpr int kHeadChunks = 4 * kMaxTiles;
+  const float* head_row = Wh + (int64_t)min(16 * head_tile + m, a.NH - 1) * a.ldw2;
+  f32x4 wh[kHeadChunks];
+  if (head_wave) {
+#pragma unroll
+    for (int c = 0; c < kHeadChunks; ++c)
+      wh[c] = load_w4(head_row, 16 * min(c, tiles - 1) + 4 * kg);
+  }
+  __builtin_amdgcn_sched_barrier(0);                  // (or the loads sink to their use)
   float* partial = lds + 2 * kRows * pitch;           // [4 waves][16 rows]
   if (value_head) {
     // q[row] = b3 + sum_f h2[row][f] * w3[f]: this lane's 16 features, then the four k groups
@@ -291,8 +300,14 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   // heads: one [16 outputs][16 rows] tile per head wave
   if (head_wave) {
     f32x4 out[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    auto from_hy = [&](int k) { return *reinterpret_cast<const f32x4*>(hy + m * pitch + k); };
-    lh.run(kg, out, from_hy, from_hy);
+#pragma unroll
+    for (int c = 0; c < kHeadChunks; ++c) {
+      if (c < tiles) {                                // scalar
+        const f32x4 b = *reinterpret_cast<const f32x4*>(hy + m * pitch + 16 * c + 4 * kg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[0] = mfma16(wh[c][e], b[e], out[0]);
+      }
+    }
     float* out_base = head == 0 ? a.out[0] : a.out[1];
     const int act = head == 0 ? a.act[0] : a.act[1];
     float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
