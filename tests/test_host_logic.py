@@ -275,3 +275,12 @@ def test_offpolicy_padded_parameter_layout_keeps_state_dict():
     other.load_state_dict(torch.load(blob))
     assert all(torch.equal(other.state_dict()[k], before[k]) for k in before)
     assert int((other.flat_online != 0).sum()) == live
+    # deterministic head with an odd action count (TD3 on humanoid-walk shapes), single critic (DDPG)
+    for agent_cls, o_dim, a_dim, critics in ((tt.agents.TD3, 67, 21, 2), (tt.agents.DDPG, 17, 6, 1)):
+        model = agent_cls().model
+        model.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)))
+        model.pack('cpu')
+        assert model.flat_actor.count == lib.tonic_mlp_actor_param_count(o_dim, 256, a_dim, 1)
+        assert model.flat_critics.count == critics * lib.tonic_q_critic_param_count(o_dim, a_dim, 256)
+        assert model.flat_actor.flat.data_ptr() == model.flat_online.data_ptr()
+        assert all(p.data_ptr() % 16 == 0 for p in model.online_variables)
