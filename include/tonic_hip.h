@@ -45,7 +45,8 @@ typedef enum tonic_status {
 
 /* ---- library ------------------------------------------------------------------------ */
 const char* tonic_last_error(void);
-/* ABI version (bumped on any signature change) and the gfx target the kernels were built for. */
+/* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks) and
+ * the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 

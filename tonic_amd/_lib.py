@@ -66,6 +66,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2        # include/tonic_hip.h: tonic_abi_version()
+
+
 class TonicHipError(RuntimeError):
     pass
 
@@ -86,6 +89,9 @@ def load():
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
         fn.restype, fn.argtypes = restype, argtypes
+    if lib.tonic_abi_version() != ABI_VERSION:
+        raise TonicHipError(f'{LIBRARY_PATH} has ABI {lib.tonic_abi_version()}, this package needs '
+                            f'{ABI_VERSION}: rebuild it (`make -C tonic_amd/csrc`)')
     _lib = lib
     return lib
 

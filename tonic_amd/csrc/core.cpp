@@ -18,5 +18,6 @@ void set_error(const char* fmt, ...) {
 }  // namespace tonic
 
 extern "C" const char* tonic_last_error(void) { return tonic::g_error; }
-extern "C" int32_t tonic_abi_version(void) { return 1; }
+// 2: off-policy parameter blocks use the padded layout (tonic_mlp_weight_stride)
+extern "C" int32_t tonic_abi_version(void) { return 2; }
 extern "C" const char* tonic_target_arch(void) { return "gfx950"; }
