@@ -1,19 +1,24 @@
 """Headline benchmark: PPO rollout-collect + learner-update on synthetic HalfCheetah shapes.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One "step" = one full pass of the hot path over one Segment of synthetic input:
-T=4096 environment steps x W=256 workers per GPU collected (one policy forward+sample launch
-and one segment-store launch per environment step, inputs resident in HBM), then ONE learner
-update (2 critic forwards, the GAE scan, 80 x [actor fwd+loss+bwd, Adam, critic fwd+bwd,
-Adam] with the device-side KL early stop), then the statistics read-back and the
-normaliser update.  `value` = env steps/s of the whole job = (N_gpus * T * W * K) / time.
+One "step" = one full pass of the hot path over one Segment of synthetic input, THROUGH the
+drop-in API with the host in the loop: T=4096 environment steps x W workers per GPU, each one
+`agent.step(observations)` (pinned-host collector: one fused launch = policy forward + sample +
+log-prob + Segment store + MeanStd.record, actions back in the shared block),
+`environment.step(actions)` (vectorised synthetic simulator writing into the same block) and
+`agent.update(**infos)`; the T-th update runs ONE learner update (2 critic forwards, the GAE
+scan, 80 x [actor fwd+loss+bwd, Adam, critic fwd+bwd, Adam] with the device-side KL early
+stop), the statistics read-back and the normaliser update.
+`value` = env steps/s of the whole job = (N_gpus * T * W_per_gpu * K) / time — PCIe and the
+Python loop included.  `device_resident` repeats the measurement with the rollout inputs
+pre-generated in HBM and no host in the loop (round 1's `value`).
 
 Extra keys on the same JSON line: `roofline` (dominant kernel = fused actor forward+backward,
 fp32 MFMA bound), `roofline_gae` (HBM-bound scan, at the config size and at a bandwidth-bound
-sweep size), `cpu_baseline` (oracle/torch_port.py = the reference's torch-CPU path timed on
-this box's cores on a bounded sample), `learner_updates_per_sec`, phase timings and the
-host-in-the-loop (PCIe-inclusive) rate through the drop-in agent API.
+sweep), `cpu_baseline` (oracle/torch_port.py = the reference's torch-CPU path timed on this
+box's cores on a bounded sample), `learner_updates_per_sec`, `host_loop` (where an environment
+step goes), `strong_scaling` (N > 1: the metric's 256 workers split over the ranks).
 """
 import argparse
 import json
@@ -173,10 +178,13 @@ def cpu_baseline():
         next_observations=rng.standard_normal((T, W, O)).astype(np.float32),
         actions=np.clip(rng.standard_normal((T, W, A)), -1, 1).astype(np.float32),
         rewards=rng.standard_normal((T, W)).astype(np.float32),
-        resets=np.zeros((T, W), np.float32), terminations=np.zeros((T, W), np.float32),
+        resets=None, terminations=None,
         log_probs=(rng.standard_normal((T, W)) * 0.1 - 6).astype(np.float32))
+    # the same episode statistics as the GPU rollout: resets ~ Bernoulli(1e-3), half terminal
+    data['resets'] = (rng.uniform(size=(T, W)) < 1e-3).astype(np.float32)
+    data['terminations'] = data['resets'] * (rng.uniform(size=(T, W)) < 0.5).astype(np.float32)
     obs = rng.standard_normal((W, O)).astype(np.float32)
-    sample_steps, sample_iters = 64, 2
+    sample_steps, sample_iters = 64, 3
 
     def measure(threads):
         torch.set_num_threads(threads)
@@ -280,35 +288,117 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
     idx = rng.randint(sample_rows, size=(6, batch))
     eps = rng.standard_normal((6, 2 if kind == 'sac' else 1, batch, a_dim)).astype(np.float32)
     port_.update(host, 1, idx[:1], eps[:1])
-    t0 = time.perf_counter()
-    port_.update(host, 1, idx[1:], eps[1:])
-    dt = (time.perf_counter() - t0) / 5
-    out['cpu_baseline'] = {'learner_updates_per_sec': round(1 / dt, 2), 'kind': 'port',
-                           'cores': torch.get_num_threads(),
-                           'sample': f'5 {kind.upper()} iterations (critic + actor + polyak) at B={batch}'}
+    default_threads = torch.get_num_threads()
+    runs = []
+    for threads in ([default_threads, 16] if default_threads > 16 else [default_threads]):
+        torch.set_num_threads(threads)
+        port_.update(host, 1, idx[:1], eps[:1])
+        t0 = time.perf_counter()
+        port_.update(host, 1, idx[1:], eps[1:])
+        dt = (time.perf_counter() - t0) / 5
+        runs.append({'threads': threads, 'learner_updates_per_sec': round(1 / dt, 2)})
+    torch.set_num_threads(default_threads)
+    best = max(runs, key=lambda r: r['learner_updates_per_sec'])
+    out['cpu_baseline'] = {'learner_updates_per_sec': best['learner_updates_per_sec'],
+                           'kind': 'port', 'cores': best['threads'], 'runs': runs,
+                           'sample': f'5 {kind.upper()} iterations (critic + actor + polyak) at '
+                                     f'B={batch}; the faster of the default and 16 torch threads'}
     return out
 
 
-def host_loop_rate(agent, steps=512):
-    """PCIe-inclusive collect through the drop-in API (agent.step / agent.update with NumPy
-    in/out, pinned staging, vectorised synthetic environment) — never `value`."""
+class HostLoop:
+    """The trainer's loop body (tonic/utils/trainer.py:44-56) over the vectorised synthetic
+    simulator: agent.step -> environment.step -> agent.update, NumPy in / NumPy out."""
+
+    def __init__(self, agent, workers, seed):
+        from tonic_amd.environments import SyntheticBatch
+        self.agent, self.workers = agent, workers
+        self.env = SyntheticBatch(workers, O, A, max_episode_steps=1000, pool=64)
+        self.env.initialize(seed=seed)
+        self.observations = self.env.start()
+        self.steps = 0
+
+    def run(self, environment_steps):
+        agent, env, observations, steps, W = (self.agent, self.env, self.observations,
+                                              self.steps, self.workers)
+        for _ in range(environment_steps):
+            actions = agent.step(observations, steps)
+            observations, infos = env.step(actions)
+            agent.update(**infos, steps=steps)
+            steps += W
+        self.observations, self.steps = observations, steps
+
+    def breakdown(self, environment_steps=1024):
+        """Seconds per environment step spent in the three calls (no learner update inside:
+        call it right after one)."""
+        agent, env, W = self.agent, self.env, self.workers
+        assert agent.replay.index + environment_steps < agent.replay.max_size
+        observations, steps = self.observations, self.steps
+        clock, parts = time.perf_counter, np.zeros(3)
+        for _ in range(environment_steps):
+            t0 = clock()
+            actions = agent.step(observations, steps)
+            t1 = clock()
+            observations, infos = env.step(actions)
+            t2 = clock()
+            agent.update(**infos, steps=steps)
+            parts += (t1 - t0, t2 - t1, clock() - t2)
+            steps += W
+        self.observations, self.steps = observations, steps
+        us = parts / environment_steps * 1e6
+        return dict(us_per_env_step=round(float(us.sum()), 2), agent_step_us=round(float(us[0]), 2),
+                    env_step_us=round(float(us[1]), 2), agent_update_us=round(float(us[2]), 2),
+                    env_steps_per_sec=round(W * 1e6 / float(us.sum()), 1),
+                    steps=environment_steps, transport=agent.transport)
+
+
+def timed_steps(run_one, steps, warmup, world):
+    """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time."""
     import torch
-    from tonic_amd.environments import SyntheticBatch
-    env = SyntheticBatch(W, O, A, max_episode_steps=1000)
-    env.initialize(seed=1)
-    agent.replay.index = 0
-    observations = env.start()
-    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        run_one()
+    barrier()
     t0 = time.perf_counter()
-    for t in range(steps):
-        actions = agent.step(observations, t * W)
-        observations, infos = env.step(actions)
-        agent.update(**infos, steps=t * W)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    agent.replay.index = 0
-    return dict(env_steps_per_sec=round(steps * W / dt, 1), ms_per_env_step=round(dt / steps * 1e3, 4),
-                steps=steps)
+    for _ in range(steps):
+        run_one()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed
+
+
+def measure_job(workers, rank, world, steps, warmup, capture, device_too=True):
+    """Builds one agent with `workers` workers on this rank and times (a) the host-in-the-loop
+    path and (b) the device-resident path; returns (agent, loop, rollout, results)."""
+    from tonic_amd.rollout import DeviceRollout
+    agent = build_agent(seed=0)                      # same seed: replicated parameters
+    loop = HostLoop(agent, workers, seed=1 + rank)
+    elapsed = timed_steps(lambda: loop.run(T), steps, warmup, world)
+    out = dict(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3,
+               value=world * T * workers * steps / elapsed,
+               actor_iterations=int((agent.last_infos[0][:, 6] > 0).sum()))
+    rollout = None
+    if device_too:
+        rollout = DeviceRollout(agent, workers, T, seed=1 + rank)
+
+        def device_step():
+            rollout.collect(capture=capture)
+            agent._update()                          # enqueue + one read-back + normaliser
+        d = timed_steps(device_step, steps, 1, world)
+        out['device_resident'] = dict(
+            env_steps_per_sec=round(world * T * workers * steps / d, 1),
+            ms_per_step=round(d / steps * 1e3, 3),
+            note='rollout inputs pre-generated in HBM, one fused launch per environment step '
+                 'replayed from a hipGraph, no host in the loop')
+    return agent, loop, rollout, out
 
 
 def main():
@@ -318,103 +408,105 @@ def main():
     parser.add_argument('--warmup', type=int, default=1)
     parser.add_argument('--no-graph', action='store_true', help='eager launches, no hipGraph')
     parser.add_argument('--no-extras', action='store_true',
-                        help='skip roofline / cpu_baseline / host-loop measurements')
+                        help='skip roofline / cpu_baseline / off-policy measurements')
+    parser.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                        help='weak (default): the configured workers PER GPU; strong: the '
+                             'configured workers are the global count, split over the ranks')
     parser.add_argument('--workload', default='cfg2', choices=('cfg2', 'cfg5'),
-                        help='cfg2 (default, the headline metric): HalfCheetah shapes, 256 workers '
-                             'per GPU; cfg5: AntBullet shapes (O=28, A=8), 1280 workers per GPU, '
-                             'i.e. BASELINE config 5 at 8 GPUs — a scaling data point, no extras')
+                        help='cfg2 (default, the headline metric): HalfCheetah shapes, 256 workers; '
+                             'cfg5: AntBullet shapes (O=28, A=8), 1280 workers per GPU under weak '
+                             'scaling = BASELINE config 5 at 8 GPUs (10 240 global under strong)')
     args = parser.parse_args()
+    global O, A, W
     if args.workload == 'cfg5':
-        global O, A, W
         O, A, W = 28, 8, 1280
         args.no_extras = True
 
     import torch
     from tonic_amd import parallel
-    from tonic_amd.rollout import DeviceRollout
     rank, world = parallel.init_from_env()
     assert world == max(args.gpus, 1) or world == 1, (world, args.gpus)
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-
-    agent = build_agent(seed=0)                      # same seed: replicated parameters
-    rollout = DeviceRollout(agent, W, T, seed=1 + rank)
     capture = not args.no_graph
-
-    def one_step():
-        rollout.collect(capture=capture)
-        agent._update()                              # enqueue + one read-back + normaliser
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    global_workers = W * world if args.scaling == 'weak' else (W if args.workload == 'cfg2' else 10240)
+    assert global_workers % world == 0, (global_workers, world)
+    workers = global_workers // world
 
     from tonic_amd.utils import logger
     logger.get_current_logger().store = lambda *a, **k: None      # no log accumulation here
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * T * W * args.steps / elapsed
-    actor_iters = int((agent.last_infos[0][:, 6] > 0).sum())
-
+    agent, loop, rollout, main_run = measure_job(workers, rank, world, args.steps, args.warmup,
+                                                 capture)
+    name = 'HalfCheetah-v3' if args.workload == 'cfg2' else 'AntBulletEnv-v0'
     result = {
-        'metric': 'env steps/sec (+ learner updates/sec), PPO HalfCheetah parallel=256'
-                  if args.workload == 'cfg2' else
-                  'env steps/sec (+ learner updates/sec), PPO AntBullet parallel=1280 per GPU',
-        'value': round(value, 1), 'unit': 'env_steps/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'PPO {"HalfCheetah-v3" if args.workload == "cfg2" else "AntBulletEnv-v0"} '
-                               f'shapes (O={O}, A={A}), parallel={W} workers per GPU, Segment T={T} '
-                               f'(N={T * W} transitions per GPU per step), '
-                               '80 full-batch iterations, 1 learner update per step',
-                   'workers_per_gpu': W, 'segment_steps': T, 'batch_iterations': ITERATIONS,
-                   'global_workers': W * world, 'parallelism': f'dp{world} (worker-axis shard, '
-                   'RCCL all-reduce of flat gradient sums)', 'hip_graph': capture},
-        'learner_updates_per_sec': round(ITERATIONS * args.steps / elapsed, 2),
-        'actor_iterations_last_update': actor_iters,
+        'metric': f'env steps/sec (+ learner updates/sec), PPO {name.split("-")[0]} '
+                  f'parallel={global_workers if args.scaling == "strong" else W}'
+                  + ('' if args.scaling == 'strong' else ' per GPU'),
+        'value': round(main_run['value'], 1), 'unit': 'env_steps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(main_run['ms_per_step'], 3), 'higher_is_better': True,
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'PPO {name} shapes (O={O}, A={A}), parallel={workers} workers per '
+                               f'GPU ({global_workers} global), Segment T={T} (N={T * workers} '
+                               'transitions per GPU per step), 80 full-batch iterations, 1 learner '
+                               'update per step; host in the loop: agent.step / environment.step / '
+                               'agent.update through the pinned-host collector',
+                   'workers_per_gpu': workers, 'segment_steps': T, 'batch_iterations': ITERATIONS,
+                   'global_workers': global_workers,
+                   'parallelism': f'dp{world} (worker-axis shard, RCCL all-reduce of flat '
+                                  'gradient sums)',
+                   'collector_transport': agent.transport},
+        'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
+        'actor_iterations_last_update': main_run['actor_iterations'],
+        'device_resident': main_run['device_resident'],
     }
 
-    if rank == 0 and not args.no_extras:
-        # phase split (untimed extras): collect-only and update-only
-        if world == 1:
-            collect_s = update_s = 0.0                   # phase split of two more whole steps
-            for _ in range(2):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                rollout.collect(capture=capture)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                agent._update()
-                torch.cuda.synchronize()
-                collect_s += t1 - t0
-                update_s += time.perf_counter() - t1
-            result['collect_ms'] = round(collect_s / 2 * 1e3, 3)
-            result['update_ms'] = round(update_s / 2 * 1e3, 3)
-            roof, roof_c, roof_g = kernel_rooflines(agent)
-            result['roofline'] = roof
-            result['roofline_critic'] = roof_c
-            result['roofline_gae'] = roof_g
-            result['host_loop'] = host_loop_rate(agent)
-            result['cpu_baseline'] = cpu_baseline()
-            result['offpolicy_sac'] = offpolicy_rates()
-            # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
-            # reference's default batch of 100 and the batch of cfg 3
-            result['offpolicy_td3'] = {
-                f'B={b}': offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)['hip_graph']
-                for b in (100, 1024)}
-            result['speedup_vs_cpu_baseline'] = round(value / result['cpu_baseline']['value'], 1)
+    if world > 1:
+        # RCCL really saw every rank: after the updates above the replicated parameters must be
+        # bit-identical everywhere (every rank applied the same all-reduced sums)
+        flat = torch.cat([agent.model.flat_actor.flat, agent.model.flat_critic.flat])
+        low, high = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(low, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(high, op=torch.distributed.ReduceOp.MAX)
+        identical = bool(torch.equal(low, high))
+        assert identical, 'parameters diverged across ranks'
+        result['ranks_hold_identical_parameters'] = identical
+        result['backend'] = torch.distributed.get_backend()
+        if args.scaling == 'weak' and args.workload == 'cfg2' and W % world == 0:
+            # the metric's own configuration: 256 workers in total, split over the ranks
+            _, _, _, strong = measure_job(W // world, rank, world, args.steps, 1, capture)
+            result['strong_scaling'] = dict(
+                global_workers=W, workers_per_gpu=W // world,
+                env_steps_per_sec=round(strong['value'], 1),
+                ms_per_step=round(strong['ms_per_step'], 3),
+                device_resident=strong['device_resident'])
+
+    if rank == 0 and not args.no_extras and world == 1:
+        # phase split (untimed extras): where a step goes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.run(T - 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loop.run(1)                                       # the T-th update() runs the learner
+        torch.cuda.synchronize()
+        result['collect_ms'] = round((t1 - t0) * 1e3 * T / (T - 1), 3)
+        result['update_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
+        result['host_loop'] = loop.breakdown()
+        loop.run(T - loop.agent.replay.index)             # finish the segment
+        roof, roof_c, roof_g = kernel_rooflines(agent)
+        result['roofline'] = roof
+        result['roofline_critic'] = roof_c
+        result['roofline_gae'] = roof_g
+        result['cpu_baseline'] = cpu_baseline()
+        result['offpolicy_sac'] = offpolicy_rates()
+        # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
+        # reference's default batch of 100 and the batch of cfg 3
+        result['offpolicy_td3'] = {
+            f'B={b}': offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)['hip_graph']
+            for b in (100, 1024)}
+        result['speedup_vs_cpu_baseline'] = round(
+            main_run['value'] / result['cpu_baseline']['value'], 1)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

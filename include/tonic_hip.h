@@ -38,15 +38,16 @@ extern "C" {
 typedef enum tonic_status {
   TONIC_OK = 0,
   TONIC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / NULL pointer / unsupported size   */
-  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* O > 64, A > 8 or hidden != 64 for mlp64 path */
-  TONIC_ERR_LAUNCH = -3,             /* hipLaunchKernel / hipMemsetAsync failed       */
-  TONIC_ERR_WORKSPACE = -4           /* workspace too small                           */
+  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* PPO path: O > 32, A > 8 or hidden != 64         */
+  TONIC_ERR_LAUNCH = -3,             /* a HIP runtime call / kernel launch failed       */
+  TONIC_ERR_WORKSPACE = -4,          /* workspace too small                             */
+  TONIC_ERR_TIMEOUT = -5             /* collector: workers / actions did not arrive     */
 } tonic_status;
 
 /* ---- library ------------------------------------------------------------------------ */
 const char* tonic_last_error(void);
-/* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks) and
- * the gfx target the kernels were built for. */
+/* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks,
+ * 3 = pinned-host collector) and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -260,6 +261,82 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
                                    float* d_seg_resets, float* d_seg_terminations,
                                    float* d_seg_log_probs, float* d_norm_acc, int64_t row0,
                                    int64_t steps, int64_t W, int32_t O, int32_t A, void* stream);
+
+/* ---- pinned-host batched collector --------------------------------------------------------------
+ * replaces: tonic/environments/distributed.py:82-95,136-155 (Parallel: one pickled Pipe message per
+ *   worker group and step, one shared Queue back) and the host <-> device hops of
+ *   tonic/torch/agents/a2c.py:41-73 (torch.as_tensor / .numpy() around every forward pass).
+ *
+ * One page-aligned shared BLOCK (the caller maps it MAP_SHARED | MAP_ANONYMOUS before forking its
+ * workers; tonic_collector_block_bytes gives the size) carries one environment step of all W workers
+ * as float32 fields [W, ...] — the enum below — plus uint8 copies of the two flags for NumPy bool
+ * views.  It is the ONLY exception to "the library owns no memory and never blocks": the collector
+ * handle owns a stream, events and a few KB of device scratch, and the wait calls block.
+ *
+ * Environment side (no HIP; parent and forked workers): the parent publishes the actions with
+ * tonic_collector_submit_actions (one futex wake for ALL worker groups), every group answers with
+ * tonic_collector_worker_done after writing its rows, the parent blocks in tonic_collector_wait_obs
+ * (TONIC_ERR_TIMEOUT instead of the reference's dead-worker hang).  tonic_collector_worker_wait
+ * returns the new step sequence number (>= 0), -1 after tonic_collector_shutdown, -2 on timeout.
+ *
+ * Agent side: tonic_collector_create page-locks the block (hipHostRegister) so that the workers'
+ * memory is the DMA source.  transport 0: the fused act kernel reads observations / noise / the
+ * previous outcome from the mapped block over PCIe and writes actions + a completion word back;
+ * transport 1: hipMemcpyAsync H2D + kernel + hipMemcpyAsync D2H on the collector's own stream and
+ * an event.  Per environment step t (tonic/utils/trainer.py:44-56):
+ *   tonic_collector_ppo_step(row t)   ONE launch: policy forward + sample + log-prob of the block's
+ *                                     observations (a2c.py:75-85) -> Segment row t and the block's
+ *                                     actions; MeanStd.record of the observations (a2c.py:66-69);
+ *                                     and, with store_previous, the block's outcome fields
+ *                                     (next_observations, rewards, resets, terminations — still
+ *                                     those of step t-1) -> Segment row t-1 (segments.py:27-36).
+ *                                     eps_slot selects the noise field (-1: the mode, no noise).
+ *   tonic_collector_wait_actions      returns when the actions are in the block and every block
+ *                                     field may be overwritten (no stream synchronisation).
+ * tonic_collector_begin_rollout orders the collector's stream behind `learner_stream` (the
+ * parameters were just updated there) and packs the actor; tonic_collector_end_rollout stores the
+ * outcome of the last step (last_row; < 0: none pending), makes `learner_stream` wait for the
+ * collector and returns once the block may be reused.
+ */
+typedef struct tonic_collector tonic_collector_t;
+enum {
+  TONIC_COLLECTOR_EPS0 = 0,            /* [W,A] standard-normal draws, slot 0               */
+  TONIC_COLLECTOR_OBSERVATIONS = 1,    /* [W,O] post-reset observations the agent acts on   */
+  TONIC_COLLECTOR_NEXT_OBSERVATIONS = 2, /* [W,O] pre-reset next observations (infos)       */
+  TONIC_COLLECTOR_REWARDS = 3,         /* [W]                                               */
+  TONIC_COLLECTOR_RESETS = 4,          /* [W] 0/1 as float32 (segments.py:33)               */
+  TONIC_COLLECTOR_TERMINATIONS = 5,    /* [W] 0/1 as float32                                */
+  TONIC_COLLECTOR_EPS1 = 6,            /* [W,A] noise slot 1                                */
+  TONIC_COLLECTOR_ACTIONS = 7,         /* [W,A] written by the agent side                   */
+  TONIC_COLLECTOR_RESETS_U8 = 8,       /* [W] uint8 copies of the flags (NumPy bool views)  */
+  TONIC_COLLECTOR_TERMINATIONS_U8 = 9,
+  TONIC_COLLECTOR_FIELD_COUNT = 10
+};
+int64_t tonic_collector_block_bytes(int64_t W, int32_t O, int32_t A);
+int tonic_collector_block_init(void* block, int64_t bytes, int64_t W, int32_t O, int32_t A,
+                               int32_t worker_groups);
+int64_t tonic_collector_block_offset(const void* block, int32_t field);   /* bytes; < 0: error */
+int64_t tonic_collector_worker_wait(void* block, int64_t seen_sequence, double timeout_s);
+int tonic_collector_worker_done(void* block);
+int tonic_collector_submit_actions(void* block);
+int tonic_collector_wait_obs(void* block, double timeout_s);
+int tonic_collector_shutdown(void* block);
+
+int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport);
+int tonic_collector_destroy(tonic_collector_t* collector);
+void* tonic_collector_stream(tonic_collector_t* collector);      /* the collector's hipStream_t */
+int tonic_collector_bind_segment(tonic_collector_t* collector, float* d_seg_observations,
+                                 float* d_seg_actions, float* d_seg_next_observations,
+                                 float* d_seg_rewards, float* d_seg_resets,
+                                 float* d_seg_terminations, float* d_seg_log_probs,
+                                 float* d_norm_acc, int64_t segment_rows);
+int tonic_collector_begin_rollout(tonic_collector_t* collector, const float* d_actor_params,
+                                  void* learner_stream);
+int tonic_collector_ppo_step(tonic_collector_t* collector, int64_t row, int32_t eps_slot,
+                             int32_t store_previous);
+int tonic_collector_wait_actions(tonic_collector_t* collector, double timeout_s);
+int tonic_collector_end_rollout(tonic_collector_t* collector, int64_t last_row,
+                                void* learner_stream);
 
 /* ---- target networks (SAC / TD3) ---------------------------------------------------------------
  * replaces: tonic/torch/models/actor_critics.py:126-130 (update_targets): per element

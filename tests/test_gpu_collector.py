@@ -1,0 +1,223 @@
+"""GPU tests of the pinned-host collector (tonic_collector_* through ctypes): the host-in-the-loop
+path — shared block, fused act + deferred outcome store, completion word / event instead of a
+stream sync — against the CPU oracle and against the device-resident collect entry points."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import numpy_port as port
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from tonic_amd import _lib
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return _lib.load()
+
+
+def _actor(O, A, seed):
+    rng = np.random.RandomState(seed)
+    shapes = [(64, O), (64,), (64, 64), (64,), (1, A), (A, 64), (A,)]
+    return [(rng.standard_normal(s) * (0.3 if len(s) == 2 else 0.1)).astype(np.float32)
+            for s in shapes]
+
+
+def _segment(T, W, O, A):
+    def new(*shape):
+        return torch.full(shape, np.nan, dtype=torch.float32, device='cuda')
+    return dict(observations=new(T, W, O), actions=new(T, W, A), next_observations=new(T, W, O),
+                rewards=new(T, W), resets=new(T, W), terminations=new(T, W), log_probs=new(T, W))
+
+
+@pytest.mark.parametrize('transport', [0, 1])
+@pytest.mark.parametrize('O,A,W', [(17, 6, 256), (28, 8, 1280), (3, 1, 5)])
+def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
+    """T host-in-the-loop steps through the C entry points: actions and log-probs against
+    numpy_port.ppo_act (the reference's forward + sample + log_prob), stored rows and outcome
+    rows bit-exact copies, normaliser sums bit-exact against MeanStdPort.record."""
+    from tonic_amd import _lib
+    from tonic_amd.collector import Block, Collector
+    T = 5
+    rng = np.random.RandomState(O * 1000 + W)
+    params = _actor(O, A, 7)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in params])).cuda()
+    block = Block(W, O, A)
+    collector = Collector(block, transport)
+    seg = _segment(T, W, O, A)
+    sums = torch.zeros(2 * O, device='cuda')
+    collector.bind_segment(seg, sums, T)
+    torch.cuda.synchronize()
+    collector.begin_rollout(flat)
+    want = {k: np.full(tuple(v.shape), np.nan, np.float32) for k, v in seg.items()}
+    recorder = port.MeanStdPort((O,))
+    for t in range(T):
+        observations = rng.standard_normal((W, O)).astype(np.float32)
+        eps = rng.standard_normal((W, A)).astype(np.float32)
+        block.observations[:] = observations
+        block.eps[t & 1][:] = eps
+        collector.ppo_step(t, t & 1, t > 0)
+        collector.wait_actions()
+        actions = block.actions.copy()
+        want_actions, want_log_probs = port.ppo_act(params, observations, eps)
+        np.testing.assert_allclose(actions, want_actions, rtol=0, atol=3e-6)
+        want['observations'][t] = observations
+        want['actions'][t] = actions
+        want['log_probs'][t] = want_log_probs
+        recorder.record(observations)
+        # the environment's answer to these actions: the outcome of step t
+        outcome = dict(next_observations=rng.standard_normal((W, O)).astype(np.float32),
+                       rewards=rng.standard_normal(W).astype(np.float32),
+                       resets=(rng.uniform(size=W) < 0.3).astype(np.float32),
+                       terminations=(rng.uniform(size=W) < 0.1).astype(np.float32))
+        for key, value in outcome.items():
+            getattr(block, key)[:] = value
+            want[key][t] = value
+    collector.end_rollout(T - 1)
+    torch.cuda.synchronize()
+    for key in ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations'):
+        assert np.array_equal(seg[key].cpu().numpy(), want[key]), key
+    np.testing.assert_allclose(seg['log_probs'].cpu().numpy(), want['log_probs'], rtol=0, atol=2e-5)
+    got = sums.cpu().numpy()
+    assert np.array_equal(got[:O], recorder.new_sum) and np.array_equal(got[O:], recorder.new_sum_sq)
+    collector.close()
+
+
+def test_collector_equals_device_resident_collect(lib):
+    """The host-in-the-loop launch is the device-resident packed collect kernel with the outcome
+    deferred by one step: identical Segment bits for identical inputs, both transports."""
+    from tonic_amd import _lib
+    from tonic_amd.collector import Block, Collector
+    O, A, W, T = 17, 6, 256, 6
+    rng = np.random.RandomState(3)
+    params = _actor(O, A, 11)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in params])).cuda()
+    obs = rng.standard_normal((T + 1, W, O)).astype(np.float32)
+    eps = rng.standard_normal((T, W, A)).astype(np.float32)
+    rewards = rng.standard_normal((T, W)).astype(np.float32)
+    resets = (rng.uniform(size=(T, W)) < 0.2).astype(np.float32)
+    terms = resets * (rng.uniform(size=(T, W)) < 0.5)
+    p = _lib.ptr
+    ref = _segment(T, W, O, A)
+    ref_sums = torch.zeros(2 * O, device='cuda')
+    packed = torch.empty(lib.tonic_ppo_packed_actor_floats(O, A), device='cuda')
+    _lib.check(lib.tonic_ppo_pack_actor(p(flat), p(packed), O, A, None), 'pack')
+    d = [torch.as_tensor(x).cuda() for x in (obs, eps, rewards, resets, terms.astype(np.float32))]
+    _lib.check(lib.tonic_ppo_collect_steps_packed(
+        p(packed), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(ref['observations']),
+        p(ref['actions']), p(ref['next_observations']), p(ref['rewards']), p(ref['resets']),
+        p(ref['terminations']), p(ref['log_probs']), p(ref_sums), 0, T, W, O, A, None), 'collect')
+    torch.cuda.synchronize()
+    for transport in (0, 1):
+        block = Block(W, O, A)
+        collector = Collector(block, transport)
+        seg = _segment(T, W, O, A)
+        sums = torch.zeros(2 * O, device='cuda')
+        collector.bind_segment(seg, sums, T)
+        torch.cuda.synchronize()
+        collector.begin_rollout(flat)
+        for t in range(T):
+            block.observations[:] = obs[t]
+            block.eps[t & 1][:] = eps[t]
+            collector.ppo_step(t, t & 1, t > 0)
+            collector.wait_actions()
+            block.next_observations[:] = obs[t + 1]
+            block.rewards[:] = rewards[t]
+            block.resets[:] = resets[t]
+            block.terminations[:] = terms[t]
+        collector.end_rollout(T - 1)
+        torch.cuda.synchronize()
+        for key in seg:
+            assert np.array_equal(seg[key].cpu().numpy(), ref[key].cpu().numpy()), (transport, key)
+        assert np.array_equal(sums.cpu().numpy(), ref_sums.cpu().numpy())
+        assert np.array_equal(block.actions, ref['actions'][T - 1].cpu().numpy())
+        collector.close()
+
+
+def test_parallel_workers_feed_the_gpu_in_place(lib):
+    """Forked worker groups write into the shared block, the agent page-locks that very block
+    (identity-bound views, no host copy) and the stored Segment equals the one collected through
+    the Sequential collector with the same seeds."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments
+    O, A, T = 17, 6, 12
+    segments = []
+    for groups, per_group in ((3, 2), (1, 6)):
+        env = environments.distribute(
+            lambda: environments.Synthetic(O, A, max_episode_steps=5), groups, per_group)
+        env.initialize(seed=4)
+        agent = tonic_amd.torch.agents.PPO(
+            replay=tonic_amd.replays.Segment(size=T + 1, batch_iterations=2))
+        agent.initialize(env.observation_space, env.action_space, seed=9)
+        observations = env.start()
+        for t in range(T):
+            actions = agent.step(observations, t * 6)
+            assert agent._block is env.block, 'the agent must adopt the environment block'
+            observations, infos = env.step(actions)
+            agent.update(**infos, steps=t * 6)
+        agent._collector.end_rollout(T - 1)
+        torch.cuda.synchronize()
+        segments.append({k: agent.replay.buffers[k][:T].cpu().numpy() for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+            'log_probs')})
+        sums = agent.model.observation_normalizer.device_sums.cpu().numpy()
+        segments[-1]['sums'] = sums
+        if groups > 1:
+            env.close()
+    for key, want in segments[1].items():
+        assert np.array_equal(segments[0][key], want), key
+    assert segments[0]['resets'].sum() > 0
+
+
+def test_test_step_keeps_the_reference_noise_order(lib):
+    """The next step's noise is drawn ahead; a test episode in between must see the generator
+    where the reference would have it (a2c.py:87-90 draws from the same stream)."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd.environments import Box
+    O, A, W = 5, 2, 8
+    rng = np.random.RandomState(0)
+    obs = rng.standard_normal((4, W, O)).astype(np.float32)
+    test_obs = rng.standard_normal((1, O)).astype(np.float32)
+
+    def run(with_test):
+        agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=64))
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+        out = []
+        for t in range(3):
+            out.append(agent.step(obs[t], t * W))
+            agent.update(obs[t + 1], np.zeros(W, np.float32), np.zeros(W, bool),
+                         np.zeros(W, bool), steps=t * W)
+            if with_test and t == 1:
+                out.append(agent.test_step(test_obs, t * W))
+        return out
+
+    got = run(True)
+    plain = run(False)
+    # steps 0 and 1 agree; the test draw sits between step 1 and step 2 in the stream
+    assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1])
+    assert not np.array_equal(got[3], plain[2])
+    agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=64))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+    state = agent.model.state_dict()
+    params = [state[k].detach().cpu().numpy() for k in (
+        'actor.torso.model.0.weight', 'actor.torso.model.0.bias', 'actor.torso.model.2.weight',
+        'actor.torso.model.2.bias', 'actor.head.log_scale', 'actor.head.loc_layer.0.weight',
+        'actor.head.loc_layer.0.bias')]
+    # agent.initialize seeds the generator, then the model initialisation consumes draws: replay
+    # the expected noise from the generator state right after initialisation instead
+    after_init = torch.get_rng_state()
+    eps = [torch.randn(W, A).numpy() for _ in range(2)]
+    eps_test = torch.randn(1, A).numpy()
+    eps_last = torch.randn(W, A).numpy()
+    torch.set_rng_state(after_init)
+    want0, _ = port.ppo_act(params, obs[0], eps[0])
+    want1, _ = port.ppo_act(params, obs[1], eps[1])
+    want_test, _ = port.ppo_act(params, test_obs, eps_test)
+    want2, _ = port.ppo_act(params, obs[2], eps_last)
+    for got_actions, want in zip(got, (want0, want1, want_test, want2)):
+        np.testing.assert_allclose(got_actions, want, rtol=0, atol=3e-6)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} missing from libtonic_hip.so'
     loaded = _lib.load()
-    assert loaded.tonic_abi_version() == 2
+    assert loaded.tonic_abi_version() == _lib.ABI_VERSION
     assert loaded.tonic_target_arch() == b'gfx950'
     assert loaded.tonic_ppo_actor_param_count(17, 6) == 5708
     assert loaded.tonic_v_critic_param_count(17) == 5377

@@ -61,12 +61,28 @@ SIGNATURES = {
                           [c_vp, c_i64, c_vp]),
     'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 7 + [c_i32] * 4 + [c_f64] +
                            [c_vp, c_i64, c_vp]),
+    'tonic_collector_block_bytes': (c_i64, [c_i64, c_i32, c_i32]),
+    'tonic_collector_block_init': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32]),
+    'tonic_collector_block_offset': (c_i64, [c_vp, c_i32]),
+    'tonic_collector_worker_wait': (c_i64, [c_vp, c_i64, c_f64]),
+    'tonic_collector_worker_done': (ctypes.c_int, [c_vp]),
+    'tonic_collector_submit_actions': (ctypes.c_int, [c_vp]),
+    'tonic_collector_wait_obs': (ctypes.c_int, [c_vp, c_f64]),
+    'tonic_collector_shutdown': (ctypes.c_int, [c_vp]),
+    'tonic_collector_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, c_i32]),
+    'tonic_collector_destroy': (ctypes.c_int, [c_vp]),
+    'tonic_collector_stream': (c_vp, [c_vp]),
+    'tonic_collector_bind_segment': (ctypes.c_int, [c_vp] * 9 + [c_i64]),
+    'tonic_collector_begin_rollout': (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    'tonic_collector_ppo_step': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
+    'tonic_collector_wait_actions': (ctypes.c_int, [c_vp, c_f64]),
+    'tonic_collector_end_rollout': (ctypes.c_int, [c_vp, c_i64, c_vp]),
     'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_gemm_f32': (ctypes.c_int, [ctypes.c_char_p] + [c_vp] * 6 + [c_i32] * 8 + [c_f64, c_vp]),
 }
 
 
-ABI_VERSION = 2        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 3        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

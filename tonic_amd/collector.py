@@ -1,0 +1,155 @@
+"""Python face of the pinned-host batched collector (``tonic_collector_*`` in
+``include/tonic_hip.h``; kernels and futex protocol in ``csrc/collector.hip``).
+
+``Block`` is the shared step record: one anonymous ``MAP_SHARED`` mapping created BEFORE the
+environment workers are forked (``tonic/environments/distributed.py:97-109`` forks there too),
+with NumPy views of its float32 fields.  The environments of ``tonic_amd.environments`` write
+their step results straight into it and hand the views out as ``observations`` / ``infos``;
+the agent recognises those views by identity and page-locks the very same memory, so between
+the simulator's write and the GPU's read no byte is copied on the host.  Arrays that are not
+block views (any other environment) are copied into a private block first — same path after.
+
+``Collector`` is the agent side: the GPU handle around a block (``tonic_collector_create``).
+"""
+import ctypes
+import mmap
+import weakref
+
+import numpy as np
+
+from tonic_amd import _lib
+
+FIELDS = dict(eps0=0, observations=1, next_observations=2, rewards=3, resets=4, terminations=5,
+              eps1=6, actions=7, resets_u8=8, terminations_u8=9)
+
+
+class Block:
+    """One environment step of W workers in shared, page-aligned host memory."""
+
+    _live = weakref.WeakSet()
+
+    def __init__(self, workers, observation_size, action_size, worker_groups=1):
+        self.lib = lib = _lib.load()
+        self.workers, self.observation_size, self.action_size = workers, observation_size, action_size
+        nbytes = lib.tonic_collector_block_bytes(workers, observation_size, action_size)
+        if nbytes <= 0:
+            raise _lib.TonicHipError(f'bad collector block shape {workers, observation_size, action_size}')
+        self.memory = mmap.mmap(-1, nbytes)          # MAP_SHARED | MAP_ANONYMOUS: survives fork
+        self.nbytes = nbytes
+        self._anchor = ctypes.c_char.from_buffer(self.memory)
+        self.address = ctypes.addressof(self._anchor)
+        _lib.check(lib.tonic_collector_block_init(self.address, nbytes, workers, observation_size,
+                                                  action_size, worker_groups),
+                   'tonic_collector_block_init')
+        W, O, A = workers, observation_size, action_size
+
+        def view(name, shape, dtype=np.float32):
+            offset = lib.tonic_collector_block_offset(self.address, FIELDS[name])
+            count = int(np.prod(shape))
+            return np.frombuffer(self.memory, dtype, count, offset).reshape(shape)
+        self.observations = view('observations', (W, O))
+        self.next_observations = view('next_observations', (W, O))
+        self.rewards = view('rewards', (W,))
+        self.resets = view('resets', (W,))
+        self.terminations = view('terminations', (W,))
+        self.actions = view('actions', (W, A))
+        self.eps = (view('eps0', (W, A)), view('eps1', (W, A)))
+        self.resets_bool = view('resets_u8', (W,), np.bool_)
+        self.terminations_bool = view('terminations_u8', (W,), np.bool_)
+        # what `environment.step` hands out when it writes into this block (persistent views)
+        self.infos = dict(observations=self.next_observations, rewards=self.rewards,
+                          resets=self.resets_bool, terminations=self.terminations_bool)
+        Block._live.add(self)
+
+    @classmethod
+    def owner_of(cls, observations):
+        """The live block whose `observations` view this very array is (None otherwise)."""
+        for block in cls._live:
+            if block.observations is observations:
+                return block
+        return None
+
+    def set_flags(self, row, reset, termination):
+        self.resets[row] = reset
+        self.terminations[row] = termination
+        self.resets_bool[row] = reset
+        self.terminations_bool[row] = termination
+
+    # -- environment-side synchronisation (futex words in the block header; no HIP) -----------
+    def submit_actions(self):
+        _lib.check(self.lib.tonic_collector_submit_actions(self.address),
+                   'tonic_collector_submit_actions')
+
+    def wait_obs(self, timeout):
+        return self.lib.tonic_collector_wait_obs(self.address, float(timeout))
+
+    def worker_wait(self, seen, timeout=3600.0):
+        return self.lib.tonic_collector_worker_wait(self.address, seen, float(timeout))
+
+    def worker_done(self):
+        self.lib.tonic_collector_worker_done(self.address)
+
+    def shutdown(self):
+        self.lib.tonic_collector_shutdown(self.address)
+
+
+class Collector:
+    """GPU side of a block: fused act + store launches on the collector's own stream."""
+
+    def __init__(self, block, transport=0):
+        self.block = block
+        self.lib = lib = block.lib
+        handle = ctypes.c_void_p()
+        _lib.check(lib.tonic_collector_create(ctypes.byref(handle), block.address, transport),
+                   'tonic_collector_create')
+        self.handle = handle.value
+        self.transport = transport
+        self._step = lib.tonic_collector_ppo_step          # bound once: the per-step hot calls
+        self._wait = lib.tonic_collector_wait_actions
+
+    @classmethod
+    def for_block(cls, block, transport=0):
+        """One collector per block and transport (a block can only be page-locked once)."""
+        cache = block.__dict__.setdefault('_collectors', {})
+        if transport not in cache:
+            cache[transport] = cls(block, transport)
+        return cache[transport]
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.tonic_collector_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library may already be gone
+            pass
+
+    def bind_segment(self, buffers, norm_acc, rows):
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_collector_bind_segment(
+            self.handle, p(buffers['observations']), p(buffers['actions']),
+            p(buffers['next_observations']), p(buffers['rewards']), p(buffers['resets']),
+            p(buffers['terminations']), p(buffers['log_probs']), p(norm_acc), rows),
+            'tonic_collector_bind_segment')
+
+    def begin_rollout(self, actor_params):
+        _lib.check(self.lib.tonic_collector_begin_rollout(
+            self.handle, _lib.ptr(actor_params), _lib.current_stream()),
+            'tonic_collector_begin_rollout')
+
+    def ppo_step(self, row, eps_slot, store_previous):
+        status = self._step(self.handle, row, eps_slot, store_previous)
+        if status != 0:
+            _lib.check(status, 'tonic_collector_ppo_step')
+
+    def wait_actions(self, timeout=60.0):
+        status = self._wait(self.handle, timeout)
+        if status != 0:
+            _lib.check(status, 'tonic_collector_wait_actions')
+
+    def end_rollout(self, last_row):
+        _lib.check(self.lib.tonic_collector_end_rollout(self.handle, last_row,
+                                                        _lib.current_stream()),
+                   'tonic_collector_end_rollout')

@@ -1,0 +1,48 @@
+// The per-environment-step collect kernel (mlp64x16.hip) as seen by its two callers: the
+// device-resident entry points in mlp64x16.hip and the pinned-host collector (collector.hip).
+#pragma once
+#include "common.h"
+
+namespace tonic {
+
+// Pre-permuted MFMA operand image of the PPO actor (tonic_ppo_pack_actor).
+struct PackedActor {
+  int W1I, W2S, B1P, B2P, W3P, HC, total;
+  __host__ __device__ PackedActor(int ks1, int ap) {
+    W1I = 0; W2S = W1I + 4 * ks1 * 64; B1P = W2S + 4096; B2P = B1P + 64; W3P = B2P + 64;
+    HC = W3P + ap * 64; total = HC + 64;
+  }
+};
+
+struct Collect16Args {
+  const float* packed; const float* obs; const float* eps;
+  const float* next_obs; const float* rewards; const float* resets; const float* terminations;
+  float* seg_obs; float* seg_act; float* seg_next; float* seg_rew; float* seg_rst;
+  float* seg_term; float* seg_lp;
+  float* norm_acc; float* actions_out;
+  int64_t row, W;
+  int O, A;
+  // inputs of the NEXT step (null: none): touched early so that the next launch finds them in
+  // L2 / Infinity Cache instead of paying an HBM round trip on its critical path
+  const float* pf_eps; const float* pf_next_obs; const float* pf_rewards;
+  const float* pf_resets; const float* pf_terminations;
+  // Segment row that receives the transition outcome (next observations, rewards, flags).
+  // Device-resident collectors know the outcome of step `row` at launch time (outcome_row = row);
+  // with the host in the loop the outcome of step t only exists after the environment has
+  // consumed the actions, so the launch of step t stores the outcome of step t - 1
+  // (outcome_row = row - 1) and none at all for the first step of a rollout (outcome_row < 0).
+  int64_t outcome_row;
+  // Host-visible completion (null: none).  Every workgroup publishes its host writes, then bumps
+  // `done_counter` (device memory, zero between launches); the last one stores `done_seq` into
+  // `done_flag` (pinned host memory) — the host spins on that word instead of synchronising the
+  // stream, and knows that EVERY role has finished reading the pinned block.
+  unsigned* done_counter; unsigned* done_flag; unsigned done_seq;
+};
+
+int collect16_ks1(int O);
+int collect16_ap(int A);
+int launch_collect16(const Collect16Args& c, hipStream_t stream);
+int launch_actor_pack(const float* d_actor_params, float* d_packed, int O, int A,
+                      hipStream_t stream);
+
+}  // namespace tonic

@@ -1,0 +1,485 @@
+// Pinned-host batched collector (include/tonic_hip.h, "collector" section).
+//
+// replaces: the process boundary of tonic/environments/distributed.py:82-95,136-155 (one pickled
+//   Pipe message per worker group and step, one shared Queue back) and the host <-> device hops of
+//   tonic/torch/agents/a2c.py:41-73 (torch.as_tensor / .numpy() per step).
+//
+// One shared float32 BLOCK carries a whole environment step of all W workers:
+//   [header | eps0 | observations | next_observations | rewards | resets | terminations | eps1 |
+//    actions | resets_u8 | terminations_u8]
+// The environment side (parent + forked workers, no HIP) synchronises on two futex words in the
+// header: the parent bumps `go_seq` once per step for ALL worker groups, each group adds one to
+// `done_count`, the last one wakes the parent — two system calls per step on the parent whatever
+// the number of groups, against one Pipe.send per group + one Queue.get per group.
+// The agent side page-locks the same block (hipHostRegister), so the workers' memory IS the DMA
+// source: transport 0 lets the fused act kernel read observations / noise / the previous step's
+// outcome straight from the block over PCIe and write the actions (and a completion word the host
+// spins on) straight back; transport 1 moves the same bytes with hipMemcpyAsync on the
+// collector's own stream around the kernel and waits on an event — no stream synchronisation
+// either way.
+#include <errno.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <string.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <new>
+
+#include "collect16.h"
+
+namespace tonic {
+namespace {
+
+constexpr uint32_t kBlockMagic = 0x544f4e43u;        // "TONC"
+constexpr int64_t kHeaderBytes = 4096;
+constexpr int kFields = TONIC_COLLECTOR_FIELD_COUNT;
+
+struct BlockHeader {
+  uint32_t magic, version;
+  int64_t W;
+  int32_t O, A, groups, reserved;
+  int64_t total_bytes;
+  int64_t offset[kFields];                         // bytes from the start of the block
+  alignas(64) uint32_t go_seq;                     // futex: bumped once per environment step
+  alignas(64) uint32_t done_count;                 // futex: groups that finished the step
+  alignas(64) uint32_t shutdown;
+  alignas(64) uint32_t act_done_seq;               // written by the GPU (transport 0)
+};
+static_assert(sizeof(BlockHeader) <= kHeaderBytes, "header does not fit its page");
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+void layout(int64_t W, int O, int A, int64_t* offset, int64_t* total) {
+  const int64_t sizes[kFields] = {
+      W * A * 4,          // EPS0
+      W * O * 4,          // OBSERVATIONS
+      W * O * 4,          // NEXT_OBSERVATIONS
+      W * 4, W * 4, W * 4,// REWARDS, RESETS, TERMINATIONS
+      W * A * 4,          // EPS1
+      W * A * 4,          // ACTIONS
+      W, W};              // RESETS_U8, TERMINATIONS_U8
+  int64_t at = kHeaderBytes;
+  for (int f = 0; f < kFields; ++f) {
+    offset[f] = at;
+    at = align_up(at + sizes[f], 256);
+  }
+  *total = align_up(at, 4096);
+}
+
+BlockHeader* header_of(void* block) {
+  BlockHeader* h = static_cast<BlockHeader*>(block);
+  return (h != nullptr && h->magic == kBlockMagic) ? h : nullptr;
+}
+
+long futex(uint32_t* word, int op, uint32_t value, const timespec* timeout) {
+  return syscall(SYS_futex, word, op, value, timeout, nullptr, 0);
+}
+
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// Waits until *word != seen (returns true) or the deadline passes: a short spin first (the
+// common case when everybody is fast), then FUTEX_WAIT slices.
+bool wait_change(uint32_t* word, uint32_t seen, double timeout_s, int spin_iterations) {
+  for (int i = 0; i < spin_iterations; ++i) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != seen) return true;
+    cpu_relax();
+  }
+  const double deadline = now_s() + timeout_s;
+  for (;;) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != seen) return true;
+    const double left = deadline - now_s();
+    if (left <= 0) return false;
+    const double slice = left < 0.5 ? left : 0.5;
+    timespec ts{(time_t)slice, (long)((slice - (time_t)slice) * 1e9)};
+    futex(word, FUTEX_WAIT, seen, &ts);            // EAGAIN / EINTR / ETIMEDOUT: re-check
+  }
+}
+
+}  // namespace
+}  // namespace tonic
+
+using namespace tonic;
+
+// ---------------------------------------------------------------- block: layout + worker sync
+
+extern "C" int64_t tonic_collector_block_bytes(int64_t W, int32_t O, int32_t A) {
+  if (W <= 0 || O <= 0 || A <= 0) return -1;
+  int64_t offset[kFields], total;
+  layout(W, O, A, offset, &total);
+  return total;
+}
+
+extern "C" int tonic_collector_block_init(void* block, int64_t bytes, int64_t W, int32_t O,
+                                          int32_t A, int32_t groups) {
+  TONIC_REQUIRE(block != nullptr && W > 0 && O > 0 && A > 0 && groups > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_block_init: bad argument");
+  TONIC_REQUIRE((reinterpret_cast<uintptr_t>(block) & 4095) == 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_block_init: the block must be page aligned");
+  BlockHeader h;
+  memset(&h, 0, sizeof(h));
+  layout(W, O, A, h.offset, &h.total_bytes);
+  TONIC_REQUIRE(bytes >= h.total_bytes, TONIC_ERR_WORKSPACE,
+                "tonic_collector_block_init: %lld bytes given, %lld needed", (long long)bytes,
+                (long long)h.total_bytes);
+  h.magic = kBlockMagic;
+  h.version = 1;
+  h.W = W; h.O = O; h.A = A; h.groups = groups;
+  memset(block, 0, (size_t)h.total_bytes);
+  memcpy(block, &h, sizeof(h));
+  return TONIC_OK;
+}
+
+extern "C" int64_t tonic_collector_block_offset(const void* block, int32_t field) {
+  const BlockHeader* h = header_of(const_cast<void*>(block));
+  if (h == nullptr || field < 0 || field >= kFields) return -1;
+  return h->offset[field];
+}
+
+extern "C" int64_t tonic_collector_worker_wait(void* block, int64_t seen, double timeout_s) {
+  BlockHeader* h = header_of(block);
+  if (h == nullptr) return -3;
+  // Workers sleep: an environment step is far longer than a futex wake-up, and W Python
+  // processes spinning would starve each other.
+  const double deadline = now_s() + timeout_s;
+  for (;;) {
+    if (__atomic_load_n(&h->shutdown, __ATOMIC_ACQUIRE)) return -1;
+    const uint32_t now = __atomic_load_n(&h->go_seq, __ATOMIC_ACQUIRE);
+    if (now != (uint32_t)seen) return (int64_t)now;
+    const double left = deadline - now_s();
+    if (left <= 0) return -2;
+    if (!wait_change(&h->go_seq, (uint32_t)seen, left < 0.5 ? left : 0.5, 200)) continue;
+  }
+}
+
+extern "C" int tonic_collector_worker_done(void* block) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_worker_done: bad block");
+  const uint32_t before = __atomic_fetch_add(&h->done_count, 1u, __ATOMIC_ACQ_REL);
+  if (before + 1 == (uint32_t)h->groups) futex(&h->done_count, FUTEX_WAKE, 1, nullptr);
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_submit_actions(void* block) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_submit_actions: bad block");
+  __atomic_store_n(&h->done_count, 0u, __ATOMIC_RELEASE);       // every group is idle here
+  __atomic_fetch_add(&h->go_seq, 1u, __ATOMIC_ACQ_REL);
+  futex(&h->go_seq, FUTEX_WAKE, INT_MAX, nullptr);
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_wait_obs(void* block, double timeout_s) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_wait_obs: bad block");
+  const uint32_t groups = (uint32_t)h->groups;
+  const double deadline = now_s() + timeout_s;
+  for (;;) {
+    const uint32_t count = __atomic_load_n(&h->done_count, __ATOMIC_ACQUIRE);
+    if (count >= groups) return TONIC_OK;
+    const double left = deadline - now_s();
+    if (left <= 0) {
+      set_error("tonic_collector_wait_obs: %u of %u worker groups answered within %.1f s", count,
+                groups, timeout_s);
+      return TONIC_ERR_TIMEOUT;
+    }
+    wait_change(&h->done_count, count, left, 2000);
+  }
+}
+
+extern "C" int tonic_collector_shutdown(void* block) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_shutdown: bad block");
+  __atomic_store_n(&h->shutdown, 1u, __ATOMIC_RELEASE);
+  __atomic_fetch_add(&h->go_seq, 1u, __ATOMIC_ACQ_REL);
+  futex(&h->go_seq, FUTEX_WAKE, INT_MAX, nullptr);
+  return TONIC_OK;
+}
+
+// ------------------------------------------------------------------------------ GPU side
+
+struct tonic_collector {
+  BlockHeader* host;            // the shared block (host address)
+  char* mapped;                 // device-visible alias of the block (hipHostGetDevicePointer)
+  char* staged;                 // transport 1: device copy of the block's fields
+  int64_t W;
+  int O, A, transport;
+  bool registered;
+  hipStream_t stream;
+  hipEvent_t learner_done, collect_done, actions_out;
+  float* d_packed;
+  unsigned* d_counter;
+  float* seg[7];                // observations, actions, next_observations, rewards, resets,
+  float* norm_acc;              //   terminations, log_probs
+  int64_t rows;
+  unsigned seq;
+  bool actor_packed, waiting;
+};
+
+namespace {
+
+#define TONIC_HIP(call, what)                                                       \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      set_error("%s: %s", (what), hipGetErrorString(e__));                          \
+      return TONIC_ERR_LAUNCH;                                                      \
+    }                                                                               \
+  } while (0)
+
+// Where the kernels read / write field `f`: the mapped block (transport 0) or its device copy.
+float* field(tonic_collector* c, int f) {
+  char* base = c->transport == 0 ? c->mapped : c->staged;
+  return reinterpret_cast<float*>(base + c->host->offset[f]);
+}
+
+// The outcome of one environment step -> Segment row (the copy role of the collect kernel on its
+// own, for the last step of a rollout).
+__global__ void outcome_store_kernel(const float* next_obs, const float* rewards,
+                                     const float* resets, const float* terminations,
+                                     float* seg_next, float* seg_rew, float* seg_rst,
+                                     float* seg_term, int64_t row, int64_t W, int O) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = tid; i < W * O; i += stride) seg_next[row * W * O + i] = next_obs[i];
+  for (int64_t i = tid; i < W; i += stride) {
+    seg_rew[row * W + i] = rewards[i];
+    seg_rst[row * W + i] = resets[i];
+    seg_term[row * W + i] = terminations[i];
+  }
+}
+
+// transport 1: the step's inputs as ONE host-to-device copy (the fields are laid out so that
+// either noise slot is contiguous with the observation / outcome fields).
+int stage_inputs(tonic_collector* c, int eps_slot) {
+  const BlockHeader* h = c->host;
+  const int first = eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_OBSERVATIONS;
+  const int last = eps_slot == 1 ? TONIC_COLLECTOR_EPS1 : TONIC_COLLECTOR_TERMINATIONS;
+  const int64_t begin = h->offset[first], end = h->offset[last + 1];
+  TONIC_HIP(hipMemcpyAsync(c->staged + begin, reinterpret_cast<char*>(c->host) + begin,
+                           (size_t)(end - begin), hipMemcpyHostToDevice, c->stream),
+            "tonic_collector: H2D of the step inputs");
+  return TONIC_OK;
+}
+
+}  // namespace
+
+extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport) {
+  TONIC_REQUIRE(out != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_create: out is NULL");
+  *out = nullptr;
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_create: not an initialised collector block");
+  TONIC_REQUIRE(transport == 0 || transport == 1, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_create: transport must be 0 (mapped) or 1 (hipMemcpyAsync)");
+  TONIC_REQUIRE(h->O <= 32 && h->A <= 8, TONIC_ERR_UNSUPPORTED_SHAPE,
+                "tonic_collector_create: the fused act kernel serves O <= 32, A <= 8 (got %d, %d)",
+                h->O, h->A);
+  tonic_collector* c = new (std::nothrow) tonic_collector();
+  TONIC_REQUIRE(c != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_create: out of memory");
+  memset(c, 0, sizeof(*c));
+  c->host = h; c->W = h->W; c->O = h->O; c->A = h->A; c->transport = transport;
+  auto fail = [&](const char* what, hipError_t e) {
+    set_error("tonic_collector_create: %s: %s", what, hipGetErrorString(e));
+    tonic_collector_destroy(c);
+    return TONIC_ERR_LAUNCH;
+  };
+  hipError_t e = hipHostRegister(block, (size_t)h->total_bytes, hipHostRegisterMapped);
+  if (e == hipErrorHostMemoryAlreadyRegistered) {
+    (void)hipGetLastError();          // a second collector on the same block: it stays locked
+  } else if (e != hipSuccess) {
+    return fail("hipHostRegister of the shared block", e);
+  } else {
+    c->registered = true;
+  }
+  void* mapped = nullptr;
+  if ((e = hipHostGetDevicePointer(&mapped, block, 0)) != hipSuccess)
+    return fail("hipHostGetDevicePointer", e);
+  c->mapped = static_cast<char*>(mapped);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+    return fail("hipStreamCreate", e);
+  if ((e = hipEventCreateWithFlags(&c->learner_done, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->collect_done, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->actions_out, hipEventDisableTiming)) != hipSuccess)
+    return fail("hipEventCreate", e);
+  const int64_t packed = PackedActor(collect16_ks1(c->O), collect16_ap(c->A)).total;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_packed), packed * 4)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->d_counter), 256)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess)
+    return fail("hipMalloc of the collector scratch", e);
+  if ((e = hipMemset(c->d_counter, 0, 256)) != hipSuccess ||
+      (e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
+    return fail("hipMemset", e);
+  c->seq = __atomic_load_n(&h->act_done_seq, __ATOMIC_ACQUIRE);
+  *out = c;
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
+  if (c == nullptr) return TONIC_OK;
+  // teardown: nothing useful can be done about a failing release
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->d_packed) (void)hipFree(c->d_packed);
+  if (c->d_counter) (void)hipFree(c->d_counter);
+  if (c->staged) (void)hipFree(c->staged);
+  if (c->learner_done) (void)hipEventDestroy(c->learner_done);
+  if (c->collect_done) (void)hipEventDestroy(c->collect_done);
+  if (c->actions_out) (void)hipEventDestroy(c->actions_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->registered) (void)hipHostUnregister(c->host);
+  delete c;
+  return TONIC_OK;
+}
+
+extern "C" void* tonic_collector_stream(tonic_collector_t* c) {
+  return c != nullptr ? c->stream : nullptr;
+}
+
+extern "C" int tonic_collector_bind_segment(
+    tonic_collector_t* c, float* d_seg_observations, float* d_seg_actions,
+    float* d_seg_next_observations, float* d_seg_rewards, float* d_seg_resets,
+    float* d_seg_terminations, float* d_seg_log_probs, float* d_norm_acc, int64_t rows) {
+  TONIC_REQUIRE(c && d_seg_observations && d_seg_actions && d_seg_next_observations &&
+                    d_seg_rewards && d_seg_resets && d_seg_terminations && d_seg_log_probs &&
+                    rows > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_bind_segment: bad argument");
+  float* seg[7] = {d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
+                   d_seg_resets, d_seg_terminations, d_seg_log_probs};
+  memcpy(c->seg, seg, sizeof(seg));
+  c->norm_acc = d_norm_acc;
+  c->rows = rows;
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_begin_rollout(tonic_collector_t* c, const float* d_actor_params,
+                                             void* learner_stream) {
+  TONIC_REQUIRE(c && d_actor_params, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_begin_rollout: bad argument");
+  // the parameters were written on the learner's stream: order the pack behind them
+  TONIC_HIP(hipEventRecord(c->learner_done, as_stream(learner_stream)), "hipEventRecord");
+  TONIC_HIP(hipStreamWaitEvent(c->stream, c->learner_done, 0), "hipStreamWaitEvent");
+  const int status = launch_actor_pack(d_actor_params, c->d_packed, c->O, c->A, c->stream);
+  if (status != TONIC_OK) return status;
+  c->actor_packed = true;
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32_t eps_slot,
+                                        int32_t store_previous) {
+  TONIC_REQUIRE(c && c->seg[0] && c->actor_packed, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_ppo_step: bind_segment / begin_rollout first");
+  TONIC_REQUIRE(row >= 0 && row < c->rows && eps_slot >= -1 && eps_slot <= 1 &&
+                    (!store_previous || row > 0),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_ppo_step: bad row %lld / slot %d",
+                (long long)row, eps_slot);
+  TONIC_REQUIRE(!c->waiting, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_ppo_step: the previous step's actions were never waited for");
+  if (c->transport == 1) {
+    const int status = stage_inputs(c, eps_slot < 0 ? 0 : eps_slot);
+    if (status != TONIC_OK) return status;
+  }
+  c->seq += 1;
+  Collect16Args a{};
+  a.packed = c->d_packed;
+  a.obs = field(c, TONIC_COLLECTOR_OBSERVATIONS);
+  a.eps = eps_slot < 0 ? nullptr
+                       : field(c, eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_EPS1);
+  a.next_obs = field(c, TONIC_COLLECTOR_NEXT_OBSERVATIONS);
+  a.rewards = field(c, TONIC_COLLECTOR_REWARDS);
+  a.resets = field(c, TONIC_COLLECTOR_RESETS);
+  a.terminations = field(c, TONIC_COLLECTOR_TERMINATIONS);
+  a.seg_obs = c->seg[0]; a.seg_act = c->seg[1]; a.seg_next = c->seg[2]; a.seg_rew = c->seg[3];
+  a.seg_rst = c->seg[4]; a.seg_term = c->seg[5]; a.seg_lp = c->seg[6];
+  a.norm_acc = c->norm_acc;
+  a.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
+  a.row = row; a.W = c->W; a.O = c->O; a.A = c->A;
+  a.outcome_row = store_previous ? row - 1 : -1;
+  if (c->transport == 0) {
+    a.done_counter = c->d_counter;
+    a.done_flag = reinterpret_cast<unsigned*>(c->mapped + offsetof(BlockHeader, act_done_seq));
+    a.done_seq = c->seq;
+  }
+  const int status = launch_collect16(a, c->stream);
+  if (status != TONIC_OK) return status;
+  if (c->transport == 1) {
+    const int64_t at = c->host->offset[TONIC_COLLECTOR_ACTIONS];
+    TONIC_HIP(hipMemcpyAsync(reinterpret_cast<char*>(c->host) + at, c->staged + at,
+                             (size_t)(c->W * c->A * 4), hipMemcpyDeviceToHost, c->stream),
+              "tonic_collector: D2H of the actions");
+    TONIC_HIP(hipEventRecord(c->actions_out, c->stream), "hipEventRecord");
+  }
+  c->waiting = true;
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout_s) {
+  TONIC_REQUIRE(c && c->waiting, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_wait_actions: no step in flight");
+  const double deadline = now_s() + timeout_s;
+  uint32_t* flag = &c->host->act_done_seq;
+  for (uint64_t spins = 0;; ++spins) {
+    bool done;
+    if (c->transport == 0) {
+      done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->seq;
+    } else {
+      const hipError_t e = hipEventQuery(c->actions_out);
+      if (e != hipSuccess && e != hipErrorNotReady) {
+        set_error("tonic_collector_wait_actions: %s", hipGetErrorString(e));
+        return TONIC_ERR_LAUNCH;
+      }
+      done = e == hipSuccess;
+    }
+    if (done) break;
+    cpu_relax();
+    if ((spins & 0xfff) == 0xfff) {
+      if (c->transport == 0) {          // a failed launch never writes the flag: look at the stream
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) {
+          set_error("tonic_collector_wait_actions: %s", hipGetErrorString(e));
+          return TONIC_ERR_LAUNCH;
+        }
+      }
+      if (now_s() > deadline) {
+        set_error("tonic_collector_wait_actions: no actions within %.1f s", timeout_s);
+        return TONIC_ERR_TIMEOUT;
+      }
+    }
+  }
+  c->waiting = false;
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_row,
+                                           void* learner_stream) {
+  TONIC_REQUIRE(c && c->seg[0] && last_row < c->rows && !c->waiting, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_end_rollout: bad argument");
+  if (last_row >= 0) {
+    if (c->transport == 1) {
+      const int status = stage_inputs(c, 0);
+      if (status != TONIC_OK) return status;
+    }
+    const int64_t items = c->W * c->O;
+    const int blocks = (int)((items + 255) / 256 < 64 ? (items + 255) / 256 : 64);
+    hipLaunchKernelGGL(outcome_store_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                       field(c, TONIC_COLLECTOR_NEXT_OBSERVATIONS),
+                       field(c, TONIC_COLLECTOR_REWARDS), field(c, TONIC_COLLECTOR_RESETS),
+                       field(c, TONIC_COLLECTOR_TERMINATIONS), c->seg[2], c->seg[3], c->seg[4],
+                       c->seg[5], last_row, c->W, c->O);
+    TONIC_CHECK_LAUNCH("outcome_store_kernel");
+  }
+  // The learner reads the Segment on its own stream; the block may be overwritten by the next
+  // environment step as soon as this call returns.
+  TONIC_HIP(hipEventRecord(c->collect_done, c->stream), "hipEventRecord");
+  TONIC_HIP(hipStreamWaitEvent(as_stream(learner_stream), c->collect_done, 0),
+            "hipStreamWaitEvent");
+  TONIC_HIP(hipEventSynchronize(c->collect_done), "hipEventSynchronize");
+  c->actor_packed = false;            // the learner is about to change the parameters
+  return TONIC_OK;
+}

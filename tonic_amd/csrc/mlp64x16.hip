@@ -20,6 +20,7 @@
 //             produced by a transpose through a private LDS tile (row stride 24 floats:
 //             conflict-free ds_read_b128).
 #include "mlp64.h"
+#include "collect16.h"
 
 namespace tonic {
 
@@ -619,14 +620,6 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 // `actor_pack_kernel` therefore writes the pre-permuted operand images ONCE per learner update
 // into HBM (L2-resident afterwards) and `ppo_collect16_kernel` streams its MFMA A operands
 // straight from that image (lane-linear, coalesced) — no weight staging through LDS.
-struct PackedActor {
-  int W1I, W2S, B1P, B2P, W3P, HC, total;
-  __host__ __device__ PackedActor(int ks1, int ap) {
-    W1I = 0; W2S = W1I + 4 * ks1 * 64; B1P = W2S + 4096; B2P = B1P + 64; W3P = B2P + 64;
-    HC = W3P + ap * 64; total = HC + 64;
-  }
-};
-
 __global__ void actor_pack_kernel(const float* params, float* packed, int O, int A, int ks1,
                                   int ap) {
   const PackedActor L(ks1, ap);
@@ -671,20 +664,6 @@ __global__ void actor_pack_kernel(const float* params, float* packed, int O, int
   }
 }
 
-struct Collect16Args {
-  const float* packed; const float* obs; const float* eps;
-  const float* next_obs; const float* rewards; const float* resets; const float* terminations;
-  float* seg_obs; float* seg_act; float* seg_next; float* seg_rew; float* seg_rst;
-  float* seg_term; float* seg_lp;
-  float* norm_acc; float* actions_out;
-  int64_t row, W;
-  int O, A;
-  // inputs of the NEXT step (null: none): touched early so that the next launch finds them in
-  // L2 / Infinity Cache instead of paying an HBM round trip on its critical path
-  const float* pf_eps; const float* pf_next_obs; const float* pf_rewards;
-  const float* pf_resets; const float* pf_terminations;
-};
-
 // Loads whose values are needed by nobody: the addresses are touched and the results only fold
 // into `sink`, which `retire_touches` consumes at the END of the workgroup's work (a store that
 // never executes for real data) — so the loads stay in flight behind everything else instead of
@@ -694,6 +673,22 @@ __device__ __forceinline__ void touch(const float* p, float& sink) {
 }
 __device__ __forceinline__ void retire_touches(float sink, float* never_written) {
   if (sink == 1.2345e-38f) *never_written = sink;
+}
+
+// End of a workgroup's role when the host is waiting on this launch (Collect16Args::done_flag).
+__device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
+  if (c.done_flag == nullptr) return;
+  __threadfence_system();                 // this thread's writes to pinned host memory are out
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = __hip_atomic_fetch_add(c.done_counter, 1u, __ATOMIC_ACQ_REL,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == gridDim.x - 1) {
+      __hip_atomic_store(c.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(c.done_flag, c.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
@@ -722,8 +717,9 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
         touch(c.pf_terminations + i, sink);
       }
     }
-    {  // all of this thread's loads first, then the stores (a plain copy loop waits per element)
-      float* dst = c.seg_next + c.row * W * O;
+    if (c.outcome_row >= 0) {
+      // all of this thread's loads first, then the stores (a plain copy loop waits per element)
+      float* dst = c.seg_next + c.outcome_row * W * O;
       int64_t i = part * 256 + tid;
       for (; i + 7 * stride < W * O; i += 8 * stride) {
         float v[8];
@@ -733,27 +729,29 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
         for (int u = 0; u < 8; ++u) dst[i + u * stride] = v[u];
       }
       for (; i < W * O; i += stride) dst[i] = c.next_obs[i];
-    }
-    for (int64_t i = part * 256 + tid; i < W; i += stride) {
-      const float rew = c.rewards[i], rst = c.resets[i], term = c.terminations[i];
-      c.seg_rew[c.row * W + i] = rew;
-      c.seg_rst[c.row * W + i] = rst;
-      c.seg_term[c.row * W + i] = term;
+      for (i = part * 256 + tid; i < W; i += stride) {
+        const float rew = c.rewards[i], rst = c.resets[i], term = c.terminations[i];
+        c.seg_rew[c.outcome_row * W + i] = rew;
+        c.seg_rst[c.outcome_row * W + i] = rst;
+        c.seg_term[c.outcome_row * W + i] = term;
+      }
     }
     retire_touches(sink, c.seg_next);
+    collect_signal_done(c);
     return;
   }
   if (blockIdx.x == gridDim.x - 1) {
     // MeanStd.record (mean_stds.py:44-48): values and their squares staged side by side, the sum
     // chain on wave 0 and the sum-of-squares chain on wave 1
-    if (c.norm_acc == nullptr) return;
+    if (c.norm_acc == nullptr) { collect_signal_done(c); return; }
     constexpr int kHalf = kCollectLds / 2;
     const int lane = tid & 63, wave = tid >> 6;
     // The next launch's record reads this step's next observations (trainer.py:44-56 hands them
     // back as the observations of step t + 1): touch them now, from the workgroup slot that will
     // need them, so that the sequential chain does not start behind an HBM round trip.
     float sink = 0.f;
-    for (int64_t i = (int64_t)tid * 16; i < W * O; i += 256 * 16) touch(c.next_obs + i, sink);
+    if (c.pf_next_obs != nullptr || c.outcome_row == c.row)      // (device-resident callers only)
+      for (int64_t i = (int64_t)tid * 16; i < W * O; i += 256 * 16) touch(c.next_obs + i, sink);
     float acc = 0.f;
     if (wave < 2 && lane < O) acc = c.norm_acc[wave * O + lane];
     const int64_t rows_per_chunk = kHalf / O;
@@ -782,6 +780,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     }
     if (wave < 2 && lane < O) c.norm_acc[wave * O + lane] = acc;
     retire_touches(sink, c.norm_acc);
+    collect_signal_done(c);
     return;
   }
   // Actor: ONE 16-sample tile per workgroup; wave w owns output-feature tile w (16 of the 64
@@ -891,6 +890,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
   retire_touches(eps_sink, c.seg_lp);
+  collect_signal_done(c);
 }
 
 // ------------------------------------------------------------------------------- host side
@@ -968,8 +968,16 @@ int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& arg
 
 using namespace tonic;
 
-static int collect16_ks1(int O) { return O <= 4 ? 1 : O <= 20 ? 5 : 8; }
-static int collect16_ap(int A) { return A <= 1 ? 1 : A <= 6 ? 6 : 8; }
+int tonic::collect16_ks1(int O) { return O <= 4 ? 1 : O <= 20 ? 5 : 8; }
+int tonic::collect16_ap(int A) { return A <= 1 ? 1 : A <= 6 ? 6 : 8; }
+
+int tonic::launch_actor_pack(const float* d_actor_params, float* d_packed, int O, int A,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(actor_pack_kernel, dim3(8), dim3(256), 0, stream, d_actor_params, d_packed,
+                     O, A, collect16_ks1(O), collect16_ap(A));
+  TONIC_CHECK_LAUNCH("tonic_ppo_pack_actor");
+  return TONIC_OK;
+}
 
 extern "C" int64_t tonic_ppo_packed_actor_floats(int32_t O, int32_t A) {
   return PackedActor(collect16_ks1(O), collect16_ap(A)).total;
@@ -979,15 +987,10 @@ extern "C" int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed
                                     int32_t A, void* stream) {
   TONIC_REQUIRE(d_actor_params && d_packed && O >= 1 && O <= 32 && A >= 1 && A <= 8,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_pack_actor: bad argument");
-  hipLaunchKernelGGL(actor_pack_kernel, dim3(8), dim3(256), 0, as_stream(stream),
-                     d_actor_params, d_packed, O, A, collect16_ks1(O), collect16_ap(A));
-  TONIC_CHECK_LAUNCH("tonic_ppo_pack_actor");
-  return TONIC_OK;
+  return launch_actor_pack(d_actor_params, d_packed, O, A, as_stream(stream));
 }
 
-namespace {
-
-int launch_collect16(const Collect16Args& c, hipStream_t st) {
+int tonic::launch_collect16(const Collect16Args& c, hipStream_t st) {
   const int64_t tiles = (c.W + 15) / 16;
   const int act_blocks = (int)(tiles < 4096 ? tiles : 4096);       // one tile per workgroup
   const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
@@ -1000,10 +1003,9 @@ int launch_collect16(const Collect16Args& c, hipStream_t st) {
   TONIC_COLLECT16(5, 1) TONIC_COLLECT16(5, 6) TONIC_COLLECT16(5, 8)
   TONIC_COLLECT16(8, 1) TONIC_COLLECT16(8, 6) TONIC_COLLECT16(8, 8) {}
 #undef TONIC_COLLECT16
+  TONIC_CHECK_LAUNCH("ppo_collect16_kernel");
   return TONIC_OK;
 }
-
-}  // namespace
 
 extern "C" int tonic_ppo_collect_steps_packed(
     const float* d_packed_actor, const float* d_observations, const float* d_eps,
@@ -1024,7 +1026,8 @@ extern "C" int tonic_ppo_collect_steps_packed(
                     d_rewards + t * W, d_resets + t * W, d_terminations + t * W,
                     d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
                     d_seg_resets, d_seg_terminations, d_seg_log_probs, d_norm_acc, nullptr,
-                    row0 + t, W, O, A, nullptr, nullptr, nullptr, nullptr, nullptr};
+                    row0 + t, W, O, A, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    row0 + t, nullptr, nullptr, 0u};
     if (t + 1 < steps) {                         // the next step's inputs exist: touch them early
       c.pf_eps = d_eps ? d_eps + (t + 1) * W * A : nullptr;
       c.pf_next_obs = obs + 2 * W * O;
@@ -1055,7 +1058,7 @@ extern "C" int tonic_ppo_collect_step_packed(
                   d_resets, d_terminations, d_seg_observations, d_seg_actions,
                   d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
                   d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A,
-                  nullptr, nullptr, nullptr, nullptr, nullptr};
+                  nullptr, nullptr, nullptr, nullptr, nullptr, row, nullptr, nullptr, 0u};
   launch_collect16(c, as_stream(stream));
   TONIC_CHECK_LAUNCH("tonic_ppo_collect_step_packed");
   return TONIC_OK;

@@ -41,42 +41,87 @@ class Synthetic:
 
 
 class SyntheticBatch:
-    """W synthetic workers stepped at once (one RandomState for the whole batch)."""
+    """W synthetic workers stepped at once (one RandomState for the whole batch), writing into a
+    collector block like ``Sequential`` / ``Parallel`` do and handing out its views.
+
+    ``pool`` > 0 pre-generates that many observation batches and cycles through them, so that a
+    step costs two row copies and the reward instead of W*O fresh normal draws: the simulator
+    then costs (almost) nothing and a loop over it measures the collector and the agent."""
 
     def __init__(self, workers, observation_size, action_size, max_episode_steps=1000,
-                 termination_probability=0.0, name=None):
+                 termination_probability=0.0, name=None, pool=0, copy_outputs=False):
         self.workers = workers
         self.observation_space = Box(-np.inf, np.inf, (observation_size,))
         self.action_space = Box(-1, 1, (action_size,))
         self.max_episode_steps = max_episode_steps
         self.termination_probability = termination_probability
         self.name = name or f'synthetic-{observation_size}-{action_size}'
+        self.pool = pool
+        self.copy_outputs = copy_outputs
 
     def initialize(self, seed):
         self.random = np.random.RandomState(seed)
+        if self.pool:
+            shape = (self.pool, self.workers) + self.observation_space.shape
+            self._pool = self.random.standard_normal(shape).astype(np.float32)
+            self._cursor = 0
 
     def _observe(self):
+        if self.pool:
+            self._cursor = (self._cursor + 1) % self.pool
+            return self._pool[self._cursor]
         shape = (self.workers,) + self.observation_space.shape
         return self.random.standard_normal(shape).astype(np.float32)
 
     def start(self):
+        from tonic_amd.collector import Block
+        self.block = Block(self.workers, self.observation_space.shape[0],
+                           self.action_space.shape[0])
         self.lengths = np.zeros(self.workers, int)
-        self.observations = self._observe()
-        return self.observations.copy()
+        self._flags = np.zeros(self.workers, bool)
+        self._quiet = 0                  # steps taken since `lengths` was last brought up to date
+        self._flags_set = False
+        self.block.observations[:] = self._observe()
+        return self.block.observations.copy() if self.copy_outputs else self.block.observations
+
+    def _outputs(self):
+        block = self.block
+        if self.copy_outputs:
+            return block.observations.copy(), {k: v.copy() for k, v in block.infos.items()}
+        return block.observations, dict(block.infos)
+
+    def _write_flags(self, resets, terminations):
+        block = self.block
+        np.copyto(block.resets, resets)
+        np.copyto(block.terminations, terminations)
+        np.copyto(block.resets_bool, resets)
+        np.copyto(block.terminations_bool, terminations)
 
     def step(self, actions):
+        block = self.block
         next_observations = self._observe()
-        rewards = -np.square(np.asarray(actions, np.float32)).sum(-1)
-        self.lengths += 1
+        np.copyto(block.next_observations, next_observations)
+        np.copyto(block.observations, next_observations)
+        np.einsum('ij,ij->i', actions, actions, out=block.rewards, casting='same_kind')
+        np.negative(block.rewards, out=block.rewards)
+        if self.termination_probability <= 0 and \
+                self._quiet + 1 + self.lengths.max() < self.max_episode_steps:
+            # nobody can time out at this step: the flags stay all False
+            self._quiet += 1
+            if self._flags_set:
+                self._write_flags(self._flags, self._flags)
+                self._flags_set = False
+            return self._outputs()
+        self.lengths += self._quiet + 1
+        self._quiet = 0
         if self.termination_probability > 0:
             terminations = self.random.uniform(size=self.workers) < self.termination_probability
         else:
-            terminations = np.zeros(self.workers, bool)
+            terminations = self._flags                          # all False
         resets = terminations | (self.lengths == self.max_episode_steps)
-        observations = next_observations.copy()
         if resets.any():
-            observations[resets] = self._observe()[resets]
+            block.observations[resets] = self._observe()[resets]
             self.lengths[resets] = 0
-        infos = dict(observations=next_observations, rewards=rewards.astype(np.float32),
-                     resets=resets, terminations=terminations)
-        return observations, infos
+        self._write_flags(resets, terminations)
+        self._flags_set = True
+        return self._outputs()

@@ -1,18 +1,22 @@
-"""PPO on the HIP engine — API of ``tonic/torch/agents/{agent,a2c,ppo}.py``.
+"""PPO / DDPG / TD3 / SAC on the HIP engine — API of ``tonic/torch/agents/*.py``.
 
 ``step`` / ``update`` keep the reference signatures (NumPy in, NumPy out) so
-``tonic.Trainer`` drives the agent unchanged.  Per environment step the host does one pinned
-H2D copy (observations + pre-drawn standard-normal noise), one ``tonic_ppo_act`` launch and
-one D2H copy of the actions; ``update`` stages the transition outcome and launches
-``tonic_segment_store`` (which also advances the observation-normaliser sums).  Every
-``Segment.size`` steps ``_update`` enqueues the whole learner update
-(2 x value forward, GAE scan, ``batch_iterations`` x [actor grad+Adam, critic grad+Adam])
-without any host synchronisation — the KL early stop of ppo.py:45-46 is a device flag — and
-reads the logged statistics back once.
+``tonic.Trainer`` drives the agents unchanged.  The on-policy agents talk to the GPU through
+the pinned-host collector (``tonic_amd.collector``, ``tonic_collector_*``): per environment
+step ONE fused launch — policy forward + sample + log-prob of the block's observations,
+Segment row store, ``MeanStd.record``, and the deferred store of the previous step's outcome —
+reads the environment's shared block in place and writes the actions back into it; the host
+waits on a completion word, not on the stream, and draws the next step's noise meanwhile.
+``update`` only marks the outcome that sits in the block as pending.  Every ``Segment.size``
+steps ``_update`` enqueues the whole learner update (2 x value forward, GAE scan,
+``batch_iterations`` x [actor grad+Adam, critic grad+Adam]) without any host synchronisation —
+the KL early stop of ppo.py:45-46 is a device flag — and reads the logged statistics back once.
 
 The action noise is drawn on the host with ``torch.randn`` from the global CPU generator,
 which consumes the same stream as the reference's ``Normal.sample()``, so
-runs with equal seeds follow the reference's trajectory up to float32 rounding.
+runs with equal seeds follow the reference's trajectory up to float32 rounding.  The draw for
+step t+1 is made while the GPU works on step t; ``test_step`` (which draws from the same
+generator, a2c.py:87-90) first rewinds the generator to where the reference would be.
 """
 import os
 import random
@@ -21,6 +25,7 @@ import numpy as np
 import torch
 
 from tonic_amd import _lib, agents, explorations, logger, replays
+from tonic_amd.collector import Block, Collector
 from tonic_amd.torch import models, normalizers, updaters
 
 
@@ -122,7 +127,9 @@ class A2C(Agent):
         self.critic_updater.initialize(self.model)
         self.observation_size = observation_space.shape[0]
         self.action_size = action_space.shape[0]
-        self._workers = None
+        self._collector = None
+        # 0: the act kernel reads / writes the page-locked block in place; 1: hipMemcpyAsync
+        self.transport = int(os.environ.get('TONIC_AMD_COLLECTOR_TRANSPORT', '0'))
 
     # ------------------------------------------------------------------ acting
     def _io(self, workers):
@@ -131,6 +138,7 @@ class A2C(Agent):
                 _Staging([('actions', (W, A)), ('log_probs', (W,))], self.device))
 
     def _act(self, observations, stage_in, stage_out, want_log_probs):
+        """Stand-alone forward + sample (test episodes): staging copies and a stream sync."""
         W, A = observations.shape[0], self.action_size
         stage_in.host_view('observations')[:] = observations
         # Same generator draw as Normal.sample() in the reference (a2c.py:81).
@@ -146,21 +154,56 @@ class A2C(Agent):
         torch.cuda.current_stream().synchronize()
         return stage_out.host_view('actions').copy()
 
+    def _bind(self, observations):
+        """First step (or a new worker count): find the environment's block — the arrays of
+        tonic_amd.environments ARE views of one — or make a private one, page-lock it and point
+        the collector at the Segment."""
+        W, O, A = observations.shape[0], self.observation_size, self.action_size
+        block = Block.owner_of(observations) or Block(W, O, A)
+        self._block = block
+        self._collector = Collector.for_block(block, self.transport)
+        replay = self.replay
+        if replay.buffers is None or replay.num_workers != W:
+            replay._allocate(W, O, A)
+        self._eps = (torch.from_numpy(block.eps[0]), torch.from_numpy(block.eps[1]))
+        self._slot, self._eps_ahead, self._pending, self._rollout_open = 0, False, False, False
+
     def step(self, observations, steps):
-        observations = np.asarray(observations, np.float32)
-        if self._workers != observations.shape[0]:
-            W, O = observations.shape[0], self.observation_size
-            self._workers = W
-            self._in, self._out = self._io(W)
-            self._outcome = _Staging([('next_observations', (W, O)), ('rewards', (W,)),
-                                      ('resets', (W,)), ('terminations', (W,))], self.device)
-        actions = self._act(observations, self._in, self._out, True)
-        self.last_observations = observations.copy()
+        block = getattr(self, '_block', None)
+        if self._collector is None or block.workers != len(observations):
+            self._bind(observations)
+            block = self._block
+        if observations is not block.observations:
+            np.copyto(block.observations, observations)
+        collector = self._collector
+        if not self._rollout_open:
+            norm = self.model.observation_normalizer
+            collector.bind_segment(self.replay.buffers,
+                                   norm.device_sums if norm is not None else None,
+                                   self.replay.max_size)
+            collector.begin_rollout(self.model.flat_actor.flat)
+            self._rollout_open = True
+        slot = self._slot
+        if not self._eps_ahead:
+            torch.randn(self._eps[slot].shape, out=self._eps[slot])     # a2c.py:81
+        collector.ppo_step(self.replay.index, slot, self._pending)
+        self._pending = False
+        # The next step's noise, drawn while the GPU works on this one.  The generator state
+        # before the draw is kept: test_step rewinds to it (its own draws come first in the
+        # reference's stream order).
+        self._rng_mark = torch.get_rng_state()
+        torch.randn(self._eps[slot ^ 1].shape, out=self._eps[slot ^ 1])
+        self._slot, self._eps_ahead = slot ^ 1, True
+        collector.wait_actions()
+        actions = block.actions.copy()
+        self.last_observations = observations
         self.last_actions = actions
-        self.last_log_probs = self._out.host_view('log_probs').copy()
         return actions
 
     def test_step(self, observations, steps):
+        if getattr(self, '_eps_ahead', False):
+            torch.set_rng_state(self._rng_mark)
+            self._eps_ahead = False
         observations = np.asarray(observations, np.float32)
         if getattr(self, '_test_workers', None) != observations.shape[0]:
             self._test_workers = observations.shape[0]
@@ -169,24 +212,29 @@ class A2C(Agent):
 
     # ---------------------------------------------------------------- learning
     def update(self, observations, rewards, resets, terminations, steps):
-        stage = self._outcome
-        stage.host_view('next_observations')[:] = observations
-        stage.host_view('rewards')[:] = rewards
-        stage.host_view('resets')[:] = resets                 # bool -> float32 (segments.py:33)
-        stage.host_view('terminations')[:] = terminations
-        stage.upload()
-        self.replay.store(
-            normalizer=self.model.observation_normalizer,
-            observations=self._in.device_view('observations'),
-            actions=self._out.device_view('actions'),
-            next_observations=stage.device_view('next_observations'),
-            rewards=stage.device_view('rewards'), resets=stage.device_view('resets'),
-            terminations=stage.device_view('terminations'),
-            log_probs=self._out.device_view('log_probs'))
+        """a2c.py:58-73.  The outcome stays in the block; the NEXT step's launch (or
+        end_rollout) moves it into the Segment row of the step it belongs to."""
+        block = self._block
+        # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
+        if observations is not block.next_observations:
+            np.copyto(block.next_observations, observations)
+        if rewards is not block.rewards:
+            np.copyto(block.rewards, rewards)
+        if resets is not block.resets_bool:
+            np.copyto(block.resets, resets)                 # bool -> float32 (segments.py:33)
+        if terminations is not block.terminations_bool:
+            np.copyto(block.terminations, terminations)
         if self.model.return_normalizer:
             raise NotImplementedError('return normalisers are not supported (never enabled by '
                                       'the reference defaults)')
-        if self.replay.ready():
+        replay = self.replay
+        replay.index += 1
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.note_device_rows(block.workers)
+        self._pending = True
+        if replay.ready():
+            self._collector.end_rollout(replay.index - 1)
+            self._pending, self._rollout_open = False, False
             self._update()
 
     def _evaluate(self):
