@@ -281,7 +281,7 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
  *
  * Agent side: tonic_collector_create page-locks the block (hipHostRegister) so that the workers'
  * memory is the DMA source.  transport 0: the fused act kernel reads observations / noise / the
- * previous outcome from the mapped block over PCIe and writes actions + a completion word back;
+ * previous outcome from the mapped block over PCIe and writes actions + completion words back;
  * transport 1: hipMemcpyAsync H2D + kernel + hipMemcpyAsync D2H on the collector's own stream and
  * an event.  Per environment step t (tonic/utils/trainer.py:44-56):
  *   tonic_collector_ppo_step(row t)   ONE launch: policy forward + sample + log-prob of the block's
@@ -310,7 +310,8 @@ enum {
   TONIC_COLLECTOR_ACTIONS = 7,         /* [W,A] written by the agent side                   */
   TONIC_COLLECTOR_RESETS_U8 = 8,       /* [W] uint8 copies of the flags (NumPy bool views)  */
   TONIC_COLLECTOR_TERMINATIONS_U8 = 9,
-  TONIC_COLLECTOR_FIELD_COUNT = 10
+  TONIC_COLLECTOR_DONE_FLAGS = 10,     /* uint32 completion words of the act launch (internal) */
+  TONIC_COLLECTOR_FIELD_COUNT = 11
 };
 int64_t tonic_collector_block_bytes(int64_t W, int32_t O, int32_t A);
 int tonic_collector_block_init(void* block, int64_t bytes, int64_t W, int32_t O, int32_t A,

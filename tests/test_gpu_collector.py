@@ -221,3 +221,18 @@ def test_test_step_keeps_the_reference_noise_order(lib):
     want2, _ = port.ppo_act(params, obs[2], eps_last)
     for got_actions, want in zip(got, (want0, want1, want_test, want2)):
         np.testing.assert_allclose(got_actions, want, rtol=0, atol=3e-6)
+
+
+def test_completion_words_order_the_actions(lib):
+    """The host must never read actions older than the completion words it waited for: many
+    steps, host copy of the block's actions / rewards against what the kernels stored."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts',
+                        'collector_stress.py')
+    spec = importlib.util.spec_from_file_location('collector_stress', path)
+    stress = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stress)
+    assert stress.main(W=6, steps=6144) == 0
+    assert stress.main(W=256, steps=2048) == 0
+    assert stress.main(W=256, steps=1024, transport=1) == 0

@@ -59,7 +59,21 @@ class Block:
         # what `environment.step` hands out when it writes into this block (persistent views)
         self.infos = dict(observations=self.next_observations, rewards=self.rewards,
                           resets=self.resets_bool, terminations=self.terminations_bool)
+        # GPU handles that page-locked this mapping.  They MUST be destroyed (hipHostUnregister)
+        # before the mapping goes away: a later mmap may reuse the address range, and a stale
+        # registration would make the GPU read the old physical pages.  The finalizer runs
+        # before the instance dictionary (and with it the mmap) is released.
+        self._handles = []
+        self._collectors = {}
+        weakref.finalize(self, Block._release, self._handles, lib)
         Block._live.add(self)
+
+    @staticmethod
+    def _release(handles, lib):
+        for cell in handles:
+            if cell[0] is not None:
+                lib.tonic_collector_destroy(cell[0])
+                cell[0] = None
 
     @classmethod
     def owner_of(cls, observations):
@@ -97,34 +111,33 @@ class Collector:
     """GPU side of a block: fused act + store launches on the collector's own stream."""
 
     def __init__(self, block, transport=0):
-        self.block = block
         self.lib = lib = block.lib
         handle = ctypes.c_void_p()
         _lib.check(lib.tonic_collector_create(ctypes.byref(handle), block.address, transport),
                    'tonic_collector_create')
-        self.handle = handle.value
+        self._cell = [handle.value]          # shared with the block, which outlives the handle
+        block._handles.append(self._cell)
         self.transport = transport
         self._step = lib.tonic_collector_ppo_step          # bound once: the per-step hot calls
         self._wait = lib.tonic_collector_wait_actions
 
+    @property
+    def handle(self):
+        if self._cell[0] is None:
+            raise _lib.TonicHipError('this collector was closed (or its block released)')
+        return self._cell[0]
+
     @classmethod
     def for_block(cls, block, transport=0):
-        """One collector per block and transport (a block can only be page-locked once)."""
-        cache = block.__dict__.setdefault('_collectors', {})
-        if transport not in cache:
-            cache[transport] = cls(block, transport)
-        return cache[transport]
+        """One collector per block and transport."""
+        if transport not in block._collectors:
+            block._collectors[transport] = cls(block, transport)
+        return block._collectors[transport]
 
     def close(self):
-        if self.handle is not None:
-            self.lib.tonic_collector_destroy(self.handle)
-            self.handle = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:          # interpreter shutdown: the library may already be gone
-            pass
+        if self._cell[0] is not None:
+            self.lib.tonic_collector_destroy(self._cell[0])
+            self._cell[0] = None
 
     def bind_segment(self, buffers, norm_acc, rows):
         p = _lib.ptr
@@ -140,12 +153,12 @@ class Collector:
             'tonic_collector_begin_rollout')
 
     def ppo_step(self, row, eps_slot, store_previous):
-        status = self._step(self.handle, row, eps_slot, store_previous)
+        status = self._step(self._cell[0], row, eps_slot, store_previous)
         if status != 0:
             _lib.check(status, 'tonic_collector_ppo_step')
 
     def wait_actions(self, timeout=60.0):
-        status = self._wait(self.handle, timeout)
+        status = self._wait(self._cell[0], timeout)
         if status != 0:
             _lib.check(status, 'tonic_collector_wait_actions')
 

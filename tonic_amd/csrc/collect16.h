@@ -32,15 +32,15 @@ struct Collect16Args {
   // consumed the actions, so the launch of step t stores the outcome of step t - 1
   // (outcome_row = row - 1) and none at all for the first step of a rollout (outcome_row < 0).
   int64_t outcome_row;
-  // Host-visible completion (null: none).  Every workgroup publishes its host writes, then bumps
-  // `done_counter` (device memory, zero between launches); the last one stores `done_seq` into
-  // `done_flag` (pinned host memory) — the host spins on that word instead of synchronising the
-  // stream, and knows that EVERY role has finished reading the pinned block.
-  unsigned* done_counter; unsigned* done_flag; unsigned done_seq;
+  // Host-visible completion (null: none): workgroup b stores `done_seq` into done_flags[b]
+  // (pinned host memory) once all of its reads of the pinned block and its writes to it are
+  // complete; the host spins on those words instead of synchronising the stream.
+  unsigned* done_flags; unsigned done_seq;
 };
 
 int collect16_ks1(int O);
 int collect16_ap(int A);
+int collect16_blocks(int64_t W);          // workgroups (= completion words) of one launch
 int launch_collect16(const Collect16Args& c, hipStream_t stream);
 int launch_actor_pack(const float* d_actor_params, float* d_packed, int O, int A,
                       hipStream_t stream);

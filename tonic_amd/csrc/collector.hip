@@ -45,7 +45,7 @@ struct BlockHeader {
   alignas(64) uint32_t go_seq;                     // futex: bumped once per environment step
   alignas(64) uint32_t done_count;                 // futex: groups that finished the step
   alignas(64) uint32_t shutdown;
-  alignas(64) uint32_t act_done_seq;               // written by the GPU (transport 0)
+  alignas(64) uint32_t act_seq;                    // sequence number of the last act launch
 };
 static_assert(sizeof(BlockHeader) <= kHeaderBytes, "header does not fit its page");
 
@@ -59,7 +59,8 @@ void layout(int64_t W, int O, int A, int64_t* offset, int64_t* total) {
       W * 4, W * 4, W * 4,// REWARDS, RESETS, TERMINATIONS
       W * A * 4,          // EPS1
       W * A * 4,          // ACTIONS
-      W, W};              // RESETS_U8, TERMINATIONS_U8
+      W, W,               // RESETS_U8, TERMINATIONS_U8
+      (int64_t)collect16_blocks(W) * 4};   // DONE_FLAGS (one word per workgroup of the act launch)
   int64_t at = kHeaderBytes;
   for (int f = 0; f < kFields; ++f) {
     offset[f] = at;
@@ -215,7 +216,6 @@ struct tonic_collector {
   hipStream_t stream;
   hipEvent_t learner_done, collect_done, actions_out;
   float* d_packed;
-  unsigned* d_counter;
   float* seg[7];                // observations, actions, next_observations, rewards, resets,
   float* norm_acc;              //   terminations, log_probs
   int64_t rows;
@@ -311,13 +311,11 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
     return fail("hipEventCreate", e);
   const int64_t packed = PackedActor(collect16_ks1(c->O), collect16_ap(c->A)).total;
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_packed), packed * 4)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&c->d_counter), 256)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
-  if ((e = hipMemset(c->d_counter, 0, 256)) != hipSuccess ||
-      (e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
+  if ((e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
     return fail("hipMemset", e);
-  c->seq = __atomic_load_n(&h->act_done_seq, __ATOMIC_ACQUIRE);
+  c->seq = __atomic_load_n(&h->act_seq, __ATOMIC_ACQUIRE);
   *out = c;
   return TONIC_OK;
 }
@@ -327,7 +325,6 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   // teardown: nothing useful can be done about a failing release
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->d_packed) (void)hipFree(c->d_packed);
-  if (c->d_counter) (void)hipFree(c->d_counter);
   if (c->staged) (void)hipFree(c->staged);
   if (c->learner_done) (void)hipEventDestroy(c->learner_done);
   if (c->collect_done) (void)hipEventDestroy(c->collect_done);
@@ -386,6 +383,7 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
     if (status != TONIC_OK) return status;
   }
   c->seq += 1;
+  __atomic_store_n(&c->host->act_seq, c->seq, __ATOMIC_RELEASE);
   Collect16Args a{};
   a.packed = c->d_packed;
   a.obs = field(c, TONIC_COLLECTOR_OBSERVATIONS);
@@ -402,8 +400,7 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
   a.row = row; a.W = c->W; a.O = c->O; a.A = c->A;
   a.outcome_row = store_previous ? row - 1 : -1;
   if (c->transport == 0) {
-    a.done_counter = c->d_counter;
-    a.done_flag = reinterpret_cast<unsigned*>(c->mapped + offsetof(BlockHeader, act_done_seq));
+    a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
     a.done_seq = c->seq;
   }
   const int status = launch_collect16(a, c->stream);
@@ -423,11 +420,16 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
   TONIC_REQUIRE(c && c->waiting, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_wait_actions: no step in flight");
   const double deadline = now_s() + timeout_s;
-  uint32_t* flag = &c->host->act_done_seq;
+  const uint32_t* flags = reinterpret_cast<const uint32_t*>(
+      reinterpret_cast<const char*>(c->host) + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+  const int words = collect16_blocks(c->W);
+  int arrived = 0;                                   // words [0, arrived) already carry c->seq
   for (uint64_t spins = 0;; ++spins) {
     bool done;
     if (c->transport == 0) {
-      done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->seq;
+      while (arrived < words && __atomic_load_n(flags + arrived, __ATOMIC_ACQUIRE) == c->seq)
+        ++arrived;
+      done = arrived == words;
     } else {
       const hipError_t e = hipEventQuery(c->actions_out);
       if (e != hipSuccess && e != hipErrorNotReady) {

@@ -675,26 +675,64 @@ __device__ __forceinline__ void retire_touches(float sink, float* never_written)
   if (sink == 1.2345e-38f) *never_written = sink;
 }
 
-// End of a workgroup's role when the host is waiting on this launch (Collect16Args::done_flag).
+// End of a workgroup's role when the host is waiting on this launch (Collect16Args::done_flags):
+// one word per workgroup in pinned host memory, stored at system scope once the workgroup's loads
+// from the pinned block have returned (s_waitcnt vmcnt(0)) and — actor role — its actions have
+// been released to the system (the fence above).  No cross-workgroup counter: a last-arriver
+// protocol costs every workgroup a system-scope fence and an atomic round trip.
 __device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
-  if (c.done_flag == nullptr) return;
-  __threadfence_system();                 // this thread's writes to pinned host memory are out
+  if (c.done_flags == nullptr) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's loads / stores are done
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned arrived = __hip_atomic_fetch_add(c.done_counter, 1u, __ATOMIC_ACQ_REL,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == gridDim.x - 1) {
-      __hip_atomic_store(c.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(c.done_flag, c.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  if (threadIdx.x == 0)
+    __hip_atomic_store(c.done_flags + blockIdx.x, c.done_seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
 constexpr int kCollectCopyBlocks = 4;  // workgroups that copy the transition outcome
 
-template <int KS1, int AP>
+// Block-wide copy src -> dst (and optionally -> lds) of `count` floats whose source is 16-byte
+// aligned, as 16-byte requests with ALL of a thread's loads in flight before the first store.
+// For sources in pinned HOST memory every load instruction becomes PCIe read requests and every
+// dependent batch a PCIe round trip (~2 us): the fields are therefore read exactly once, in as
+// few and as wide requests as possible.  Handles up to 8 * threads * 4 floats per call.
+__device__ __forceinline__ void wide_copy(const float* src, float* dst, float* lds, int64_t count,
+                                          int tid, int threads) {
+  const int64_t vecs = count >> 2;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int64_t i = tid + (int64_t)u * threads;
+    if (i < vecs) v[u] = __builtin_nontemporal_load(s4 + i);
+  }
+  float tail = 0.f;
+  const int64_t ti = (vecs << 2) + tid;
+  if (ti < count) tail = __builtin_nontemporal_load(src + ti);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int64_t i = tid + (int64_t)u * threads;
+    if (i < vecs) {
+      if (dst != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * i + e] = v[u][e];       // (dst rows may be 4-byte aligned)
+      }
+      if (lds != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[4 * i + e] = v[u][e];
+      }
+    }
+  }
+  if (ti < count) {
+    if (dst != nullptr) dst[ti] = tail;
+    if (lds != nullptr) lds[ti] = tail;
+  }
+}
+
+// HOST: the step inputs (observations, noise, previous outcome) live in pinned host memory that
+// the kernel reads in place over PCIe (pinned-host collector, transport 0).
+template <int KS1, int AP, bool HOST>
 __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   __shared__ float tile[kCollectLds];
   const int64_t W = c.W;
@@ -717,7 +755,22 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
         touch(c.pf_terminations + i, sink);
       }
     }
-    if (c.outcome_row >= 0) {
+    if (HOST && c.outcome_row >= 0) {
+      // one PCIe round trip per 32 KB: each copy block takes a contiguous, 16-byte aligned
+      // quarter of the next observations
+      const int64_t total = W * O;
+      const int64_t each = ((total + kCollectCopyBlocks - 1) / kCollectCopyBlocks + 3) & ~(int64_t)3;
+      const int64_t f0 = min(total, part * each), f1 = min(total, f0 + each);
+      float* dst = c.seg_next + c.outcome_row * total;
+      for (int64_t f = f0; f < f1; f += 8 * 256 * 4)
+        wide_copy(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
+      for (int64_t i = part * 256 + tid; i < W; i += stride) {
+        const float rew = c.rewards[i], rst = c.resets[i], term = c.terminations[i];
+        c.seg_rew[c.outcome_row * W + i] = rew;
+        c.seg_rst[c.outcome_row * W + i] = rst;
+        c.seg_term[c.outcome_row * W + i] = term;
+      }
+    } else if (c.outcome_row >= 0) {
       // all of this thread's loads first, then the stores (a plain copy loop waits per element)
       float* dst = c.seg_next + c.outcome_row * W * O;
       int64_t i = part * 256 + tid;
@@ -754,11 +807,31 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
       for (int64_t i = (int64_t)tid * 16; i < W * O; i += 256 * 16) touch(c.next_obs + i, sink);
     float acc = 0.f;
     if (wave < 2 && lane < O) acc = c.norm_acc[wave * O + lane];
-    const int64_t rows_per_chunk = kHalf / O;
+    const int64_t rows_per_chunk = (kHalf / O) & ~3;            // (x4 rows: 16-byte aligned chunks)
     for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
       const int64_t rows = min(rows_per_chunk, W - w0);
       __syncthreads();
-      {  // staging with eight loads in flight per thread (a plain loop waits for every load)
+      if (HOST) {
+        // the whole chunk (<= 32 KB) as 16-byte requests, all in flight: ONE PCIe round trip
+        const float* src = c.obs + w0 * O;
+        const int64_t count = rows * O, vecs = count >> 2;
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (tid + u * 256 < vecs) v[u] = __builtin_nontemporal_load(s4 + tid + u * 256);
+        const int64_t ti = (vecs << 2) + tid;
+        float tail = 0.f;
+        if (ti < count) tail = __builtin_nontemporal_load(src + ti);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (tid + u * 256 < vecs) {
+            const int64_t i = 4 * (int64_t)(tid + u * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tile[i + e] = v[u][e]; tile[kHalf + i + e] = v[u][e] * v[u][e]; }
+          }
+        if (ti < count) { tile[ti] = tail; tile[kHalf + ti] = tail * tail; }
+      } else {  // staging with eight loads in flight per thread (a plain loop waits for every load)
         const float* src = c.obs + w0 * O;
         const int64_t count = rows * O;
         int64_t i = tid;
@@ -800,16 +873,37 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     const bool valid = ns < W;
     const int64_t nc = valid ? ns : W - 1;
     float xr[KS1], ep[AP];
+    // HOST: the tile's observation and noise rows cross PCIe exactly once, as 16-byte requests
+    // that are all in flight together; they meet in LDS (SO / SE) further down.
+    const int tile_rows = (int)min<int64_t>(16, W - t * 16);
+    const int64_t o_first = t * 16 * O, o_count = (int64_t)tile_rows * O, o_vecs = o_count >> 2;
+    const int64_t e_first = t * 16 * A, e_count = (int64_t)tile_rows * A, e_vecs = e_count >> 2;
+    const int etid = (tid + 128) & 255;                           // noise on the other two waves
+    f32x4 vo = {0.f, 0.f, 0.f, 0.f}, ve = {0.f, 0.f, 0.f, 0.f};
+    float to = 0.f, te = 0.f;
+    if constexpr (HOST) {
+      if (tid < o_vecs)
+        vo = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.obs + o_first) + tid);
+      if ((o_vecs << 2) + tid < o_count)
+        to = __builtin_nontemporal_load(c.obs + o_first + (o_vecs << 2) + tid);
+      if (c.eps != nullptr) {
+        if (etid < e_vecs)
+          ve = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.eps + e_first) + etid);
+        if ((e_vecs << 2) + etid < e_count)
+          te = __builtin_nontemporal_load(c.eps + e_first + (e_vecs << 2) + etid);
+      }
+    } else {
 #pragma unroll
-    for (int st = 0; st < KS1; ++st) {
-      const int k = 4 * st + g;
-      xr[st] = c.obs[nc * O + (k < O ? k : O - 1)];
+      for (int st = 0; st < KS1; ++st) {
+        const int k = 4 * st + g;
+        xr[st] = c.obs[nc * O + (k < O ? k : O - 1)];
+      }
+      // (noise and head constants are wave 0's alone: every load instruction costs the CU's
+      //  memory pipe 5 - 10 ns, and the four waves share it)
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa)
+        ep[aa] = (wave == 0 && c.eps != nullptr) ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
     }
-    // (noise and head constants are wave 0's alone: every load instruction costs the CU's
-    //  memory pipe 5 - 10 ns, and the four waves share it)
-#pragma unroll
-    for (int aa = 0; aa < AP; ++aa)
-      ep[aa] = (wave == 0 && c.eps != nullptr) ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
     // this tile's weight operands, all requested up front
     const f32x4 bias1 = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16)[wave];
     const f32x4 bias2 = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16)[wave];
@@ -825,12 +919,40 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
       w3[aa] = reinterpret_cast<const f32x4*>(P + L.W3P)[(aa * 4 + g) * 4 + wave];
       hcA[aa] = wave == 0 ? *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    {  // the tile's 16 observation rows -> Segment row (contiguous, coalesced)
-      const int64_t first = t * 16 * O, count = min<int64_t>(16, W - t * 16) * O;
-      for (int64_t i = tid; i < count; i += 256)
-        c.seg_obs[c.row * W * O + first + i] = c.obs[first + i];
+    if constexpr (HOST) {
+      float* SO = tile + 2048;                     // [16][O] observation rows of the tile
+      float* SE = tile + 2048 + 512;               // [16][A] noise rows
+      float* seg = c.seg_obs + c.row * W * O + o_first;
+      if (tid < o_vecs) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { SO[4 * tid + e] = vo[e]; seg[4 * tid + e] = vo[e]; }
+      }
+      if ((o_vecs << 2) + tid < o_count) {
+        SO[(o_vecs << 2) + tid] = to;
+        seg[(o_vecs << 2) + tid] = to;
+      }
+      if (c.eps != nullptr) {
+        if (etid < e_vecs) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) SE[4 * etid + e] = ve[e];
+        }
+        if ((e_vecs << 2) + etid < e_count) SE[(e_vecs << 2) + etid] = te;
+      }
+      __syncthreads();
+      const int sr = s < tile_rows ? s : tile_rows - 1;
+#pragma unroll
+      for (int st = 0; st < KS1; ++st) {
+        const int k = 4 * st + g;
+        xr[st] = SO[sr * O + (k < O ? k : O - 1)];
+      }
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa)
+        ep[aa] = (wave == 0 && c.eps != nullptr) ? SE[sr * A + (aa < A ? aa : A - 1)] : 0.f;
+    } else {
+      // the tile's 16 observation rows -> Segment row (contiguous, coalesced)
+      for (int64_t i = tid; i < o_count; i += 256)
+        c.seg_obs[c.row * W * O + o_first + i] = c.obs[o_first + i];
       if (c.pf_eps != nullptr) {                  // next step's noise rows of this tile
-        const int64_t e_first = t * 16 * A, e_count = min<int64_t>(16, W - t * 16) * A;
         for (int64_t i = (int64_t)tid * 16; i < e_count; i += 256 * 16)
           touch(c.pf_eps + e_first + i, eps_sink);
       }
@@ -886,6 +1008,10 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
         }
       }
       if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
+      // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
+      // only then may the completion word go out (scripts/collector_stress.py: without the
+      // fence the host reads stale actions within a few thousand steps).
+      if constexpr (HOST) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
@@ -990,14 +1116,19 @@ extern "C" int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed
   return launch_actor_pack(d_actor_params, d_packed, O, A, as_stream(stream));
 }
 
+int tonic::collect16_blocks(int64_t W) {
+  const int64_t tiles = (W + 15) / 16;
+  return (int)(tiles < 4096 ? tiles : 4096) + kCollectCopyBlocks + 1;   // one tile per workgroup
+}
+
 int tonic::launch_collect16(const Collect16Args& c, hipStream_t st) {
-  const int64_t tiles = (c.W + 15) / 16;
-  const int act_blocks = (int)(tiles < 4096 ? tiles : 4096);       // one tile per workgroup
-  const dim3 grid(act_blocks + kCollectCopyBlocks + 1), block(256);
+  const dim3 grid(collect16_blocks(c.W)), block(256);
   const int ks1 = collect16_ks1(c.O), ap = collect16_ap(c.A);
+  const bool host = c.done_flags != nullptr;          // the pinned-host collector, transport 0
 #define TONIC_COLLECT16(K, P_)                                                        \
   if (ks1 == K && ap == P_) {                                                         \
-    hipLaunchKernelGGL((ppo_collect16_kernel<K, P_>), grid, block, 0, st, c);         \
+    if (host) hipLaunchKernelGGL((ppo_collect16_kernel<K, P_, true>), grid, block, 0, st, c);   \
+    else hipLaunchKernelGGL((ppo_collect16_kernel<K, P_, false>), grid, block, 0, st, c);       \
   } else
   TONIC_COLLECT16(1, 1) TONIC_COLLECT16(1, 6) TONIC_COLLECT16(1, 8)
   TONIC_COLLECT16(5, 1) TONIC_COLLECT16(5, 6) TONIC_COLLECT16(5, 8)
@@ -1027,7 +1158,7 @@ extern "C" int tonic_ppo_collect_steps_packed(
                     d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
                     d_seg_resets, d_seg_terminations, d_seg_log_probs, d_norm_acc, nullptr,
                     row0 + t, W, O, A, nullptr, nullptr, nullptr, nullptr, nullptr,
-                    row0 + t, nullptr, nullptr, 0u};
+                    row0 + t, nullptr, 0u};
     if (t + 1 < steps) {                         // the next step's inputs exist: touch them early
       c.pf_eps = d_eps ? d_eps + (t + 1) * W * A : nullptr;
       c.pf_next_obs = obs + 2 * W * O;
@@ -1058,7 +1189,7 @@ extern "C" int tonic_ppo_collect_step_packed(
                   d_resets, d_terminations, d_seg_observations, d_seg_actions,
                   d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
                   d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A,
-                  nullptr, nullptr, nullptr, nullptr, nullptr, row, nullptr, nullptr, 0u};
+                  nullptr, nullptr, nullptr, nullptr, nullptr, row, nullptr, 0u};
   launch_collect16(c, as_stream(stream));
   TONIC_CHECK_LAUNCH("tonic_ppo_collect_step_packed");
   return TONIC_OK;
