@@ -1,0 +1,96 @@
+"""The drop-in claims checked against the REFERENCE's own code in the build container (skipped
+where /root/reference is absent, e.g. on the GPU box): `tonic.train.train()` drives an agent of
+this package and the learner statistics land in the reference's log.csv; the reference's own
+agent loads a checkpoint written by this package."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import reference_loader
+
+pytestmark = pytest.mark.skipif(not reference_loader.reference_available(),
+                                reason='needs the reference checkout (build container only)')
+
+PPO_KEYS = ('actor/loss', 'actor/kl', 'actor/entropy', 'actor/clip_fraction', 'actor/std',
+            'actor/stop', 'actor/iterations', 'critic/loss', 'critic/v', 'critic/iterations')
+
+
+def test_reference_train_logs_this_packages_learner_keys(tmp_path, monkeypatch):
+    """tonic/train.py:76-133 end to end with `--header 'import tonic_amd as amd'`: the agent logs
+    through tonic_amd.logger, the reference initialised tonic.logger — one log.csv, one
+    checkpoint folder, under the reference's environment/name/seed path."""
+    tonic = reference_loader.load_reference()
+    import tonic.train
+    import tonic_amd
+    from tonic_amd.utils import logger as amd_logger
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(amd_logger, 'current_logger', None)        # nobody initialised ours
+    monkeypatch.setattr(tonic.logger, 'current_logger', None)
+    tonic.train.train(
+        header='import tonic_amd as amd, tonic_amd.torch, stub_agents',
+        agent='stub_agents.LoggingOnlyPPO(update_every=8, iterations=3)',
+        environment='__import__("tonic_amd").environments.Synthetic(5, 2, max_episode_steps=7)',
+        test_environment=None,
+        trainer='tonic.Trainer(steps=96, epoch_steps=48, save_steps=96, show_progress=False)',
+        before_training=None, after_training=None, parallel=1, sequential=4, seed=3,
+        name=None, environment_name=None, checkpoint='last', path=None)
+    run = tmp_path / 'synthetic-5-2' / 'LoggingOnlyPPO-1x4' / '3'
+    header = (run / 'log.csv').read_text().split('\n')[0].split(',')
+    for key in PPO_KEYS + ('train/episode_score/mean', 'test/episode_score/mean',
+                           'train/steps_per_second'):
+        assert key in header, (key, header)
+    assert (run / 'config.yaml').exists()
+    assert (run / 'checkpoints' / 'step_96.pt').exists()
+    assert amd_logger.current_logger is None, 'the reference logger must stay the only one'
+    rows = (run / 'log.csv').read_text().strip().split('\n')
+    assert len(rows) == 3                                           # header + two epochs
+
+
+def test_this_packages_trainer_under_the_reference_logger(tmp_path, monkeypatch):
+    """`--trainer 'amd.Trainer(...)'` with the reference's logger: same single log."""
+    tonic = reference_loader.load_reference()
+    import tonic.train
+    from tonic_amd.utils import logger as amd_logger
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(amd_logger, 'current_logger', None)
+    monkeypatch.setattr(tonic.logger, 'current_logger', None)
+    tonic.train.train(
+        header='import tonic_amd as amd, tonic_amd.torch, stub_agents',
+        agent='stub_agents.LoggingOnlyPPO(update_every=8, iterations=3)',
+        environment='__import__("tonic_amd").environments.Synthetic(5, 2, max_episode_steps=7)',
+        test_environment=None,
+        trainer='amd.Trainer(steps=96, epoch_steps=48, save_steps=96, show_progress=False)',
+        before_training=None, after_training=None, parallel=1, sequential=4, seed=3,
+        name='run', environment_name='env', checkpoint='last', path=None)
+    header = (tmp_path / 'env' / 'run' / '3' / 'log.csv').read_text().split('\n')[0].split(',')
+    for key in PPO_KEYS + ('train/episode_score/mean', 'test/episode_length/mean'):
+        assert key in header, key
+    assert (tmp_path / 'env' / 'run' / '3' / 'checkpoints' / 'step_96.pt').exists()
+
+
+@pytest.mark.parametrize('name', ['PPO', 'SAC', 'TD3', 'DDPG'])
+def test_reference_agents_load_this_packages_checkpoints(tmp_path, name):
+    """tonic/torch/agents/agent.py:23-26: the reference agent's strict load_state_dict accepts a
+    `.pt` written by this package's Agent.save (same keys, same shapes)."""
+    import torch
+    tonic = reference_loader.load_reference()
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd.environments import Box
+    observation_space, action_space = Box(-np.inf, np.inf, (11,)), Box(-1, 1, (3,))
+    mine = getattr(tonic_amd.torch.agents, name)()
+    mine.model.initialize(observation_space, action_space)         # CPU parameters suffice
+    torch.manual_seed(1)
+    for parameter in mine.model.parameters():
+        parameter.data.copy_(torch.randn(parameter.shape))
+    mine.save(str(tmp_path / 'step_1'))
+    theirs = getattr(tonic.torch.agents, name)()
+    theirs.initialize(observation_space, action_space, seed=0)
+    theirs.load(str(tmp_path / 'step_1'))                           # strict: keys and shapes
+    want = mine.model.state_dict()
+    got = theirs.model.state_dict()
+    assert set(got) == set(want)
+    for key in want:
+        assert torch.equal(got[key], want[key].cpu()), key

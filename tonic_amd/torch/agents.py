@@ -289,19 +289,26 @@ class PPO(A2C):
 
     def _update(self):
         infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
-        actor_rows = infos[0][infos[0][:, 6] > 0]
-        for row in actor_rows:
-            for i, key in enumerate(updaters.ACTOR_INFO):
-                value = row[i] > 0.5 if key == 'stop' else row[i]
-                logger.store('actor/' + key, value)
-        for row in infos[1]:
-            logger.store('critic/loss', row[0])
-            logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
-        logger.store('actor/iterations', len(actor_rows))
-        logger.store('critic/iterations', len(infos[1]))
+        log_ppo_update(infos)
         self.last_infos = infos
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
+
+
+def log_ppo_update(infos):
+    """The keys ppo.py:46-67 logs for one learner update, from the statistics rows the device
+    wrote: infos[0] = actor rows {loss, kl, entropy, clip_fraction, std, stop, ran}, one per
+    iteration that ran before the KL stop; infos[1] = critic rows {loss, v}."""
+    actor_rows = infos[0][infos[0][:, 6] > 0]
+    for row in actor_rows:
+        for i, key in enumerate(updaters.ACTOR_INFO):
+            value = row[i] > 0.5 if key == 'stop' else row[i]
+            logger.store('actor/' + key, value)
+    for row in infos[1]:
+        logger.store('critic/loss', row[0])
+        logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
+    logger.store('actor/iterations', len(actor_rows))
+    logger.store('critic/iterations', len(infos[1]))
 
 
 # ----------------------------------------------------------------- off-policy (SAC / TD3)

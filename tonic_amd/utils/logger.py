@@ -6,6 +6,7 @@ The key names (``train/steps_per_second``, ``actor/kl`` ...) are part of the dro
 """
 import datetime
 import os
+import sys
 import time
 
 import numpy as np
@@ -144,8 +145,41 @@ def initialize(*args, **kwargs):
     return current_logger
 
 
+def use(module):
+    """Forwards every call of this module to `module` (any object with the functions of
+    tonic/utils/logger.py); ``use(None)`` restores the automatic choice below."""
+    global _injected
+    _injected = module
+
+
+_injected = None
+
+
+def _host():
+    """Where the calls of this module go when they are not handled here.
+
+    Under ``python -m tonic.train --header 'import tonic_amd as amd' --agent 'amd...'`` the
+    REFERENCE package owns the run: tonic/train.py:117 initialises ``tonic.logger`` and the
+    reference's Trainer dumps it every epoch (tonic/utils/trainer.py:92).  The agents of this
+    package log through this module, so as long as this logger has not been initialised itself
+    everything is forwarded to the reference's — the learner statistics land in the one
+    ``log.csv``, checkpoints are announced and placed under the one experiment path."""
+    if _injected is not None:
+        return _injected
+    if current_logger is not None:
+        return None
+    package = sys.modules.get('tonic')
+    other = getattr(package, 'logger', None) if package is not None else None
+    if other is None or other is sys.modules[__name__]:
+        return None
+    return other if hasattr(other, 'store') and hasattr(other, 'dump') else None
+
+
 def get_current_logger():
     global current_logger
+    host = _host()
+    if host is not None:
+        return host.get_current_logger()
     if current_logger is None:
         current_logger = Logger()
     return current_logger
@@ -168,12 +202,21 @@ def get_path():
 
 
 def log(msg, color='green'):
+    host = _host()
+    if host is not None:
+        return host.log(msg, color)
     print(_paint(msg, color, attrs=['bold']))
 
 
 def warning(msg, color='yellow'):
+    host = _host()
+    if host is not None:
+        return host.warning(msg, color)
     print(_paint('Warning: ' + msg, color, attrs=['bold']))
 
 
 def error(msg, color='red'):
+    host = _host()
+    if host is not None:
+        return host.error(msg, color)
     print(_paint('Error: ' + msg, color, attrs=['bold']))
