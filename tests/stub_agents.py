@@ -22,10 +22,12 @@ class LoggingOnlyPPO(agents.Agent):
         self.calls = 0
 
     def step(self, observations, steps):
+        from tonic_amd.collector import Block
+        self.saw_block_views = Block.owner_of(observations) is not None
         return self.random.uniform(-1, 1, (len(observations), self.action_size)).astype(np.float32)
 
     def test_step(self, observations, steps):
-        return self.step(observations, steps)
+        return self.random.uniform(-1, 1, (len(observations), self.action_size)).astype(np.float32)
 
     def update(self, observations, rewards, resets, terminations, steps):
         self.calls += 1

@@ -70,6 +70,37 @@ def test_this_packages_trainer_under_the_reference_logger(tmp_path, monkeypatch)
     assert (tmp_path / 'env' / 'run' / '3' / 'checkpoints' / 'step_96.pt').exists()
 
 
+def test_install_puts_the_collector_under_the_reference_cli(tmp_path, monkeypatch):
+    """`tonic_amd.install()` from the header: the reference's train() then builds its
+    environments with this package's distribute (forked workers writing into the shared block)
+    and the agent receives the block's views."""
+    tonic = reference_loader.load_reference()
+    import tonic.train
+    import stub_agents
+    from tonic_amd.utils import logger as amd_logger
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(amd_logger, 'current_logger', None)
+    monkeypatch.setattr(tonic.logger, 'current_logger', None)
+    monkeypatch.setattr(tonic.environments, 'distribute', tonic.environments.distribute)
+    seen = []
+    original = stub_agents.LoggingOnlyPPO.update
+
+    def spy(self, *args, **kwargs):
+        seen.append(self.saw_block_views)
+        return original(self, *args, **kwargs)
+    monkeypatch.setattr(stub_agents.LoggingOnlyPPO, 'update', spy)
+    tonic.train.train(
+        header='import tonic_amd as amd, tonic_amd.torch, stub_agents; amd.install()',
+        agent='stub_agents.LoggingOnlyPPO(update_every=8, iterations=3)',
+        environment='__import__("tonic_amd").environments.Synthetic(5, 2, max_episode_steps=7)',
+        test_environment=None,
+        trainer='tonic.Trainer(steps=48, epoch_steps=48, save_steps=48, show_progress=False)',
+        before_training=None, after_training=None, parallel=2, sequential=3, seed=3,
+        name='run', environment_name='env', checkpoint='last', path=None)
+    assert seen and all(seen), 'the agent must be handed views of the shared block'
+    assert (tmp_path / 'env' / 'run' / '3' / 'log.csv').exists()
+
+
 @pytest.mark.parametrize('name', ['PPO', 'SAC', 'TD3', 'DDPG'])
 def test_reference_agents_load_this_packages_checkpoints(tmp_path, name):
     """tonic/torch/agents/agent.py:23-26: the reference agent's strict load_state_dict accepts a
