@@ -457,6 +457,9 @@ def main():
             if name == 'ddpg_small':
                 run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2,
                               batch=16, seed=5)
+            elif name == 'ppo_halfcheetah_w256':
+                run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6,
+                        updates=1)
             else:
                 globals()['golden_' + name](tonic)
         return
@@ -476,6 +479,8 @@ def main():
     # minibatch mode (segments.py:58-65): N = 20*12 = 240 samples, ragged last minibatch of 48
     run_ppo(tonic, 'ppo_minibatch_small', 17, 6, workers=12, steps=20, seed=4, iterations=5,
             batch_size=64)
+    # the metric's worker count (parallel=256, BASELINE cfg 2) on a short segment: N = 3*256
+    run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6, updates=1)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)

@@ -333,3 +333,35 @@ def test_policy_tail_in_the_forward_launch_is_bit_identical(lib, kind, o_dim, a_
         assert torch.equal(results[0][k], results[1][k]), k
     assert torch.equal(actions[0], actions[2]) and torch.equal(actions[1], actions[3])
     assert all(torch.isfinite(v).all() for v in results[0].values())
+
+
+@pytest.mark.parametrize('n,coeff', [(292114, 0.005), (1, 0.005), (70001, 0.25), (4097, 1.0)])
+def test_polyak_update_bit_exact_vs_oracle(lib, n, coeff):
+    """tonic_polyak_update against numpy_port.polyak (actor_critics.py:126-130: t.mul_(1-c);
+    t.add_(c*o), three float32 roundings) bit for bit — three consecutive updates, values over
+    many binades, and the polyak half of tonic_adam_polyak_step against the same oracle."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(n)
+    scale = np.exp(rng.uniform(-20, 20, n)).astype(np.float32)
+    online = (rng.standard_normal(n).astype(np.float32) * scale)
+    target = (rng.standard_normal(n).astype(np.float32) * scale[::-1])
+    d_online, d_target = dev(online), dev(target)
+    want = target
+    for _ in range(3):
+        _lib.check(lib.tonic_polyak_update(d_target.data_ptr(), d_online.data_ptr(), n, coeff, None),
+                   'tonic_polyak_update')
+        want = port.polyak([want], [online], coeff)[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(d_target.cpu().numpy(), want)
+    # fused form: zero gradients leave the online block where it is, the targets still move
+    d_target2 = dev(target)
+    grads = torch.zeros(n + 8, device='cuda')
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    state = torch.zeros(4, dtype=torch.int32, device='cuda')
+    info = torch.zeros(8, device='cuda')
+    _lib.check(lib.tonic_adam_polyak_step(
+        d_online.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(), 0, n, n,
+        1.0, 3e-4, 0.9, 0.999, 1e-8, 0, info.data_ptr(), d_target2.data_ptr(), coeff, None), 'fused')
+    torch.cuda.synchronize()
+    assert np.array_equal(d_online.cpu().numpy(), online), 'a zero gradient must not move Adam'
+    assert np.array_equal(d_target2.cpu().numpy(), port.polyak([target], [online], coeff)[0])

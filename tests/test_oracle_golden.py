@@ -5,7 +5,8 @@ import pytest
 
 import numpy_port as port
 
-PPO_CASES = ['ppo_halfcheetah_small', 'ppo_pendulum_small', 'ppo_antbullet_small']
+PPO_CASES = ['ppo_halfcheetah_small', 'ppo_pendulum_small', 'ppo_antbullet_small',
+             'ppo_halfcheetah_w256']
 
 
 def test_lambda_returns_bit_exact(golden):
