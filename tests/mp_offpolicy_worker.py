@@ -37,6 +37,14 @@ def run(kind, out_path, rows=40, W=8, O=11, A=3, iterations=6, batch=48):
     if rank == 0:
         state = {k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
         np.savez(out_path, infos=agent.last_infos, **state)
+    # Buffer.get (buffers.py:81-91) across ranks: tiny batches so that some rank draws nothing
+    replay = agent.replay
+    replay.np_random = np.random.RandomState(99)
+    replay.batch_size = 3
+    parts = list(replay.get('observations', 'rewards', steps=rows * W))
+    np.savez(out_path + f'.get{rank}.npz',
+             **{f'rewards{i}': b['rewards'].cpu().numpy() for i, b in enumerate(parts)},
+             **{f'observations{i}': b['observations'].cpu().numpy() for i, b in enumerate(parts)})
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

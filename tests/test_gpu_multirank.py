@@ -63,3 +63,28 @@ def test_offpolicy_two_ranks_equal_single_process(tmp_path, kind, port):
             # differ by a few lr; everything else agrees to 2e-5.
             diff = np.abs(b[key] - a[key])
             assert diff.max() < 3e-3 and np.mean(diff > 2e-5) < 1e-3, (key, diff.max())
+
+
+def test_buffer_get_yields_each_ranks_part_of_the_global_batch(tmp_path):
+    """Buffer.get with 1 / 2 / 4 ranks: every rank yields exactly its rows of each globally drawn
+    batch (possibly none, never an uninitialised tail); the union over ranks is the batch one
+    process holding the whole buffer yields."""
+    outs = {}
+    for world in (1, 2, 4):
+        outs[world] = str(tmp_path / f'get{world}.npz')
+        launch(world, outs[world], 29670 + world, command=(OFFPOLICY_WORKER, 'td3'))
+    whole = np.load(outs[1] + '.get0.npz')
+    iterations = len([k for k in whole.files if k.startswith('rewards')])
+    for world in (2, 4):
+        parts = [np.load(outs[world] + f'.get{r}.npz') for r in range(world)]
+        empty = 0
+        for i in range(iterations):
+            rewards = np.concatenate([p[f'rewards{i}'] for p in parts])
+            observations = np.concatenate([p[f'observations{i}'] for p in parts])
+            assert rewards.shape == whole[f'rewards{i}'].shape
+            assert np.isfinite(observations).all()
+            order, want = np.argsort(rewards), np.argsort(whole[f'rewards{i}'])
+            assert np.array_equal(rewards[order], whole[f'rewards{i}'][want])
+            assert np.array_equal(observations[order], whole[f'observations{i}'][want])
+            empty += sum(p[f'rewards{i}'].shape[0] == 0 for p in parts)
+        assert empty > 0, 'the case of a rank drawing nothing must be exercised'

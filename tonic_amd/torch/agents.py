@@ -86,6 +86,7 @@ class _Staging:
         self.host = torch.empty(total, dtype=torch.float32).pin_memory()
         self.device = torch.empty(total, dtype=torch.float32, device=device)
         self.host_np = self.host.numpy()
+        self.uploaded = None         # event behind the last H2D copy that read `host`
 
     def host_view(self, name):
         start, size, shape = self.offsets[name]
@@ -95,8 +96,19 @@ class _Staging:
         start, size, shape = self.offsets[name]
         return self.device[start:start + size].view(shape)
 
+    def writable(self):
+        """Blocks until the DMA of the previous upload() has read the pinned block: the host may
+        not overwrite it earlier (nothing else orders consecutive update() calls while an agent
+        is still warming up and never reads anything back)."""
+        if self.uploaded is not None:
+            self.uploaded.synchronize()
+        return self
+
     def upload(self):
         self.device.copy_(self.host, non_blocking=True)
+        if self.uploaded is None:
+            self.uploaded = torch.cuda.Event()
+        self.uploaded.record()
 
     def download(self):
         self.host.copy_(self.device, non_blocking=True)
@@ -367,6 +379,7 @@ class DDPG(Agent):
         self.hidden = self.critic_updater.hidden
         self._workers = None
         self._policy_io = {}
+        self._graph, self._static_key = None, None       # a re-initialised agent re-captures
 
     # ------------------------------------------------------------------ acting
     def _forward_policy(self, observations, kind, stochastic):
@@ -418,10 +431,14 @@ class DDPG(Agent):
         if self._workers != W:
             self._workers = W
             O, A = self.observation_size, self.action_size
-            self._transition = _Staging(
-                [('observations', (W, O)), ('actions', (W, A)), ('next_observations', (W, O)),
-                 ('rewards', (W,)), ('resets', (W,)), ('terminations', (W,))], self.device)
-        stage = self._transition
+            fields = [('observations', (W, O)), ('actions', (W, A)), ('next_observations', (W, O)),
+                      ('rewards', (W,)), ('resets', (W,)), ('terminations', (W,))]
+            # two pinned blocks used in turn: the copy of step t may still be in flight while the
+            # host fills the block of step t+1
+            self._transitions = (_Staging(fields, self.device), _Staging(fields, self.device))
+            self._transition_turn = 0
+        self._transition_turn ^= 1
+        stage = self._transitions[self._transition_turn].writable()
         stage.host_view('observations')[:] = self.last_observations
         stage.host_view('actions')[:] = self.last_actions          # float64 warm-up -> float32
         stage.host_view('next_observations')[:] = observations
@@ -463,7 +480,10 @@ class DDPG(Agent):
                 c = counts[it]
                 local_eps[it, :, :c] = eps[it][:, positions[it, :c]]
             eps = local_eps
-        key = (iterations, tuple(eps.shape))
+        # everything a captured graph bakes in: shapes, the replay's storage, the updaters'
+        # hyper-parameters and schedules — a change of any of them re-captures
+        key = (iterations, tuple(eps.shape), self.replay.buffers['observations'].data_ptr(),
+               self.replay.max_size, self._graph_signature())
         if getattr(self, '_static_key', None) != key:
             self._static_key = key
             self._static_indices = torch.zeros(indices.shape, dtype=torch.int64, device=self.device)
@@ -511,6 +531,19 @@ class DDPG(Agent):
                 enqueue()
         self._graph.replay()
         return self._infos
+
+    def _graph_signature(self):
+        parts = []
+        for updater in (self.actor_updater, self.critic_updater):
+            hyper = updater.hyper
+            noise = getattr(updater, 'target_action_noise', None)
+            parts.append((hyper['lr'], hyper['betas'], hyper['eps'],
+                          float(getattr(updater, 'entropy_coeff', 0.0)),
+                          float(getattr(updater, 'gradient_clip', 0.0) or 0.0),
+                          (noise.scale, noise.clip) if noise is not None else None))
+        norm = self.model.observation_normalizer
+        return (tuple(parts), float(self.model.target_coeff), getattr(self, 'delay_steps', 1),
+                norm._mean.data_ptr() if norm is not None else 0)
 
     def _draw_noise(self, iterations):
         # DeterministicQLearning / DeterministicPolicyGradient draw nothing (one unused slot)
