@@ -103,7 +103,7 @@ def kernel_rooflines(agent):
 
     def critic_grad():
         _lib.check(lib.tonic_value_regression_grad(
-            p(critic.flat.flat), p(mean), p(std), p(obs), p(ret), p(critic.grad_sums), n, O,
+            p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, O,
             p(wsc), wsc.numel(), stream), 'critic')
 
     out = {}

@@ -47,7 +47,7 @@ typedef enum tonic_status {
 /* ---- library ------------------------------------------------------------------------ */
 const char* tonic_last_error(void);
 /* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks,
- * 3 = pinned-host collector) and the gfx target the kernels were built for. */
+ * 3 = pinned-host collector, gradient / normaliser clipping) and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -108,11 +108,13 @@ int tonic_ppo_act(const float* d_actor_params, const float* d_observations,
  * replaces: tonic/torch/agents/a2c.py:92-99 (A2C._evaluate) = Critic.forward
  *           (tonic/torch/models/critics.py:15-20,87-90; encoders.py:13-16;
  *            tonic/torch/normalizers/mean_stds.py:34-39 with clip=None).
- * d_norm_mean / d_norm_std: [O] (the MeanStd `_mean` / `_std` parameters).
+ * d_norm_mean / d_norm_std: [O] (the MeanStd `_mean` / `_std` parameters); norm_clip: MeanStd's
+ *   `clip` (mean_stds.py:37-38: the normalised input clamped to [-clip, clip]); <= 0 = None.
+ *   The same pair + clip travels into every entry point that normalises observations.
  */
 int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
-                        const float* d_norm_std, const float* d_observations, float* d_values,
-                        int64_t n, int32_t O, void* stream);
+                        const float* d_norm_std, double norm_clip, const float* d_observations,
+                        float* d_values, int64_t n, int32_t O, void* stream);
 
 /* ---- learner: fused forward + loss + backward over the whole batch ------------------------
  * Both calls write per-workgroup partial sums into d_workspace, then reduce them into
@@ -138,7 +140,8 @@ int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_observation
                          double ratio_clip, double entropy_coeff, const int32_t* d_skip_flag,
                          void* d_workspace, int64_t workspace_bytes, void* stream);
 int tonic_value_regression_grad(const float* d_critic_params, const float* d_norm_mean,
-                                const float* d_norm_std, const float* d_observations,
+                                const float* d_norm_std, double norm_clip,
+                                const float* d_observations,
                                 const float* d_returns, float* d_grad_sums, int64_t n,
                                 int32_t O, void* d_workspace, int64_t workspace_bytes,
                                 void* stream);
@@ -147,8 +150,8 @@ int tonic_value_regression_grad(const float* d_critic_params, const float* d_nor
  * replaces: torch.optim.Adam single-tensor path (torch/optim/adam.py:395-547) as
  *   constructed at tonic/torch/updaters/actors.py:58-59 and critics.py:9-10, applied to the
  *   flat parameter block: grad = d_grad_sums[i] * grad_scale (grad_scale = 1/N_global).
- * d_state: int32[4] = {step_count, stop_flag, reserved, reserved}; step_count is
- *   incremented on the device so the call is graph-replayable.
+ * d_state: int32[4] = {step_count, stop_flag, reserved, arrival counter (zero between calls)};
+ *   step_count is incremented on the device so the call is graph-replayable.
  * Statistic extras (stats_kind: 0 none, 1 PPO actor, 2 V critic, 3 twin Q critics
  *   {loss, q1 mean, q2 mean}, 4 Q-gradient actor {loss}): finalises
  *   the 8 statistic sums into d_info_row[8] and, for the actor, sets stop_flag when
@@ -163,6 +166,17 @@ int tonic_adam_step(float* d_params, const float* d_grad_sums, float* d_exp_avg,
                     int32_t stats_kind, double kl_threshold, double entropy_coeff,
                     const float* d_adv_stats, float* d_info_row, const int32_t* d_skip_flag,
                     void* stream);
+/* replaces: torch.nn.utils.clip_grad_norm_(variables, gradient_clip) as every updater calls it
+ *   between backward() and optimizer.step() (tonic/torch/updaters/actors.py:40-42,96-98,182-184,
+ *   260-262; critics.py:24-25,79-80,176-177,229-230): scales the n gradient SUMS in place by
+ *   min(1, max_norm / (||grad_scale * sums||_2 + 1e-6)).  The norm is reduced in float64 in a
+ *   fixed order (bit-reproducible; with several ranks it is taken AFTER the all-reduce, so every
+ *   rank clips alike).  Call it before tonic_adam_step*; d_skip_flag as in the grad kernels.
+ *   The workspace ends with two floats {factor, norm} for inspection. */
+int64_t tonic_clip_workspace_bytes(int64_t n);
+int tonic_clip_grad_norm(float* d_grad_sums, int64_t n, double grad_scale, double max_norm,
+                         const int32_t* d_skip_flag, void* d_workspace, int64_t workspace_bytes,
+                         void* stream);
 /* Two independent optimizer steps in ONE launch pair (PPO: actor, with its KL early-stop flag and
  * statistics, and critic — ppo.py:33-46 steps them back to back); same arithmetic as two
  * tonic_adam_step calls sharing grad_scale / betas / eps. */
@@ -433,7 +447,7 @@ int tonic_policy_forward(const float* d_actor_params, const float* d_observation
  *   tonic_adam_step(grad_scale = 1/B). */
 int tonic_twin_q_grad(int32_t kind, const float* d_policy_params, const float* d_target_critics,
                       const float* d_critics, const float* d_norm_mean, const float* d_norm_std,
-                      const float* d_observations, const float* d_actions,
+                      double norm_clip, const float* d_observations, const float* d_actions,
                       const float* d_next_observations, const float* d_rewards,
                       const float* d_discounts, const float* d_eps, float* d_grad_sums, int32_t B,
                       int32_t O, int32_t H, int32_t A, double entropy_coeff, double noise_scale,
@@ -444,7 +458,7 @@ int tonic_twin_q_grad(int32_t kind, const float* d_policy_params, const float* d
  *   (actors.py:238-267).  Critics are frozen (no weight gradients).  Output: gradient SUMS for
  *   the actor + 8 statistics {loss_sum, 0, 0, 0, 0, B, 0, 0}. */
 int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d_critics,
-                       const float* d_norm_mean, const float* d_norm_std,
+                       const float* d_norm_mean, const float* d_norm_std, double norm_clip,
                        const float* d_observations, const float* d_eps, float* d_grad_sums,
                        int32_t B, int32_t O, int32_t H, int32_t A, double entropy_coeff,
                        void* d_workspace, int64_t workspace_bytes, void* stream);

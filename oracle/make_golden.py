@@ -229,18 +229,35 @@ def golden_sequential(tonic):
 
 
 def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
-            reward_scale=1.0, updates=1, batch_size=None):
+            reward_scale=1.0, updates=1, batch_size=None, actor_clip=0, critic_clip=0,
+            normalizer_clip=None):
     """tonic/torch/agents/{a2c.py:41-73, ppo.py:20-67}: acts with the reference agent on
     a synthetic env for `steps` time steps so the real store/record/update path runs."""
     def builder():
         return rl.SyntheticEnvironment(obs_dim, act_dim, max_episode_steps=7)
     env = tonic.environments.distribute(builder, 1, workers)
     env.initialize(seed=seed)
+    clipped = actor_clip > 0 or critic_clip > 0 or normalizer_clip is not None
+    kwargs = {}
+    if clipped:     # gradient-norm clipping (actors.py:96-98, critics.py:24-25), MeanStd(clip)
+        models, norms = tonic.torch.models, tonic.torch.normalizers
+        kwargs = dict(
+            model=models.ActorCritic(
+                actor=models.Actor(encoder=models.ObservationEncoder(),
+                                   torso=models.MLP((64, 64), torch.nn.Tanh),
+                                   head=models.DetachedScaleGaussianPolicyHead()),
+                critic=models.Critic(encoder=models.ObservationEncoder(),
+                                     torso=models.MLP((64, 64), torch.nn.Tanh),
+                                     head=models.ValueHead()),
+                observation_normalizer=norms.MeanStd(clip=normalizer_clip)),
+            actor_updater=tonic.torch.updaters.ClippedRatio(gradient_clip=actor_clip),
+            critic_updater=tonic.torch.updaters.VRegression(gradient_clip=critic_clip))
     agent = tonic.torch.agents.PPO(
         replay=tonic.replays.Segment(size=steps, batch_iterations=iterations,
-                                     batch_size=batch_size))
+                                     batch_size=batch_size), **kwargs)
     agent.initialize(env.observation_space, env.action_space, seed=seed)
     out = state_arrays('init/', agent.model.state_dict())
+    out['clips'] = np.array([actor_clip, critic_clip, normalizer_clip or 0], np.float64)
     out['batch_size'] = np.int64(batch_size or 0)
     recorder = RecordingLogger()
     tonic.logger.current_logger = recorder
@@ -288,7 +305,7 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 out[pre + 'info/' + k] = np.array(v)
         recorder.records.clear()
         out[pre + 'norm/count'] = np.int64(norm.count)
-        if update == 0 and batch_size is None:
+        if update == 0 and batch_size is None and not clipped:
             out.update(first_update_probes(tonic, builder, seed, seg, iterations))
     out['act/observations'] = np.array(obs_all)
     out['act/eps'] = np.array(eps_all)
@@ -457,6 +474,10 @@ def main():
             if name == 'ddpg_small':
                 run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2,
                               batch=16, seed=5)
+            elif name == 'ppo_clipped_small':
+                run_ppo(tonic, 'ppo_clipped_small', 17, 6, workers=8, steps=24, seed=8,
+                        iterations=12, updates=2, actor_clip=0.05, critic_clip=0.3,
+                        normalizer_clip=1.5)
             elif name == 'ppo_halfcheetah_w256':
                 run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6,
                         updates=1)
@@ -481,6 +502,10 @@ def main():
             batch_size=64)
     # the metric's worker count (parallel=256, BASELINE cfg 2) on a short segment: N = 3*256
     run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6, updates=1)
+    # gradient_clip on both updaters and a clipping observation normaliser; two updates so that
+    # the second one runs with non-trivial normaliser statistics (values beyond +-1.5 exist)
+    run_ppo(tonic, 'ppo_clipped_small', 17, 6, workers=8, steps=24, seed=8, iterations=12,
+            updates=2, actor_clip=0.05, critic_clip=0.3, normalizer_clip=1.5)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)

@@ -285,23 +285,35 @@ def clipped_ratio_grads(params, observations, actions, advantages, old_log_probs
     return [g.astype(F32) for g in grads], stats
 
 
-def critic_forward(params, mean, std, observations):
+def clip_grad_norm(grads, max_norm):
+    """``torch.nn.utils.clip_grad_norm_`` (called at ``updaters/actors.py:96-98``,
+    ``critics.py:24-25``): norm of the per-tensor norms, factor ``max_norm / (norm + 1e-6)``
+    clamped to 1, applied to every gradient."""
+    norms = np.array([np.sqrt(np.sum(np.square(g, dtype=F32), dtype=F32)) for g in grads], F32)
+    total = F32(np.sqrt(np.sum(np.square(norms), dtype=F32)))
+    coef = min(F32(max_norm) / (total + F32(1e-6)), F32(1.0))
+    return [(g * F32(coef)).astype(F32) for g in grads], total
+
+
+def critic_forward(params, mean, std, observations, clip=None):
     """``Critic.forward`` with ``ObservationEncoder`` + ``MeanStd`` + ``ValueHead`` —
     ``tonic/torch/models/critics.py:15-20,87-90``, ``encoders.py:13-16``,
     ``normalizers/mean_stds.py:34-39``.  params = ``[W1,b1,W2,b2,w3,b3]``."""
     w1, b1, w2, b2, w3, b3 = params
     x = ((observations - mean) / std).astype(F32)
+    if clip is not None:                                  # mean_stds.py:37-38
+        x = np.clip(x, -F32(clip), F32(clip))
     h1, h2 = torso_forward(x, w1, b1, w2, b2)
     values = (h2 @ w3.T + b3).reshape(-1).astype(F32)
     return x, h1, h2, values
 
 
-def value_regression_grads(params, mean, std, observations, returns):
+def value_regression_grads(params, mean, std, observations, returns, clip=None):
     """``VRegression.__call__`` — ``tonic/torch/updaters/critics.py:18-28``:
     MSE loss and gradients; also returns the pre-step values (``v`` info)."""
     w1, b1, w2, b2, w3, b3 = params
     n = observations.shape[0]
-    x, h1, h2, values = critic_forward(params, mean, std, observations)
+    x, h1, h2, values = critic_forward(params, mean, std, observations, clip)
     err = values - returns
     loss = np.mean(np.square(err, dtype=np.float64))
     d_v = (2 * err / n).astype(F32)
@@ -358,15 +370,17 @@ def polyak(targets, onlines, coeff=0.005):
 
 def ppo_update(actor_params, critic_params, normalizer, segment, batch_iterations=80,
                discount_factor=0.99, trace_decay=0.97, actor_lr=3e-4, critic_lr=1e-3,
-               actor_adam=None, critic_adam=None, batch_size=None, np_random=None):
+               actor_adam=None, critic_adam=None, batch_size=None, np_random=None,
+               actor_clip=0, critic_clip=0, normalizer_clip=None):
     """``PPO._update`` — ``tonic/torch/agents/ppo.py:20-59`` (default full-batch path,
     ``Segment.batch_size=None``).  ``segment`` maps the seven stored keys to ``[T, W,
     ...]`` float32 arrays.  Returns new params, per-iteration infos and the returns."""
     mean, std = normalizer
     flat = {k: flatten_time_major(v) for k, v in segment.items()}
     shape = segment['rewards'].shape
-    values = critic_forward(critic_params, mean, std, flat['observations'])[3]
-    next_values = critic_forward(critic_params, mean, std, flat['next_observations'])[3]
+    values = critic_forward(critic_params, mean, std, flat['observations'], normalizer_clip)[3]
+    next_values = critic_forward(critic_params, mean, std, flat['next_observations'],
+                                 normalizer_clip)[3]
     returns = lambda_returns(next_values.reshape(shape), segment['rewards'],
                              segment['resets'], segment['terminations'],
                              discount_factor, trace_decay)
@@ -393,10 +407,15 @@ def ppo_update(actor_params, critic_params, normalizer, segment, batch_iteration
                                      clip_fraction=F32(0), std=F32(scale.mean()), stop=False)
             else:
                 grads, stats = clipped_ratio_grads(actor_params, obs_b, act_b, adv_b, lp_b)
+                if actor_clip > 0:
+                    grads, _ = clip_grad_norm(grads, actor_clip)
                 actor_params = actor_adam.step(actor_params, grads)
                 info['actor'] = stats
             train_actor = not info['actor']['stop']
-        grads, stats = value_regression_grads(critic_params, mean, std, obs_b, ret_b)
+        grads, stats = value_regression_grads(critic_params, mean, std, obs_b, ret_b,
+                                              normalizer_clip)
+        if critic_clip > 0:
+            grads, _ = clip_grad_norm(grads, critic_clip)
         critic_params = critic_adam.step(critic_params, grads)
         info['critic'] = dict(loss=stats['loss'], v=stats['v'])
         infos.append(info)

@@ -34,6 +34,6 @@ for n in (1 << 20, 1 << 19, 1 << 18, 1 << 17, 1 << 16, 1 << 15):
         p(params), p(obs), p(act), p(adv), p(st), p(logp), p(out), n, O, A, 0.2, 0.0, None, p(ws),
         ws.numel(), None), 'a'))
     c = timed(lambda: _lib.check(lib.tonic_value_regression_grad(
-        p(cparams), p(mean), p(std), p(obs), p(ret), p(outc), n, O, p(ws), ws.numel(), None), 'c'))
+        p(cparams), p(mean), p(std), 0.0, p(obs), p(ret), p(outc), n, O, p(ws), ws.numel(), None), 'c'))
     print(f'n={n:8d}  actor {a:8.1f} us  critic {c:8.1f} us   per 16-sample tile and wave: '
           f'{a * 2.4e3 / max(n / 16 / 2048, 1):8.0f} / {c * 2.4e3 / max(n / 16 / 2048, 1):8.0f} cycles')

@@ -43,7 +43,7 @@ ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8, 
 for _ in range(3):
     _lib.check(lib.tonic_ppo_actor_grad(p(params), p(obs), p(act), p(advn), p(st), p(logp), p(out),
                                         n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), None), 'actor')
-    _lib.check(lib.tonic_value_regression_grad(p(cparams), p(mean), p(std), p(obs), p(rets), p(outc),
+    _lib.check(lib.tonic_value_regression_grad(p(cparams), p(mean), p(std), 0.0, p(obs), p(rets), p(outc),
                                                n, O, p(ws), ws.numel(), None), 'critic')
 torch.cuda.synchronize()
 print('done')

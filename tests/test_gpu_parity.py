@@ -139,8 +139,8 @@ def test_value_forward_vs_oracle(lib, O, n):
     want = port.critic_forward(params, mean, std, obs)[3]
     out = torch.empty(n).cuda()
     keep = [dev(flat(params)), dev(mean), dev(std), dev(obs)]   # keep the tensors alive
-    _lib.check(lib.tonic_value_forward(*[t.data_ptr() for t in keep], out.data_ptr(),
-                                       n, O, None), 'value')
+    _lib.check(lib.tonic_value_forward(*[t.data_ptr() for t in keep[:3]], 0.0, keep[3].data_ptr(),
+                                       out.data_ptr(), n, O, None), 'value')
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
 
 
@@ -164,7 +164,7 @@ def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
     return out.cpu().numpy(), P
 
 
-def critic_grad(lib, params, mean, std, obs, returns, variant=None):
+def critic_grad(lib, params, mean, std, obs, returns, variant=None, clip=0.0):
     from tonic_amd import _lib
     if variant is not None:
         _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
@@ -174,8 +174,8 @@ def critic_grad(lib, params, mean, std, obs, returns, variant=None):
     ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8).cuda()
     keep = [dev(flat(params)), dev(mean), dev(std), dev(obs), dev(returns)]
     _lib.check(lib.tonic_value_regression_grad(
-        *[t.data_ptr() for t in keep], out.data_ptr(), n, O, ws.data_ptr(),
-        ws.numel(), None), 'critic_grad')
+        *[t.data_ptr() for t in keep[:3]], float(clip), *[t.data_ptr() for t in keep[3:]],
+        out.data_ptr(), n, O, ws.data_ptr(), ws.numel(), None), 'critic_grad')
     torch.cuda.synchronize()
     _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
     return out.cpu().numpy(), P
@@ -764,3 +764,85 @@ def test_two_whole_iterations_at_baseline_size_vs_oracle(lib):
             live = np.abs(grad) > 1e-6 * np.abs(grad).max()
             np.testing.assert_allclose((got - first)[live], (want - first)[live], rtol=0,
                                        atol=1e-5, err_msg=f'iteration {it + 1}: {key}')
+
+
+def test_ppo_update_with_gradient_and_normaliser_clipping(golden, lib):
+    """gradient_clip on both updaters (tonic_clip_grad_norm between the grad kernels and Adam;
+    actors.py:96-98, critics.py:24-25) and MeanStd(clip=1.5) (the clamp in the critic kernels'
+    input stage; mean_stds.py:37-38) against two consecutive updates of the reference."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    g = golden('ppo_clipped_small')
+    O, A, W, steps, seed, iterations, updates = (int(x) for x in g['cfg'])
+    actor_clip, critic_clip, normalizer_clip = (float(x) for x in g['clips'])
+    model = tt.models.ActorCritic(
+        actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
+                              torso=tt.models.MLP((64, 64), torch.nn.Tanh),
+                              head=tt.models.DetachedScaleGaussianPolicyHead()),
+        critic=tt.models.Critic(encoder=tt.models.ObservationEncoder(),
+                                torso=tt.models.MLP((64, 64), torch.nn.Tanh),
+                                head=tt.models.ValueHead()),
+        observation_normalizer=tt.normalizers.MeanStd(clip=normalizer_clip))
+    agent = tt.agents.PPO(
+        model=model, replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations),
+        actor_updater=tt.updaters.ClippedRatio(gradient_clip=actor_clip),
+        critic_updater=tt.updaters.VRegression(gradient_clip=critic_clip))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    for u in range(updates):
+        state = {k[len(f'pre{u}/'):]: torch.as_tensor(g[k]) for k in g.files
+                 if k.startswith(f'pre{u}/')}
+        if u == 0:
+            agent.model.load_state_dict(state)
+        else:       # parameters continue from the first update; only the normaliser moved
+            for key in ('observation_normalizer._mean', 'observation_normalizer._std'):
+                target = dict(agent.model.state_dict())[key]
+                target.copy_(state[key])
+        before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+        agent.replay.index = 0
+        _fill_segment(agent, g, u)
+        infos = agent.enqueue_update().cpu().numpy()
+        np.testing.assert_allclose(agent.replay.buffers['returns'].cpu().numpy(),
+                                   g[f'u{u}/segment/returns'], rtol=1e-5, atol=1e-5)
+        n_actor = int(g[f'u{u}/info/actor/iterations'][0])
+        assert (infos[0][:, 6] > 0).sum() == n_actor
+        np.testing.assert_allclose(infos[0][:n_actor, 1], g[f'u{u}/info/actor/kl'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(infos[0][:n_actor, 0], g[f'u{u}/info/actor/loss'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(infos[1][:, 0], g[f'u{u}/info/critic/loss'], rtol=2e-5, atol=1e-5)
+        after = agent.model.state_dict()
+        for key, start in before.items():
+            if 'normalizer' in key:
+                continue
+            got = after[key].detach().cpu().numpy() - start
+            want = g[f'post{u}/' + key] - start
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-5, err_msg=f'update {u}: {key}')
+    report = agent.critic_updater.clip_workspace[-16:-8].view(torch.float32).cpu().numpy()
+    assert 0 < report[0] < 1 and report[1] > critic_clip, 'the critic gradient must have been clipped'
+
+
+def test_clip_grad_norm_against_torch(lib):
+    """tonic_clip_grad_norm == torch.nn.utils.clip_grad_norm_ on the mean gradient, for norms
+    above and below the bound, deterministic, and a no-op under the skip flag."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(5)
+    for n, scale, max_norm in ((5708, 1.0 / 1048576, 0.05), (193538, 1.0 / 1024, 40.0), (7, 1.0, 100.0)):
+        sums = (rng.standard_normal(n + 8) * (1.0 / scale) * 0.01).astype(np.float32)
+        d = dev(sums)
+        ws = torch.zeros(lib.tonic_clip_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.tonic_clip_grad_norm(d.data_ptr(), n, scale, max_norm, None, ws.data_ptr(),
+                                            ws.numel(), None), 'clip')
+        grad = torch.nn.Parameter(torch.zeros(n))
+        grad.grad = torch.as_tensor(sums[:n]) * np.float32(scale)
+        torch.nn.utils.clip_grad_norm_([grad], max_norm)
+        got = d.cpu().numpy()
+        np.testing.assert_allclose(got[:n] * np.float32(scale), grad.grad.numpy(), rtol=3e-6, atol=0)
+        assert np.array_equal(got[n:], sums[n:]), 'the statistic slots are not gradients'
+        d2 = dev(sums)
+        _lib.check(lib.tonic_clip_grad_norm(d2.data_ptr(), n, scale, max_norm, None, ws.data_ptr(),
+                                            ws.numel(), None), 'clip')
+        assert torch.equal(d, d2)
+        flag = torch.ones(1, dtype=torch.int32, device='cuda')
+        d3 = dev(sums)
+        _lib.check(lib.tonic_clip_grad_norm(d3.data_ptr(), n, scale, max_norm, flag.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), None), 'clip')
+        assert np.array_equal(d3.cpu().numpy(), sums)

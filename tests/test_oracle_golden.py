@@ -163,6 +163,39 @@ def test_ppo_update_matches_reference(golden, name):
             np.testing.assert_allclose(got - before, want - before, atol=tol, rtol=0)
 
 
+def test_ppo_update_with_gradient_and_normaliser_clipping(golden):
+    """`gradient_clip` on both updaters (actors.py:96-98, critics.py:24-25) and
+    `MeanStd(clip=1.5)` (mean_stds.py:37-38): two consecutive reference updates, the second one
+    with learnt normaliser statistics so that inputs beyond the clip exist."""
+    g = golden('ppo_clipped_small')
+    actor_clip, critic_clip, normalizer_clip = (float(x) for x in g['clips'])
+    actor_adam = critic_adam = None
+    for u in range(int(g['cfg'][6])):
+        actor, critic, norm = _params(g, f'pre{u}/')
+        seg = {k: g[f'u{u}/segment/{k}'] for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets',
+            'terminations', 'log_probs')}
+        if actor_adam is None:
+            actor_adam, critic_adam = port.AdamPort(actor, 3e-4), port.AdamPort(critic, 1e-3)
+        new_actor, new_critic, infos, extra = port.ppo_update(
+            actor, critic, norm, seg, batch_iterations=int(g['cfg'][5]), actor_adam=actor_adam,
+            critic_adam=critic_adam, actor_clip=actor_clip, critic_clip=critic_clip,
+            normalizer_clip=normalizer_clip)
+        np.testing.assert_allclose(extra['returns'], g[f'u{u}/segment/returns'], atol=1e-5, rtol=1e-6)
+        n_actor = int(g[f'u{u}/info/actor/iterations'][0])
+        assert sum('actor' in i for i in infos) == n_actor
+        kl = np.array([i['actor']['kl'] for i in infos if 'actor' in i])
+        np.testing.assert_allclose(kl, g[f'u{u}/info/actor/kl'], atol=1e-5, rtol=1e-5)
+        closs = np.array([i['critic']['loss'] for i in infos])
+        np.testing.assert_allclose(closs, g[f'u{u}/info/critic/loss'], rtol=1e-5, atol=1e-5)
+        ref_actor, ref_critic, _ = _params(g, f'post{u}/')
+        for got, want, before in zip(new_actor + new_critic, ref_actor + ref_critic, actor + critic):
+            np.testing.assert_allclose(got - before, want - before, atol=2e-5, rtol=0)
+    # the clipping must actually bite in this golden
+    x = (g['u1/segment/observations'] - norm[0]) / norm[1]
+    assert (np.abs(x) > normalizer_clip).mean() > 0.01
+
+
 @pytest.mark.parametrize('name', PPO_CASES)
 def test_ppo_single_iteration_deltas_strict(golden, name):
     """One actor + one critic optimizer step: parameter deltas within 1e-5, strictly."""

@@ -26,13 +26,16 @@ SIGNATURES = {
                                                               c_vp, c_i64, c_vp]),
     'tonic_advantage_stats_from_moments': (ctypes.c_int, [c_vp, c_vp, c_vp]),
     'tonic_ppo_act': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_vp]),
-    'tonic_value_forward': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_vp]),
+    'tonic_value_forward': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 2 + [c_i64, c_i32, c_vp]),
     'tonic_mlp64_grad_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'tonic_ppo_actor_grad': (ctypes.c_int, [c_vp] * 7 + [c_i64, c_i32, c_i32, c_f64, c_f64,
                                                           c_vp, c_vp, c_i64, c_vp]),
-    'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_vp, c_i64, c_vp]),
+    'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 3 +
+                                    [c_i64, c_i32, c_vp, c_i64, c_vp]),
     'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    'tonic_clip_workspace_bytes': (c_i64, [c_i64]),
+    'tonic_clip_grad_norm': (ctypes.c_int, [c_vp, c_i64, c_f64, c_f64, c_vp, c_vp, c_i64, c_vp]),
     'tonic_adam_step_pair': (ctypes.c_int,
                              [c_vp] * 5 + [c_i64, c_f64, c_i32, c_f64, c_f64, c_vp, c_vp, c_vp] +
                              [c_vp] * 5 + [c_i64, c_f64, c_i32, c_vp] + [c_f64] * 4 + [c_vp]),
@@ -57,9 +60,11 @@ SIGNATURES = {
     'tonic_buffer_store': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i32, c_i32, c_f64, c_vp]),
     'tonic_buffer_gather': (ctypes.c_int, [c_vp] * 11 + [c_i64, c_i32, c_i32, c_i32, c_vp]),
     'tonic_policy_forward': (ctypes.c_int, [c_vp] * 4 + [c_i32] * 5 + [c_vp, c_i64, c_vp]),
-    'tonic_twin_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 12 + [c_i32] * 4 + [c_f64] * 3 +
+    'tonic_twin_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 5 + [c_f64] + [c_vp] * 7 + [c_i32] * 4 +
+                          [c_f64] * 3 +
                           [c_vp, c_i64, c_vp]),
-    'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 7 + [c_i32] * 4 + [c_f64] +
+    'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 4 + [c_f64] + [c_vp] * 3 + [c_i32] * 4 +
+                           [c_f64] +
                            [c_vp, c_i64, c_vp]),
     'tonic_collector_block_bytes': (c_i64, [c_i64, c_i32, c_i32]),
     'tonic_collector_block_init': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32]),

@@ -117,6 +117,11 @@ __device__ __forceinline__ void add_rows(const float* column, int stride, int ro
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// MeanStd(clip) as passed through the C ABI (<= 0: no clipping) -> the bound the kernels clamp to.
+inline float clip_bound(double norm_clip) {
+  return norm_clip > 0 ? (float)norm_clip : __builtin_huge_valf();
+}
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace tonic

@@ -18,6 +18,7 @@ struct MlpArgs {
   const float* returns;     // critic grad
   const float* norm_mean;   // critic
   const float* norm_std;
+  float norm_clip;          // MeanStd(clip=...): clamp bound of the normalised input (+inf: none)
   const float* eps;         // act
   float* out0;              // act: actions, value: values, grad: partials
   float* out1;              // act: log_probs

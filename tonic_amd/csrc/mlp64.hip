@@ -207,7 +207,8 @@ __device__ __forceinline__ void load_obs(const MlpArgs& a, const float* norm, in
     const int k = 2 * st + h;
     const int kc = k < a.O ? k : a.O - 1;
     float v = a.obs[nc * a.O + kc];
-    if (NORMALISE) v = (v - norm[kc]) / norm[2 * KS1 + kc];   // mean_stds.py:36
+    if (NORMALISE)                                            // mean_stds.py:36-38
+      v = __builtin_amdgcn_fmed3f((v - norm[kc]) / norm[2 * KS1 + kc], -a.norm_clip, a.norm_clip);
     x[st] = v * ((valid && k < a.O) ? 1.f : 0.f);   // mask-multiply: a select lets the load sink into a branch
   }
 }
@@ -969,7 +970,8 @@ extern "C" int tonic_ppo_collect_step(
 }
 
 extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
-                                   const float* d_norm_std, const float* d_observations,
+                                   const float* d_norm_std, double norm_clip,
+                                   const float* d_observations,
                                    float* d_values, int64_t n, int32_t O, void* stream) {
   TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_values &&
                     n >= 0, TONIC_ERR_INVALID_ARGUMENT, "tonic_value_forward: bad argument");
@@ -977,7 +979,8 @@ extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_
   if (n == 0) return TONIC_OK;
   MlpArgs a{};
   a.params = d_critic_params; a.obs = d_observations; a.norm_mean = d_norm_mean;
-  a.norm_std = d_norm_std; a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
+  a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
+  a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
   const int64_t tiles = (n + 31) / 32;
   int blocks = (int)((tiles + kFwdWaves - 1) / kFwdWaves);
   if (blocks > 1024) blocks = 1024;
@@ -1074,6 +1077,7 @@ extern "C" int tonic_debug_grad16_phases(const float* d_actor_params, const floa
 
 extern "C" int tonic_value_regression_grad(const float* d_critic_params,
                                            const float* d_norm_mean, const float* d_norm_std,
+                                           double norm_clip,
                                            const float* d_observations, const float* d_returns,
                                            float* d_grad_sums, int64_t n, int32_t O,
                                            void* d_workspace, int64_t workspace_bytes,
@@ -1084,7 +1088,8 @@ extern "C" int tonic_value_regression_grad(const float* d_critic_params,
   if (int rc = check_shape(O, 1, false)) return rc;
   MlpArgs a{};
   a.params = d_critic_params; a.obs = d_observations; a.returns = d_returns;
-  a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.n = n; a.O = O; a.A = 1;
+  a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
+  a.n = n; a.O = O; a.A = 1;
   return run_grad<false>(a, tonic_v_critic_param_count(O), d_grad_sums, 0.f, d_workspace,
                          workspace_bytes, stream);
 }

@@ -314,7 +314,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       const int k = 4 * st + g;
       const int kc = k < O ? k : O - 1;
       float v = cur.x[st];
-      if (!ACTOR) v = (v - lds[L::NORM + kc]) / lds[L::NORM + 4 * KS1 + kc];
+      if (!ACTOR)                                       // mean_stds.py:36-38 (clip: +inf = none)
+        v = __builtin_amdgcn_fmed3f((v - lds[L::NORM + kc]) / lds[L::NORM + 4 * KS1 + kc],
+                                    -a.norm_clip, a.norm_clip);
       x[st] = v * ((valid && k < O) ? 1.f : 0.f);
     }
     float (&in_act)[AP] = cur.act;

@@ -94,6 +94,7 @@ struct MlpFwdArgs {
   // enc_out2[row] = [ (enc_obs2[row] - mean) / std , enc_act2[row] ].
   const float* enc_obs; const float* enc_obs2; const float* enc_act2;   // [B, enc_O], [B, NH]
   const float* enc_mean; const float* enc_std;                          // [enc_O]
+  float enc_clip;                                                       // MeanStd(clip): +inf = none
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
 };

@@ -381,8 +381,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
       for (int u = 0; u < 8; ++u) {
         const int c = c0 + 16 * u + slot;
         if (ok && c < O) {
-          a.enc_out[grow * a.enc_ld + c] = (x[u] - mean[u]) / sdev[u];
-          if (second) a.enc_out2[grow * a.enc_ld + c] = (y[u] - mean[u]) / sdev[u];
+          a.enc_out[grow * a.enc_ld + c] =
+              __builtin_amdgcn_fmed3f((x[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
+          if (second)
+            a.enc_out2[grow * a.enc_ld + c] =
+                __builtin_amdgcn_fmed3f((y[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
         }
       }
     }

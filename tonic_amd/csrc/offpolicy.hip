@@ -41,15 +41,16 @@ __host__ __device__ inline int64_t critic_count(CriticShape s) {
 // X[m] = [ (obs[m] - mean) / std , actions[m] ]   (encoders.py:28-31 + mean_stds.py:36)
 // blockIdx.y == 1 encodes a second (obs, act) pair into X2 in the same launch.
 __global__ void encode_kernel(const float* obs, const float* act, const float* mean,
-                              const float* std, float* X, int B, int O, int A, int ldx,
+                              const float* std, float clip, float* X, int B, int O, int A, int ldx,
                               const float* obs2 = nullptr, const float* act2 = nullptr,
                               float* X2 = nullptr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * (O + A)) return;
   if (blockIdx.y == 1) { obs = obs2; act = act2; X = X2; }
   const int m = idx / (O + A), c = idx - m * (O + A);
-  X[(int64_t)m * ldx + c] = c < O ? (obs[(int64_t)m * O + c] - mean[c]) / std[c]
-                                  : act[(int64_t)m * A + (c - O)];
+  X[(int64_t)m * ldx + c] =
+      c < O ? __builtin_amdgcn_fmed3f((obs[(int64_t)m * O + c] - mean[c]) / std[c], -clip, clip)
+            : act[(int64_t)m * A + (c - O)];
 }
 
 // SAC: u = loc + sigma * eps, a = tanh(u), logp = sum_a [N(u; loc, sigma) - log(1 - a^2 + 1e-6)]
@@ -377,6 +378,7 @@ struct PolicyTail {
   // second pair from stored actions -> enc_out2 (see MlpFwdArgs)
   const float* enc_obs; const float* enc_obs2; const float* enc_act2;
   const float* enc_mean; const float* enc_std;
+  float enc_clip;
   float* enc_out; float* enc_out2;
   int enc_ld;
 };
@@ -403,7 +405,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
       f.post_sigma = tail->sigma; f.post_logp = tail->logp;
       f.noise_scale = tail->noise_scale; f.noise_clip = tail->noise_clip;
       f.enc_obs = tail->enc_obs; f.enc_obs2 = tail->enc_obs2; f.enc_act2 = tail->enc_act2;
-      f.enc_mean = tail->enc_mean; f.enc_std = tail->enc_std;
+      f.enc_mean = tail->enc_mean; f.enc_std = tail->enc_std; f.enc_clip = tail->enc_clip;
       f.enc_out = tail->enc_out; f.enc_out2 = tail->enc_out2; f.enc_O = s.O; f.enc_ld = tail->enc_ld;
       if (tail_done != nullptr) *tail_done = true;
     }
@@ -614,6 +616,7 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
 extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
                                  const float* d_target_critics, const float* d_critics,
                                  const float* d_norm_mean, const float* d_norm_std,
+                                 double norm_clip,
                                  const float* d_observations, const float* d_actions,
                                  const float* d_next_observations, const float* d_rewards,
                                  const float* d_discounts, const float* d_eps,
@@ -656,7 +659,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   tail.eps = d_eps; tail.actions = next_act; tail.logp = kind == 1 ? logp : nullptr;
   tail.noise_scale = (float)noise_scale; tail.noise_clip = (float)noise_clip;
   tail.enc_obs = d_next_observations; tail.enc_obs2 = d_observations; tail.enc_act2 = d_actions;
-  tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std;
+  tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std; tail.enc_clip = clip_bound(norm_clip);
   tail.enc_out = X; tail.enc_out2 = X2; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
@@ -680,7 +683,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   if (!tail_done) {
     hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads, 2),
                        dim3(threads), 0, st, d_next_observations, next_act, d_norm_mean, d_norm_std,
-                       X, B, O, A, ldx, d_observations, d_actions, X2);
+                       clip_bound(norm_clip), X, B, O, A, ldx, d_observations, d_actions, X2);
   }
   TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                       d_critics, X2));
@@ -698,7 +701,8 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
 // (actors.py:238-267).  Gradient SUMS for the actor + 8 statistics {loss_sum, 0.., B, ..}.
 extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                                   const float* d_critics, const float* d_norm_mean,
-                                  const float* d_norm_std, const float* d_observations,
+                                  const float* d_norm_std, double norm_clip,
+                                  const float* d_observations,
                                   const float* d_eps, float* d_grad_sums, int32_t B, int32_t O,
                                   int32_t H, int32_t A, double entropy_coeff, void* d_workspace,
                                   int64_t workspace_bytes, void* stream) {
@@ -730,6 +734,7 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = d_eps; tail.actions = act;
   tail.sigma = kind == 0 ? nullptr : sigma; tail.logp = kind == 0 ? nullptr : logp;
   tail.enc_obs = d_observations; tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std;
+  tail.enc_clip = clip_bound(norm_clip);
   tail.enc_out = X; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
@@ -746,7 +751,8 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   }
   if (!tail_done) {
     hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads),
-                       0, st, d_observations, act, d_norm_mean, d_norm_std, X, B, O, A, ldx);
+                       0, st, d_observations, act, d_norm_mean, d_norm_std, clip_bound(norm_clip), X,
+                       B, O, A, ldx);
   }
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
   hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,

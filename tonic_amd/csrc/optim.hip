@@ -45,49 +45,8 @@ __device__ __forceinline__ float polyak(float target, float online, float keep, 
 // critic together.
 struct AdamPair { AdamArgs net[2]; };
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamPair pair) {
-  const AdamArgs& a = blockIdx.y == 0 ? pair.net[0] : pair.net[1];
-  if (a.polyak_target != nullptr && (int)blockIdx.x >= a.adam_blocks) {
-    // the target entries OUTSIDE this optimizer block: their online values are final already
-    const int64_t first = (int64_t)((int)blockIdx.x - a.adam_blocks) * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)((int)gridDim.x - a.adam_blocks) * blockDim.x;
-    for (int64_t i = first; i < a.polyak_total; i += stride) {
-      if (i >= a.polyak_offset && i < a.polyak_offset + a.n) continue;
-      a.polyak_target[i] = polyak(a.polyak_target[i], a.polyak_online[i], a.polyak_keep, a.polyak_mix);
-    }
-    return;
-  }
-  if (a.skip != nullptr && *a.skip != 0) return;
-  if (a.stats_kind == 1 && a.adv_stats != nullptr && a.adv_stats[2] != 0.f) return;  // actors.py:71
-  const int step = a.state[0] + 1;
-  const double bias1 = 1.0 - pow(a.beta1_d, (double)step);
-  const double bias2 = 1.0 - pow(a.beta2_d, (double)step);
-  const float step_size = (float)(a.lr_d / bias1);                 // adam.py:533
-  const float bias2_sqrt = (float)sqrt(bias2);                     // adam.py:535
-  const float w1 = (float)(1.0 - a.beta1_d), w2 = (float)(1.0 - a.beta2_d);
-  const int64_t grid = a.polyak_target != nullptr ? a.adam_blocks : (int64_t)gridDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += grid * blockDim.x) {
-    const float g = a.grad_sums[i] * a.grad_scale;
-    float m = a.exp_avg[i], v = a.exp_avg_sq[i];
-    m = m + w1 * (g - m);                                          // lerp_, adam.py:457
-    v = v * a.beta2 + w2 * (g * g);                                // mul_().addcmul_(), :476
-    const float denom = sqrtf(v) / bias2_sqrt + a.eps;             // :545
-    const float p = a.params[i] - step_size * (m / denom);         // addcdiv_, :547
-    a.params[i] = p;
-    a.exp_avg[i] = m;
-    a.exp_avg_sq[i] = v;
-    if (a.polyak_target != nullptr) {                               // this entry's target, same thread
-      float* t = a.polyak_target + a.polyak_offset + i;
-      *t = polyak(*t, p, a.polyak_keep, a.polyak_mix);
-    }
-  }
-}
-
 // One thread: bump the step counter, turn the statistic sums into the logged values.
-__global__ void adam_finalize_kernel(AdamPair pair) {
-  const AdamArgs& a = blockIdx.y == 0 ? pair.net[0] : pair.net[1];
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (a.skip != nullptr && *a.skip != 0) return;
+__device__ void adam_finalize(const AdamArgs& a) {
   const float* st = a.grad_sums + a.n;
   const bool all_zero = a.stats_kind == 1 && a.adv_stats != nullptr && a.adv_stats[2] != 0.f;
   if (!all_zero) a.state[0] += 1;
@@ -120,6 +79,108 @@ __global__ void adam_finalize_kernel(AdamPair pair) {
     a.info_row[0] = st[0] * a.grad_scale;      // actor loss (actors.py:179,257)
     a.info_row[6] = 1.f;
   }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamPair pair) {
+  const AdamArgs& a = blockIdx.y == 0 ? pair.net[0] : pair.net[1];
+  if (a.polyak_target != nullptr && (int)blockIdx.x >= a.adam_blocks) {
+    // the target entries OUTSIDE this optimizer block: their online values are final already
+    const int64_t first = (int64_t)((int)blockIdx.x - a.adam_blocks) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)((int)gridDim.x - a.adam_blocks) * blockDim.x;
+    for (int64_t i = first; i < a.polyak_total; i += stride) {
+      if (i >= a.polyak_offset && i < a.polyak_offset + a.n) continue;
+      a.polyak_target[i] = polyak(a.polyak_target[i], a.polyak_online[i], a.polyak_keep, a.polyak_mix);
+    }
+    return;
+  }
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int64_t grid = a.polyak_target != nullptr ? a.adam_blocks : (int64_t)gridDim.x;
+  if ((int64_t)blockIdx.x >= grid) return;         // (pairs: the shorter network's spare blocks)
+  const bool all_zero = a.stats_kind == 1 && a.adv_stats != nullptr && a.adv_stats[2] != 0.f;  // actors.py:71
+  const int step = a.state[0] + 1;
+  if (!all_zero) {
+    const double bias1 = 1.0 - pow(a.beta1_d, (double)step);
+    const double bias2 = 1.0 - pow(a.beta2_d, (double)step);
+    const float step_size = (float)(a.lr_d / bias1);                 // adam.py:533
+    const float bias2_sqrt = (float)sqrt(bias2);                     // adam.py:535
+    const float w1 = (float)(1.0 - a.beta1_d), w2 = (float)(1.0 - a.beta2_d);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += grid * blockDim.x) {
+      const float g = a.grad_sums[i] * a.grad_scale;
+      float m = a.exp_avg[i], v = a.exp_avg_sq[i];
+      m = m + w1 * (g - m);                                          // lerp_, adam.py:457
+      v = v * a.beta2 + w2 * (g * g);                                // mul_().addcmul_(), :476
+      const float denom = sqrtf(v) / bias2_sqrt + a.eps;             // :545
+      const float p = a.params[i] - step_size * (m / denom);         // addcdiv_, :547
+      a.params[i] = p;
+      a.exp_avg[i] = m;
+      a.exp_avg_sq[i] = v;
+      if (a.polyak_target != nullptr) {                               // this entry's target, same thread
+        float* t = a.polyak_target + a.polyak_offset + i;
+        *t = polyak(*t, p, a.polyak_keep, a.polyak_mix);
+      }
+    }
+  }
+  // The LAST optimizer workgroup to get here finalises (step counter, logged statistics, KL stop
+  // flag) — it used to be a launch of its own (4.6 us for an 8-float row).  Every workgroup has
+  // read state[0] / the skip flag before it arrives, so the writes below race with nobody.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* arrivals = reinterpret_cast<unsigned*>(a.state + 3);
+    const unsigned before = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    if (before == (unsigned)grid - 1) {
+      __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      adam_finalize(a);
+    }
+  }
+}
+
+// ---- gradient-norm clipping: torch.nn.utils.clip_grad_norm_ on the flat gradient-sum block ----
+// Pass 1: fixed-order partial sums of squares (float64) of a contiguous slice per workgroup.
+constexpr int kClipBlocks = 64;
+
+__global__ __launch_bounds__(256) void clip_partials_kernel(const float* sums, int64_t n,
+                                                            double* partials,
+                                                            const int32_t* skip) {
+  __shared__ double red[256];
+  if (skip != nullptr && *skip != 0) return;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per, hi = min(n, lo + per);
+  double acc = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const double g = (double)sums[i];
+    acc += g * g;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// Pass 2: every workgroup folds the partials in index order (same bits everywhere) into ||g|| and
+// the factor min(1, max_norm / (||g|| + 1e-6)), then scales its slice of the sums in place.
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* sums, int64_t n,
+                                                         const double* partials, int blocks,
+                                                         double grad_scale, float max_norm,
+                                                         float* report, const int32_t* skip) {
+  __shared__ float coef_shared;
+  if (skip != nullptr && *skip != 0) return;
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    for (int b = 0; b < blocks; ++b) total += partials[b];
+    const float norm = (float)(sqrt(total) * grad_scale);        // norm of the MEAN gradient
+    const float c = max_norm / (norm + 1e-6f);                    // clip_grad.py: clip_coef ...
+    coef_shared = c < 1.0f ? c : 1.0f;                            // ... clamped to 1
+    if (blockIdx.x == 0 && report != nullptr) { report[0] = coef_shared; report[1] = norm; }
+  }
+  __syncthreads();
+  const float coef = coef_shared;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    sums[i] = sums[i] * coef;
 }
 
 __global__ __launch_bounds__(256) void polyak_kernel(float* target, const float* online,
@@ -187,7 +248,6 @@ int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, flo
   }
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, st, pair);
-  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(64), 0, st, pair);
   TONIC_CHECK_LAUNCH(what);
   return TONIC_OK;
 }
@@ -216,7 +276,6 @@ extern "C" int tonic_adam_step_pair(
   const int blocks = adam_blocks_for(param_count_a > param_count_b ? param_count_a : param_count_b);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks, 2), dim3(256), 0, st, pair);
-  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1, 2), dim3(64), 0, st, pair);
   TONIC_CHECK_LAUNCH("tonic_adam_step_pair");
   return TONIC_OK;
 }
@@ -248,6 +307,35 @@ extern "C" int tonic_adam_polyak_step(float* d_online, const float* d_grad_sums,
                      param_count, grad_scale, lr, beta1, beta2, eps, stats_kind, 0.0, 0.0, nullptr,
                      d_info_row, nullptr, d_target, d_online, total_count, block_offset, coeff,
                      stream, "tonic_adam_polyak_step");
+}
+
+extern "C" int64_t tonic_clip_workspace_bytes(int64_t n) {
+  (void)n;
+  return kClipBlocks * (int64_t)sizeof(double) + 16;
+}
+
+extern "C" int tonic_clip_grad_norm(float* d_grad_sums, int64_t n, double grad_scale,
+                                    double max_norm, const int32_t* d_skip_flag,
+                                    void* d_workspace, int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_grad_sums && d_workspace && n > 0 && max_norm > 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_clip_grad_norm: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_clip_workspace_bytes(n), TONIC_ERR_WORKSPACE,
+                "tonic_clip_grad_norm: workspace of %lld bytes, %lld needed",
+                (long long)workspace_bytes, (long long)tonic_clip_workspace_bytes(n));
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > kClipBlocks) blocks = kClipBlocks;
+  double* partials = static_cast<double*>(d_workspace);
+  float* report = reinterpret_cast<float*>(partials + kClipBlocks);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(clip_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grad_sums, n,
+                     partials, d_skip_flag);
+  int64_t scale_blocks = (n + 255) / 256;
+  if (scale_blocks > 1024) scale_blocks = 1024;
+  hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)scale_blocks), dim3(256), 0, st,
+                     d_grad_sums, n, partials, (int)blocks, grad_scale, (float)max_norm, report,
+                     d_skip_flag);
+  TONIC_CHECK_LAUNCH("tonic_clip_grad_norm");
+  return TONIC_OK;
 }
 
 extern "C" int tonic_polyak_update(float* d_target, const float* d_online, int64_t n,

@@ -36,9 +36,6 @@ class MeanStd(torch.nn.Module):
 
     def attach(self, device):
         """Allocates the HBM accumulators read/written by tonic_segment_store."""
-        if self.clip is not None:
-            raise NotImplementedError('MeanStd(clip=...) is not supported by the HIP critic '
-                                      'kernel (no default model enables it)')
         size = int(np.prod(self.mean.shape))
         self.device_sums = torch.zeros(2 * size, dtype=torch.float32, device=device)
         return self

@@ -50,6 +50,9 @@ class _FlatUpdater:
         self.state = torch.zeros(4, dtype=torch.int32, device=device)   # {step, stop, -, -}
         self.workspace = None
         self.scratch_info = torch.zeros(INFO_WIDTH, dtype=torch.float32, device=device)
+        self.gradient_clip = float(getattr(self, 'gradient_clip', 0) or 0)
+        self.clip_workspace = torch.zeros(self.lib.tonic_clip_workspace_bytes(self.count),
+                                          dtype=torch.uint8, device=device)
         self.world_size = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world_size = torch.distributed.get_world_size()
@@ -66,6 +69,15 @@ class _FlatUpdater:
         assert buffer.numel() == self.count + INFO_WIDTH
         self.grad_sums = buffer
 
+    def enqueue_clip(self, n_global, skip=None):
+        """clip_grad_norm_ between backward and the optimizer step (actors.py:96-98,
+        critics.py:24-25): on the (all-reduced) gradient sums, in place."""
+        if self.gradient_clip > 0:
+            _lib.check(self.lib.tonic_clip_grad_norm(
+                _lib.ptr(self.grad_sums), self.count, 1.0 / n_global, self.gradient_clip, skip,
+                _lib.ptr(self.clip_workspace), self.clip_workspace.numel(),
+                _lib.current_stream()), 'tonic_clip_grad_norm')
+
     def _step(self, n_global, info_row, adv_stats=None, skip=None, kl_threshold=0.0,
               entropy_coeff=0.0, allreduce=True, targets=None):
         """All-reduce of the gradient sums (world > 1) + Adam + statistics.  `targets` =
@@ -74,6 +86,7 @@ class _FlatUpdater:
         step, as ddpg.py:105-112 orders them)."""
         if self.world_size > 1 and allreduce:
             torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
+        self.enqueue_clip(n_global, skip)
         h = self.hyper
         if targets is not None:
             target, online, offset, coeff = targets
@@ -101,6 +114,9 @@ def enqueue_step_pair(actor, critic, n_local, adv_stats, actor_info, critic_info
         actor.enqueue_step(n_local, adv_stats, actor_info, allreduce=False)
         critic.enqueue_step(n_local, critic_info, allreduce=False)
         return
+    n_global = n_local * actor.world_size
+    actor.enqueue_clip(n_global, actor.stop_flag_ptr())
+    critic.enqueue_clip(n_global)
     p = _lib.ptr
     _lib.check(actor.lib.tonic_adam_step_pair(
         p(actor.flat.flat), p(actor.grad_sums), p(actor.exp_avg), p(actor.exp_avg_sq),
@@ -122,8 +138,6 @@ class ClippedRatio(_FlatUpdater):
         self.kl_threshold = kl_threshold
         self.entropy_coeff = entropy_coeff
         self.gradient_clip = gradient_clip
-        if gradient_clip > 0:
-            raise NotImplementedError('gradient_clip > 0 is not implemented in the fused PPO path')
 
     def initialize(self, model):
         self.model = model
@@ -178,8 +192,6 @@ class VRegression(_FlatUpdater):
     def __init__(self, loss=None, optimizer=None, gradient_clip=0):
         if loss is not None and not isinstance(loss, torch.nn.MSELoss):
             raise NotImplementedError('only the default MSE loss is fused')
-        if gradient_clip > 0:
-            raise NotImplementedError('gradient_clip > 0 is not implemented in the fused PPO path')
         self.loss = loss
         self.optimizer = optimizer
         self.gradient_clip = gradient_clip
@@ -202,11 +214,16 @@ class VRegression(_FlatUpdater):
             return self._unit_mean, self._unit_std
         return self.normalizer._mean.data, self.normalizer._std.data
 
+    def norm_clip(self):
+        """MeanStd(clip=...) (mean_stds.py:37-38) as the C ABI wants it: 0 = None."""
+        return float(getattr(self.normalizer, 'clip', None) or 0.0)
+
     def forward_values(self, observations, out):
         mean, std = self.norm_tensors()
         p = _lib.ptr
         _lib.check(self.lib.tonic_value_forward(
-            p(self.flat.flat), p(mean), p(std), p(observations), p(out), observations.shape[0],
+            p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(out),
+            observations.shape[0],
             self.observation_size, _lib.current_stream()), 'tonic_value_forward')
         return out
 
@@ -216,8 +233,9 @@ class VRegression(_FlatUpdater):
         mean, std = self.norm_tensors()
         p = _lib.ptr
         _lib.check(self.lib.tonic_value_regression_grad(
-            p(self.flat.flat), p(mean), p(std), p(observations), p(returns), p(self.grad_sums),
-            n, self.observation_size, p(ws), ws.numel(), _lib.current_stream()),
+            p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(returns),
+            p(self.grad_sums), n, self.observation_size, p(ws), ws.numel(),
+            _lib.current_stream()),
             'tonic_value_regression_grad')
 
     def enqueue_step(self, n_local, info_row, allreduce=True):
@@ -286,6 +304,9 @@ class _QUpdater(_FlatUpdater):
             return self._unit
         return self.normalizer._mean.data, self.normalizer._std.data
 
+    def norm_clip(self):
+        return float(getattr(self.normalizer, 'clip', None) or 0.0)
+
     def _offpolicy_workspace(self, batch):
         need = self.lib.tonic_offpolicy_workspace_bytes(batch, self.observation_size,
                                                         self.action_size, self.hidden)
@@ -333,7 +354,8 @@ class _TwinCriticQLearning(_QUpdater):
         p = _lib.ptr
         _lib.check(self.lib.tonic_twin_q_grad(
             self.kind, p(self._policy_params()), p(self.model.flat_target_critics.flat),
-            p(self.flat.flat), p(mean), p(std), p(batch['observations']), p(batch['actions']),
+            p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(batch['observations']),
+            p(batch['actions']),
             p(batch['next_observations']), p(batch['rewards']), p(batch['discounts']), p(eps),
             p(self.grad_sums), B, self.observation_size, self.hidden, self.action_size,
             float(getattr(self, 'entropy_coeff', 0.0)), float(noise.scale if noise else 0.0),
@@ -357,6 +379,7 @@ class DeterministicQLearning(_TwinCriticQLearning):
     def __init__(self, loss=None, optimizer=None, gradient_clip=0):
         _check_plain(loss, gradient_clip)
         self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
 
     def _policy_params(self):
         return self.model.flat_target_actor.flat
@@ -375,6 +398,7 @@ class TwinCriticDeterministicQLearning(_TwinCriticQLearning):
     def __init__(self, loss=None, optimizer=None, target_action_noise=None, gradient_clip=0):
         _check_plain(loss, gradient_clip)
         self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
         self.target_action_noise = target_action_noise or TargetActionNoise(scale=0.2, clip=0.5)
 
     def _policy_params(self):
@@ -388,6 +412,7 @@ class TwinCriticSoftQLearning(_TwinCriticQLearning):
     def __init__(self, loss=None, optimizer=None, entropy_coeff=0.2, gradient_clip=0):
         _check_plain(loss, gradient_clip)
         self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
         self.entropy_coeff = entropy_coeff
 
     def _policy_params(self):
@@ -411,7 +436,7 @@ class _ActorQGradient(_QUpdater):
         p = _lib.ptr
         _lib.check(self.lib.tonic_actor_q_grad(
             self.kind, p(self.flat.flat), p(self.model.flat_critics.flat), p(mean), p(std),
-            p(observations), p(eps), p(self.grad_sums), B, self.observation_size, self.hidden,
+            self.norm_clip(), p(observations), p(eps), p(self.grad_sums), B, self.observation_size, self.hidden,
             self.action_size, float(getattr(self, 'entropy_coeff', 0.0)), p(ws), ws.numel(),
             _lib.current_stream()), 'tonic_actor_q_grad')
         self._step(n_global or B * self.world_size, info_row, targets=targets)
@@ -430,6 +455,7 @@ class DeterministicPolicyGradient(_ActorQGradient):
     def __init__(self, optimizer=None, gradient_clip=0):
         _check_plain(None, gradient_clip)
         self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
 
 
 class TwinCriticSoftDeterministicPolicyGradient(_ActorQGradient):
@@ -439,11 +465,10 @@ class TwinCriticSoftDeterministicPolicyGradient(_ActorQGradient):
     def __init__(self, optimizer=None, entropy_coeff=0.2, gradient_clip=0):
         _check_plain(None, gradient_clip)
         self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
         self.entropy_coeff = entropy_coeff
 
 
 def _check_plain(loss, gradient_clip):
     if loss is not None and not isinstance(loss, torch.nn.MSELoss):
         raise NotImplementedError('only the default MSE loss is fused')
-    if gradient_clip > 0:
-        raise NotImplementedError('gradient_clip > 0 is not implemented in the fused path')
