@@ -278,25 +278,38 @@ class PPO(A2C):
         self._infos.zero_()
         actor.reset_stop()
         world = actor.world_size
-        if world > 1 and getattr(self, '_joint_grads', None) is None:
-            # one all-reduce per iteration for BOTH networks: [actor sums|8 stats|critic sums|8 stats]
-            na, nc = actor.count + updaters.INFO_WIDTH, critic.count + updaters.INFO_WIDTH
-            self._joint_grads = torch.zeros(na + nc, device=self.device)
-            actor.share_gradient_buffer(self._joint_grads[:na])
-            critic.share_gradient_buffer(self._joint_grads[na:])
         # Full batch (ppo.py:40-47 over segments.py:55-57) or shuffled minibatches
         # (segments.py:58-65); the advantages stay raw and are normalised in-register with the
         # GLOBAL statistics, exactly what get_full computes before the reference slices.
+        if world == 1:
+            for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
+                actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+                critic.enqueue_grad(obs, returns)
+                updaters.enqueue_step_pair(actor, critic, obs.shape[0], replay.adv_stats,
+                                           self._infos[0, it], self._infos[1, it])
+            return self._infos
+        # Several ranks: every iteration exchanges [gradient sums | 8 statistics] of both networks
+        # (RCCL over xGMI), each reduction hidden behind the OTHER network's fused grad kernel:
+        #   actor grad i | all-reduce(actor i) over critic grad i | Adam(actor i)
+        #   critic grad i | all-reduce(critic i) over Adam(actor i) + actor grad i+1 | Adam(critic i)
+        # After the KL stop the actor half is zero-filled on every rank alike and its step is
+        # skipped by the same device flag everywhere.
+        all_reduce = torch.distributed.all_reduce
+        pending = None                           # (work handle, rows, info row) of the critic
         for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
             n = obs.shape[0]
             actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+            actor_sums = all_reduce(actor.grad_sums, async_op=True)
+            if pending is not None:
+                pending[0].wait()
+                critic.enqueue_step(pending[1], pending[2], allreduce=False)
             critic.enqueue_grad(obs, returns)
-            if world > 1:
-                # After the KL stop the actor half is stale on every rank alike and ignored
-                # (tonic_adam_step is skipped by the same device flag on all ranks).
-                torch.distributed.all_reduce(self._joint_grads)          # RCCL over xGMI
-            updaters.enqueue_step_pair(actor, critic, n, replay.adv_stats, self._infos[0, it],
-                                       self._infos[1, it])
+            pending = (all_reduce(critic.grad_sums, async_op=True), n, self._infos[1, it])
+            actor_sums.wait()
+            actor.enqueue_step(n, replay.adv_stats, self._infos[0, it], allreduce=False)
+        if pending is not None:
+            pending[0].wait()
+            critic.enqueue_step(pending[1], pending[2], allreduce=False)
         return self._infos
 
     def _update(self):
