@@ -435,8 +435,10 @@ def main():
 
     from tonic_amd.utils import logger
     logger.get_current_logger().store = lambda *a, **k: None      # no log accumulation here
+    # (the device-resident leg replays a hipGraph: single-process only — a capture next to
+    #  RCCL's watchdog threads is not worth risking the multi-GPU line for)
     agent, loop, rollout, main_run = measure_job(workers, rank, world, args.steps, args.warmup,
-                                                 capture)
+                                                 capture, device_too=world == 1)
     name = 'HalfCheetah-v3' if args.workload == 'cfg2' else 'AntBulletEnv-v0'
     result = {
         'metric': f'env steps/sec (+ learner updates/sec), PPO {name.split("-")[0]} '
@@ -458,8 +460,9 @@ def main():
                    'collector_transport': agent.transport},
         'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
         'actor_iterations_last_update': main_run['actor_iterations'],
-        'device_resident': main_run['device_resident'],
     }
+    if 'device_resident' in main_run:
+        result['device_resident'] = main_run['device_resident']
 
     if world > 1:
         # RCCL really saw every rank: after the updates above the replicated parameters must be
@@ -474,12 +477,12 @@ def main():
         result['backend'] = torch.distributed.get_backend()
         if args.scaling == 'weak' and args.workload == 'cfg2' and W % world == 0:
             # the metric's own configuration: 256 workers in total, split over the ranks
-            _, _, _, strong = measure_job(W // world, rank, world, args.steps, 1, capture)
+            _, _, _, strong = measure_job(W // world, rank, world, args.steps, 1, capture,
+                                          device_too=False)
             result['strong_scaling'] = dict(
                 global_workers=W, workers_per_gpu=W // world,
                 env_steps_per_sec=round(strong['value'], 1),
-                ms_per_step=round(strong['ms_per_step'], 3),
-                device_resident=strong['device_resident'])
+                ms_per_step=round(strong['ms_per_step'], 3))
 
     if rank == 0 and not args.no_extras and world == 1:
         # phase split (untimed extras): where a step goes
