@@ -297,7 +297,11 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
  * memory is the DMA source.  transport 0: the fused act kernel reads observations / noise / the
  * previous outcome from the mapped block over PCIe and writes actions + completion words back;
  * transport 1: hipMemcpyAsync H2D + kernel + hipMemcpyAsync D2H on the collector's own stream and
- * an event.  Per environment step t (tonic/utils/trainer.py:44-56):
+ * an event; transport 2: as 0, but the kernel is RESIDENT for a rollout — launched by the first
+ * step, it waits for the host's next command word in pinned memory instead of being launched
+ * again, and parks itself (the next step starts it again) after TONIC_AMD_COLLECTOR_PARK_US
+ * (default 200) microseconds without a command, e.g. under a slow simulator or a test episode.
+ * Per environment step t (tonic/utils/trainer.py:44-56):
  *   tonic_collector_ppo_step(row t)   ONE launch: policy forward + sample + log-prob of the block's
  *                                     observations (a2c.py:75-85) -> Segment row t and the block's
  *                                     actions; MeanStd.record of the observations (a2c.py:66-69);

@@ -94,7 +94,7 @@ if __name__ == '__main__':
     parser.add_argument('--act', type=int, default=6)
     args = parser.parse_args()
     out = dict(W=args.workers, O=args.obs, A=args.act, raw=[], agent=[])
-    transports = [int(t) for t in os.environ.get('TRANSPORTS', '0,1').split(',')]
+    transports = [int(t) for t in os.environ.get('TRANSPORTS', '2,0,1').split(',')]
     for transport in transports:
         out['raw'].append(raw_round_trip(args.workers, args.obs, args.act, transport))
     if os.environ.get('RAW_ONLY') != '1':

@@ -54,4 +54,6 @@ if __name__ == '__main__':
     for W in (256, 6, 1280):
         total += main(W=W)
     total += main(transport=1, steps=4000)
+    for W in (256, 6, 1280):
+        total += main(W=W, transport=2)
     sys.exit(1 if total else 0)

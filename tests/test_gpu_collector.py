@@ -33,7 +33,7 @@ def _segment(T, W, O, A):
                 rewards=new(T, W), resets=new(T, W), terminations=new(T, W), log_probs=new(T, W))
 
 
-@pytest.mark.parametrize('transport', [0, 1])
+@pytest.mark.parametrize('transport', [0, 1, 2])
 @pytest.mark.parametrize('O,A,W', [(17, 6, 256), (28, 8, 1280), (3, 1, 5)])
 def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     """T host-in-the-loop steps through the C entry points: actions and log-probs against
@@ -111,7 +111,7 @@ def test_collector_equals_device_resident_collect(lib):
         p(ref['actions']), p(ref['next_observations']), p(ref['rewards']), p(ref['resets']),
         p(ref['terminations']), p(ref['log_probs']), p(ref_sums), 0, T, W, O, A, None), 'collect')
     torch.cuda.synchronize()
-    for transport in (0, 1):
+    for transport in (0, 1, 2):
         block = Block(W, O, A)
         collector = Collector(block, transport)
         seg = _segment(T, W, O, A)
@@ -236,6 +236,52 @@ def test_completion_words_order_the_actions(lib):
     assert stress.main(W=6, steps=6144) == 0
     assert stress.main(W=256, steps=2048) == 0
     assert stress.main(W=256, steps=1024, transport=1) == 0
+    assert stress.main(W=6, steps=6144, transport=2) == 0
+    assert stress.main(W=256, steps=4096, transport=2) == 0
+
+
+def test_resident_kernel_parks_and_resumes(lib):
+    """transport 2: the resident collect kernel leaves after ~200 us without a command (a slow
+    simulator, a test episode, the end of training) and the next step starts it again; a rollout
+    may also end while it is parked.  Same Segment as the launch-per-step transport."""
+    import time
+    from tonic_amd.collector import Block, Collector
+    O, A, W, T = 17, 6, 48, 9
+    rng = np.random.RandomState(1)
+    params = _actor(O, A, 3)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in params])).cuda()
+    obs = rng.standard_normal((T + 1, W, O)).astype(np.float32)
+    eps = rng.standard_normal((T, W, A)).astype(np.float32)
+    rewards = rng.standard_normal((T, W)).astype(np.float32)
+    results = {}
+    for transport, pauses in ((0, ()), (2, (2, 3, 6, 8))):
+        block = Block(W, O, A)
+        collector = Collector(block, transport)
+        seg = _segment(T, W, O, A)
+        sums = torch.zeros(2 * O, device='cuda')
+        collector.bind_segment(seg, sums, T)
+        torch.cuda.synchronize()
+        collector.begin_rollout(flat)
+        for t in range(T):
+            if t in pauses:
+                time.sleep(0.02)                  # 100 x the park time
+            block.observations[:] = obs[t]
+            block.eps[t & 1][:] = eps[t]
+            collector.ppo_step(t, t & 1, t > 0)
+            collector.wait_actions()
+            block.next_observations[:] = obs[t + 1]
+            block.rewards[:] = rewards[t]
+            block.resets[:] = 0
+            block.terminations[:] = 0
+        if pauses:
+            time.sleep(0.02)                      # the rollout ends while the kernel is parked
+        collector.end_rollout(T - 1)
+        torch.cuda.synchronize()
+        results[transport] = {k: v.cpu().numpy() for k, v in seg.items()}
+        results[transport]['sums'] = sums.cpu().numpy()
+        collector.close()
+    for key, want in results[0].items():
+        assert np.array_equal(results[2][key], want), key
 
 
 @pytest.mark.parametrize('name,golden_name,prefix', [

@@ -38,10 +38,21 @@ struct Collect16Args {
   unsigned* done_flags; unsigned done_seq;
 };
 
+// What the resident form of the collect kernel needs besides the per-step arguments.
+struct CollectResident {
+  const unsigned long long* command;   // pinned host memory: the host's next command word
+  unsigned* relay;                     // device memory, zero at launch: the leader's park notice
+  unsigned* parked;                    // pinned host memory: sequence number the leader parked at
+  const float* eps0; const float* eps1;
+  unsigned first_seq;
+  unsigned long long park_ticks;       // 100 MHz ticks without a command before parking
+};
+
 int collect16_ks1(int O);
 int collect16_ap(int A);
 int collect16_blocks(int64_t W);          // workgroups (= completion words) of one launch
 int launch_collect16(const Collect16Args& c, hipStream_t stream);
+int launch_collect_resident(const Collect16Args& c, const CollectResident& r, hipStream_t stream);
 int launch_actor_pack(const float* d_actor_params, float* d_packed, int O, int A,
                       hipStream_t stream);
 

@@ -45,7 +45,9 @@ struct BlockHeader {
   alignas(64) uint32_t go_seq;                     // futex: bumped once per environment step
   alignas(64) uint32_t done_count;                 // futex: groups that finished the step
   alignas(64) uint32_t shutdown;
-  alignas(64) uint32_t act_seq;                    // sequence number of the last act launch
+  alignas(64) uint32_t act_seq;                    // sequence number of the last act command
+  alignas(64) uint64_t command;                    // transport 2: the host's next command word
+  alignas(64) uint32_t parked;                     // transport 2: written by the resident kernel
 };
 static_assert(sizeof(BlockHeader) <= kHeaderBytes, "header does not fit its page");
 
@@ -221,6 +223,10 @@ struct tonic_collector {
   int64_t rows;
   unsigned seq;
   bool actor_packed, waiting;
+  // transport 2: the resident collect kernel
+  unsigned* d_relay;
+  bool live;
+  double park_us;
 };
 
 namespace {
@@ -236,7 +242,7 @@ namespace {
 
 // Where the kernels read / write field `f`: the mapped block (transport 0) or its device copy.
 float* field(tonic_collector* c, int f) {
-  char* base = c->transport == 0 ? c->mapped : c->staged;
+  char* base = c->transport != 1 ? c->mapped : c->staged;
   return reinterpret_cast<float*>(base + c->host->offset[f]);
 }
 
@@ -277,8 +283,9 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   BlockHeader* h = header_of(block);
   TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_create: not an initialised collector block");
-  TONIC_REQUIRE(transport == 0 || transport == 1, TONIC_ERR_INVALID_ARGUMENT,
-                "tonic_collector_create: transport must be 0 (mapped) or 1 (hipMemcpyAsync)");
+  TONIC_REQUIRE(transport >= 0 && transport <= 2, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_create: transport must be 0 (mapped, one launch per step), "
+                "1 (hipMemcpyAsync) or 2 (mapped, resident kernel)");
   TONIC_REQUIRE(h->O <= 32 && h->A <= 8, TONIC_ERR_UNSUPPORTED_SHAPE,
                 "tonic_collector_create: the fused act kernel serves O <= 32, A <= 8 (got %d, %d)",
                 h->O, h->A);
@@ -311,8 +318,11 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
     return fail("hipEventCreate", e);
   const int64_t packed = PackedActor(collect16_ks1(c->O), collect16_ap(c->A)).total;
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_packed), packed * 4)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess)
+      (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
+  const char* park = getenv("TONIC_AMD_COLLECTOR_PARK_US");
+  c->park_us = park != nullptr ? atof(park) : 200.0;
   if ((e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
     return fail("hipMemset", e);
   c->seq = __atomic_load_n(&h->act_seq, __ATOMIC_ACQUIRE);
@@ -323,9 +333,15 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
 extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (c == nullptr) return TONIC_OK;
   // teardown: nothing useful can be done about a failing release
+  if (c->live) {                     // a stop command (nothing to store) ends the resident kernel
+    c->seq += 1;
+    __atomic_store_n(&c->host->command, ((uint64_t)c->seq << 32) | 8u, __ATOMIC_RELEASE);
+    c->live = false;
+  }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->d_packed) (void)hipFree(c->d_packed);
   if (c->staged) (void)hipFree(c->staged);
+  if (c->d_relay) (void)hipFree(c->d_relay);
   if (c->learner_done) (void)hipEventDestroy(c->learner_done);
   if (c->collect_done) (void)hipEventDestroy(c->collect_done);
   if (c->actions_out) (void)hipEventDestroy(c->actions_out);
@@ -345,7 +361,7 @@ extern "C" int tonic_collector_bind_segment(
     float* d_seg_terminations, float* d_seg_log_probs, float* d_norm_acc, int64_t rows) {
   TONIC_REQUIRE(c && d_seg_observations && d_seg_actions && d_seg_next_observations &&
                     d_seg_rewards && d_seg_resets && d_seg_terminations && d_seg_log_probs &&
-                    rows > 0,
+                    rows > 0 && !c->live,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_bind_segment: bad argument");
   float* seg[7] = {d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
                    d_seg_resets, d_seg_terminations, d_seg_log_probs};
@@ -368,6 +384,44 @@ extern "C" int tonic_collector_begin_rollout(tonic_collector_t* c, const float* 
   return TONIC_OK;
 }
 
+namespace {
+
+Collect16Args step_arguments(tonic_collector* c) {
+  Collect16Args a{};
+  a.packed = c->d_packed;
+  a.obs = field(c, TONIC_COLLECTOR_OBSERVATIONS);
+  a.next_obs = field(c, TONIC_COLLECTOR_NEXT_OBSERVATIONS);
+  a.rewards = field(c, TONIC_COLLECTOR_REWARDS);
+  a.resets = field(c, TONIC_COLLECTOR_RESETS);
+  a.terminations = field(c, TONIC_COLLECTOR_TERMINATIONS);
+  a.seg_obs = c->seg[0]; a.seg_act = c->seg[1]; a.seg_next = c->seg[2]; a.seg_rew = c->seg[3];
+  a.seg_rst = c->seg[4]; a.seg_term = c->seg[5]; a.seg_lp = c->seg[6];
+  a.norm_acc = c->norm_acc;
+  a.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
+  a.W = c->W; a.O = c->O; a.A = c->A;
+  if (c->transport != 1)
+    a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+  return a;
+}
+
+// transport 2: (re)starts the resident kernel; it waits for command number `first_seq`.
+int launch_resident(tonic_collector* c, unsigned first_seq) {
+  TONIC_HIP(hipMemsetAsync(c->d_relay, 0, 4, c->stream), "hipMemsetAsync");
+  CollectResident r{};
+  r.command = reinterpret_cast<const unsigned long long*>(c->mapped + offsetof(BlockHeader, command));
+  r.relay = c->d_relay;
+  r.parked = reinterpret_cast<unsigned*>(c->mapped + offsetof(BlockHeader, parked));
+  r.eps0 = field(c, TONIC_COLLECTOR_EPS0);
+  r.eps1 = field(c, TONIC_COLLECTOR_EPS1);
+  r.first_seq = first_seq;
+  r.park_ticks = (unsigned long long)(c->park_us * 100.0);        // 100 MHz wall clock
+  const int status = launch_collect_resident(step_arguments(c), r, c->stream);
+  if (status == TONIC_OK) c->live = true;
+  return status;
+}
+
+}  // namespace
+
 extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32_t eps_slot,
                                         int32_t store_previous) {
   TONIC_REQUIRE(c && c->seg[0] && c->actor_packed, TONIC_ERR_INVALID_ARGUMENT,
@@ -384,25 +438,24 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
   }
   c->seq += 1;
   __atomic_store_n(&c->host->act_seq, c->seq, __ATOMIC_RELEASE);
-  Collect16Args a{};
-  a.packed = c->d_packed;
-  a.obs = field(c, TONIC_COLLECTOR_OBSERVATIONS);
+  if (c->transport == 2) {
+    if (!c->live) {
+      const int status = launch_resident(c, c->seq);
+      if (status != TONIC_OK) return status;
+    }
+    const uint64_t word = ((uint64_t)c->seq << 32) | ((uint64_t)row << 8) |
+                          (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
+                          (eps_slot == 1 ? 1u : 0u);
+    __atomic_store_n(&c->host->command, word, __ATOMIC_RELEASE);
+    c->waiting = true;
+    return TONIC_OK;
+  }
+  Collect16Args a = step_arguments(c);
   a.eps = eps_slot < 0 ? nullptr
                        : field(c, eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_EPS1);
-  a.next_obs = field(c, TONIC_COLLECTOR_NEXT_OBSERVATIONS);
-  a.rewards = field(c, TONIC_COLLECTOR_REWARDS);
-  a.resets = field(c, TONIC_COLLECTOR_RESETS);
-  a.terminations = field(c, TONIC_COLLECTOR_TERMINATIONS);
-  a.seg_obs = c->seg[0]; a.seg_act = c->seg[1]; a.seg_next = c->seg[2]; a.seg_rew = c->seg[3];
-  a.seg_rst = c->seg[4]; a.seg_term = c->seg[5]; a.seg_lp = c->seg[6];
-  a.norm_acc = c->norm_acc;
-  a.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
-  a.row = row; a.W = c->W; a.O = c->O; a.A = c->A;
+  a.row = row;
   a.outcome_row = store_previous ? row - 1 : -1;
-  if (c->transport == 0) {
-    a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
-    a.done_seq = c->seq;
-  }
+  a.done_seq = c->seq;
   const int status = launch_collect16(a, c->stream);
   if (status != TONIC_OK) return status;
   if (c->transport == 1) {
@@ -426,10 +479,20 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
   int arrived = 0;                                   // words [0, arrived) already carry c->seq
   for (uint64_t spins = 0;; ++spins) {
     bool done;
-    if (c->transport == 0) {
+    if (c->transport != 1) {
       while (arrived < words && __atomic_load_n(flags + arrived, __ATOMIC_ACQUIRE) == c->seq)
         ++arrived;
       done = arrived == words;
+      if (!done && c->transport == 2 &&
+          __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) == c->seq) {
+        // the resident kernel parked while this command was on its way: start it again (the
+        // command word still holds the command; work done twice is idempotent, see the kernel)
+        TONIC_HIP(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        c->live = false;
+        __atomic_store_n(&c->host->parked, 0u, __ATOMIC_RELEASE);
+        const int status = launch_resident(c, c->seq);
+        if (status != TONIC_OK) return status;
+      }
     } else {
       const hipError_t e = hipEventQuery(c->actions_out);
       if (e != hipSuccess && e != hipErrorNotReady) {
@@ -441,7 +504,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
     if (done) break;
     cpu_relax();
     if ((spins & 0xfff) == 0xfff) {
-      if (c->transport == 0) {          // a failed launch never writes the flag: look at the stream
+      if (c->transport != 1) {          // a failed launch never writes the flags: look at the stream
         const hipError_t e = hipStreamQuery(c->stream);
         if (e != hipSuccess && e != hipErrorNotReady) {
           set_error("tonic_collector_wait_actions: %s", hipGetErrorString(e));
@@ -462,6 +525,19 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
                                            void* learner_stream) {
   TONIC_REQUIRE(c && c->seg[0] && last_row < c->rows && !c->waiting, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_end_rollout: bad argument");
+  if (c->live) {
+    // transport 2: a stop command — the copy workgroups store the pending outcome first — then
+    // the resident kernel leaves and the stream drains
+    c->seq += 1;
+    const uint64_t word = ((uint64_t)c->seq << 32) | ((uint64_t)(last_row + 1) << 8) |
+                          (last_row >= 0 ? 4u : 0u) | 8u;
+    __atomic_store_n(&c->host->command, word, __ATOMIC_RELEASE);
+    c->waiting = true;
+    const int status = tonic_collector_wait_actions(c, 60.0);
+    if (status != TONIC_OK) return status;
+    c->live = false;                   // (a kernel relaunched by the wait has left as well)
+    last_row = -1;                     // stored
+  }
   if (last_row >= 0) {
     if (c->transport == 1) {
       const int status = stage_inputs(c, 0);

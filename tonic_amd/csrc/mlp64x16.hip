@@ -699,19 +699,44 @@ constexpr int kCollectCopyBlocks = 4;  // workgroups that copy the transition ou
 // For sources in pinned HOST memory every load instruction becomes PCIe read requests and every
 // dependent batch a PCIe round trip (~2 us): the fields are therefore read exactly once, in as
 // few and as wide requests as possible.  Handles up to 8 * threads * 4 floats per call.
+// Loads from the pinned host block.  SYS = false (one launch per environment step): streaming
+// loads — the launch's acquire made L2 forget the previous step's lines.  SYS = true (resident
+// kernel): system-scope loads (sc0 sc1) that bypass the XCD's L2, where the lines of the previous
+// step would otherwise still be found.
+template <bool SYS>
+__device__ __forceinline__ f32x4 host_load4(const float* base, int64_t vec_index) {
+  if constexpr (SYS) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                                                 0x7fffffff, 0x27000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(vec_index * 16), 0, 17));
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + vec_index);
+  }
+}
+template <bool SYS>
+__device__ __forceinline__ float host_load1(const float* base, int64_t index) {
+  if constexpr (SYS) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                                                 0x7fffffff, 0x27000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(index * 4), 0, 17));
+  } else {
+    return __builtin_nontemporal_load(base + index);
+  }
+}
+
+template <bool SYS>
 __device__ __forceinline__ void wide_copy(const float* src, float* dst, float* lds, int64_t count,
                                           int tid, int threads) {
   const int64_t vecs = count >> 2;
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
   f32x4 v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int64_t i = tid + (int64_t)u * threads;
-    if (i < vecs) v[u] = __builtin_nontemporal_load(s4 + i);
+    if (i < vecs) v[u] = host_load4<SYS>(src, i);
   }
   float tail = 0.f;
   const int64_t ti = (vecs << 2) + tid;
-  if (ti < count) tail = __builtin_nontemporal_load(src + ti);
+  if (ti < count) tail = host_load1<SYS>(src, ti);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int64_t i = tid + (int64_t)u * threads;
@@ -734,9 +759,8 @@ __device__ __forceinline__ void wide_copy(const float* src, float* dst, float* l
 
 // HOST: the step inputs (observations, noise, previous outcome) live in pinned host memory that
 // the kernel reads in place over PCIe (pinned-host collector, transport 0).
-template <int KS1, int AP, bool HOST>
-__global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
-  __shared__ float tile[kCollectLds];
+template <int KS1, int AP, bool HOST, bool SYS>
+__device__ __forceinline__ void collect16_step(const Collect16Args& c, float* tile) {
   const int64_t W = c.W;
   const int O = c.O, A = c.A;
   const int tid = threadIdx.x;
@@ -765,9 +789,10 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
       const int64_t f0 = min(total, part * each), f1 = min(total, f0 + each);
       float* dst = c.seg_next + c.outcome_row * total;
       for (int64_t f = f0; f < f1; f += 8 * 256 * 4)
-        wide_copy(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
+        wide_copy<SYS>(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
       for (int64_t i = part * 256 + tid; i < W; i += stride) {
-        const float rew = c.rewards[i], rst = c.resets[i], term = c.terminations[i];
+        const float rew = host_load1<SYS>(c.rewards, i), rst = host_load1<SYS>(c.resets, i),
+                    term = host_load1<SYS>(c.terminations, i);
         c.seg_rew[c.outcome_row * W + i] = rew;
         c.seg_rst[c.outcome_row * W + i] = rst;
         c.seg_term[c.outcome_row * W + i] = term;
@@ -817,14 +842,13 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
         // the whole chunk (<= 32 KB) as 16-byte requests, all in flight: ONE PCIe round trip
         const float* src = c.obs + w0 * O;
         const int64_t count = rows * O, vecs = count >> 2;
-        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (tid + u * 256 < vecs) v[u] = __builtin_nontemporal_load(s4 + tid + u * 256);
+          if (tid + u * 256 < vecs) v[u] = host_load4<SYS>(src, tid + u * 256);
         const int64_t ti = (vecs << 2) + tid;
         float tail = 0.f;
-        if (ti < count) tail = __builtin_nontemporal_load(src + ti);
+        if (ti < count) tail = host_load1<SYS>(src, ti);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (tid + u * 256 < vecs) {
@@ -885,14 +909,14 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
     float to = 0.f, te = 0.f;
     if constexpr (HOST) {
       if (tid < o_vecs)
-        vo = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.obs + o_first) + tid);
+        vo = host_load4<SYS>(c.obs + o_first, tid);
       if ((o_vecs << 2) + tid < o_count)
-        to = __builtin_nontemporal_load(c.obs + o_first + (o_vecs << 2) + tid);
+        to = host_load1<SYS>(c.obs + o_first, (o_vecs << 2) + tid);
       if (c.eps != nullptr) {
         if (etid < e_vecs)
-          ve = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(c.eps + e_first) + etid);
+          ve = host_load4<SYS>(c.eps + e_first, etid);
         if ((e_vecs << 2) + etid < e_count)
-          te = __builtin_nontemporal_load(c.eps + e_first + (e_vecs << 2) + etid);
+          te = host_load1<SYS>(c.eps + e_first, (e_vecs << 2) + etid);
       }
     } else {
 #pragma unroll
@@ -1021,6 +1045,78 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   collect_signal_done(c);
 }
 
+// One launch per environment step.
+template <int KS1, int AP, bool HOST>
+__global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
+  __shared__ float tile[kCollectLds];
+  collect16_step<KS1, AP, HOST, false>(c, tile);
+}
+
+// RESIDENT form for the pinned-host collector (transport 2): launched once per rollout, every
+// workgroup keeps its role and waits for the host's next command word instead of being launched
+// again — the launch (3.4 us of host call + ~4 us until the first wave runs) and the cold start
+// of a fresh kernel leave the critical path of an environment step (17.7 -> ~9 us from command to
+// actions; scripts/ubench/pingpong.hip measures 5.4 us for the bare exchange of these bytes).
+//   command word (pinned host memory, written by the host with one 8-byte store):
+//     [63:32] sequence number | [31:8] Segment row | bit 3 stop | bit 2 store the previous
+//     outcome | bit 1 noise on | bit 0 noise slot
+// Thread 0 of every workgroup polls it with system-scope loads.  Nobody waits forever: after
+// `park_ticks` of the 100 MHz wall clock without a command the LEADER (the record workgroup, the
+// only role whose work is not idempotent) announces that it parks — to the other workgroups
+// through `relay` (device memory), to the host through `parked` — and exits; the host launches
+// the kernel again when it has the next command.  Workgroups that happened to see that command
+// before they saw the announcement execute it (same inputs, same outputs) and leave afterwards.
+template <int KS1, int AP>
+__global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args c,
+                                                                   CollectResident r) {
+  __shared__ float tile[kCollectLds];
+  __shared__ unsigned long long command;
+  const bool leader = blockIdx.x == gridDim.x - 1;
+  const int act_blocks = (int)gridDim.x - 1 - kCollectCopyBlocks;
+  const bool copy_role = (int)blockIdx.x >= act_blocks && !leader;
+  for (unsigned expect = r.first_seq;; ++expect) {
+    if (threadIdx.x == 0) {
+      unsigned long long word;
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        word = __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(word >> 32) == expect) break;
+        const unsigned long long waited = wall_clock64() - t0;
+        if (leader) {
+          if (waited > r.park_ticks) {
+            __hip_atomic_store(r.relay, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(r.parked, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            word = 8;                              // leave
+            break;
+          }
+        } else if (__hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                   waited > 5000 * r.park_ticks) {
+          word = 8;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      command = word;
+    }
+    __syncthreads();
+    const unsigned long long word = command;
+    const bool in_time = (unsigned)(word >> 32) == expect;
+    if (!in_time) return;                          // parked
+    Collect16Args step = c;
+    step.row = (int64_t)((word >> 8) & 0xffffff);
+    step.outcome_row = (word & 4) ? step.row - 1 : -1;
+    step.eps = (word & 2) ? ((word & 1) ? r.eps1 : r.eps0) : nullptr;
+    step.done_seq = expect;
+    if (word & 8) {                                // stop: only the pending outcome is stored
+      if (copy_role) collect16_step<KS1, AP, true, true>(step, tile);
+      else collect_signal_done(step);
+      return;
+    }
+    collect16_step<KS1, AP, true, true>(step, tile);
+    __syncthreads();                               // `command` / tile are reused
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
 
 bool grad16_supported(int O, int A, bool actor) {
@@ -1121,6 +1217,22 @@ extern "C" int tonic_ppo_pack_actor(const float* d_actor_params, float* d_packed
 int tonic::collect16_blocks(int64_t W) {
   const int64_t tiles = (W + 15) / 16;
   return (int)(tiles < 4096 ? tiles : 4096) + kCollectCopyBlocks + 1;   // one tile per workgroup
+}
+
+int tonic::launch_collect_resident(const Collect16Args& c, const CollectResident& r,
+                                   hipStream_t st) {
+  const dim3 grid(collect16_blocks(c.W)), block(256);
+  const int ks1 = collect16_ks1(c.O), ap = collect16_ap(c.A);
+#define TONIC_RESIDENT(K, P_)                                                              \
+  if (ks1 == K && ap == P_) {                                                              \
+    hipLaunchKernelGGL((ppo_collect_resident_kernel<K, P_>), grid, block, 0, st, c, r);    \
+  } else
+  TONIC_RESIDENT(1, 1) TONIC_RESIDENT(1, 6) TONIC_RESIDENT(1, 8)
+  TONIC_RESIDENT(5, 1) TONIC_RESIDENT(5, 6) TONIC_RESIDENT(5, 8)
+  TONIC_RESIDENT(8, 1) TONIC_RESIDENT(8, 6) TONIC_RESIDENT(8, 8) {}
+#undef TONIC_RESIDENT
+  TONIC_CHECK_LAUNCH("ppo_collect_resident_kernel");
+  return TONIC_OK;
 }
 
 int tonic::launch_collect16(const Collect16Args& c, hipStream_t st) {

@@ -140,8 +140,10 @@ class A2C(Agent):
         self.observation_size = observation_space.shape[0]
         self.action_size = action_space.shape[0]
         self._collector = None
-        # 0: the act kernel reads / writes the page-locked block in place; 1: hipMemcpyAsync
-        self.transport = int(os.environ.get('TONIC_AMD_COLLECTOR_TRANSPORT', '0'))
+        # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
+        # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
+        # around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per round trip)
+        self.transport = int(os.environ.get('TONIC_AMD_COLLECTOR_TRANSPORT', '2'))
 
     # ------------------------------------------------------------------ acting
     def _io(self, workers):
