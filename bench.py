@@ -272,6 +272,24 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
             dt = min(dt, (time.perf_counter() - t0) / reps)
         out[label] = {'learner_updates_per_sec': round(iterations / dt, 1),
                       'ms_per_update_call': round(dt * 1e3, 3)}
+    # roofline of one learner iteration: dense fp32 contractions, 2 FLOP per MAC
+    H, heads = 256, (2 if kind == 'sac' else 1)
+    actor_fwd = 2 * (o_dim * H + H * H + heads * H * a_dim)
+    critic_fwd = 2 * ((o_dim + a_dim) * H + H * H + H)
+    critic_dx_hidden = 2 * (H * H + H)
+    critic_step = actor_fwd + 4 * critic_fwd + 2 * critic_fwd + 2 * critic_dx_hidden
+    used = 2 if kind == 'sac' else 1                     # critics behind the actor's loss
+    actor_step = (actor_fwd + used * critic_fwd + used * 2 * (H + H * H + H * a_dim)
+                  + actor_fwd + 2 * (H * H + heads * H * a_dim))
+    per_iteration = batch * (critic_step + (actor_step if kind == 'sac' else actor_step / 2))
+    seconds = out['hip_graph']['ms_per_update_call'] * 1e-3 / iterations
+    tflops = per_iteration / seconds / 1e12
+    out['roofline'] = dict(bound='mfma (latency-bound in practice: ~14 dependent launches of '
+                                 '5-16 us per iteration at B=1024)',
+                           flop_per_iteration=int(per_iteration), achieved=round(tflops, 2),
+                           peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                           frac=round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                           us_per_iteration=round(seconds * 1e6, 1))
     if not cpu:
         return out
     # CPU baseline: same path on torch-CPU, bounded sample
@@ -505,9 +523,10 @@ def main():
         result['offpolicy_sac'] = offpolicy_rates()
         # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
         # reference's default batch of 100 and the batch of cfg 3
-        result['offpolicy_td3'] = {
-            f'B={b}': offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)['hip_graph']
-            for b in (100, 1024)}
+        result['offpolicy_td3'] = {}
+        for b in (100, 1024):
+            rates = offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)
+            result['offpolicy_td3'][f'B={b}'] = dict(rates['hip_graph'], roofline=rates['roofline'])
         result['speedup_vs_cpu_baseline'] = round(
             main_run['value'] / result['cpu_baseline']['value'], 1)
     if rank == 0:

@@ -220,9 +220,12 @@ int adam_fill(AdamArgs& a, const char* what, float* d_params, const float* d_gra
   return TONIC_OK;
 }
 
+// Few, fat workgroups: every optimizer workgroup ends with one agent-scope atomic on the same
+// counter (the last arriver finalises), and those serialise at ~10 ns each — 760 of them cost more
+// than the finalisation launch they replaced (11.8 vs 10.3 us at 200 k parameters).
 int adam_blocks_for(int64_t param_count) {
   const int64_t blocks = (param_count + 255) / 256;
-  return (int)(blocks > 2048 ? 2048 : blocks);
+  return (int)(blocks > 128 ? 128 : blocks);
 }
 
 int adam_launch(float* d_params, const float* d_grad_sums, float* d_exp_avg, float* d_exp_avg_sq,
