@@ -149,10 +149,14 @@ def kernel_rooflines(agent):
         gbs = 28.0 * t_steps * workers / (ms * 1e-3) / 1e9
         return dict(T=t_steps, W=workers, chunks=chunks, ms=round(ms, 4),
                     achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    sweep = [gae_entry(T, W, 0), gae_entry(T, W, 1), gae_entry(T, 4096, 0),
-             gae_entry(T, 65536, 1), gae_entry(T, 65536, 4)]
+    # chunks: 1 = the bit-exact single chain per column (the Segment's default), 0 = the library's
+    # choice = 128-row segments in one pass below W = 65 536; cfg-2 (256), cfg-5 per GPU (1280),
+    # cfg-5 global (10 240) and the bandwidth-bound size SURVEY §8d asks for (65 536)
+    sweep = [gae_entry(T, W, 1), gae_entry(T, W, 0), gae_entry(T, 1280, 1), gae_entry(T, 1280, 0),
+             gae_entry(T, 4096, 0), gae_entry(T, 10240, 1), gae_entry(T, 10240, 0),
+             gae_entry(T, 65536, 1), gae_entry(T, 65536, 2)]
     top = max(sweep, key=lambda e: e['achieved'])
-    roof_gae = dict(bound='hbm', kernel='gae_scan_kernel (+summary/carry/stats)',
+    roof_gae = dict(bound='hbm', kernel='gae_onepass_kernel / gae_scan_kernel (+gae_stats_kernel)',
                     achieved=top['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=top['frac'],
                     bytes_per_transition=28, at=dict(T=top['T'], W=top['W']), sweep=sweep,
                     **pmc_traffic('gae_scan_kernel'),

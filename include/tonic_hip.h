@@ -73,10 +73,12 @@ int64_t tonic_v_critic_param_count(int32_t O);
  *           (adv-mean)/std is applied in-register by the PPO actor kernel from d_adv_stats).
  *         d_adv_stats[4] float32 = {mean, std, all_zero_flag (1.0 if every raw advantage is
  *           0, actors.py:71), normalise_flag (1.0 if std != 0, segments.py:44)}.
- * `chunks` = number of time chunks the scan is split into (>=1, divides nothing required);
- *           0 lets the library choose from (T, W).  With 1 chunk the float32 operation
- *           order is exactly the reference's (bit-exact returns); with more, chunk carries
- *           are composed as affine maps and returns agree to ~1e-6 relative.
+ * `chunks`: 1 = ONE chain per worker column over the whole T axis in the reference's float32
+ *           operation order (bit-exact returns); > 1 = T is cut into 128-row segments (64 from W = 8192; whatever the
+ *           number) that run concurrently, each segment held in registers by one workgroup and
+ *           the carries between segments composed as affine maps: one pass over the
+ *           data, 28 B per transition, returns agree to ~1e-6 relative; 0 = the library chooses
+ *           (segments unless W alone fills the chip).
  */
 int64_t tonic_gae_workspace_bytes(int64_t T, int64_t W, int32_t chunks);
 int tonic_gae_lambda_returns(const float* d_next_values, const float* d_rewards,

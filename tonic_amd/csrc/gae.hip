@@ -5,17 +5,10 @@
 // population std).  Layout: every array is [T, W] row-major float32, so a time row is W
 // contiguous floats and lane <-> worker gives perfectly coalesced row accesses.
 //
-// Parallelisation: one lane per worker column, and the T axis split into `chunks` pieces
-// that run concurrently:
-//   pass 1 (chunks > 1 only)  each chunk composes its steps into one affine map
-//                             ret_in -> A + B * ret_in  (SURVEY.md Appendix A.1);
-//   pass 2 (chunks > 1 only)  per column, the carries entering each chunk are formed by
-//                             applying the chunk maps from the last chunk backwards;
-//   pass 3                    each chunk re-runs the EXACT reference recurrence (same float32
-//                             operation order, compiled with -ffp-contract=off) from its
-//                             carry, writing returns and raw advantages and accumulating
-//                             sum(adv), sum(adv^2) in float64.
-// With chunks == 1 only pass 3 runs and the returns are bit-identical to the reference.
+// Parallelisation: one lane per worker column.  With ONE chunk a lane walks the whole T axis with
+// the reference's float32 operation order (compiled with -ffp-contract=off): returns bit-identical
+// to the reference.  With more chunks T is cut into 128- or 64-row segments that run concurrently and
+// exchange affine carries (gae_onepass_kernel below): one pass over the data, ~1e-6 relative.
 #include "common.h"
 
 namespace tonic {
@@ -31,62 +24,246 @@ struct GaeArgs {
   const float* values;
   float* returns;
   float* advantages;
-  float* carry_a;     // [chunks, W]
-  float* carry_b;     // [chunks, W]
-  float* carry_in;    // [chunks, W]
+  float* carry_a;     // [segments, W]: the segments' affine maps (segmented pass only)
+  float* carry_b;
   double* block_sums; // [blocks, 4] = {sum, sum_sq, min, max}
   int64_t T, W;
-  int chunks;
-  int64_t chunk_len;
   float gamma, lambda, one_minus_lambda;
 };
 
-// pass 1: affine summary of one chunk for one column.
-__global__ __launch_bounds__(kGaeThreads) void gae_chunk_summary_kernel(GaeArgs g) {
-  const int64_t w = (int64_t)blockIdx.x * kGaeThreads + threadIdx.x;
-  const int chunk = blockIdx.y;
-  if (w >= g.W) return;
-  const int64_t t0 = (int64_t)chunk * g.chunk_len;
-  const int64_t t1 = min(t0 + g.chunk_len, g.T);
-  // ret[t] = A[t] + B[t] * ret[t+1];  compose from the end of the chunk backwards.
+// ---- more than one chunk: ONE pass over the data (28 B / transition) ------------------------------
+// T is cut into segments of 128 (64) rows; a workgroup of 8 (4) waves owns one segment of one
+// 64-column tile and keeps it ENTIRELY in registers (two to four workgroups per CU, so that one
+// loads while another computes or stores): wave k holds rows [16k, 16k+16) of the segment
+// (5 arrays x 16 rows per lane, all 80 loads in flight at once — that, not occupancy, is the
+// memory-level parallelism).  Nothing is read twice:
+//   1. every wave composes its 16 rows into an affine map ret_in -> a + b * ret_in;
+//   2. the maps meet in LDS; wave 0 composes them into the segment's map and publishes it (release,
+//      one flag per workgroup);
+//   3. wave 0 forms the carry entering the segment by applying the maps of all LATER segments of its
+//      column tile in order, starting from next_values[T-1] (8 B per lane and segment, fetched by
+//      the waves side by side); later segments hold smaller tickets (below), so they are running
+//      or done: no deadlock;
+//   4. every wave applies the maps of the later waves of its own segment (LDS) to that carry and
+//      replays the EXACT reference recurrence over its 16 rows from registers, writing returns and
+//      raw advantages and the float64 moments.
+// The summary / carry / scan triple this replaces read the four scan inputs twice (44 B).
+constexpr int kSegRowsPerWave = 16;
+// 8 waves (128-row segments, two workgroups per CU): fewer segments, shorter carry walks — the
+// latency-bound sizes; 4 waves (64-row segments, four per CU): more workgroups in different phases
+// per CU — the bandwidth-bound sizes (0.75 of the HBM peak at W = 65 536, against 0.70).
+constexpr int64_t kWideColumns = 8192;
+inline int seg_waves(int64_t W) { return W >= kWideColumns ? 4 : 8; }
+constexpr int kFarSegments = 64;    // later segments whose maps a workgroup can hold in LDS
+
+struct GaeOnePass {
+  GaeArgs g;
+  unsigned* ticket;     // zero at launch
+  unsigned* flags;      // [segments, tiles], zero at launch: 1 = the segment's map is published,
+                        //   2 = also `inclusive`, the carry LEAVING the segment towards earlier rows
+  float* inclusive;     // [segments, W]
+  int tiles, segments;
+};
+
+template <int kSegWaves>
+__global__ __launch_bounds__(kSegWaves * 64, 4) void gae_onepass_kernel(GaeOnePass p) {
+  constexpr int kSegRows = kSegWaves * kSegRowsPerWave;
+  __shared__ float map_a[kSegWaves][64], map_b[kSegWaves][64], carry_in[64];
+  __shared__ float far_a[kFarSegments][64], far_b[kFarSegments][64], far_incl[kSegWaves][64];
+  __shared__ int far_state[kSegWaves], resolved;
+  __shared__ double red[4][kSegWaves];
+  __shared__ unsigned ticket;
+  const GaeArgs& g = p.g;
+  // Workgroups take their (segment, tile) in the order they START: later segments first.
+  if (threadIdx.x == 0)
+    ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int seg = p.segments - 1 - (int)(ticket / (unsigned)p.tiles);
+  const int tile = (int)(ticket % (unsigned)p.tiles);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t w = (int64_t)tile * 64 + lane;
+  const bool column = w < g.W;
+  const int64_t wc = column ? w : g.W - 1;
+  const int64_t base = (int64_t)seg * kSegRows + wave * kSegRowsPerWave;   // first row of the wave
+  constexpr int R = kSegRowsPerWave;
+  float nv[R], r[R], rs[R], tm[R], v[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t t = min(base + u, g.T - 1);
+    const int64_t i = t * g.W + wc;
+    nv[u] = __builtin_nontemporal_load(g.next_values + i);
+    r[u] = __builtin_nontemporal_load(g.rewards + i);
+    rs[u] = __builtin_nontemporal_load(g.resets + i);
+    tm[u] = __builtin_nontemporal_load(g.terminations + i);
+    v[u] = __builtin_nontemporal_load(g.values + i);
+  }
+  // 1. the wave's rows as one affine map (rows past T are the identity)
   float ca = 0.f, cb = 1.f;
-  for (int64_t t = t1 - 1; t >= t0; --t) {
-    const int64_t i = t * g.W + w;
-    const float nv = g.next_values[i], r = g.rewards[i];
-    const float keep = 1.f - g.terminations[i], cont = 1.f - g.resets[i];
-    const float b = g.gamma * g.lambda * keep * cont;
-    const float a = r + g.gamma * keep * nv * (cont * g.one_minus_lambda + g.resets[i]);
-    // (a, b) o (ca, cb) = (a + b * ca, b * cb)
-    ca = a + b * ca;
-    cb = b * cb;
+#pragma unroll
+  for (int u = R - 1; u >= 0; --u) {
+    if (base + u < g.T) {
+      const float keep = 1.f - tm[u], cont = 1.f - rs[u];
+      const float b = g.gamma * g.lambda * keep * cont;
+      const float a = r[u] + g.gamma * keep * nv[u] * (cont * g.one_minus_lambda + rs[u]);
+      ca = a + b * ca;
+      cb = b * cb;
+    }
   }
-  g.carry_a[(int64_t)chunk * g.W + w] = ca;
-  g.carry_b[(int64_t)chunk * g.W + w] = cb;
+  map_a[wave][lane] = ca;
+  map_b[wave][lane] = cb;
+  __syncthreads();
+  float seg_a = 0.f, seg_b = 1.f;
+  if (wave == 0) {
+    // 2. the segment's map, published for the EARLIER segments of this column tile
+    float sa = 0.f, sb = 1.f;
+#pragma unroll
+    for (int k = kSegWaves - 1; k >= 0; --k) {
+      sa = map_a[k][lane] + map_b[k][lane] * sa;
+      sb = map_b[k][lane] * sb;
+    }
+    if (seg > 0) {
+      // Agent-scope stores (written through to where the other XCDs read) + a plain wait for
+      // their acknowledgement order the map before its flag; a release / acquire FENCE pair here
+      // is an L2 write-back / invalidate per wave and cost 2x the whole kernel.
+      if (column) {
+        __hip_atomic_store(g.carry_a + (int64_t)seg * g.W + w, sa, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.carry_b + (int64_t)seg * g.W + w, sb, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(p.flags + (int64_t)seg * p.tiles + tile, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    seg_a = sa;
+    seg_b = sb;
+  }
+  // 3. the carry entering this segment = the maps of the later segments applied, from the end of
+  //    time towards this segment, to next_values[T-1] (utils.py:11).  A later segment that already
+  //    knows its own carry has published the value it hands on (`inclusive`): the walk starts at
+  //    the NEAREST such segment and only applies the maps in between — the same float32 operations
+  //    as the full walk, so the result does not depend on timing.  The waves look at one later
+  //    segment each per round, nearest first (flag, then 8-12 bytes per lane with agent-scope
+  //    loads): a dependent walk costs a cross-XCD round trip per segment.
+  const int later = p.segments - 1 - seg;
+  int found = -1;
+  for (int d0 = 0; d0 < later && found < 0; d0 += kSegWaves) {
+    const int d = d0 + wave;
+    if (d < later) {
+      const int s2 = seg + 1 + d;
+      // the LDS stash is full at distance kFarSegments - 1: that segment must hand over its carry
+      const unsigned need = (d >= kFarSegments - 1 && d < later - 1) ? 2u : 1u;
+      const unsigned* flag = p.flags + (int64_t)s2 * p.tiles + tile;
+      unsigned state;
+      while ((state = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need)
+        __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+      if (d < kFarSegments) {
+        far_a[d][lane] = __hip_atomic_load(g.carry_a + (int64_t)s2 * g.W + wc, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        far_b[d][lane] = __hip_atomic_load(g.carry_b + (int64_t)s2 * g.W + wc, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (state == 2u)
+        far_incl[wave][lane] = __hip_atomic_load(p.inclusive + (int64_t)s2 * g.W + wc,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) far_state[wave] = (int)state;
+    } else if (lane == 0) {
+      far_state[wave] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int hit = -1;
+      for (int k = kSegWaves - 1; k >= 0; --k)
+        if (far_state[k] == 2) hit = d0 + k;             // the nearest one wins
+      resolved = hit;
+    }
+    __syncthreads();
+    found = resolved;
+    if (found < 0 && d0 + kSegWaves < later) __syncthreads();     // far_state is rewritten next round
+  }
+  if (wave == 0) {
+    float carry;
+    int from;
+    if (found >= 0) {
+      carry = far_incl[found % kSegWaves][lane];
+      from = found - 1;
+    } else {
+      carry = g.next_values[(g.T - 1) * g.W + wc];
+      from = later - 1;
+    }
+    for (int d = from; d >= 0; --d) carry = far_a[d][lane] + far_b[d][lane] * carry;
+    carry_in[lane] = carry;
+    if (seg > 0) {                        // what this segment hands on to the earlier ones
+      if (column)
+        __hip_atomic_store(p.inclusive + (int64_t)seg * g.W + w, seg_a + seg_b * carry,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(p.flags + (int64_t)seg * p.tiles + tile, 2u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  // 4. the later waves of this segment, then the exact recurrence over this wave's rows
+  float last = carry_in[lane];
+  for (int k = kSegWaves - 1; k > wave; --k) last = map_a[k][lane] + map_b[k][lane] * last;
+  double sum = 0.0, sum_sq = 0.0;
+  float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+  for (int u = R - 1; u >= 0; --u) {
+    if (base + u < g.T) {
+      float boot = g.one_minus_lambda * nv[u] + g.lambda * last;   // utils.py:13-14
+      boot = boot * (1.f - rs[u]);                                 // :15
+      boot = boot + rs[u] * nv[u];                                 // :16
+      boot = boot * (1.f - tm[u]);                                 // :17
+      last = r[u] + g.gamma * boot;                                // :18
+      const float adv = last - v[u];                               // segments.py:42
+      if (column) {
+        const int64_t i = (base + u) * g.W + w;
+        __builtin_nontemporal_store(last, g.returns + i);
+        __builtin_nontemporal_store(adv, g.advantages + i);
+        sum += (double)adv;
+        sum_sq += (double)adv * (double)adv;
+        lo = fminf(lo, adv);
+        hi = fmaxf(hi, adv);
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  sum_sq = wave_sum(sum_sq);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+  }
+  if (lane == 0) { red[0][wave] = sum; red[1][wave] = sum_sq; red[2][wave] = lo; red[3][wave] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < kSegWaves; ++i) {
+      s0 += red[0][i]; s1 += red[1][i];
+      mn = fmin(mn, red[2][i]); mx = fmax(mx, red[3][i]);
+    }
+    const int64_t b = (int64_t)seg * p.tiles + tile;          // (not the ticket: fixed order)
+    g.block_sums[4 * b] = s0;
+    g.block_sums[4 * b + 1] = s1;
+    g.block_sums[4 * b + 2] = mn;
+    g.block_sums[4 * b + 3] = mx;
+  }
 }
 
-// pass 2: carry entering each chunk (the value of ret just after the chunk's last step).
-__global__ __launch_bounds__(kGaeThreads) void gae_chunk_carry_kernel(GaeArgs g) {
-  const int64_t w = (int64_t)blockIdx.x * kGaeThreads + threadIdx.x;
-  if (w >= g.W) return;
-  float carry = g.next_values[(g.T - 1) * g.W + w];      // utils.py:11
-  for (int chunk = g.chunks - 1; chunk >= 0; --chunk) {
-    g.carry_in[(int64_t)chunk * g.W + w] = carry;
-    carry = g.carry_a[(int64_t)chunk * g.W + w] + g.carry_b[(int64_t)chunk * g.W + w] * carry;
-  }
-}
-
-// pass 3: the reference recurrence inside one chunk, kUnroll rows of loads in flight.
+// One chunk: the reference recurrence over the whole T axis, kUnroll rows of loads in flight.
 __global__ __launch_bounds__(kGaeThreads) void gae_scan_kernel(GaeArgs g) {
   const int64_t w = (int64_t)blockIdx.x * kGaeThreads + threadIdx.x;
-  const int chunk = blockIdx.y;
   const bool active = w < g.W;
   double sum = 0.0, sum_sq = 0.0;
   float lo = INFINITY, hi = -INFINITY;
   if (active) {
-    const int64_t t0 = (int64_t)chunk * g.chunk_len;
-    const int64_t t1 = min(t0 + g.chunk_len, g.T);
-    float last = g.chunks > 1 ? g.carry_in[(int64_t)chunk * g.W + w]
-                              : g.next_values[(g.T - 1) * g.W + w];
+    const int64_t t0 = 0, t1 = g.T;
+    float last = g.next_values[(g.T - 1) * g.W + w];             // utils.py:11
     int64_t t = t1 - 1;
     for (; t - (kUnroll - 1) >= t0; t -= kUnroll) {
       float nv[kUnroll], r[kUnroll], rs[kUnroll], tm[kUnroll], v[kUnroll], ret[kUnroll];
@@ -155,7 +332,7 @@ __global__ __launch_bounds__(kGaeThreads) void gae_scan_kernel(GaeArgs g) {
       s0 += red[0][i]; s1 += red[1][i];
       mn = fmin(mn, red[2][i]); mx = fmax(mx, red[3][i]);
     }
-    const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t b = blockIdx.x;
     g.block_sums[4 * b] = s0;
     g.block_sums[4 * b + 1] = s1;
     g.block_sums[4 * b + 2] = mn;
@@ -185,10 +362,18 @@ __global__ void adv_stats_from_moments_kernel(const double* moments, float* adv_
     write_adv_stats(moments[0], moments[1], -moments[2], moments[3], moments[4], adv_stats);
 }
 
-__global__ void gae_stats_kernel(const double* block_sums, int nblocks, double count,
-                                 float* adv_stats, double* moments) {
+constexpr int kStatsThreads = 1024;
+
+// Fixed-order fold of the workgroups' partial moments (the segmented pass leaves up to tens of
+// thousands of them: 64 threads walking them four dependent loads at a time took longer than the
+// scan itself).
+__global__ __launch_bounds__(kStatsThreads) void gae_stats_kernel(const double* block_sums,
+                                                                  int nblocks, double count,
+                                                                  float* adv_stats,
+                                                                  double* moments) {
+  __shared__ double red[4][kStatsThreads / 64];
   double s0 = 0.0, s1 = 0.0, mn = INFINITY, mx = -INFINITY;
-  for (int i = threadIdx.x; i < nblocks; i += 64) {
+  for (int i = threadIdx.x; i < nblocks; i += kStatsThreads) {
     s0 += block_sums[4 * i];
     s1 += block_sums[4 * i + 1];
     mn = fmin(mn, block_sums[4 * i + 2]);
@@ -201,7 +386,15 @@ __global__ void gae_stats_kernel(const double* block_sums, int nblocks, double c
     mn = fmin(mn, __shfl_xor(mn, off, 64));
     mx = fmax(mx, __shfl_xor(mx, off, 64));
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = mn; red[3][wave] = mx; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s0 = 0.0; s1 = 0.0; mn = INFINITY; mx = -INFINITY;
+    for (int i = 0; i < kStatsThreads / 64; ++i) {
+      s0 += red[0][i]; s1 += red[1][i];
+      mn = fmin(mn, red[2][i]); mx = fmax(mx, red[3][i]);
+    }
     write_adv_stats(s0, s1, mn, mx, count, adv_stats);
     if (moments != nullptr) {
       moments[0] = s0; moments[1] = s1; moments[2] = -mn; moments[3] = mx; moments[4] = count;
@@ -211,33 +404,37 @@ __global__ void gae_stats_kernel(const double* block_sums, int nblocks, double c
 
 namespace {
 
-int choose_chunks(int64_t T, int64_t W) {
-  // Enough (chunk, column) lanes to put several waves on every CU; chunks of >= 32 steps.
-  const int64_t want_lanes = 256 * 8 * 64;
-  int64_t chunks = 1;
-  while (W * chunks < want_lanes && T / (chunks * 2) >= 32) chunks *= 2;
-  return (int)chunks;
+// chunks: 1 = the exact single-chain scan; 0 = the library's choice; > 1 = the segmented pass
+// (the segment length is fixed — 128 rows, 64 from W = 8192 — whatever the number asked for).
+bool use_onepass(int64_t T, int64_t W, int chunks) {
+  if (chunks == 1 || T <= seg_waves(W) * kSegRowsPerWave) return false;
+  if (chunks > 1) return true;
+  // auto: the single chain needs W alone to fill the chip (64 lanes x 8 rows in flight per wave)
+  return W < 65536;
 }
 
 struct GaeLayout {
-  int chunks;
-  int64_t chunk_len, col_blocks, scan_blocks;
-  int64_t off_a, off_b, off_in, off_sums, bytes;
+  bool onepass;
+  int chunks, tiles;
+  int64_t col_blocks, scan_blocks;
+  int64_t off_a, off_b, off_incl, off_flags, off_sums, bytes, flag_bytes;
 };
 
 GaeLayout gae_layout(int64_t T, int64_t W, int chunks) {
-  GaeLayout l;
-  l.chunks = chunks > 0 ? chunks : choose_chunks(T, W);
-  if (l.chunks > T) l.chunks = (int)(T > 0 ? T : 1);
-  l.chunk_len = (T + l.chunks - 1) / l.chunks;
-  l.chunks = (int)((T + l.chunk_len - 1) / l.chunk_len);
+  GaeLayout l{};
+  l.onepass = use_onepass(T, W, chunks);
+  const int64_t seg_rows = seg_waves(W) * kSegRowsPerWave;
+  l.chunks = l.onepass ? (int)((T + seg_rows - 1) / seg_rows) : 1;
+  l.tiles = (int)((W + 63) / 64);
   l.col_blocks = (W + kGaeThreads - 1) / kGaeThreads;
-  l.scan_blocks = l.col_blocks * l.chunks;
+  l.scan_blocks = l.onepass ? (int64_t)l.chunks * l.tiles : l.col_blocks;
   const int64_t cw = round_up((int64_t)l.chunks * W * 4, 256);
   l.off_a = 0;
   l.off_b = cw;
-  l.off_in = 2 * cw;
-  l.off_sums = 3 * cw;
+  l.off_incl = 2 * cw;
+  l.off_flags = 3 * cw;
+  l.flag_bytes = round_up(((int64_t)l.chunks * l.tiles + 1) * 4, 256);      // flags + the ticket
+  l.off_sums = l.off_flags + l.flag_bytes;
   l.bytes = l.off_sums + round_up(l.scan_blocks * 32, 256);
   return l;
 }
@@ -270,7 +467,6 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
   TONIC_REQUIRE(d_workspace && workspace_bytes >= l.bytes, TONIC_ERR_WORKSPACE,
                 "gae workspace too small: %lld < %lld", (long long)workspace_bytes,
                 (long long)l.bytes);
-  TONIC_REQUIRE(l.chunks <= 65535, TONIC_ERR_INVALID_ARGUMENT, "too many chunks");
   char* ws = static_cast<char*>(d_workspace);
   GaeArgs g;
   g.next_values = d_next_values; g.rewards = d_rewards; g.resets = d_resets;
@@ -278,23 +474,31 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
   g.advantages = d_advantages;
   g.carry_a = reinterpret_cast<float*>(ws + l.off_a);
   g.carry_b = reinterpret_cast<float*>(ws + l.off_b);
-  g.carry_in = reinterpret_cast<float*>(ws + l.off_in);
   g.block_sums = reinterpret_cast<double*>(ws + l.off_sums);
-  g.T = T; g.W = W; g.chunks = l.chunks; g.chunk_len = l.chunk_len;
+  g.T = T; g.W = W;
   // Python-float scalars are rounded to float32 when they multiply a float32 array; `1 -
   // trace_decay` is formed in float64 first (utils.py:14), hence the double arguments.
   g.gamma = (float)discount_factor; g.lambda = (float)trace_decay;
   g.one_minus_lambda = (float)(1.0 - trace_decay);
   hipStream_t st = as_stream(stream);
-  if (l.chunks > 1) {
-    hipLaunchKernelGGL(gae_chunk_summary_kernel, dim3((unsigned)l.col_blocks, l.chunks),
-                       dim3(kGaeThreads), 0, st, g);
-    hipLaunchKernelGGL(gae_chunk_carry_kernel, dim3((unsigned)l.col_blocks), dim3(kGaeThreads),
-                       0, st, g);
+  if (l.onepass) {
+    GaeOnePass p{};
+    p.g = g;
+    p.flags = reinterpret_cast<unsigned*>(ws + l.off_flags);
+    p.inclusive = reinterpret_cast<float*>(ws + l.off_incl);
+    p.ticket = p.flags + (int64_t)l.chunks * l.tiles;
+    p.tiles = l.tiles; p.segments = l.chunks;
+    if (hipMemsetAsync(p.flags, 0, (size_t)l.flag_bytes, st) != hipSuccess) {
+      set_error("tonic_gae_lambda_returns: hipMemsetAsync failed");
+      return TONIC_ERR_LAUNCH;
+    }
+    const dim3 grid((unsigned)(l.chunks * l.tiles));
+    if (seg_waves(W) == 4) hipLaunchKernelGGL(gae_onepass_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gae_onepass_kernel<8>, grid, dim3(512), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(gae_scan_kernel, dim3((unsigned)l.col_blocks), dim3(kGaeThreads), 0, st, g);
   }
-  hipLaunchKernelGGL(gae_scan_kernel, dim3((unsigned)l.col_blocks, l.chunks), dim3(kGaeThreads),
-                     0, st, g);
-  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(64), 0, st, g.block_sums,
+  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(kStatsThreads), 0, st, g.block_sums,
                      (int)l.scan_blocks, (double)T * (double)W, d_adv_stats, d_adv_moments);
   TONIC_CHECK_LAUNCH("tonic_gae_lambda_returns");
   return TONIC_OK;
