@@ -359,6 +359,29 @@ int tonic_collector_wait_actions(tonic_collector_t* collector, double timeout_s)
 int tonic_collector_end_rollout(tonic_collector_t* collector, int64_t last_row,
                                 void* learner_stream);
 
+/* ---- one-shot all-reduce between the GPUs of a node -----------------------
+ * replaces: nothing in the reference (single process); it is the exchange step of the sharded
+ *   learner: after the fused grad kernels every rank holds gradient SUMS over its worker shard
+ *   (+ 8 statistic sums), the sum over ranks is what tonic_adam_step scales by 1 / N_global.
+ * For the 44 KB - 711 KB buffers of this path a ring all-reduce is latency-bound (2 (G - 1) hops
+ * over point-to-point xGMI).  tonic_allreduce_f32 is ONE launch per rank: each rank writes its
+ * buffer into a window of every peer (G - 1 links used concurrently, one hop), raises a flag
+ * there, waits for the flags in its own window and adds the G contributions IN RANK ORDER, in
+ * place — identical bits on every rank, independent of arrival order.  n <= max_floats.
+ * Set-up (once): tonic_comm_init allocates this rank's window; tonic_comm_export gives its
+ * hipIpcMemHandle_t (tonic_comm_handle_bytes() bytes) which the caller carries to the other
+ * processes by any means; tonic_comm_connect takes all `world` handles in rank order.
+ * A peer that never arrives makes the kernel give up after 5 s instead of hanging:
+ * tonic_comm_status (synchronous, call it where the host reads results anyway) reports it. */
+typedef struct tonic_comm tonic_comm_t;
+int64_t tonic_comm_handle_bytes(void);
+int tonic_comm_init(tonic_comm_t** out, int32_t rank, int32_t world, int64_t max_floats);
+int tonic_comm_export(tonic_comm_t* comm, void* handle_out);
+int tonic_comm_connect(tonic_comm_t* comm, const void* all_handles);
+int tonic_allreduce_f32(tonic_comm_t* comm, float* d_buffer, int64_t n, void* stream);
+int tonic_comm_status(tonic_comm_t* comm);
+int tonic_comm_destroy(tonic_comm_t* comm);
+
 /* ---- target networks (SAC / TD3) ---------------------------------------------------------------
  * replaces: tonic/torch/models/actor_critics.py:126-130 (update_targets): per element
  *   t = fl(fl(t*(1-coeff)) + fl(coeff*o)) — three roundings, no FMA — on flat buffers.

@@ -16,9 +16,9 @@ WORKER = os.path.join(ROOT, 'tests', 'mp_ppo_worker.py')
 OFFPOLICY_WORKER = os.path.join(ROOT, 'tests', 'mp_offpolicy_worker.py')
 
 
-def launch(world, out, port, command=(WORKER,)):
+def launch(world, out, port, command=(WORKER,), extra_env=None):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               TONIC_AMD_BACKEND='gloo')
+               TONIC_AMD_BACKEND='gloo', **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, *command, out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
@@ -88,3 +88,45 @@ def test_buffer_get_yields_each_ranks_part_of_the_global_batch(tmp_path):
             assert np.array_equal(observations[order], whole[f'observations{i}'][want])
             empty += sum(p[f'rewards{i}'].shape[0] == 0 for p in parts)
         assert empty > 0, 'the case of a rank drawing nothing must be exercised'
+
+
+ALLREDUCE_WORKER = os.path.join(ROOT, 'tests', 'mp_allreduce_worker.py')
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_one_shot_allreduce_is_the_rank_ordered_sum(tmp_path, world):
+    """tonic_allreduce_f32 between `world` processes (sharing this box's GPU; windows exchanged as
+    IPC handles): every rank ends with the float32 sum of the contributions taken in rank order —
+    bit for bit, the same on all ranks — for buffer sizes of this path (11 k PPO, 178 k TD3 floats),
+    odd tails, and 25 back-to-back calls without host synchronisation."""
+    out = str(tmp_path / 'ar')
+    launch(world, out, 29700 + world, command=(ALLREDUCE_WORKER,))
+    ranks = [np.load(out + f'.rank{r}.npz') for r in range(world)]
+    for call, n in enumerate((11101, 7, 177666, 4096, 11101, 11101, 1, 65536)):
+        want = None
+        for r in range(world):
+            rng = np.random.RandomState(1000 * call + r)
+            mine = (rng.standard_normal(n) * 10.0 ** rng.randint(-3, 4)).astype(np.float32)
+            want = mine if want is None else (want + mine).astype(np.float32)
+        for r in range(world):
+            assert np.array_equal(ranks[r][f'call{call}'], want), (call, r)
+    for r in range(1, world):
+        assert np.array_equal(ranks[r]['chain'], ranks[0]['chain'])
+    np.testing.assert_allclose(ranks[0]['chain'], (world + 1) / 2, rtol=1e-5)
+
+
+def test_two_ranks_with_the_one_shot_allreduce_equal_single_process(tmp_path):
+    """The sharded PPO update with TONIC_AMD_ALLREDUCE=oneshot (tonic_allreduce_f32 instead of
+    torch.distributed for the per-iteration gradient exchange) against the single-process update."""
+    single, double = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    launch(1, single, 29731)
+    launch(2, double, 29732, extra_env={'TONIC_AMD_ALLREDUCE': 'oneshot'})
+    a, b = np.load(single), np.load(double)
+    ran = a['infos'][0][:, 6] > 0
+    assert np.array_equal(ran, b['infos'][0][:, 6] > 0)
+    np.testing.assert_allclose(b['infos'][0][ran, :5], a['infos'][0][ran, :5], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b['infos'][1][:, :2], a['infos'][1][:, :2], rtol=1e-4, atol=1e-5)
+    for key in a.files:
+        if key in ('infos', 'adv_stats'):
+            continue
+        np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)

@@ -82,6 +82,13 @@ SIGNATURES = {
     'tonic_collector_ppo_step': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
     'tonic_collector_wait_actions': (ctypes.c_int, [c_vp, c_f64]),
     'tonic_collector_end_rollout': (ctypes.c_int, [c_vp, c_i64, c_vp]),
+    'tonic_comm_handle_bytes': (c_i64, []),
+    'tonic_comm_init': (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i64]),
+    'tonic_comm_export': (ctypes.c_int, [c_vp, c_vp]),
+    'tonic_comm_connect': (ctypes.c_int, [c_vp, c_vp]),
+    'tonic_allreduce_f32': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    'tonic_comm_status': (ctypes.c_int, [c_vp]),
+    'tonic_comm_destroy': (ctypes.c_int, [c_vp]),
     'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_gemm_f32': (ctypes.c_int, [ctypes.c_char_p] + [c_vp] * 6 + [c_i32] * 8 + [c_f64, c_vp]),
 }

@@ -71,3 +71,63 @@ def combine_advantage_moments(total, total_sq, minimum, maximum, count):
     constant = minimum == maximum
     std = 0.0 if constant else var ** 0.5
     return mean, std, constant and minimum == 0.0
+
+
+_one_shot = None
+
+
+def one_shot(max_floats):
+    """The process-wide OneShotAllReduce when TONIC_AMD_ALLREDUCE=oneshot asks for it (windows grow
+    on demand before first use only), else None: callers then use torch.distributed (RCCL)."""
+    global _one_shot
+    if os.environ.get('TONIC_AMD_ALLREDUCE', '') != 'oneshot' or world_size() == 1:
+        return None
+    if _one_shot is None or _one_shot.max_floats < max_floats:
+        _one_shot = OneShotAllReduce(max(max_floats, 1 << 18))
+    return _one_shot
+
+
+class OneShotAllReduce:
+    """``tonic_allreduce_f32`` (include/tonic_hip.h): in-place sum all-reduce of small float32
+    device buffers as ONE launch per rank — every rank writes its buffer into a window of every
+    peer and adds the contributions in rank order (deterministic, identical on all ranks).
+    ``torch.distributed`` is only the bootstrap channel that carries the IPC handles once.
+    Opt-in for the learner (``TONIC_AMD_ALLREDUCE=oneshot``): validated between processes that
+    share one GPU (tests/test_gpu_multirank.py), not yet on an xGMI node."""
+
+    def __init__(self, max_floats):
+        import ctypes
+
+        from tonic_amd import _lib
+        self._lib_module = _lib
+        self.lib = lib = _lib.load()
+        self.rank, self.world = rank(), world_size()
+        self.max_floats = max_floats
+        handle = ctypes.c_void_p()
+        _lib.check(lib.tonic_comm_init(ctypes.byref(handle), self.rank, self.world, max_floats),
+                   'tonic_comm_init')
+        self.handle = handle.value
+        if self.world > 1:
+            size = lib.tonic_comm_handle_bytes()
+            mine = ctypes.create_string_buffer(size)
+            _lib.check(lib.tonic_comm_export(self.handle, mine), 'tonic_comm_export')
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, mine.raw)
+            everyone = ctypes.create_string_buffer(b''.join(gathered), size * self.world)
+            _lib.check(lib.tonic_comm_connect(self.handle, everyone), 'tonic_comm_connect')
+            dist.barrier()                  # every window is mapped everywhere before first use
+
+    def all_reduce(self, tensor):
+        _lib = self._lib_module
+        _lib.check(self.lib.tonic_allreduce_f32(self.handle, _lib.ptr(tensor), tensor.numel(),
+                                                _lib.current_stream()), 'tonic_allreduce_f32')
+        return tensor
+
+    def check(self):
+        """Synchronous: raises if a peer failed to arrive in some earlier call."""
+        self._lib_module.check(self.lib.tonic_comm_status(self.handle), 'tonic_comm_status')
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.tonic_comm_destroy(self.handle)
+            self.handle = None

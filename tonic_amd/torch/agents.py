@@ -296,6 +296,18 @@ class PPO(A2C):
         #   critic grad i | all-reduce(critic i) over Adam(actor i) + actor grad i+1 | Adam(critic i)
         # After the KL stop the actor half is zero-filled on every rank alike and its step is
         # skipped by the same device flag everywhere.
+        from tonic_amd import parallel
+        one_shot = parallel.one_shot(max(actor.count, critic.count) + updaters.INFO_WIDTH)
+        if one_shot is not None:
+            # tonic_allreduce_f32: one ~10 us launch per exchange, nothing to hide it behind
+            for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
+                actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+                one_shot.all_reduce(actor.grad_sums)
+                critic.enqueue_grad(obs, returns)
+                one_shot.all_reduce(critic.grad_sums)
+                updaters.enqueue_step_pair(actor, critic, obs.shape[0], replay.adv_stats,
+                                           self._infos[0, it], self._infos[1, it])
+            return self._infos
         all_reduce = torch.distributed.all_reduce
         pending = None                           # (work handle, rows, info row) of the critic
         for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):

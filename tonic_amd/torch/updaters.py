@@ -85,7 +85,12 @@ class _FlatUpdater:
         polyak update of ALL targets rides in the same launch (update_targets right after the
         step, as ddpg.py:105-112 orders them)."""
         if self.world_size > 1 and allreduce:
-            torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
+            from tonic_amd import parallel
+            one_shot = parallel.one_shot(self.count + INFO_WIDTH)
+            if one_shot is not None:
+                one_shot.all_reduce(self.grad_sums)              # tonic_allreduce_f32
+            else:
+                torch.distributed.all_reduce(self.grad_sums)     # RCCL sum over xGMI
         self.enqueue_clip(n_global, skip)
         h = self.hyper
         if targets is not None:
