@@ -131,7 +131,9 @@ int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
  *
  * tonic_ppo_actor_grad replaces: tonic/torch/updaters/actors.py:70-99 (ClippedRatio
  *   forward, surrogate loss, entropy, backward).   d_adv_stats as produced by
- *   tonic_gae_lambda_returns.
+ *   tonic_gae_lambda_returns.  ratio_clip < 0 selects the plain policy gradient of
+ *   StochasticPolicyGradient (A2C; actors.py:20-51): loss_sum = -sum(adv * logp), no ratio, no
+ *   clipping; kl_sum keeps its meaning (old - new log-probabilities).
  * tonic_value_regression_grad replaces: tonic/torch/updaters/critics.py:18-24 (VRegression).
  */
 int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_count);

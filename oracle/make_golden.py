@@ -230,7 +230,7 @@ def golden_sequential(tonic):
 
 def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
             reward_scale=1.0, updates=1, batch_size=None, actor_clip=0, critic_clip=0,
-            normalizer_clip=None):
+            normalizer_clip=None, algorithm='PPO', entropy_coeff=0):
     """tonic/torch/agents/{a2c.py:41-73, ppo.py:20-67}: acts with the reference agent on
     a synthetic env for `steps` time steps so the real store/record/update path runs."""
     def builder():
@@ -252,11 +252,15 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 observation_normalizer=norms.MeanStd(clip=normalizer_clip)),
             actor_updater=tonic.torch.updaters.ClippedRatio(gradient_clip=actor_clip),
             critic_updater=tonic.torch.updaters.VRegression(gradient_clip=critic_clip))
-    agent = tonic.torch.agents.PPO(
+    if algorithm == 'A2C':          # a2c.py:20-127 with StochasticPolicyGradient (actors.py:9-51)
+        kwargs['actor_updater'] = tonic.torch.updaters.StochasticPolicyGradient(
+            entropy_coeff=entropy_coeff)
+    agent = getattr(tonic.torch.agents, algorithm)(
         replay=tonic.replays.Segment(size=steps, batch_iterations=iterations,
                                      batch_size=batch_size), **kwargs)
     agent.initialize(env.observation_space, env.action_space, seed=seed)
     out = state_arrays('init/', agent.model.state_dict())
+    out['entropy_coeff'] = np.float64(entropy_coeff)
     out['clips'] = np.array([actor_clip, critic_clip, normalizer_clip or 0], np.float64)
     out['batch_size'] = np.int64(batch_size or 0)
     recorder = RecordingLogger()
@@ -305,7 +309,7 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 out[pre + 'info/' + k] = np.array(v)
         recorder.records.clear()
         out[pre + 'norm/count'] = np.int64(norm.count)
-        if update == 0 and batch_size is None and not clipped:
+        if update == 0 and batch_size is None and not clipped and algorithm == 'PPO':
             out.update(first_update_probes(tonic, builder, seed, seg, iterations))
     out['act/observations'] = np.array(obs_all)
     out['act/eps'] = np.array(eps_all)
@@ -478,6 +482,9 @@ def main():
                 run_ppo(tonic, 'ppo_clipped_small', 17, 6, workers=8, steps=24, seed=8,
                         iterations=12, updates=2, actor_clip=0.05, critic_clip=0.3,
                         normalizer_clip=1.5)
+            elif name == 'a2c_small':
+                run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6,
+                        updates=2, algorithm='A2C', entropy_coeff=0.01)
             elif name == 'ppo_halfcheetah_w256':
                 run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6,
                         updates=1)
@@ -506,6 +513,9 @@ def main():
     # the second one runs with non-trivial normaliser statistics (values beyond +-1.5 exist)
     run_ppo(tonic, 'ppo_clipped_small', 17, 6, workers=8, steps=24, seed=8, iterations=12,
             updates=2, actor_clip=0.05, critic_clip=0.3, normalizer_clip=1.5)
+    # A2C (StochasticPolicyGradient with an entropy bonus): one actor step + 6 critic steps
+    run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6, updates=2,
+            algorithm='A2C', entropy_coeff=0.01)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)

@@ -241,10 +241,11 @@ def ppo_act(params, observations, eps):
 
 
 def clipped_ratio_grads(params, observations, actions, advantages, old_log_probs,
-                        ratio_clip=0.2, entropy_coeff=0.0, kl_threshold=0.015):
+                        ratio_clip=0.2, entropy_coeff=0.0, kl_threshold=0.015, plain=False):
     """Loss, statistics and parameter gradients of ``ClippedRatio.__call__`` —
     ``tonic/torch/updaters/actors.py:70-112`` — by explicit back-propagation
-    (Appendix A.3).  Returns (grads in parameter order, stats dict)."""
+    (Appendix A.3).  Returns (grads in parameter order, stats dict).  ``plain=True``:
+    ``StochasticPolicyGradient.__call__`` (``actors.py:20-51``), loss = -mean(adv * logp)."""
     w1, b1, w2, b2, log_scale, w3, b3 = params
     n, a_dim = actions.shape
     h1, h2, loc, scale, dscale_dls = ppo_actor_forward(params, observations)
@@ -255,6 +256,8 @@ def clipped_ratio_grads(params, observations, actions, advantages, old_log_probs
     surr1 = advantages * ratio
     surr2 = advantages * np.clip(ratio, low, high)
     loss = -np.minimum(surr1, surr2).mean(dtype=np.float64)
+    if plain:
+        loss = -(advantages * new_lp).mean(dtype=np.float64)
     entropy = float(np.mean(0.5 + 0.5 * math.log(2 * math.pi) + np.log(scale.astype(np.float64))))
     if entropy_coeff != 0:
         loss -= entropy_coeff * entropy
@@ -263,6 +266,8 @@ def clipped_ratio_grads(params, observations, actions, advantages, old_log_probs
     # d loss / d new_lp: zero where the clipped surrogate is the active minimum.
     dead = ((ratio > high) & (advantages > 0)) | ((ratio < low) & (advantages < 0))
     g_lp = np.where(dead, 0, -(advantages * ratio) / n).astype(F32)
+    if plain:
+        g_lp = (-advantages / n).astype(F32)
     diff = actions - loc
     d_loc = g_lp[:, None] * diff / var
     d_scale = (g_lp[:, None] * (diff * diff / (var * scale) - 1 / scale)).sum(0, dtype=np.float64)

@@ -846,3 +846,42 @@ def test_clip_grad_norm_against_torch(lib):
         _lib.check(lib.tonic_clip_grad_norm(d3.data_ptr(), n, scale, max_norm, flag.data_ptr(),
                                             ws.data_ptr(), ws.numel(), None), 'clip')
         assert np.array_equal(d3.cpu().numpy(), sums)
+
+
+def test_a2c_update_matches_reference(golden, lib):
+    """tonic_amd.torch.agents.A2C (StochasticPolicyGradient = the fused actor kernel in its plain
+    mode + entropy bonus, then VRegression iterations) against two consecutive updates of the
+    reference's A2C agent (a2c.py:101-127, actors.py:20-51)."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    g = golden('a2c_small')
+    O, A, W, steps, seed, iterations, updates = (int(x) for x in g['cfg'])
+    agent = tt.agents.A2C(
+        replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations),
+        actor_updater=tt.updaters.StochasticPolicyGradient(entropy_coeff=float(g['entropy_coeff'])))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    for u in range(updates):
+        state = {k[len(f'pre{u}/'):]: torch.as_tensor(g[k]) for k in g.files
+                 if k.startswith(f'pre{u}/')}
+        if u == 0:
+            agent.model.load_state_dict(state)
+        else:
+            for key in ('observation_normalizer._mean', 'observation_normalizer._std'):
+                dict(agent.model.state_dict())[key].copy_(state[key])
+        before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+        agent.replay.index = 0
+        _fill_segment(agent, g, u)
+        infos = agent.enqueue_update().cpu().numpy()
+        for i, key in ((0, 'loss'), (1, 'kl'), (2, 'entropy'), (4, 'std')):
+            np.testing.assert_allclose(infos[0, 0, i], g[f'u{u}/info/actor/{key}'][0], rtol=1e-5,
+                                       atol=1e-5, err_msg=key)
+        np.testing.assert_allclose(infos[1][:, 0], g[f'u{u}/info/critic/loss'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(infos[1][:, 1], g[f'u{u}/info/critic/v_mean'], rtol=1e-5, atol=1e-5)
+        after = agent.model.state_dict()
+        for key, start in before.items():
+            if 'normalizer' in key:
+                continue
+            got = after[key].detach().cpu().numpy() - start
+            np.testing.assert_allclose(got, g[f'post{u}/' + key] - start, rtol=0, atol=1e-5,
+                                       err_msg=f'update {u}: {key}')

@@ -196,6 +196,37 @@ def test_ppo_update_with_gradient_and_normaliser_clipping(golden):
     assert (np.abs(x) > normalizer_clip).mean() > 0.01
 
 
+def test_a2c_update_matches_reference(golden):
+    """A2C (a2c.py:101-127): ONE StochasticPolicyGradient step with an entropy bonus on the full
+    batch, then `batch_iterations` VRegression steps; two consecutive reference updates."""
+    g = golden('a2c_small')
+    entropy_coeff, iterations = float(g['entropy_coeff']), int(g['cfg'][5])
+    actor_adam = critic_adam = None
+    for u in range(int(g['cfg'][6])):
+        actor, critic, norm = _params(g, f'pre{u}/')
+        seg = {k: g[f'u{u}/segment/{k}'] for k in (
+            'observations', 'actions', 'log_probs', 'advantages', 'returns')}
+        flat = {k: port.flatten_time_major(v) for k, v in seg.items()}
+        if actor_adam is None:
+            actor_adam, critic_adam = port.AdamPort(actor, 3e-4), port.AdamPort(critic, 1e-3)
+        grads, stats = port.clipped_ratio_grads(
+            actor, flat['observations'], flat['actions'], flat['advantages'].reshape(-1),
+            flat['log_probs'], entropy_coeff=entropy_coeff, plain=True)
+        new_actor = actor_adam.step(actor, grads)
+        for key in ('loss', 'kl', 'entropy', 'std'):
+            np.testing.assert_allclose(stats[key], g[f'u{u}/info/actor/{key}'][0], rtol=1e-5, atol=1e-5)
+        new_critic, losses = critic, []
+        for _ in range(iterations):
+            grads, stats = port.value_regression_grads(new_critic, norm[0], norm[1],
+                                                       flat['observations'], flat['returns'].reshape(-1))
+            new_critic = critic_adam.step(new_critic, grads)
+            losses.append(stats['loss'])
+        np.testing.assert_allclose(losses, g[f'u{u}/info/critic/loss'], rtol=1e-5, atol=1e-5)
+        ref_actor, ref_critic, _ = _params(g, f'post{u}/')
+        for got, want, before in zip(new_actor + new_critic, ref_actor + ref_critic, actor + critic):
+            np.testing.assert_allclose(got - before, want - before, atol=1e-5, rtol=0)
+
+
 @pytest.mark.parametrize('name', PPO_CASES)
 def test_ppo_single_iteration_deltas_strict(golden, name):
     """One actor + one critic optimizer step: parameter deltas within 1e-5, strictly."""

@@ -26,6 +26,7 @@ struct MlpArgs {
   int64_t n;
   int O, A;
   float clip_lo, clip_hi;
+  int plain;                // 1: plain policy gradient, loss = -mean(adv * logp) (actors.py:20-51)
   int pstride;
   int skew;                 // initial phase offset (x ~8k cycles) of the second wave per SIMD
 };

@@ -477,11 +477,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       const float surr1 = adv * ratio, surr2 = adv * clipped_ratio;
       const bool outside = ratio > a.clip_hi || ratio < a.clip_lo;
       const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
-      const float g = (dead || !valid) ? 0.f : -(adv * ratio);    // d(-min)/d logp, unscaled
+      const bool plain = a.plain != 0;                            // StochasticPolicyGradient
+      const float g = (valid && (plain || !dead)) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
       if (counted) {
-        st0 += -fminf(surr1, surr2);
+        st0 += plain ? -(adv * logp) : -fminf(surr1, surr2);
         st1 += old_lp - logp;
-        st2 += outside ? 1.f : 0.f;
+        st2 += (outside && !plain) ? 1.f : 0.f;
         st3 += 1.f;
       }
 #pragma unroll
@@ -1047,6 +1048,7 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
   a.skip = d_skip_flag; a.n = n; a.O = O; a.A = A;
   a.clip_lo = (float)(1.0 - ratio_clip);     // actors.py:85-86 (f64, then f32 in clamp)
   a.clip_hi = (float)(1.0 + ratio_clip);
+  a.plain = ratio_clip < 0 ? 1 : 0;
   return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
                         (float)entropy_coeff,
                         d_workspace, workspace_bytes, stream);

@@ -388,10 +388,12 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       const float surr1 = adv * ratio, surr2 = adv * clipped_ratio;
       const bool outside = ratio > a.clip_hi || ratio < a.clip_lo;
       const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
-      const float gl = (dead || !valid) ? 0.f : -(adv * ratio);
-      st0 += cw * -fminf(surr1, surr2);
+      // (a.plain: StochasticPolicyGradient, d(-adv * logp) / d logp = -adv, nothing is clipped)
+      const bool plain = a.plain != 0;
+      const float gl = (valid && (plain || !dead)) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
+      st0 += cw * (plain ? -(adv * logp) : -fminf(surr1, surr2));
       st1 += cw * (old_lp - logp);
-      st2 += (counted && outside) ? 1.f : 0.f;
+      st2 += (counted && outside && !plain) ? 1.f : 0.f;
       st3 += cw;
 #pragma unroll
       for (int aa = 0; aa < AP; ++aa) {

@@ -120,11 +120,8 @@ class A2C(Agent):
     def __init__(self, model=None, replay=None, actor_updater=None, critic_updater=None):
         self.model = model or default_model()
         self.replay = replay or replays.Segment()
-        self.actor_updater = actor_updater
+        self.actor_updater = actor_updater or updaters.StochasticPolicyGradient()
         self.critic_updater = critic_updater or updaters.VRegression()
-        if self.actor_updater is None:
-            raise NotImplementedError(
-                'A2C (StochasticPolicyGradient) is outside the accelerated path; use PPO')
 
     def initialize(self, observation_space, action_space, seed=None):
         super().initialize(seed=seed)
@@ -259,6 +256,38 @@ class A2C(Agent):
         critic.forward_values(replays.flatten_batch(b['next_observations']),
                               b['next_values'].view(-1))
         return b['values'], b['next_values']
+
+
+    def enqueue_update(self):
+        """a2c.py:101-127 without a host sync: evaluate, lambda-returns, ONE actor step on the
+        full batch, then the critic over `replay.get` (full batch `batch_iterations` times, or
+        minibatches).  Returns the statistic rows: [0, 0] the actor's, [1, :] the critic's."""
+        replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
+        values, next_values = self._evaluate()
+        replay.compute_returns(values, next_values)
+        updates = replay.updates_per_get()
+        if getattr(self, '_infos', None) is None or self._infos.shape[1] != updates:
+            self._infos = torch.zeros(2, updates, updaters.INFO_WIDTH, device=self.device)
+        self._infos.zero_()
+        actor.reset_stop()
+        full = tuple(replays.flatten_batch(replay.buffers[k]) for k in replays.segments.LEARNER_KEYS)
+        obs, act, raw_adv, log_probs, _ = full
+        actor.enqueue(obs, act, raw_adv, replay.adv_stats, log_probs, self._infos[0, 0])
+        for it, (obs, _, _, _, returns) in enumerate(replay.learner_batches()):
+            critic.enqueue(obs, returns, self._infos[1, it])
+        return self._infos
+
+    def _update(self):
+        infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+        for i, key in enumerate(updaters.ACTOR_INFO):
+            if key in ('loss', 'kl', 'entropy', 'std'):
+                logger.store('actor/' + key, infos[0, 0, i])
+        for row in infos[1]:
+            logger.store('critic/loss', row[0])
+            logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
+        self.last_infos = infos
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.update()
 
 
 class PPO(A2C):

@@ -191,6 +191,20 @@ class ClippedRatio(_FlatUpdater):
         return out
 
 
+class StochasticPolicyGradient(ClippedRatio):
+    """actors.py:9-51 (A2C): loss = -mean(advantages * log_probs) [- entropy_coeff * entropy], one
+    Adam step.  Same fused kernel as ClippedRatio in its plain mode (`ratio_clip < 0` in the C ABI:
+    the gradient of -adv * logp is -adv, nothing to clip) and no KL stop."""
+
+    def __init__(self, optimizer=None, entropy_coeff=0, gradient_clip=0):
+        super().__init__(optimizer=optimizer, ratio_clip=-1.0, kl_threshold=float('inf'),
+                         entropy_coeff=entropy_coeff, gradient_clip=gradient_clip)
+
+    def __call__(self, observations, actions, advantages, log_probs):
+        out = super().__call__(observations, actions, advantages, log_probs)
+        return {k: out[k] for k in ('loss', 'kl', 'entropy', 'std')}
+
+
 class VRegression(_FlatUpdater):
     stats_kind = 2
 
