@@ -38,7 +38,8 @@ extern "C" {
 typedef enum tonic_status {
   TONIC_OK = 0,
   TONIC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / NULL pointer / unsupported size   */
-  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* PPO path: O > 32, A > 8 or hidden != 64         */
+  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* PPO path: O > 384, A > 32 or hidden != 64; the    */
+                                     /* workspace-less forwards: O > 32 or A > 8          */
   TONIC_ERR_LAUNCH = -3,             /* a HIP runtime call / kernel launch failed       */
   TONIC_ERR_WORKSPACE = -4,          /* workspace too small                             */
   TONIC_ERR_TIMEOUT = -5             /* collector: workers / actions did not arrive     */
@@ -135,8 +136,23 @@ int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
  *   StochasticPolicyGradient (A2C; actors.py:20-51): loss_sum = -sum(adv * logp), no ratio, no
  *   clipping; kl_sum keeps its meaning (old - new log-probabilities).
  * tonic_value_regression_grad replaces: tonic/torch/updaters/critics.py:18-24 (VRegression).
+ *
+ * Shapes: O <= 32 and A <= 8 run in the fused kernels (a whole network per 16-sample tile in
+ * registers).  Wider ones (O <= 384, A <= 32: Ant-v3, Humanoid, humanoid-walk ...) run layer by
+ * layer with the activations in the workspace (csrc/mlpwide.hip), same arguments, same outputs;
+ * tonic_ppo_workspace_bytes sizes the workspace for either kind (the *_wide forwards fall back to
+ * the fused kernels for narrow shapes, so callers may always use them).
  */
 int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_count);
+int64_t tonic_ppo_workspace_bytes(int64_t n, int32_t O, int32_t A, int32_t actor);
+int tonic_ppo_act_wide(const float* d_actor_params, const float* d_observations,
+                       const float* d_eps, float* d_actions, float* d_log_probs, int64_t n,
+                       int32_t O, int32_t A, void* d_workspace, int64_t workspace_bytes,
+                       void* stream);
+int tonic_value_forward_wide(const float* d_critic_params, const float* d_norm_mean,
+                             const float* d_norm_std, double norm_clip,
+                             const float* d_observations, float* d_values, int64_t n, int32_t O,
+                             void* d_workspace, int64_t workspace_bytes, void* stream);
 int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_observations,
                          const float* d_actions, const float* d_advantages,
                          const float* d_adv_stats, const float* d_old_log_probs,

@@ -485,6 +485,12 @@ def main():
             elif name == 'a2c_small':
                 run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6,
                         updates=2, algorithm='A2C', entropy_coeff=0.01)
+            elif name == 'ppo_ant_wide':
+                run_ppo(tonic, 'ppo_ant_wide', 111, 8, workers=6, steps=16, seed=11, iterations=8,
+                        updates=1)
+            elif name == 'ppo_humanoid_wide':
+                run_ppo(tonic, 'ppo_humanoid_wide', 376, 17, workers=4, steps=12, seed=12,
+                        iterations=6, updates=1)
             elif name == 'ppo_halfcheetah_w256':
                 run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6,
                         updates=1)
@@ -513,6 +519,10 @@ def main():
     # the second one runs with non-trivial normaliser statistics (values beyond +-1.5 exist)
     run_ppo(tonic, 'ppo_clipped_small', 17, 6, workers=8, steps=24, seed=8, iterations=12,
             updates=2, actor_clip=0.05, critic_clip=0.3, normalizer_clip=1.5)
+    # shapes beyond the fused kernels: Ant-v3 (O = 111, A = 8) and Humanoid-v3 (O = 376, A = 17)
+    run_ppo(tonic, 'ppo_ant_wide', 111, 8, workers=6, steps=16, seed=11, iterations=8, updates=1)
+    run_ppo(tonic, 'ppo_humanoid_wide', 376, 17, workers=4, steps=12, seed=12, iterations=6,
+            updates=1)
     # A2C (StochasticPolicyGradient with an entropy bonus): one actor step + 6 critic steps
     run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6, updates=2,
             algorithm='A2C', entropy_coeff=0.01)

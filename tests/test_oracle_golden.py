@@ -6,7 +6,7 @@ import pytest
 import numpy_port as port
 
 PPO_CASES = ['ppo_halfcheetah_small', 'ppo_pendulum_small', 'ppo_antbullet_small',
-             'ppo_halfcheetah_w256']
+             'ppo_halfcheetah_w256', 'ppo_ant_wide', 'ppo_humanoid_wide']
 
 
 def test_lambda_returns_bit_exact(golden):
@@ -136,7 +136,8 @@ def test_ppo_update_matches_reference(golden, name):
             actor_adam = port.AdamPort(actor, 3e-4)
             critic_adam = port.AdamPort(critic, 1e-3)
         new_actor, new_critic, infos, extra = port.ppo_update(
-            actor, critic, norm, seg, actor_adam=actor_adam, critic_adam=critic_adam)
+            actor, critic, norm, seg, batch_iterations=int(g['cfg'][5]), actor_adam=actor_adam,
+            critic_adam=critic_adam)
         np.testing.assert_allclose(extra['returns'], g[f'u{u}/segment/returns'], atol=1e-5, rtol=1e-6)
         np.testing.assert_allclose(extra['advantages'].reshape(seg['rewards'].shape),
                                    g[f'u{u}/segment/advantages'], atol=1e-5, rtol=1e-5)

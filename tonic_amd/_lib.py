@@ -28,6 +28,10 @@ SIGNATURES = {
     'tonic_ppo_act': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_vp]),
     'tonic_value_forward': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 2 + [c_i64, c_i32, c_vp]),
     'tonic_mlp64_grad_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'tonic_ppo_workspace_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
+    'tonic_ppo_act_wide': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    'tonic_value_forward_wide': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 2 +
+                                 [c_i64, c_i32, c_vp, c_i64, c_vp]),
     'tonic_ppo_actor_grad': (ctypes.c_int, [c_vp] * 7 + [c_i64, c_i32, c_i32, c_f64, c_f64,
                                                           c_vp, c_vp, c_i64, c_vp]),
     'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 3 +

@@ -40,6 +40,24 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return copysignf(y, x);
 }
 
+// mlp64.hip: fixed-order fold of the per-workgroup partial images into d_grad_sums (+ the
+// log_scale / entropy / sigma post-processing of the actor)
+int launch_reduce_partials(bool actor, const float* partials, int blocks, int pstride, int P,
+                           const float* params, float* d_grad_sums, int O, int A,
+                           float entropy_coeff, double rows, const int32_t* skip,
+                           hipStream_t stream);
+
+// mlpwide.hip: the layer-by-layer path for shapes outside the fused kernels (O > 32 or A > 8)
+bool wide_shape(int O, int A, bool actor);
+bool wide_supported(int O, int A, bool actor);
+int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor);
+int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, void* d_workspace,
+                    int64_t workspace_bytes, hipStream_t stream);
+int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
+                     int64_t workspace_bytes, hipStream_t stream);
+int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream);
+int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream);
+
 // mlp64x16.hip
 bool grad16_supported(int O, int A, bool actor);
 int grad16_blocks(int64_t n);

@@ -878,11 +878,64 @@ extern "C" int64_t tonic_v_critic_param_count(int32_t O) {
 
 static int check_shape(int32_t O, int32_t A, bool actor) {
   TONIC_REQUIRE(O >= 1 && ks1_bucket(O) > 0, TONIC_ERR_UNSUPPORTED_SHAPE,
-                "observation size %d not supported by the mlp64 kernels (1..32)", O);
+                "observation size %d: the fused kernels serve 1..32 (wider ones go through the "
+                "entry points that take a workspace)", O);
   if (actor)
     TONIC_REQUIRE(A >= 1 && ap_bucket(A) > 0, TONIC_ERR_UNSUPPORTED_SHAPE,
-                  "action size %d not supported by the mlp64 kernels (1..8)", A);
+                  "action size %d: the fused kernels serve 1..8 (more go through the entry points "
+                  "that take a workspace)", A);
   return TONIC_OK;
+}
+
+static int check_wide(int32_t O, int32_t A, bool actor) {
+  TONIC_REQUIRE(wide_supported(O, A, actor), TONIC_ERR_UNSUPPORTED_SHAPE,
+                "observation size %d / action size %d: supported are O <= 384, A <= 32", O, A);
+  return TONIC_OK;
+}
+
+extern "C" int64_t tonic_ppo_workspace_bytes(int64_t n, int32_t O, int32_t A, int32_t actor) {
+  if (n <= 0 || O < 1 || (actor && A < 1)) return -1;
+  if (wide_shape(O, A, actor != 0))
+    return wide_supported(O, A, actor != 0) ? wide_workspace_bytes(n, O, A, actor != 0) : -1;
+  const int64_t P = actor ? tonic_ppo_actor_param_count(O, A) : tonic_v_critic_param_count(O);
+  return tonic_mlp64_grad_workspace_bytes(n, P);
+}
+
+extern "C" int tonic_ppo_act_wide(const float* d_actor_params, const float* d_observations,
+                                  const float* d_eps, float* d_actions, float* d_log_probs,
+                                  int64_t n, int32_t O, int32_t A, void* d_workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  if (!wide_shape(O, A, true))
+    return tonic_ppo_act(d_actor_params, d_observations, d_eps, d_actions, d_log_probs, n, O, A,
+                         stream);
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && n >= 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_act_wide: bad argument");
+  if (int rc = check_wide(O, A, true)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.eps = d_eps;
+  a.out0 = d_actions; a.out1 = d_log_probs; a.n = n; a.O = O; a.A = A;
+  return wide_act(a, d_workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int tonic_value_forward_wide(const float* d_critic_params, const float* d_norm_mean,
+                                        const float* d_norm_std, double norm_clip,
+                                        const float* d_observations, float* d_values, int64_t n,
+                                        int32_t O, void* d_workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  if (!wide_shape(O, 1, false))
+    return tonic_value_forward(d_critic_params, d_norm_mean, d_norm_std, norm_clip,
+                               d_observations, d_values, n, O, stream);
+  TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_values &&
+                    n >= 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_value_forward_wide: bad argument");
+  if (int rc = check_wide(O, 1, false)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_critic_params; a.obs = d_observations; a.norm_mean = d_norm_mean;
+  a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
+  a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
+  return wide_value(a, d_workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int tonic_ppo_act(const float* d_actor_params, const float* d_observations,
@@ -1022,11 +1075,23 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
     }
   });
   if (rc != TONIC_OK) return rc;
-  const int total = (int)P + kStatSlots;
-  hipLaunchKernelGGL(reduce_partials_kernel<ACTOR>, dim3((total + 63) / 64),
-                     dim3(kReduceWaves * 64), 0, as_stream(stream),
-                     static_cast<const float*>(d_workspace), blocks, (int)pstride, (int)P,
-                     a.params, d_grad_sums, a.O, a.A, entropy_coeff, (double)a.n, a.skip);
+  return launch_reduce_partials(ACTOR, static_cast<const float*>(d_workspace), blocks,
+                                (int)pstride, (int)P, a.params, d_grad_sums, a.O, a.A,
+                                entropy_coeff, (double)a.n, a.skip, st);
+}
+
+int tonic::launch_reduce_partials(bool actor, const float* partials, int blocks, int pstride, int P,
+                                  const float* params, float* d_grad_sums, int O, int A,
+                                  float entropy_coeff, double rows, const int32_t* skip,
+                                  hipStream_t st) {
+  const int total = P + kStatSlots;
+  const dim3 grid((total + 63) / 64), block(kReduceWaves * 64);
+  if (actor)
+    hipLaunchKernelGGL(reduce_partials_kernel<true>, grid, block, 0, st, partials, blocks, pstride,
+                       P, params, d_grad_sums, O, A, entropy_coeff, rows, skip);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, block, 0, st, partials, blocks, pstride,
+                       P, params, d_grad_sums, O, A, entropy_coeff, rows, skip);
   TONIC_CHECK_LAUNCH("reduce_partials_kernel");
   return TONIC_OK;
 }
@@ -1041,7 +1106,8 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
   TONIC_REQUIRE(d_actor_params && d_observations && d_actions && d_advantages && d_adv_stats &&
                     d_old_log_probs && d_grad_sums && n > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_actor_grad: bad argument");
-  if (int rc = check_shape(O, A, true)) return rc;
+  const bool wide = wide_shape(O, A, true);
+  if (int rc = wide ? check_wide(O, A, true) : check_shape(O, A, true)) return rc;
   MlpArgs a{};
   a.params = d_actor_params; a.obs = d_observations; a.actions = d_actions;
   a.adv = d_advantages; a.adv_stats = d_adv_stats; a.old_logp = d_old_log_probs;
@@ -1049,6 +1115,9 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
   a.clip_lo = (float)(1.0 - ratio_clip);     // actors.py:85-86 (f64, then f32 in clamp)
   a.clip_hi = (float)(1.0 + ratio_clip);
   a.plain = ratio_clip < 0 ? 1 : 0;
+  if (wide)
+    return wide_actor_grad(a, d_grad_sums, (float)entropy_coeff, d_workspace, workspace_bytes,
+                           as_stream(stream));
   return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
                         (float)entropy_coeff,
                         d_workspace, workspace_bytes, stream);
@@ -1087,11 +1156,13 @@ extern "C" int tonic_value_regression_grad(const float* d_critic_params,
   TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_returns &&
                     d_grad_sums && n > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_value_regression_grad: bad argument");
-  if (int rc = check_shape(O, 1, false)) return rc;
+  const bool wide = wide_shape(O, 1, false);
+  if (int rc = wide ? check_wide(O, 1, false) : check_shape(O, 1, false)) return rc;
   MlpArgs a{};
   a.params = d_critic_params; a.obs = d_observations; a.returns = d_returns;
   a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
   a.n = n; a.O = O; a.A = 1;
+  if (wide) return wide_critic_grad(a, d_grad_sums, d_workspace, workspace_bytes, as_stream(stream));
   return run_grad<false>(a, tonic_v_critic_param_count(O), d_grad_sums, 0.f, d_workspace,
                          workspace_bytes, stream);
 }

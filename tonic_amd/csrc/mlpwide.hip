@@ -1,0 +1,583 @@
+// PPO networks OUTSIDE the fused kernels' shapes (observations wider than 32, more than 8 actions):
+// the same mathematics, layer by layer.
+//
+// The fused kernels (mlp64x16.hip) keep a whole 2x64-tanh network per 16-sample tile in registers:
+// the layer-1 weight image lives in LDS next to eight per-wave transpose tiles, dW1 sits in 64 * O / 64
+// accumulator registers per lane.  Ant-v3 (O = 111), Humanoid (O = 376, A = 17) or humanoid-walk
+// (A = 21) fit neither.  Here every layer is its own launch over the whole batch and activations
+// travel through HBM (1.5 KB per sample and iteration instead of ~100 B) — about three times the
+// fused kernels' time per sample, against the reference's torch-CPU path still two orders of
+// magnitude ahead; tonic_ppo_actor_grad / tonic_value_regression_grad / tonic_ppo_act /
+// tonic_value_forward dispatch here on their own.
+//
+//   dense_kernel   Y = act(norm(X) . W^T + b) [* (1 - D^2)]     fp32 MFMA 16x16x4, W staged once per
+//                  workgroup into LDS as the MFMA A-operand image (one conflict-free ds_read_b32 per
+//                  k-step and feature tile); the transposed form (W^T) serves the backward pass
+//                  dZ = (dY . W) * tanh'(H).
+//   wgrad_kernel   dW = dY^T . norm(X), db = column sums of dY over a slab of rows per workgroup:
+//                  both operands are read straight from HBM in MFMA layout (4 rows x 64 contiguous
+//                  bytes per fragment); one partial image per workgroup in the flat parameter layout
+//                  of the fused kernels, so reduce_partials_kernel / Adam / clipping are shared.
+//   ppo_loss_kernel, value_loss_kernel   the element-wise losses and their gradients with respect
+//                  to the head outputs (tonic/torch/updaters/actors.py:81-108, critics.py:18-24).
+//   sample_kernel  actions = loc + sigma * eps, log-probabilities (a2c.py:75-85).
+#include "mlp64.h"
+
+namespace tonic {
+namespace {
+
+constexpr int kWideThreads = 256;          // 4 waves
+constexpr int kWideLd = 32;                // row pitch of the head-sized arrays (A <= 32)
+constexpr int kWideBlocks = 1024;          // row slabs = partial images of the weight gradients
+
+__device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct DenseArgs {
+  const float* X; int ldx;                 // [N, K] input rows
+  const float* W; int ldw; int transposed; // weight(j, k) = transposed ? W[k * ldw + j] : W[j * ldw + k]
+  const float* bias;                       // [NOUT] or null
+  const float* norm_mean; const float* norm_std; float norm_clip;   // null: input not normalised
+  const float* D;                          // [N, ldy] or null: multiply the result by (1 - D^2)
+  float* Y; int ldy;
+  int64_t N;
+  int K, NOUT, act;                        // act: 0 none, 1 tanh
+  const int32_t* skip;
+};
+
+// TN = feature tiles of 16 outputs (NOUT <= 16 * TN).
+template <int TN>
+__global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
+  extern __shared__ float wl[];            // [TN][KS][64] A-operand image of the weights
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KS = (a.K + 3) >> 2;
+  for (int idx = tid; idx < TN * KS * 64; idx += kWideThreads) {
+    const int l = idx & 63, st = (idx >> 6) % KS, T = (idx >> 6) / KS;
+    const int j = 16 * T + (l & 15), k = 4 * st + (l >> 4);
+    float w = 0.f;
+    if (j < a.NOUT && k < a.K) w = a.transposed ? a.W[(int64_t)k * a.ldw + j] : a.W[(int64_t)j * a.ldw + k];
+    wl[idx] = w;
+  }
+  __syncthreads();
+  const int s = lane & 15, g = lane >> 4;
+  const int64_t tiles = (a.N + 15) >> 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t row = t * 16 + s;
+    const bool valid = row < a.N;
+    const float* x = a.X + (valid ? row : a.N - 1) * a.ldx;
+    f32x4 acc[TN];
+#pragma unroll
+    for (int T = 0; T < TN; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (; st + 4 <= KS; st += 4) {        // four k-steps of loads in flight
+      float xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * (st + u) + g, kc = k < a.K ? k : a.K - 1;
+        float v = x[kc];
+        if (a.norm_mean != nullptr)
+          v = __builtin_amdgcn_fmed3f((v - a.norm_mean[kc]) / a.norm_std[kc], -a.norm_clip, a.norm_clip);
+        xv[u] = (valid && k < a.K) ? v : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int T = 0; T < TN; ++T) acc[T] = mfma16w(wl[(T * KS + st + u) * 64 + lane], xv[u], acc[T]);
+    }
+    for (; st < KS; ++st) {
+      const int k = 4 * st + g, kc = k < a.K ? k : a.K - 1;
+      float v = x[kc];
+      if (a.norm_mean != nullptr)
+        v = __builtin_amdgcn_fmed3f((v - a.norm_mean[kc]) / a.norm_std[kc], -a.norm_clip, a.norm_clip);
+      const float xv = (valid && k < a.K) ? v : 0.f;
+#pragma unroll
+      for (int T = 0; T < TN; ++T) acc[T] = mfma16w(wl[(T * KS + st) * 64 + lane], xv, acc[T]);
+    }
+    if (!valid) continue;
+#pragma unroll
+    for (int T = 0; T < TN; ++T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * T + 4 * g + r;              // D[row = feature][col = sample]
+        if (j < a.NOUT) {
+          float v = acc[T][r] + (a.bias != nullptr ? a.bias[j] : 0.f);
+          if (a.act == 1) v = tanh_fast(v);
+          if (a.D != nullptr) {
+            const float d = a.D[row * a.ldy + j];
+            v = v * (1.f - d * d);
+          }
+          a.Y[row * a.ldy + j] = v;
+        }
+      }
+    }
+  }
+}
+
+struct WgradArgs {
+  const float* dY; int ldy; int NOUT;      // [N, ldy]
+  const float* X; int ldx; int K;          // [N, ldx]
+  const float* norm_mean; const float* norm_std; float norm_clip;
+  float* image; int pstride;               // partial images [blocks, pstride]
+  int w_offset, b_offset;                  // where W [NOUT, K] and b [NOUT] sit in an image
+  int64_t N, slab;                         // rows per workgroup
+  const int32_t* skip;
+};
+
+// TJ = 16-row tiles of dW (outputs of the layer); every wave owns the column tiles
+// tk = wave, wave + 4, ... (at most 6: K <= 384).
+template <int TJ>
+__global__ __launch_bounds__(kWideThreads) void wgrad_kernel(WgradArgs a) {
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g = lane >> 4;
+  constexpr int kMaxTk = 6;
+  const int TK = (a.K + 15) >> 4;
+  f32x4 acc[TJ][kMaxTk];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int i = 0; i < kMaxTk; ++i) acc[tj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) bsum[tj] = 0.f;
+  const int64_t r_begin = (int64_t)blockIdx.x * a.slab, r_end = min(a.N, r_begin + a.slab);
+  // per-column constants of this wave's tiles (normalisation of the layer-1 input)
+  float nm[kMaxTk], ns[kMaxTk];
+  int kcol[kMaxTk];
+#pragma unroll
+  for (int i = 0; i < kMaxTk; ++i) {
+    const int k = 16 * (wave + 4 * i) + s;
+    kcol[i] = k < a.K ? k : a.K - 1;
+    nm[i] = a.norm_mean != nullptr ? a.norm_mean[kcol[i]] : 0.f;
+    ns[i] = a.norm_mean != nullptr ? a.norm_std[kcol[i]] : 1.f;
+  }
+  constexpr int kSteps = 4;                              // k-steps (of 4 samples) loaded together
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4 * kSteps) {
+    float av[kSteps][TJ], bv[kSteps][kMaxTk];
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+      const int64_t row = r0 + 4 * u + g;                // this lane's sample of the k-step
+      const bool valid = row < r_end;
+      const int64_t rc = valid ? row : r_end - 1;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int j = 16 * tj + s;
+        const float v = a.dY[rc * a.ldy + (j < a.NOUT ? j : 0)];
+        av[u][tj] = (valid && j < a.NOUT) ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxTk; ++i) {
+        float v = 0.f;
+        if (wave + 4 * i < TK) {
+          v = a.X[rc * a.ldx + kcol[i]];
+          if (a.norm_mean != nullptr)
+            v = __builtin_amdgcn_fmed3f((v - nm[i]) / ns[i], -a.norm_clip, a.norm_clip);
+          v = (valid && 16 * (wave + 4 * i) + s < a.K) ? v : 0.f;
+        }
+        bv[u][i] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        bsum[tj] += av[u][tj];
+#pragma unroll
+        for (int i = 0; i < kMaxTk; ++i)
+          if (wave + 4 * i < TK) acc[tj][i] = mfma16w(av[u][tj], bv[u][i], acc[tj][i]);
+      }
+  }
+  float* image = a.image + (int64_t)blockIdx.x * a.pstride;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+#pragma unroll
+    for (int i = 0; i < kMaxTk; ++i) {
+      const int tk = wave + 4 * i, k = 16 * tk + s;
+      if (tk < TK && k < a.K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * tj + 4 * g + r;             // D[row = output j][col = input k]
+          if (j < a.NOUT) image[a.w_offset + j * a.K + k] = acc[tj][i][r];
+        }
+      }
+    }
+    // bias gradient: this wave saw every sample of the slab; fold the four lane groups
+    float b = bsum[tj];
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (wave == 0 && g == 0 && 16 * tj + s < a.NOUT) image[a.b_offset + 16 * tj + s] = b;
+  }
+}
+
+struct PpoLossArgs {
+  const float* loc; float* dz3; int ld;    // [N, ld]: tanh'ed head outputs in, d loss / d (pre-tanh) out
+  const float* actions; const float* adv; const float* adv_stats; const float* old_logp;
+  const float* log_scale;                  // [A] (inside the parameter block)
+  float* image; int pstride; int ls_offset; int P;
+  int64_t N, slab;
+  int A;
+  float clip_lo, clip_hi;
+  int plain;
+  const int32_t* skip;
+};
+
+__global__ __launch_bounds__(kWideThreads) void ppo_loss_kernel(PpoLossArgs a) {
+  __shared__ float sigma_s[kWideLd], half_inv_var_s[kWideLd], logc_s[kWideLd];
+  __shared__ double red[4][kWideLd + 4];
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < a.A) {
+    const float ls = a.log_scale[tid];
+    const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+    const float sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);       // actors.py:63-64
+    sigma_s[tid] = sigma;
+    half_inv_var_s[tid] = 1.0f / (2.0f * (sigma * sigma));
+    logc_s[tid] = logf(sigma) + kLogSqrt2Pi;
+  }
+  __syncthreads();
+  const float adv_mean = a.adv_stats[0], adv_std = a.adv_stats[1];
+  const bool adv_norm = a.adv_stats[3] != 0.f;
+  double dsg[kWideLd];
+#pragma unroll
+  for (int aa = 0; aa < kWideLd; ++aa) dsg[aa] = 0.0;
+  double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;
+  const int64_t r_begin = (int64_t)blockIdx.x * a.slab, r_end = min(a.N, r_begin + a.slab);
+  for (int64_t n = r_begin + tid; n < r_end; n += kWideThreads) {
+    float logp = 0.f;
+    for (int aa = 0; aa < a.A; ++aa) {
+      const float dif = a.actions[n * a.A + aa] - a.loc[n * a.ld + aa];
+      logp += -(dif * dif) * half_inv_var_s[aa] - logc_s[aa];
+    }
+    const float old_lp = a.old_logp[n];
+    float adv = a.adv[n];
+    if (adv_norm) adv = (adv - adv_mean) / adv_std;                  // segments.py:45
+    const float ratio = __expf(logp - old_lp);
+    const float clipped = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+    const bool outside = ratio > a.clip_hi || ratio < a.clip_lo;
+    const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
+    const bool plain = a.plain != 0;
+    const float gl = (plain || !dead) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
+    st0 += plain ? -(double)(adv * logp) : -(double)fminf(adv * ratio, adv * clipped);
+    st1 += (double)(old_lp - logp);
+    st2 += (outside && !plain) ? 1.0 : 0.0;
+    st3 += 1.0;
+#pragma unroll
+    for (int aa = 0; aa < kWideLd; ++aa) {
+      if (aa < a.A) {
+        const float loc = a.loc[n * a.ld + aa];
+        const float dif = a.actions[n * a.A + aa] - loc;
+        const float inv_var = 2.f * half_inv_var_s[aa], inv_sigma = 1.f / sigma_s[aa];
+        a.dz3[n * a.ld + aa] = gl * dif * inv_var * (1.f - loc * loc);
+        dsg[aa] += (double)(gl * (dif * dif * inv_var * inv_sigma - inv_sigma));
+      }
+    }
+  }
+  // fixed-order fold: lanes (xor tree), then the four waves in order
+  float* image = a.image + (int64_t)blockIdx.x * a.pstride;
+#pragma unroll
+  for (int aa = 0; aa < kWideLd; ++aa) {
+    if (aa < a.A) {
+      const double v = wave_sum(dsg[aa]);
+      if (lane == 0) red[wave][aa] = v;
+    }
+  }
+  st0 = wave_sum(st0); st1 = wave_sum(st1); st2 = wave_sum(st2); st3 = wave_sum(st3);
+  if (lane == 0) {
+    red[wave][kWideLd] = st0; red[wave][kWideLd + 1] = st1;
+    red[wave][kWideLd + 2] = st2; red[wave][kWideLd + 3] = st3;
+  }
+  __syncthreads();
+  if (tid < a.A)
+    image[a.ls_offset + tid] = (float)(((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+  if (tid < 8) {
+    double v = 0.0;
+    const int slot = tid == 0 ? 0 : tid == 1 ? 1 : tid == 2 ? 2 : tid == 5 ? 3 : -1;
+    if (slot >= 0)
+      v = ((red[0][kWideLd + slot] + red[1][kWideLd + slot]) + red[2][kWideLd + slot]) +
+          red[3][kWideLd + slot];
+    image[a.P + tid] = (float)v;                        // {loss, kl, clipped, -, -, count, -, -}
+  }
+}
+
+struct ValueLossArgs {
+  const float* values; float* dv; int ld;  // [N, ld], column 0
+  const float* returns;
+  float* image; int pstride; int P;
+  int64_t N, slab;
+  const int32_t* skip;
+};
+
+__global__ __launch_bounds__(kWideThreads) void value_loss_kernel(ValueLossArgs a) {
+  __shared__ double red[4][3];
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double sq = 0.0, sv = 0.0, cnt = 0.0;
+  const int64_t r_begin = (int64_t)blockIdx.x * a.slab, r_end = min(a.N, r_begin + a.slab);
+  for (int64_t n = r_begin + tid; n < r_end; n += kWideThreads) {
+    const float v = a.values[n * a.ld], err = v - a.returns[n];
+    a.dv[n * a.ld] = 2.f * err;                          // d sum((v - ret)^2) / dv (critics.py:22)
+    sq += (double)(err * err);
+    sv += (double)v;
+    cnt += 1.0;
+  }
+  sq = wave_sum(sq); sv = wave_sum(sv); cnt = wave_sum(cnt);
+  if (lane == 0) { red[wave][0] = sq; red[wave][1] = sv; red[wave][2] = cnt; }
+  __syncthreads();
+  if (tid < 8) {
+    float* image = a.image + (int64_t)blockIdx.x * a.pstride;
+    const int slot = tid == 0 ? 0 : tid == 1 ? 1 : tid == 5 ? 2 : -1;
+    double v = 0.0;
+    if (slot >= 0) v = ((red[0][slot] + red[1][slot]) + red[2][slot]) + red[3][slot];
+    image[a.P + tid] = (float)v;                        // {sq_err, value, -, -, -, count, -, -}
+  }
+}
+
+__global__ __launch_bounds__(kWideThreads) void sample_kernel(const float* loc, int ld,
+                                                            const float* log_scale,
+                                                            const float* eps, float* actions,
+                                                            float* log_probs, int64_t n, int A) {
+  __shared__ float sigma_s[kWideLd], half_inv_var_s[kWideLd], logc_s[kWideLd];
+  if ((int)threadIdx.x < A) {
+    const float ls = log_scale[threadIdx.x];
+    const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+    const float sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);
+    sigma_s[threadIdx.x] = sigma;
+    half_inv_var_s[threadIdx.x] = 1.0f / (2.0f * (sigma * sigma));
+    logc_s[threadIdx.x] = logf(sigma) + kLogSqrt2Pi;
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float logp = 0.f;
+    for (int aa = 0; aa < A; ++aa) {
+      const float mu = loc[i * ld + aa];
+      const float act = eps != nullptr ? mu + sigma_s[aa] * eps[i * A + aa] : mu;   // a2c.py:81
+      const float dif = act - mu;
+      logp += -(dif * dif) * half_inv_var_s[aa] - logc_s[aa];
+      actions[i * A + aa] = act;
+    }
+    if (log_probs != nullptr) log_probs[i] = logp;
+  }
+}
+
+__global__ void gather_column_kernel(const float* src, int ld, float* dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i * ld];
+}
+
+// ---------------------------------------------------------------------------------- host side
+
+int launch_dense(const DenseArgs& a, hipStream_t st) {
+  const int tn = (a.NOUT + 15) / 16, ks = (a.K + 3) / 4;
+  const int lds_bytes = tn * ks * 64 * 4;
+  const int64_t tiles = (a.N + 15) / 16;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  constexpr int kMaxLds = 4 * 96 * 64 * 4;                 // 64 outputs x 384 inputs
+  auto go = [&](auto kernel) {
+    static thread_local bool configured = false;           // (one flag per instantiation)
+    if (!configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      if (e != hipSuccess) {
+        set_error("mlpwide: %d B of LDS for the weight image: %s", kMaxLds, hipGetErrorString(e));
+        return (int)TONIC_ERR_LAUNCH;
+      }
+      configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kWideThreads), lds_bytes, st, a);
+    return (int)TONIC_OK;
+  };
+  int rc;
+  if (tn <= 1) rc = go(dense_kernel<1>);
+  else if (tn == 2) rc = go(dense_kernel<2>);
+  else rc = go(dense_kernel<4>);
+  if (rc != TONIC_OK) return rc;
+  TONIC_CHECK_LAUNCH("dense_kernel");
+  return TONIC_OK;
+}
+
+int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
+  const int tj = (a.NOUT + 15) / 16;
+  if (tj <= 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3(blocks), dim3(kWideThreads), 0, st, a);
+  else if (tj == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3(blocks), dim3(kWideThreads), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel<4>, dim3(blocks), dim3(kWideThreads), 0, st, a);
+  TONIC_CHECK_LAUNCH("wgrad_kernel");
+  return TONIC_OK;
+}
+
+struct WideLayout {        // offsets (floats) inside the flat parameter block, and the scratch
+  int W1, b1, W2, b2, ls, W3, b3, P;
+  int blocks; int64_t slab, pstride;
+  int64_t off_h1, off_h2, off_out, off_dz3, off_dz2, off_dz1, off_image, bytes;
+  WideLayout(int64_t n, int O, int A, bool actor) {
+    W1 = 0; b1 = 64 * O; W2 = b1 + 64; b2 = W2 + 4096;
+    if (actor) { ls = b2 + 64; W3 = ls + A; b3 = W3 + 64 * A; P = b3 + A; }
+    else { ls = -1; W3 = b2 + 64; b3 = W3 + 64; P = b3 + 1; }
+    blocks = (int)((n + 63) / 64 < kWideBlocks ? (n + 63) / 64 : kWideBlocks);
+    if (blocks < 1) blocks = 1;
+    slab = round_up((n + blocks - 1) / blocks, 4);
+    pstride = round_up(P + kStatSlots, 64);
+    const int64_t hidden = round_up(n * 64 * 4, 256), head = round_up(n * kWideLd * 4, 256);
+    off_h1 = 0; off_h2 = hidden; off_out = 2 * hidden; off_dz3 = off_out + head;
+    off_dz2 = off_dz3 + head; off_dz1 = off_dz2 + hidden;
+    off_image = off_dz1 + hidden;
+    bytes = off_image + round_up((int64_t)blocks * pstride * 4, 256);
+  }
+};
+
+// forward pass into the scratch: h1, h2, head outputs (tanh'ed locations / the value column)
+int wide_forward(const float* params, const WideLayout& L, const float* obs, int64_t n, int O,
+                 int A, bool actor, const float* mean, const float* std, float clip, char* ws,
+                 const int32_t* skip, hipStream_t st) {
+  float* h1 = reinterpret_cast<float*>(ws + L.off_h1);
+  float* h2 = reinterpret_cast<float*>(ws + L.off_h2);
+  float* out = reinterpret_cast<float*>(ws + L.off_out);
+  DenseArgs d{};
+  d.N = n; d.skip = skip; d.act = 1;
+  d.X = obs; d.ldx = O; d.W = params + L.W1; d.ldw = O; d.bias = params + L.b1; d.K = O;
+  d.NOUT = 64; d.Y = h1; d.ldy = 64;
+  d.norm_mean = mean; d.norm_std = std; d.norm_clip = clip;
+  if (int rc = launch_dense(d, st)) return rc;
+  d.norm_mean = nullptr; d.norm_std = nullptr;
+  d.X = h1; d.ldx = 64; d.W = params + L.W2; d.ldw = 64; d.bias = params + L.b2; d.K = 64;
+  d.Y = h2;
+  if (int rc = launch_dense(d, st)) return rc;
+  d.X = h2; d.W = params + L.W3; d.bias = params + L.b3; d.NOUT = actor ? A : 1; d.Y = out;
+  d.ldy = kWideLd; d.act = actor ? 1 : 0;
+  return launch_dense(d, st);
+}
+
+// backward pass from dz3 (in the scratch) to the per-slab partial images
+int wide_backward(const float* params, const WideLayout& L, const float* obs, int64_t n, int O,
+                  int A, bool actor, const float* mean, const float* std, float clip, char* ws,
+                  const int32_t* skip, hipStream_t st) {
+  float* h1 = reinterpret_cast<float*>(ws + L.off_h1);
+  float* h2 = reinterpret_cast<float*>(ws + L.off_h2);
+  float* dz3 = reinterpret_cast<float*>(ws + L.off_dz3);
+  float* dz2 = reinterpret_cast<float*>(ws + L.off_dz2);
+  float* dz1 = reinterpret_cast<float*>(ws + L.off_dz1);
+  float* image = reinterpret_cast<float*>(ws + L.off_image);
+  const int nout = actor ? A : 1;
+  WgradArgs w{};
+  w.image = image; w.pstride = (int)L.pstride; w.N = n; w.slab = L.slab; w.skip = skip;
+  w.dY = dz3; w.ldy = kWideLd; w.NOUT = nout; w.X = h2; w.ldx = 64; w.K = 64;
+  w.w_offset = L.W3; w.b_offset = L.b3;
+  if (int rc = launch_wgrad(w, L.blocks, st)) return rc;
+  DenseArgs d{};
+  d.N = n; d.skip = skip; d.act = 0; d.transposed = 1;
+  d.X = dz3; d.ldx = kWideLd; d.K = nout; d.W = params + L.W3; d.ldw = 64; d.NOUT = 64;
+  d.D = h2; d.Y = dz2; d.ldy = 64;
+  if (int rc = launch_dense(d, st)) return rc;
+  w.dY = dz2; w.ldy = 64; w.NOUT = 64; w.X = h1; w.w_offset = L.W2; w.b_offset = L.b2;
+  if (int rc = launch_wgrad(w, L.blocks, st)) return rc;
+  d.X = dz2; d.ldx = 64; d.K = 64; d.W = params + L.W2; d.D = h1; d.Y = dz1;
+  if (int rc = launch_dense(d, st)) return rc;
+  w.dY = dz1; w.X = obs; w.ldx = O; w.K = O; w.w_offset = L.W1; w.b_offset = L.b1;
+  w.norm_mean = mean; w.norm_std = std; w.norm_clip = clip;
+  return launch_wgrad(w, L.blocks, st);
+}
+
+}  // namespace
+
+bool wide_shape(int O, int A, bool actor) { return O > 32 || (actor && A > 8); }
+
+bool wide_supported(int O, int A, bool actor) {
+  return O >= 1 && O <= 384 && (!actor || (A >= 1 && A <= kWideLd));
+}
+
+int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor) {
+  return WideLayout(n, O, A, actor).bytes;
+}
+
+int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, void* d_workspace,
+                    int64_t workspace_bytes, hipStream_t st) {
+  const WideLayout L(a.n, a.O, a.A, true);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
+                "wide actor grad: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+                (long long)L.bytes);
+  char* ws = static_cast<char*>(d_workspace);
+  if (int rc = wide_forward(a.params, L, a.obs, a.n, a.O, a.A, true, nullptr, nullptr, 0.f, ws,
+                            a.skip, st))
+    return rc;
+  PpoLossArgs l{};
+  l.loc = reinterpret_cast<float*>(ws + L.off_out);
+  l.dz3 = reinterpret_cast<float*>(ws + L.off_dz3);
+  l.ld = kWideLd; l.actions = a.actions; l.adv = a.adv; l.adv_stats = a.adv_stats;
+  l.old_logp = a.old_logp; l.log_scale = a.params + L.ls;
+  l.image = reinterpret_cast<float*>(ws + L.off_image); l.pstride = (int)L.pstride;
+  l.ls_offset = L.ls; l.P = L.P; l.N = a.n; l.slab = L.slab; l.A = a.A;
+  l.clip_lo = a.clip_lo; l.clip_hi = a.clip_hi; l.plain = a.plain; l.skip = a.skip;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(L.blocks), dim3(kWideThreads), 0, st, l);
+  TONIC_CHECK_LAUNCH("ppo_loss_kernel");
+  if (int rc = wide_backward(a.params, L, a.obs, a.n, a.O, a.A, true, nullptr, nullptr, 0.f, ws,
+                             a.skip, st))
+    return rc;
+  return launch_reduce_partials(true, l.image, L.blocks, (int)L.pstride, L.P, a.params,
+                                d_grad_sums, a.O, a.A, entropy_coeff, (double)a.n, a.skip, st);
+}
+
+int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
+                     int64_t workspace_bytes, hipStream_t st) {
+  const WideLayout L(a.n, a.O, 1, false);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
+                "wide critic grad: workspace of %lld bytes, %lld needed",
+                (long long)workspace_bytes, (long long)L.bytes);
+  char* ws = static_cast<char*>(d_workspace);
+  if (int rc = wide_forward(a.params, L, a.obs, a.n, a.O, 1, false, a.norm_mean, a.norm_std,
+                            a.norm_clip, ws, a.skip, st))
+    return rc;
+  ValueLossArgs l{};
+  l.values = reinterpret_cast<float*>(ws + L.off_out);
+  l.dv = reinterpret_cast<float*>(ws + L.off_dz3);
+  l.ld = kWideLd; l.returns = a.returns;
+  l.image = reinterpret_cast<float*>(ws + L.off_image); l.pstride = (int)L.pstride; l.P = L.P;
+  l.N = a.n; l.slab = L.slab; l.skip = a.skip;
+  hipLaunchKernelGGL(value_loss_kernel, dim3(L.blocks), dim3(kWideThreads), 0, st, l);
+  TONIC_CHECK_LAUNCH("value_loss_kernel");
+  if (int rc = wide_backward(a.params, L, a.obs, a.n, a.O, 1, false, a.norm_mean, a.norm_std,
+                             a.norm_clip, ws, a.skip, st))
+    return rc;
+  return launch_reduce_partials(false, l.image, L.blocks, (int)L.pstride, L.P, a.params,
+                                d_grad_sums, a.O, 1, 0.f, (double)a.n, a.skip, st);
+}
+
+int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st) {
+  const WideLayout L(a.n, a.O, a.A, true);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
+                "wide act: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+                (long long)L.bytes);
+  char* ws = static_cast<char*>(d_workspace);
+  if (int rc = wide_forward(a.params, L, a.obs, a.n, a.O, a.A, true, nullptr, nullptr, 0.f, ws,
+                            nullptr, st))
+    return rc;
+  int64_t blocks = (a.n + kWideThreads - 1) / kWideThreads;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(kWideThreads), 0, st,
+                     reinterpret_cast<const float*>(ws + L.off_out), kWideLd, a.params + L.ls,
+                     a.eps, a.out0, a.out1, a.n, a.A);
+  TONIC_CHECK_LAUNCH("sample_kernel");
+  return TONIC_OK;
+}
+
+int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st) {
+  const WideLayout L(a.n, a.O, 1, false);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
+                "wide value forward: workspace of %lld bytes, %lld needed",
+                (long long)workspace_bytes, (long long)L.bytes);
+  char* ws = static_cast<char*>(d_workspace);
+  if (int rc = wide_forward(a.params, L, a.obs, a.n, a.O, 1, false, a.norm_mean, a.norm_std,
+                            a.norm_clip, ws, nullptr, st))
+    return rc;
+  int64_t blocks = (a.n + kWideThreads - 1) / kWideThreads;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gather_column_kernel, dim3((unsigned)blocks), dim3(kWideThreads), 0, st,
+                     reinterpret_cast<const float*>(ws + L.off_out), kWideLd, a.out0, a.n);
+  TONIC_CHECK_LAUNCH("gather_column_kernel");
+  return TONIC_OK;
+}
+
+}  // namespace tonic

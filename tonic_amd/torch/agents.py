@@ -156,11 +156,15 @@ class A2C(Agent):
         stage_in.host_view('eps')[:] = torch.randn(W, A).numpy()
         stage_in.upload()
         p = _lib.ptr
-        _lib.check(self.lib.tonic_ppo_act(
+        need = self.lib.tonic_ppo_workspace_bytes(W, self.observation_size, A, 1)
+        if getattr(self, '_act_workspace', None) is None or self._act_workspace.numel() < need:
+            self._act_workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.tonic_ppo_act_wide(
             p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
             p(stage_in.device_view('eps')), p(stage_out.device_view('actions')),
             p(stage_out.device_view('log_probs')) if want_log_probs else None,
-            W, self.observation_size, A, _lib.current_stream()), 'tonic_ppo_act')
+            W, self.observation_size, A, p(self._act_workspace), self._act_workspace.numel(),
+            _lib.current_stream()), 'tonic_ppo_act_wide')
         stage_out.download()
         torch.cuda.current_stream().synchronize()
         return stage_out.host_view('actions').copy()
@@ -179,7 +183,43 @@ class A2C(Agent):
         self._eps = (torch.from_numpy(block.eps[0]), torch.from_numpy(block.eps[1]))
         self._slot, self._eps_ahead, self._pending, self._rollout_open = 0, False, False, False
 
+    # -- shapes beyond the fused act kernel (O > 32 or A > 8): staged copies + separate launches
+    def _wide(self):
+        return self.observation_size > 32 or self.action_size > 8
+
+    def _step_staged(self, observations):
+        observations = np.asarray(observations, np.float32)
+        W, O = observations.shape[0], self.observation_size
+        if getattr(self, '_staged_workers', None) != W:
+            self._staged_workers = W
+            self._in, self._out = self._io(W)
+            self._outcome = _Staging([('next_observations', (W, O)), ('rewards', (W,)),
+                                      ('resets', (W,)), ('terminations', (W,))], self.device)
+        actions = self._act(observations, self._in, self._out, True)
+        self.last_observations, self.last_actions = observations, actions
+        return actions
+
+    def _update_staged(self, observations, rewards, resets, terminations):
+        stage = self._outcome.writable()
+        stage.host_view('next_observations')[:] = observations
+        stage.host_view('rewards')[:] = rewards
+        stage.host_view('resets')[:] = resets                 # bool -> float32 (segments.py:33)
+        stage.host_view('terminations')[:] = terminations
+        stage.upload()
+        self.replay.store(
+            normalizer=self.model.observation_normalizer,
+            observations=self._in.device_view('observations'),
+            actions=self._out.device_view('actions'),
+            next_observations=stage.device_view('next_observations'),
+            rewards=stage.device_view('rewards'), resets=stage.device_view('resets'),
+            terminations=stage.device_view('terminations'),
+            log_probs=self._out.device_view('log_probs'))
+        if self.replay.ready():
+            self._update()
+
     def step(self, observations, steps):
+        if self._wide():
+            return self._step_staged(observations)
         block = getattr(self, '_block', None)
         if self._collector is None or block.workers != len(observations):
             self._bind(observations)
@@ -225,6 +265,8 @@ class A2C(Agent):
     def update(self, observations, rewards, resets, terminations, steps):
         """a2c.py:58-73.  The outcome stays in the block; the NEXT step's launch (or
         end_rollout) moves it into the Segment row of the step it belongs to."""
+        if self._wide():
+            return self._update_staged(observations, rewards, resets, terminations)
         block = self._block
         # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
         if observations is not block.next_observations:

@@ -58,7 +58,17 @@ class _FlatUpdater:
             self.world_size = torch.distributed.get_world_size()
 
     def _workspace_for(self, n):
-        need = self.lib.tonic_mlp64_grad_workspace_bytes(n, self.count)
+        """Scratch of the grad kernels: per-workgroup partial images for the fused kernels; for
+        shapes beyond them (O > 32, A > 8: csrc/mlpwide.hip) also the activations of the
+        layer-by-layer passes."""
+        actor = self.stats_kind == 1
+        need = self.lib.tonic_ppo_workspace_bytes(
+            n, self.observation_size, self.action_size if actor else 1, 1 if actor else 0)
+        if need < 0:
+            raise NotImplementedError(
+                f'PPO networks with {self.observation_size} observations / '
+                f'{getattr(self, "action_size", 1)} actions are outside the HIP kernels '
+                '(O <= 384, A <= 32)')
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
         return self.workspace
@@ -240,10 +250,11 @@ class VRegression(_FlatUpdater):
     def forward_values(self, observations, out):
         mean, std = self.norm_tensors()
         p = _lib.ptr
-        _lib.check(self.lib.tonic_value_forward(
+        ws = self._workspace_for(observations.shape[0])
+        _lib.check(self.lib.tonic_value_forward_wide(
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(out),
-            observations.shape[0],
-            self.observation_size, _lib.current_stream()), 'tonic_value_forward')
+            observations.shape[0], self.observation_size, p(ws), ws.numel(),
+            _lib.current_stream()), 'tonic_value_forward_wide')
         return out
 
     def enqueue_grad(self, observations, returns):
