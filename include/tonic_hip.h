@@ -52,14 +52,6 @@ const char* tonic_last_error(void);
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
-/* Developer tuning knobs (process-wide; call before sizing workspaces).  Keys:
- *   "grad_waves" = 4       waves per workgroup of the 32x32x2-tile fused grad kernel;
- *   "grad_variant" = 0 | 1 fused grad kernel: 0 = 32x32x2 tiles, 1 wave/SIMD; 1 = 16x16x4
- *                          tiles, 2 waves/SIMD (default);
- *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0);
- *   "policy_tail" = 0 | 1  off-policy actors: sampling / target noise / dense copy in the tail of
- *                          the forward launch (1, default) or in their own launches (0); same bits. */
-int tonic_set_tuning(const char* key, int32_t value);
 
 /* Sizes of the flat parameter blocks described above. */
 int64_t tonic_ppo_actor_param_count(int32_t O, int32_t A);
@@ -509,21 +501,6 @@ int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d
                        const float* d_observations, const float* d_eps, float* d_grad_sums,
                        int32_t B, int32_t O, int32_t H, int32_t A, double entropy_coeff,
                        void* d_workspace, int64_t workspace_bytes, void* stream);
-
-/* Developer tool: per-phase cycle totals (s_memtime) of the 8 waves of workgroup 0 of the
- * 16x16x4 fused actor grad kernel; d_phase_cycles = uint64[8][12]. */
-int tonic_debug_grad16_phases(const float* d_actor_params, const float* d_observations,
-                              const float* d_actions, const float* d_advantages,
-                              const float* d_adv_stats, const float* d_old_log_probs, int64_t n,
-                              int32_t O, int32_t A, void* d_workspace, int64_t workspace_bytes,
-                              uint64_t* d_phase_cycles, void* stream);
-
-/* Developer / test entry: one GEMM of the small-batch fp32 MFMA building block
- * (mode "NT" | "NN" | "TN"; act 0 none, 1 relu, 2 tanh; d_mask multiplies by (mask > 0)). */
-int tonic_gemm_f32(const char* mode, const float* d_a, const float* d_b, float* d_c,
-                   const float* d_bias, const float* d_mask, float* d_colsum, int32_t M,
-                   int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t act,
-                   int32_t accumulate, double alpha, void* stream);
 
 #ifdef __cplusplus
 }

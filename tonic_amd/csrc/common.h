@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/tonic_hip.h"
+#include "../../include/tonic_hip_dev.h"
 
 namespace tonic {
 

@@ -27,6 +27,9 @@
 
 #include <type_traits>
 
+#include <atomic>
+#include <unordered_set>
+
 #include "mlp64.h"
 #include "mlpfwd.h"
 
@@ -753,11 +756,11 @@ constexpr int kFwdWaves = 4;
 constexpr int kMaxGradBlocks = 256;   // one workgroup per CU
 // Waves per workgroup of the fused grad kernel: one wave per SIMD with the whole 512-register
 // file (a two-waves-per-SIMD build spilled >100 registers and measured no faster).
-int g_grad_waves = 4;
+std::atomic<int> g_grad_waves{4};
 // 0 = 32x32x2 tiles, one wave per SIMD (mlp64_grad_kernel); 1 = 16x16x4 tiles, two waves per
 // SIMD (mlp64x16.hip).
-int g_grad_variant = 1;
-int g_grad_skew = 0;       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
+std::atomic<int> g_grad_variant{1};
+std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
 int ks1_bucket(int O) {
@@ -786,18 +789,15 @@ int launch(K kernel, int blocks, int threads, int lds_bytes, hipStream_t stream,
            const char* what) {
   // >64 KiB of dynamic LDS needs an opt-in, once per kernel (not a stream operation, so it is
   // done outside any graph capture that may be active on later calls).
-  static thread_local const void* configured[64];
-  static thread_local int n_configured = 0;
+  static thread_local std::unordered_set<const void*> configured;
   const void* fn = reinterpret_cast<const void*>(kernel);
-  bool known = false;
-  for (int i = 0; i < n_configured; ++i) known |= configured[i] == fn;
-  if (!known) {
+  if (configured.find(fn) == configured.end()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, lds_bytes, hipGetErrorString(e));
       return TONIC_ERR_LAUNCH;
     }
-    if (n_configured < 64) configured[n_configured++] = fn;
+    configured.insert(fn);
   }
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, args);
   TONIC_CHECK_LAUNCH(what);

@@ -1,5 +1,6 @@
 // Fused forward of a two-hidden-layer ReLU MLP with up to two narrow heads: see mlpfwd.hip.
 #pragma once
+#include <atomic>
 #include "gemm16.h"
 
 namespace tonic {
@@ -122,7 +123,7 @@ struct MlpBwdArgs {
 
 bool mlp_forward_supported(int H, int NH, int heads);
 bool mlp_policy_tail_supported(int H, int NH);
-extern int g_policy_tail;      // tuning key "policy_tail": 0 keeps sampling / noise / copy in their own launches
+extern std::atomic<int> g_policy_tail;      // tuning key "policy_tail": 0 keeps sampling / noise / copy in their own launches
 bool mlp_backward_supported(int H, int NH, int heads, int xa_count);
 int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream);
 int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream);

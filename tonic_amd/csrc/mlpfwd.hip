@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 
 }  // namespace
 
-int g_policy_tail = 1;
+std::atomic<int> g_policy_tail{1};
 
 // the tail's three [16][kPostPitch] images live in the first hidden image (the second is being read)
 bool mlp_policy_tail_supported(int H, int NH) {
