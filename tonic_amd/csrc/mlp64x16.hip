@@ -22,6 +22,10 @@
 #include "mlp64.h"
 #include "collect16.h"
 
+#ifndef TONIC_COLLECT_SC1
+#define TONIC_COLLECT_SC1 0
+#endif
+
 namespace tonic {
 
 constexpr int TS16 = 24;
@@ -1032,14 +1036,24 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
         if (valid && g == 0 && aa < A) {
           c.seg_act[(c.row * W + ns) * A + aa] = act;
-          if (c.actions_out != nullptr) c.actions_out[ns * A + aa] = act;
+          if (c.actions_out != nullptr) {
+#if TONIC_COLLECT_SC1
+            if constexpr (HOST)
+              __hip_atomic_store(c.actions_out + ns * A + aa, act, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+#endif
+              c.actions_out[ns * A + aa] = act;
+          }
         }
       }
       if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
       // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
       // only then may the completion word go out (scripts/collector_stress.py: without the
       // fence the host reads stale actions within a few thousand steps).
+#if !TONIC_COLLECT_SC1
       if constexpr (HOST) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
