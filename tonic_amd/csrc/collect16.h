@@ -36,6 +36,10 @@ struct Collect16Args {
   // (pinned host memory) once all of its reads of the pinned block and its writes to it are
   // complete; the host spins on those words instead of synchronising the stream.
   unsigned* done_flags; unsigned done_seq;
+  // Developer probe (null: off; TONIC_AMD_COLLECTOR_STAMPS=1): 100 MHz wall-clock stamps of one
+  // actor workgroup, the record workgroup and one copy workgroup, summed per phase:
+  // stamps[role * 8 + phase] += now - t0 (t0 = the moment the role saw its command), [.. + 7] counts.
+  unsigned long long* stamps; unsigned long long stamp_t0;
 };
 
 // What the resident form of the collect kernel needs besides the per-step arguments.

@@ -20,6 +20,7 @@
 #include <errno.h>
 #include <limits.h>
 #include <linux/futex.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -227,6 +228,7 @@ struct tonic_collector {
   unsigned* d_relay;
   bool live;
   double park_us;
+  unsigned long long* d_stamps;   // developer probe (TONIC_AMD_COLLECTOR_STAMPS=1)
 };
 
 namespace {
@@ -321,6 +323,11 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
       (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
+  if (getenv("TONIC_AMD_COLLECTOR_STAMPS") != nullptr) {
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 24 * 8)) != hipSuccess ||
+        (e = hipMemset(c->d_stamps, 0, 24 * 8)) != hipSuccess)
+      return fail("hipMalloc of the stamp buffer", e);
+  }
   const char* park = getenv("TONIC_AMD_COLLECTOR_PARK_US");
   c->park_us = park != nullptr ? atof(park) : 200.0;
   if ((e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
@@ -339,6 +346,20 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
     c->live = false;
   }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->d_stamps) {
+    unsigned long long t[24];
+    if (hipMemcpy(t, c->d_stamps, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+      const char* role[3] = {"actor tile 0", "record", "copy 0"};
+      for (int r = 0; r < 3; ++r) {
+        const double n = t[r * 8 + 7] > 0 ? (double)t[r * 8 + 7] : 1.0;
+        fprintf(stderr, "collector stamps, %s (us after the command was seen, %llu steps):", role[r],
+                t[r * 8 + 7]);
+        for (int p = 0; p < 5; ++p) fprintf(stderr, " %.2f", t[r * 8 + p] / n / 100.0);
+        fprintf(stderr, "\n");
+      }
+    }
+    (void)hipFree(c->d_stamps);
+  }
   if (c->d_packed) (void)hipFree(c->d_packed);
   if (c->staged) (void)hipFree(c->staged);
   if (c->d_relay) (void)hipFree(c->d_relay);
@@ -401,6 +422,7 @@ Collect16Args step_arguments(tonic_collector* c) {
   a.W = c->W; a.O = c->O; a.A = c->A;
   if (c->transport != 1)
     a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+  a.stamps = c->d_stamps;
   return a;
 }
 

@@ -697,6 +697,13 @@ __device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__device__ __forceinline__ void collect_stamp(const Collect16Args& c, int role, int phase) {
+  if (c.stamps != nullptr && threadIdx.x == 0) {
+    c.stamps[role * 8 + phase] += wall_clock64() - c.stamp_t0;
+    if (phase == 0) c.stamps[role * 8 + 7] += 1;
+  }
+}
+
 constexpr int kCollectLds = 16384;     // floats: MeanStd.record staging tile of the last block
 constexpr int kCollectCopyBlocks = 4;  // workgroups that copy the transition outcome
 
@@ -794,14 +801,36 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       const int64_t each = ((total + kCollectCopyBlocks - 1) / kCollectCopyBlocks + 3) & ~(int64_t)3;
       const int64_t f0 = min(total, part * each), f1 = min(total, f0 + each);
       float* dst = c.seg_next + c.outcome_row * total;
+      // the scalar fields of this block's workers FIRST (their loads then share the PCIe round
+      // trip of the observation rows instead of paying a second one behind them)
+      const int64_t i0 = part * 256 + tid;
+      float rew[2], rst[2], term[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < W) {
+          rew[u] = host_load1<SYS>(c.rewards, i);
+          rst[u] = host_load1<SYS>(c.resets, i);
+          term[u] = host_load1<SYS>(c.terminations, i);
+        }
+      }
       for (int64_t f = f0; f < f1; f += 8 * 256 * 4)
         wide_copy<SYS>(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
-      for (int64_t i = part * 256 + tid; i < W; i += stride) {
-        const float rew = host_load1<SYS>(c.rewards, i), rst = host_load1<SYS>(c.resets, i),
-                    term = host_load1<SYS>(c.terminations, i);
-        c.seg_rew[c.outcome_row * W + i] = rew;
-        c.seg_rst[c.outcome_row * W + i] = rst;
-        c.seg_term[c.outcome_row * W + i] = term;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < W) {
+          c.seg_rew[c.outcome_row * W + i] = rew[u];
+          c.seg_rst[c.outcome_row * W + i] = rst[u];
+          c.seg_term[c.outcome_row * W + i] = term[u];
+        }
+      }
+      for (int64_t i = i0 + 2 * stride; i < W; i += stride) {          // (W > 2048)
+        const float r = host_load1<SYS>(c.rewards, i), x = host_load1<SYS>(c.resets, i),
+                    t = host_load1<SYS>(c.terminations, i);
+        c.seg_rew[c.outcome_row * W + i] = r;
+        c.seg_rst[c.outcome_row * W + i] = x;
+        c.seg_term[c.outcome_row * W + i] = t;
       }
     } else if (c.outcome_row >= 0) {
       // all of this thread's loads first, then the stores (a plain copy loop waits per element)
@@ -823,7 +852,9 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       }
     }
     retire_touches(sink, c.seg_next);
+    if (part == 0) collect_stamp(c, 2, 0);           // copies issued
     collect_signal_done(c);
+    if (part == 0) collect_stamp(c, 2, 1);           // flag out
     return;
   }
   if (blockIdx.x == gridDim.x - 1) {
@@ -885,7 +916,9 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     }
     if (wave < 2 && lane < O) c.norm_acc[wave * O + lane] = acc;
     retire_touches(sink, c.norm_acc);
+    collect_stamp(c, 1, 0);                          // staged + chained
     collect_signal_done(c);
+    collect_stamp(c, 1, 1);
     return;
   }
   // Actor: ONE 16-sample tile per workgroup; wave w owns output-feature tile w (16 of the 64
@@ -971,6 +1004,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         if ((e_vecs << 2) + etid < e_count) SE[(e_vecs << 2) + etid] = te;
       }
       __syncthreads();
+      if (blockIdx.x == 0) collect_stamp(c, 0, 0);   // inputs in LDS
       const int sr = s < tile_rows ? s : tile_rows - 1;
 #pragma unroll
       for (int st = 0; st < KS1; ++st) {
@@ -1000,6 +1034,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     for (int e = 0; e < 4; ++e) h[e] = tanh_fast(acc[e]);
     X1[wave * 64 + lane] = h;
     __syncthreads();
+    if (blockIdx.x == 0) collect_stamp(c, 0, 1);     // layer 1 done (inputs arrived before)
     f32x4 h1[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) h1[cc] = X1[cc * 64 + lane];
@@ -1051,14 +1086,17 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
       // only then may the completion word go out (scripts/collector_stress.py: without the
       // fence the host reads stale actions within a few thousand steps).
+      if (blockIdx.x == 0) collect_stamp(c, 0, 2);   // head, sample, stores issued
 #if !TONIC_COLLECT_SC1
       if constexpr (HOST) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 #endif
+      if (blockIdx.x == 0) collect_stamp(c, 0, 3);   // released
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
   retire_touches(eps_sink, c.seg_lp);
   collect_signal_done(c);
+  if (blockIdx.x == 0) collect_stamp(c, 0, 4);       // flag out
 }
 
 // One launch per environment step.
@@ -1123,6 +1161,7 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
     step.outcome_row = (word & 4) ? step.row - 1 : -1;
     step.eps = (word & 2) ? ((word & 1) ? r.eps1 : r.eps0) : nullptr;
     step.done_seq = expect;
+    step.stamp_t0 = wall_clock64();
     if (word & 8) {                                // stop: only the pending outcome is stored
       if (copy_role) collect16_step<KS1, AP, true, true>(step, tile);
       else collect_signal_done(step);
