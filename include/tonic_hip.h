@@ -354,6 +354,12 @@ int tonic_collector_wait_obs(void* block, double timeout_s);
 int tonic_collector_shutdown(void* block);
 
 int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport);
+/* The address at which kernels see page-locked host memory (hipHostMalloc'ed, e.g. a pinned torch
+ * tensor, or registered), NULL if it is not mapped into the current device's address space.  The
+ * agents' per-step staging passes such pointers to the ordinary entry points (tonic_ppo_act_wide,
+ * tonic_policy_forward, tonic_segment_store, tonic_buffer_store ...): the kernels then read the
+ * step's inputs and write its results in host memory, no copy in either direction. */
+void* tonic_host_device_pointer(void* pinned_host);
 int tonic_collector_destroy(tonic_collector_t* collector);
 void* tonic_collector_stream(tonic_collector_t* collector);      /* the collector's hipStream_t */
 int tonic_collector_bind_segment(tonic_collector_t* collector, float* d_seg_observations,

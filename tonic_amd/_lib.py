@@ -79,6 +79,7 @@ SIGNATURES = {
     'tonic_collector_wait_obs': (ctypes.c_int, [c_vp, c_f64]),
     'tonic_collector_shutdown': (ctypes.c_int, [c_vp]),
     'tonic_collector_create': (ctypes.c_int, [ctypes.POINTER(c_vp), c_vp, c_i32]),
+    'tonic_host_device_pointer': (c_vp, [c_vp]),
     'tonic_collector_destroy': (ctypes.c_int, [c_vp]),
     'tonic_collector_stream': (c_vp, [c_vp]),
     'tonic_collector_bind_segment': (ctypes.c_int, [c_vp] * 9 + [c_i64]),

@@ -279,6 +279,15 @@ int stage_inputs(tonic_collector* c, int eps_slot) {
 
 }  // namespace
 
+extern "C" void* tonic_host_device_pointer(void* pinned_host) {
+  void* device = nullptr;
+  if (pinned_host == nullptr || hipHostGetDevicePointer(&device, pinned_host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return device;
+}
+
 extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport) {
   TONIC_REQUIRE(out != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_create: out is NULL");
   *out = nullptr;

@@ -75,43 +75,65 @@ class Agent(agents.Agent):
 
 
 class _Staging:
-    """Pinned host <-> device staging for one [W, ...] record per environment step."""
+    """One [W, ...] record per environment step in PINNED host memory that the kernels read and
+    write IN PLACE (page-locked memory is mapped into the GPU's address space at the same
+    address): no hipMemcpyAsync in either direction, no stream synchronisation — the host fills
+    the fields, enqueues the kernels with these very pointers, records an event behind them and
+    spins on it.  (`TONIC_AMD_STAGING=copy` restores explicit H2D / D2H copies through a device
+    mirror.)"""
 
     def __init__(self, fields, device):
         self.offsets, total = {}, 0
         for name, shape in fields:
             size = int(np.prod(shape))
             self.offsets[name] = (total, size, tuple(shape))
-            total += size
-        self.host = torch.empty(total, dtype=torch.float32).pin_memory()
-        self.device = torch.empty(total, dtype=torch.float32, device=device)
+            total += (size + 63) // 64 * 64              # fields on 256-byte boundaries
+        self.host = torch.zeros(total, dtype=torch.float32).pin_memory()
         self.host_np = self.host.numpy()
-        self.uploaded = None         # event behind the last H2D copy that read `host`
+        self.mapped = os.environ.get('TONIC_AMD_STAGING', 'mapped') != 'copy'
+        if self.mapped:      # kernels must see the block at the address the host uses
+            seen = _lib.load().tonic_host_device_pointer(self.host.data_ptr())
+            self.mapped = seen == self.host.data_ptr()
+        self.device = self.host if self.mapped else torch.empty(total, dtype=torch.float32,
+                                                                device=device)
+        self.done = None             # event behind the last kernels / copies that touched `host`
 
     def host_view(self, name):
         start, size, shape = self.offsets[name]
         return self.host_np[start:start + size].reshape(shape)
 
     def device_view(self, name):
+        """What the kernels get: the pinned field itself, or its device mirror."""
         start, size, shape = self.offsets[name]
         return self.device[start:start + size].view(shape)
 
     def writable(self):
-        """Blocks until the DMA of the previous upload() has read the pinned block: the host may
+        """Blocks until the work recorded by mark() has consumed the pinned block: the host may
         not overwrite it earlier (nothing else orders consecutive update() calls while an agent
         is still warming up and never reads anything back)."""
-        if self.uploaded is not None:
-            self.uploaded.synchronize()
+        if self.done is not None:
+            self.done.synchronize()
         return self
 
     def upload(self):
-        self.device.copy_(self.host, non_blocking=True)
-        if self.uploaded is None:
-            self.uploaded = torch.cuda.Event()
-        self.uploaded.record()
+        if not self.mapped:
+            self.device.copy_(self.host, non_blocking=True)
 
     def download(self):
-        self.host.copy_(self.device, non_blocking=True)
+        if not self.mapped:
+            self.host.copy_(self.device, non_blocking=True)
+
+    def mark(self):
+        """Records the event behind everything enqueued so far that reads / writes this block."""
+        if self.done is None:
+            self.done = torch.cuda.Event()
+        self.done.record()
+
+    def wait(self):
+        """Spins until the marked work is complete (results written in place are visible)."""
+        done = self.done
+        while not done.query():
+            pass
 
 
 class A2C(Agent):
@@ -151,6 +173,8 @@ class A2C(Agent):
     def _act(self, observations, stage_in, stage_out, want_log_probs):
         """Stand-alone forward + sample (test episodes): staging copies and a stream sync."""
         W, A = observations.shape[0], self.action_size
+        stage_in.writable()
+        stage_out.writable()
         stage_in.host_view('observations')[:] = observations
         # Same generator draw as Normal.sample() in the reference (a2c.py:81).
         stage_in.host_view('eps')[:] = torch.randn(W, A).numpy()
@@ -166,7 +190,9 @@ class A2C(Agent):
             W, self.observation_size, A, p(self._act_workspace), self._act_workspace.numel(),
             _lib.current_stream()), 'tonic_ppo_act_wide')
         stage_out.download()
-        torch.cuda.current_stream().synchronize()
+        stage_out.mark()
+        stage_in.done = stage_out.done
+        stage_out.wait()
         return stage_out.host_view('actions').copy()
 
     def _bind(self, observations):
@@ -214,6 +240,8 @@ class A2C(Agent):
             rewards=stage.device_view('rewards'), resets=stage.device_view('resets'),
             terminations=stage.device_view('terminations'),
             log_probs=self._out.device_view('log_probs'))
+        stage.mark()                  # the store kernel reads the pinned fields in place
+        self._in.done = self._out.done = stage.done
         if self.replay.ready():
             self._update()
 
@@ -505,7 +533,9 @@ class DDPG(Agent):
             self.action_size, p(workspace), workspace.numel(), _lib.current_stream()),
             'tonic_policy_forward')
         stage_out.download()
-        torch.cuda.current_stream().synchronize()
+        stage_out.mark()
+        stage_in.done = stage_out.done
+        stage_out.wait()
         return stage_out.host_view('actions').copy()
 
     def _greedy_actions(self, observations):
@@ -548,6 +578,7 @@ class DDPG(Agent):
             normalizer=self.model.observation_normalizer,
             **{k: stage.device_view(k) for k in ('observations', 'actions', 'next_observations',
                                                  'rewards', 'resets', 'terminations')})
+        stage.mark()                  # the store kernel(s) read the pinned fields in place
         if self.model.return_normalizer:
             raise NotImplementedError('return normalisers are not supported')
         if self.replay.ready(steps):
