@@ -45,7 +45,7 @@ def run(kind, out_path, rows=40, W=8, O=11, A=3, iterations=6, batch=48):
     np.savez(out_path + f'.get{rank}.npz',
              **{f'rewards{i}': b['rewards'].cpu().numpy() for i, b in enumerate(parts)},
              **{f'observations{i}': b['observations'].cpu().numpy() for i, b in enumerate(parts)})
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

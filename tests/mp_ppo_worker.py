@@ -41,7 +41,7 @@ def run(out_path, T=12, W=16, O=17, A=6, iterations=4):
         state = {k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
         np.savez(out_path, infos=agent.last_infos, adv_stats=agent.replay.adv_stats.cpu().numpy(),
                  **state)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

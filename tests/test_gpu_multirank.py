@@ -18,7 +18,8 @@ OFFPOLICY_WORKER = os.path.join(ROOT, 'tests', 'mp_offpolicy_worker.py')
 
 def launch(world, out, port, command=(WORKER,), extra_env=None):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               TONIC_AMD_BACKEND='gloo', **(extra_env or {}))
+               TONIC_AMD_BACKEND='gloo')
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, *command, out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
@@ -130,3 +131,18 @@ def test_two_ranks_with_the_one_shot_allreduce_equal_single_process(tmp_path):
         if key in ('infos', 'adv_stats'):
             continue
         np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)
+
+
+@pytest.mark.parametrize('worker,args', [(WORKER, ()), (OFFPOLICY_WORKER, ('sac',))])
+def test_exchange_schedule_over_rccl_with_one_rank(tmp_path, worker, args):
+    """The multi-rank learner schedule — asynchronous all-reduces of the gradient sums hidden behind
+    the other network's grad kernel, moments and normaliser sums — driven through the REAL RCCL
+    backend ("nccl") with a process group of one rank (TONIC_AMD_EXERCISE_EXCHANGE=1): reductions
+    are identities, so every output must equal the plain single-process run bit for bit."""
+    plain, exchanged = str(tmp_path / 'plain.npz'), str(tmp_path / 'rccl.npz')
+    launch(1, plain, 29761, command=(worker, *args))
+    launch(1, exchanged, 29762, command=(worker, *args),
+           extra_env={'TONIC_AMD_BACKEND': 'nccl', 'TONIC_AMD_EXERCISE_EXCHANGE': '1', 'RANK': '0'})
+    a, b = np.load(plain), np.load(exchanged)
+    for key in a.files:
+        assert np.array_equal(a[key], b[key]), key

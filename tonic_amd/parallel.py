@@ -17,7 +17,8 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1 or dist.is_initialized():
+    exercise = os.environ.get('TONIC_AMD_EXERCISE_EXCHANGE') == '1'
+    if (world <= 1 and not exercise) or dist.is_initialized():
         return rank(), world_size()
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -36,6 +37,17 @@ def rank():
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def exchanging():
+    """True when the learner exchanges gradient sums between ranks.  Besides world_size > 1 that is
+    a process group of ONE rank with TONIC_AMD_EXERCISE_EXCHANGE=1: a test hook that drives the
+    whole exchange schedule (asynchronous RCCL all-reduces, stream hand-overs) on a single GPU —
+    with one rank the reductions are identities, so results must equal the plain path bit for bit."""
+    if world_size() > 1:
+        return True
+    return (dist.is_available() and dist.is_initialized()
+            and os.environ.get('TONIC_AMD_EXERCISE_EXCHANGE') == '1')
 
 
 def shard_bounds(total, r=None, world=None):

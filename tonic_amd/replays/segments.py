@@ -115,7 +115,7 @@ class Segment:
             p(self.adv_moments), shape[0], shape[1], float(self.discount_factor),
             float(self.trace_decay), self.gae_chunks, p(self.gae_workspace),
             self.gae_workspace.numel(), _lib.current_stream()), 'tonic_gae_lambda_returns')
-        if parallel.world_size() > 1:
+        if parallel.exchanging():
             # global advantage statistics over every rank's worker shard
             m = self.adv_moments
             torch.distributed.all_reduce(m[0:2])

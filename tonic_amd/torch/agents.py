@@ -382,7 +382,8 @@ class PPO(A2C):
         # Full batch (ppo.py:40-47 over segments.py:55-57) or shuffled minibatches
         # (segments.py:58-65); the advantages stay raw and are normalised in-register with the
         # GLOBAL statistics, exactly what get_full computes before the reference slices.
-        if world == 1:
+        from tonic_amd import parallel
+        if not parallel.exchanging():
             for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
                 actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
                 critic.enqueue_grad(obs, returns)
@@ -395,7 +396,6 @@ class PPO(A2C):
         #   critic grad i | all-reduce(critic i) over Adam(actor i) + actor grad i+1 | Adam(critic i)
         # After the KL stop the actor half is zero-filled on every rank alike and its step is
         # skipped by the same device flag everywhere.
-        from tonic_amd import parallel
         one_shot = parallel.one_shot(max(actor.count, critic.count) + updaters.INFO_WIDTH)
         if one_shot is not None:
             # tonic_allreduce_f32: one ~10 us launch per exchange, nothing to hide it behind
@@ -647,7 +647,8 @@ class DDPG(Agent):
                     else:
                         self.actor_updater.enqueue_empty(self._infos[1, it], n_global, targets)
 
-        if not graph or world > 1:
+        from tonic_amd import parallel
+        if not graph or parallel.exchanging():      # collectives sit between the kernels
             enqueue()
             return self._infos
         if self._graph is None:

@@ -66,8 +66,8 @@ class MeanStd(torch.nn.Module):
             # mean_stds.py:52 divides the integer 0 by the integer 0 here: same error, no NaNs
             raise ZeroDivisionError('MeanStd.update() without any recorded values')
         if self.device_sums is not None:
-            if torch.distributed.is_available() and torch.distributed.is_initialized() \
-                    and torch.distributed.get_world_size() > 1:
+            from tonic_amd import parallel
+            if parallel.exchanging():
                 # every rank recorded its own worker shard: merge the running sums
                 torch.distributed.all_reduce(self.device_sums)
                 self.new_count *= torch.distributed.get_world_size()

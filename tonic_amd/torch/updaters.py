@@ -94,8 +94,8 @@ class _FlatUpdater:
         (flat target buffer, flat online buffer, offset of this block in them, coeff): the
         polyak update of ALL targets rides in the same launch (update_targets right after the
         step, as ddpg.py:105-112 orders them)."""
-        if self.world_size > 1 and allreduce:
-            from tonic_amd import parallel
+        from tonic_amd import parallel
+        if parallel.exchanging() and allreduce:
             one_shot = parallel.one_shot(self.count + INFO_WIDTH)
             if one_shot is not None:
                 one_shot.all_reduce(self.grad_sums)              # tonic_allreduce_f32
