@@ -444,6 +444,10 @@ def main():
         O, A, W = 28, 8, 1280
         args.no_extras = True
 
+    # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION (set in this image): the contract
+    # is ONE JSON line on rank 0's stdout
+    if os.environ.get('NCCL_DEBUG', 'VERSION').upper() == 'VERSION':
+        os.environ['NCCL_DEBUG'] = 'WARN'
     import torch
     from tonic_amd import parallel
     rank, world = parallel.init_from_env()

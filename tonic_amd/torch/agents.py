@@ -391,11 +391,17 @@ class PPO(A2C):
                                            self._infos[0, it], self._infos[1, it])
             return self._infos
         # Several ranks: every iteration exchanges [gradient sums | 8 statistics] of both networks
-        # (RCCL over xGMI), each reduction hidden behind the OTHER network's fused grad kernel:
-        #   actor grad i | all-reduce(actor i) over critic grad i | Adam(actor i)
-        #   critic grad i | all-reduce(critic i) over Adam(actor i) + actor grad i+1 | Adam(critic i)
-        # After the KL stop the actor half is zero-filled on every rank alike and its step is
-        # skipped by the same device flag everywhere.
+        # (RCCL over xGMI).  After the KL stop the actor half is zero-filled on every rank alike and
+        # its step is skipped by the same device flag everywhere.  Two schedules
+        # (TONIC_AMD_EXCHANGE), A/B-measured through RCCL with a one-rank group:
+        #   joint (default)  one all-reduce of both halves per iteration, both Adam steps in one
+        #                    launch: +8.6 ms per 80-iteration update over the exchange-free path;
+        #   overlap          one asynchronous all-reduce per network, each hidden behind the OTHER
+        #                    network's fused grad kernel
+        #                      actor grad i | AR(actor i) over critic grad i | Adam(actor i)
+        #                      critic grad i | AR(critic i) over Adam(actor i) + actor grad i+1 | Adam(critic i)
+        #                    : +12.4 ms — the stream hand-overs of 160 collectives cost more than
+        #                    the latency of 80 they hide when there is no link latency to hide.
         one_shot = parallel.one_shot(max(actor.count, critic.count) + updaters.INFO_WIDTH)
         if one_shot is not None:
             # tonic_allreduce_f32: one ~10 us launch per exchange, nothing to hide it behind
@@ -408,6 +414,21 @@ class PPO(A2C):
                                            self._infos[0, it], self._infos[1, it])
             return self._infos
         all_reduce = torch.distributed.all_reduce
+        if os.environ.get('TONIC_AMD_EXCHANGE', 'joint') == 'joint':
+            # ONE synchronous all-reduce of [actor sums | 8 | critic sums | 8] per iteration, both
+            # optimizer steps in one launch (half the collectives, none of them hidden)
+            if getattr(self, '_joint_grads', None) is None:
+                na, nc = actor.count + updaters.INFO_WIDTH, critic.count + updaters.INFO_WIDTH
+                self._joint_grads = torch.zeros(na + nc, device=self.device)
+                actor.share_gradient_buffer(self._joint_grads[:na])
+                critic.share_gradient_buffer(self._joint_grads[na:])
+            for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
+                actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+                critic.enqueue_grad(obs, returns)
+                all_reduce(self._joint_grads)
+                updaters.enqueue_step_pair(actor, critic, obs.shape[0], replay.adv_stats,
+                                           self._infos[0, it], self._infos[1, it])
+            return self._infos
         pending = None                           # (work handle, rows, info row) of the critic
         for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
             n = obs.shape[0]
