@@ -28,10 +28,12 @@ def launch(world, out, port, command=(WORKER,), extra_env=None):
         assert p.returncode == 0, output[-3000:]
 
 
-def test_two_ranks_equal_single_process(tmp_path):
+@pytest.mark.parametrize('schedule', ['joint', 'overlap'])
+def test_two_ranks_equal_single_process(tmp_path, schedule):
+    """Both exchange schedules (TONIC_AMD_EXCHANGE, agents.py PPO.enqueue_update)."""
     single, double = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
     launch(1, single, 29631)
-    launch(2, double, 29632)
+    launch(2, double, 29632, extra_env={'TONIC_AMD_EXCHANGE': schedule})
     a, b = np.load(single), np.load(double)
     np.testing.assert_allclose(b['adv_stats'], a['adv_stats'], rtol=1e-5, atol=1e-6)
     ran = a['infos'][0][:, 6] > 0
@@ -133,16 +135,19 @@ def test_two_ranks_with_the_one_shot_allreduce_equal_single_process(tmp_path):
         np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)
 
 
-@pytest.mark.parametrize('worker,args', [(WORKER, ()), (OFFPOLICY_WORKER, ('sac',))])
-def test_exchange_schedule_over_rccl_with_one_rank(tmp_path, worker, args):
-    """The multi-rank learner schedule — asynchronous all-reduces of the gradient sums hidden behind
-    the other network's grad kernel, moments and normaliser sums — driven through the REAL RCCL
+@pytest.mark.parametrize('worker,args,schedule', [(WORKER, (), 'joint'), (WORKER, (), 'overlap'),
+                                                  (OFFPOLICY_WORKER, ('sac',), 'joint')])
+def test_exchange_schedule_over_rccl_with_one_rank(tmp_path, worker, args, schedule):
+    """The multi-rank learner schedule — all-reduces of the gradient sums (one joint per iteration, or
+    one asynchronous per network hidden behind the other network's grad kernel), moments and
+    normaliser sums — driven through the REAL RCCL
     backend ("nccl") with a process group of one rank (TONIC_AMD_EXERCISE_EXCHANGE=1): reductions
     are identities, so every output must equal the plain single-process run bit for bit."""
     plain, exchanged = str(tmp_path / 'plain.npz'), str(tmp_path / 'rccl.npz')
     launch(1, plain, 29761, command=(worker, *args))
     launch(1, exchanged, 29762, command=(worker, *args),
-           extra_env={'TONIC_AMD_BACKEND': 'nccl', 'TONIC_AMD_EXERCISE_EXCHANGE': '1', 'RANK': '0'})
+           extra_env={'TONIC_AMD_BACKEND': 'nccl', 'TONIC_AMD_EXERCISE_EXCHANGE': '1', 'RANK': '0',
+                      'TONIC_AMD_EXCHANGE': schedule})
     a, b = np.load(plain), np.load(exchanged)
     for key in a.files:
         assert np.array_equal(a[key], b[key]), key
