@@ -21,6 +21,7 @@ box's cores on a bounded sample), `learner_updates_per_sec`, `host_loop` (where 
 step goes), `strong_scaling` (N > 1: the metric's 256 workers split over the ranks).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -60,6 +61,13 @@ def time_events(fn, repeats):
     end.record()
     torch.cuda.synchronize()
     return start.elapsed_time(end) / repeats
+
+
+# The arithmetic type of the path.  Everything is fp32 in and fp32 out with fp32 accumulation; the
+# two 64x64 hidden-layer products of the fused grad kernels split each fp32 operand EXACTLY into three
+# bf16 terms and sum the six bf16 MFMAs that matter at fp32 precision ("bf16x3"; tests/test_gpu_parity.py
+# holds that variant to the same tolerances as the fp32-MFMA variants, tonic_set_tuning selects them).
+DTYPE = 'f32 (hidden-layer products of the grad kernels bf16x3-emulated: exact 3-term split, fp32 accumulate)'
 
 
 def pmc_traffic(prefix):
@@ -106,25 +114,35 @@ def kernel_rooflines(agent):
             p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, O,
             p(wsc), wsc.numel(), stream), 'critic')
 
+    # grad_variant: 0 = 32x32x2 fp32 tiles, 1 wave per SIMD; 1 = 16x16x4 fp32 tiles, 2 waves; 2 = 1 with
+    # the two 64x64 hidden-layer products on bf16x3 terms.  The roofline entry is the variant the
+    # library ships as its default (the one the timed job above ran); the others are listed beside it.
+    shipped = ctypes.c_int32(-1)
+    _lib.check(lib.tonic_get_tuning(b'grad_variant', ctypes.byref(shipped)), 'tuning')
+    shipped = shipped.value
     out = {}
-    for waves in (0, 1):          # grad_variant: 0 = 32x32x2 / 1 wave per SIMD, 1 = 16x16x4 / 2 waves
-        _lib.check(lib.tonic_set_tuning(b'grad_variant', waves), 'tuning')
+    for variant in (0, 1, 2):
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
         ws = actor._workspace_for(n)
         wsc = critic._workspace_for(n)
         ms_a, ms_c = time_events(actor_grad, 10), time_events(critic_grad, 10)
-        out[waves] = (ms_a, ms_c)
-    best = min(out, key=lambda k: out[k][0] + out[k][1])
-    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
-    ms_a, ms_c = out[best]
+        out[variant] = (ms_a, ms_c)
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
+    ms_a, ms_c = out[shipped]
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
-    roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> / mlp64_grad_kernel<actor> (+reduce_partials)',
+    arithmetic = ('fp32 MFMA throughout' if shipped < 2 else
+                  'fp32-equivalent: layer 1 and the weight-gradient products on fp32 MFMA; the two 64x64 '
+                  'hidden-layer products (41 % of the flops) as six bf16 MFMAs per product on exact '
+                  'hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak stays the fp32 '
+                  'MFMA peak: that is what the same arithmetic costs without the split')
+    roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
                 ms_per_launch=round(ms_a, 4), samples_per_launch=n,
-                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=best,
+                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=shipped, arithmetic=arithmetic,
                 variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
-    roof_critic = dict(bound='mfma', kernel='mlp64_grad_kernel<critic> (+reduce_partials)',
+    roof_critic = dict(bound='mfma', kernel='mlp64_grad16_kernel<critic> (+reduce_partials)',
                        achieved=round(tf_c, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                        frac=round(tf_c / FP32_MFMA_PEAK_TFLOPS, 4),
                        ms_per_launch=round(ms_c, 4))
@@ -473,7 +491,7 @@ def main():
         'value': round(main_run['value'], 1), 'unit': 'env_steps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(main_run['ms_per_step'], 3), 'higher_is_better': True,
-        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
         'config': {'workload': f'PPO {name} shapes (O={O}, A={A}), parallel={workers} workers per '
                                f'GPU ({global_workers} global), Segment T={T} (N={T * workers} '
                                'transitions per GPU per step), 80 full-batch iterations, 1 learner '

@@ -162,7 +162,7 @@ def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
         *[t.data_ptr() for t in keep], out.data_ptr(),
         n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor_grad')
     torch.cuda.synchronize()
-    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
     return out.cpu().numpy(), P
 
 
@@ -179,7 +179,7 @@ def critic_grad(lib, params, mean, std, obs, returns, variant=None, clip=0.0):
         *[t.data_ptr() for t in keep[:3]], float(clip), *[t.data_ptr() for t in keep[3:]],
         out.data_ptr(), n, O, ws.data_ptr(), ws.numel(), None), 'critic_grad')
     torch.cuda.synchronize()
-    _lib.check(lib.tonic_set_tuning(b'grad_variant', 1), 'tuning')
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
     return out.cpu().numpy(), P
 
 
@@ -191,7 +191,7 @@ def assert_grads_close(got_sums, want_grads, n, what):
     assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 @pytest.mark.parametrize('name', PPO_CASES)
 def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     g = golden(name)
@@ -227,7 +227,7 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_grads_ratio_clipping_branches(lib, variant):
     """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
     the still-live ones; ragged n (not a multiple of the 32-sample tile)."""
@@ -250,7 +250,7 @@ def test_grads_ratio_clipping_branches(lib, variant):
     np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_grads_full_size_properties(lib, variant):
     """BASELINE size (N = 4096 x 256): sums are additive over a split of the batch,
     bit-reproducible run to run, and agree with the oracle on a 4096-sample slice."""
@@ -278,6 +278,57 @@ def test_grads_full_size_properties(lib, variant):
     want, _ = port.clipped_ratio_grads(params, obs[:m], actions[:m], adv[:m], old_lp[:m])
     part, _ = actor_grad(lib, params, obs[:m], actions[:m], adv[:m], stats, old_lp[:m], variant)
     assert_grads_close(part[:P], want, m, 'slice of the full batch')
+
+
+def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
+    """grad_variant 2 computes the two 64x64 hidden-layer products of a tile as six bf16 MFMAs on exact
+    hi + mid + lo splits of the fp32 operands.  Against a float64 autograd reference of the same loss
+    its gradient sums must be as close as those of the fp32-MFMA variants (0 and 1): the split is a
+    re-association of fp32 arithmetic, not a precision cut."""
+    rng = np.random.RandomState(23)
+    O, A, n = 17, 6, 65536
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, A)) * 0.2, rng.normal(size=(A, 64)) * 0.1, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.1).astype(np.float32)
+    returns = rng.standard_normal(n).astype(np.float32)
+    mean, std = np.zeros(O, np.float32), np.ones(O, np.float32)
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+
+    def f64(arrays):
+        return [torch.tensor(np.asarray(a, np.float64), device='cuda', requires_grad=True) for a in arrays]
+
+    x, a_t, adv_t, lp_t, ret_t = (torch.tensor(np.asarray(v, np.float64), device='cuda')
+                                  for v in (obs, actions, adv, old_lp, returns))
+    W1, b1, W2, b2, ls, W3, b3 = pa = f64(params)
+    h = torch.tanh(torch.tanh(x @ W1.T + b1) @ W2.T + b2)
+    dist = torch.distributions.Normal(
+        torch.tanh(h @ W3.T + b3), (torch.nn.functional.softplus(ls) + 1e-8).clamp(1e-4, 1.0))
+    ratio = torch.exp(dist.log_prob(a_t).sum(-1) - lp_t)
+    loss = -torch.min(adv_t * ratio, adv_t * ratio.clamp(0.8, 1.2)).sum()
+    want_a = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, pa)]).cpu().numpy()
+    V1, c1, V2, c2, V3, c3 = pc = f64(cparams)
+    v = (torch.tanh(torch.tanh(x @ V1.T + c1) @ V2.T + c2) @ V3.T + c3)[:, 0]
+    want_c = torch.cat([g.reshape(-1) for g in
+                        torch.autograd.grad(((v - ret_t) ** 2).sum(), pc)]).cpu().numpy()
+
+    errors = {}
+    for variant in (0, 1, 2):
+        got_a, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32),
+                              old_lp, variant)
+        got_c, Pc = critic_grad(lib, cparams, mean, std, obs, returns, variant)
+        errors[variant] = (np.abs(got_a[:P] - want_a).max() / np.abs(want_a).max(),
+                           np.abs(got_c[:Pc] - want_c).max() / np.abs(want_c).max())
+    print('max relative error vs float64 (actor, critic) per grad_variant:', errors)
+    for k in (0, 1):                                   # actor, critic
+        fp32_class = max(errors[0][k], errors[1][k])
+        assert fp32_class < 2e-6, errors
+        assert errors[2][k] <= 2.0 * fp32_class + 1e-8, errors
 
 
 def test_config5_size_properties(lib):

@@ -19,6 +19,7 @@ SIGNATURES = {
     'tonic_abi_version': (c_i32, []),
     'tonic_target_arch': (ctypes.c_char_p, []),
     'tonic_set_tuning': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
+    'tonic_get_tuning': (ctypes.c_int, [ctypes.c_char_p, c_vp]),
     'tonic_ppo_actor_param_count': (c_i64, [c_i32, c_i32]),
     'tonic_v_critic_param_count': (c_i64, [c_i32]),
     'tonic_gae_workspace_bytes': (c_i64, [c_i64, c_i64, c_i32]),

@@ -758,8 +758,10 @@ constexpr int kMaxGradBlocks = 256;   // one workgroup per CU
 // file (a two-waves-per-SIMD build spilled >100 registers and measured no faster).
 std::atomic<int> g_grad_waves{4};
 // 0 = 32x32x2 tiles, one wave per SIMD (mlp64_grad_kernel); 1 = 16x16x4 tiles, two waves per
-// SIMD (mlp64x16.hip).
-std::atomic<int> g_grad_variant{1};
+// SIMD (mlp64x16.hip); 2 = 1 with the two 64x64 hidden-layer products of a tile on bf16x3 terms
+// (six v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulation; Lds16<.., CH = 1>).
+constexpr int kDefaultGradVariant = 2;
+std::atomic<int> g_grad_variant{kDefaultGradVariant};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
@@ -853,9 +855,9 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     return TONIC_OK;
   }
   if (strcmp(key, "grad_variant") == 0) {
-    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
-                  "grad_variant must be 0 or 1, got %d", value);
-    g_grad_variant = value;
+    TONIC_REQUIRE(value >= -1 && value <= 2, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_variant must be 0, 1, 2 or -1 (default), got %d", value);
+    g_grad_variant = value < 0 ? kDefaultGradVariant : value;
     return TONIC_OK;
   }
   if (strcmp(key, "policy_tail") == 0) {
@@ -865,6 +867,17 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     return TONIC_OK;
   }
   set_error("tonic_set_tuning: unknown key '%s'", key);
+  return TONIC_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
+  TONIC_REQUIRE(key != nullptr && value != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_get_tuning: null argument");
+  if (strcmp(key, "grad_waves") == 0) { *value = g_grad_waves; return TONIC_OK; }
+  if (strcmp(key, "grad_skew") == 0) { *value = g_grad_skew; return TONIC_OK; }
+  if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
+  if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
+  set_error("tonic_get_tuning: unknown key '%s'", key);
   return TONIC_ERR_INVALID_ARGUMENT;
 }
 
@@ -1053,7 +1066,8 @@ extern "C" int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_cou
 template <bool ACTOR>
 static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coeff,
                     void* d_workspace, int64_t workspace_bytes, void* stream) {
-  const bool use16 = g_grad_variant == 1 && grad16_supported(a.O, a.A, ACTOR);
+  const int variant = g_grad_variant;
+  const bool use16 = variant >= 1 && grad16_supported(a.O, a.A, ACTOR);
   const int blocks = use16 ? grad16_blocks(a.n) : grad_blocks(a.n);
   const int64_t pstride = round_up(P + kStatSlots, 64);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= blocks * pstride * (int64_t)sizeof(float),
@@ -1064,7 +1078,7 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
   a.skew = g_grad_skew;
   const int ap = ACTOR ? ap_bucket(a.A) : 1;
   hipStream_t st = as_stream(stream);
-  const int rc = use16 ? launch_grad16(ACTOR, blocks, st, a) : dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
+  const int rc = use16 ? launch_grad16(ACTOR, blocks, st, a, variant == 2) : dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
     constexpr int KS1 = decltype(ks)::value;
     if constexpr (!ACTOR) {
       return launch_grad<KS1, 1, false>(blocks, st, a);

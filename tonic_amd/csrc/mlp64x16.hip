@@ -28,8 +28,11 @@
 
 namespace tonic {
 
-constexpr int TS16 = 24;
 constexpr int kWaves16 = 8;
+// tanh(z) = 1 - 2 / (1 + 2^(2 log2(e) z)): the forward weight / bias images of the two hidden layers
+// are staged pre-multiplied by 2 log2(e), so the exponent's argument comes straight out of the MFMA
+// chain (one multiply per hidden unit and sample less; the backward image of W2 stays unscaled).
+constexpr float kTanhScale = 2.8853900817779268f;
 
 __host__ __device__ constexpr int feat16(int q, int g) { return 16 * (q >> 2) + 4 * g + (q & 3); }
 
@@ -37,27 +40,59 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int KS1, int AP>
+// CH selects how the two 64x64 hidden-layer products of a tile (h1 -> z2 and dz2 -> dh1) run:
+//   0  fp32 MFMA (v_mfma_f32_16x16x4_f32): 64 instructions of 32 cycles per product;
+//   1  bf16x3: every fp32 operand is split EXACTLY into three bf16 terms (hi + mid + lo, 8 + 8 + 8
+//      significant bits) and the product is the sum of the six bf16 MFMAs whose terms matter at fp32
+//      precision (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped terms are below 2^-24 of
+//      |a||b|), accumulated in fp32: 48 v_mfma_f32_16x16x32_bf16 of ~18 cycles per product plus
+//      5.5 VALU instructions per activation for the split.  Weights are split once, at staging.
+template <int KS1, int AP, int CH>
 struct Lds16 {
+  static constexpr int TS = CH ? 20 : 24;                // row stride of the transpose tiles
+  static constexpr int kW2 = CH ? 6144 : 4096;           // floats per W2 image
   static constexpr int W1I = 0;                          // [4][KS1][64]       (b32 per step)
-  static constexpr int W2S = W1I + 4 * KS1 * 64;         // [4][4][64][4]      (b128 per 4 steps)
-  static constexpr int W2B = W2S + 4096;                 // [4][4][64][4]
-  static constexpr int B1P = W2B + 4096;                 // [4 groups][16]
+  static constexpr int W2S = W1I + 4 * KS1 * 64;         // CH 0: [4][4][64][4] (b128 per 4 steps)
+  static constexpr int W2B = W2S + kW2;                  // CH 1: [2][4][3 terms][64][8 bf16]
+  static constexpr int B1P = W2B + kW2;                  // [4 groups][16]
   static constexpr int B2P = B1P + 64;
   static constexpr int W3P = B2P + 64;                   // [AP][4 groups][16]
   static constexpr int HC = W3P + AP * 64;               // [8][8] head constants
   static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
   static constexpr int WAVE0 = (NORM + 8 * KS1 + 3) / 4 * 4;
-  static constexpr int T_FLOATS = 64 * TS16;
+  static constexpr int T_FLOATS = 64 * TS;
   static constexpr int DO_FLOATS = 16 * 16;
   static constexpr int WAVE_FLOATS = 2 * T_FLOATS + DO_FLOATS;
   static constexpr int TOTAL = WAVE0 + kWaves16 * WAVE_FLOATS;
   static constexpr int BYTES = TOTAL * 4;
 };
 
-template <int KS1, int AP, bool ACTOR>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// (bf16(a), bf16(b)) packed into one register, round to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// a = hi + mid + lo exactly (each residual is exact in fp32 and has at most 8 significant bits
+// more than the next term keeps); the three terms of (a, b) come packed pairwise.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid,
+                                            unsigned& lo) {
+  hi = pack_bf16(a, b);
+  a -= __uint_as_float(hi << 16);
+  b -= __uint_as_float(hi & 0xffff0000u);
+  mid = pack_bf16(a, b);
+  a -= __uint_as_float(mid << 16);
+  b -= __uint_as_float(mid & 0xffff0000u);
+  lo = pack_bf16(a, b);
+}
+
+template <int KS1, int AP, bool ACTOR, int CH>
 __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
-  using L = Lds16<KS1, AP>;
+  using L = Lds16<KS1, AP, CH>;
   const int tid = threadIdx.x, nth = kWaves16 * 64;
   const int O = a.O, A = a.A;
   const float* W1 = a.params;
@@ -72,7 +107,7 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
     const int row = gi / O, k = gi - row * O;
     const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
-    lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi];
+    lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi] * kTanhScale;
   }
   {
     // all eight W2 values of this thread are requested before the first LDS scatter (a load in a
@@ -85,22 +120,48 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
     for (int u = 0; u < kPer; ++u) {
       const int gi = tid + u * nth, row = gi >> 6, col = gi & 63;
       const float w = w2v[u];
-      {  // forward image: A row = output feature `row`, k = input feature `col`
-        const int T = row >> 4, i = row & 15;
-        const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
-        lds[L::W2S + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
-      }
-      {  // backward image: A row = input feature `col`, k = output feature `row`
-        const int T = col >> 4, i = col & 15;
-        const int st = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
-        lds[L::W2B + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+      if (CH == 0) {
+        {  // forward image: A row = output feature `row`, k = input feature `col`
+          const int T = row >> 4, i = row & 15;
+          const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
+          lds[L::W2S + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w * kTanhScale;
+        }
+        {  // backward image: A row = input feature `col`, k = output feature `row`
+          const int T = col >> 4, i = col & 15;
+          const int st = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
+          lds[L::W2B + ((T * 4 + (st >> 2)) * 64 + gg * 16 + i) * 4 + (st & 3)] = w;
+        }
+      } else {
+        // bf16x3 images: MFMA m in {0, 1} contracts the 32 features feat16(8m + e, g), e < 8 — lane
+        // (i, g) holds the 8 bf16 of one term contiguously (ds_read_b128)
+        unsigned short* fwd = reinterpret_cast<unsigned short*>(lds + L::W2S);
+        unsigned short* bwd = reinterpret_cast<unsigned short*>(lds + L::W2B);
+        unsigned hi, mid, lo;
+        {
+          const int T = row >> 4, i = row & 15;
+          const int q = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
+          const int at = ((((q >> 3) * 4 + T) * 3) * 64 + gg * 16 + i) * 8 + (q & 7);
+          split3_pair(w * kTanhScale, 0.f, hi, mid, lo);
+          fwd[at] = (unsigned short)hi;
+          fwd[at + 512] = (unsigned short)mid;
+          fwd[at + 1024] = (unsigned short)lo;
+        }
+        {
+          const int T = col >> 4, i = col & 15;
+          const int q = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
+          const int at = ((((q >> 3) * 4 + T) * 3) * 64 + gg * 16 + i) * 8 + (q & 7);
+          split3_pair(w, 0.f, hi, mid, lo);
+          bwd[at] = (unsigned short)hi;
+          bwd[at + 512] = (unsigned short)mid;
+          bwd[at + 1024] = (unsigned short)lo;
+        }
       }
     }
   }
   for (int idx = tid; idx < 64; idx += nth) {
     const int g = idx >> 4, q = idx & 15;
-    lds[L::B1P + idx] = b1[feat16(q, g)];
-    lds[L::B2P + idx] = b2[feat16(q, g)];
+    lds[L::B1P + idx] = b1[feat16(q, g)] * kTanhScale;
+    lds[L::B2P + idx] = b2[feat16(q, g)] * kTanhScale;
   }
   for (int idx = tid; idx < AP * 64; idx += nth) {
     const int aa = idx >> 6, g = (idx >> 4) & 3, q = idx & 15;
@@ -149,12 +210,12 @@ __device__ __forceinline__ float sum_groups(float v) {
 }
 
 __device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16]) {
-  // tanh(x) = 1 - 2 / (1 + e^{2x}): five instructions per element (mul, exp, add, rcp, fma)
-  // against seven for the odd-symmetric form; absolute error <= 2e-7 over the whole range
-  // (e^{2x} = inf gives exactly 1, e^{2x} = 0 exactly -1).
+  // acc = 2 log2(e) x (kTanhScale); tanh(x) = 1 - 2 / (1 + e^{2x}): four instructions per element
+  // (exp, add, rcp, fma) against seven for the odd-symmetric form; absolute error <= 2e-7 over the
+  // whole range (e^{2x} = inf gives exactly 1, e^{2x} = 0 exactly -1).
   float t[16], d[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(acc[q >> 2][q & 3] * 2.8853900817779268f);
+  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(acc[q >> 2][q & 3]);
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = __builtin_amdgcn_rcpf(1.f + t[q]);
 #pragma unroll
@@ -178,19 +239,55 @@ __device__ __forceinline__ void chain64(const float* wimg, const float (&in)[16]
   }
 }
 
+// The same product on bf16x3 terms (Lds16 CH = 1): per 32-feature block the activations are split
+// in registers, then six MFMAs per 16-row output tile, smallest terms first.
+__device__ __forceinline__ f32x4 mfma_b16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void chain64_b3(const float* wimg, const float (&in)[16], int lane,
+                                           f32x4 (&acc)[4]) {
+  const u32x4* w4 = reinterpret_cast<const u32x4*>(wimg);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned h, mi, l;
+      split3_pair(in[8 * m + 2 * p], in[8 * m + 2 * p + 1], h, mi, l);
+      bh[p] = h; bm[p] = mi; bl[p] = l;
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      const u32x4 wh = w4[((m * 4 + T) * 3 + 0) * 64 + lane];
+      const u32x4 wm = w4[((m * 4 + T) * 3 + 1) * 64 + lane];
+      const u32x4 wl = w4[((m * 4 + T) * 3 + 2) * 64 + lane];
+      acc[T] = mfma_b16(wl, bh, acc[T]);
+      acc[T] = mfma_b16(wh, bl, acc[T]);
+      acc[T] = mfma_b16(wm, bm, acc[T]);
+      acc[T] = mfma_b16(wm, bh, acc[T]);
+      acc[T] = mfma_b16(wh, bm, acc[T]);
+      acc[T] = mfma_b16(wh, bh, acc[T]);
+    }
+  }
+}
+
 __device__ __forceinline__ void load_bias16(const float* bimg, int g, f32x4 (&acc)[4]) {
   const f32x4* p = reinterpret_cast<const f32x4*>(bimg + g * 16);
 #pragma unroll
   for (int T = 0; T < 4; ++T) acc[T] = p[T];
 }
 
+template <int TS>
 __device__ __forceinline__ void scatter_S16(float* T, const float (&v)[16], int s, int g) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) T[feat16(q, g) * TS16 + s] = v[q];
+  for (int q = 0; q < 16; ++q) T[feat16(q, g) * TS + s] = v[q];
 }
 
+template <int TS>
 __device__ __forceinline__ f32x4 gather_F16(const float* T, int tile, int i, int g) {
-  return *reinterpret_cast<const f32x4*>(T + (16 * tile + i) * TS16 + 4 * g);
+  return *reinterpret_cast<const f32x4*>(T + (16 * tile + i) * TS + 4 * g);
 }
 
 // PROBE builds (developer tool, tonic_debug_grad16_phases) stamp s_memtime at phase boundaries of
@@ -211,14 +308,15 @@ __device__ __forceinline__ unsigned long long probe_clock() {
     }                                                         \
   } while (0)
 
-template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, bool PROBE = false>
+template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, int CH, bool PROBE = false>
 __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs a) {
-  using L = Lds16<KS1, AP>;
+  using L = Lds16<KS1, AP, CH>;
+  constexpr int TS16 = L::TS;
   // LDS reads of head weights kept in flight (4 registers each); the widest bucket has none to spare
   constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (a.skip != nullptr && *a.skip != 0) return;
-  stage_weights16<KS1, AP, ACTOR>(lds, a);
+  stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
   __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
@@ -344,7 +442,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       tanh16(acc, h1);
       PHASE(1);
       load_bias16(lds + L::B2P, g, acc);
-      chain64(lds + L::W2S, h1, lane, acc);
+      if (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
+      else chain64_b3(lds + L::W2S, h1, lane, acc);
       PHASE(2);
       tanh16(acc, h2);
       PHASE(3);
@@ -430,7 +529,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 
     PHASE(4);                                        // head + loss
     // ---- backward
-    scatter_S16(TA, h2, s, g);                       // h2^T for dW3
+    scatter_S16<TS16>(TA, h2, s, g);                       // h2^T for dW3
     if (g == 0) {
       f32x4 lo = zero4, hi = zero4;
 #pragma unroll
@@ -465,12 +564,13 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       }
     }
     float (&dz2)[16] = h2;
-    scatter_S16(TB, dz2, s, g);
+    scatter_S16<TS16>(TB, dz2, s, g);
     wave_lds_sync();
     PHASE(5);                                        // dz2 + scatters
 
     f32x4 dacc[4] = {zero4, zero4, zero4, zero4};
-    chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
+    if (CH == 0) chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
+    else chain64_b3(lds + L::W2B, dz2, lane, dacc);
     PHASE(6);
 
     // dW3[a][f] += dO^T . h2  (MFMA: rows = action index, padded to 16)
@@ -482,7 +582,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       for (int e = 0; e < 4; ++e) gHead = mfma16(aop[e], 1.f, gHead);
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
-        const f32x4 hF = gather_F16(TA, T, i, g);
+        const f32x4 hF = gather_F16<TS16>(TA, T, i, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gW3[T] = mfma16(aop[e], hF[e], gW3[T]);
       }
@@ -490,7 +590,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     f32x4 aF[4];
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-      aF[T] = gather_F16(TB, T, i, g);
+      aF[T] = gather_F16<TS16>(TB, T, i, g);
       gb2[T] += (aF[T][0] + aF[T][1]) + (aF[T][2] + aF[T][3]);
     }
     PHASE(7);                                        // dW3 + dz2^T gathers
@@ -498,15 +598,15 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 #pragma unroll
     for (int q = 0; q < 16; ++q) dz1[q] = dacc[q >> 2][q & 3] * fmaf(-h1[q], h1[q], 1.f);
     wave_lds_sync();
-    scatter_S16(TA, h1, s, g);
-    scatter_S16(TB, dz1, s, g);
+    scatter_S16<TS16>(TA, h1, s, g);
+    scatter_S16<TS16>(TB, dz1, s, g);
     wave_lds_sync();
     PHASE(8);                                        // dz1 + scatters
 
     // dW2[out][in] += dz2^T . h1
 #pragma unroll
     for (int Tj = 0; Tj < 4; ++Tj) {
-      const f32x4 bF = gather_F16(TA, Tj, i, g);
+      const f32x4 bF = gather_F16<TS16>(TA, Tj, i, g);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -518,7 +618,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     f32x4 cF[4];
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-      cF[T] = gather_F16(TB, T, i, g);
+      cF[T] = gather_F16<TS16>(TB, T, i, g);
       gb1[T] += (cF[T][0] + cF[T][1]) + (cF[T][2] + cF[T][3]);
     }
     wave_lds_sync();
@@ -527,7 +627,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     wave_lds_sync();
 #pragma unroll
     for (int Tj = 0; Tj < XT; ++Tj) {
-      f32x4 xF = gather_F16(TA, Tj, i, g);
+      f32x4 xF = gather_F16<TS16>(TA, Tj, i, g);
       if (16 * Tj + i >= 4 * KS1) xF = zero4;          // rows beyond the staged x hold stale data
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1187,10 +1287,11 @@ int grad16_blocks(int64_t n) {
 
 namespace {
 
-template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT>
+template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, int CH>
 int go16(int blocks, hipStream_t stream, const MlpArgs& args) {
-  auto kernel = mlp64_grad16_kernel<KS1, XT, XR, AP, ACTOR, EXACT>;
-  constexpr int lds_bytes = Lds16<KS1, AP>::BYTES;
+  auto kernel = mlp64_grad16_kernel<KS1, XT, XR, AP, ACTOR, EXACT, CH>;
+  constexpr int lds_bytes = Lds16<KS1, AP, CH>::BYTES;
+  static_assert(lds_bytes <= 160 * 1024, "mlp64_grad16: LDS budget");
   static thread_local bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -1211,21 +1312,31 @@ int go16(int blocks, hipStream_t stream, const MlpArgs& args) {
   return TONIC_OK;
 }
 
-template <int KS1, int XT, int XR>
+template <int KS1, int XT, int XR, int CH>
 int by_heads(bool actor, int blocks, hipStream_t st, const MlpArgs& a) {
-  if (!actor) return go16<KS1, XT, XR, 1, false, true>(blocks, st, a);
-  if (a.A == 1) return go16<KS1, XT, XR, 1, true, true>(blocks, st, a);
-  if (a.A == 6) return go16<KS1, XT, XR, 6, true, true>(blocks, st, a);
-  if (a.A == 8) return go16<KS1, XT, XR, 8, true, true>(blocks, st, a);
-  if (a.A < 6) return go16<KS1, XT, XR, 6, true, false>(blocks, st, a);
-  return go16<KS1, XT, XR, 8, true, false>(blocks, st, a);
+  if (!actor) return go16<KS1, XT, XR, 1, false, true, CH>(blocks, st, a);
+  if (a.A == 1) return go16<KS1, XT, XR, 1, true, true, CH>(blocks, st, a);
+  if (a.A == 6) return go16<KS1, XT, XR, 6, true, true, CH>(blocks, st, a);
+  if (a.A == 8) return go16<KS1, XT, XR, 8, true, true, CH>(blocks, st, a);
+  if (a.A < 6) return go16<KS1, XT, XR, 6, true, false, CH>(blocks, st, a);
+  return go16<KS1, XT, XR, 8, true, false, CH>(blocks, st, a);
+}
+
+template <int CH>
+int by_inputs(bool actor, int blocks, hipStream_t stream, const MlpArgs& args) {
+  // (x steps KS1 = ceil(O/4), full 16-column dW1 tiles, remainder columns)
+  if (args.O <= 4) return by_heads<1, 0, 4, CH>(actor, blocks, stream, args);
+  if (args.O <= 16) return by_heads<4, 1, 0, CH>(actor, blocks, stream, args);
+  if (args.O == 17) return by_heads<5, 1, 1, CH>(actor, blocks, stream, args);     // HalfCheetah
+  if (args.O <= 20) return by_heads<5, 1, 4, CH>(actor, blocks, stream, args);
+  return by_heads<8, 2, 0, CH>(actor, blocks, stream, args);
 }
 
 }  // namespace
 
 int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
-  auto kernel = mlp64_grad16_kernel<5, 1, 1, 6, true, true, true>;
-  constexpr int lds_bytes = Lds16<5, 6>::BYTES;
+  auto kernel = mlp64_grad16_kernel<5, 1, 1, 6, true, true, 0, true>;
+  constexpr int lds_bytes = Lds16<5, 6, 0>::BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) { set_error("probe: %s", hipGetErrorString(e)); return TONIC_ERR_LAUNCH; }
@@ -1234,13 +1345,9 @@ int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
   return TONIC_OK;
 }
 
-int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args) {
-  // (x steps KS1 = ceil(O/4), full 16-column dW1 tiles, remainder columns)
-  if (args.O <= 4) return by_heads<1, 0, 4>(actor, blocks, stream, args);
-  if (args.O <= 16) return by_heads<4, 1, 0>(actor, blocks, stream, args);
-  if (args.O == 17) return by_heads<5, 1, 1>(actor, blocks, stream, args);     // HalfCheetah
-  if (args.O <= 20) return by_heads<5, 1, 4>(actor, blocks, stream, args);
-  return by_heads<8, 2, 0>(actor, blocks, stream, args);
+int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, bool bf16x3) {
+  return bf16x3 ? by_inputs<1>(actor, blocks, stream, args)
+                : by_inputs<0>(actor, blocks, stream, args);
 }
 
 }  // namespace tonic
