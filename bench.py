@@ -67,7 +67,7 @@ def time_events(fn, repeats):
 # two 64x64 hidden-layer products of the fused grad kernels split each fp32 operand EXACTLY into three
 # bf16 terms and sum the six bf16 MFMAs that matter at fp32 precision ("bf16x3"; tests/test_gpu_parity.py
 # holds that variant to the same tolerances as the fp32-MFMA variants, tonic_set_tuning selects them).
-DTYPE = 'f32 (hidden-layer products of the grad kernels bf16x3-emulated: exact 3-term split, fp32 accumulate)'
+DTYPE = 'f32 (64x64 products of the grad kernels bf16x3-emulated: exact 3-term split, fp32 accumulate)'
 
 
 def pmc_traffic(prefix):
@@ -115,13 +115,14 @@ def kernel_rooflines(agent):
             p(wsc), wsc.numel(), stream), 'critic')
 
     # grad_variant: 0 = 32x32x2 fp32 tiles, 1 wave per SIMD; 1 = 16x16x4 fp32 tiles, 2 waves; 2 = 1 with
-    # the two 64x64 hidden-layer products on bf16x3 terms.  The roofline entry is the variant the
-    # library ships as its default (the one the timed job above ran); the others are listed beside it.
+    # the two 64x64 hidden-layer products on bf16x3 terms; 3 = 2 with dW2 on bf16x3 terms.  The roofline
+    # entry is the variant the library ships as its default (the one the timed job above ran); the
+    # others are listed beside it.
     shipped = ctypes.c_int32(-1)
     _lib.check(lib.tonic_get_tuning(b'grad_variant', ctypes.byref(shipped)), 'tuning')
     shipped = shipped.value
     out = {}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
         ws = actor._workspace_for(n)
         wsc = critic._workspace_for(n)
@@ -132,10 +133,10 @@ def kernel_rooflines(agent):
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
     arithmetic = ('fp32 MFMA throughout' if shipped < 2 else
-                  'fp32-equivalent: layer 1 and the weight-gradient products on fp32 MFMA; the two 64x64 '
-                  'hidden-layer products (41 % of the flops) as six bf16 MFMAs per product on exact '
-                  'hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak stays the fp32 '
-                  'MFMA peak: that is what the same arithmetic costs without the split')
+                  'fp32-equivalent: layer 1, dW1, dW3 on fp32 MFMA; the 64x64 products (h1->z2, dz2->dh1'
+                  + (', dW2: 77 %' if shipped == 3 else ': 52 %') + ' of the flops) as six bf16 MFMAs per '
+                  'product on exact hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak '
+                  'stays the fp32 MFMA peak: what the same arithmetic costs without the split')
     roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),

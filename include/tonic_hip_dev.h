@@ -17,11 +17,12 @@ extern "C" {
 /* Tuning knobs (process-wide atomics: a setting takes effect for launches issued after the call;
  * call before sizing workspaces).  Keys:
  *   "grad_waves" = 4       waves per workgroup of the 32x32x2-tile fused grad kernel;
- *   "grad_variant" = 0 | 1 | 2 | -1  fused grad kernel: 0 = 32x32x2 fp32 tiles, 1 wave/SIMD;
- *                          1 = 16x16x4 fp32 tiles, 2 waves/SIMD; 2 (default) = 1 with the two 64x64
+ *   "grad_variant" = 0 .. 3 | -1  fused grad kernel: 0 = 32x32x2 fp32 tiles, 1 wave/SIMD;
+ *                          1 = 16x16x4 fp32 tiles, 2 waves/SIMD; 2 = 1 with the two 64x64
  *                          hidden-layer products of a tile computed on bf16x3 terms (each fp32
  *                          operand = hi + mid + lo bf16 exactly; six bf16 MFMAs per product, fp32
- *                          accumulation: fp32-equivalent results, 2.4x less MFMA time);
+ *                          accumulation: fp32-equivalent results, 2.4x less MFMA time); 3 (default)
+ *                          = 2 with the 64x64 weight-gradient product dW2 on bf16x3 terms as well;
  *                          -1 restores the default;
  *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0);
  *   "policy_tail" = 0 | 1  off-policy actors: sampling / target noise / dense copy in the tail of

@@ -31,7 +31,7 @@ def critic_grad():
 
 
 sums = {}
-for variant in (1, 0, 2, 1, 2):
+for variant in (1, 0, 2, 3, 2, 3):
     _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
     actor._workspace_for(n), critic._workspace_for(n)
     ms_a, ms_c = bench.time_events(actor_grad, 20), bench.time_events(critic_grad, 20)
@@ -39,7 +39,7 @@ for variant in (1, 0, 2, 1, 2):
     sums[variant] = (actor.grad_sums.clone().double(), critic.grad_sums.clone().double())
     print(f'variant {variant}: actor {ms_a * 1e3:.1f} us ({bench.ACTOR_FLOP_PER_SAMPLE * n / ms_a / 1e9 / 157.3:.4f} '
           f'of the fp32 peak)  critic {ms_c * 1e3:.1f} us ({bench.CRITIC_FLOP_PER_SAMPLE * n / ms_c / 1e9 / 157.3:.4f})')
-for variant in (0, 2):
+for variant in (0, 2, 3):
     for name, got, want in zip(('actor', 'critic'), sums[variant], sums[1]):
         scale = want.abs().max()
         print(f'variant {variant} vs 1, {name}: max |diff| / max |grad| = {((got - want).abs().max() / scale).item():.3e}, '

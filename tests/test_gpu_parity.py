@@ -191,7 +191,7 @@ def assert_grads_close(got_sums, want_grads, n, what):
     assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('name', PPO_CASES)
 def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     g = golden(name)
@@ -227,7 +227,7 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_grads_ratio_clipping_branches(lib, variant):
     """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
     the still-live ones; ragged n (not a multiple of the 32-sample tile)."""
@@ -250,7 +250,7 @@ def test_grads_ratio_clipping_branches(lib, variant):
     np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_grads_full_size_properties(lib, variant):
     """BASELINE size (N = 4096 x 256): sums are additive over a split of the batch,
     bit-reproducible run to run, and agree with the oracle on a 4096-sample slice."""
@@ -318,7 +318,7 @@ def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
                         torch.autograd.grad(((v - ret_t) ** 2).sum(), pc)]).cpu().numpy()
 
     errors = {}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         got_a, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32),
                               old_lp, variant)
         got_c, Pc = critic_grad(lib, cparams, mean, std, obs, returns, variant)
@@ -328,7 +328,7 @@ def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
     for k in (0, 1):                                   # actor, critic
         fp32_class = max(errors[0][k], errors[1][k])
         assert fp32_class < 2e-6, errors
-        assert errors[2][k] <= 2.0 * fp32_class + 1e-8, errors
+        assert max(errors[2][k], errors[3][k]) <= 2.0 * fp32_class + 1e-8, errors
 
 
 def test_config5_size_properties(lib):

@@ -61,7 +61,7 @@ int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hip
 // mlp64x16.hip
 bool grad16_supported(int O, int A, bool actor);
 int grad16_blocks(int64_t n);
-int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, bool bf16x3);
+int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain);
 int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args);
 
 }  // namespace tonic

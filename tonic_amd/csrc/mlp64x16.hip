@@ -246,6 +246,23 @@ __device__ __forceinline__ f32x4 mfma_b16(const u32x4& a, const u32x4& b, f32x4 
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+__device__ __forceinline__ f32x16 mfma_b32(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// eight fp32 values (two ds_read_b128) -> their three bf16 terms, element order preserved
+__device__ __forceinline__ void split3_x8(const f32x4& a, const f32x4& b, u32x4 (&t)[3]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned h, m, l;
+    split3_pair(a[2 * p], a[2 * p + 1], h, m, l);
+    t[0][p] = h; t[1][p] = m; t[2][p] = l;
+    split3_pair(b[2 * p], b[2 * p + 1], h, m, l);
+    t[0][2 + p] = h; t[1][2 + p] = m; t[2][2 + p] = l;
+  }
+}
+
 __device__ __forceinline__ void chain64_b3(const float* wimg, const float (&in)[16], int lane,
                                            f32x4 (&acc)[4]) {
   const u32x4* w4 = reinterpret_cast<const u32x4*>(wimg);
@@ -312,6 +329,10 @@ template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, int CH, bool 
 __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs a) {
   using L = Lds16<KS1, AP, CH>;
   constexpr int TS16 = L::TS;
+  // CH 2: dW2 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 on bf16x3 terms — the 16 samples of a tile
+  // are exactly one K block; 24 MFMAs of 32 cycles instead of 64 fp32 MFMAs of 32 cycles.  Lane
+  // (feature l & 31 of a 32-feature tile, half l >> 5) contributes samples 8 half .. 8 half + 7.
+  constexpr bool W2B3 = CH == 2;
   // LDS reads of head weights kept in flight (4 registers each); the widest bucket has none to spare
   constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -338,6 +359,16 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // dW1: XT full 16-column tiles on MFMA + XR (<= 4) remainder columns on VALU (O = 17 would
   // otherwise pay a whole padded tile — 16 registers and 16 MFMAs per tile — for one column).
   f32x4 gW2[4][4], gW1[4][XT], gW3[4];
+  f32x16 gW2w[2][2];
+  float gb2w[2] = {0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gW2w[x][y][r] = 0.f;
+    }
+  }
   float gW1r[4][XR > 0 ? XR : 1];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -442,7 +473,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       tanh16(acc, h1);
       PHASE(1);
       load_bias16(lds + L::B2P, g, acc);
-      if (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
+      if constexpr (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
       else chain64_b3(lds + L::W2S, h1, lane, acc);
       PHASE(2);
       tanh16(acc, h2);
@@ -569,7 +600,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     PHASE(5);                                        // dz2 + scatters
 
     f32x4 dacc[4] = {zero4, zero4, zero4, zero4};
-    if (CH == 0) chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
+    if constexpr (CH == 0) chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
     else chain64_b3(lds + L::W2B, dz2, lane, dacc);
     PHASE(6);
 
@@ -588,10 +619,22 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       }
     }
     f32x4 aF[4];
+    u32x4 aT[2][3];
+    if constexpr (!W2B3) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      aF[T] = gather_F16<TS16>(TB, T, i, g);
-      gb2[T] += (aF[T][0] + aF[T][1]) + (aF[T][2] + aF[T][3]);
+      for (int T = 0; T < 4; ++T) {
+        aF[T] = gather_F16<TS16>(TB, T, i, g);
+        gb2[T] += (aF[T][0] + aF[T][1]) + (aF[T][2] + aF[T][3]);
+      }
+    } else {
+#pragma unroll
+      for (int Ti = 0; Ti < 2; ++Ti) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(TB + (32 * Ti + (lane & 31)) * TS16 +
+                                                          8 * (lane >> 5));
+        const f32x4 v0 = row[0], v1 = row[1];
+        gb2w[Ti] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        split3_x8(v0, v1, aT[Ti]);
+      }
     }
     PHASE(7);                                        // dW3 + dz2^T gathers
     float dz1[16];
@@ -604,13 +647,34 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     PHASE(8);                                        // dz1 + scatters
 
     // dW2[out][in] += dz2^T . h1
+    if constexpr (!W2B3) {
 #pragma unroll
-    for (int Tj = 0; Tj < 4; ++Tj) {
-      const f32x4 bF = gather_F16<TS16>(TA, Tj, i, g);
+      for (int Tj = 0; Tj < 4; ++Tj) {
+        const f32x4 bF = gather_F16<TS16>(TA, Tj, i, g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int Ti = 0; Ti < 4; ++Ti) gW2[Ti][Tj] = mfma16(aF[Ti][e], bF[e], gW2[Ti][Tj]);
+          for (int Ti = 0; Ti < 4; ++Ti) gW2[Ti][Tj] = mfma16(aF[Ti][e], bF[e], gW2[Ti][Tj]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int Tj = 0; Tj < 2; ++Tj) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(TA + (32 * Tj + (lane & 31)) * TS16 +
+                                                          8 * (lane >> 5));
+        u32x4 bT[3];
+        split3_x8(row[0], row[1], bT);
+#pragma unroll
+        for (int Ti = 0; Ti < 2; ++Ti) {
+          f32x16 acc = gW2w[Ti][Tj];
+          acc = mfma_b32(aT[Ti][2], bT[0], acc);
+          acc = mfma_b32(aT[Ti][0], bT[2], acc);
+          acc = mfma_b32(aT[Ti][1], bT[1], acc);
+          acc = mfma_b32(aT[Ti][1], bT[0], acc);
+          acc = mfma_b32(aT[Ti][0], bT[1], acc);
+          acc = mfma_b32(aT[Ti][0], bT[0], acc);
+          gW2w[Ti][Tj] = acc;
+        }
       }
     }
     PHASE(9);                                        // dW2
@@ -676,14 +740,20 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * Ti + 4 * g + r;
+          if constexpr (!W2B3) {
 #pragma unroll
-          for (int Tj = 0; Tj < 4; ++Tj) IMG[oW2 + row * 64 + 16 * Tj + s] = gW2[Ti][Tj][r];
+            for (int Tj = 0; Tj < 4; ++Tj) IMG[oW2 + row * 64 + 16 * Tj + s] = gW2[Ti][Tj][r];
+          }
 #pragma unroll
           for (int Tj = 0; Tj < XT; ++Tj)
             if (16 * Tj + s < O) IMG[oW1 + row * O + 16 * Tj + s] = gW1[Ti][Tj][r];
         }
-        const float v1 = sum_groups(gb1[Ti]), v2 = sum_groups(gb2[Ti]);
-        if (g == 0) { IMG[ob1 + 16 * Ti + i] = v1; IMG[ob2 + 16 * Ti + i] = v2; }
+        const float v1 = sum_groups(gb1[Ti]);
+        if (g == 0) IMG[ob1 + 16 * Ti + i] = v1;
+        if constexpr (!W2B3) {
+          const float v2 = sum_groups(gb2[Ti]);
+          if (g == 0) IMG[ob2 + 16 * Ti + i] = v2;
+        }
 #pragma unroll
         for (int c = 0; c < XR; ++c) {                  // lane (i, g): feature 16*Ti + i, 4 samples
           const float vr = sum_groups(gW1r[Ti][c]);
@@ -693,6 +763,24 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
         for (int r = 0; r < 4; ++r) {
           const int aa = 4 * g + r;                    // gW3[T] rows are action indices
           if (aa < nout) IMG[oW3 + aa * 64 + 16 * Ti + s] = gW3[Ti][r];
+        }
+      }
+      if constexpr (W2B3) {
+        // 32x32 tiles: lane l, register r -> row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
+#pragma unroll
+        for (int Ti = 0; Ti < 2; ++Ti) {
+#pragma unroll
+          for (int Tj = 0; Tj < 2; ++Tj) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = 32 * Ti + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+              IMG[oW2 + row * 64 + 32 * Tj + (lane & 31)] = gW2w[Ti][Tj][r];
+            }
+          }
+          const unsigned bits = __float_as_uint(gb2w[Ti]);
+          auto halves = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+          const float v2 = __uint_as_float(halves[0]) + __uint_as_float(halves[1]);
+          if (lane < 32) IMG[ob2 + 32 * Ti + lane] = v2;
         }
       }
       // gHead rows: lane (j, g), reg r -> row 4g + r (every column j holds the same sum)
@@ -1345,9 +1433,10 @@ int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
   return TONIC_OK;
 }
 
-int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, bool bf16x3) {
-  return bf16x3 ? by_inputs<1>(actor, blocks, stream, args)
-                : by_inputs<0>(actor, blocks, stream, args);
+int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
+  if (chain == 2) return by_inputs<2>(actor, blocks, stream, args);
+  return chain == 1 ? by_inputs<1>(actor, blocks, stream, args)
+                    : by_inputs<0>(actor, blocks, stream, args);
 }
 
 }  // namespace tonic
