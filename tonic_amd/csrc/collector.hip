@@ -363,7 +363,7 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
         const double n = t[r * 8 + 7] > 0 ? (double)t[r * 8 + 7] : 1.0;
         fprintf(stderr, "collector stamps, %s (us after the command was seen, %llu steps):", role[r],
                 t[r * 8 + 7]);
-        for (int p = 0; p < 5; ++p) fprintf(stderr, " %.2f", t[r * 8 + p] / n / 100.0);
+        for (int p = 0; p < 7; ++p) fprintf(stderr, " %.2f", t[r * 8 + p] / n / 100.0);
         fprintf(stderr, "\n");
       }
     }

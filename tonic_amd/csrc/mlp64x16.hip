@@ -887,8 +887,12 @@ __device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
 
 __device__ __forceinline__ void collect_stamp(const Collect16Args& c, int role, int phase) {
   if (c.stamps != nullptr && threadIdx.x == 0) {
-    c.stamps[role * 8 + phase] += wall_clock64() - c.stamp_t0;
-    if (phase == 0) c.stamps[role * 8 + 7] += 1;
+    // (no-return atomics: a read-modify-write would park the wave for an L2 round trip per stamp)
+    __hip_atomic_fetch_add(c.stamps + role * 8 + phase, wall_clock64() - c.stamp_t0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (phase == 0)
+      __hip_atomic_fetch_add(c.stamps + role * 8 + 7, 1ull, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1237,6 +1241,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[e] = tanh_fast(even[e] + odd[e]);
+    if (blockIdx.x == 0) collect_stamp(c, 0, 2);     // layer 2 done
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       float part = 0.f;
@@ -1246,45 +1251,60 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       if (g == 0) ZP[(wave * AP + aa) * 16 + s] = part;
     }
     __syncthreads();
+    if (blockIdx.x == 0) collect_stamp(c, 0, 3);     // head partials exchanged
     if (wave == 0) {
+      // Three straight-line stages — all LDS reads, then the AP independent head chains, then the
+      // stores under ONE branch.  (Stores inside the per-action loop made every action its own
+      // exec-masked block: read -> wait -> tanh chain -> store, six times in a row, 1.4 us of
+      // the step's 5.8 us on the one wave everybody waits for.)
+      float zp[AP][4], actv[AP];
+#pragma unroll
+      for (int aa = 0; aa < AP; ++aa) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) zp[aa][w] = ZP[(w * AP + aa) * 16 + s];
+      }
       float logp = 0.f;
 #pragma unroll
       for (int aa = 0; aa < AP; ++aa) {
-        const float z = (ZP[aa * 16 + s] + ZP[(AP + aa) * 16 + s]) +
-                        (ZP[(2 * AP + aa) * 16 + s] + ZP[(3 * AP + aa) * 16 + s]);
+        const float z = (zp[aa][0] + zp[aa][1]) + (zp[aa][2] + zp[aa][3]);
         const f32x4 hc = hcA[aa];
         const float loc = tanh_fast(z + hc[0]);
-        const float act = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
-        const float d = act - loc;
+        actv[aa] = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
+        const float d = actv[aa] - loc;
         logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
-        if (valid && g == 0 && aa < A) {
-          c.seg_act[(c.row * W + ns) * A + aa] = act;
-          if (c.actions_out != nullptr) {
+      }
+      if (valid && g == 0) {
+#pragma unroll
+        for (int aa = 0; aa < AP; ++aa) {
+          if (aa < A) {
+            c.seg_act[(c.row * W + ns) * A + aa] = actv[aa];
+            if (c.actions_out != nullptr) {
 #if TONIC_COLLECT_SC1
-            if constexpr (HOST)
-              __hip_atomic_store(c.actions_out + ns * A + aa, act, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM);
-            else
+              if constexpr (HOST)
+                __hip_atomic_store(c.actions_out + ns * A + aa, actv[aa], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+              else
 #endif
-              c.actions_out[ns * A + aa] = act;
+                c.actions_out[ns * A + aa] = actv[aa];
+            }
           }
         }
+        c.seg_lp[c.row * W + ns] = logp;
       }
-      if (valid && g == 0) c.seg_lp[c.row * W + ns] = logp;
       // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
       // only then may the completion word go out (scripts/collector_stress.py: without the
       // fence the host reads stale actions within a few thousand steps).
-      if (blockIdx.x == 0) collect_stamp(c, 0, 2);   // head, sample, stores issued
+      if (blockIdx.x == 0) collect_stamp(c, 0, 4);   // head, sample, stores issued
 #if !TONIC_COLLECT_SC1
       if constexpr (HOST) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 #endif
-      if (blockIdx.x == 0) collect_stamp(c, 0, 3);   // released
+      if (blockIdx.x == 0) collect_stamp(c, 0, 5);   // released
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
   retire_touches(eps_sink, c.seg_lp);
   collect_signal_done(c);
-  if (blockIdx.x == 0) collect_stamp(c, 0, 4);       // flag out
+  if (blockIdx.x == 0) collect_stamp(c, 0, 6);       // flag out
 }
 
 // One launch per environment step.
