@@ -485,6 +485,9 @@ def main():
             elif name == 'a2c_small':
                 run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6,
                         updates=2, algorithm='A2C', entropy_coeff=0.01)
+            elif name == 'trpo_small':
+                run_ppo(tonic, 'trpo_small', 17, 6, workers=8, steps=24, seed=13, iterations=6,
+                        updates=2, algorithm='TRPO', reward_scale=2.0)
             elif name == 'ppo_ant_wide':
                 run_ppo(tonic, 'ppo_ant_wide', 111, 8, workers=6, steps=16, seed=11, iterations=8,
                         updates=1)
@@ -526,6 +529,9 @@ def main():
     # A2C (StochasticPolicyGradient with an entropy bonus): one actor step + 6 critic steps
     run_ppo(tonic, 'a2c_small', 17, 6, workers=8, steps=24, seed=9, iterations=6, updates=2,
             algorithm='A2C', entropy_coeff=0.01)
+    # TRPO (trpo.py:7-97, actors.py:115-156, optimizers.py:25-115): conjugate gradient + backtracking
+    run_ppo(tonic, 'trpo_small', 17, 6, workers=8, steps=24, seed=13, iterations=6, updates=2,
+            algorithm='TRPO', reward_scale=2.0)
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)

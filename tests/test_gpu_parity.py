@@ -740,6 +740,37 @@ def test_trainer_runs_ppo_end_to_end_and_checkpoints_interchange(lib, tmp_path):
     assert torch.equal(flat[:first.numel()], first)
 
 
+@pytest.mark.parametrize('name,keys', [
+    ('TRPO', ('actor/loss', 'actor/kl', 'actor/backtrack_steps', 'critic/loss', 'critic/v',
+              'critic/iterations')),
+    ('A2C', ('actor/loss', 'actor/kl', 'actor/entropy', 'actor/std', 'critic/loss', 'critic/v'))])
+def test_trainer_runs_the_other_on_policy_agents(lib, tmp_path, name, keys):
+    """A2C (a2c.py) and TRPO (trpo.py) through the same collector / Segment / Trainer path as PPO:
+    updates happen, the parameters stay finite and the reference's log keys appear."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments, logger
+    logger.initialize(path=str(tmp_path))
+    env = environments.distribute(lambda: environments.Synthetic(5, 2, max_episode_steps=7), 1, 4)
+    env.initialize(seed=0)
+    agent = getattr(tonic_amd.torch.agents, name)(
+        replay=tonic_amd.replays.Segment(size=16, batch_iterations=3))
+    agent.initialize(env.observation_space, env.action_space, seed=3)
+    before = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+    trainer = tonic_amd.Trainer(steps=160, epoch_steps=80, save_steps=160, show_progress=False)
+    trainer.initialize(agent, env)
+    trainer.run()
+    header = open(tmp_path / 'log.csv').read().split('\n')[0].split(',')
+    for key in keys:
+        assert any(h == key or h.startswith(key + '/') for h in header), key
+    after = agent.model.state_dict()
+    assert all(torch.isfinite(v).all() for v in after.values())
+    assert not torch.equal(after['actor.torso.model.0.weight'].cpu(),
+                           before['actor.torso.model.0.weight'])
+    assert not torch.equal(after['critic.torso.model.0.weight'].cpu(),
+                           before['critic.torso.model.0.weight'])
+
+
 def test_two_whole_iterations_at_baseline_size_vs_oracle(lib):
     """BASELINE cfg 2 at FULL size (T=4096 x W=256, N = 1 048 576): evaluate + GAE + two whole
     PPO iterations (actor grad -> reduce -> Adam, critic grad -> reduce -> Adam, twice) through
@@ -943,6 +974,58 @@ def test_a2c_update_matches_reference(golden, lib):
                 continue
             got = after[key].detach().cpu().numpy() - start
             np.testing.assert_allclose(got, g[f'post{u}/' + key] - start, rtol=0, atol=1e-5,
+                                       err_msg=f'update {u}: {key}')
+
+
+def test_trpo_update_matches_reference(golden, monkeypatch):
+    """TRPO (trpo.py:7-97): evaluation, lambda-returns and the critic regression on the HIP engine,
+    the actor step — conjugate gradient over autograd Fisher-vector products, backtracking line
+    search (actors.py:115-156, optimizers.py:25-115) — as stock torch on the device, against two
+    consecutive updates of the reference's TRPO agent.  The behaviour policy's locs / scales are
+    recomputed from the stored observations instead of being stored per step."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    from tonic_amd.torch import agents as agents_module
+    g = golden('trpo_small')
+    O, A, W, steps, seed, iterations, updates = (int(x) for x in g['cfg'])
+    agent = tt.agents.TRPO(replay=tonic_amd.replays.Segment(size=steps, batch_iterations=iterations))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    records = {}
+    monkeypatch.setattr(agents_module.logger, 'store',
+                        lambda key, value, stats=False: records.setdefault(key, []).append(
+                            np.asarray(value)))
+    # (the segment is filled without recording; the normaliser statistics come from the golden)
+    monkeypatch.setattr(agent.model.observation_normalizer, 'update', lambda: None)
+    for u in range(updates):
+        state = {k[len(f'pre{u}/'):]: torch.as_tensor(g[k]) for k in g.files
+                 if k.startswith(f'pre{u}/')}
+        if u == 0:
+            agent.model.load_state_dict(state)
+        else:
+            for key in ('observation_normalizer._mean', 'observation_normalizer._std'):
+                dict(agent.model.state_dict())[key].copy_(state[key])
+        before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+        agent.replay.index = 0
+        _fill_segment(agent, g, u)
+        records.clear()
+        agent._update()
+        for key in ('loss', 'kl'):
+            np.testing.assert_allclose(records['actor/' + key][0], g[f'u{u}/info/actor/{key}'][0],
+                                       rtol=2e-4, atol=1e-6, err_msg=key)
+        assert int(records['actor/backtrack_steps'][0]) == int(g[f'u{u}/info/actor/backtrack_steps'][0])
+        np.testing.assert_allclose(np.array(records['critic/loss']), g[f'u{u}/info/critic/loss'],
+                                   rtol=1e-5, atol=1e-5)
+        assert int(records['critic/iterations'][0]) == int(g[f'u{u}/info/critic/iterations'][0])
+        after = agent.model.state_dict()
+        for key, start in before.items():
+            if 'normalizer' in key:
+                continue
+            got = after[key].detach().cpu().numpy() - start
+            want = g[f'post{u}/' + key] - start
+            # ten conjugate-gradient iterations in float32 amplify rounding differences between
+            # the device's and NumPy's dot products: 1e-3 of the step, not 1e-5 of the parameter
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 + 2e-3 * np.abs(want).max(),
                                        err_msg=f'update {u}: {key}')
 
 

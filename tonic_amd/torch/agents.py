@@ -360,6 +360,40 @@ class A2C(Agent):
             self.model.observation_normalizer.update()
 
 
+class TRPO(A2C):
+    """tonic/torch/agents/trpo.py:7-97.  Acting, storing, evaluation, lambda-returns and the
+    critic regression are the A2C / PPO machinery (fused collector, HBM-resident Segment, HIP
+    kernels); the actor step is TrustRegionPolicyGradient (stock-torch autograd on the device,
+    SURVEY.md §8(f4)).  The behaviour policy's locs / scales are not stored per step
+    (trpo.py:27-28,41-43): the parameters are those of the rollout until this update moves them,
+    so the updater recomputes them from the stored observations."""
+
+    def __init__(self, model=None, replay=None, actor_updater=None, critic_updater=None):
+        super().__init__(model=model, replay=replay,
+                         actor_updater=actor_updater or updaters.TrustRegionPolicyGradient(),
+                         critic_updater=critic_updater)
+
+    def _update(self):
+        replay, critic = self.replay, self.critic_updater
+        values, next_values = self._evaluate()
+        replay.compute_returns(values, next_values)
+        batch = replay.get_full('observations', 'actions', 'log_probs', 'advantages')
+        for key, value in self.actor_updater(**batch).items():
+            logger.store('actor/' + key, value.numpy())
+        updates = replay.updates_per_get()
+        infos = torch.zeros(updates, updaters.INFO_WIDTH, device=self.device)
+        for it, (obs, _, _, _, returns) in enumerate(replay.learner_batches()):
+            critic.enqueue(obs, returns, infos[it])
+        infos = infos.cpu().numpy()
+        for row in infos:
+            logger.store('critic/loss', row[0])
+            logger.store('critic/v', row[1])
+        logger.store('critic/iterations', updates)
+        self.last_infos = infos
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.update()
+
+
 class PPO(A2C):
     """tonic/torch/agents/ppo.py:7-67."""
 

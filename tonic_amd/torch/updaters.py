@@ -215,6 +215,135 @@ class StochasticPolicyGradient(ClippedRatio):
         return {k: out[k] for k in ('loss', 'kl', 'entropy', 'std')}
 
 
+class ConjugateGradient:
+    """optimizers.py:25-115 — truncated natural gradient with a backtracking line search, on the
+    device: the search direction solves H x = g by `conjugate_gradient_steps` CG iterations whose
+    Hessian-vector products are autograd double-backward passes of the constraint (KL) over the
+    HBM-resident batch; then x is scaled to the trust region and shrunk until the constraint holds
+    and the loss did not rise.  The CG scalars stay 0-dim device tensors (no host sync inside the
+    loop); each backtracking trial reads two scalars back, like the reference."""
+
+    def __init__(self, conjugate_gradient_steps=10, damping_coefficient=0.1,
+                 constraint_threshold=0.01, backtrack_steps=10, backtrack_coefficient=0.8):
+        self.conjugate_gradient_steps = conjugate_gradient_steps
+        self.damping_coefficient = damping_coefficient
+        self.constraint_threshold = constraint_threshold
+        self.backtrack_steps = backtrack_steps
+        self.backtrack_coefficient = backtrack_coefficient
+
+    def optimize(self, loss_function, constraint_function, variables):
+        eps = 1e-8                                              # optimizers.py:5
+
+        def flat(tensors):
+            return torch.cat([t.reshape(-1) for t in tensors])
+
+        def hessian_vector(x):                                  # optimizers.py:36-48
+            first = flat(torch.autograd.grad(constraint_function(), variables, create_graph=True))
+            second = flat(torch.autograd.grad((first * x).sum(), variables))
+            if self.damping_coefficient > 0:
+                second = second + self.damping_coefficient * x
+            return second
+
+        def assign(values):                                     # optimizers.py:13-22
+            offset = 0
+            with torch.no_grad():
+                for v in variables:
+                    v.copy_(values[offset:offset + v.numel()].view(v.shape))
+                    offset += v.numel()
+
+        def trial(scale):                                       # optimizers.py:68-74
+            assign(start - alpha * direction * scale)
+            with torch.no_grad():
+                return constraint_function(), loss_function()
+
+        start = flat([v.detach() for v in variables]).clone()
+        loss = loss_function()
+        gradient = flat(torch.autograd.grad(loss, variables))
+        start_loss = float(loss.detach())
+        zero = torch.zeros((), dtype=torch.float32)
+        residual_dot = gradient.dot(gradient)
+        if float(residual_dot) == 0:                            # optimizers.py:55-56, 87-91
+            return zero, zero, torch.as_tensor(0, dtype=torch.int32)
+        direction = torch.zeros_like(gradient)
+        residual, search = gradient.clone(), gradient.clone()
+        for _ in range(self.conjugate_gradient_steps):          # optimizers.py:58-65
+            z = hessian_vector(search)
+            step = residual_dot / (search.dot(z) + eps)
+            direction += step * search
+            residual -= step * z
+            new_dot = residual.dot(residual)
+            search = residual + (new_dot / residual_dot) * search
+            residual_dot = new_dot
+        alpha = torch.sqrt(2 * self.constraint_threshold /
+                           direction.dot(hessian_vector(direction)) + eps)      # optimizers.py:93-94
+        if self.backtrack_steps is None or self.backtrack_coefficient is None:
+            constraint, loss = trial(1)
+            return constraint.cpu(), loss.cpu()
+        for i in range(self.backtrack_steps):                   # optimizers.py:101-113
+            constraint, loss = trial(self.backtrack_coefficient ** i)
+            if float(constraint) <= self.constraint_threshold and float(loss) <= start_loss:
+                break
+            if i == self.backtrack_steps - 1:
+                constraint, loss = trial(0)
+                i = self.backtrack_steps
+        return constraint.cpu(), loss.cpu(), torch.as_tensor(i + 1, dtype=torch.int32)
+
+
+class TrustRegionPolicyGradient:
+    """actors.py:115-156 (TRPO).  The one updater of this package that is not a fused HIP kernel:
+    SURVEY.md §8(f4) scopes A2C / TRPO as the stock-torch path — the loss, the KL and the
+    Fisher-vector products are PyTorch autograd over `model.actor`, whose parameters ARE views of
+    the flat HBM buffer the act kernels read, on the HBM-resident Segment (no host copy of the
+    batch).  `locs` / `scales` of the behaviour policy may be omitted: the parameters have not
+    moved since the rollout, so the actor itself reproduces them."""
+
+    def __init__(self, optimizer=None, entropy_coeff=0):
+        self.optimizer = optimizer or ConjugateGradient()
+        self.entropy_coeff = entropy_coeff
+
+    def initialize(self, model):
+        self.model = model
+        self.variables = list(model.flat_actor.params)
+        self.world_size = 1
+
+    def __call__(self, observations, actions, log_probs, advantages, locs=None, scales=None):
+        from tonic_amd import parallel
+        if parallel.exchanging():
+            raise NotImplementedError('TrustRegionPolicyGradient runs on one rank')
+        device = self.variables[0].device
+        observations, actions, log_probs, advantages = (
+            torch.as_tensor(v, dtype=torch.float32, device=device)
+            for v in (observations, actions, log_probs, advantages))
+        if locs is None or scales is None:
+            with torch.no_grad():
+                behaviour = self.model.actor(observations)
+                locs, scales = behaviour.loc, behaviour.stddev
+        else:
+            locs, scales = (torch.as_tensor(v, dtype=torch.float32, device=device)
+                            for v in (locs, scales))
+        if bool((advantages == 0.).all()):                     # actors.py:127-130
+            zero = torch.zeros((), dtype=torch.float32)
+            return dict(loss=zero, kl=zero, backtrack_steps=torch.as_tensor(0, dtype=torch.int32))
+        kl, loss, steps = self.optimizer.optimize(
+            loss_function=lambda: self._loss(observations, actions, log_probs, advantages),
+            constraint_function=lambda: self._kl(observations, locs, scales),
+            variables=self.variables)
+        return dict(loss=loss, kl=kl, backtrack_steps=steps)
+
+    def _loss(self, observations, actions, old_log_probs, advantages):        # actors.py:142-150
+        distributions = self.model.actor(observations)
+        log_probs = distributions.log_prob(actions).sum(dim=-1)
+        loss = -(torch.exp(log_probs - old_log_probs) * advantages).mean()
+        if self.entropy_coeff != 0:
+            loss = loss - self.entropy_coeff * distributions.entropy().mean()
+        return loss
+
+    def _kl(self, observations, locs, scales):                                # actors.py:152-156
+        distributions = self.model.actor(observations)
+        behaviour = type(distributions)(locs, scales)
+        return torch.distributions.kl.kl_divergence(distributions, behaviour).mean()
+
+
 class VRegression(_FlatUpdater):
     stats_kind = 2
 
