@@ -48,7 +48,8 @@ typedef enum tonic_status {
 /* ---- library ------------------------------------------------------------------------ */
 const char* tonic_last_error(void);
 /* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks,
- * 3 = pinned-host collector, gradient / normaliser clipping) and the gfx target the kernels were built for. */
+ * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries)
+ * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -507,6 +508,37 @@ int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d
                        const float* d_observations, const float* d_eps, float* d_grad_sums,
                        int32_t B, int32_t O, int32_t H, int32_t A, double entropy_coeff,
                        void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- D4PG: distributional critic (tonic/torch/models/critics.py:23-66, agents/d4pg.py).
+ *   The critic is an actor-shaped network on the encoded input [normalised observation | action]:
+ *   parameters in the layout of tonic_mlp_actor_param_count(O + A, H, NA, 1) — W1 [H, O + A], b1,
+ *   W2, b2, distributional_layer [NA, H], bias [NA]; 2 <= NA <= 64 atoms; d_values = the support
+ *   (DistributionalValueHead.values, float32 [NA], ascending).
+ *
+ * tonic_distributional_q_grad — DistributionalDeterministicQLearning.__call__ (updaters/critics.py:
+ *   100-122) up to the optimizer step: a' = target_actor(s'), the target critic's distribution at
+ *   (s', a') projected onto the support at r + discount * z (CategoricalWithSupport.project,
+ *   critics.py:32-46), cross-entropy against log_softmax of the online critic's logits at (s, a).
+ *   Output: gradient SUMS of the critic + 8 statistics {loss_sum, 0, 0, 0, 0, B, 0, 0}.
+ * tonic_distributional_actor_grad — DistributionalDeterministicPolicyGradient.__call__
+ *   (updaters/actors.py:203-224): loss = -mean(sum_i softmax(critic(s, actor(s)))_i z_i), critic
+ *   frozen.  Output: gradient SUMS of the actor + the same 8 statistics. */
+int64_t tonic_distributional_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H, int32_t NA);
+int tonic_distributional_q_grad(const float* d_target_actor, const float* d_target_critic,
+                                const float* d_critic, const float* d_norm_mean,
+                                const float* d_norm_std, double norm_clip,
+                                const float* d_observations, const float* d_actions,
+                                const float* d_next_observations, const float* d_rewards,
+                                const float* d_discounts, const float* d_values,
+                                float* d_grad_sums, int32_t B, int32_t O, int32_t H, int32_t A,
+                                int32_t NA, void* d_workspace, int64_t workspace_bytes,
+                                void* stream);
+int tonic_distributional_actor_grad(const float* d_actor_params, const float* d_critic,
+                                    const float* d_norm_mean, const float* d_norm_std,
+                                    double norm_clip, const float* d_observations,
+                                    const float* d_values, float* d_grad_sums, int32_t B,
+                                    int32_t O, int32_t H, int32_t A, int32_t NA,
+                                    void* d_workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -360,7 +360,7 @@ def first_update_probes(tonic, builder, seed, seg, iterations):
 
 
 def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32, batch=24,
-                  iterations=6, seed=0, loop_steps=16):
+                  iterations=6, seed=0, loop_steps=16, atoms=(-6.0, 6.0, 21), return_steps=1):
     """tonic/torch/agents/{ddpg.py:45-112, td3.py:38-55, sac.py:40-51} driven through the
     reference agent on a synthetic env (small custom torso so the fixture stays small).  The
     first learner update is captured completely: buffer contents, the index stream of
@@ -373,27 +373,31 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
         return rl.SyntheticEnvironment(obs_dim, act_dim, max_episode_steps=5)
     env = tonic.environments.distribute(builder, 1, workers)
     env.initialize(seed=seed)
+    critic_head = (models.DistributionalValueHead(*atoms) if kind == 'd4pg'     # d4pg.py:15-17
+                   else models.ValueHead())
     critic = models.Critic(encoder=models.ObservationActionEncoder(),
-                           torso=models.MLP((hidden, hidden), relu), head=models.ValueHead())
+                           torso=models.MLP((hidden, hidden), relu), head=critic_head)
     if kind == 'sac':
         head = models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                          distribution=models.SquashedMultivariateNormalDiag)
     else:
         head = models.DeterministicPolicyHead()
-    container = (models.ActorCriticWithTargets if kind == 'ddpg'
+    container = (models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg')
                  else models.ActorTwinCriticWithTargets)
     model = container(
         actor=models.Actor(encoder=models.ObservationEncoder(),
                            torso=models.MLP((hidden, hidden), relu), head=head),
         critic=critic, observation_normalizer=tonic.torch.normalizers.MeanStd())
     replay = tonic.replays.Buffer(size=400, batch_iterations=iterations, batch_size=batch,
-                                  steps_before_batches=workers * 10, steps_between_batches=workers * 10)
+                                  steps_before_batches=workers * 10, steps_between_batches=workers * 10,
+                                  return_steps=return_steps)
     if kind == 'sac':
         agent = tonic.torch.agents.SAC(
             model=model, replay=replay,
             exploration=tonic.explorations.NoActionNoise(start_steps=workers * 5))
     else:
-        cls = tonic.torch.agents.DDPG if kind == 'ddpg' else tonic.torch.agents.TD3
+        cls = {'ddpg': tonic.torch.agents.DDPG, 'd4pg': tonic.torch.agents.D4PG,
+               'td3': tonic.torch.agents.TD3}[kind]
         agent = cls(
             model=model, replay=replay,
             exploration=tonic.explorations.NormalActionNoise(start_steps=workers * 5))
@@ -465,6 +469,8 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
     out['buffer_size'] = np.int64(captured['size'])
     out['cfg'] = np.array([obs_dim, act_dim, workers, hidden, batch, iterations, seed,
                            loop_steps], np.int64)
+    out['atoms'] = np.array(atoms, np.float64)
+    out['return_steps'] = np.int64(return_steps)
     save(name, source='tonic/torch/agents/ddpg.py:45-112; td3.py:38-55; sac.py:40-51; '
                       'updaters/critics.py:125-235; updaters/actors.py:159-267; '
                       'replays/buffers.py:28-91', **out)
@@ -475,7 +481,10 @@ def main():
     tonic = rl.load_reference()
     if len(sys.argv) > 1:                    # regenerate only the named goldens
         for name in sys.argv[1:]:
-            if name == 'ddpg_small':
+            if name == 'd4pg_small':
+                run_offpolicy(tonic, 'd4pg_small', 'd4pg', obs_dim=8, act_dim=3, workers=3,
+                              batch=20, seed=7, return_steps=3)
+            elif name == 'ddpg_small':
                 run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2,
                               batch=16, seed=5)
             elif name == 'ppo_clipped_small':
@@ -535,6 +544,9 @@ def main():
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)
+    # D4PG (d4pg.py:21-37): 21-atom distributional critic, 3-step returns
+    run_offpolicy(tonic, 'd4pg_small', 'd4pg', obs_dim=8, act_dim=3, workers=3, batch=20, seed=7,
+                  return_steps=3)
 
 
 if __name__ == '__main__':

@@ -139,9 +139,24 @@ ACTOR_KEYS = {'sac': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model
               'td3': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
                       'torso.model.2.bias', 'head.action_layer.0.weight',
                       'head.action_layer.0.bias')}
-ACTOR_KEYS['ddpg'] = ACTOR_KEYS['td3']
+ACTOR_KEYS['ddpg'] = ACTOR_KEYS['d4pg'] = ACTOR_KEYS['td3']
 CRITIC_KEYS = ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
                'torso.model.2.bias', 'head.v_layer.weight', 'head.v_layer.bias')
+DISTRIBUTIONAL_CRITIC_KEYS = CRITIC_KEYS[:4] + ('head.distributional_layer.weight',
+                                                'head.distributional_layer.bias')
+
+
+def project_onto_support(values, probabilities, returns):
+    """``CategoricalWithSupport.project`` (tonic/torch/models/critics.py:32-46): the mass of atom j,
+    moved to returns[:, j], is shared between the two support points around it (everything outside
+    the support goes to the end points)."""
+    vmin, vmax = values[0], values[-1]
+    to_next = (torch.cat([values, vmin[None]], 0)[1:] - values)[None, :, None]
+    to_previous = (values - torch.cat([vmax[None], values], 0)[:-1])[None, :, None]
+    delta = torch.clamp(returns, vmin, vmax)[:, None] - values[None, :, None]
+    right = (delta >= 0).float()
+    distance = (right * delta / to_next) - ((1 - right) * delta / to_previous)
+    return (torch.clamp(1 - distance, 0, 1) * probabilities[:, None]).sum(dim=2)
 
 
 class OffPolicyPort:
@@ -152,17 +167,24 @@ class OffPolicyPort:
     ``models/actor_critics.py:126-130`` (polyak), ``tonic/replays/buffers.py:84-91`` (gather)
     and the iteration schedule of ``agents/ddpg.py:105-112`` / ``td3.py:38-47``."""
 
-    def __init__(self, kind, state, prefix, delay_steps=2, entropy_coeff=0.2, target_coeff=0.005):
+    def __init__(self, kind, state, prefix, delay_steps=2, entropy_coeff=0.2, target_coeff=0.005,
+                 atoms=None):
+        """kind 'd4pg' (agents/d4pg.py, critics.py:89-122, actors.py:192-224): `atoms` =
+        (vmin, vmax, count) of the DistributionalValueHead (models/critics.py:49-66)."""
         self.kind, self.delay, self.alpha, self.tau = kind, delay_steps, entropy_coeff, target_coeff
+        critic_keys = DISTRIBUTIONAL_CRITIC_KEYS if kind == 'd4pg' else CRITIC_KEYS
+        self.critic_keys = critic_keys
+        if kind == 'd4pg':
+            self.values = torch.linspace(float(atoms[0]), float(atoms[1]), int(atoms[2])).float()
 
         def grab(net, keys, grad):
             return [torch.tensor(state[f'{prefix}{net}.{k}'], requires_grad=grad) for k in keys]
         # DDPG (agents/ddpg.py, critics.py:56-86): ONE critic named `critic` / `target_critic`
-        self.critic_names = ('critic',) if kind == 'ddpg' else ('critic_1', 'critic_2')
+        self.critic_names = ('critic',) if kind in ('ddpg', 'd4pg') else ('critic_1', 'critic_2')
         self.actor = grab('actor', ACTOR_KEYS[kind], True)
-        self.critics = [grab(n, CRITIC_KEYS, True) for n in self.critic_names]
+        self.critics = [grab(n, critic_keys, True) for n in self.critic_names]
         self.target_actor = grab('target_actor', ACTOR_KEYS[kind], False)
-        self.target_critics = [grab('target_' + n, CRITIC_KEYS, False) for n in self.critic_names]
+        self.target_critics = [grab('target_' + n, critic_keys, False) for n in self.critic_names]
         self.mean = torch.tensor(state[prefix + 'observation_normalizer._mean'])
         self.std = torch.tensor(state[prefix + 'observation_normalizer._std'])
         lr_actor, lr_critic = (3e-4, 3e-4) if kind == 'sac' else (1e-3, 1e-3)
@@ -192,7 +214,25 @@ class OffPolicyPort:
         log_probs = normal.log_prob(raw) - torch.log(1 - squashed ** 2 + 1e-6)
         return squashed, log_probs.sum(dim=-1)
 
+    def logits(self, p, observations, actions):
+        x = torch.cat([(observations - self.mean) / self.std, actions], dim=-1)
+        return torch.nn.functional.linear(self.torso(p, x), p[4], p[5])
+
     def critic_step(self, b, eps):
+        if self.kind == 'd4pg':                                    # critics.py:100-122
+            with torch.no_grad():
+                next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
+                next_probabilities = torch.nn.functional.softmax(self.logits(
+                    self.target_critics[0], b['next_observations'], next_actions), dim=-1)
+                returns = b['rewards'][:, None] + b['discounts'][:, None] * self.values
+                targets = project_onto_support(self.values, next_probabilities, returns)
+            self.critic_opt.zero_grad()
+            log_probabilities = torch.nn.functional.log_softmax(
+                self.logits(self.critics[0], b['observations'], b['actions']), dim=-1)
+            loss = -(targets * log_probabilities).sum(dim=-1).mean()
+            loss.backward()
+            self.critic_opt.step()
+            return dict(loss=float(loss.detach()), q1=0.0, q2=0.0)
         if self.kind == 'ddpg':                                    # critics.py:68-86
             with torch.no_grad():
                 next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
@@ -228,7 +268,11 @@ class OffPolicyPort:
     def actor_step(self, b, eps):
         self.actor_opt.zero_grad()
         actions, lp = self.policy(self.actor, b['observations'], eps)
-        if self.kind != 'sac':
+        if self.kind == 'd4pg':                                    # actors.py:211-214
+            probabilities = torch.nn.functional.softmax(
+                self.logits(self.critics[0], b['observations'], actions), dim=-1)
+            loss = -(probabilities * self.values).sum(dim=-1).mean()
+        elif self.kind != 'sac':
             loss = -self.q(self.critics[0], b['observations'], actions).mean()
         else:
             q = torch.min(self.q(self.critics[0], b['observations'], actions),
@@ -268,7 +312,7 @@ class OffPolicyPort:
         nets = [('actor', self.actor, ACTOR_KEYS[self.kind]),
                 ('target_actor', self.target_actor, ACTOR_KEYS[self.kind])]
         for n, online, target in zip(self.critic_names, self.critics, self.target_critics):
-            nets += [(n, online, CRITIC_KEYS), ('target_' + n, target, CRITIC_KEYS)]
+            nets += [(n, online, self.critic_keys), ('target_' + n, target, self.critic_keys)]
         for net, params, keys in nets:
             for k, p in zip(keys, params):
                 out[f'{net}.{k}'] = p.detach().numpy()

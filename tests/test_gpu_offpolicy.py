@@ -109,34 +109,38 @@ def _agent_from_golden(g, kind):
     from tonic_amd.environments import Box
     O, A, W, hidden, B, iterations, seed, loop_steps = (int(x) for x in g['cfg'])
     relu = torch.nn.ReLU
+    critic_head = (tt.models.DistributionalValueHead(*[int(v) if i == 2 else float(v)
+                                                        for i, v in enumerate(g['atoms'])])
+                   if kind == 'd4pg' else tt.models.ValueHead())
     critic = tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
-                              torso=tt.models.MLP((hidden, hidden), relu),
-                              head=tt.models.ValueHead())
+                              torso=tt.models.MLP((hidden, hidden), relu), head=critic_head)
     if kind == 'sac':
         head = tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                             distribution=tt.models.SquashedMultivariateNormalDiag)
     else:
         head = tt.models.DeterministicPolicyHead()
-    container = (tt.models.ActorCriticWithTargets if kind == 'ddpg'
+    container = (tt.models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg')
                  else tt.models.ActorTwinCriticWithTargets)
     model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
                               torso=tt.models.MLP((hidden, hidden), relu), head=head),
         critic=critic, observation_normalizer=tt.normalizers.MeanStd())
     replay = tonic_amd.replays.Buffer(size=400, batch_iterations=iterations, batch_size=B,
-                                      steps_before_batches=W * 10, steps_between_batches=W * 10)
+                                      steps_before_batches=W * 10, steps_between_batches=W * 10,
+                                      return_steps=int(g['return_steps']) if 'return_steps' in g.files else 1)
     if kind == 'sac':
         agent = tt.agents.SAC(model=model, replay=replay,
                               exploration=tonic_amd.explorations.NoActionNoise(start_steps=W * 5))
     else:
-        cls = tt.agents.DDPG if kind == 'ddpg' else tt.agents.TD3
+        cls = {'ddpg': tt.agents.DDPG, 'd4pg': tt.agents.D4PG, 'td3': tt.agents.TD3}[kind]
         agent = cls(model=model, replay=replay,
                     exploration=tonic_amd.explorations.NormalActionNoise(start_steps=W * 5))
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
     return agent
 
 
-OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg')]
+OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg'),
+                   ('d4pg_small', 'd4pg')]
 
 
 @pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
@@ -153,10 +157,17 @@ def test_offpolicy_update_matches_reference(lib, golden, name, kind):
     for t in range(int(g['buffer_size'])):
         agent.replay.store(**{k: dev(ref[k][t]) for k in (
             'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations')})
+    if agent.replay.return_steps > 1:
+        # the captured buffer already holds the accumulated n-step rows (their bit-exactness is
+        # test_buffer_n_step_returns_bit_exact's subject): install them as they are
+        for k, v in ref.items():
+            agent.replay.buffers[k].copy_(dev(v))
     infos = agent.enqueue_update(g['indices'], g['eps']).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], g['info/critic/loss'], rtol=1e-5, atol=1e-5)
     if kind == 'ddpg':
         np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q_mean'], rtol=1e-5, atol=1e-5)
+    elif kind == 'd4pg':
+        pass                # DistributionalDeterministicQLearning logs the loss only (critics.py:122)
     else:
         np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q1_mean'], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(infos[0][:, 2], g['info/critic/q2_mean'], rtol=1e-5, atol=1e-5)
@@ -206,7 +217,7 @@ def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
 
 
 @pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100),
-                                          ('ddpg', 17, 6, 4, 100)])
+                                          ('ddpg', 17, 6, 4, 100), ('d4pg', 24, 6, 4, 256)])
 def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     """cfg-3 (SAC, O=111, A=8, B=1024) and cfg-4 per-GPU (TD3, O=67, A=21, 64 workers, the
     reference's default B=100) shapes with the default 256-wide networks: two learner iterations
@@ -219,7 +230,8 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     rng = np.random.RandomState(7)
     rows = 64
     replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
-    agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG)[kind](replay=replay)
+    agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG,
+                 d4pg=tt.agents.D4PG)[kind](replay=replay)    # (d4pg: default 51 atoms on +-150)
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
     # make the normaliser non-trivial
     norm = agent.model.observation_normalizer
@@ -227,7 +239,8 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     norm._std.data.copy_(dev(np.abs(rng.normal(size=O)) + 0.5))
     state = {'pre/' + k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
     host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
-                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                next_observations=rng.normal(size=(rows, W, O)),
+                rewards=rng.normal(size=(rows, W)) * (60.0 if kind == 'd4pg' else 1.0),
                 resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
     host = {k: np.asarray(v, np.float32) for k, v in host.items()}
     for t in range(rows):
@@ -236,11 +249,12 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     indices = replay.sample_indices()
     draws = 2 if kind == 'sac' else 1
     eps = rng.normal(size=(2, draws, B, A)).astype(np.float32)
-    oracle = torch_port.OffPolicyPort(kind, state, 'pre/')
+    oracle = torch_port.OffPolicyPort(kind, state, 'pre/', atoms=(-150., 150., 51))
     want = oracle.update(host, W, indices, eps)
     infos = agent.enqueue_update(indices, eps).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], [i['critic']['loss'] for i in want], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(infos[0][:, 1], [i['critic']['q1'] for i in want], rtol=1e-5, atol=1e-5)
+    if kind != 'd4pg':
+        np.testing.assert_allclose(infos[0][:, 1], [i['critic']['q1'] for i in want], rtol=1e-5, atol=1e-5)
     ran = infos[1][:, 6] > 0
     np.testing.assert_allclose(infos[1][ran, 0], [i['actor']['loss'] for i in want if 'actor' in i],
                                rtol=1e-5, atol=1e-5)

@@ -101,7 +101,7 @@ def test_install_puts_the_collector_under_the_reference_cli(tmp_path, monkeypatc
     assert (tmp_path / 'env' / 'run' / '3' / 'log.csv').exists()
 
 
-@pytest.mark.parametrize('name', ['PPO', 'A2C', 'TRPO', 'SAC', 'TD3', 'DDPG'])
+@pytest.mark.parametrize('name', ['PPO', 'A2C', 'TRPO', 'SAC', 'TD3', 'DDPG', 'D4PG'])
 def test_reference_agents_load_this_packages_checkpoints(tmp_path, name):
     """tonic/torch/agents/agent.py:23-26: the reference agent's strict load_state_dict accepts a
     `.pt` written by this package's Agent.save (same keys, same shapes)."""
@@ -125,3 +125,26 @@ def test_reference_agents_load_this_packages_checkpoints(tmp_path, name):
     assert set(got) == set(want)
     for key in want:
         assert torch.equal(got[key], want[key].cpu()), key
+
+
+def test_categorical_with_support_equals_the_reference():
+    """models.CategoricalWithSupport / DistributionalValueHead (critics.py:23-66): same support,
+    probabilities, mean and projection as the reference's, bit for bit, on returns inside, outside
+    and exactly on the support."""
+    import torch
+    tonic = reference_loader.load_reference()
+    import tonic_amd.torch as tt
+    torch.manual_seed(3)
+    theirs = tonic.torch.models.DistributionalValueHead(-7.5, 4.0, 23)
+    mine = tt.models.DistributionalValueHead(-7.5, 4.0, 23)
+    assert torch.equal(theirs.values, mine.values)
+    logits = torch.randn(40, 23) * 2
+    a = tonic.torch.models.critics.CategoricalWithSupport(theirs.values, logits)
+    b = tt.models.CategoricalWithSupport(mine.values, logits)
+    returns = torch.randn(40, 23) * 6
+    returns[0] = theirs.values                       # exactly on the atoms
+    returns[1] = -100.0
+    returns[2] = 100.0
+    assert torch.equal(a.probabilities, b.probabilities)
+    assert torch.equal(a.mean(), b.mean())
+    assert torch.equal(a.project(returns), b.project(returns))

@@ -71,6 +71,11 @@ SIGNATURES = {
     'tonic_actor_q_grad': (ctypes.c_int, [c_i32] + [c_vp] * 4 + [c_f64] + [c_vp] * 3 + [c_i32] * 4 +
                            [c_f64] +
                            [c_vp, c_i64, c_vp]),
+    'tonic_distributional_workspace_bytes': (c_i64, [c_i32] * 5),
+    'tonic_distributional_q_grad': (ctypes.c_int, [c_vp] * 5 + [c_f64] + [c_vp] * 7 + [c_i32] * 5 +
+                                    [c_vp, c_i64, c_vp]),
+    'tonic_distributional_actor_grad': (ctypes.c_int, [c_vp] * 4 + [c_f64] + [c_vp] * 3 +
+                                        [c_i32] * 5 + [c_vp, c_i64, c_vp]),
     'tonic_collector_block_bytes': (c_i64, [c_i64, c_i32, c_i32]),
     'tonic_collector_block_init': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32]),
     'tonic_collector_block_offset': (c_i64, [c_vp, c_i32]),
@@ -100,7 +105,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 4        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

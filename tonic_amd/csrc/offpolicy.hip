@@ -170,6 +170,86 @@ __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha
   }
 }
 
+// ---- distributional critic (models/critics.py:23-66, D4PG): one wave per sample, lane = atom.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// softmax over the NA lanes of a wave (torch.nn.functional.softmax: exp(x - max) / sum)
+__device__ __forceinline__ float wave_softmax(float logit, bool live, float* log_norm) {
+  const float mx = wave_max(live ? logit : -INFINITY);
+  const float e = live ? expf(logit - mx) : 0.f;
+  const float sum = wave_sum(e);
+  if (log_norm != nullptr) *log_norm = mx + logf(sum);
+  return e / sum;
+}
+
+// DistributionalDeterministicQLearning (critics.py:100-122):
+//   returns_j = r + disc * z_j ; targets = CategoricalWithSupport.project(returns) of the TARGET
+//   critic's distribution (critics.py:32-46, restated with the same float32 expressions) ;
+//   loss = -sum_i targets_i log_softmax(logits)_i ; d loss / d logits_i = softmax_i sum_k targets_k - targets_i
+// (gradient of the SUM over the batch; the optimizer step divides by B).  loss_m: per-sample losses.
+__global__ __launch_bounds__(256) void distributional_critic_loss_kernel(
+    const float* target_logits, const float* logits, int ld, const float* rewards,
+    const float* discounts, const float* values, int NA, float* dlogits, float* loss_m, int B) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= B) return;
+  const bool live = lane < NA;
+  const int i = live ? lane : NA - 1;
+  const float z = values[i], vmin = values[0], vmax = values[NA - 1];
+  const float p_next = wave_softmax(target_logits[(int64_t)m * ld + i], live, nullptr);
+  const float ret = rewards[m] + discounts[m] * z;
+  const float clipped = fminf(fmaxf(ret, vmin), vmax);
+  const float d_pos = (i + 1 < NA ? values[i + 1] : vmin) - z;      // critics.py:34-35
+  const float d_neg = z - (i > 0 ? values[i - 1] : vmax);           // critics.py:36-37
+  float target = 0.f;
+  for (int j = 0; j < NA; ++j) {
+    const float delta = __shfl(clipped, j, 64) - z;                 // critics.py:40
+    const float sign = delta >= 0.f ? 1.f : 0.f;
+    const float hat = (sign * delta / d_pos) - ((1.f - sign) * delta / d_neg);
+    target += fminf(fmaxf(1.f - hat, 0.f), 1.f) * __shfl(p_next, j, 64);
+  }
+  if (!live) target = 0.f;
+  float log_norm;
+  const float logit = logits[(int64_t)m * ld + i];
+  const float p = wave_softmax(logit, live, &log_norm);
+  const float total = wave_sum(target);
+  const float loss = -wave_sum(live ? target * (logit - log_norm) : 0.f);
+  if (lane < ld) dlogits[(int64_t)m * ld + lane] = live ? p * total - target : 0.f;
+  if (lane == 0) loss_m[m] = loss;
+}
+
+// DistributionalDeterministicPolicyGradient (actors.py:203-224): value = sum_i softmax(logits)_i z_i,
+// loss = -mean(value): d(-value) / d logits_i = -p_i (z_i - value).
+__global__ __launch_bounds__(256) void distributional_actor_loss_kernel(
+    const float* logits, int ld, const float* values, int NA, float* dlogits, float* loss_m,
+    int B) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= B) return;
+  const bool live = lane < NA;
+  const int i = live ? lane : NA - 1;
+  const float z = values[i];
+  const float p = wave_softmax(logits[(int64_t)m * ld + i], live, nullptr);
+  const float value = wave_sum(live ? p * z : 0.f);
+  if (lane < ld) dlogits[(int64_t)m * ld + lane] = live ? -(p * (z - value)) : 0.f;
+  if (lane == 0) loss_m[m] = -value;
+}
+
+// the 8 statistics {loss_sum, 0, 0, 0, 0, B, 0, 0} from per-sample losses (fixed order, float64)
+__global__ void loss_stats_kernel(const float* loss_m, float* stats, int B) {
+  double a = 0, unused1 = 0, unused2 = 0;
+  for (int m = threadIdx.x; m < B; m += blockDim.x) a += loss_m[m];
+  block_sum3(a, unused1, unused2);
+  if (threadIdx.x == 0) {
+    stats[0] = (float)a;
+    for (int i = 1; i < 8; ++i) stats[i] = i == 5 ? (float)B : 0.f;
+  }
+}
+
 // Back through the squashed Gaussian head (SAC) or the tanh head (TD3).
 //   da[m][a] = d loss / d action (the action columns of the critics' input gradients, [B, pad16(A)])
 // SAC: u = loc + sigma eps, a = tanh(u):
@@ -385,13 +465,15 @@ struct PolicyTail {
 
 int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
-                  hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr) {
+                  hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr,
+                  int ldx = 0) {
   ActorParams p(params, s);
+  if (ldx <= 0) ldx = s.O;                      // dense observation rows unless told otherwise
   if (tail_done != nullptr) *tail_done = false;
   const int HP = weight_ld(s.H);
   if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
     MlpFwdArgs f{};
-    f.X = obs; f.ldx = s.O; f.K1 = s.O;
+    f.X = obs; f.ldx = ldx; f.K1 = s.O;
     f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2; f.ldw1 = p.ld1; f.ldw2 = p.ldH;
     f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
     f.Wh[1] = p.head_w(s.heads - 1); f.bh[1] = p.head_b(s.heads - 1);
@@ -411,7 +493,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     }
     return launch_mlp_forward(f, 1, st);
   }
-  GemmArgs g = gemm(obs, s.O, p.W1, p.ld1, h1, HP, B, s.H, s.O);
+  GemmArgs g = gemm(obs, ldx, p.W1, p.ld1, h1, HP, B, s.H, s.O);
   g.bias = p.b1; g.act = ACT_RELU;
   TRY(launch_gemm('c', 'c', g, 1, st));
   g = gemm(h1, HP, p.W2, p.ldH, h2, HP, B, s.H, s.H);
@@ -696,8 +778,204 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   return TONIC_OK;
 }
 
+namespace {
+
+// Backward of an actor-shaped network (torso + `heads` linear heads) from the gradients at its head
+// outputs: the input-gradient chain (dz2, dz1; optionally the columns [xa_first, xa_first + xa_count)
+// of the input gradient -> dxa), then all weight / bias gradient SUMS into the flat layout `grads`
+// (null: none — a frozen network) in one grouped launch.  X: the network's input rows, ldx apart.
+int actor_shaped_backward(const float* params, ActorShape as, const float* X, int ldx, int B,
+                          const float* a_h1, const float* a_h2, const float* dloc,
+                          const float* dspre, int ldh, float* da_h2, float* da_h1, float* grads,
+                          float* dxa, int xa_first, int xa_count, hipStream_t st) {
+  const int H = as.H, A = as.A, HP = weight_ld(H);
+  ActorParams p(params, as);
+  GemmArgs g;
+  // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
+  if (mlp_backward_supported(H, A, as.heads, xa_count)) {
+    MlpBwdArgs b{};
+    b.heads = as.heads; b.NH = A; b.ldh = ldh;
+    b.dhead[0] = dloc; b.dhead[1] = dspre ? dspre : dloc;
+    b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
+    b.W2 = p.W2; b.W1 = p.W1; b.K1 = as.O; b.ldw1 = p.ld1; b.ldw2 = p.ldH;
+    b.xa_first = xa_first; b.xa_count = dxa ? xa_count : 0;
+    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = dxa; b.ldhid = HP;
+    b.ldxa = pad16(xa_count > 0 ? xa_count : 1);
+    b.B = B; b.H = H;
+    TRY(launch_mlp_backward(b, 1, st));
+  } else {
+    for (int h = 0; h < as.heads; ++h) {
+      const float* dhead = h == 0 ? dloc : dspre;
+      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, HP, B, H, A);
+      g.mask = a_h2; g.ldmask = HP; g.accumulate = h > 0;
+      TRY(launch_gemm('c', 's', g, 1, st));
+    }
+    g = gemm(da_h2, HP, p.W2, p.ldH, da_h1, HP, B, H, H);
+    g.mask = a_h1; g.ldmask = HP;
+    TRY(launch_gemm('c', 's', g, 1, st));
+    if (dxa) {
+      g = gemm(da_h1, HP, p.W1 + xa_first, p.ld1, dxa, pad16(xa_count), B, xa_count, H);
+      TRY(launch_gemm('c', 's', g, 1, st));
+    }
+  }
+  if (grads == nullptr) return TONIC_OK;
+  // ... then all weight gradients (they contract over the batch) in ONE launch:
+  //   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T X, db1
+  const ActorBlock<float> gp(grads, as);               // the gradient sums share the layout
+  GemmArgs w[4];
+  int count = 0;
+  for (int h = 0; h < as.heads; ++h) {
+    const float* dhead = h == 0 ? dloc : dspre;
+    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
+    w[count++].colsum = gp.head_b(h);
+  }
+  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
+  w[count++].colsum = gp.b2;
+  w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
+  w[count++].colsum = gp.b1;
+  return launch_gemm_group('s', 's', w, count, 1, st);
+}
+
+}  // namespace
+
 // Actor gradient through the (frozen) critics.  kind 0 = DeterministicPolicyGradient on
 // critic_1 only (actors.py:170-189 with td3.py:36), 1 = TwinCriticSoftDeterministicPolicyGradient
+
+// ------------------------------------------------------------------ D4PG (distributional critic)
+// The critic is an actor-shaped network: input [normalised observation | action] (O + A columns),
+// two ReLU layers, ONE linear head of NA logits (models/critics.py:49-66) — same packed layout as
+// tonic_mlp_actor_param_count(O + A, H, NA, 1).
+
+namespace {
+
+struct DistributionalBuffers {
+  float *a_h1, *a_h2, *head, *act, *X, *X2, *t_h1, *t_h2, *t_logits, *c_h1, *c_h2, *logits,
+      *dlogits, *loss_m, *dz2, *dz1, *dxa, *dloc, *da_h2, *da_h1;
+  static int64_t floats(int Bp, int HP, int ldh, int ldx, int ldl, int A) {
+    const int64_t hid = (int64_t)Bp * HP;
+    return 2 * hid + (int64_t)Bp * ldh + (int64_t)Bp * A + 2LL * Bp * ldx + 4 * hid +
+           3LL * Bp * ldl + Bp + 2 * hid + 2LL * Bp * ldh + 2 * hid + 64 * 24;
+  }
+  DistributionalBuffers(void* d_workspace, int64_t bytes, int Bp, int HP, int ldh, int ldx,
+                        int ldl, int A) {
+    Workspace ws{static_cast<char*>(d_workspace), 0, bytes};
+    const int64_t hid = (int64_t)Bp * HP;
+    a_h1 = ws.take(hid); a_h2 = ws.take(hid);
+    head = ws.take((int64_t)Bp * ldh); act = ws.take((int64_t)Bp * A);
+    X = ws.take((int64_t)Bp * ldx); X2 = ws.take((int64_t)Bp * ldx);
+    t_h1 = ws.take(hid); t_h2 = ws.take(hid); c_h1 = ws.take(hid); c_h2 = ws.take(hid);
+    t_logits = ws.take((int64_t)Bp * ldl); logits = ws.take((int64_t)Bp * ldl);
+    dlogits = ws.take((int64_t)Bp * ldl); loss_m = ws.take(Bp);
+    dz2 = ws.take(hid); dz1 = ws.take(hid);
+    dxa = ws.take((int64_t)Bp * ldh); dloc = ws.take((int64_t)Bp * ldh);
+    da_h2 = ws.take(hid); da_h1 = ws.take(hid);
+  }
+};
+
+}  // namespace
+
+extern "C" int64_t tonic_distributional_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H,
+                                                        int32_t NA) {
+  return DistributionalBuffers::floats(pad16(B), weight_ld(H), pad16(A), pitch16(O + A), pad16(NA),
+                                       A) * 4;
+}
+
+extern "C" int tonic_distributional_q_grad(
+    const float* d_target_actor, const float* d_target_critic, const float* d_critic,
+    const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    const float* d_observations, const float* d_actions, const float* d_next_observations,
+    const float* d_rewards, const float* d_discounts, const float* d_values, float* d_grad_sums,
+    int32_t B, int32_t O, int32_t H, int32_t A, int32_t NA, void* d_workspace,
+    int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_target_actor && d_target_critic && d_critic && d_norm_mean && d_norm_std &&
+                    d_observations && d_actions && d_next_observations && d_rewards &&
+                    d_discounts && d_values && d_grad_sums && d_workspace && B > 0 && NA >= 2 &&
+                    NA <= 64,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_distributional_q_grad: bad argument (2 <= atoms <= 64)");
+  TONIC_REQUIRE(workspace_bytes >= tonic_distributional_workspace_bytes(B, O, A, H, NA),
+                TONIC_ERR_WORKSPACE, "tonic_distributional_q_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), ldl = pad16(NA), threads = 256;
+  const DistributionalBuffers w(d_workspace, workspace_bytes, Bp, weight_ld(H), ldh, ldx, ldl, A);
+  const ActorShape as{O, H, A, 1}, cs{O + A, H, NA, 1};
+  // a' = target_actor(s') (critics.py:104); its tail encodes (s', a') -> X and the stored (s, a) -> X2
+  PolicyTail tail{};
+  tail.post = POST_COPY; tail.actions = w.act;
+  tail.enc_obs = d_next_observations; tail.enc_obs2 = d_observations; tail.enc_act2 = d_actions;
+  tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std; tail.enc_clip = clip_bound(norm_clip);
+  tail.enc_out = w.X; tail.enc_out2 = w.X2; tail.enc_ld = ldx;
+  bool tail_done = false;
+  TRY(actor_forward(d_target_actor, as, d_next_observations, B, w.a_h1, w.a_h2, w.head, w.head, ldh,
+                    true, st, &tail, &tail_done));
+  if (!tail_done) {
+    hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, w.head, ldh, w.act, B, A);
+    hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads, 2),
+                       dim3(threads), 0, st, d_next_observations, w.act, d_norm_mean, d_norm_std,
+                       clip_bound(norm_clip), w.X, B, O, A, ldx, d_observations, d_actions, w.X2);
+  }
+  TRY(actor_forward(d_target_critic, cs, w.X, B, w.t_h1, w.t_h2, w.t_logits, w.t_logits, ldl, false,
+                    st, nullptr, nullptr, ldx));
+  TRY(actor_forward(d_critic, cs, w.X2, B, w.c_h1, w.c_h2, w.logits, w.logits, ldl, false, st,
+                    nullptr, nullptr, ldx));
+  hipLaunchKernelGGL(distributional_critic_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st,
+                     w.t_logits, w.logits, ldl, d_rewards, d_discounts, d_values, NA, w.dlogits,
+                     w.loss_m, B);
+  hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(1024), 0, st, w.loss_m,
+                     d_grad_sums + actor_count(cs), B);
+  TRY(actor_shaped_backward(d_critic, cs, w.X2, ldx, B, w.c_h1, w.c_h2, w.dlogits, nullptr, ldl,
+                            w.dz2, w.dz1, d_grad_sums, nullptr, 0, 0, st));
+  TONIC_CHECK_LAUNCH("tonic_distributional_q_grad");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_distributional_actor_grad(
+    const float* d_actor_params, const float* d_critic, const float* d_norm_mean,
+    const float* d_norm_std, double norm_clip, const float* d_observations, const float* d_values,
+    float* d_grad_sums, int32_t B, int32_t O, int32_t H, int32_t A, int32_t NA, void* d_workspace,
+    int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_critic && d_norm_mean && d_norm_std && d_observations &&
+                    d_values && d_grad_sums && d_workspace && B > 0 && NA >= 2 && NA <= 64,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_distributional_actor_grad: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_distributional_workspace_bytes(B, O, A, H, NA),
+                TONIC_ERR_WORKSPACE, "tonic_distributional_actor_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), ldl = pad16(NA), threads = 256;
+  const DistributionalBuffers w(d_workspace, workspace_bytes, Bp, weight_ld(H), ldh, ldx, ldl, A);
+  const ActorShape as{O, H, A, 1}, cs{O + A, H, NA, 1};
+  PolicyTail tail{};                              // a = actor(s); the tail encodes (s, a) -> X
+  tail.post = POST_COPY; tail.actions = w.act;
+  tail.enc_obs = d_observations; tail.enc_mean = d_norm_mean; tail.enc_std = d_norm_std;
+  tail.enc_clip = clip_bound(norm_clip); tail.enc_out = w.X; tail.enc_ld = ldx;
+  bool tail_done = false;
+  TRY(actor_forward(d_actor_params, as, d_observations, B, w.a_h1, w.a_h2, w.head, w.head, ldh,
+                    true, st, &tail, &tail_done));
+  if (!tail_done) {
+    hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, w.head, ldh, w.act, B, A);
+    hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads),
+                       0, st, d_observations, w.act, d_norm_mean, d_norm_std, clip_bound(norm_clip),
+                       w.X, B, O, A, ldx);
+  }
+  TRY(actor_forward(d_critic, cs, w.X, B, w.c_h1, w.c_h2, w.logits, w.logits, ldl, false, st,
+                    nullptr, nullptr, ldx));
+  hipLaunchKernelGGL(distributional_actor_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st,
+                     w.logits, ldl, d_values, NA, w.dlogits, w.loss_m, B);
+  hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(1024), 0, st, w.loss_m,
+                     d_grad_sums + actor_count(as), B);
+  // through the frozen critic to the action columns of its input, then the tanh head and the actor
+  TRY(actor_shaped_backward(d_critic, cs, w.X, ldx, B, w.c_h1, w.c_h2, w.dlogits, nullptr, ldl,
+                            w.dz2, w.dz1, nullptr, w.dxa, O, A, st));
+  hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
+                     dim3(threads), 0, st, w.dxa, (const float*)nullptr, ldh, w.act,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ldh, 0.f,
+                     0, w.dloc, (float*)nullptr, B, A);
+  TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, w.a_h1, w.a_h2, w.dloc,
+                            nullptr, ldh, w.da_h2, w.da_h1, d_grad_sums, nullptr, 0, 0, st));
+  TONIC_CHECK_LAUNCH("tonic_distributional_actor_grad");
+  return TONIC_OK;
+}
+
 // (actors.py:238-267).  Gradient SUMS for the actor + 8 statistics {loss_sum, 0.., B, ..}.
 extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                                   const float* d_critics, const float* d_norm_mean,
@@ -763,45 +1041,9 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                      dim3(threads), 0, st, dxa, nets == 2 ? dxa + (int64_t)Bp * ldh : (float*)nullptr,
                      ldh, act, d_eps, sigma, head1, ldh,
                      (float)entropy_coeff, kind == 1 ? 1 : 0, dloc, dspre, B, A);
-  // ---- actor backward (weight-gradient sums into the flat layout)
-  ActorParams p(d_actor_params, as);
-  const ActorBlock<float> gp(d_grad_sums, as);         // the gradient sums share the layout
-  GemmArgs g;
-  // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
-  if (mlp_backward_supported(H, A, as.heads, 0)) {
-    MlpBwdArgs b{};
-    b.heads = as.heads; b.NH = A; b.ldh = ldh;
-    b.dhead[0] = dloc; b.dhead[1] = dspre;
-    b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
-    b.W2 = p.W2; b.W1 = p.W1; b.K1 = O; b.ldw1 = p.ld1; b.ldw2 = p.ldH; b.xa_first = 0; b.xa_count = 0;
-    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = nullptr; b.ldhid = HP;
-    b.B = B; b.H = H;
-    TRY(launch_mlp_backward(b, 1, st));
-  } else {
-    for (int h = 0; h < as.heads; ++h) {
-      const float* dhead = h == 0 ? dloc : dspre;
-      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, HP, B, H, A);
-      g.mask = a_h2; g.ldmask = HP; g.accumulate = h > 0;
-      TRY(launch_gemm('c', 's', g, 1, st));
-    }
-    g = gemm(da_h2, HP, p.W2, p.ldH, da_h1, HP, B, H, H);
-    g.mask = a_h1; g.ldmask = HP;
-    TRY(launch_gemm('c', 's', g, 1, st));
-  }
-  // ... then all weight gradients (they contract over the batch) in ONE launch:
-  //   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T obs, db1
-  GemmArgs w[4];
-  int count = 0;
-  for (int h = 0; h < as.heads; ++h) {
-    const float* dhead = h == 0 ? dloc : dspre;
-    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
-    w[count++].colsum = gp.head_b(h);
-  }
-  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
-  w[count++].colsum = gp.b2;
-  w[count] = gemm(da_h1, HP, d_observations, O, gp.W1, gp.ld1, H, O, B);
-  w[count++].colsum = gp.b1;
-  TRY(launch_gemm_group('s', 's', w, count, 1, st));
+  TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, a_h1, a_h2, dloc,
+                            kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, d_grad_sums, nullptr,
+                            0, 0, st));
   TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
   return TONIC_OK;
 }

@@ -746,13 +746,38 @@ class DDPG(Agent):
             if twin:
                 logger.store('critic/q1', row[1])    # batch means (log-equivalent)
                 logger.store('critic/q2', row[2])
-            else:
+            elif not getattr(self.critic_updater, 'atoms', 0):
                 logger.store('critic/q', row[1])
         for row in infos[1][infos[1][:, 6] > 0]:
             logger.store('actor/loss', row[0])
         self.last_infos = infos
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
+
+
+def _d4pg_model():
+    """tonic/torch/agents/d4pg.py:7-18 (support for the control suite with 0.99 discount)."""
+    return models.ActorCriticWithTargets(
+        actor=models.Actor(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.DeterministicPolicyHead()),
+        critic=models.Critic(
+            encoder=models.ObservationActionEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU),
+            head=models.DistributionalValueHead(-150., 150., 51)),
+        observation_normalizer=normalizers.MeanStd())
+
+
+class D4PG(DDPG):
+    """tonic/torch/agents/d4pg.py:21-37: DDPG's acting / storing / scheduling with a categorical
+    critic on 5-step returns (the HBM Buffer accumulates them, buffers.py:58-79)."""
+
+    def __init__(self, model=None, replay=None, exploration=None, actor_updater=None,
+                 critic_updater=None):
+        super().__init__(
+            model or _d4pg_model(), replay or replays.Buffer(return_steps=5), exploration,
+            actor_updater or updaters.DistributionalDeterministicPolicyGradient(),
+            critic_updater or updaters.DistributionalDeterministicQLearning())
 
 
 class TD3(DDPG):

@@ -184,6 +184,53 @@ class ValueHead(torch.nn.Module):
         return out
 
 
+class CategoricalWithSupport:
+    """tonic/torch/models/critics.py:23-46: a categorical distribution over the fixed support
+    `values` (drop-in surface for callers of `model.critic(...)`; the learner kernels work on the
+    logits, csrc/offpolicy.hip distributional_critic_loss_kernel)."""
+
+    def __init__(self, values, logits):
+        self.values = values
+        self.logits = logits
+        self.probabilities = torch.nn.functional.softmax(logits, dim=-1)
+
+    def mean(self):
+        return (self.probabilities * self.values).sum(dim=-1)
+
+    def project(self, returns):
+        """Probability mass of every atom of `returns` [B, NA] spread onto its two neighbours in
+        the support (critics.py:32-46), as a triangular kernel per support point."""
+        z = self.values
+        vmin, vmax = z[0], z[-1]
+        above = (torch.cat([z[1:], vmin[None]]) - z)[None, :, None]       # distance to the next atom
+        below = (z - torch.cat([vmax[None], z[:-1]]))[None, :, None]      # ... to the previous one
+        delta = torch.clamp(returns, vmin, vmax)[:, None] - z[None, :, None]
+        up = (delta >= 0).float()
+        hat = (up * delta / above) - ((1 - up) * delta / below)
+        return (torch.clamp(1 - hat, 0, 1) * self.probabilities[:, None]).sum(dim=2)
+
+
+class DistributionalValueHead(torch.nn.Module):
+    """tonic/torch/models/critics.py:49-66."""
+
+    def __init__(self, vmin, vmax, num_atoms, fn=None):
+        super().__init__()
+        self.num_atoms = num_atoms
+        self.fn = fn
+        self.values = torch.linspace(vmin, vmax, num_atoms).float()
+
+    def initialize(self, input_size, return_normalizer=None):
+        if return_normalizer:
+            raise ValueError('Return normalizers cannot be used with distributional value heads.')
+        self.distributional_layer = torch.nn.Linear(input_size, self.num_atoms)
+        if self.fn:
+            self.distributional_layer.apply(self.fn)
+
+    def forward(self, inputs):
+        logits = self.distributional_layer(inputs)
+        return CategoricalWithSupport(values=self.values.to(logits.device), logits=logits)
+
+
 class _Network(torch.nn.Module):
     """encoder -> torso -> head (actors.py:118-137, critics.py:70-90)."""
 

@@ -445,8 +445,16 @@ class _QUpdater(_FlatUpdater):
         lib = _lib.load()
         want_actor = lib.tonic_mlp_actor_param_count(
             self.observation_size, self.hidden, self.action_size, heads)
-        want_critic = lib.tonic_q_critic_param_count(
-            self.observation_size, self.action_size, self.hidden)
+        self.atoms = getattr(critic.head, 'num_atoms', 0)          # > 0: distributional critic (D4PG)
+        if self.atoms:
+            if not 2 <= self.atoms <= 64:
+                raise NotImplementedError('the distributional kernels serve 2 .. 64 atoms')
+            want_critic = lib.tonic_mlp_actor_param_count(
+                self.observation_size + self.action_size, self.hidden, self.atoms, 1)
+            self.values = critic.head.values.to(device=device, dtype=torch.float32).contiguous()
+        else:
+            want_critic = lib.tonic_q_critic_param_count(
+                self.observation_size, self.action_size, self.hidden)
         n_critics = 2 if hasattr(model, 'critic_1') else 1
         if (model.flat_actor.count, model.flat_critics.count) != (want_actor,
                                                                    n_critics * want_critic):
@@ -467,8 +475,12 @@ class _QUpdater(_FlatUpdater):
         return float(getattr(self.normalizer, 'clip', None) or 0.0)
 
     def _offpolicy_workspace(self, batch):
-        need = self.lib.tonic_offpolicy_workspace_bytes(batch, self.observation_size,
-                                                        self.action_size, self.hidden)
+        if self.atoms:
+            need = self.lib.tonic_distributional_workspace_bytes(
+                batch, self.observation_size, self.action_size, self.hidden, self.atoms)
+        else:
+            need = self.lib.tonic_offpolicy_workspace_bytes(batch, self.observation_size,
+                                                            self.action_size, self.hidden)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.grad_sums.device)
         return self.workspace
@@ -578,6 +590,41 @@ class TwinCriticSoftQLearning(_TwinCriticQLearning):
         return self.model.flat_actor.flat
 
 
+class DistributionalDeterministicQLearning(_TwinCriticQLearning):
+    """critics.py:89-122 (D4PG): cross-entropy of the online critic's categorical distribution
+    against the projected target distribution (tonic_distributional_q_grad)."""
+    stats_kind = 4          # {loss}
+
+    def __init__(self, optimizer=None, gradient_clip=0):
+        self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
+
+    def initialize(self, model):
+        super().initialize(model)
+        if not self.atoms:
+            raise NotImplementedError('DistributionalDeterministicQLearning needs a critic with a '
+                                      'DistributionalValueHead')
+
+    def enqueue(self, batch, eps, info_row, n_global=None):
+        B = batch['observations'].shape[0]
+        ws = self._offpolicy_workspace(B)
+        mean, std = self.norm_tensors()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_distributional_q_grad(
+            p(self.model.flat_target_actor.flat), p(self.model.flat_target_critics.flat),
+            p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(batch['observations']),
+            p(batch['actions']), p(batch['next_observations']), p(batch['rewards']),
+            p(batch['discounts']), p(self.values), p(self.grad_sums), B, self.observation_size,
+            self.hidden, self.action_size, self.atoms, p(ws), ws.numel(), _lib.current_stream()),
+            'tonic_distributional_q_grad')
+        self._step(n_global or B * self.world_size, info_row)
+
+    def __call__(self, observations, actions, next_observations, rewards, discounts):
+        batch = dict(observations=observations, actions=actions,
+                     next_observations=next_observations, rewards=rewards, discounts=discounts)
+        return self._info(lambda row: self.enqueue(batch, None, row), ('loss',))
+
+
 class _ActorQGradient(_QUpdater):
     stats_kind = 4          # {loss}
     default_lr = 1e-3
@@ -615,6 +662,33 @@ class DeterministicPolicyGradient(_ActorQGradient):
         _check_plain(None, gradient_clip)
         self.optimizer = optimizer
         self.gradient_clip = gradient_clip
+
+
+class DistributionalDeterministicPolicyGradient(_ActorQGradient):
+    """actors.py:192-224 (D4PG): ascend the mean of the critic's value distribution
+    (tonic_distributional_actor_grad)."""
+
+    def __init__(self, optimizer=None, gradient_clip=0):
+        self.optimizer = optimizer
+        self.gradient_clip = gradient_clip
+
+    def initialize(self, model):
+        super().initialize(model)
+        if not self.atoms:
+            raise NotImplementedError('DistributionalDeterministicPolicyGradient needs a critic '
+                                      'with a DistributionalValueHead')
+
+    def enqueue(self, observations, eps, info_row, n_global=None, targets=None):
+        B = observations.shape[0]
+        ws = self._offpolicy_workspace(B)
+        mean, std = self.norm_tensors()
+        p = _lib.ptr
+        _lib.check(self.lib.tonic_distributional_actor_grad(
+            p(self.flat.flat), p(self.model.flat_critics.flat), p(mean), p(std), self.norm_clip(),
+            p(observations), p(self.values), p(self.grad_sums), B, self.observation_size,
+            self.hidden, self.action_size, self.atoms, p(ws), ws.numel(), _lib.current_stream()),
+            'tonic_distributional_actor_grad')
+        self._step(n_global or B * self.world_size, info_row, targets=targets)
 
 
 class TwinCriticSoftDeterministicPolicyGradient(_ActorQGradient):
