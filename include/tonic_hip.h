@@ -540,6 +540,43 @@ int tonic_distributional_actor_grad(const float* d_actor_params, const float* d_
                                     int32_t O, int32_t H, int32_t A, int32_t NA,
                                     void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- MPO (tonic/torch/agents/mpo.py): Gaussian policy head with a tanh loc and
+ *   sigma = clamp(softplus(.), 1e-4, 1) (models/actors.py:69-98, two heads), ONE critic with
+ *   targets (layouts as for DDPG / SAC); S <= 64 sampled actions per state, tiled like
+ *   updaters.tile + merge_first_two_dims (row s * B + m); d_eps = the standard-normal draws
+ *   [S, B, A] in the order Normal.rsample / Normal.sample consume them.
+ *   tonic_policy_forward kind 2 acts with this head (a = loc + sigma * eps; eps NULL = loc).
+ *
+ * tonic_expected_sarsa_grad — ExpectedSARSA.__call__ (updaters/critics.py:253-282) up to the
+ *   optimizer step: returns = r + discount * mean_s target_critic(s', a'_s), a'_s ~ target_actor(s');
+ *   MSE against critic(s, a).  Output: gradient SUMS of the critic + {sq_err_sum, q_sum, 0, 0, 0, B, 0, 0}.
+ * tonic_mpo_actor_grad — MaximumAPosterioriPolicyOptimization.__call__ (updaters/actors.py:318-464)
+ *   up to the optimizer steps, per-dimension KL constraints: E-step weights softmax_s(Q / temperature)
+ *   (+ the action-bound penalty weights), decomposed fixed-std / fixed-mean policy losses, the
+ *   alpha-weighted KL terms and the dual losses.  d_duals [2 A + 2] = {log_temperature,
+ *   log_alpha_mean[A], log_alpha_std[A], log_penalty_temperature} (already floored at min_log_dual by
+ *   the caller).  Outputs: d_grad_sums = gradient SUMS of the actor + {B * (policy + KL losses), 0, 0,
+ *   0, 0, B, 0, 0}; d_dual_grads [2 A + 2 + 8] = d loss / d log-duals + {0, 0, 0, 0, 0, 1, 0, 0};
+ *   d_stats [9 + 2 A] = {policy_mean_loss, policy_std_loss, kl_mean_loss, kl_std_loss, alpha_mean_loss,
+ *   alpha_std_loss, temperature_loss, temperature, alpha_mean[A], alpha_std[A], penalty_temperature}. */
+int64_t tonic_mpo_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H, int32_t S);
+int tonic_expected_sarsa_grad(const float* d_target_actor, const float* d_target_critic,
+                              const float* d_critic, const float* d_norm_mean,
+                              const float* d_norm_std, double norm_clip,
+                              const float* d_observations, const float* d_actions,
+                              const float* d_next_observations, const float* d_rewards,
+                              const float* d_discounts, const float* d_eps, float* d_grad_sums,
+                              int32_t B, int32_t O, int32_t H, int32_t A, int32_t S,
+                              void* d_workspace, int64_t workspace_bytes, void* stream);
+int tonic_mpo_actor_grad(const float* d_actor_params, const float* d_target_actor,
+                         const float* d_target_critic, const float* d_duals,
+                         const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+                         const float* d_observations, const float* d_eps, float* d_grad_sums,
+                         float* d_dual_grads, float* d_stats, int32_t B, int32_t O, int32_t H,
+                         int32_t A, int32_t S, double epsilon, double epsilon_penalty,
+                         double epsilon_mean, double epsilon_std, int32_t action_penalization,
+                         void* d_workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

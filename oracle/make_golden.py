@@ -360,7 +360,8 @@ def first_update_probes(tonic, builder, seed, seg, iterations):
 
 
 def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32, batch=24,
-                  iterations=6, seed=0, loop_steps=16, atoms=(-6.0, 6.0, 21), return_steps=1):
+                  iterations=6, seed=0, loop_steps=16, atoms=(-6.0, 6.0, 21), return_steps=1,
+                  samples=4):
     """tonic/torch/agents/{ddpg.py:45-112, td3.py:38-55, sac.py:40-51} driven through the
     reference agent on a synthetic env (small custom torso so the fixture stays small).  The
     first learner update is captured completely: buffer contents, the index stream of
@@ -380,9 +381,11 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
     if kind == 'sac':
         head = models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                          distribution=models.SquashedMultivariateNormalDiag)
+    elif kind == 'mpo':
+        head = models.GaussianPolicyHead()                              # mpo.py:12
     else:
         head = models.DeterministicPolicyHead()
-    container = (models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg')
+    container = (models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg', 'mpo')
                  else models.ActorTwinCriticWithTargets)
     model = container(
         actor=models.Actor(encoder=models.ObservationEncoder(),
@@ -395,6 +398,11 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
         agent = tonic.torch.agents.SAC(
             model=model, replay=replay,
             exploration=tonic.explorations.NoActionNoise(start_steps=workers * 5))
+    elif kind == 'mpo':
+        agent = tonic.torch.agents.MPO(
+            model=model, replay=replay,
+            actor_updater=updaters.MaximumAPosterioriPolicyOptimization(num_samples=samples),
+            critic_updater=updaters.ExpectedSARSA(num_samples=samples))
     else:
         cls = {'ddpg': tonic.torch.agents.DDPG, 'd4pg': tonic.torch.agents.D4PG,
                'td3': tonic.torch.agents.TD3}[kind]
@@ -448,16 +456,22 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
                         for _ in range(iterations)])
     saved = torch.get_rng_state()
     torch.set_rng_state(captured['torch_state'])
-    draws = 2 if kind == 'sac' else 1
-    eps = np.array([[torch.randn(batch, act_dim).numpy() for _ in range(draws)]
-                    for _ in range(iterations)])
+    draws = 2 if kind in ('sac', 'mpo') else 1
+    if kind == 'mpo':       # rsample((S,)) of the critic step, sample((S,)) of the actor step
+        eps = np.array([[torch.randn(samples, batch, act_dim).numpy().reshape(-1, act_dim)
+                         for _ in range(draws)] for _ in range(iterations)])
+    else:
+        eps = np.array([[torch.randn(batch, act_dim).numpy() for _ in range(draws)]
+                        for _ in range(iterations)])
     torch.set_rng_state(saved)
     out.update(captured['pre'])
     out.update(captured['post'])
     for k, v in captured['buffers'].items():
         out['buffer/' + k] = v
     for k, v in captured['infos'].items():
-        if v.ndim == 2:
+        if k.startswith('actor/alpha'):
+            out['info/' + k] = v
+        elif v.ndim == 2:
             out['info/' + k + '_mean'] = v.mean(axis=1)
         else:
             out['info/' + k] = v
@@ -471,6 +485,7 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
                            loop_steps], np.int64)
     out['atoms'] = np.array(atoms, np.float64)
     out['return_steps'] = np.int64(return_steps)
+    out['samples'] = np.int64(samples)
     save(name, source='tonic/torch/agents/ddpg.py:45-112; td3.py:38-55; sac.py:40-51; '
                       'updaters/critics.py:125-235; updaters/actors.py:159-267; '
                       'replays/buffers.py:28-91', **out)
@@ -481,7 +496,10 @@ def main():
     tonic = rl.load_reference()
     if len(sys.argv) > 1:                    # regenerate only the named goldens
         for name in sys.argv[1:]:
-            if name == 'd4pg_small':
+            if name == 'mpo_small':
+                run_offpolicy(tonic, 'mpo_small', 'mpo', obs_dim=9, act_dim=3, workers=3,
+                              batch=20, seed=11, return_steps=2, samples=4)
+            elif name == 'd4pg_small':
                 run_offpolicy(tonic, 'd4pg_small', 'd4pg', obs_dim=8, act_dim=3, workers=3,
                               batch=20, seed=7, return_steps=3)
             elif name == 'ddpg_small':
@@ -547,6 +565,9 @@ def main():
     # D4PG (d4pg.py:21-37): 21-atom distributional critic, 3-step returns
     run_offpolicy(tonic, 'd4pg_small', 'd4pg', obs_dim=8, act_dim=3, workers=3, batch=20, seed=7,
                   return_steps=3)
+    # MPO (mpo.py:21-109): ExpectedSARSA + the MPO actor / dual step, 4 sampled actions per state
+    run_offpolicy(tonic, 'mpo_small', 'mpo', obs_dim=9, act_dim=3, workers=3, batch=20, seed=11,
+                  return_steps=2, samples=4)
 
 
 if __name__ == '__main__':

@@ -140,6 +140,7 @@ ACTOR_KEYS = {'sac': ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model
                       'torso.model.2.bias', 'head.action_layer.0.weight',
                       'head.action_layer.0.bias')}
 ACTOR_KEYS['ddpg'] = ACTOR_KEYS['d4pg'] = ACTOR_KEYS['td3']
+ACTOR_KEYS['mpo'] = ACTOR_KEYS['sac']
 CRITIC_KEYS = ('torso.model.0.weight', 'torso.model.0.bias', 'torso.model.2.weight',
                'torso.model.2.bias', 'head.v_layer.weight', 'head.v_layer.bias')
 DISTRIBUTIONAL_CRITIC_KEYS = CRITIC_KEYS[:4] + ('head.distributional_layer.weight',
@@ -168,9 +169,12 @@ class OffPolicyPort:
     and the iteration schedule of ``agents/ddpg.py:105-112`` / ``td3.py:38-47``."""
 
     def __init__(self, kind, state, prefix, delay_steps=2, entropy_coeff=0.2, target_coeff=0.005,
-                 atoms=None):
+                 atoms=None, samples=20):
         """kind 'd4pg' (agents/d4pg.py, critics.py:89-122, actors.py:192-224): `atoms` =
-        (vmin, vmax, count) of the DistributionalValueHead (models/critics.py:49-66)."""
+        (vmin, vmax, count) of the DistributionalValueHead (models/critics.py:49-66).
+        kind 'mpo' (agents/mpo.py, critics.py:238-282, actors.py:270-464): `samples` actions per
+        state; per-dimension KL constraints and action penalisation as in the defaults."""
+        self.samples = samples
         self.kind, self.delay, self.alpha, self.tau = kind, delay_steps, entropy_coeff, target_coeff
         critic_keys = DISTRIBUTIONAL_CRITIC_KEYS if kind == 'd4pg' else CRITIC_KEYS
         self.critic_keys = critic_keys
@@ -180,14 +184,22 @@ class OffPolicyPort:
         def grab(net, keys, grad):
             return [torch.tensor(state[f'{prefix}{net}.{k}'], requires_grad=grad) for k in keys]
         # DDPG (agents/ddpg.py, critics.py:56-86): ONE critic named `critic` / `target_critic`
-        self.critic_names = ('critic',) if kind in ('ddpg', 'd4pg') else ('critic_1', 'critic_2')
+        self.critic_names = (('critic',) if kind in ('ddpg', 'd4pg', 'mpo')
+                             else ('critic_1', 'critic_2'))
         self.actor = grab('actor', ACTOR_KEYS[kind], True)
         self.critics = [grab(n, critic_keys, True) for n in self.critic_names]
         self.target_actor = grab('target_actor', ACTOR_KEYS[kind], False)
         self.target_critics = [grab('target_' + n, critic_keys, False) for n in self.critic_names]
         self.mean = torch.tensor(state[prefix + 'observation_normalizer._mean'])
         self.std = torch.tensor(state[prefix + 'observation_normalizer._std'])
-        lr_actor, lr_critic = (3e-4, 3e-4) if kind == 'sac' else (1e-3, 1e-3)
+        lr_actor, lr_critic = (3e-4, 3e-4) if kind in ('sac', 'mpo') else (1e-3, 1e-3)
+        if kind == 'mpo':                                          # actors.py:300-316
+            A = self.actor[4].shape[0]
+            self.duals = [torch.nn.Parameter(torch.tensor([1.0])),
+                          torch.nn.Parameter(torch.full((A,), 1.0)),
+                          torch.nn.Parameter(torch.full((A,), 10.0)),
+                          torch.nn.Parameter(torch.tensor([1.0]))]
+            self.dual_opt = torch.optim.Adam(self.duals, lr=1e-2)
         self.actor_opt = torch.optim.Adam(self.actor, lr=lr_actor)
         self.critic_opt = torch.optim.Adam(sum(self.critics, []), lr=lr_critic)
 
@@ -214,11 +226,89 @@ class OffPolicyPort:
         log_probs = normal.log_prob(raw) - torch.log(1 - squashed ** 2 + 1e-6)
         return squashed, log_probs.sum(dim=-1)
 
+    def gaussian(self, p, observations):
+        """GaussianPolicyHead with its defaults (models/actors.py:69-98): tanh loc, softplus scale."""
+        h = self.torso(p, observations)
+        loc = torch.tanh(torch.nn.functional.linear(h, p[4], p[5]))
+        scale = torch.clamp(torch.nn.functional.softplus(
+            torch.nn.functional.linear(h, p[6], p[7])), 1e-4, 1)
+        return loc, scale
+
+    def sampled_values(self, observations, eps):
+        """S actions per state from the target actor, valued by the target critic -> [S, B]."""
+        loc, scale = self.gaussian(self.target_actor, observations)
+        S = self.samples
+        actions = loc + eps.view(S, -1, loc.shape[-1]) * scale
+        tiled = observations[None].expand(S, *observations.shape).reshape(-1, observations.shape[-1])
+        values = self.q(self.target_critics[0], tiled, actions.reshape(-1, loc.shape[-1]))
+        return loc, scale, actions, values.view(S, -1)
+
+    def mpo_actor_step(self, b, eps):
+        """actors.py:318-464, restated term by term."""
+        floor = torch.tensor(-18.0)
+        softplus = torch.nn.functional.softplus
+        with torch.no_grad():
+            for d in self.duals:
+                d.copy_(torch.maximum(floor, d))
+            loc_t, scale_t, actions, values = self.sampled_values(b['observations'], eps)
+        self.actor_opt.zero_grad()
+        self.dual_opt.zero_grad()
+        loc, scale = self.gaussian(self.actor, b['observations'])
+        temperature = softplus(self.duals[0]) + 1e-8
+        alpha_mean = softplus(self.duals[1]) + 1e-8
+        alpha_std = softplus(self.duals[2]) + 1e-8
+        penalty_temperature = softplus(self.duals[3]) + 1e-8
+        log_samples = torch.log(torch.tensor(float(self.samples)))
+
+        def e_step(scores, epsilon, temp):                         # actors.py:325-338
+            tempered = scores / temp
+            return (torch.softmax(tempered, dim=0).detach(),
+                    temp * (epsilon + torch.logsumexp(tempered, dim=0).mean() - log_samples))
+        weights, temperature_loss = e_step(values, 1e-1, temperature)
+        outside = actions - torch.clamp(actions, -1, 1)
+        penalty_weights, penalty_loss = e_step(-torch.norm(outside, dim=-1), 1e-3,
+                                               penalty_temperature)
+        weights = weights + penalty_weights
+        temperature_loss = temperature_loss + penalty_loss
+        normal = torch.distributions.normal.Normal
+        fixed_std, fixed_mean, target = normal(loc, scale_t), normal(loc_t, scale), normal(loc_t, scale_t)
+        policy_mean_loss = -(fixed_std.log_prob(actions).sum(-1) * weights).sum(0).mean()
+        policy_std_loss = -(fixed_mean.log_prob(actions).sum(-1) * weights).sum(0).mean()
+        kl_mean = torch.distributions.kl.kl_divergence(target, fixed_std).mean(0)
+        kl_std = torch.distributions.kl.kl_divergence(target, fixed_mean).mean(0)
+        kl_mean_loss = (alpha_mean.detach() * kl_mean).sum()
+        kl_std_loss = (alpha_std.detach() * kl_std).sum()
+        alpha_mean_loss = (alpha_mean * (1e-3 - kl_mean.detach())).sum()
+        alpha_std_loss = (alpha_std * (1e-6 - kl_std.detach())).sum()
+        loss = (policy_mean_loss + policy_std_loss + kl_mean_loss + kl_std_loss + alpha_mean_loss +
+                alpha_std_loss + temperature_loss)
+        loss.backward()
+        self.actor_opt.step()
+        self.dual_opt.step()
+        scalars = dict(policy_mean_loss=policy_mean_loss, policy_std_loss=policy_std_loss,
+                       kl_mean_loss=kl_mean_loss, kl_std_loss=kl_std_loss,
+                       alpha_mean_loss=alpha_mean_loss, alpha_std_loss=alpha_std_loss,
+                       temperature_loss=temperature_loss, temperature=temperature,
+                       penalty_temperature=penalty_temperature)
+        return dict({k: float(v.detach()) for k, v in scalars.items()},
+                    alpha_mean=alpha_mean.detach().numpy().copy(),
+                    alpha_std=alpha_std.detach().numpy().copy())
+
     def logits(self, p, observations, actions):
         x = torch.cat([(observations - self.mean) / self.std, actions], dim=-1)
         return torch.nn.functional.linear(self.torso(p, x), p[4], p[5])
 
     def critic_step(self, b, eps):
+        if self.kind == 'mpo':                                     # critics.py:253-282
+            with torch.no_grad():
+                _, _, _, next_values = self.sampled_values(b['next_observations'], eps)
+                returns = b['rewards'] + b['discounts'] * next_values.mean(dim=0)
+            self.critic_opt.zero_grad()
+            q = self.q(self.critics[0], b['observations'], b['actions'])
+            loss = torch.nn.functional.mse_loss(returns, q)
+            loss.backward()
+            self.critic_opt.step()
+            return dict(loss=float(loss.detach()), q1=float(q.detach().mean()), q2=0.0)
         if self.kind == 'd4pg':                                    # critics.py:100-122
             with torch.no_grad():
                 next_actions, _ = self.policy(self.target_actor, b['next_observations'], None)
@@ -266,6 +356,8 @@ class OffPolicyPort:
                     q2=float(q2.detach().mean()))
 
     def actor_step(self, b, eps):
+        if self.kind == 'mpo':
+            return self.mpo_actor_step(b, eps)
         self.actor_opt.zero_grad()
         actions, lp = self.policy(self.actor, b['observations'], eps)
         if self.kind == 'd4pg':                                    # actors.py:211-214
@@ -301,7 +393,7 @@ class OffPolicyPort:
                 'observations', 'actions', 'next_observations', 'rewards', 'discounts')}
             info = dict(critic=self.critic_step(b, torch.as_tensor(eps[it, 0])))
             if self.kind != 'td3' or (it + 1) % self.delay == 0:
-                actor_eps = torch.as_tensor(eps[it, 1]) if self.kind == 'sac' else None
+                actor_eps = torch.as_tensor(eps[it, 1]) if self.kind in ('sac', 'mpo') else None
                 info['actor'] = self.actor_step(b, actor_eps)
                 self.update_targets()
             infos.append(info)

@@ -117,9 +117,11 @@ def _agent_from_golden(g, kind):
     if kind == 'sac':
         head = tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                             distribution=tt.models.SquashedMultivariateNormalDiag)
+    elif kind == 'mpo':
+        head = tt.models.GaussianPolicyHead()
     else:
         head = tt.models.DeterministicPolicyHead()
-    container = (tt.models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg')
+    container = (tt.models.ActorCriticWithTargets if kind in ('ddpg', 'd4pg', 'mpo')
                  else tt.models.ActorTwinCriticWithTargets)
     model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
@@ -131,6 +133,12 @@ def _agent_from_golden(g, kind):
     if kind == 'sac':
         agent = tt.agents.SAC(model=model, replay=replay,
                               exploration=tonic_amd.explorations.NoActionNoise(start_steps=W * 5))
+    elif kind == 'mpo':
+        samples = int(g['samples'])
+        agent = tt.agents.MPO(
+            model=model, replay=replay,
+            actor_updater=tt.updaters.MaximumAPosterioriPolicyOptimization(num_samples=samples),
+            critic_updater=tt.updaters.ExpectedSARSA(num_samples=samples))
     else:
         cls = {'ddpg': tt.agents.DDPG, 'd4pg': tt.agents.D4PG, 'td3': tt.agents.TD3}[kind]
         agent = cls(model=model, replay=replay,
@@ -140,12 +148,13 @@ def _agent_from_golden(g, kind):
 
 
 OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg'),
-                   ('d4pg_small', 'd4pg')]
+                   ('d4pg_small', 'd4pg'), ('mpo_small', 'mpo')]
 
 
 @pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
 def test_offpolicy_update_matches_reference(lib, golden, name, kind):
     g = golden(name)
+    import tonic_amd.torch as tt
     agent = _agent_from_golden(g, kind)
     state = agent.model.state_dict()
     for key in state:       # identical initialisation from the same seed (CPU init parity)
@@ -164,16 +173,28 @@ def test_offpolicy_update_matches_reference(lib, golden, name, kind):
             agent.replay.buffers[k].copy_(dev(v))
     infos = agent.enqueue_update(g['indices'], g['eps']).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], g['info/critic/loss'], rtol=1e-5, atol=1e-5)
-    if kind == 'ddpg':
+    if kind in ('ddpg', 'mpo'):
         np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q_mean'], rtol=1e-5, atol=1e-5)
     elif kind == 'd4pg':
         pass                # DistributionalDeterministicQLearning logs the loss only (critics.py:122)
     else:
         np.testing.assert_allclose(infos[0][:, 1], g['info/critic/q1_mean'], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(infos[0][:, 2], g['info/critic/q2_mean'], rtol=1e-5, atol=1e-5)
-    ran = infos[1][:, 6] > 0
-    assert ran.sum() == len(g['info/actor/loss'])
-    np.testing.assert_allclose(infos[1][ran, 0], g['info/actor/loss'], rtol=1e-5, atol=1e-5)
+    if kind == 'mpo':            # the eleven logged values of actors.py:449-464, every iteration
+        stats = agent._mpo_stats.cpu().numpy()
+        A = agent.action_size
+        for i, key in enumerate(tt.updaters.MPO_INFO):
+            suffix = '_mean' if key.startswith('temperature') else ''
+            np.testing.assert_allclose(stats[:, i], g['info/actor/' + key + suffix], rtol=2e-5,
+                                       atol=2e-6, err_msg=key)
+        np.testing.assert_allclose(stats[:, 8:8 + A], g['info/actor/alpha_mean'], rtol=1e-5)
+        np.testing.assert_allclose(stats[:, 8 + A:8 + 2 * A], g['info/actor/alpha_std'], rtol=1e-5)
+        np.testing.assert_allclose(stats[:, 8 + 2 * A], g['info/actor/penalty_temperature_mean'],
+                                   rtol=1e-5)
+    else:
+        ran = infos[1][:, 6] > 0
+        assert ran.sum() == len(g['info/actor/loss'])
+        np.testing.assert_allclose(infos[1][ran, 0], g['info/actor/loss'], rtol=1e-5, atol=1e-5)
     after = agent.model.state_dict()
     for key, start in before.items():
         if 'normalizer' in key:
@@ -217,7 +238,8 @@ def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
 
 
 @pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100),
-                                          ('ddpg', 17, 6, 4, 100), ('d4pg', 24, 6, 4, 256)])
+                                          ('ddpg', 17, 6, 4, 100), ('d4pg', 24, 6, 4, 256),
+                                          ('mpo', 24, 6, 4, 100)])
 def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     """cfg-3 (SAC, O=111, A=8, B=1024) and cfg-4 per-GPU (TD3, O=67, A=21, 64 workers, the
     reference's default B=100) shapes with the default 256-wide networks: two learner iterations
@@ -231,7 +253,7 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     rows = 64
     replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
     agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG,
-                 d4pg=tt.agents.D4PG)[kind](replay=replay)    # (d4pg: default 51 atoms on +-150)
+                 d4pg=tt.agents.D4PG, mpo=tt.agents.MPO)[kind](replay=replay)    # (d4pg: 51 atoms on +-150)
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
     # make the normaliser non-trivial
     norm = agent.model.observation_normalizer
@@ -247,17 +269,27 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
         replay.store(**{k: dev(v[t]) for k, v in host.items()})
     host['discounts'] = port.buffer_discounts(host['terminations'] != 0, 0.99)
     indices = replay.sample_indices()
-    draws = 2 if kind == 'sac' else 1
-    eps = rng.normal(size=(2, draws, B, A)).astype(np.float32)
+    draws = 2 if kind in ('sac', 'mpo') else 1
+    eps = rng.normal(size=(2, draws, B * (20 if kind == 'mpo' else 1), A)).astype(np.float32)
     oracle = torch_port.OffPolicyPort(kind, state, 'pre/', atoms=(-150., 150., 51))
     want = oracle.update(host, W, indices, eps)
     infos = agent.enqueue_update(indices, eps).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], [i['critic']['loss'] for i in want], rtol=1e-5, atol=1e-5)
     if kind != 'd4pg':
         np.testing.assert_allclose(infos[0][:, 1], [i['critic']['q1'] for i in want], rtol=1e-5, atol=1e-5)
-    ran = infos[1][:, 6] > 0
-    np.testing.assert_allclose(infos[1][ran, 0], [i['actor']['loss'] for i in want if 'actor' in i],
-                               rtol=1e-5, atol=1e-5)
+    if kind == 'mpo':
+        stats = agent._mpo_stats.cpu().numpy()
+        for i, key in enumerate(tt.updaters.MPO_INFO):
+            np.testing.assert_allclose(stats[:, i], [w['actor'][key] for w in want], rtol=2e-5,
+                                       atol=2e-6, err_msg=key)
+        np.testing.assert_allclose(agent.actor_updater.duals.cpu().numpy(),
+                                   np.concatenate([d.detach().numpy() for d in oracle.duals]),
+                                   rtol=0, atol=1e-6)
+    else:
+        ran = infos[1][:, 6] > 0
+        np.testing.assert_allclose(infos[1][ran, 0],
+                                   [i['actor']['loss'] for i in want if 'actor' in i],
+                                   rtol=1e-5, atol=1e-5)
     after = agent.model.state_dict()
     for key, value in oracle.state().items():
         got = after[key].detach().cpu().numpy() - state['pre/' + key]

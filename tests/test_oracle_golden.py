@@ -308,7 +308,8 @@ def test_c_restatement_matches_golden(golden):
 
 
 @pytest.mark.parametrize('name,kind', [('sac_small', 'sac'), ('td3_small', 'td3'),
-                                       ('ddpg_small', 'ddpg'), ('d4pg_small', 'd4pg')])
+                                       ('ddpg_small', 'ddpg'), ('d4pg_small', 'd4pg'),
+                                       ('mpo_small', 'mpo')])
 def test_offpolicy_port_matches_reference(golden, name, kind):
     """oracle/torch_port.OffPolicyPort replays the reference's first SAC / TD3 update from the
     golden buffer, index stream and normal draws (this also pins the RNG bookkeeping)."""
@@ -319,21 +320,31 @@ def test_offpolicy_port_matches_reference(golden, name, kind):
     workers = int(g['cfg'][2])
     state = {k: g[k] for k in g.files}
     port_ = torch_port.OffPolicyPort(kind, state, 'pre/',
-                                     atoms=g['atoms'] if kind == 'd4pg' else None)
+                                     atoms=g['atoms'] if kind == 'd4pg' else None,
+                                     samples=int(g['samples']) if kind == 'mpo' else 20)
     buffers = {k[len('buffer/'):]: g[k] for k in g.files if k.startswith('buffer/')}
     # Buffer.store semantics (buffers.py:33-56): discounts, NaN padding beyond `size`
     size = int(g['buffer_size'])
-    if kind != 'd4pg':            # (d4pg_small: 3-step returns, discounts accumulated, buffers.py:58-79)
+    if kind not in ('d4pg', 'mpo'):   # (those: n-step returns, discounts accumulated, buffers.py:58-79)
         assert np.array_equal(buffers['discounts'][:size],
                               port.buffer_discounts(buffers['terminations'][:size] != 0, 0.99))
     assert np.isnan(buffers['rewards'][size:]).all()
     infos = port_.update(buffers, workers, g['indices'], g['eps'])
     np.testing.assert_allclose([i['critic']['loss'] for i in infos], g['info/critic/loss'], rtol=1e-6)
     if kind != 'd4pg':
-        q_key = 'info/critic/q_mean' if kind == 'ddpg' else 'info/critic/q1_mean'
+        q_key = 'info/critic/q_mean' if kind in ('ddpg', 'mpo') else 'info/critic/q1_mean'
         np.testing.assert_allclose([i['critic']['q1'] for i in infos], g[q_key], rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose([i['actor']['loss'] for i in infos if 'actor' in i],
-                               g['info/actor/loss'], rtol=1e-5, atol=1e-7)
+    if kind == 'mpo':
+        for key in ('policy_mean_loss', 'policy_std_loss', 'kl_mean_loss', 'kl_std_loss',
+                    'alpha_mean_loss', 'alpha_std_loss', 'alpha_mean', 'alpha_std'):
+            np.testing.assert_allclose([i['actor'][key] for i in infos], g['info/actor/' + key],
+                                       rtol=1e-5, atol=1e-7, err_msg=key)
+        for key in ('temperature_loss', 'temperature', 'penalty_temperature'):
+            np.testing.assert_allclose([i['actor'][key] for i in infos],
+                                       g['info/actor/' + key + '_mean'], rtol=1e-5, err_msg=key)
+    else:
+        np.testing.assert_allclose([i['actor']['loss'] for i in infos if 'actor' in i],
+                                   g['info/actor/loss'], rtol=1e-5, atol=1e-7)
     for key, value in port_.state().items():
         np.testing.assert_allclose(value, g['post/' + key], rtol=0, atol=1e-7, err_msg=key)
 

@@ -101,7 +101,7 @@ def test_install_puts_the_collector_under_the_reference_cli(tmp_path, monkeypatc
     assert (tmp_path / 'env' / 'run' / '3' / 'log.csv').exists()
 
 
-@pytest.mark.parametrize('name', ['PPO', 'A2C', 'TRPO', 'SAC', 'TD3', 'DDPG', 'D4PG'])
+@pytest.mark.parametrize('name', ['PPO', 'A2C', 'TRPO', 'SAC', 'TD3', 'DDPG', 'D4PG', 'MPO'])
 def test_reference_agents_load_this_packages_checkpoints(tmp_path, name):
     """tonic/torch/agents/agent.py:23-26: the reference agent's strict load_state_dict accepts a
     `.pt` written by this package's Agent.save (same keys, same shapes)."""

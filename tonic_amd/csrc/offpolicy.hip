@@ -250,6 +250,191 @@ __global__ void loss_stats_kernel(const float* loss_m, float* stats, int B) {
   }
 }
 
+// ---- MPO (agents/mpo.py; updaters/critics.py:238-282, updaters/actors.py:270-464)
+// GaussianPolicyHead (models/actors.py:69-98): loc = tanh(.) (applied by the forward), sigma =
+// clamp(softplus(spre), 1e-4, 1).
+__device__ __forceinline__ float gaussian_sigma(float spre) {
+  return fminf(fmaxf(softplus_f(spre), 1e-4f), 1.0f);
+}
+
+// Normal.sample / rsample: a = loc + sigma * eps (eps == null: the greedy loc, mpo.py:82-85)
+__global__ void gaussian_sample_kernel(const float* loc, const float* spre, const float* eps,
+                                       int ld, float* act, int B, int A) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  const int m = idx / A, a = idx - m * A;
+  const float l = loc[(int64_t)m * ld + a];
+  act[idx] = eps ? l + gaussian_sigma(spre[(int64_t)m * ld + a]) * eps[idx] : l;
+}
+
+// S samples per state, tiled like updaters.tile + merge_first_two_dims (row s * B + m):
+//   act[s, m] = loc[m] + sigma[m] * eps[s, m] ;  X[s * B + m] = [ norm(obs[m]) | act[s, m] ]
+__global__ void gaussian_tile_kernel(const float* obs, const float* loc, const float* spre,
+                                     const float* eps, int ldh, const float* mean,
+                                     const float* std, float clip, float* act, float* X, int B,
+                                     int O, int A, int S, int ldx) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)S * B * (O + A)) return;
+  const int64_t r = idx / (O + A);
+  const int c = (int)(idx - r * (O + A));
+  const int m = (int)(r % B);
+  if (c < O) {
+    X[r * ldx + c] = __builtin_amdgcn_fmed3f((obs[(int64_t)m * O + c] - mean[c]) / std[c], -clip, clip);
+  } else {
+    const int a = c - O;
+    const float v = loc[(int64_t)m * ldh + a] + gaussian_sigma(spre[(int64_t)m * ldh + a]) * eps[r * A + a];
+    act[r * A + a] = v;
+    X[r * ldx + c] = v;
+  }
+}
+
+// next_values.view(S, -1).mean(dim=0) (critics.py:269-270)
+__global__ void sample_mean_kernel(const float* q, float* out, int B, int S) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= B) return;
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += q[(int64_t)s * B + m];
+  out[m] = sum / (float)S;
+}
+
+constexpr int kMpoMaxSamples = 64;
+constexpr int kMpoStats = 16;    // per-state partials: see mpo_state_kernel
+
+// duals [2 A + 2] = {log_temperature, log_alpha_mean[A], log_alpha_std[A], log_penalty_temperature}
+// (actors.py:300-316, per_dim_constraining); value = softplus(log) + 1e-8 (actors.py:378-383)
+__device__ __forceinline__ float dual_value(float log_dual) { return softplus_f(log_dual) + 1e-8f; }
+
+// E-step weights and the M-step gradients at the head outputs, one state per thread
+// (actors.py:384-432).  SUMS over the batch (the optimizer step divides by B):
+//   d/d loc   = -sum_s W_s (a_s - loc) / sigma_t^2 + alpha_mean (loc - loc_t) / sigma_t^2
+//   d/d sigma = -sum_s W_s ((a_s - loc_t)^2 / sigma^3 - 1 / sigma) + alpha_std (1 / sigma - sigma_t^2 / sigma^3)
+// with W = softmax_s(q / T) + softmax_s(bound cost / T_penalty).  part[m][.] = {policy_mean, policy_std,
+// LSE, sum_s w q / T, LSE_penalty, sum_s w_p cost / T_p}; klm / kls [m][a] = the per-dimension KLs.
+__global__ void mpo_state_kernel(const float* q, const float* act, const float* loc_t,
+                                 const float* spre_t, const float* loc, const float* spre, int ldh,
+                                 const float* duals, int penalize, float* dloc, float* dspre,
+                                 float* part, float* klm, float* kls, int B, int A, int S) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= B) return;
+  const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
+  float w[kMpoMaxSamples];
+  // weights_and_temperature_loss (actors.py:325-338): softmax over the samples of q / T
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) { w[s] = q[(int64_t)s * B + m] / T; mx = fmaxf(mx, w[s]); }
+  float sum = 0.f, wq = 0.f;
+  for (int s = 0; s < S; ++s) sum += expf(w[s] - mx);
+  const float lse = mx + logf(sum);
+  for (int s = 0; s < S; ++s) { const float t = w[s]; w[s] = expf(t - mx) / sum; wq += w[s] * t; }
+  float lse_p = 0.f, wc = 0.f;
+  if (penalize) {                                              // actors.py:388-398
+    float cost[kMpoMaxSamples];
+    float mp = -INFINITY;
+    for (int s = 0; s < S; ++s) {
+      float n2 = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float v = act[((int64_t)s * B + m) * A + a];
+        const float d = v - fminf(fmaxf(v, -1.f), 1.f);
+        n2 += d * d;
+      }
+      cost[s] = -sqrtf(n2) / Tp;
+      mp = fmaxf(mp, cost[s]);
+    }
+    float sp = 0.f;
+    for (int s = 0; s < S; ++s) sp += expf(cost[s] - mp);
+    lse_p = mp + logf(sp);
+    for (int s = 0; s < S; ++s) {
+      const float wp = expf(cost[s] - mp) / sp;
+      wc += wp * cost[s];
+      w[s] += wp;
+    }
+  }
+  float pm = 0.f, ps = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float lt = loc_t[(int64_t)m * ldh + a], st = gaussian_sigma(spre_t[(int64_t)m * ldh + a]);
+    const float lo = loc[(int64_t)m * ldh + a], pre = spre[(int64_t)m * ldh + a];
+    const float sg = gaussian_sigma(pre);
+    float g_loc = 0.f, g_sigma = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float v = act[((int64_t)s * B + m) * A + a];
+      const float d_mean = v - lo, d_std = v - lt;
+      // Normal.log_prob: -(x - mu)^2 / (2 var) - log(sigma) - log(sqrt(2 pi))
+      pm += w[s] * (-(d_mean * d_mean) / (2.f * (st * st)) - logf(st) - kHalfLog2Pi);
+      ps += w[s] * (-(d_std * d_std) / (2.f * (sg * sg)) - logf(sg) - kHalfLog2Pi);
+      g_loc -= w[s] * d_mean / (st * st);
+      g_sigma -= w[s] * (d_std * d_std / (sg * sg * sg) - 1.f / sg);
+    }
+    // kl_divergence(Normal(lt, st), Normal(lo, st)) and (.., Normal(lt, sg)) (actors.py:416-421)
+    const float ratio = st / sg;
+    const float kl_mean = 0.5f * ((lt - lo) / st) * ((lt - lo) / st);
+    const float kl_std = 0.5f * (ratio * ratio - 1.f - logf(ratio * ratio));
+    klm[(int64_t)m * A + a] = kl_mean;
+    kls[(int64_t)m * A + a] = kl_std;
+    const float alpha_mean = dual_value(duals[1 + a]), alpha_std = dual_value(duals[1 + A + a]);
+    g_loc += alpha_mean * (lo - lt) / (st * st);
+    g_sigma += alpha_std * (1.f / sg - st * st / (sg * sg * sg));
+    const float raw = softplus_f(pre);
+    const bool inside = raw >= 1e-4f && raw <= 1.0f;
+    dloc[(int64_t)m * ldh + a] = g_loc * (1.f - lo * lo);                  // tanh loc head
+    dspre[(int64_t)m * ldh + a] = inside ? g_sigma / (1.f + expf(-pre)) : 0.f;
+  }
+  float* out = part + (int64_t)m * kMpoStats;
+  out[0] = pm; out[1] = ps; out[2] = lse; out[3] = wq; out[4] = lse_p; out[5] = wc;
+}
+
+// Batch means -> the logged losses, the dual variables' values and their gradients (one workgroup).
+// stats [7 + 2 A + 2] = {policy_mean_loss, policy_std_loss, kl_mean_loss, kl_std_loss, alpha_mean_loss,
+// alpha_std_loss, temperature_loss, temperature, alpha_mean[A], alpha_std[A], penalty_temperature};
+// dual_grads [2 A + 2 + 8]: d loss / d log-duals + the statistics slot of the optimizer step.
+__global__ void mpo_dual_kernel(const float* part, const float* klm, const float* kls,
+                                const float* duals, int penalize, float epsilon,
+                                float epsilon_penalty, float epsilon_mean, float epsilon_std,
+                                float* dual_grads, float* stats, float* actor_stats, int B, int A,
+                                int S) {
+  __shared__ double col[2 * 64 + 6];
+  const int tid = threadIdx.x;
+  // column sums in fixed order: threads 0..5 the six partials, 6..6+A-1 kl_mean, then kl_std
+  const int columns = 6 + 2 * A;
+  if (tid < columns) {
+    double sum = 0;
+    for (int m = 0; m < B; ++m)
+      sum += tid < 6 ? part[(int64_t)m * kMpoStats + tid]
+                     : tid < 6 + A ? klm[(int64_t)m * A + (tid - 6)] : kls[(int64_t)m * A + (tid - 6 - A)];
+    col[tid] = sum / B;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
+  const float log_S = logf((float)S);
+  auto sigmoid = [](float x) { return 1.f / (1.f + expf(-x)); };
+  float kl_mean_loss = 0.f, kl_std_loss = 0.f, alpha_mean_loss = 0.f, alpha_std_loss = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float am = dual_value(duals[1 + a]), as = dual_value(duals[1 + A + a]);
+    const float km = (float)col[6 + a], ks = (float)col[6 + A + a];
+    kl_mean_loss += am * km; kl_std_loss += as * ks;                      // actors.py:319-323
+    alpha_mean_loss += am * (epsilon_mean - km);
+    alpha_std_loss += as * (epsilon_std - ks);
+    dual_grads[1 + a] = (epsilon_mean - km) * sigmoid(duals[1 + a]);
+    dual_grads[1 + A + a] = (epsilon_std - ks) * sigmoid(duals[1 + A + a]);
+    stats[8 + a] = am; stats[8 + A + a] = as;
+  }
+  // temperature * (epsilon + mean(logsumexp) - log S): d / dT = epsilon + mean(LSE) - log S - mean(sum_s w q / T)
+  float temperature_loss = T * (epsilon + (float)col[2] - log_S);
+  dual_grads[0] = (epsilon + (float)col[2] - log_S - (float)col[3]) * sigmoid(duals[0]);
+  dual_grads[2 * A + 1] = 0.f;
+  if (penalize) {
+    temperature_loss += Tp * (epsilon_penalty + (float)col[4] - log_S);
+    dual_grads[2 * A + 1] =
+        (epsilon_penalty + (float)col[4] - log_S - (float)col[5]) * sigmoid(duals[2 * A + 1]);
+  }
+  for (int i = 0; i < 8; ++i) dual_grads[2 * A + 2 + i] = i == 5 ? 1.f : 0.f;
+  stats[0] = -(float)col[0]; stats[1] = -(float)col[1]; stats[2] = kl_mean_loss; stats[3] = kl_std_loss;
+  stats[4] = alpha_mean_loss; stats[5] = alpha_std_loss; stats[6] = temperature_loss; stats[7] = T;
+  stats[8 + 2 * A] = Tp;
+  // the actor's statistics slot {loss_sum = B * (policy losses + KL losses), 0, 0, 0, 0, B, 0, 0}
+  actor_stats[0] = (float)B * (stats[0] + stats[1] + kl_mean_loss + kl_std_loss);
+  for (int i = 1; i < 8; ++i) actor_stats[i] = i == 5 ? (float)B : 0.f;
+}
+
 // Back through the squashed Gaussian head (SAC) or the tanh head (TD3).
 //   da[m][a] = d loss / d action (the action columns of the critics' input gradients, [B, pad16(A)])
 // SAC: u = loc + sigma eps, a = tanh(u):
@@ -670,12 +855,19 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
   const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
+  const int threads = 256;
+  if (kind == 2) {       // Gaussian head with a tanh loc (MPO, mpo.py:77-85): a = loc + sigma * eps
+    TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, true, st));
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
+                       0, st, head0, head1, d_eps, ldh, d_actions, B, A);
+    TONIC_CHECK_LAUNCH("tonic_policy_forward");
+    return TONIC_OK;
+  }
   PolicyTail tail{};
   tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = d_eps; tail.actions = d_actions;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, kind == 0, st,
                     &tail, &tail_done));
-  const int threads = 256;
   if (tail_done) {
   } else if (kind == 0) {
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
@@ -973,6 +1165,125 @@ extern "C" int tonic_distributional_actor_grad(
   TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, w.a_h1, w.a_h2, w.dloc,
                             nullptr, ldh, w.da_h2, w.da_h1, d_grad_sums, nullptr, 0, 0, st));
   TONIC_CHECK_LAUNCH("tonic_distributional_actor_grad");
+  return TONIC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------- MPO
+namespace {
+
+struct MpoBuffers {
+  float *a_h1, *a_h2, *loc_t, *spre_t, *loc, *spre, *o_h1, *o_h2, *act, *X, *X2, *t_h1, *t_h2, *tq,
+      *tq_mean, *c_h1, *c_h2, *q, *dq, *dh2, *dh1, *dloc, *dspre, *da_h2, *da_h1, *part, *klm, *kls;
+  static int64_t floats(int B, int S, int HP, int ldh, int ldx, int A) {
+    const int64_t Bp = pad16(B), Rp = pad16(S * B);
+    return 4 * Bp * HP + 4 * Bp * ldh + Rp * A + Rp * ldx + Bp * ldx + 2 * Rp * HP + Rp + Bp +
+           2 * Bp * HP + 2 * Bp + 2 * Bp * HP + 2 * Bp * ldh + 2 * Bp * HP + Bp * kMpoStats +
+           2 * Bp * A + 64 * 32;
+  }
+  MpoBuffers(void* d_workspace, int64_t bytes, int B, int S, int HP, int ldh, int ldx, int A) {
+    Workspace ws{static_cast<char*>(d_workspace), 0, bytes};
+    const int64_t Bp = pad16(B), Rp = pad16(S * B), hid = Bp * HP;
+    a_h1 = ws.take(hid); a_h2 = ws.take(hid); o_h1 = ws.take(hid); o_h2 = ws.take(hid);
+    loc_t = ws.take(Bp * ldh); spre_t = ws.take(Bp * ldh); loc = ws.take(Bp * ldh);
+    spre = ws.take(Bp * ldh);
+    act = ws.take(Rp * A); X = ws.take(Rp * ldx); X2 = ws.take(Bp * ldx);
+    t_h1 = ws.take(Rp * HP); t_h2 = ws.take(Rp * HP); tq = ws.take(Rp); tq_mean = ws.take(Bp);
+    c_h1 = ws.take(hid); c_h2 = ws.take(hid); q = ws.take(Bp); dq = ws.take(Bp);
+    dh2 = ws.take(hid); dh1 = ws.take(hid);
+    dloc = ws.take(Bp * ldh); dspre = ws.take(Bp * ldh); da_h2 = ws.take(hid); da_h1 = ws.take(hid);
+    part = ws.take(Bp * kMpoStats); klm = ws.take(Bp * A); kls = ws.take(Bp * A);
+  }
+};
+
+// target_actor(obs) -> S sampled actions per state -> target_critic on the tiled rows: tq [S * B]
+int mpo_sampled_values(const float* d_target_actor, const float* d_target_critic,
+                       const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+                       const float* d_obs, const float* d_eps, int B, int O, int H, int A, int S,
+                       const MpoBuffers& w, hipStream_t st) {
+  const int ldx = pitch16(O + A), ldh = pad16(A), threads = 256;
+  const ActorShape as{O, H, A, 2};
+  TRY(actor_forward(d_target_actor, as, d_obs, B, w.a_h1, w.a_h2, w.loc_t, w.spre_t, ldh, true, st));
+  const int64_t items = (int64_t)S * B * (O + A);
+  hipLaunchKernelGGL(gaussian_tile_kernel, dim3((unsigned)((items + threads - 1) / threads)),
+                     dim3(threads), 0, st, d_obs, w.loc_t, w.spre_t, d_eps, ldh, d_norm_mean,
+                     d_norm_std, clip_bound(norm_clip), w.act, w.X, B, O, A, S, ldx);
+  return critics_forward(d_target_critic, CriticShape{O, A, H}, 1, w.X, ldx, S * B, pad16(S * B),
+                         w.t_h1, w.t_h2, w.tq, st);
+}
+
+}  // namespace
+
+extern "C" int64_t tonic_mpo_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H, int32_t S) {
+  return MpoBuffers::floats(B, S, weight_ld(H), pad16(A), pitch16(O + A), A) * 4;
+}
+
+extern "C" int tonic_expected_sarsa_grad(
+    const float* d_target_actor, const float* d_target_critic, const float* d_critic,
+    const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    const float* d_observations, const float* d_actions, const float* d_next_observations,
+    const float* d_rewards, const float* d_discounts, const float* d_eps, float* d_grad_sums,
+    int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, void* d_workspace,
+    int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_target_actor && d_target_critic && d_critic && d_norm_mean && d_norm_std &&
+                    d_observations && d_actions && d_next_observations && d_rewards &&
+                    d_discounts && d_eps && d_grad_sums && d_workspace && B > 0 && S >= 1 &&
+                    S <= kMpoMaxSamples,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_expected_sarsa_grad: bad argument (1 <= samples <= 64)");
+  TONIC_REQUIRE(workspace_bytes >= tonic_mpo_workspace_bytes(B, O, A, H, S), TONIC_ERR_WORKSPACE,
+                "tonic_expected_sarsa_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pitch16(O + A), threads = 256;
+  const MpoBuffers w(d_workspace, workspace_bytes, B, S, weight_ld(H), pad16(A), ldx, A);
+  const CriticShape cs{O, A, H};
+  TRY(mpo_sampled_values(d_target_actor, d_target_critic, d_norm_mean, d_norm_std, norm_clip,
+                         d_next_observations, d_eps, B, O, H, A, S, w, st));
+  hipLaunchKernelGGL(sample_mean_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st,
+                     w.tq, w.tq_mean, B, S);
+  hipLaunchKernelGGL(encode_kernel, dim3((B * (O + A) + threads - 1) / threads), dim3(threads), 0,
+                     st, d_observations, d_actions, d_norm_mean, d_norm_std, clip_bound(norm_clip),
+                     w.X2, B, O, A, ldx);
+  TRY(critics_forward(d_critic, cs, 1, w.X2, ldx, B, Bp, w.c_h1, w.c_h2, w.q, st));
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts,
+                     w.tq_mean, (const float*)nullptr, 0.f, w.q, w.dq,
+                     d_grad_sums + critic_count(cs), B, Bp, 1);
+  TRY(critics_backward(d_critic, cs, 1, w.X2, ldx, B, Bp, w.c_h1, w.c_h2, w.dq, w.dh2, w.dh1,
+                       d_grad_sums, nullptr, st));
+  TONIC_CHECK_LAUNCH("tonic_expected_sarsa_grad");
+  return TONIC_OK;
+}
+
+extern "C" int tonic_mpo_actor_grad(
+    const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
+    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    const float* d_observations, const float* d_eps, float* d_grad_sums, float* d_dual_grads,
+    float* d_stats, int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, double epsilon,
+    double epsilon_penalty, double epsilon_mean, double epsilon_std, int32_t action_penalization,
+    void* d_workspace, int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_target_actor && d_target_critic && d_duals && d_norm_mean &&
+                    d_norm_std && d_observations && d_eps && d_grad_sums && d_dual_grads &&
+                    d_stats && d_workspace && B > 0 && S >= 1 && S <= kMpoMaxSamples && A <= 64,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_mpo_actor_grad: bad argument");
+  TONIC_REQUIRE(workspace_bytes >= tonic_mpo_workspace_bytes(B, O, A, H, S), TONIC_ERR_WORKSPACE,
+                "tonic_mpo_actor_grad: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int ldh = pad16(A), threads = 64;
+  const MpoBuffers w(d_workspace, workspace_bytes, B, S, weight_ld(H), ldh, pitch16(O + A), A);
+  const ActorShape as{O, H, A, 2};
+  TRY(mpo_sampled_values(d_target_actor, d_target_critic, d_norm_mean, d_norm_std, norm_clip,
+                         d_observations, d_eps, B, O, H, A, S, w, st));
+  TRY(actor_forward(d_actor_params, as, d_observations, B, w.o_h1, w.o_h2, w.loc, w.spre, ldh, true,
+                    st));
+  hipLaunchKernelGGL(mpo_state_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st, w.tq,
+                     w.act, w.loc_t, w.spre_t, w.loc, w.spre, ldh, d_duals, action_penalization,
+                     w.dloc, w.dspre, w.part, w.klm, w.kls, B, A, S);
+  hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(192), 0, st, w.part, w.klm, w.kls, d_duals,
+                     action_penalization, (float)epsilon, (float)epsilon_penalty,
+                     (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats,
+                     d_grad_sums + actor_count(as), B, A, S);
+  TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, w.o_h1, w.o_h2, w.dloc,
+                            w.dspre, ldh, w.da_h2, w.da_h1, d_grad_sums, nullptr, 0, 0, st));
+  TONIC_CHECK_LAUNCH("tonic_mpo_actor_grad");
   return TONIC_OK;
 }
 

@@ -682,23 +682,23 @@ class DDPG(Agent):
         def enqueue():
             self._infos.zero_()
             draws = self._static_eps.shape[1]
+            per_sample = self._static_eps.shape[2] // global_batch     # (MPO: num_samples rows each)
             for it in range(iterations):
                 c = global_batch if counts is None else int(counts[it])
                 n_global = None if counts is None else global_batch
                 if c > 0:
                     batch = self.replay.gather(self._static_indices[it, :c])
-                    self.critic_updater.enqueue(batch, self._static_eps[it, 0, :c],
+                    self.critic_updater.enqueue(batch, self._static_eps[it, 0, :c * per_sample],
                                                 self._infos[0, it], n_global)
                 else:
                     self.critic_updater.enqueue_empty(self._infos[0, it], n_global)
                 if self._actor_due(it):
-                    actor_eps = self._static_eps[it, 1, :c] if draws > 1 else None
+                    actor_eps = self._static_eps[it, 1, :c * per_sample] if draws > 1 else None
                     # update_targets() (ddpg.py:112) rides in the actor's optimizer launch
                     targets = (self.model.flat_target, self.model.flat_online, 0,
                                self.model.target_coeff)
                     if c > 0:
-                        self.actor_updater.enqueue(batch['observations'], actor_eps,
-                                                   self._infos[1, it], n_global, targets)
+                        self._enqueue_actor(batch['observations'], actor_eps, it, n_global, targets)
                     else:
                         self.actor_updater.enqueue_empty(self._infos[1, it], n_global, targets)
 
@@ -716,6 +716,9 @@ class DDPG(Agent):
                 enqueue()
         self._graph.replay()
         return self._infos
+
+    def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
+        self.actor_updater.enqueue(observations, eps, self._infos[1, iteration], n_global, targets)
 
     def _graph_signature(self):
         parts = []
@@ -778,6 +781,77 @@ class D4PG(DDPG):
             model or _d4pg_model(), replay or replays.Buffer(return_steps=5), exploration,
             actor_updater or updaters.DistributionalDeterministicPolicyGradient(),
             critic_updater or updaters.DistributionalDeterministicQLearning())
+
+
+def _mpo_model():
+    """tonic/torch/agents/mpo.py:7-18."""
+    return models.ActorCriticWithTargets(
+        actor=models.Actor(
+            encoder=models.ObservationEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.GaussianPolicyHead()),
+        critic=models.Critic(
+            encoder=models.ObservationActionEncoder(),
+            torso=models.MLP((256, 256), torch.nn.ReLU), head=models.ValueHead()),
+        observation_normalizer=normalizers.MeanStd())
+
+
+class MPO(DDPG):
+    """tonic/torch/agents/mpo.py:21-109: acts by sampling the Gaussian policy (no exploration
+    object), stores 5-step returns, and per batch runs ExpectedSARSA, the MPO actor / dual step
+    and the target update — DDPG's staging, HBM Buffer, hipGraph capture and schedule."""
+
+    policy_kind = 2
+
+    def __init__(self, model=None, replay=None, actor_updater=None, critic_updater=None):
+        super().__init__(
+            model or _mpo_model(), replay or replays.Buffer(return_steps=5),
+            explorations.NoActionNoise(start_steps=0),
+            actor_updater or updaters.MaximumAPosterioriPolicyOptimization(),
+            critic_updater or updaters.ExpectedSARSA())
+
+    def step(self, observations, steps):
+        actions = self._forward_policy(observations, 2, True)       # mpo.py:38-46, 77-80
+        self.last_observations = observations.copy()
+        self.last_actions = actions.copy()
+        return actions
+
+    def _draw_noise(self, iterations):
+        # per iteration: rsample((S,)) of ExpectedSARSA (critics.py:260), then sample((S,)) of the
+        # actor step (actors.py:359) — [S, B, A] standard normals each, kept as [S * B, A]
+        B, A = self.replay.batch_size, self.action_size
+        S_c, S_a = self.critic_updater.num_samples, self.actor_updater.num_samples
+        if S_c != S_a:
+            raise NotImplementedError('ExpectedSARSA and MPO must draw the same number of samples')
+        return np.stack([np.stack([torch.randn(S_c, B, A).numpy().reshape(S_c * B, A),
+                                   torch.randn(S_a, B, A).numpy().reshape(S_a * B, A)])
+                         for _ in range(iterations)])
+
+    def enqueue_update(self, indices, eps, graph=None):
+        width = 9 + 2 * self.action_size
+        if getattr(self, '_mpo_stats', None) is None or self._mpo_stats.shape[0] != indices.shape[0]:
+            self._mpo_stats = torch.zeros(indices.shape[0], width, device=self.device)
+            self._graph = None
+        return super().enqueue_update(indices, eps, graph)
+
+    def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
+        self.actor_updater.enqueue(observations, eps, self._infos[1, iteration], n_global, targets,
+                                   stats_row=self._mpo_stats[iteration])
+
+    def _update(self, steps):
+        replay = self.replay
+        indices = replay.sample_indices()
+        eps = self._draw_noise(indices.shape[0])
+        infos = self.enqueue_update(indices, eps).cpu().numpy()
+        stats = self._mpo_stats.cpu().numpy()
+        replay.last_steps = steps
+        for row, actor_row in zip(infos[0], stats):                 # mpo.py:92-97
+            logger.store('critic/loss', row[0])
+            logger.store('critic/q', row[1])
+            for key, value in self.actor_updater.infos(actor_row).items():
+                logger.store('actor/' + key, value)
+        self.last_infos, self.last_actor_infos = infos, stats
+        if self.model.observation_normalizer:
+            self.model.observation_normalizer.update()
 
 
 class TD3(DDPG):
