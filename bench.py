@@ -71,10 +71,10 @@ DTYPE = 'f32 (64x64 products of the grad kernels bf16x3-emulated: exact 3-term s
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: FETCH_SIZE
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json: FETCH_SIZE
     and WRITE_SIZE collected separately, gfx950 read correction applied) — PMC counters cannot be
     collected from inside the timed run, so the summary of the same kernels is quoted."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_traffic.json')
     try:
         with open(path) as f:
             table = json.load(f)['kernels']
@@ -82,7 +82,7 @@ def pmc_traffic(prefix):
     except (OSError, StopIteration, KeyError, ValueError):
         return dict(traffic=None)
     return dict(traffic=entry['read_bytes'] + entry['write_bytes'], traffic_unit='B/launch',
-                traffic_source='profiles/r01_traffic.json')
+                traffic_source='profiles/r02_traffic.json')
 
 
 def kernel_rooflines(agent):
