@@ -21,6 +21,11 @@ struct Collect16Args {
   float* seg_term; float* seg_lp;
   float* norm_acc; float* actions_out;
   int64_t row, W;
+  // MeanStd.record running sums: read at norm_acc + row * norm_stride, written at
+  // norm_acc + (row + 1) * norm_stride.  0 (device-resident callers): in place.  2 * O (the
+  // pinned-host collector): a history with one entry per Segment row, which makes a step
+  // idempotent — issuing the same row again recomputes the same sums (see collector.hip).
+  int64_t norm_stride;
   int O, A;
   // inputs of the NEXT step (null: none): touched early so that the next launch finds them in
   // L2 / Infinity Cache instead of paying an HBM round trip on its critical path

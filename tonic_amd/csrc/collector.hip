@@ -221,6 +221,14 @@ struct tonic_collector {
   float* d_packed;
   float* seg[7];                // observations, actions, next_observations, rewards, resets,
   float* norm_acc;              //   terminations, log_probs
+  // MeanStd.record sums per Segment row: hist[r] = the sums before step r, hist[r + 1] after it.
+  // A step reads one entry and writes the next, so issuing a row twice (a speculative launch
+  // that has to be repeated) accumulates nothing twice.  norm_acc -> hist[first row] when a
+  // rollout starts, hist[last row + 1] -> norm_acc when it ends.
+  float* d_norm_hist;
+  int64_t hist_rows;
+  bool hist_loaded;
+  int64_t last_row;             // row of the last step issued
   int64_t rows;
   unsigned seq;
   bool actor_packed, waiting;
@@ -369,6 +377,7 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
     }
     (void)hipFree(c->d_stamps);
   }
+  if (c->d_norm_hist) (void)hipFree(c->d_norm_hist);
   if (c->d_packed) (void)hipFree(c->d_packed);
   if (c->staged) (void)hipFree(c->staged);
   if (c->d_relay) (void)hipFree(c->d_relay);
@@ -398,6 +407,14 @@ extern "C" int tonic_collector_bind_segment(
   memcpy(c->seg, seg, sizeof(seg));
   c->norm_acc = d_norm_acc;
   c->rows = rows;
+  if (d_norm_acc != nullptr && c->hist_rows < rows + 1) {
+    if (c->d_norm_hist) (void)hipFree(c->d_norm_hist);
+    c->d_norm_hist = nullptr;
+    TONIC_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_norm_hist),
+                        (size_t)(rows + 1) * 2 * c->O * sizeof(float)),
+              "hipMalloc of the normaliser history");
+    c->hist_rows = rows + 1;
+  }
   return TONIC_OK;
 }
 
@@ -411,6 +428,7 @@ extern "C" int tonic_collector_begin_rollout(tonic_collector_t* c, const float* 
   const int status = launch_actor_pack(d_actor_params, c->d_packed, c->O, c->A, c->stream);
   if (status != TONIC_OK) return status;
   c->actor_packed = true;
+  c->hist_loaded = false;             // the first step of the rollout seeds the history
   return TONIC_OK;
 }
 
@@ -426,7 +444,8 @@ Collect16Args step_arguments(tonic_collector* c) {
   a.terminations = field(c, TONIC_COLLECTOR_TERMINATIONS);
   a.seg_obs = c->seg[0]; a.seg_act = c->seg[1]; a.seg_next = c->seg[2]; a.seg_rew = c->seg[3];
   a.seg_rst = c->seg[4]; a.seg_term = c->seg[5]; a.seg_lp = c->seg[6];
-  a.norm_acc = c->norm_acc;
+  a.norm_acc = c->norm_acc != nullptr ? c->d_norm_hist : nullptr;
+  a.norm_stride = 2 * c->O;
   a.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
   a.W = c->W; a.O = c->O; a.A = c->A;
   if (c->transport != 1)
@@ -467,6 +486,16 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
     const int status = stage_inputs(c, eps_slot < 0 ? 0 : eps_slot);
     if (status != TONIC_OK) return status;
   }
+  if (c->norm_acc != nullptr && !c->hist_loaded) {
+    // (stream-ordered before the launch of this step; the resident kernel is not running yet)
+    TONIC_REQUIRE(!c->live, TONIC_ERR_INVALID_ARGUMENT,
+                  "tonic_collector_ppo_step: begin_rollout while the resident kernel runs");
+    TONIC_HIP(hipMemcpyAsync(c->d_norm_hist + row * 2 * c->O, c->norm_acc,
+                             (size_t)2 * c->O * sizeof(float), hipMemcpyDeviceToDevice, c->stream),
+              "seeding the normaliser history");
+    c->hist_loaded = true;
+  }
+  c->last_row = row;
   c->seq += 1;
   __atomic_store_n(&c->host->act_seq, c->seq, __ATOMIC_RELEASE);
   if (c->transport == 2) {
@@ -556,6 +585,7 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
                                            void* learner_stream) {
   TONIC_REQUIRE(c && c->seg[0] && last_row < c->rows && !c->waiting, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_end_rollout: bad argument");
+  const int64_t final_row = last_row;          // the last row that belongs to the rollout
   if (c->live) {
     // transport 2: a stop command — the copy workgroups store the pending outcome first — then
     // the resident kernel leaves and the stream drains
@@ -582,6 +612,12 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
                        field(c, TONIC_COLLECTOR_TERMINATIONS), c->seg[2], c->seg[3], c->seg[4],
                        c->seg[5], last_row, c->W, c->O);
     TONIC_CHECK_LAUNCH("outcome_store_kernel");
+  }
+  if (c->norm_acc != nullptr && c->hist_loaded && final_row >= 0) {   // the sums after that row
+    TONIC_HIP(hipMemcpyAsync(c->norm_acc, c->d_norm_hist + (final_row + 1) * 2 * c->O,
+                             (size_t)2 * c->O * sizeof(float), hipMemcpyDeviceToDevice, c->stream),
+              "reading the normaliser history back");
+    c->hist_loaded = false;
   }
   // The learner reads the Segment on its own stream; the block may be overwritten by the next
   // environment step as soon as this call returns.

@@ -1062,7 +1062,9 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     if (c.pf_next_obs != nullptr || c.outcome_row == c.row)      // (device-resident callers only)
       for (int64_t i = (int64_t)tid * 16; i < W * O; i += 256 * 16) touch(c.next_obs + i, sink);
     float acc = 0.f;
-    if (wave < 2 && lane < O) acc = c.norm_acc[wave * O + lane];
+    const float* acc_in = c.norm_acc + c.row * c.norm_stride;
+    float* acc_out = c.norm_acc + (c.row + 1) * c.norm_stride;
+    if (wave < 2 && lane < O) acc = acc_in[wave * O + lane];
     const int64_t rows_per_chunk = (kHalf / O) & ~3;            // (x4 rows: 16-byte aligned chunks)
     for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
       const int64_t rows = min(rows_per_chunk, W - w0);
@@ -1106,7 +1108,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       __syncthreads();
       if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
     }
-    if (wave < 2 && lane < O) c.norm_acc[wave * O + lane] = acc;
+    if (wave < 2 && lane < O) acc_out[wave * O + lane] = acc;
     retire_touches(sink, c.norm_acc);
     collect_stamp(c, 1, 0);                          // staged + chained
     collect_signal_done(c);
@@ -1542,7 +1544,7 @@ extern "C" int tonic_ppo_collect_steps_packed(
                     d_rewards + t * W, d_resets + t * W, d_terminations + t * W,
                     d_seg_observations, d_seg_actions, d_seg_next_observations, d_seg_rewards,
                     d_seg_resets, d_seg_terminations, d_seg_log_probs, d_norm_acc, nullptr,
-                    row0 + t, W, O, A, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    row0 + t, W, 0, O, A, nullptr, nullptr, nullptr, nullptr, nullptr,
                     row0 + t, nullptr, 0u};
     if (t + 1 < steps) {                         // the next step's inputs exist: touch them early
       c.pf_eps = d_eps ? d_eps + (t + 1) * W * A : nullptr;
@@ -1573,7 +1575,7 @@ extern "C" int tonic_ppo_collect_step_packed(
   Collect16Args c{d_packed_actor, d_observations, d_eps, d_next_observations, d_rewards,
                   d_resets, d_terminations, d_seg_observations, d_seg_actions,
                   d_seg_next_observations, d_seg_rewards, d_seg_resets, d_seg_terminations,
-                  d_seg_log_probs, d_norm_acc, d_actions_out, row, W, O, A,
+                  d_seg_log_probs, d_norm_acc, d_actions_out, row, W, 0, O, A,
                   nullptr, nullptr, nullptr, nullptr, nullptr, row, nullptr, 0u};
   launch_collect16(c, as_stream(stream));
   TONIC_CHECK_LAUNCH("tonic_ppo_collect_step_packed");
