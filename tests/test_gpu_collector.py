@@ -159,6 +159,7 @@ def test_parallel_workers_feed_the_gpu_in_place(lib):
             assert agent._block is env.block, 'the agent must adopt the environment block'
             observations, infos = env.step(actions)
             agent.update(**infos, steps=t * 6)
+        agent._settle()                 # (update() has issued step T already: let it finish)
         agent._collector.end_rollout(T - 1)
         torch.cuda.synchronize()
         segments.append({k: agent.replay.buffers[k][:T].cpu().numpy() for k in (
@@ -221,6 +222,56 @@ def test_test_step_keeps_the_reference_noise_order(lib):
     want2, _ = port.ppo_act(params, obs[2], eps_last)
     for got_actions, want in zip(got, (want0, want1, want_test, want2)):
         np.testing.assert_allclose(got_actions, want, rtol=0, atol=3e-6)
+
+
+def test_step_issued_from_update_is_bit_identical(lib, monkeypatch):
+    """With a block-backed environment `agent.update` issues the next step's launch itself
+    (the observations are already in the block, the noise is drawn ahead) and `agent.step` only
+    collects the result — or issues the step again when a test episode came in between or other
+    observations are handed over.  Everything a rollout leaves behind must be bit-identical to
+    the run with TONIC_AMD_SPECULATE=0: actions, Segment rows, normaliser sums, learner update."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments
+    O, A, W, T = 6, 3, 12, 10
+
+    def run(speculate):
+        monkeypatch.setenv('TONIC_AMD_SPECULATE', '1' if speculate else '0')
+        env = environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=4), 1, W)
+        env.initialize(seed=3)
+        agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T, batch_iterations=2))
+        agent.initialize(env.observation_space, env.action_space, seed=9)
+        observations = env.start()
+        rng = np.random.RandomState(1)
+        test_obs = rng.standard_normal((2, O)).astype(np.float32)
+        trace, issued_early = [], 0
+        for t in range(2 * T + 3):
+            if t == 5:                                   # foreign observations: a copy of the block's
+                observations = observations.copy()
+            actions = agent.step(observations, t * W)
+            trace.append(actions.copy())
+            observations, infos = env.step(actions)
+            agent.update(**infos, steps=t * W)
+            issued_early += bool(agent._speculated)
+            if t in (2, 7, 13):                          # test episodes between update and step
+                trace.append(agent.test_step(test_obs, t * W))
+            if t == T - 2:
+                kept = {k: v.clone() for k, v in agent.replay.buffers.items()}
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+        return trace, kept, state, issued_early
+
+    with_early, kept_a, state_a, early = run(True)
+    plain, kept_b, state_b, none = run(False)
+    assert early >= T and none == 0, 'the early launch must actually be exercised'
+    assert len(with_early) == len(plain)
+    for a, b in zip(with_early, plain):
+        assert np.array_equal(a, b)
+    for key in ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+                'log_probs'):
+        assert torch.equal(kept_a[key][:T - 2], kept_b[key][:T - 2]), key
+    for key in state_a:                                  # two learner updates incl. the normaliser
+        assert torch.equal(state_a[key], state_b[key]), key
 
 
 def test_completion_words_order_the_actions(lib):

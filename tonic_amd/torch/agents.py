@@ -208,6 +208,10 @@ class A2C(Agent):
             replay._allocate(W, O, A)
         self._eps = (torch.from_numpy(block.eps[0]), torch.from_numpy(block.eps[1]))
         self._slot, self._eps_ahead, self._pending, self._rollout_open = 0, False, False, False
+        # update() may issue the NEXT step's launch itself (see there): whether it did, and whether
+        # the caller has been handing over the block's own arrays so far
+        self._speculated, self._block_fed = False, False
+        self._speculate = os.environ.get('TONIC_AMD_SPECULATE', '1') != '0'
 
     # -- shapes beyond the fused act kernel (O > 32 or A > 8): staged copies + separate launches
     def _wide(self):
@@ -252,21 +256,33 @@ class A2C(Agent):
         if self._collector is None or block.workers != len(observations):
             self._bind(observations)
             block = self._block
-        if observations is not block.observations:
+        fed = observations is block.observations
+        if not fed:
             np.copyto(block.observations, observations)
         collector = self._collector
-        if not self._rollout_open:
-            norm = self.model.observation_normalizer
-            collector.bind_segment(self.replay.buffers,
-                                   norm.device_sums if norm is not None else None,
-                                   self.replay.max_size)
-            collector.begin_rollout(self.model.flat_actor.flat)
-            self._rollout_open = True
+        launched = False
+        if self._speculated:
+            # update() already issued this step with the block's contents and the noise drawn
+            # ahead.  Still what the reference would compute?  (Other observations, or a test
+            # episode in between whose draws come first in the generator's order: no.)
+            self._speculated = False
+            if fed and self._eps_ahead:
+                launched = True
+            else:
+                collector.wait_actions()          # discard; a step is idempotent (collector.hip)
+        if not launched:
+            if not self._rollout_open:
+                norm = self.model.observation_normalizer
+                collector.bind_segment(self.replay.buffers,
+                                       norm.device_sums if norm is not None else None,
+                                       self.replay.max_size)
+                collector.begin_rollout(self.model.flat_actor.flat)
+                self._rollout_open = True
+            if not self._eps_ahead:
+                torch.randn(self._eps[self._slot].shape, out=self._eps[self._slot])     # a2c.py:81
+            collector.ppo_step(self.replay.index, self._slot, self._pending)
+            self._pending = False
         slot = self._slot
-        if not self._eps_ahead:
-            torch.randn(self._eps[slot].shape, out=self._eps[slot])     # a2c.py:81
-        collector.ppo_step(self.replay.index, slot, self._pending)
-        self._pending = False
         # The next step's noise, drawn while the GPU works on this one.  The generator state
         # before the draw is kept: test_step rewinds to it (its own draws come first in the
         # reference's stream order).
@@ -275,9 +291,17 @@ class A2C(Agent):
         self._slot, self._eps_ahead = slot ^ 1, True
         collector.wait_actions()
         actions = block.actions.copy()
+        self._block_fed = fed
         self.last_observations = observations
         self.last_actions = actions
         return actions
+
+    def _settle(self):
+        """Waits out a step that update() issued early and nobody asked for yet (the Segment row it
+        wrote lies beyond the rows stored so far and is rewritten by the real step)."""
+        if getattr(self, '_speculated', False):
+            self._collector.wait_actions()
+            self._speculated = False
 
     def test_step(self, observations, steps):
         if getattr(self, '_eps_ahead', False):
@@ -295,24 +319,35 @@ class A2C(Agent):
         end_rollout) moves it into the Segment row of the step it belongs to."""
         if self._wide():
             return self._update_staged(observations, rewards, resets, terminations)
-        block = self._block
+        block, replay = self._block, self.replay
         # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
-        if observations is not block.next_observations:
-            np.copyto(block.next_observations, observations)
-        if rewards is not block.rewards:
-            np.copyto(block.rewards, rewards)
-        if resets is not block.resets_bool:
-            np.copyto(block.resets, resets)                 # bool -> float32 (segments.py:33)
-        if terminations is not block.terminations_bool:
-            np.copyto(block.terminations, terminations)
+        if (self._block_fed and observations is block.next_observations
+                and rewards is block.rewards and resets is block.resets_bool
+                and terminations is block.terminations_bool):
+            # The environment lives in the block: the outcome is in place and so are the next
+            # step's observations (distributed.py:136-155 returns them with these infos).  With
+            # its noise drawn ahead, the next step's launch goes out FIRST — the rest of this call,
+            # the trainer's bookkeeping and the head of the next agent.step run while the GPU
+            # works.  step() issues it again if it turns out to be obsolete.
+            if (self._eps_ahead and self._speculate and replay.index + 2 <= replay.max_size):
+                self._collector.ppo_step(replay.index + 1, self._slot, True)
+                self._speculated = True
+        else:
+            if observations is not block.next_observations:
+                np.copyto(block.next_observations, observations)
+            if rewards is not block.rewards:
+                np.copyto(block.rewards, rewards)
+            if resets is not block.resets_bool:
+                np.copyto(block.resets, resets)             # bool -> float32 (segments.py:33)
+            if terminations is not block.terminations_bool:
+                np.copyto(block.terminations, terminations)
         if self.model.return_normalizer:
             raise NotImplementedError('return normalisers are not supported (never enabled by '
                                       'the reference defaults)')
-        replay = self.replay
         replay.index += 1
         if self.model.observation_normalizer:
             self.model.observation_normalizer.note_device_rows(block.workers)
-        self._pending = True
+        self._pending = not self._speculated
         if replay.ready():
             self._collector.end_rollout(replay.index - 1)
             self._pending, self._rollout_open = False, False
