@@ -258,7 +258,8 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
     import torch_port
     iterations, rows = 50, 1000000
     replay = tonic_amd.replays.Buffer(size=rows, batch_iterations=iterations, batch_size=batch)
-    agent = (tt.agents.SAC if kind == 'sac' else tt.agents.TD3)(replay=replay)
+    agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, d4pg=tt.agents.D4PG,
+                 mpo=tt.agents.MPO)[kind](replay=replay)
     agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=0)
     replay._allocate(workers, o_dim, a_dim)
     gen = torch.Generator(device=agent.device)
@@ -295,6 +296,9 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
             dt = min(dt, (time.perf_counter() - t0) / reps)
         out[label] = {'learner_updates_per_sec': round(iterations / dt, 1),
                       'ms_per_update_call': round(dt * 1e3, 3)}
+    if kind in ('d4pg', 'mpo'):      # (the rows added last: rates only)
+        out['us_per_iteration'] = round(out['hip_graph']['ms_per_update_call'] * 1e3 / iterations, 1)
+        return out
     # roofline of one learner iteration: dense fp32 contractions, 2 FLOP per MAC
     H, heads = 256, (2 if kind == 'sac' else 1)
     actor_fwd = 2 * (o_dim * H + H * H + heads * H * a_dim)
@@ -554,6 +558,11 @@ def main():
         for b in (100, 1024):
             rates = offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)
             result['offpolicy_td3'][f'B={b}'] = dict(rates['hip_graph'], roofline=rates['roofline'])
+        # D4PG (51 atoms) and MPO (20 sampled actions per state) on the same shapes, default B=100
+        for other in ('d4pg', 'mpo'):
+            rates = offpolicy_rates(other, 67, 21, 100, workers=64, cpu=False)
+            result['offpolicy_' + other] = dict(rates['hip_graph'], workload=rates['workload'],
+                                                us_per_iteration=rates['us_per_iteration'])
         result['speedup_vs_cpu_baseline'] = round(
             main_run['value'] / result['cpu_baseline']['value'], 1)
     if rank == 0:
