@@ -304,71 +304,73 @@ constexpr int kMpoStats = 16;    // per-state partials: see mpo_state_kernel
 // (actors.py:300-316, per_dim_constraining); value = softplus(log) + 1e-8 (actors.py:378-383)
 __device__ __forceinline__ float dual_value(float log_dual) { return softplus_f(log_dual) + 1e-8f; }
 
-// E-step weights and the M-step gradients at the head outputs, one state per thread
-// (actors.py:384-432).  SUMS over the batch (the optimizer step divides by B):
+// E-step weights and the M-step gradients at the head outputs, one WAVE per state: lane = sample for
+// the weights, lane = action dimension for the gradients (actors.py:384-432).  SUMS over the batch
+// (the optimizer step divides by B):
 //   d/d loc   = -sum_s W_s (a_s - loc) / sigma_t^2 + alpha_mean (loc - loc_t) / sigma_t^2
 //   d/d sigma = -sum_s W_s ((a_s - loc_t)^2 / sigma^3 - 1 / sigma) + alpha_std (1 / sigma - sigma_t^2 / sigma^3)
 // with W = softmax_s(q / T) + softmax_s(bound cost / T_penalty).  part[m][.] = {policy_mean, policy_std,
 // LSE, sum_s w q / T, LSE_penalty, sum_s w_p cost / T_p}; klm / kls [m][a] = the per-dimension KLs.
-__global__ void mpo_state_kernel(const float* q, const float* act, const float* loc_t,
-                                 const float* spre_t, const float* loc, const float* spre, int ldh,
-                                 const float* duals, int penalize, float* dloc, float* dspre,
-                                 float* part, float* klm, float* kls, int B, int A, int S) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void mpo_state_kernel(
+    const float* q, const float* act, const float* loc_t, const float* spre_t, const float* loc,
+    const float* spre, int ldh, const float* duals, int penalize, float* dloc, float* dspre,
+    float* part, float* klm, float* kls, int B, int A, int S) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (m >= B) return;
   const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
-  float w[kMpoMaxSamples];
   // weights_and_temperature_loss (actors.py:325-338): softmax over the samples of q / T
-  float mx = -INFINITY;
-  for (int s = 0; s < S; ++s) { w[s] = q[(int64_t)s * B + m] / T; mx = fmaxf(mx, w[s]); }
-  float sum = 0.f, wq = 0.f;
-  for (int s = 0; s < S; ++s) sum += expf(w[s] - mx);
+  const bool sample = lane < S;
+  const float tempered = sample ? q[(int64_t)lane * B + m] / T : -INFINITY;
+  const float mx = wave_max(tempered);
+  const float e = sample ? expf(tempered - mx) : 0.f;
+  const float sum = wave_sum(e);
   const float lse = mx + logf(sum);
-  for (int s = 0; s < S; ++s) { const float t = w[s]; w[s] = expf(t - mx) / sum; wq += w[s] * t; }
+  float w = e / sum;
+  const float wq = wave_sum(sample ? w * tempered : 0.f);
   float lse_p = 0.f, wc = 0.f;
   if (penalize) {                                              // actors.py:388-398
-    float cost[kMpoMaxSamples];
-    float mp = -INFINITY;
-    for (int s = 0; s < S; ++s) {
-      float n2 = 0.f;
+    float n2 = 0.f;
+    if (sample) {
       for (int a = 0; a < A; ++a) {
-        const float v = act[((int64_t)s * B + m) * A + a];
+        const float v = act[((int64_t)lane * B + m) * A + a];
         const float d = v - fminf(fmaxf(v, -1.f), 1.f);
         n2 += d * d;
       }
-      cost[s] = -sqrtf(n2) / Tp;
-      mp = fmaxf(mp, cost[s]);
     }
-    float sp = 0.f;
-    for (int s = 0; s < S; ++s) sp += expf(cost[s] - mp);
+    const float cost = sample ? -sqrtf(n2) / Tp : -INFINITY;
+    const float mp = wave_max(cost);
+    const float ep = sample ? expf(cost - mp) : 0.f;
+    const float sp = wave_sum(ep);
     lse_p = mp + logf(sp);
-    for (int s = 0; s < S; ++s) {
-      const float wp = expf(cost[s] - mp) / sp;
-      wc += wp * cost[s];
-      w[s] += wp;
-    }
+    const float wp = ep / sp;
+    wc = wave_sum(sample ? wp * cost : 0.f);
+    w += wp;
   }
-  float pm = 0.f, ps = 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float lt = loc_t[(int64_t)m * ldh + a], st = gaussian_sigma(spre_t[(int64_t)m * ldh + a]);
-    const float lo = loc[(int64_t)m * ldh + a], pre = spre[(int64_t)m * ldh + a];
-    const float sg = gaussian_sigma(pre);
-    float g_loc = 0.f, g_sigma = 0.f;
-    for (int s = 0; s < S; ++s) {
-      const float v = act[((int64_t)s * B + m) * A + a];
-      const float d_mean = v - lo, d_std = v - lt;
-      // Normal.log_prob: -(x - mu)^2 / (2 var) - log(sigma) - log(sqrt(2 pi))
-      pm += w[s] * (-(d_mean * d_mean) / (2.f * (st * st)) - logf(st) - kHalfLog2Pi);
-      ps += w[s] * (-(d_std * d_std) / (2.f * (sg * sg)) - logf(sg) - kHalfLog2Pi);
-      g_loc -= w[s] * d_mean / (st * st);
-      g_sigma -= w[s] * (d_std * d_std / (sg * sg * sg) - 1.f / sg);
-    }
+  // lane = action dimension: the sums over the samples in sample order
+  const bool live = lane < A;
+  const int a = live ? lane : A - 1;
+  const float lt = loc_t[(int64_t)m * ldh + a], st = gaussian_sigma(spre_t[(int64_t)m * ldh + a]);
+  const float lo = loc[(int64_t)m * ldh + a], pre = spre[(int64_t)m * ldh + a];
+  const float sg = gaussian_sigma(pre);
+  float pm = 0.f, ps = 0.f, g_loc = 0.f, g_sigma = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ws = __shfl(w, s, 64);
+    const float v = act[((int64_t)s * B + m) * A + a];
+    const float d_mean = v - lo, d_std = v - lt;
+    // Normal.log_prob: -(x - mu)^2 / (2 var) - log(sigma) - log(sqrt(2 pi))
+    pm += ws * (-(d_mean * d_mean) / (2.f * (st * st)) - logf(st) - kHalfLog2Pi);
+    ps += ws * (-(d_std * d_std) / (2.f * (sg * sg)) - logf(sg) - kHalfLog2Pi);
+    g_loc -= ws * d_mean / (st * st);
+    g_sigma -= ws * (d_std * d_std / (sg * sg * sg) - 1.f / sg);
+  }
+  pm = wave_sum(live ? pm : 0.f);
+  ps = wave_sum(live ? ps : 0.f);
+  if (live) {
     // kl_divergence(Normal(lt, st), Normal(lo, st)) and (.., Normal(lt, sg)) (actors.py:416-421)
     const float ratio = st / sg;
-    const float kl_mean = 0.5f * ((lt - lo) / st) * ((lt - lo) / st);
-    const float kl_std = 0.5f * (ratio * ratio - 1.f - logf(ratio * ratio));
-    klm[(int64_t)m * A + a] = kl_mean;
-    kls[(int64_t)m * A + a] = kl_std;
+    klm[(int64_t)m * A + a] = 0.5f * ((lt - lo) / st) * ((lt - lo) / st);
+    kls[(int64_t)m * A + a] = 0.5f * (ratio * ratio - 1.f - logf(ratio * ratio));
     const float alpha_mean = dual_value(duals[1 + a]), alpha_std = dual_value(duals[1 + A + a]);
     g_loc += alpha_mean * (lo - lt) / (st * st);
     g_sigma += alpha_std * (1.f / sg - st * st / (sg * sg * sg));
@@ -377,8 +379,10 @@ __global__ void mpo_state_kernel(const float* q, const float* act, const float* 
     dloc[(int64_t)m * ldh + a] = g_loc * (1.f - lo * lo);                  // tanh loc head
     dspre[(int64_t)m * ldh + a] = inside ? g_sigma / (1.f + expf(-pre)) : 0.f;
   }
-  float* out = part + (int64_t)m * kMpoStats;
-  out[0] = pm; out[1] = ps; out[2] = lse; out[3] = wq; out[4] = lse_p; out[5] = wc;
+  if (lane == 0) {
+    float* out = part + (int64_t)m * kMpoStats;
+    out[0] = pm; out[1] = ps; out[2] = lse; out[3] = wq; out[4] = lse_p; out[5] = wc;
+  }
 }
 
 // Batch means -> the logged losses, the dual variables' values and their gradients (one workgroup).
@@ -392,14 +396,16 @@ __global__ void mpo_dual_kernel(const float* part, const float* klm, const float
                                 int S) {
   __shared__ double col[2 * 64 + 6];
   const int tid = threadIdx.x;
-  // column sums in fixed order: threads 0..5 the six partials, 6..6+A-1 kl_mean, then kl_std
-  const int columns = 6 + 2 * A;
-  if (tid < columns) {
+  // column means in fixed order: columns 0..5 the six partials, 6..6+A-1 kl_mean, then kl_std; one
+  // wave per column, the lanes stride over the batch
+  const int columns = 6 + 2 * A, lane = tid & 63, waves = blockDim.x >> 6;
+  for (int c = tid >> 6; c < columns; c += waves) {
     double sum = 0;
-    for (int m = 0; m < B; ++m)
-      sum += tid < 6 ? part[(int64_t)m * kMpoStats + tid]
-                     : tid < 6 + A ? klm[(int64_t)m * A + (tid - 6)] : kls[(int64_t)m * A + (tid - 6 - A)];
-    col[tid] = sum / B;
+    for (int m = lane; m < B; m += 64)
+      sum += c < 6 ? part[(int64_t)m * kMpoStats + c]
+                   : c < 6 + A ? klm[(int64_t)m * A + (c - 6)] : kls[(int64_t)m * A + (c - 6 - A)];
+    sum = wave_sum(sum);
+    if (lane == 0) col[c] = sum / B;
   }
   __syncthreads();
   if (tid != 0) return;
@@ -1267,17 +1273,17 @@ extern "C" int tonic_mpo_actor_grad(
   TONIC_REQUIRE(workspace_bytes >= tonic_mpo_workspace_bytes(B, O, A, H, S), TONIC_ERR_WORKSPACE,
                 "tonic_mpo_actor_grad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int ldh = pad16(A), threads = 64;
+  const int ldh = pad16(A);
   const MpoBuffers w(d_workspace, workspace_bytes, B, S, weight_ld(H), ldh, pitch16(O + A), A);
   const ActorShape as{O, H, A, 2};
   TRY(mpo_sampled_values(d_target_actor, d_target_critic, d_norm_mean, d_norm_std, norm_clip,
                          d_observations, d_eps, B, O, H, A, S, w, st));
   TRY(actor_forward(d_actor_params, as, d_observations, B, w.o_h1, w.o_h2, w.loc, w.spre, ldh, true,
                     st));
-  hipLaunchKernelGGL(mpo_state_kernel, dim3((B + threads - 1) / threads), dim3(threads), 0, st, w.tq,
+  hipLaunchKernelGGL(mpo_state_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.tq,
                      w.act, w.loc_t, w.spre_t, w.loc, w.spre, ldh, d_duals, action_penalization,
                      w.dloc, w.dspre, w.part, w.klm, w.kls, B, A, S);
-  hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(192), 0, st, w.part, w.klm, w.kls, d_duals,
+  hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(1024), 0, st, w.part, w.klm, w.kls, d_duals,
                      action_penalization, (float)epsilon, (float)epsilon_penalty,
                      (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats,
                      d_grad_sums + actor_count(as), B, A, S);
