@@ -408,21 +408,25 @@ __global__ void mpo_dual_kernel(const float* part, const float* klm, const float
     if (lane == 0) col[c] = sum / B;
   }
   __syncthreads();
-  if (tid != 0) return;
+  if (tid >= 64) return;                              // wave 0: lane = action dimension
   const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
   const float log_S = logf((float)S);
   auto sigmoid = [](float x) { return 1.f / (1.f + expf(-x)); };
   float kl_mean_loss = 0.f, kl_std_loss = 0.f, alpha_mean_loss = 0.f, alpha_std_loss = 0.f;
-  for (int a = 0; a < A; ++a) {
+  if (tid < A) {
+    const int a = tid;
     const float am = dual_value(duals[1 + a]), as = dual_value(duals[1 + A + a]);
     const float km = (float)col[6 + a], ks = (float)col[6 + A + a];
-    kl_mean_loss += am * km; kl_std_loss += as * ks;                      // actors.py:319-323
-    alpha_mean_loss += am * (epsilon_mean - km);
-    alpha_std_loss += as * (epsilon_std - ks);
+    kl_mean_loss = am * km; kl_std_loss = as * ks;                        // actors.py:319-323
+    alpha_mean_loss = am * (epsilon_mean - km);
+    alpha_std_loss = as * (epsilon_std - ks);
     dual_grads[1 + a] = (epsilon_mean - km) * sigmoid(duals[1 + a]);
     dual_grads[1 + A + a] = (epsilon_std - ks) * sigmoid(duals[1 + A + a]);
     stats[8 + a] = am; stats[8 + A + a] = as;
   }
+  kl_mean_loss = wave_sum(kl_mean_loss); kl_std_loss = wave_sum(kl_std_loss);
+  alpha_mean_loss = wave_sum(alpha_mean_loss); alpha_std_loss = wave_sum(alpha_std_loss);
+  if (tid != 0) return;
   // temperature * (epsilon + mean(logsumexp) - log S): d / dT = epsilon + mean(LSE) - log S - mean(sum_s w q / T)
   float temperature_loss = T * (epsilon + (float)col[2] - log_S);
   dual_grads[0] = (epsilon + (float)col[2] - log_S - (float)col[3]) * sigmoid(duals[0]);
