@@ -526,6 +526,12 @@ def main():
         result['backend'] = torch.distributed.get_backend()
         if args.scaling == 'weak' and args.workload == 'cfg2' and W % world == 0:
             # the metric's own configuration: 256 workers in total, split over the ranks
+            # (the first job's agent — Segment, collector, pinned block — is released first: with it
+            #  alive, the second agent's exchanges crawled under two gloo ranks sharing one GPU)
+            import gc
+            del agent, loop, rollout, flat, low, high
+            gc.collect()
+            torch.cuda.empty_cache()
             _, _, _, strong = measure_job(W // world, rank, world, args.steps, 1, capture,
                                           device_too=False)
             result['strong_scaling'] = dict(

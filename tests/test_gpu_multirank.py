@@ -151,3 +151,28 @@ def test_exchange_schedule_over_rccl_with_one_rank(tmp_path, worker, args, sched
     a, b = np.load(plain), np.load(exchanged)
     for key in a.files:
         assert np.array_equal(a[key], b[key]), key
+
+
+def test_bench_runs_under_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (the driver's launch line
+    for the scaling runs; gloo here, both ranks on this box's GPU): ONE JSON line on rank 0's
+    stdout, the replicated parameters bit-identical across ranks after the updates, and the
+    strong-scaling leg (the metric's 256 workers split over the ranks) in the same ballpark as the
+    weak one."""
+    import json
+    env = dict(os.environ, TONIC_AMD_BACKEND='gloo')
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', '29791', os.path.join(ROOT, 'bench.py'),
+         '--gpus', '2', '--steps', '1', '--warmup', '1'],
+        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [line for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    result = json.loads(lines[0])
+    assert result['n_gpus'] == 2 and result['scaling'] == 'weak'
+    assert result['ranks_hold_identical_parameters'] is True
+    assert result['config']['global_workers'] == 512
+    strong = result['strong_scaling']
+    assert strong['global_workers'] == 256 and strong['workers_per_gpu'] == 128
+    assert strong['ms_per_step'] < 2 * result['ms_per_step']
