@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_w && mkdir -p /tmp/prof_w
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -o w -- python $REPO/scripts/wide_timing.py > $REPO/gpurun_out/prof_wide.log 2>&1
+WIDE_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -o w -- python $REPO/scripts/wide_timing.py > $REPO/gpurun_out/prof_wide.log 2>&1
 STATS=$(find /tmp/prof_w -name "*kernel_stats.csv" | head -1)
 cp "$STATS" $REPO/gpurun_out/prof_wide_kernel_stats.csv
 grep "O=" $REPO/gpurun_out/prof_wide.log

@@ -11,7 +11,10 @@ import bench                                    # noqa: E402
 from tonic_amd import _lib                      # noqa: E402
 
 lib, p = _lib.load(), _lib.ptr
-for O, A, n in ((111, 8, 1 << 20), (376, 17, 1 << 20), (17, 6, 1 << 20)):
+SHAPES = ((111, 8, 1 << 20), (376, 17, 1 << 20), (17, 6, 1 << 20))
+if os.environ.get("WIDE_ONLY"):
+    SHAPES = SHAPES[:1]
+for O, A, n in SHAPES:
     Pa, Pc = lib.tonic_ppo_actor_param_count(O, A), lib.tonic_v_critic_param_count(O)
     gen = torch.Generator(device='cuda').manual_seed(0)
     actor = torch.randn(Pa, device='cuda', generator=gen) * 0.1

@@ -62,56 +62,73 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
   }
   __syncthreads();
   const int s = lane & 15, g = lane >> 4;
-  const int64_t tiles = (a.N + 15) >> 4;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
+  const int64_t tiles = (a.N + 15) >> 4, stride = (int64_t)gridDim.x * 4;
+  // Software pipeline over (tile, chunk of kChunk k-steps): the loads of the NEXT chunk — the
+  // next tile's first one at a tile's end — are in flight while the MFMAs of the current chunk
+  // run (the plain loop "4 loads, wait, 16 MFMAs" exposed an HBM round trip per 16 input columns).
+  // Addresses are clamped and the padding is masked at the consumer, so no load is predicated.
+  constexpr int kChunk = 16;
+  auto load_chunk = [&](int64_t t, int c0, float (&xv)[kChunk]) {
+    const int64_t row = t * 16 + s;
+    const float* x = a.X + (row < a.N ? row : a.N - 1) * a.ldx;
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int k = 4 * (c0 + u) + g;
+      xv[u] = x[k < a.K ? k : a.K - 1];
+    }
+  };
+  float cur[kChunk], nxt[kChunk];
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  int c0 = 0;
+  if (t < tiles) load_chunk(t, 0, cur);
+  f32x4 acc[TN];
+#pragma unroll
+  for (int T = 0; T < TN; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+  while (t < tiles) {
+    const bool last_chunk = c0 + kChunk >= KS;
+    const int64_t t_next = last_chunk ? t + stride : t;
+    const int c_next = last_chunk ? 0 : c0 + kChunk;
+    if (t_next < tiles) load_chunk(t_next, c_next, nxt);
     const int64_t row = t * 16 + s;
     const bool valid = row < a.N;
-    const float* x = a.X + (valid ? row : a.N - 1) * a.ldx;
-    f32x4 acc[TN];
 #pragma unroll
-    for (int T = 0; T < TN; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int st = 0;
-    for (; st + 4 <= KS; st += 4) {        // four k-steps of loads in flight
-      float xv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = 4 * (st + u) + g, kc = k < a.K ? k : a.K - 1;
-        float v = x[kc];
+    for (int u = 0; u < kChunk; ++u) {
+      const int st = c0 + u, k = 4 * st + g, kc = k < a.K ? k : a.K - 1;
+      if (st < KS) {                                   // (uniform)
+        float v = cur[u];
         if (a.norm_mean != nullptr)
           v = __builtin_amdgcn_fmed3f((v - a.norm_mean[kc]) / a.norm_std[kc], -a.norm_clip, a.norm_clip);
-        xv[u] = (valid && k < a.K) ? v : 0.f;
+        v = (valid && k < a.K) ? v : 0.f;
+#pragma unroll
+        for (int T = 0; T < TN; ++T) acc[T] = mfma16w(wl[(T * KS + st) * 64 + lane], v, acc[T]);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int T = 0; T < TN; ++T) acc[T] = mfma16w(wl[(T * KS + st + u) * 64 + lane], xv[u], acc[T]);
     }
-    for (; st < KS; ++st) {
-      const int k = 4 * st + g, kc = k < a.K ? k : a.K - 1;
-      float v = x[kc];
-      if (a.norm_mean != nullptr)
-        v = __builtin_amdgcn_fmed3f((v - a.norm_mean[kc]) / a.norm_std[kc], -a.norm_clip, a.norm_clip);
-      const float xv = (valid && k < a.K) ? v : 0.f;
+    if (last_chunk) {
+      if (valid) {
 #pragma unroll
-      for (int T = 0; T < TN; ++T) acc[T] = mfma16w(wl[(T * KS + st) * 64 + lane], xv, acc[T]);
-    }
-    if (!valid) continue;
+        for (int T = 0; T < TN; ++T) {
 #pragma unroll
-    for (int T = 0; T < TN; ++T) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * T + 4 * g + r;              // D[row = feature][col = sample]
-        if (j < a.NOUT) {
-          float v = acc[T][r] + (a.bias != nullptr ? a.bias[j] : 0.f);
-          if (a.act == 1) v = tanh_fast(v);
-          if (a.D != nullptr) {
-            const float d = a.D[row * a.ldy + j];
-            v = v * (1.f - d * d);
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * T + 4 * g + r;              // D[row = feature][col = sample]
+            if (j < a.NOUT) {
+              float v = acc[T][r] + (a.bias != nullptr ? a.bias[j] : 0.f);
+              if (a.act == 1) v = tanh_fast(v);
+              if (a.D != nullptr) {
+                const float d = a.D[row * a.ldy + j];
+                v = v * (1.f - d * d);
+              }
+              a.Y[row * a.ldy + j] = v;
+            }
           }
-          a.Y[row * a.ldy + j] = v;
         }
       }
+#pragma unroll
+      for (int T = 0; T < TN; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) cur[u] = nxt[u];
+    t = t_next;
+    c0 = c_next;
   }
 }
 
@@ -154,29 +171,40 @@ __global__ __launch_bounds__(kWideThreads) void wgrad_kernel(WgradArgs a) {
     ns[i] = a.norm_mean != nullptr ? a.norm_std[kcol[i]] : 1.f;
   }
   constexpr int kSteps = 4;                              // k-steps (of 4 samples) loaded together
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4 * kSteps) {
-    float av[kSteps][TJ], bv[kSteps][kMaxTk];
+  // Software pipeline: the loads of the next 16 rows are issued before the MFMAs of the current
+  // ones (the plain loop — load, wait, 16 x TJ x tiles MFMAs — exposed an HBM round trip per 16
+  // rows of the slab).  Clamped addresses, padding masked at the consumer.
+  auto load_rows = [&](int64_t r0, float (&av)[kSteps][TJ], float (&bv)[kSteps][kMaxTk]) {
 #pragma unroll
     for (int u = 0; u < kSteps; ++u) {
       const int64_t row = r0 + 4 * u + g;                // this lane's sample of the k-step
-      const bool valid = row < r_end;
-      const int64_t rc = valid ? row : r_end - 1;
+      const int64_t rc = row < r_end ? row : r_end - 1;
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) {
         const int j = 16 * tj + s;
-        const float v = a.dY[rc * a.ldy + (j < a.NOUT ? j : 0)];
-        av[u][tj] = (valid && j < a.NOUT) ? v : 0.f;
+        av[u][tj] = a.dY[rc * a.ldy + (j < a.NOUT ? j : 0)];
       }
 #pragma unroll
+      for (int i = 0; i < kMaxTk; ++i)
+        bv[u][i] = wave + 4 * i < TK ? a.X[rc * a.ldx + kcol[i]] : 0.f;
+    }
+  };
+  float av[kSteps][TJ], bv[kSteps][kMaxTk], an[kSteps][TJ], bn[kSteps][kMaxTk];
+  if (r_begin < r_end) load_rows(r_begin, av, bv);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4 * kSteps) {
+    if (r0 + 4 * kSteps < r_end) load_rows(r0 + 4 * kSteps, an, bn);
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+      const bool valid = r0 + 4 * u + g < r_end;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+        av[u][tj] = (valid && 16 * tj + s < a.NOUT) ? av[u][tj] : 0.f;
+#pragma unroll
       for (int i = 0; i < kMaxTk; ++i) {
-        float v = 0.f;
-        if (wave + 4 * i < TK) {
-          v = a.X[rc * a.ldx + kcol[i]];
-          if (a.norm_mean != nullptr)
-            v = __builtin_amdgcn_fmed3f((v - nm[i]) / ns[i], -a.norm_clip, a.norm_clip);
-          v = (valid && 16 * (wave + 4 * i) + s < a.K) ? v : 0.f;
-        }
-        bv[u][i] = v;
+        float v = bv[u][i];
+        if (a.norm_mean != nullptr)
+          v = __builtin_amdgcn_fmed3f((v - nm[i]) / ns[i], -a.norm_clip, a.norm_clip);
+        bv[u][i] = (valid && wave + 4 * i < TK && 16 * (wave + 4 * i) + s < a.K) ? v : 0.f;
       }
     }
 #pragma unroll
@@ -188,6 +216,13 @@ __global__ __launch_bounds__(kWideThreads) void wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < kMaxTk; ++i)
           if (wave + 4 * i < TK) acc[tj][i] = mfma16w(av[u][tj], bv[u][i], acc[tj][i]);
       }
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) av[u][tj] = an[u][tj];
+#pragma unroll
+      for (int i = 0; i < kMaxTk; ++i) bv[u][i] = bn[u][i];
+    }
   }
   float* image = a.image + (int64_t)blockIdx.x * a.pstride;
 #pragma unroll
