@@ -53,9 +53,14 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
   if (a.skip != nullptr && *a.skip != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KS = (a.K + 3) >> 2;
+  // Which input column a lane group contracts at k-step st is free (the weight image follows):
+  // plain k = 4 st + g; vec (16-byte aligned rows of a multiple of 16 columns — every hidden-layer
+  // input): k = 16 (st / 4) + 4 g + st % 4, so that a lane's four steps are ONE 16-byte load.
+  const bool vec = (a.K & 15) == 0 && (a.ldx & 3) == 0 && a.norm_mean == nullptr;
+  auto column = [&](int st, int gg) { return vec ? 16 * (st >> 2) + 4 * gg + (st & 3) : 4 * st + gg; };
   for (int idx = tid; idx < TN * KS * 64; idx += kWideThreads) {
     const int l = idx & 63, st = (idx >> 6) % KS, T = (idx >> 6) / KS;
-    const int j = 16 * T + (l & 15), k = 4 * st + (l >> 4);
+    const int j = 16 * T + (l & 15), k = column(st, l >> 4);
     float w = 0.f;
     if (j < a.NOUT && k < a.K) w = a.transposed ? a.W[(int64_t)k * a.ldw + j] : a.W[(int64_t)j * a.ldw + k];
     wl[idx] = w;
@@ -71,6 +76,16 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
   auto load_chunk = [&](int64_t t, int c0, float (&xv)[kChunk]) {
     const int64_t row = t * 16 + s;
     const float* x = a.X + (row < a.N ? row : a.N - 1) * a.ldx;
+    if (vec) {                                         // (uniform) four 16-byte loads
+#pragma unroll
+      for (int q = 0; q < kChunk / 4; ++q) {
+        const int c = (c0 >> 2) + q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (16 * c + 4 * g < a.K ? 16 * c + 4 * g : 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[4 * q + e] = v[e];
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) {
       const int k = 4 * (c0 + u) + g;
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
     const bool valid = row < a.N;
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) {
-      const int st = c0 + u, k = 4 * st + g, kc = k < a.K ? k : a.K - 1;
+      const int st = c0 + u, k = column(st, g), kc = k < a.K ? k : a.K - 1;
       if (st < KS) {                                   // (uniform)
         float v = cur[u];
         if (a.norm_mean != nullptr)
@@ -104,7 +119,30 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
       }
     }
     if (last_chunk) {
-      if (valid) {
+      if (valid && (a.NOUT & 3) == 0 && (a.ldy & 3) == 0) {
+        // registers 0..3 of a tile are four consecutive outputs of one row: 16-byte stores
+#pragma unroll
+        for (int T = 0; T < TN; ++T) {
+          const int j = 16 * T + 4 * g;
+          if (j < a.NOUT) {
+            f32x4 v = acc[T];
+            if (a.bias != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += a.bias[j + r];
+            }
+            if (a.act == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = tanh_fast(v[r]);
+            }
+            if (a.D != nullptr) {
+              const f32x4 d = *reinterpret_cast<const f32x4*>(a.D + row * a.ldy + j);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] * (1.f - d[r] * d[r]);
+            }
+            *reinterpret_cast<f32x4*>(a.Y + row * a.ldy + j) = v;
+          }
+        }
+      } else if (valid) {
 #pragma unroll
         for (int T = 0; T < TN; ++T) {
 #pragma unroll
