@@ -284,6 +284,124 @@ __global__ __launch_bounds__(kWideThreads) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// Row-split form of wgrad_kernel for K <= 16 * TKM columns: every wave takes every fourth round of 16
+// rows and ALL TJ x TK tiles (2.5x fewer load instructions per MFMA than the column split, where each
+// wave fetched its own copy of dY for one or two column tiles), the four waves' accumulators meet in
+// LDS at the end and are added in wave order (bit-reproducible).
+template <int TJ, int TKM>
+__global__ __launch_bounds__(kWideThreads) void wgrad_rows_kernel(WgradArgs a) {
+  extern __shared__ float fold[];                        // [4 waves][TJ * TKM tiles + TJ][64 lanes][4]
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g = lane >> 4;
+  const int TK = (a.K + 15) >> 4;
+  f32x4 acc[TJ][TKM];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int i = 0; i < TKM; ++i) acc[tj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[TJ];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) bsum[tj] = 0.f;
+  const int64_t r_begin = (int64_t)blockIdx.x * a.slab, r_end = min(a.N, r_begin + a.slab);
+  float nm[TKM], ns[TKM];
+  int kcol[TKM];
+#pragma unroll
+  for (int i = 0; i < TKM; ++i) {
+    const int k = 16 * i + s;
+    kcol[i] = k < a.K ? k : a.K - 1;
+    nm[i] = a.norm_mean != nullptr ? a.norm_mean[kcol[i]] : 0.f;
+    ns[i] = a.norm_mean != nullptr ? a.norm_std[kcol[i]] : 1.f;
+  }
+  constexpr int kSteps = 4, kRows = 4 * kSteps;
+  auto load_rows = [&](int64_t r0, float (&av)[kSteps][TJ], float (&bv)[kSteps][TKM]) {
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+      const int64_t row = r0 + 4 * u + g;
+      const int64_t rc = row < r_end ? row : r_end - 1;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int j = 16 * tj + s;
+        av[u][tj] = a.dY[rc * a.ldy + (j < a.NOUT ? j : 0)];
+      }
+#pragma unroll
+      for (int i = 0; i < TKM; ++i) bv[u][i] = i < TK ? a.X[rc * a.ldx + kcol[i]] : 0.f;
+    }
+  };
+  float av[kSteps][TJ], bv[kSteps][TKM], an[kSteps][TJ], bn[kSteps][TKM];
+  const int64_t first = r_begin + (int64_t)wave * kRows, step = 4 * kRows;
+  if (first < r_end) load_rows(first, av, bv);
+  for (int64_t r0 = first; r0 < r_end; r0 += step) {
+    if (r0 + step < r_end) load_rows(r0 + step, an, bn);
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+      const bool valid = r0 + 4 * u + g < r_end;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const float v = (valid && 16 * tj + s < a.NOUT) ? av[u][tj] : 0.f;
+        bsum[tj] += v;
+#pragma unroll
+        for (int i = 0; i < TKM; ++i) {
+          if (i < TK) {                                  // (uniform)
+            float x = bv[u][i];
+            if (tj == 0) {
+              if (a.norm_mean != nullptr)
+                x = __builtin_amdgcn_fmed3f((x - nm[i]) / ns[i], -a.norm_clip, a.norm_clip);
+              x = (valid && 16 * i + s < a.K) ? x : 0.f;
+              bv[u][i] = x;
+            }
+            acc[tj][i] = mfma16w(v, x, acc[tj][i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSteps; ++u) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) av[u][tj] = an[u][tj];
+#pragma unroll
+      for (int i = 0; i < TKM; ++i) bv[u][i] = bn[u][i];
+    }
+  }
+  // the four waves' accumulators -> LDS, then the sum in wave order
+  constexpr int kSlots = TJ * TKM + TJ;
+  f32x4* mine = reinterpret_cast<f32x4*>(fold) + (int64_t)wave * kSlots * 64;
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+#pragma unroll
+    for (int i = 0; i < TKM; ++i) mine[(tj * TKM + i) * 64 + lane] = acc[tj][i];
+    float b = bsum[tj];
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    mine[(TJ * TKM + tj) * 64 + lane] = f32x4{b, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  float* image = a.image + (int64_t)blockIdx.x * a.pstride;
+  const f32x4* all = reinterpret_cast<const f32x4*>(fold);
+  for (int slot = wave; slot < kSlots; slot += 4) {      // each wave folds its share of the slots
+    f32x4 v = all[slot * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 o = all[((int64_t)w * kSlots + slot) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += o[r];
+    }
+    if (slot < TJ * TKM) {
+      const int tj = slot / TKM, i = slot - tj * TKM, k = 16 * i + s;
+      if (i < TK && k < a.K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * tj + 4 * g + r;             // D[row = output j][col = input k]
+          if (j < a.NOUT) image[a.w_offset + j * a.K + k] = v[r];
+        }
+      }
+    } else {
+      const int tj = slot - TJ * TKM;
+      if (g == 0 && 16 * tj + s < a.NOUT) image[a.b_offset + 16 * tj + s] = v[0];
+    }
+  }
+}
+
 struct PpoLossArgs {
   const float* loc; float* dz3; int ld;    // [N, ld]: tanh'ed head outputs in, d loss / d (pre-tanh) out
   const float* actions; const float* adv; const float* adv_stats; const float* old_logp;
@@ -473,8 +591,33 @@ int launch_dense(const DenseArgs& a, hipStream_t st) {
   return TONIC_OK;
 }
 
+template <int TJ, int TKM>
+int launch_wgrad_rows(const WgradArgs& a, int blocks, hipStream_t st) {
+  constexpr int lds_bytes = 4 * (TJ * TKM + TJ) * 64 * 16;
+  auto kernel = wgrad_rows_kernel<TJ, TKM>;
+  static thread_local bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      set_error("mlpwide: %d B of LDS for the wgrad fold: %s", lds_bytes, hipGetErrorString(e));
+      return TONIC_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWideThreads), lds_bytes, st, a);
+  TONIC_CHECK_LAUNCH("wgrad_rows_kernel");
+  return TONIC_OK;
+}
+
 int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
-  const int tj = (a.NOUT + 15) / 16;
+  const int tj = (a.NOUT + 15) / 16, tk = (a.K + 15) / 16;
+  if (tk <= 4) {                                         // hidden-layer inputs: row split
+    if (tj <= 1) return launch_wgrad_rows<1, 4>(a, blocks, st);
+    if (tj == 2) return launch_wgrad_rows<2, 4>(a, blocks, st);
+    return launch_wgrad_rows<4, 4>(a, blocks, st);
+  }
+  if (tk <= 7 && tj > 2) return launch_wgrad_rows<4, 7>(a, blocks, st);
   if (tj <= 1) hipLaunchKernelGGL(wgrad_kernel<1>, dim3(blocks), dim3(kWideThreads), 0, st, a);
   else if (tj == 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3(blocks), dim3(kWideThreads), 0, st, a);
   else hipLaunchKernelGGL(wgrad_kernel<4>, dim3(blocks), dim3(kWideThreads), 0, st, a);
