@@ -52,11 +52,11 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
   extern __shared__ float wl[];            // [TN][KS][64] A-operand image of the weights
   if (a.skip != nullptr && *a.skip != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int KS = (a.K + 3) >> 2;
   // Which input column a lane group contracts at k-step st is free (the weight image follows):
   // plain k = 4 st + g; vec (16-byte aligned rows of a multiple of 16 columns — every hidden-layer
   // input): k = 16 (st / 4) + 4 g + st % 4, so that a lane's four steps are ONE 16-byte load.
-  const bool vec = (a.K & 15) == 0 && (a.ldx & 3) == 0 && a.norm_mean == nullptr;
+  const bool vec = (a.K & 3) == 0 && (a.ldx & 3) == 0;
+  const int KS = vec ? 4 * ((a.K + 15) >> 4) : (a.K + 3) >> 2;
   auto column = [&](int st, int gg) { return vec ? 16 * (st >> 2) + 4 * gg + (st & 3) : 4 * st + gg; };
   for (int idx = tid; idx < TN * KS * 64; idx += kWideThreads) {
     const int l = idx & 63, st = (idx >> 6) % KS, T = (idx >> 6) / KS;
@@ -562,7 +562,8 @@ __global__ void gather_column_kernel(const float* src, int ld, float* dst, int64
 // ---------------------------------------------------------------------------------- host side
 
 int launch_dense(const DenseArgs& a, hipStream_t st) {
-  const int tn = (a.NOUT + 15) / 16, ks = (a.K + 3) / 4;
+  const bool vec = (a.K & 3) == 0 && (a.ldx & 3) == 0;           // (as in the kernel)
+  const int tn = (a.NOUT + 15) / 16, ks = vec ? 4 * ((a.K + 15) / 16) : (a.K + 3) / 4;
   const int lds_bytes = tn * ks * 64 * 4;
   const int64_t tiles = (a.N + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;
