@@ -86,12 +86,19 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
       }
       return;
     }
+    // rows that are not 16-byte aligned (O = 111: 444 bytes): row i of the tile, 64 consecutive
+    // columns of the chunk across the lanes — one contiguous 256-byte read per instruction instead
+    // of 16 rows x 4 bytes; the consumer transposes through the wave's LDS tile
+    const int col = 4 * c0 + lane;
+    const int64_t base = t * 16;
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) {
-      const int k = 4 * (c0 + u) + g;
-      xv[u] = x[k < a.K ? k : a.K - 1];
+    for (int i = 0; i < kChunk; ++i) {
+      const int64_t r = base + i < a.N ? base + i : a.N - 1;
+      xv[i] = a.X[r * a.ldx + (col < a.K ? col : a.K - 1)];
     }
   };
+  constexpr int kTilePitch = 68;                       // (4 s + 4 u + g) mod 64: conflict-free reads
+  float* xt = wl + TN * KS * 64 + wave * (16 * kTilePitch);
   float cur[kChunk], nxt[kChunk];
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
   int c0 = 0;
@@ -106,6 +113,14 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
     if (t_next < tiles) load_chunk(t_next, c_next, nxt);
     const int64_t row = t * 16 + s;
     const bool valid = row < a.N;
+    if (!vec) {                                        // (uniform) [row i][column] -> [row s][k-step]
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) xt[i * kTilePitch + lane] = cur[i];
+      wave_lds_sync();
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) cur[u] = xt[s * kTilePitch + 4 * u + g];
+      wave_lds_sync();
+    }
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) {
       const int st = c0 + u, k = column(st, g), kc = k < a.K ? k : a.K - 1;
@@ -564,11 +579,11 @@ __global__ void gather_column_kernel(const float* src, int ld, float* dst, int64
 int launch_dense(const DenseArgs& a, hipStream_t st) {
   const bool vec = (a.K & 3) == 0 && (a.ldx & 3) == 0;           // (as in the kernel)
   const int tn = (a.NOUT + 15) / 16, ks = vec ? 4 * ((a.K + 15) / 16) : (a.K + 3) / 4;
-  const int lds_bytes = tn * ks * 64 * 4;
+  const int lds_bytes = tn * ks * 64 * 4 + (vec ? 0 : 4 * 16 * 68 * 4);   // + the waves' transpose tiles
   const int64_t tiles = (a.N + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > 2048) blocks = 2048;
-  constexpr int kMaxLds = 4 * 96 * 64 * 4;                 // 64 outputs x 384 inputs
+  constexpr int kMaxLds = 4 * 96 * 64 * 4 + 4 * 16 * 68 * 4;   // 64 outputs x 384 inputs + transpose tiles
   auto go = [&](auto kernel) {
     static thread_local bool configured = false;           // (one flag per instantiation)
     if (!configured) {
