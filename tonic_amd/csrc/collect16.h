@@ -57,6 +57,27 @@ struct CollectResident {
   unsigned long long park_ticks;       // 100 MHz ticks without a command before parking
 };
 
+// One environment step of the pinned-host collector for shapes beyond the fused act kernel
+// (O <= 384, A <= 32; mlpwide.hip): ingest (inputs over PCIe once -> device staging + Segment row,
+// the previous step's outcome -> its Segment row, MeanStd.record) -> three dense launches -> sample +
+// store + actions back to the block + completion words.
+struct WideCollect {
+  const float* params;                                   // flat PPO actor parameters
+  const float* obs; const float* eps;                    // the block's fields (mapped); eps null = greedy
+  const float* next_obs; const float* rewards; const float* resets; const float* terminations;
+  float* seg_obs; float* seg_act; float* seg_next; float* seg_rew; float* seg_rst; float* seg_term;
+  float* seg_lp;
+  float* norm_hist;                                      // [rows + 1][2 O] or null
+  float* actions_out;                                    // the block's action field (mapped)
+  unsigned* done_flags; unsigned done_seq;               // wide_collect_words(W) completion words
+  int64_t row, outcome_row, W;
+  int O, A;
+};
+int64_t wide_collect_workspace_bytes(int64_t W, int O, int A);
+int wide_collect_words(int64_t W);
+int wide_collect_step(const WideCollect& c, void* d_workspace, int64_t workspace_bytes,
+                      hipStream_t stream);
+
 int collect16_ks1(int O);
 int collect16_ap(int A);
 int collect16_blocks(int64_t W);          // workgroups (= completion words) of one launch

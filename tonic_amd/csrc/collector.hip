@@ -229,6 +229,10 @@ struct tonic_collector {
   int64_t hist_rows;
   bool hist_loaded;
   int64_t last_row;             // row of the last step issued
+  bool wide;                    // shapes beyond the fused act kernel
+  const float* actor_params;
+  void* d_wide_ws;
+  int64_t wide_ws_bytes;
   int64_t rows;
   unsigned seq;
   bool actor_packed, waiting;
@@ -305,13 +309,17 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   TONIC_REQUIRE(transport >= 0 && transport <= 2, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_create: transport must be 0 (mapped, one launch per step), "
                 "1 (hipMemcpyAsync) or 2 (mapped, resident kernel)");
-  TONIC_REQUIRE(h->O <= 32 && h->A <= 8, TONIC_ERR_UNSUPPORTED_SHAPE,
-                "tonic_collector_create: the fused act kernel serves O <= 32, A <= 8 (got %d, %d)",
+  TONIC_REQUIRE(h->O <= 384 && h->A <= 32, TONIC_ERR_UNSUPPORTED_SHAPE,
+                "tonic_collector_create: the act kernels serve O <= 384, A <= 32 (got %d, %d)",
                 h->O, h->A);
   tonic_collector* c = new (std::nothrow) tonic_collector();
   TONIC_REQUIRE(c != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_create: out of memory");
   memset(c, 0, sizeof(*c));
   c->host = h; c->W = h->W; c->O = h->O; c->A = h->A; c->transport = transport;
+  // beyond the fused act kernel (O > 32 or A > 8): layer-by-layer launches per step on the mapped
+  // block (mlpwide.hip wide_collect_step), i.e. transport 0 whatever was asked for
+  c->wide = h->O > 32 || h->A > 8;
+  if (c->wide) c->transport = 0;
   auto fail = [&](const char* what, hipError_t e) {
     set_error("tonic_collector_create: %s: %s", what, hipGetErrorString(e));
     tonic_collector_destroy(c);
@@ -340,6 +348,11 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
       (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
+  if (c->wide) {
+    c->wide_ws_bytes = wide_collect_workspace_bytes(c->W, c->O, c->A);
+    if ((e = hipMalloc(&c->d_wide_ws, (size_t)c->wide_ws_bytes)) != hipSuccess)
+      return fail("hipMalloc of the wide act workspace", e);
+  }
   if (getenv("TONIC_AMD_COLLECTOR_STAMPS") != nullptr) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 24 * 8)) != hipSuccess ||
         (e = hipMemset(c->d_stamps, 0, 24 * 8)) != hipSuccess)
@@ -378,6 +391,7 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
     (void)hipFree(c->d_stamps);
   }
   if (c->d_norm_hist) (void)hipFree(c->d_norm_hist);
+  if (c->d_wide_ws) (void)hipFree(c->d_wide_ws);
   if (c->d_packed) (void)hipFree(c->d_packed);
   if (c->staged) (void)hipFree(c->staged);
   if (c->d_relay) (void)hipFree(c->d_relay);
@@ -425,8 +439,11 @@ extern "C" int tonic_collector_begin_rollout(tonic_collector_t* c, const float* 
   // the parameters were written on the learner's stream: order the pack behind them
   TONIC_HIP(hipEventRecord(c->learner_done, as_stream(learner_stream)), "hipEventRecord");
   TONIC_HIP(hipStreamWaitEvent(c->stream, c->learner_done, 0), "hipStreamWaitEvent");
-  const int status = launch_actor_pack(d_actor_params, c->d_packed, c->O, c->A, c->stream);
-  if (status != TONIC_OK) return status;
+  c->actor_params = d_actor_params;               // (wide: read in place, they rest during a rollout)
+  if (!c->wide) {
+    const int status = launch_actor_pack(d_actor_params, c->d_packed, c->O, c->A, c->stream);
+    if (status != TONIC_OK) return status;
+  }
   c->actor_packed = true;
   c->hist_loaded = false;             // the first step of the rollout seeds the history
   return TONIC_OK;
@@ -510,6 +527,28 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
     c->waiting = true;
     return TONIC_OK;
   }
+  if (c->wide) {
+    WideCollect w{};
+    w.params = c->actor_params;
+    w.obs = field(c, TONIC_COLLECTOR_OBSERVATIONS);
+    w.eps = eps_slot < 0 ? nullptr
+                         : field(c, eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_EPS1);
+    w.next_obs = field(c, TONIC_COLLECTOR_NEXT_OBSERVATIONS);
+    w.rewards = field(c, TONIC_COLLECTOR_REWARDS);
+    w.resets = field(c, TONIC_COLLECTOR_RESETS);
+    w.terminations = field(c, TONIC_COLLECTOR_TERMINATIONS);
+    w.seg_obs = c->seg[0]; w.seg_act = c->seg[1]; w.seg_next = c->seg[2]; w.seg_rew = c->seg[3];
+    w.seg_rst = c->seg[4]; w.seg_term = c->seg[5]; w.seg_lp = c->seg[6];
+    w.norm_hist = c->norm_acc != nullptr ? c->d_norm_hist : nullptr;
+    w.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
+    w.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+    w.done_seq = c->seq;
+    w.row = row; w.outcome_row = store_previous ? row - 1 : -1; w.W = c->W; w.O = c->O; w.A = c->A;
+    const int status = wide_collect_step(w, c->d_wide_ws, c->wide_ws_bytes, c->stream);
+    if (status != TONIC_OK) return status;
+    c->waiting = true;
+    return TONIC_OK;
+  }
   Collect16Args a = step_arguments(c);
   a.eps = eps_slot < 0 ? nullptr
                        : field(c, eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_EPS1);
@@ -535,7 +574,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
   const double deadline = now_s() + timeout_s;
   const uint32_t* flags = reinterpret_cast<const uint32_t*>(
       reinterpret_cast<const char*>(c->host) + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
-  const int words = collect16_blocks(c->W);
+  const int words = c->wide ? wide_collect_words(c->W) : collect16_blocks(c->W);
   int arrived = 0;                                   // words [0, arrived) already carry c->seq
   for (uint64_t spins = 0;; ++spins) {
     bool done;

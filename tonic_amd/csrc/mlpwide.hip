@@ -22,6 +22,7 @@
 //                  to the head outputs (tonic/torch/updaters/actors.py:81-108, critics.py:18-24).
 //   sample_kernel  actions = loc + sigma * eps, log-probabilities (a2c.py:75-85).
 #include "mlp64.h"
+#include "collect16.h"
 
 namespace tonic {
 namespace {
@@ -792,6 +793,148 @@ int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipSt
                      reinterpret_cast<const float*>(ws + L.off_out), kWideLd, a.params + L.ls,
                      a.eps, a.out0, a.out1, a.n, a.A);
   TONIC_CHECK_LAUNCH("sample_kernel");
+  return TONIC_OK;
+}
+
+// ------------------------------------------------------------ the collector's step (wide shapes)
+namespace {
+
+constexpr int kIngestThreads = 512;
+constexpr int kIngestCopyBlocks = 4;
+
+// src (pinned host memory, 16-byte aligned) -> up to two destinations; every thread's loads are in
+// flight before its first store (one PCIe round trip per ~32 KB per workgroup)
+__device__ __forceinline__ void ingest_copy(const float* src, float* dst0, float* dst1, int64_t count,
+                                            int part, int parts) {
+  const int64_t vecs = count >> 2, stride = (int64_t)parts * kIngestThreads;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  for (int64_t base = (int64_t)part * kIngestThreads + threadIdx.x; base < vecs; base += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + u * stride < vecs) v[u] = __builtin_nontemporal_load(s4 + base + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = base + u * stride;
+      if (i < vecs) {
+        if (dst0 != nullptr) reinterpret_cast<f32x4*>(dst0)[i] = v[u];
+        if (dst1 != nullptr) reinterpret_cast<f32x4*>(dst1)[i] = v[u];
+      }
+    }
+  }
+  if (part == 0 && threadIdx.x < (count & 3)) {           // tail floats
+    const int64_t i = (vecs << 2) + threadIdx.x;
+    const float v = src[i];
+    if (dst0 != nullptr) dst0[i] = v;
+    if (dst1 != nullptr) dst1[i] = v;
+  }
+}
+
+struct IngestArgs {
+  WideCollect c;
+  float* d_obs; float* d_eps;
+};
+
+__global__ __launch_bounds__(kIngestThreads) void wide_ingest_kernel(IngestArgs a) {
+  __shared__ float tile[16384];
+  const WideCollect& c = a.c;
+  const int64_t W = c.W, n_obs = W * c.O, n_eps = W * c.A;
+  if ((int)blockIdx.x < kIngestCopyBlocks) {
+    const int part = blockIdx.x;
+    // this step's inputs: device staging for the forward pass, observations also into their row
+    ingest_copy(c.obs, a.d_obs, c.seg_obs + c.row * n_obs, n_obs, part, kIngestCopyBlocks);
+    if (c.eps != nullptr) ingest_copy(c.eps, a.d_eps, nullptr, n_eps, part, kIngestCopyBlocks);
+    if (c.outcome_row >= 0) {                            // segments.py:27-36, the previous step's
+      ingest_copy(c.next_obs, c.seg_next + c.outcome_row * n_obs, nullptr, n_obs, part,
+                  kIngestCopyBlocks);
+      ingest_copy(c.rewards, c.seg_rew + c.outcome_row * W, nullptr, W, part, kIngestCopyBlocks);
+      ingest_copy(c.resets, c.seg_rst + c.outcome_row * W, nullptr, W, part, kIngestCopyBlocks);
+      ingest_copy(c.terminations, c.seg_term + c.outcome_row * W, nullptr, W, part,
+                  kIngestCopyBlocks);
+    }
+    return;
+  }
+  // MeanStd.record (mean_stds.py:44-48): thread k walks feature k over the rows IN ORDER; the sums
+  // go from history entry `row` to `row + 1` (collector.hip: a step may be issued twice)
+  if (c.norm_hist == nullptr) return;
+  const int k = threadIdx.x;
+  const float* in = c.norm_hist + c.row * 2 * c.O;
+  float* out = c.norm_hist + (c.row + 1) * 2 * c.O;
+  float sum = 0.f, sum_sq = 0.f;
+  if (k < c.O) { sum = in[k]; sum_sq = in[c.O + k]; }
+  const int64_t rows_per_chunk = (16384 / c.O) & ~(int64_t)3;
+  for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
+    const int64_t rows = min(rows_per_chunk, W - w0);
+    __syncthreads();
+    ingest_copy(c.obs + w0 * c.O, tile, nullptr, rows * c.O, 0, 1);
+    __syncthreads();
+    if (k < c.O) record_rows(tile + k, c.O, (int)rows, sum, sum_sq);
+  }
+  if (k < c.O) { out[k] = sum; out[c.O + k] = sum_sq; }
+}
+
+// a2c.py:75-85 after the head: actions = loc + sigma * eps and their log-probabilities -> the
+// Segment row and the block's action field, then the completion word of this workgroup (the
+// ingest launch ahead of it on the stream has read everything it needs from the block by now)
+__global__ __launch_bounds__(kWideThreads) void wide_sample_store_kernel(
+    const float* loc, int ld, const float* log_scale, const float* eps, WideCollect c) {
+  __shared__ float sigma_s[kWideLd], half_inv_var_s[kWideLd], logc_s[kWideLd];
+  if ((int)threadIdx.x < c.A) {
+    const float ls = log_scale[threadIdx.x];
+    const float sp = ls > 20.f ? ls : log1pf(expf(ls));
+    const float sigma = fminf(fmaxf(sp + 1e-8f, 1e-4f), 1.0f);
+    sigma_s[threadIdx.x] = sigma;
+    half_inv_var_s[threadIdx.x] = 1.0f / (2.0f * (sigma * sigma));
+    logc_s[threadIdx.x] = logf(sigma) + kLogSqrt2Pi;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.W) {
+    float logp = 0.f;
+    for (int aa = 0; aa < c.A; ++aa) {
+      const float mu = loc[i * ld + aa];
+      const float act = eps != nullptr ? mu + sigma_s[aa] * eps[i * c.A + aa] : mu;   // a2c.py:81
+      const float dif = act - mu;
+      logp += -(dif * dif) * half_inv_var_s[aa] - logc_s[aa];
+      c.seg_act[(c.row * c.W + i) * c.A + aa] = act;
+      c.actions_out[i * c.A + aa] = act;
+    }
+    c.seg_lp[c.row * c.W + i] = logp;
+  }
+  // pinned host memory is cached write-back in this XCD's L2: release before the word goes out
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x == 0 && c.done_flags != nullptr)
+    __hip_atomic_store(c.done_flags + blockIdx.x, c.done_seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+int wide_collect_words(int64_t W) { return (int)((W + kWideThreads - 1) / kWideThreads); }
+
+int64_t wide_collect_workspace_bytes(int64_t W, int O, int A) {
+  return WideLayout(W, O, A, true).bytes + round_up(W * O * 4, 256) + round_up(W * A * 4, 256);
+}
+
+int wide_collect_step(const WideCollect& c, void* d_workspace, int64_t workspace_bytes,
+                      hipStream_t st) {
+  const WideLayout L(c.W, c.O, c.A, true);
+  TONIC_REQUIRE(d_workspace && workspace_bytes >= wide_collect_workspace_bytes(c.W, c.O, c.A),
+                TONIC_ERR_WORKSPACE, "wide collect step: workspace too small");
+  char* ws = static_cast<char*>(d_workspace);
+  IngestArgs in{c, reinterpret_cast<float*>(ws + L.bytes),
+                reinterpret_cast<float*>(ws + L.bytes + round_up(c.W * c.O * 4, 256))};
+  hipLaunchKernelGGL(wide_ingest_kernel, dim3(kIngestCopyBlocks + 1), dim3(kIngestThreads), 0, st, in);
+  TONIC_CHECK_LAUNCH("wide_ingest_kernel");
+  if (int rc = wide_forward(c.params, L, in.d_obs, c.W, c.O, c.A, true, nullptr, nullptr, 0.f, ws,
+                            nullptr, st))
+    return rc;
+  hipLaunchKernelGGL(wide_sample_store_kernel, dim3(wide_collect_words(c.W)), dim3(kWideThreads), 0,
+                     st, reinterpret_cast<const float*>(ws + L.off_out), kWideLd, c.params + L.ls,
+                     c.eps != nullptr ? in.d_eps : (const float*)nullptr, c);
+  TONIC_CHECK_LAUNCH("wide_sample_store_kernel");
   return TONIC_OK;
 }
 

@@ -215,7 +215,11 @@ class A2C(Agent):
 
     # -- shapes beyond the fused act kernel (O > 32 or A > 8): staged copies + separate launches
     def _wide(self):
-        return self.observation_size > 32 or self.action_size > 8
+        """Shapes beyond the fused act kernel go through the collector as well (layer-by-layer
+        launches per step on the mapped block, csrc/mlpwide.hip wide_collect_step);
+        TONIC_AMD_WIDE_STAGED=1 keeps the older path of staged copies and separate launches."""
+        return ((self.observation_size > 32 or self.action_size > 8)
+                and os.environ.get('TONIC_AMD_WIDE_STAGED', '0') == '1')
 
     def _step_staged(self, observations):
         observations = np.asarray(observations, np.float32)
