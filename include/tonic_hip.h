@@ -314,6 +314,11 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
  * step, it waits for the host's next command word in pinned memory instead of being launched
  * again, and parks itself (the next step starts it again) after TONIC_AMD_COLLECTOR_PARK_US
  * (default 200) microseconds without a command, e.g. under a slow simulator or a test episode.
+ * Shapes beyond the fused act kernel (32 < O <= 384 or 8 < A <= 32) always run as transport 0 with
+ * five launches per step (ingest, three dense layers, sample + store + completion words).
+ * A step is idempotent — issuing the same row again overwrites the same rows and recomputes the same
+ * MeanStd.record sums (kept as one entry per row between begin_rollout and end_rollout) — so a caller
+ * may issue the next step before it knows that the block's contents are final, and repeat it.
  * Per environment step t (tonic/utils/trainer.py:44-56):
  *   tonic_collector_ppo_step(row t)   ONE launch: policy forward + sample + log-prob of the block's
  *                                     observations (a2c.py:75-85) -> Segment row t and the block's

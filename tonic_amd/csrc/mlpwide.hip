@@ -59,12 +59,32 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
   const bool vec = (a.K & 3) == 0 && (a.ldx & 3) == 0;
   const int KS = vec ? 4 * ((a.K + 15) >> 4) : (a.K + 3) >> 2;
   auto column = [&](int st, int gg) { return vec ? 16 * (st >> 2) + 4 * gg + (st & 3) : 4 * st + gg; };
-  for (int idx = tid; idx < TN * KS * 64; idx += kWideThreads) {
-    const int l = idx & 63, st = (idx >> 6) % KS, T = (idx >> 6) / KS;
-    const int j = 16 * T + (l & 15), k = column(st, l >> 4);
-    float w = 0.f;
-    if (j < a.NOUT && k < a.K) w = a.transposed ? a.W[(int64_t)k * a.ldw + j] : a.W[(int64_t)j * a.ldw + k];
-    wl[idx] = w;
+  // Weight image: zero fill, then W read in MEMORY order (coalesced) and scattered to its slot —
+  // (j, k) -> tile j / 16, k-step st and lane g * 16 + j % 16 with k = column(st, g).  Sixteen
+  // loads in flight per thread: staging is most of a launch over a few hundred rows (the
+  // collector's per-step forward), where a gather in image order cost 10 us of 14.
+  for (int idx = tid; idx < TN * KS * 64; idx += kWideThreads) wl[idx] = 0.f;
+  __syncthreads();
+  {
+    const int rows = a.transposed ? a.K : a.NOUT, cols = a.transposed ? a.NOUT : a.K;
+    const int total = rows * cols;
+    for (int base = tid; base < total; base += 16 * kWideThreads) {
+      float w[16];
+      int slot[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int f = base + u * kWideThreads;
+        const bool live = f < total;
+        const int r = live ? f / cols : 0, cc = live ? f - r * cols : 0;
+        w[u] = a.W[(int64_t)r * a.ldw + cc];
+        const int j = a.transposed ? cc : r, k = a.transposed ? r : cc;
+        const int st = vec ? 4 * (k >> 4) + (k & 3) : k >> 2, gg = vec ? (k >> 2) & 3 : k & 3;
+        slot[u] = live ? ((j >> 4) * KS + st) * 64 + gg * 16 + (j & 15) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (slot[u] >= 0) wl[slot[u]] = w[u];
+    }
   }
   __syncthreads();
   const int s = lane & 15, g = lane >> 4;
