@@ -33,12 +33,18 @@ def _segment(T, W, O, A):
                 rewards=new(T, W), resets=new(T, W), terminations=new(T, W), log_probs=new(T, W))
 
 
-@pytest.mark.parametrize('transport', [0, 1, 2])
-@pytest.mark.parametrize('O,A,W', [(17, 6, 256), (28, 8, 1280), (3, 1, 5)])
+WIDE_STEPS = [pytest.param(0, O, A, W, id=f'wide-{O}-{A}-{W}')
+              for O, A, W in ((111, 8, 256), (376, 17, 67), (40, 21, 5), (33, 3, 300))]
+
+
+@pytest.mark.parametrize('transport,O,A,W',
+                         [(t, O, A, W) for t in (0, 1, 2)
+                          for O, A, W in ((17, 6, 256), (28, 8, 1280), (3, 1, 5))] + WIDE_STEPS)
 def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     """T host-in-the-loop steps through the C entry points: actions and log-probs against
     numpy_port.ppo_act (the reference's forward + sample + log_prob), stored rows and outcome
-    rows bit-exact copies, normaliser sums bit-exact against MeanStdPort.record."""
+    rows bit-exact copies, normaliser sums bit-exact against MeanStdPort.record.  The wide cases
+    (O > 32 or A > 8) take the collector's layer-by-layer steps (ingest, dense x 3, sample + store)."""
     from tonic_amd import _lib
     from tonic_amd.collector import Block, Collector
     T = 5
@@ -63,7 +69,8 @@ def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
         collector.wait_actions()
         actions = block.actions.copy()
         want_actions, want_log_probs = port.ppo_act(params, observations, eps)
-        np.testing.assert_allclose(actions, want_actions, rtol=0, atol=3e-6)
+        # (wide cases: hundreds of float32 products per pre-activation, weights of 0.3 each)
+        np.testing.assert_allclose(actions, want_actions, rtol=0, atol=3e-6 if O <= 32 else 5e-5)
         want['observations'][t] = observations
         want['actions'][t] = actions
         want['log_probs'][t] = want_log_probs
@@ -80,7 +87,8 @@ def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     torch.cuda.synchronize()
     for key in ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations'):
         assert np.array_equal(seg[key].cpu().numpy(), want[key]), key
-    np.testing.assert_allclose(seg['log_probs'].cpu().numpy(), want['log_probs'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(seg['log_probs'].cpu().numpy(), want['log_probs'], rtol=0,
+                               atol=2e-5 if O <= 32 else 2e-4)
     got = sums.cpu().numpy()
     assert np.array_equal(got[:O], recorder.new_sum) and np.array_equal(got[O:], recorder.new_sum_sq)
     collector.close()
