@@ -17,7 +17,8 @@ from tonic_amd.environments import Box  # noqa: E402
 
 def run(kind, out_path, rows=40, W=8, O=11, A=3, iterations=6, batch=48):
     rank, world = parallel.init_from_env()
-    cls = tonic_amd.torch.agents.SAC if kind == 'sac' else tonic_amd.torch.agents.TD3
+    cls = dict(sac=tonic_amd.torch.agents.SAC, td3=tonic_amd.torch.agents.TD3,
+               d4pg=tonic_amd.torch.agents.D4PG)[kind]
     agent = cls(replay=tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations,
                                                 batch_size=batch, steps_before_batches=0,
                                                 steps_between_batches=1))

@@ -46,7 +46,7 @@ def test_two_ranks_equal_single_process(tmp_path, schedule):
         np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)
 
 
-@pytest.mark.parametrize('kind,port', [('td3', 29641), ('sac', 29651)])
+@pytest.mark.parametrize('kind,port', [('td3', 29641), ('sac', 29651), ('d4pg', 29661)])
 def test_offpolicy_two_ranks_equal_single_process(tmp_path, kind, port):
     """Sharded Buffer + global index / noise streams: 1, 2 and 4 ranks give the same
     TD3 / SAC update as one process holding the whole buffer."""
