@@ -337,8 +337,6 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (a.skip != nullptr && *a.skip != 0) return;
-  stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
-  __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
   const int i = s;   // feature index inside a 16-feature tile when the lane acts in F layout
@@ -432,7 +430,12 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   const int64_t tile_stride = (int64_t)gridDim.x * kWaves16;
   TileIn cur, nxt;
   int64_t tile = (int64_t)blockIdx.x * kWaves16 + wave;
-  if (tile < ntiles) load_tile(tile, cur);
+  // critic: the first tile's inputs are on their way from HBM while the weights are staged (the
+  // actor kernel, at its register limit, loses more in the tile loop than it gains: 287 -> 295 us)
+  if (!ACTOR && tile < ntiles) load_tile(tile, cur);
+  stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
+  __syncthreads();
+  if (ACTOR && tile < ntiles) load_tile(tile, cur);
   for (; tile < ntiles; tile += tile_stride) {
     PHASE(11);                                       // loop overhead / previous tail
     const int64_t ns = tile * 16 + s;
