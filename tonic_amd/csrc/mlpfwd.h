@@ -119,7 +119,55 @@ struct MlpBwdArgs {
   int ldxa;
   int B, H;
   int64_t stride_params, stride_hidden, stride_dq, stride_dxa;
+  // heads == 0, loss != LOSS_GIVEN: dq is formed HERE from the forward outputs — the element-wise
+  // loss of the step folded into its backward launch (one launch and one pass over q less) — and
+  // written to dq for the weight-gradient GEMM; workgroup (0, 0) also folds the logged sums.
+  //   LOSS_TD     y = r + disc * (min over the target critics - alpha * logp'), dq_z = 2 (q_z - y)
+  //               (critics.py:72-79, 166-175, 219-227); stats {sq_err_sum, q1_sum, q2_sum, 0, 0, B, 0, 0}
+  //   LOSS_ACTOR  SAC: alpha * logp - min(q1, q2); TD3 / DDPG: -q1 (actors.py:177-179, 254-257);
+  //               dq_z = -1 on the smaller critic (-1/2 each on ties); stats {loss_sum, 0, ..., B, ..}
+  int loss;
+  const float* l_rewards; const float* l_discounts; const float* l_tq; const float* l_logp;
+  const float* l_q; float* l_stats;
+  float l_alpha;
+  int l_nets, l_Bp;
 };
+enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
+
+// The TD target and the errors of one sample (shared by critic_loss_kernel and the folded form)
+__device__ __forceinline__ float td_target(const float* rewards, const float* discounts,
+                                           const float* tq, const float* logp_next, float alpha,
+                                           int m, int Bp, int nets) {
+  if (nets == 1) return rewards[m] + discounts[m] * tq[m];
+  float next = fminf(tq[m], tq[Bp + m]);
+  if (logp_next) next = next - alpha * logp_next[m];
+  return rewards[m] + discounts[m] * next;
+}
+
+// d (actor objective) / d q_z of one sample (shared by actor_loss_kernel and the folded form)
+__device__ __forceinline__ float actor_dq(const float* q, int m, int Bp, int twin, int z) {
+  if (!twin) return -1.f;
+  const float q1 = q[m], q2 = q[Bp + m];
+  if (z == 0) return q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
+  return q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
+}
+
+// Sum of up to three per-thread values over a workgroup of whole waves: float64 xor tree inside
+// each wave, then the wave partials in wave order by thread 0 (deterministic).  Result valid on
+// thread 0 only.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
+  __shared__ double wave_part[3][16];
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { wave_part[0][wave] = a; wave_part[1][wave] = b; wave_part[2][wave] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      a += wave_part[0][w]; b += wave_part[1][w]; c += wave_part[2][w];
+    }
+  }
+}
 
 bool mlp_forward_supported(int H, int NH, int heads);
 bool mlp_policy_tail_supported(int H, int NH);

@@ -487,7 +487,20 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (a.heads == 0) {                                 // critic: dq[row] * w3[feature]
-    const float dq = a.dq[net * a.stride_dq + row];
+    float dq;
+    if (a.loss == LOSS_GIVEN) {
+      dq = a.dq[net * a.stride_dq + row];
+    } else {                                          // the step's loss, folded into this launch
+      if (a.loss == LOSS_TD) {
+        const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, row,
+                                  a.l_Bp, a.l_nets);
+        dq = 2.f * (a.l_q[net * a.l_Bp + row] - y);
+      } else {
+        dq = actor_dq(a.l_q, row, a.l_Bp, a.l_nets == 2, net);
+      }
+      if (row_ok && wave == 0 && kg == 0)             // for the weight-gradient GEMM (dw3, db3)
+        const_cast<float*>(a.dq)[net * a.stride_dq + row] = dq;
+    }
     const float* w3 = a.w3 + net * a.stride_params;
 #pragma unroll
     for (int j = 0; j < kMaxTiles; ++j) {
@@ -576,6 +589,34 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
         const int o = 16 * wave + 4 * kg + e;
         if (o < a.xa_count) dst[o] = out[0][e];
       }
+    }
+  }
+  if (a.loss != LOSS_GIVEN && blockIdx.x == 0 && blockIdx.y == 0) {     // the logged sums (uniform)
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int r = tid; r < a.B; r += blockDim.x) {
+      if (a.loss == LOSS_TD) {
+        const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, r, a.l_Bp,
+                                  a.l_nets);
+        const float e1 = a.l_q[r] - y;
+        float sq = e1 * e1;
+        s1 += a.l_q[r];
+        if (a.l_nets == 2) {
+          const float e2 = a.l_q[a.l_Bp + r] - y;
+          sq = sq + e2 * e2;
+          s2 += a.l_q[a.l_Bp + r];
+        }
+        s0 += sq;
+      } else if (a.l_nets == 2) {
+        s0 += a.l_alpha * a.l_logp[r] - fminf(a.l_q[r], a.l_q[a.l_Bp + r]);
+      } else {
+        s0 += -a.l_q[r];
+      }
+    }
+    block_sum3(s0, s1, s2);
+    if (tid == 0) {
+      a.l_stats[0] = (float)s0; a.l_stats[1] = (float)s1; a.l_stats[2] = (float)s2;
+      a.l_stats[3] = 0.f; a.l_stats[4] = 0.f; a.l_stats[5] = (float)a.B; a.l_stats[6] = 0.f;
+      a.l_stats[7] = 0.f;
     }
   }
 }

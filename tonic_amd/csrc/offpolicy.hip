@@ -92,23 +92,6 @@ __global__ void copy_actions_kernel(const float* loc, int ld, float* act, int B,
   act[idx] = loc[(int64_t)(idx / A) * ld + (idx % A)];
 }
 
-// Sum of up to three per-thread values over a workgroup of whole waves: float64 xor tree inside
-// each wave, then the wave partials in wave order by thread 0 (deterministic).  Result valid on
-// thread 0 only.
-__device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
-  __shared__ double wave_part[3][16];
-  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { wave_part[0][wave] = a; wave_part[1][wave] = b; wave_part[2][wave] = c; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a = b = c = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-      a += wave_part[0][w]; b += wave_part[1][w]; c += wave_part[2][w];
-    }
-  }
-}
-
 // y = r + disc * (min(q1', q2') - alpha * logp')  (critics.py:219-221; alpha = 0 and logp = null
 // give TD3's critics.py:166-167), then dq_z = 2 (q_z - y) and the statistics.
 // nets == 1 (DDPG, critics.py:72-79): y = r + disc * q', one critic, statistics {sq_err, q, 0}.
@@ -118,17 +101,14 @@ __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
                                    int nets) {
   float s_loss = 0.f, s_q1 = 0.f, s_q2 = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
+    const float y = td_target(rewards, discounts, tq, logp_next, alpha, m, Bp, nets);
     if (nets == 1) {
-      const float y = rewards[m] + discounts[m] * tq[m];
       const float e1 = q[m] - y;
       dq[m] = 2.f * e1;
       s_loss += e1 * e1;
       s_q1 += q[m];
       continue;
     }
-    float next = fminf(tq[m], tq[Bp + m]);
-    if (logp_next) next = next - alpha * logp_next[m];
-    const float y = rewards[m] + discounts[m] * next;
     const float e1 = q[m] - y, e2 = q[Bp + m] - y;
     dq[m] = 2.f * e1;
     dq[Bp + m] = 2.f * e2;
@@ -152,13 +132,11 @@ __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha
   float s = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
     const float q1 = q[m];
+    dq[m] = actor_dq(q, m, Bp, twin, 0);
     if (twin) {
-      const float q2 = q[Bp + m];
-      dq[m] = q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
-      dq[Bp + m] = q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
-      s += alpha * logp[m] - fminf(q1, q2);
+      dq[Bp + m] = actor_dq(q, m, Bp, twin, 1);
+      s += alpha * logp[m] - fminf(q1, q[Bp + m]);
     } else {
-      dq[m] = -1.f;
       s += -q1;
     }
   }
@@ -757,19 +735,46 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
 // Backward of `nets` critics from dq [nets][Bp].  grads != null: weight/bias gradient SUMS into
 // the flat layout (stride = critic param count).  dxa != null: the ACTION columns of the input
 // gradient, [nets][Bp][pad16(A)] (all the actor step needs of dX; the caller adds the critics).
+// loss != null: dq is not given but FORMED from the forward outputs by the step's loss (LOSS_TD /
+// LOSS_ACTOR, mlpfwd.h) and written to `dq`, the logged sums to loss->stats — inside the backward
+// launch when the one-launch chain applies, by the stand-alone loss kernel otherwise.
+struct StepLoss {
+  int kind;                                   // LOSS_TD | LOSS_ACTOR
+  const float* rewards; const float* discounts; const float* tq; const float* logp;
+  float alpha;
+  const float* q; float* stats;
+};
+
 int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
-                     int Bp, const float* h1, const float* h2, const float* dq, float* dh2,
-                     float* dh1, float* grads, float* dxa, hipStream_t st) {
+                     int Bp, const float* h1, const float* h2, float* dq, float* dh2,
+                     float* dh1, float* grads, float* dxa, hipStream_t st,
+                     const StepLoss* loss = nullptr) {
   const CriticOffsets o(s);
+  const bool one_launch = mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0);
+  if (loss && !one_launch) {
+    if (loss->kind == LOSS_TD) {
+      hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, loss->rewards,
+                         loss->discounts, loss->tq, loss->logp, loss->alpha, loss->q, dq,
+                         loss->stats, B, Bp, nets);
+    } else {
+      hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, loss->q, loss->logp,
+                         loss->alpha, nets == 2 ? 1 : 0, dq, loss->stats, B, Bp);
+    }
+  }
   const int in = s.O + s.A;
   const int HP = weight_ld(s.H);
   const int64_t hs = (int64_t)Bp * HP;
   const int ldxa = pad16(s.A);
   GemmArgs g;
   // the input-gradient chain first ...
-  if (mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0)) {        // ... in ONE launch
+  if (one_launch) {                                               // ... in ONE launch
     MlpBwdArgs b{};
     b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
+    if (loss) {
+      b.loss = loss->kind; b.l_rewards = loss->rewards; b.l_discounts = loss->discounts;
+      b.l_tq = loss->tq; b.l_logp = loss->logp; b.l_alpha = loss->alpha; b.l_q = loss->q;
+      b.l_stats = loss->stats; b.l_nets = nets; b.l_Bp = Bp;
+    }
     b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
     b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
     b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa; b.ldhid = HP;
@@ -971,11 +976,10 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   }
   TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                       d_critics, X2));
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts, tq,
-                     kind == 1 ? logp : (const float*)nullptr, (float)entropy_coeff, q, dq,
-                     d_grad_sums + nets * Pc, B, Bp, nets);
+  const StepLoss td{LOSS_TD, d_rewards, d_discounts, tq, kind == 1 ? logp : (const float*)nullptr,
+                    (float)entropy_coeff, q, d_grad_sums + nets * Pc};
   TRY(critics_backward(d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
-                       nullptr, st));
+                       nullptr, st, &td));
   TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
   return TONIC_OK;
 }
@@ -1254,11 +1258,10 @@ extern "C" int tonic_expected_sarsa_grad(
                      st, d_observations, d_actions, d_norm_mean, d_norm_std, clip_bound(norm_clip),
                      w.X2, B, O, A, ldx);
   TRY(critics_forward(d_critic, cs, 1, w.X2, ldx, B, Bp, w.c_h1, w.c_h2, w.q, st));
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, d_rewards, d_discounts,
-                     w.tq_mean, (const float*)nullptr, 0.f, w.q, w.dq,
-                     d_grad_sums + critic_count(cs), B, Bp, 1);
+  const StepLoss td{LOSS_TD, d_rewards, d_discounts, w.tq_mean, nullptr, 0.f, w.q,
+                    d_grad_sums + critic_count(cs)};
   TRY(critics_backward(d_critic, cs, 1, w.X2, ldx, B, Bp, w.c_h1, w.c_h2, w.dq, w.dh2, w.dh1,
-                       d_grad_sums, nullptr, st));
+                       d_grad_sums, nullptr, st, &td));
   TONIC_CHECK_LAUNCH("tonic_expected_sarsa_grad");
   return TONIC_OK;
 }
@@ -1354,10 +1357,10 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                        B, O, A, ldx);
   }
   TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
-  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, st, q, logp, (float)entropy_coeff,
-                     nets == 2 ? 1 : 0, dq, d_grad_sums + Pa, B, Bp);
+  const StepLoss objective{LOSS_ACTOR, nullptr, nullptr, nullptr, logp, (float)entropy_coeff, q,
+                           d_grad_sums + Pa};
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dxa,
-                       st));
+                       st, &objective));
   hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
                      dim3(threads), 0, st, dxa, nets == 2 ? dxa + (int64_t)Bp * ldh : (float*)nullptr,
                      ldh, act, d_eps, sigma, head1, ldh,
