@@ -6,7 +6,8 @@ full-size float32 checker.  Pinned against the golden vectors by tests/test_orac
 
 Cited reference code (relative to the reference checkout): ``tonic/torch/agents/a2c.py:41-99``,
 ``ppo.py:20-67``, ``tonic/torch/updaters/actors.py:70-112``, ``critics.py:18-28``,
-``tonic/replays/segments.py:27-78``, ``tonic/torch/normalizers/mean_stds.py:34-74``.
+``tonic/replays/segments.py:27-78``, ``tonic/torch/normalizers/mean_stds.py:34-74``; TRPO:
+``tonic/torch/agents/trpo.py:7-97``, ``updaters/actors.py:115-156``, ``updaters/optimizers.py:25-115``.
 """
 import numpy as np
 import torch
@@ -129,6 +130,98 @@ class TorchPPO:
         mean, std = self.normalizer.update()
         self.norm_mean, self.norm_std = torch.as_tensor(mean), torch.as_tensor(std)
         return infos
+
+
+class TorchTRPO(TorchPPO):
+    """TRPO (``tonic/torch/agents/trpo.py:7-97``): the natural-gradient actor step of
+    ``updaters/actors.py:115-156`` — surrogate ``-(ratio * advantage).mean()``, constraint
+    ``KL(new || behaviour).mean()`` — solved as in ``updaters/optimizers.py:25-115``: ten conjugate
+    gradient iterations on damped Fisher-vector products (double back-propagation through the KL,
+    vector algebra in NumPy float32), step length ``sqrt(2 delta / x^T H x + 1e-8)``, then up to
+    ten backtracking trials ``0.8 ** i`` accepted when ``KL <= delta`` and the surrogate did not
+    get worse; the critic is the plain regression, ``iterations`` full-batch steps."""
+    CG_STEPS, DAMPING, DELTA, BACKTRACK_STEPS, BACKTRACK = 10, 0.1, 0.01, 10, 0.8
+
+    def _flat(self, tensors):
+        return torch.cat([t.reshape(-1) for t in tensors])
+
+    def _assign(self, flat):
+        offset = 0
+        with torch.no_grad():
+            for p in self.actor_vars:
+                p.copy_(flat[offset:offset + p.numel()].reshape(p.shape))
+                offset += p.numel()
+
+    def natural_step(self, observations, actions, log_probs, locs, scales, advantages):
+        if bool((advantages == 0).all()):
+            return dict(loss=0.0, kl=0.0, backtrack_steps=0)
+        behaviour = torch.distributions.normal.Normal(locs, scales)
+
+        def surrogate():
+            new = self.distribution(observations).log_prob(actions).sum(dim=-1)
+            return -(torch.exp(new - log_probs) * advantages).mean()
+
+        def divergence():
+            return torch.distributions.kl.kl_divergence(
+                self.distribution(observations), behaviour).mean()
+
+        def fisher_vector(v):
+            first = self._flat(torch.autograd.grad(divergence(), self.actor_vars,
+                                                   create_graph=True))
+            second = self._flat(torch.autograd.grad((first * torch.as_tensor(v)).sum(),
+                                                    self.actor_vars))
+            return (second + self.DAMPING * torch.as_tensor(v)).numpy()
+
+        start = self._flat(self.actor_vars).detach().clone()
+        loss = surrogate()
+        b = self._flat(torch.autograd.grad(loss, self.actor_vars)).numpy()
+        start_loss = loss.detach().numpy()
+        x, r, p = np.zeros_like(b), b.copy(), b.copy()
+        rr = np.dot(r, r)
+        if rr == 0:
+            return dict(loss=0.0, kl=0.0, backtrack_steps=0)
+        for _ in range(self.CG_STEPS):
+            z = fisher_vector(p)
+            alpha = rr / (np.dot(p, z) + port.FLOAT_EPSILON)
+            x += alpha * p
+            r -= alpha * z
+            rr_new = np.dot(r, r)
+            p = r + (rr_new / rr) * p
+            rr = rr_new
+        length = np.sqrt(2 * self.DELTA / np.dot(x, fisher_vector(x)) + port.FLOAT_EPSILON)
+        direction = torch.as_tensor(x)
+
+        def trial(fraction):
+            self._assign(start - length * direction * fraction)
+            with torch.no_grad():
+                return divergence(), surrogate()
+
+        for i in range(self.BACKTRACK_STEPS):
+            kl, loss = trial(self.BACKTRACK ** i)
+            if kl.numpy() <= self.DELTA and loss.numpy() <= start_loss:
+                break
+            if i == self.BACKTRACK_STEPS - 1:
+                kl, loss = trial(0)
+                i = self.BACKTRACK_STEPS
+        return dict(loss=float(loss), kl=float(kl), backtrack_steps=i + 1)
+
+    def update(self, iterations=None):                                   # trpo.py:69-97
+        batch = self.evaluate_and_returns()
+        if 'locs' in self.buffers:                   # as stored at acting time (trpo.py:20-33)
+            locs, scales = (torch.as_tensor(port.flatten_time_major(self.buffers[k]))
+                            for k in ('locs', 'scales'))
+        else:                                        # the same numbers, from the unchanged policy
+            with torch.no_grad():
+                behaviour = self.distribution(batch['observations'])
+            locs, scales = behaviour.loc, behaviour.stddev
+        info = dict(actor=self.natural_step(batch['observations'], batch['actions'],
+                                            batch['log_probs'], locs, scales,
+                                            batch['advantages']))
+        info['critic'] = [self.critic_update(batch['observations'], batch['returns'])
+                          for _ in range(iterations or self.iterations)]
+        mean, std = self.normalizer.update()
+        self.norm_mean, self.norm_std = torch.as_tensor(mean), torch.as_tensor(std)
+        return info
 
 
 # ------------------------------------------------------------------- off-policy (SAC / TD3)

@@ -282,6 +282,38 @@ def test_torch_port_matches_reference(golden, name):
         np.testing.assert_allclose(got.detach().numpy(), want, rtol=0, atol=1e-6)
 
 
+def test_trpo_port_matches_reference(golden):
+    """oracle/torch_port.TorchTRPO — conjugate gradient on Fisher-vector products, backtracking
+    line search, critic regression — against two consecutive updates of the reference's TRPO agent."""
+    import torch
+    import torch_port
+    torch.set_num_threads(1)
+    g = golden('trpo_small')
+    O, A, W, steps, seed, iterations, updates = (int(x) for x in g['cfg'])
+    agent = torch_port.TorchTRPO(O, A, steps=steps, iterations=iterations)
+    for u in range(updates):
+        actor, critic, norm = _params(g, f'pre{u}/')
+        agent.load(actor, critic, norm)
+        agent.buffers = {k: g[f'u{u}/segment/{k}'].copy() for k in (
+            'observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+            'log_probs')}
+        agent.normalizer.new_count = 1
+        agent.normalizer.new_sum = np.zeros(O, np.float32)
+        agent.normalizer.new_sum_sq = np.zeros(O, np.float32)
+        info = agent.update()
+        assert np.array_equal(agent.buffers['returns'], g[f'u{u}/segment/returns'])
+        assert info['actor']['backtrack_steps'] == int(g[f'u{u}/info/actor/backtrack_steps'][0])
+        np.testing.assert_allclose(info['actor']['loss'], g[f'u{u}/info/actor/loss'][0], rtol=1e-5,
+                                   atol=1e-7)
+        np.testing.assert_allclose(info['actor']['kl'], g[f'u{u}/info/actor/kl'][0], rtol=1e-4,
+                                   atol=1e-7)
+        np.testing.assert_allclose([float(c['loss']) for c in info['critic']],
+                                   g[f'u{u}/info/critic/loss'], rtol=1e-6, atol=1e-6)
+        ref_actor, ref_critic, _ = _params(g, f'post{u}/')
+        for got, want in zip(agent.actor_vars + agent.critic_vars, ref_actor + ref_critic):
+            np.testing.assert_allclose(got.detach().numpy(), want, rtol=0, atol=2e-6)
+
+
 def test_c_restatement_matches_golden(golden):
     """oracle/gae_ref.c (built by __graft_entry__.build()) is bit-exact with the reference."""
     import ctypes
