@@ -148,3 +148,44 @@ def test_categorical_with_support_equals_the_reference():
     assert torch.equal(a.probabilities, b.probabilities)
     assert torch.equal(a.mean(), b.mean())
     assert torch.equal(a.project(returns), b.project(returns))
+
+
+def test_explorations_and_scripted_agents_follow_the_reference_streams():
+    """tonic/explorations/noisy.py and tonic/agents/basic.py (host logic either side of the policy
+    forward): same constructor arguments, same NumPy RandomState stream, same per-worker reset
+    handling — bit-identical action sequences over warm-up, policy steps and resets."""
+    tonic = reference_loader.load_reference()
+    import tonic_amd
+    from tonic_amd.environments import Box
+    action_space = Box(-1, 1, (3,))
+    policy = lambda observations: np.tanh(observations[:, :3] * 0.7).astype(np.float32)
+    rng = np.random.RandomState(5)
+    for name, kwargs in (('NoActionNoise', dict(start_steps=3)),
+                         ('NormalActionNoise', dict(scale=0.3, start_steps=3)),
+                         ('OrnsteinUhlenbeckActionNoise', dict(scale=0.4, clip=1.5, start_steps=3))):
+        theirs = getattr(tonic.explorations, name)(**kwargs)
+        ours = getattr(tonic_amd.explorations, name)(**kwargs)
+        theirs.initialize(policy, action_space, seed=11)
+        ours.initialize(policy, action_space, seed=11)
+        for steps in range(12):
+            observations = rng.standard_normal((4, 5)).astype(np.float32)
+            a, b = theirs(observations, steps), ours(observations, steps)
+            assert a.dtype == b.dtype and np.array_equal(a, b), (name, steps)
+            resets = rng.rand(4) < 0.3
+            theirs.update(resets)
+            ours.update(resets)
+    for name, kwargs in (('NormalRandom', dict(loc=0.1, scale=0.5)), ('UniformRandom', {}),
+                         ('OrnsteinUhlenbeck', dict(scale=0.3)), ('Constant', dict(constant=0.25))):
+        theirs = getattr(tonic.agents, name)(**kwargs)
+        ours = getattr(tonic_amd.agents, name)(**kwargs)
+        theirs.initialize(None, action_space, seed=3)
+        ours.initialize(None, action_space, seed=3)
+        for steps in range(8):
+            observations = np.zeros((4, 5), np.float32)
+            assert np.array_equal(theirs.step(observations, steps), ours.step(observations, steps))
+            assert np.array_equal(theirs.test_step(observations, steps),
+                                  ours.test_step(observations, steps))
+            resets = rng.rand(4) < 0.3
+            outcome = (observations, np.zeros(4), resets, resets, steps)
+            theirs.update(*outcome), ours.update(*outcome)
+            theirs.test_update(*outcome), ours.test_update(*outcome)

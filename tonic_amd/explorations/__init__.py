@@ -38,4 +38,33 @@ class NormalActionNoise(NoActionNoise):
         return self.np_random.uniform(-1, 1, (len(observations), self.action_size))
 
 
-__all__ = ['NoActionNoise', 'NormalActionNoise']
+class OrnsteinUhlenbeckActionNoise(NoActionNoise):
+    """noisy.py:53-91: policy + a per-worker Ornstein-Uhlenbeck state (mean reversion theta * dt,
+    clipped N(0, 1) increments scaled by scale * sqrt(dt)) that `update` zeroes for the workers
+    whose episode was reset."""
+
+    def __init__(self, scale=0.1, clip=2, theta=.15, dt=1e-2, start_steps=20000):
+        super().__init__(start_steps)
+        self.scale, self.clip, self.theta, self.dt = scale, clip, theta, dt
+
+    def initialize(self, policy, action_space, seed=None):
+        super().initialize(policy, action_space, seed)
+        self.noises = None
+
+    def __call__(self, observations, steps):
+        if steps <= self.start_steps:
+            return self.np_random.uniform(-1, 1, (len(observations), self.action_size))
+        actions = self.policy(observations)
+        if self.noises is None:
+            self.noises = np.zeros_like(actions)
+        draws = np.clip(self.np_random.normal(size=actions.shape), -self.clip, self.clip)
+        self.noises -= self.theta * self.noises * self.dt
+        self.noises += self.scale * np.sqrt(self.dt) * draws
+        return np.clip((actions + self.noises).astype(np.float32), -1, 1)
+
+    def update(self, resets):
+        if self.noises is not None:
+            self.noises *= (1. - resets)[:, None]
+
+
+__all__ = ['NoActionNoise', 'NormalActionNoise', 'OrnsteinUhlenbeckActionNoise']

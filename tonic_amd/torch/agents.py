@@ -1,4 +1,4 @@
-"""PPO / DDPG / TD3 / SAC on the HIP engine — API of ``tonic/torch/agents/*.py``.
+"""A2C / PPO / TRPO / DDPG / TD3 / SAC / D4PG / MPO on the HIP engine — API of ``tonic/torch/agents/*.py``.
 
 ``step`` / ``update`` keep the reference signatures (NumPy in, NumPy out) so
 ``tonic.Trainer`` drives the agents unchanged.  The on-policy agents talk to the GPU through
@@ -258,6 +258,7 @@ class A2C(Agent):
             return self._step_staged(observations)
         block = getattr(self, '_block', None)
         if self._collector is None or block.workers != len(observations):
+            self._settle()
             self._bind(observations)
             block = self._block
         fed = observations is block.observations
@@ -686,8 +687,8 @@ class DDPG(Agent):
         """Enqueues `indices.shape[0]` learner iterations (no host sync).  indices: int64
         [iterations, B] host array; eps: float32 [iterations, draws, B, A] host array with the
         standard-normal draws in the order the reference consumes them.  With `graph` (default:
-        on unless TONIC_AMD_NO_GRAPH=1) the launch sequence — gather, ~45 small GEMM /
-        element-wise launches per iteration, Adam, polyak — is captured once into a hipGraph
+        on unless TONIC_AMD_NO_GRAPH=1) the launch sequence — gather, the fused forward / backward /
+        grouped weight-gradient launches, Adam + polyak: 13 per SAC iteration — is captured once into a hipGraph
         reading fixed index / noise buffers and replayed on later calls."""
         iterations, global_batch = indices.shape
         world = self.critic_updater.world_size
