@@ -38,6 +38,12 @@ int tonic_debug_grad16_phases(const float* d_actor_params, const float* d_observ
                               int32_t O, int32_t A, void* d_workspace, int64_t workspace_bytes,
                               uint64_t* d_phase_cycles, void* stream);
 
+/* Developer tool: wall-clock stamps (10 ns ticks) of workgroup (0, 0) of the fused off-policy
+ * forward at its phase boundaries {entry, loads issued, layer 1, epilogue + barrier, layer 2,
+ * epilogue + barrier, heads / output, policy tail}; d_stamps = uint64[8 launches][8], filled in
+ * rotation by the launches that follow; null switches the probe off (scripts/forward_stamps.py). */
+int tonic_debug_forward_stamps(uint64_t* d_stamps);
+
 /* Developer / test entry: one GEMM of the small-batch fp32 MFMA building block
  * (mode "NT" | "NN" | "TN"; act 0 none, 1 relu, 2 tanh; d_mask multiplies by (mask > 0)). */
 int tonic_gemm_f32(const char* mode, const float* d_a, const float* d_b, float* d_c,

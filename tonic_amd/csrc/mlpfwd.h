@@ -98,6 +98,7 @@ struct MlpFwdArgs {
   float enc_clip;                                                       // MeanStd(clip): +inf = none
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
+  unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
 };
 
 // Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).

@@ -13,6 +13,8 @@
 // activations are also written to HBM because the backward pass needs them.
 #include "mlpfwd.h"
 
+#include <atomic>
+
 namespace tonic {
 
 namespace {
@@ -173,6 +175,16 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const int H = a.H, pitch = H + 4, tiles = H / 16;
   const int net = blockIdx.y;
   const int r0 = blockIdx.x * kRows;
+  // developer probe: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
+  const bool probe = a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  auto stamp = [&](int i) {
+    if (probe) {
+      __builtin_amdgcn_sched_barrier(0);
+      a.stamps[i] = wall_clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
   const int row = min(r0 + m, a.B - 1);               // batch row of this lane (clamped)
   const bool row_ok = r0 + m < a.B;
   const bool second = net >= a.split;                 // scalar
@@ -248,17 +260,21 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const float* xrow = (second ? a.X2 : a.X) + (int64_t)row * a.ldx;
   Layer<kMaxTiles> l1;
   l1.start(rows1, a.K1, kg);
+  stamp(1);
   l1.run(kg, acc, [&](int k) { return load_k4(xrow, k); },
          [&](int k) { return load_k4_tail(xrow, k, a.K1); });
+  stamp(2);
   Layer<kMaxTiles> l2;
   l2.start(rows2, H, kg);                             // W2's first operands fly over the epilogue
   finish(acc, bias1, h1g, hx);
   __syncthreads();
+  stamp(3);
 
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
   l2.run(kg, acc, from_hx, from_hx);
+  stamp(4);
   // A head tile is one dependent chain of H / 4 MFMAs on one wave with nothing to hide a load
   // behind: its whole weight row (H <= 256: 16 loads per lane) is requested here, over the
   // second layer's epilogue and barrier.
@@ -288,12 +304,14 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   }
   finish(acc, bias2, h2g, hy);
   __syncthreads();
+  stamp(5);
   if (value_head) {
     if (wave == 0 && kg == 0 && row_ok) {
       float* out_base = a.out[0];
       out_base[net * a.stride_out + (int64_t)(r0 + m) * a.ldo] =
           ((partial[m] + partial[16 + m]) + (partial[32 + m] + partial[48 + m])) + hbias[0];
     }
+    stamp(6);
     return;
   }
 
@@ -322,6 +340,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
       }
     }
   }
+  stamp(6);
   if (a.post == POST_NONE) return;                    // scalar
 
   // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
@@ -402,6 +421,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
       for (int j = 0; j < off; ++j) v[j] += v[j + off];
     a.post_logp[r0 + tid] = v[0];
   }
+  stamp(7);
 }
 
 // Fused input-gradient chain of the same networks (the backward of mlp_forward_kernel without the
@@ -635,6 +655,15 @@ bool mlp_forward_supported(int H, int NH, int heads) {
          heads * ((NH + 15) / 16) <= 4;
 }
 
+static std::atomic<unsigned long long*> g_forward_stamps{nullptr};
+static std::atomic<unsigned> g_forward_launches{0};
+
+extern "C" int tonic_debug_forward_stamps(uint64_t* d_stamps) {
+  g_forward_stamps.store(reinterpret_cast<unsigned long long*>(d_stamps));
+  g_forward_launches.store(0);
+  return TONIC_OK;
+}
+
 int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(mlp_forward_supported(a.H, a.NH, a.heads) && a.B > 0 && a.K1 > 0 && nets > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: H=%d NH=%d heads=%d B=%d K1=%d", a.H,
@@ -657,8 +686,13 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
   const size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);
+  MlpFwdArgs launch = a;
+  launch.stamps = nullptr;
+  if (unsigned long long* base = g_forward_stamps.load()) {      // developer probe: ring of 8 launches
+    launch.stamps = base + 8 * (g_forward_launches.fetch_add(1) % 8);
+  }
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
-                     stream, a);
+                     stream, launch);
   TONIC_CHECK_LAUNCH("mlp_forward_kernel");
   return TONIC_OK;
 }
