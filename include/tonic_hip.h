@@ -518,7 +518,9 @@ int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d
  *   The critic is an actor-shaped network on the encoded input [normalised observation | action]:
  *   parameters in the layout of tonic_mlp_actor_param_count(O + A, H, NA, 1) — W1 [H, O + A], b1,
  *   W2, b2, distributional_layer [NA, H], bias [NA]; 2 <= NA <= 64 atoms; d_values = the support
- *   (DistributionalValueHead.values, float32 [NA], ascending).
+ *   (DistributionalValueHead.values, float32 [NA], ascending) — of the TARGET critic's head for
+ *   tonic_distributional_q_grad (returns and projection are taken from the target distribution,
+ *   critics.py:104-109), of the online critic's for tonic_distributional_actor_grad.
  *
  * tonic_distributional_q_grad — DistributionalDeterministicQLearning.__call__ (updaters/critics.py:
  *   100-122) up to the optimizer step: a' = target_actor(s'), the target critic's distribution at

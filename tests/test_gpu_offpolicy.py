@@ -237,10 +237,11 @@ def test_offpolicy_agent_drop_in_trajectory(lib, golden, name, kind):
     assert updated
 
 
-@pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100),
-                                          ('ddpg', 17, 6, 4, 100), ('d4pg', 24, 6, 4, 256),
-                                          ('mpo', 24, 6, 4, 100)])
-def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
+@pytest.mark.parametrize('kind,O,A,W,B,support', [
+    ('sac', 111, 8, 1, 1024, None), ('td3', 67, 21, 64, 100, None), ('ddpg', 17, 6, 4, 100, None),
+    ('d4pg', 24, 6, 4, 256, (-150., 150., 51)), ('d4pg', 6, 3, 4, 100, (-2., 12., 51)),
+    ('mpo', 24, 6, 4, 100, None)])
+def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B, support):
     """cfg-3 (SAC, O=111, A=8, B=1024) and cfg-4 per-GPU (TD3, O=67, A=21, 64 workers, the
     reference's default B=100) shapes with the default 256-wide networks: two learner iterations
     on the HIP path vs the torch-CPU oracle from identical parameters, buffer, indices, noise."""
@@ -254,6 +255,9 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
     agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG,
                  d4pg=tt.agents.D4PG, mpo=tt.agents.MPO)[kind](replay=replay)    # (d4pg: 51 atoms on +-150)
+    if support is not None:         # (the target networks are copies made at construction)
+        agent.model.critic.head = tt.models.DistributionalValueHead(*support)
+        agent.model.target_critic.head = tt.models.DistributionalValueHead(*support)
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
     # make the normaliser non-trivial
     norm = agent.model.observation_normalizer
@@ -262,7 +266,7 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     state = {'pre/' + k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
     host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
                 next_observations=rng.normal(size=(rows, W, O)),
-                rewards=rng.normal(size=(rows, W)) * (60.0 if kind == 'd4pg' else 1.0),
+                rewards=rng.normal(size=(rows, W)) * (0.4 * support[1] if kind == 'd4pg' else 1.0),
                 resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
     host = {k: np.asarray(v, np.float32) for k, v in host.items()}
     for t in range(rows):
@@ -271,7 +275,7 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B):
     indices = replay.sample_indices()
     draws = 2 if kind in ('sac', 'mpo') else 1
     eps = rng.normal(size=(2, draws, B * (20 if kind == 'mpo' else 1), A)).astype(np.float32)
-    oracle = torch_port.OffPolicyPort(kind, state, 'pre/', atoms=(-150., 150., 51))
+    oracle = torch_port.OffPolicyPort(kind, state, 'pre/', atoms=support or (-150., 150., 51))
     want = oracle.update(host, W, indices, eps)
     infos = agent.enqueue_update(indices, eps).cpu().numpy()
     np.testing.assert_allclose(infos[0][:, 0], [i['critic']['loss'] for i in want], rtol=1e-5, atol=1e-5)

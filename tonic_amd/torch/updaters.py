@@ -452,6 +452,14 @@ class _QUpdater(_FlatUpdater):
             want_critic = lib.tonic_mlp_actor_param_count(
                 self.observation_size + self.action_size, self.hidden, self.atoms, 1)
             self.values = critic.head.values.to(device=device, dtype=torch.float32).contiguous()
+            # the critic step takes returns and projection from the TARGET critic's distribution
+            # (critics.py:104-109); its support is the online one unless somebody changed one head
+            # after the model was built (the targets are copies made at construction)
+            target = getattr(model, 'target_critic', critic)
+            if getattr(target.head, 'num_atoms', self.atoms) != self.atoms:
+                raise NotImplementedError('online and target critic with different numbers of atoms')
+            self.target_values = target.head.values.to(device=device,
+                                                       dtype=torch.float32).contiguous()
         else:
             want_critic = lib.tonic_q_critic_param_count(
                 self.observation_size, self.action_size, self.hidden)
@@ -614,7 +622,7 @@ class DistributionalDeterministicQLearning(_TwinCriticQLearning):
             p(self.model.flat_target_actor.flat), p(self.model.flat_target_critics.flat),
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(batch['observations']),
             p(batch['actions']), p(batch['next_observations']), p(batch['rewards']),
-            p(batch['discounts']), p(self.values), p(self.grad_sums), B, self.observation_size,
+            p(batch['discounts']), p(self.target_values), p(self.grad_sums), B, self.observation_size,
             self.hidden, self.action_size, self.atoms, p(ws), ws.numel(), _lib.current_stream()),
             'tonic_distributional_q_grad')
         self._step(n_global or B * self.world_size, info_row)
