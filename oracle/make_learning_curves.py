@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — trains the UNMODIFIED reference's eight torch agents (CPU) on the task
-of tests/reach_task.py and writes the mean training reward of every tenth of each run to
+and in the cases of tests/reach_task.py and writes the mean training reward of every tenth of each run to
 tests/golden/learning_curves.json: what tests/test_gpu_learning.py holds this package's agents
 against (same task, same hyper-parameters, same seeds, same Trainer contract).
-Run in the build container: python oracle/make_learning_curves.py [AGENT ...]"""
+Run in the build container: python oracle/make_learning_curves.py [CASE ...]"""
 import json
 import os
 import sys
@@ -22,7 +22,7 @@ def main():
     tonic = reference_loader.load_reference()
     import tonic.torch
     out = os.path.join(ROOT, 'tests', 'golden', 'learning_curves.json')
-    names = sys.argv[1:] or ('PPO', 'A2C', 'TRPO', 'DDPG', 'TD3', 'SAC', 'D4PG', 'MPO')
+    names = sys.argv[1:] or tuple(reach_task.CASES)
     curves = json.load(open(out))['curves'] if sys.argv[1:] and os.path.exists(out) else {}
     for name in names:
         agent = reach_task.build_agent(tonic, tonic.torch.agents, name)

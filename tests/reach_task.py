@@ -1,17 +1,35 @@
 """The task of tests/test_gpu_learning.py and oracle/make_learning_curves.py (shared so that this
 package's agents and the reference's are trained on exactly the same thing): observations ~
-N(0, 1)^6, reward = 1 - mean((a - tanh(M obs))^2) for a fixed random M, time-outs after 20 steps."""
+N(0, 1)^O, reward = 1 - mean((a - tanh(M obs))^2) for a fixed random M, time-outs after 20 steps.
+
+CASES: name -> (agent, options).  Options: `shape` (O, A) of the task; `segment` / `buffer` keyword
+overrides; `groups` > 1: that many worker processes (`distribute(builder, groups, workers / groups)`);
+`test`: a test environment and four epochs, i.e. four rounds of test episodes interleaved with
+training (their `test_step` draws come out of the same generators)."""
+import functools
+
 import numpy as np
 
-O, A = 6, 3
-ON_POLICY = dict(size=64, batch_iterations=20)                  # Segment
+SEGMENT = dict(size=64, batch_iterations=20)
+BUFFER = dict(size=20000, batch_iterations=20, batch_size=100, discount_factor=0.9,
+              steps_before_batches=400, steps_between_batches=40)
 ON_POLICY_RUN = dict(steps=64 * 16 * 40, workers=16)
-OFF_POLICY = dict(size=20000, batch_iterations=20, batch_size=100, discount_factor=0.9,
-                  steps_before_batches=400, steps_between_batches=40)         # Buffer
 OFF_POLICY_RUN = dict(steps=6000, workers=4)
 START_STEPS = 400
 D4PG_SUPPORT = (-2., 12., 51)              # this task's values: (1 - mse) / (1 - 0.9)
-SEEDS = dict(environment=1, agent=5)
+SEEDS = dict(environment=1, test_environment=101, agent=5)
+ON_POLICY = ('PPO', 'A2C', 'TRPO')
+
+CASES = {
+    'PPO': ('PPO', {}), 'A2C': ('A2C', {}), 'TRPO': ('TRPO', {}), 'DDPG': ('DDPG', {}),
+    'TD3': ('TD3', {}), 'SAC': ('SAC', {}), 'D4PG': ('D4PG', {}), 'MPO': ('MPO', {}),
+    'PPO-test-episodes': ('PPO', dict(test=True)),
+    'SAC-test-episodes': ('SAC', dict(test=True)),
+    'PPO-minibatches': ('PPO', dict(segment=dict(batch_iterations=8, batch_size=256))),
+    'PPO-wide': ('PPO', dict(shape=(40, 10))),
+    'PPO-worker-processes': ('PPO', dict(groups=2)),
+    'TD3-worker-processes': ('TD3', dict(groups=2)),
+}
 
 
 class _Space:
@@ -21,37 +39,36 @@ class _Space:
 
 
 class Reach:
-    rewards = []
-
-    def __init__(self):
+    def __init__(self, O=6, A=3):
         self.observation_space = _Space(-np.inf, np.inf, (O,))
         self.action_space = _Space(-1, 1, (A,))
         self.max_episode_steps = 20
-        self.name = 'reach'
-        self.matrix = np.random.RandomState(7).standard_normal((A, O)).astype(np.float32) * 0.8
+        self.name = f'reach-{O}-{A}'
+        self.matrix = (np.random.RandomState(7).standard_normal((A, O)) * 2 / np.sqrt(O)).astype(np.float32)
         self.random = np.random.RandomState(0)
 
     def seed(self, seed):
         self.random = np.random.RandomState(seed)
 
     def reset(self):
-        self.observation = self.random.standard_normal(O).astype(np.float32)
+        self.observation = self.random.standard_normal(
+            self.observation_space.shape).astype(np.float32)
         return self.observation
 
     def step(self, action):
         target = np.tanh(self.matrix @ self.observation)
         reward = 1.0 - float(np.mean(np.square(np.clip(action, -1, 1) - target)))
-        Reach.rewards.append(reward)
         return self.reset(), reward, False, {}
 
 
-def build_agent(tonic, torch_agents, name):
-    """The agent `name` of either package (`tonic` = tonic_amd or the reference's tonic) in the
-    configuration of this task."""
-    if name in ('PPO', 'A2C', 'TRPO'):
-        return getattr(torch_agents, name)(replay=tonic.replays.Segment(**ON_POLICY))
+def build_agent(tonic, torch_agents, case):
+    """The agent of `case` from either package (`tonic` = tonic_amd or the reference's tonic)."""
+    name, options = CASES[case]
+    if name in ON_POLICY:
+        return getattr(torch_agents, name)(
+            replay=tonic.replays.Segment(**dict(SEGMENT, **options.get('segment', {}))))
     extra = dict(return_steps=3) if name in ('D4PG', 'MPO') else {}
-    replay = tonic.replays.Buffer(**OFF_POLICY, **extra)
+    replay = tonic.replays.Buffer(**dict(BUFFER, **options.get('buffer', {})), **extra)
     cls = getattr(torch_agents, name)
     if name == 'MPO':
         return cls(replay=replay)
@@ -72,18 +89,33 @@ def build_agent(tonic, torch_agents, name):
     return cls(model=model, replay=replay, exploration=noise(start_steps=START_STEPS))
 
 
-def train(tonic, agent, name, path):
-    """Runs the Trainer of `tonic`; returns the mean training reward of every tenth of the run."""
-    run = ON_POLICY_RUN if name in ('PPO', 'A2C', 'TRPO') else OFF_POLICY_RUN
+def train(tonic, agent, case, path):
+    """Runs the Trainer of `tonic`; returns the mean training reward of every tenth of the run
+    (from the `infos` the distributed environment hands to the trainer)."""
+    name, options = CASES[case]
+    run = ON_POLICY_RUN if name in ON_POLICY else OFF_POLICY_RUN
+    builder = functools.partial(Reach, *options.get('shape', (6, 3)))
+    groups = options.get('groups', 1)
     tonic.logger.initialize(path=path)
-    Reach.rewards = []
-    environment = tonic.environments.distribute(Reach, 1, run['workers'])
+    environment = tonic.environments.distribute(builder, groups, run['workers'] // groups)
     environment.initialize(seed=SEEDS['environment'])
+    test_environment = None
+    if options.get('test'):
+        test_environment = tonic.environments.distribute(builder, 1, 1)
+        test_environment.initialize(seed=SEEDS['test_environment'])
+    rewards, original_step = [], environment.step
+
+    def recording_step(actions):
+        observations, infos = original_step(actions)
+        rewards.append(float(np.mean(infos['rewards'])))
+        return observations, infos
+    environment.step = recording_step
     agent.initialize(environment.observation_space, environment.action_space, seed=SEEDS['agent'])
-    trainer = tonic.Trainer(steps=run['steps'], epoch_steps=run['steps'], save_steps=10 * run['steps'],
-                            show_progress=False)
-    trainer.initialize(agent, environment)
+    epochs = 4 if test_environment is not None else 1
+    trainer = tonic.Trainer(steps=run['steps'], epoch_steps=run['steps'] // epochs,
+                            save_steps=10 * run['steps'], test_episodes=4, show_progress=False)
+    trainer.initialize(agent, environment, test_environment)
     trainer.run()
-    rewards = np.array(Reach.rewards)
+    rewards = np.array(rewards)
     tenth = len(rewards) // 10
     return [float(rewards[i * tenth:(i + 1) * tenth].mean()) for i in range(10)]
