@@ -29,6 +29,11 @@ CASES = {
     'PPO-wide': ('PPO', dict(shape=(40, 10))),
     'PPO-worker-processes': ('PPO', dict(groups=2)),
     'TD3-worker-processes': ('TD3', dict(groups=2)),
+    'PPO-entropy-bonus': ('PPO', dict(entropy_coeff=0.02)),
+    'PPO-clipped': ('PPO', dict(clips=(0.05, 0.5, 1.5))),       # gradient_clip x 2, MeanStd(clip)
+    'TD3-ou-noise': ('TD3', dict(exploration='ou')),
+    'DDPG-5-step': ('DDPG', dict(buffer=dict(return_steps=5))),
+    'SAC-wide': ('SAC', dict(shape=(40, 10))),
 }
 
 
@@ -63,21 +68,39 @@ class Reach:
 
 def build_agent(tonic, torch_agents, case):
     """The agent of `case` from either package (`tonic` = tonic_amd or the reference's tonic)."""
+    import torch
     name, options = CASES[case]
+    package = __import__(torch_agents.__name__.rsplit('.', 1)[0],
+                         fromlist=['models', 'normalizers', 'updaters'])
+    models, updaters = package.models, package.updaters
     if name in ON_POLICY:
+        kwargs = {}
+        if 'entropy_coeff' in options:
+            kwargs['actor_updater'] = updaters.ClippedRatio(entropy_coeff=options['entropy_coeff'])
+        if 'clips' in options:      # a2c.py:7-17 with a clipping normaliser, clipped gradient norms
+            actor_clip, critic_clip, normalizer_clip = options['clips']
+            kwargs['actor_updater'] = updaters.ClippedRatio(gradient_clip=actor_clip)
+            kwargs['critic_updater'] = updaters.VRegression(gradient_clip=critic_clip)
+            kwargs['model'] = models.ActorCritic(
+                actor=models.Actor(encoder=models.ObservationEncoder(),
+                                   torso=models.MLP((64, 64), torch.nn.Tanh),
+                                   head=models.DetachedScaleGaussianPolicyHead()),
+                critic=models.Critic(encoder=models.ObservationEncoder(),
+                                     torso=models.MLP((64, 64), torch.nn.Tanh),
+                                     head=models.ValueHead()),
+                observation_normalizer=package.normalizers.MeanStd(clip=normalizer_clip))
         return getattr(torch_agents, name)(
-            replay=tonic.replays.Segment(**dict(SEGMENT, **options.get('segment', {}))))
+            replay=tonic.replays.Segment(**dict(SEGMENT, **options.get('segment', {}))), **kwargs)
     extra = dict(return_steps=3) if name in ('D4PG', 'MPO') else {}
-    replay = tonic.replays.Buffer(**dict(BUFFER, **options.get('buffer', {})), **extra)
+    replay = tonic.replays.Buffer(**dict(BUFFER, **extra, **options.get('buffer', {})))
     cls = getattr(torch_agents, name)
     if name == 'MPO':
         return cls(replay=replay)
     noise = tonic.explorations.NoActionNoise if name == 'SAC' else tonic.explorations.NormalActionNoise
+    if options.get('exploration') == 'ou':
+        noise = functools.partial(tonic.explorations.OrnsteinUhlenbeckActionNoise, scale=0.3)
     model = None
     if name == 'D4PG':          # d4pg.py:7-18 with a support for this task's values
-        package = __import__(torch_agents.__name__.rsplit('.', 1)[0], fromlist=['models', 'normalizers'])
-        import torch
-        models = package.models
         model = models.ActorCriticWithTargets(
             actor=models.Actor(encoder=models.ObservationEncoder(),
                                torso=models.MLP((256, 256), torch.nn.ReLU),
