@@ -7,6 +7,7 @@ overrides; `groups` > 1: that many worker processes (`distribute(builder, groups
 `test`: a test environment and four epochs, i.e. four rounds of test episodes interleaved with
 training (their `test_step` draws come out of the same generators)."""
 import functools
+import os
 
 import numpy as np
 
@@ -119,8 +120,10 @@ def train(tonic, agent, case, path):
     run = ON_POLICY_RUN if name in ON_POLICY else OFF_POLICY_RUN
     builder = functools.partial(Reach, *options.get('shape', (6, 3)))
     groups = options.get('groups', 1)
+    # one process per GPU (this package only): every rank takes its share of the workers
+    workers = run['workers'] // int(os.environ.get('WORLD_SIZE', '1'))
     tonic.logger.initialize(path=path)
-    environment = tonic.environments.distribute(builder, groups, run['workers'] // groups)
+    environment = tonic.environments.distribute(builder, groups, workers // groups)
     environment.initialize(seed=SEEDS['environment'])
     test_environment = None
     if options.get('test'):

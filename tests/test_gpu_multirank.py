@@ -176,3 +176,28 @@ def test_bench_runs_under_two_ranks(tmp_path):
     strong = result['strong_scaling']
     assert strong['global_workers'] == 256 and strong['workers_per_gpu'] == 128
     assert strong['ms_per_step'] < 2 * result['ms_per_step']
+
+
+LEARNING_WORKER = os.path.join(ROOT, 'tests', 'mp_learning_worker.py')
+
+
+@pytest.mark.parametrize('case,port', [('PPO', 29811), ('TD3', 29821), ('SAC', 29831)])
+def test_two_ranks_learn_like_the_single_process_reference(tmp_path, case, port):
+    """Whole training runs with one process per "GPU" (two ranks sharing this box's GPU, gloo):
+    each rank steps HALF of the workers through the Trainer — rank-offset environment seeds, the
+    rows of its own workers out of the global noise draws (TONIC_AMD_GLOBAL_NOISE=1), its shard of
+    Segment / Buffer, all-reduced gradients, moments and normaliser sums, global step counting.
+    Together the ranks are one run with all the workers: the mean of their reward curves must be
+    the curve of the UNMODIFIED single-process reference (tests/golden/learning_curves.json), and
+    the replicated parameters must be identical on both ranks."""
+    import json
+    out = str(tmp_path / 'run')
+    launch(2, out, port, command=(LEARNING_WORKER, case),
+           extra_env={'TONIC_AMD_GLOBAL_NOISE': '1'})
+    ranks = [json.load(open(f'{out}.rank{r}.json')) for r in range(2)]
+    assert ranks[0]['parameters'] == ranks[1]['parameters']
+    curve = np.mean([r['curve'] for r in ranks], axis=0)
+    golden = os.path.join(ROOT, 'tests', 'golden', 'learning_curves.json')
+    reference = np.array(json.load(open(golden))['curves'][case])
+    print('LEARN 2 ranks', case, ' '.join(f'{x:.3f}' for x in curve))
+    np.testing.assert_allclose(curve, reference, rtol=0, atol=0.03, err_msg=case)

@@ -57,6 +57,11 @@ def _outputs(block, copy):
     return block.observations.copy(), {k: v.copy() for k, v in block.infos.items()}
 
 
+def _rank_offset(workers):
+    from tonic_amd import parallel
+    return parallel.launch_rank()[0] * workers
+
+
 class Sequential:
     """A group of environments stepped in sequence (distributed.py:8-67)."""
 
@@ -69,6 +74,10 @@ class Sequential:
         self.copy_outputs = _copy_default() if copy_outputs is None else copy_outputs
 
     def initialize(self, seed):
+        # worker i of rank r is worker r * W + i of the whole job (the reference seeds worker i with
+        # seed + i, distributed.py:18-20): N ranks with W / N workers each see what one process
+        # with W workers would
+        seed += _rank_offset(len(self.environments))
         for i, environment in enumerate(self.environments):
             environment.seed(seed + i)
 
@@ -130,6 +139,7 @@ class Parallel:
         del dummy
         self.started = False
         workers = self.worker_groups * self.workers_per_group
+        seed += _rank_offset(workers)                       # (see Sequential.initialize)
         self.block = Block(workers, self.observation_space.shape[0],
                            self.action_space.shape[0], worker_groups=self.worker_groups)
         context = multiprocessing.get_context('fork')      # builders are closures (Q12)

@@ -10,14 +10,31 @@ class NoActionNoise:
         self.start_steps = start_steps
 
     def initialize(self, policy, action_space, seed=None):
+        from tonic_amd import parallel
         self.policy = policy
         self.action_size = action_space.shape[0]
         self.np_random = np.random.RandomState(seed)
+        # several ranks: the draws of ALL workers with TONIC_AMD_GLOBAL_NOISE=1 (this rank keeps the
+        # rows of its own: the single-process stream), else a stream of this rank's own
+        self.rank, self.world = parallel.rank(), parallel.world_size()
+        self.global_noise = self.world > 1 and parallel.global_noise()
+        if self.world > 1 and not self.global_noise and seed is not None:
+            self.np_random = np.random.RandomState(seed + self.rank)
+
+    def _draw(self, method, workers, *args):
+        """`method(*args, size=(workers, action_size))` for this rank's workers."""
+        if not self.global_noise:
+            return method(*args, size=(workers, self.action_size))
+        rows = method(*args, size=(self.world * workers, self.action_size))
+        return rows[self.rank * workers:(self.rank + 1) * workers]
+
+    def _warm_up(self, observations):
+        return self._draw(self.np_random.uniform, len(observations), -1, 1)
 
     def __call__(self, observations, steps):
         if steps > self.start_steps:
             return np.clip(self.policy(observations), -1, 1)
-        return self.np_random.uniform(-1, 1, (len(observations), self.action_size))
+        return self._warm_up(observations)
 
     def update(self, resets):
         pass
@@ -33,9 +50,9 @@ class NormalActionNoise(NoActionNoise):
     def __call__(self, observations, steps):
         if steps > self.start_steps:
             actions = self.policy(observations)
-            noises = self.scale * self.np_random.normal(size=actions.shape)
+            noises = self.scale * self._draw(self.np_random.normal, len(actions))
             return np.clip((actions + noises).astype(np.float32), -1, 1)
-        return self.np_random.uniform(-1, 1, (len(observations), self.action_size))
+        return self._warm_up(observations)
 
 
 class OrnsteinUhlenbeckActionNoise(NoActionNoise):
@@ -53,11 +70,11 @@ class OrnsteinUhlenbeckActionNoise(NoActionNoise):
 
     def __call__(self, observations, steps):
         if steps <= self.start_steps:
-            return self.np_random.uniform(-1, 1, (len(observations), self.action_size))
+            return self._warm_up(observations)
         actions = self.policy(observations)
         if self.noises is None:
             self.noises = np.zeros_like(actions)
-        draws = np.clip(self.np_random.normal(size=actions.shape), -self.clip, self.clip)
+        draws = np.clip(self._draw(self.np_random.normal, len(actions)), -self.clip, self.clip)
         self.noises -= self.theta * self.noises * self.dt
         self.noises += self.scale * np.sqrt(self.dt) * draws
         return np.clip((actions + self.noises).astype(np.float32), -1, 1)

@@ -39,6 +39,33 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def launch_rank():
+    """(rank, world) of this process as the launcher announced them (RANK / WORLD_SIZE of
+    ``python -m torch.distributed.run``), available before torch.distributed is initialised:
+    the environments are seeded before any agent exists."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    return (int(os.environ.get('RANK', '0')), world) if world > 1 else (0, 1)
+
+
+def global_noise():
+    """TONIC_AMD_GLOBAL_NOISE=1: every rank draws the action / exploration noise of ALL workers
+    and keeps the rows of its own (cost grows with the number of ranks), so that N ranks with W / N
+    workers each consume the random streams exactly like one process with W workers — what the
+    multi-rank learning-curve tests use.  Default: each rank draws for its own workers from a
+    generator re-seeded with seed + rank once the (replicated) parameters exist."""
+    return os.environ.get('TONIC_AMD_GLOBAL_NOISE', '0') == '1'
+
+
+def broadcast_from_first(tensors):
+    """Rank 0's values everywhere (parameters at start-up: replicas must not depend on every rank
+    having been given the same seed)."""
+    if world_size() > 1:
+        for tensor in tensors:
+            dist.broadcast(tensor, src=0)
+
+
 def exchanging():
     """True when the learner exchanges gradient sums between ranks.  Besides world_size > 1 that is
     a process group of ONE rank with TONIC_AMD_EXERCISE_EXCHANGE=1: a test hook that drives the

@@ -56,10 +56,35 @@ class Agent(agents.Agent):
     """tonic/torch/agents/agent.py:10-26 (seeding and .pt checkpoints)."""
 
     def initialize(self, seed=None):
+        from tonic_amd import parallel
+        parallel.init_from_env()          # one process per GPU under torch.distributed.run; else no-op
+        self.seed = seed
         if seed is not None:
             np.random.seed(seed)
             random.seed(seed)
             torch.manual_seed(seed)
+
+    def _replicate(self, buffers, own_noise):
+        """Several ranks: rank 0's parameters everywhere (replicas must not hinge on equal seeds),
+        then — `own_noise`, the on-policy agents, whose torch generator only feeds the action
+        noise — a generator of this rank's own, unless TONIC_AMD_GLOBAL_NOISE asks for the
+        single-process stream (parallel.global_noise)."""
+        from tonic_amd import parallel
+        self.rank, self.world = parallel.rank(), parallel.world_size()
+        self.global_noise = self.world > 1 and parallel.global_noise()
+        if self.world == 1:
+            return
+        parallel.broadcast_from_first(buffers)
+        if own_noise and not self.global_noise and self.seed is not None and self.rank > 0:
+            torch.manual_seed(self.seed + self.rank)
+
+    def _randn(self, workers, width, out=None):
+        """Standard-normal action noise for this rank's `workers` workers (global_noise: rows
+        [rank * workers, (rank + 1) * workers) of the draw for all of them)."""
+        if not self.global_noise:
+            return torch.randn(workers, width, out=out) if out is not None else torch.randn(workers, width)
+        rows = torch.randn(self.world * workers, width)[self.rank * workers:(self.rank + 1) * workers]
+        return rows if out is None else out.copy_(rows)
 
     def save(self, path):
         path = path + '.pt'
@@ -158,6 +183,7 @@ class A2C(Agent):
         self.critic_updater.initialize(self.model)
         self.observation_size = observation_space.shape[0]
         self.action_size = action_space.shape[0]
+        self._replicate([self.model.flat_actor.flat, self.model.flat_critic.flat], own_noise=True)
         self._collector = None
         # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
         # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
@@ -177,7 +203,9 @@ class A2C(Agent):
         stage_out.writable()
         stage_in.host_view('observations')[:] = observations
         # Same generator draw as Normal.sample() in the reference (a2c.py:81).
-        stage_in.host_view('eps')[:] = torch.randn(W, A).numpy()
+        # (test episodes run on every rank alike: plain draws; training workers are a shard)
+        draw = self._randn if want_log_probs else torch.randn
+        stage_in.host_view('eps')[:] = draw(W, A).numpy()
         stage_in.upload()
         p = _lib.ptr
         need = self.lib.tonic_ppo_workspace_bytes(W, self.observation_size, A, 1)
@@ -284,7 +312,7 @@ class A2C(Agent):
                 collector.begin_rollout(self.model.flat_actor.flat)
                 self._rollout_open = True
             if not self._eps_ahead:
-                torch.randn(self._eps[self._slot].shape, out=self._eps[self._slot])     # a2c.py:81
+                self._randn(*self._eps[self._slot].shape, out=self._eps[self._slot])    # a2c.py:81
             collector.ppo_step(self.replay.index, self._slot, self._pending)
             self._pending = False
         slot = self._slot
@@ -292,7 +320,7 @@ class A2C(Agent):
         # before the draw is kept: test_step rewinds to it (its own draws come first in the
         # reference's stream order).
         self._rng_mark = torch.get_rng_state()
-        torch.randn(self._eps[slot ^ 1].shape, out=self._eps[slot ^ 1])
+        self._randn(*self._eps[slot ^ 1].shape, out=self._eps[slot ^ 1])
         self._slot, self._eps_ahead = slot ^ 1, True
         collector.wait_actions()
         actions = block.actions.copy()
@@ -598,6 +626,8 @@ class DDPG(Agent):
         self.observation_size = observation_space.shape[0]
         self.action_size = action_space.shape[0]
         self.hidden = self.critic_updater.hidden
+        # (the torch generator also feeds the update's GLOBAL noise stream here: it stays in step)
+        self._replicate([self.model.flat_online, self.model.flat_target], own_noise=False)
         self._workers = None
         self._policy_io = {}
         self._graph, self._static_key = None, None       # a re-initialised agent re-captures
@@ -618,7 +648,7 @@ class DDPG(Agent):
         stage_in, stage_out, workspace = io
         stage_in.host_view('observations')[:] = observations
         if stochastic:      # Normal.sample() of sac.py:43 == loc + scale * randn
-            stage_in.host_view('eps')[:] = torch.randn(W, self.action_size).numpy()
+            stage_in.host_view('eps')[:] = self._randn(W, self.action_size).numpy()
         stage_in.upload()
         p = _lib.ptr
         _lib.check(self.lib.tonic_policy_forward(

@@ -28,6 +28,12 @@ def _paint(text, color=None, on_color=None, attrs=None):
 class Logger:
     def __init__(self, path=None, width=60, script_path=None, config=None):
         self.path = path or str(time.time())
+        # one process per GPU: rank 0 owns the experiment folder, the others write next to it
+        # (their episode statistics are those of their own workers)
+        from tonic_amd import parallel
+        rank = parallel.launch_rank()[0]
+        if rank > 0:
+            self.path = os.path.join(self.path, f'rank{rank}')
         self.log_file_path = os.path.join(self.path, 'log.csv')
         if script_path:
             with open(script_path) as source:

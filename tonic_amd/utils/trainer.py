@@ -127,9 +127,14 @@ class Trainer:
 
     def run(self):
         agent, environment = self.agent, self.environment
+        from tonic_amd import parallel
+        rank, world = parallel.launch_rank()
         observations = environment.start()
         workers = len(observations)
-        clock = EpochClock(workers, self.epoch_steps, self.save_steps, self.max_steps)
+        # `steps` counts the environment steps of the whole job (every rank steps its share of the
+        # workers in lockstep): schedules written in steps — epochs, checkpoints, Buffer.ready,
+        # exploration start — mean the same thing on one GPU and on eight
+        clock = EpochClock(workers * world, self.epoch_steps, self.save_steps, self.max_steps)
         ledger = EpisodeLedger(workers, 'train')
         keeper = CheckpointKeeper(self.replace_checkpoint)
         self.steps = 0
@@ -150,7 +155,8 @@ class Trainer:
                     self._test()
                 clock.report(ledger.finished)
             if clock.checkpoint_due:
-                keeper.save(agent, self.steps)
+                if rank == 0:                          # replicated parameters: one copy is enough
+                    keeper.save(agent, self.steps)
                 clock.saved()
 
     def _test(self):
