@@ -287,3 +287,62 @@ def test_offpolicy_padded_parameter_layout_keeps_state_dict():
         assert model.flat_critics.count == critics * lib.tonic_q_critic_param_count(o_dim, a_dim, 256)
         assert model.flat_actor.flat.data_ptr() == model.flat_online.data_ptr()
         assert all(p.data_ptr() % 16 == 0 for p in model.online_variables)
+
+
+def test_ranks_partition_the_single_process_run(monkeypatch):
+    """One process per GPU (RANK / WORLD_SIZE of the launcher): the workers of N ranks are seeded
+    like the workers of one process, the rows a rank keeps of the global exploration draws
+    (TONIC_AMD_GLOBAL_NOISE=1) are its workers' rows of the single-process stream, its own stream
+    (default) differs from rank to rank, and the Trainer counts the steps of the whole job."""
+    import tonic_amd
+    from tonic_amd import environments, explorations
+
+    def observations(rank, world, workers):
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        env = environments.distribute(lambda: environments.Synthetic(5, 2), 1, workers)
+        env.initialize(seed=3)
+        first = env.start().copy()
+        second = env.step(np.zeros((workers, 2), np.float32))[0].copy()
+        return np.stack([first, second], 1)
+    whole = observations(0, 1, 8)
+    assert np.array_equal(np.concatenate([observations(r, 2, 4) for r in range(2)]), whole)
+    assert np.array_equal(np.concatenate([observations(r, 4, 2) for r in range(4)]), whole)
+
+    policy = lambda obs: np.zeros((len(obs), 2), np.float32)
+    space = environments.Box(-1, 1, (2,))
+
+    def actions(rank, world, workers, global_noise, cls):
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setenv('TONIC_AMD_GLOBAL_NOISE', '1' if global_noise else '0')
+        noise = cls(start_steps=2)
+        noise.initialize(policy, space, seed=9)
+        return np.stack([noise(np.zeros((workers, 5), np.float32), steps) for steps in range(6)], 1)
+    for cls in (explorations.NoActionNoise, explorations.NormalActionNoise,
+                explorations.OrnsteinUhlenbeckActionNoise):
+        whole = actions(0, 1, 6, False, cls)
+        parts = [actions(r, 3, 2, True, cls) for r in range(3)]
+        assert np.array_equal(np.concatenate(parts), whole), cls.__name__
+        own = [actions(r, 3, 2, False, cls) for r in range(3)]
+        assert not np.array_equal(own[0][:, :3], own[1][:, :3])          # warm-up draws differ
+
+    class Counting(tonic_amd.agents.Agent):
+        def __init__(self):
+            self.steps = []
+
+        def step(self, observations, steps):
+            self.steps.append(steps)
+            return np.zeros((len(observations), 2), np.float32)
+
+        def test_step(self, observations, steps):
+            return self.step(observations, steps)
+    monkeypatch.setenv('RANK', '1')
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    env = environments.distribute(lambda: environments.Synthetic(5, 2), 1, 3)
+    env.initialize(seed=0)
+    agent = Counting()
+    trainer = tonic_amd.Trainer(steps=48, epoch_steps=24, save_steps=1000, show_progress=False)
+    trainer.initialize(agent, env)
+    trainer.run()
+    assert agent.steps == [0, 12, 24, 36]

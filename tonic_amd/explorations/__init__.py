@@ -16,7 +16,7 @@ class NoActionNoise:
         self.np_random = np.random.RandomState(seed)
         # several ranks: the draws of ALL workers with TONIC_AMD_GLOBAL_NOISE=1 (this rank keeps the
         # rows of its own: the single-process stream), else a stream of this rank's own
-        self.rank, self.world = parallel.rank(), parallel.world_size()
+        self.rank, self.world = parallel.launch_rank()
         self.global_noise = self.world > 1 and parallel.global_noise()
         if self.world > 1 and not self.global_noise and seed is not None:
             self.np_random = np.random.RandomState(seed + self.rank)
