@@ -181,7 +181,8 @@ def test_bench_runs_under_two_ranks(tmp_path):
 LEARNING_WORKER = os.path.join(ROOT, 'tests', 'mp_learning_worker.py')
 
 
-@pytest.mark.parametrize('case,port', [('PPO', 29811), ('TD3', 29821), ('SAC', 29831)])
+@pytest.mark.parametrize('case,port', [('PPO', 29811), ('TD3', 29821), ('SAC', 29831), ('TRPO', 29841),
+                                       ('A2C', 29851)])
 def test_two_ranks_learn_like_the_single_process_reference(tmp_path, case, port):
     """Whole training runs with one process per "GPU" (two ranks sharing this box's GPU, gloo):
     each rank steps HALF of the workers through the Trainer — rank-offset environment seeds, the

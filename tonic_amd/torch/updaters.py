@@ -221,7 +221,11 @@ class ConjugateGradient:
     Hessian-vector products are autograd double-backward passes of the constraint (KL) over the
     HBM-resident batch; then x is scaled to the trust region and shrunk until the constraint holds
     and the loss did not rise.  The CG scalars stay 0-dim device tensors (no host sync inside the
-    loop); each backtracking trial reads two scalars back, like the reference."""
+    loop); each backtracking trial reads two scalars back, like the reference.
+
+    Several ranks (equal shards of the batch): the loss / constraint values, the gradient and every
+    Hessian-vector product are batch MEANS, so each is averaged over the ranks with one all-reduce
+    and all ranks walk through identical CG iterations and backtracking trials."""
 
     def __init__(self, conjugate_gradient_steps=10, damping_coefficient=0.1,
                  constraint_threshold=0.01, backtrack_steps=10, backtrack_coefficient=0.8):
@@ -232,14 +236,23 @@ class ConjugateGradient:
         self.backtrack_coefficient = backtrack_coefficient
 
     def optimize(self, loss_function, constraint_function, variables):
+        from tonic_amd import parallel
         eps = 1e-8                                              # optimizers.py:5
+        world = parallel.world_size() if parallel.exchanging() else 1
+
+        def across(tensor):
+            """Mean over the ranks of a per-rank batch mean (in place; one rank: nothing)."""
+            if world > 1:
+                torch.distributed.all_reduce(tensor)
+                tensor /= world
+            return tensor
 
         def flat(tensors):
             return torch.cat([t.reshape(-1) for t in tensors])
 
         def hessian_vector(x):                                  # optimizers.py:36-48
             first = flat(torch.autograd.grad(constraint_function(), variables, create_graph=True))
-            second = flat(torch.autograd.grad((first * x).sum(), variables))
+            second = across(flat(torch.autograd.grad((first * x).sum(), variables)))
             if self.damping_coefficient > 0:
                 second = second + self.damping_coefficient * x
             return second
@@ -254,12 +267,13 @@ class ConjugateGradient:
         def trial(scale):                                       # optimizers.py:68-74
             assign(start - alpha * direction * scale)
             with torch.no_grad():
-                return constraint_function(), loss_function()
+                both = across(torch.stack([constraint_function(), loss_function()]))
+                return both[0], both[1]
 
         start = flat([v.detach() for v in variables]).clone()
         loss = loss_function()
-        gradient = flat(torch.autograd.grad(loss, variables))
-        start_loss = float(loss.detach())
+        gradient = across(flat(torch.autograd.grad(loss, variables)))
+        start_loss = float(across(loss.detach().clone()))
         zero = torch.zeros((), dtype=torch.float32)
         residual_dot = gradient.dot(gradient)
         if float(residual_dot) == 0:                            # optimizers.py:55-56, 87-91
@@ -308,8 +322,6 @@ class TrustRegionPolicyGradient:
 
     def __call__(self, observations, actions, log_probs, advantages, locs=None, scales=None):
         from tonic_amd import parallel
-        if parallel.exchanging():
-            raise NotImplementedError('TrustRegionPolicyGradient runs on one rank')
         device = self.variables[0].device
         observations, actions, log_probs, advantages = (
             torch.as_tensor(v, dtype=torch.float32, device=device)
@@ -321,7 +333,10 @@ class TrustRegionPolicyGradient:
         else:
             locs, scales = (torch.as_tensor(v, dtype=torch.float32, device=device)
                             for v in (locs, scales))
-        if bool((advantages == 0.).all()):                     # actors.py:127-130
+        nothing = (advantages == 0.).all().float()             # actors.py:127-130 (on ALL ranks)
+        if parallel.exchanging():
+            torch.distributed.all_reduce(nothing, op=torch.distributed.ReduceOp.MIN)
+        if bool(nothing):
             zero = torch.zeros((), dtype=torch.float32)
             return dict(loss=zero, kl=zero, backtrack_steps=torch.as_tensor(0, dtype=torch.int32))
         kl, loss, steps = self.optimizer.optimize(
