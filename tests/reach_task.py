@@ -35,6 +35,8 @@ CASES = {
     'TD3-ou-noise': ('TD3', dict(exploration='ou')),
     'DDPG-5-step': ('DDPG', dict(buffer=dict(return_steps=5))),
     'SAC-wide': ('SAC', dict(shape=(40, 10))),
+    'MPO-wide': ('MPO', dict(shape=(40, 10))),
+    'PPO-humanoid-shapes': ('PPO', dict(shape=(376, 17))),
 }
 
 
