@@ -583,6 +583,27 @@ int tonic_mpo_actor_grad(const float* d_actor_params, const float* d_target_acto
                          int32_t A, int32_t S, double epsilon, double epsilon_penalty,
                          double epsilon_mean, double epsilon_std, int32_t action_penalization,
                          void* d_workspace, int64_t workspace_bytes, void* stream);
+/* The same step when the batch is spread over several ranks.  The dual losses and gradients are
+ * functions of batch MEANS of per-state terms, so the step runs in two halves around one all-reduce:
+ * tonic_mpo_actor_grad_shard — everything of tonic_mpo_actor_grad for this rank's B states (the
+ *   actor's gradient SUMS -> d_grad_sums, statistics slot left to the second half) and, instead of the
+ *   dual step, the local column sums d_column_sums [6 + 2 A] (float64: the six per-state partials,
+ *   kl_mean[A], kl_std[A]); the caller sum-all-reduces them;
+ * tonic_mpo_dual_step — dual gradients, logged losses (d_stats) and the actor's statistics slot
+ *   (d_actor_stats = d_grad_sums + actor parameter count: {B * losses, 0, 0, 0, 0, B, 0, 0} with this
+ *   rank's B, possibly 0) from the all-reduced sums and the global batch size. */
+int tonic_mpo_actor_grad_shard(const float* d_actor_params, const float* d_target_actor,
+                               const float* d_target_critic, const float* d_duals,
+                               const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+                               const float* d_observations, const float* d_eps, float* d_grad_sums,
+                               double* d_column_sums, int32_t B, int32_t O, int32_t H, int32_t A,
+                               int32_t S, int32_t action_penalization, void* d_workspace,
+                               int64_t workspace_bytes, void* stream);
+int tonic_mpo_dual_step(const double* d_column_sums, const float* d_duals, float* d_dual_grads,
+                        float* d_stats, float* d_actor_stats, int32_t B, int32_t B_global,
+                        int32_t A, int32_t S, double epsilon, double epsilon_penalty,
+                        double epsilon_mean, double epsilon_std, int32_t action_penalization,
+                        void* stream);
 
 #ifdef __cplusplus
 }

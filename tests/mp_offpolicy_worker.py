@@ -18,7 +18,7 @@ from tonic_amd.environments import Box  # noqa: E402
 def run(kind, out_path, rows=40, W=8, O=11, A=3, iterations=6, batch=48):
     rank, world = parallel.init_from_env()
     cls = dict(sac=tonic_amd.torch.agents.SAC, td3=tonic_amd.torch.agents.TD3,
-               d4pg=tonic_amd.torch.agents.D4PG)[kind]
+               d4pg=tonic_amd.torch.agents.D4PG, mpo=tonic_amd.torch.agents.MPO)[kind]
     agent = cls(replay=tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations,
                                                 batch_size=batch, steps_before_batches=0,
                                                 steps_between_batches=1))
@@ -37,6 +37,9 @@ def run(kind, out_path, rows=40, W=8, O=11, A=3, iterations=6, batch=48):
     torch.cuda.synchronize()
     if rank == 0:
         state = {k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
+        if kind == 'mpo':           # the dual variables and the logged losses of the actor step
+            state['duals'] = agent.actor_updater.duals.cpu().numpy()
+            state['actor_infos'] = agent.last_actor_infos
         np.savez(out_path, infos=agent.last_infos, **state)
     # Buffer.get (buffers.py:81-91) across ranks: tiny batches so that some rank draws nothing
     replay = agent.replay

@@ -46,7 +46,7 @@ def test_two_ranks_equal_single_process(tmp_path, schedule):
         np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-5, err_msg=key)
 
 
-@pytest.mark.parametrize('kind,port', [('td3', 29641), ('sac', 29651), ('d4pg', 29661)])
+@pytest.mark.parametrize('kind,port', [('td3', 29641), ('sac', 29651), ('d4pg', 29661), ('mpo', 29871)])
 def test_offpolicy_two_ranks_equal_single_process(tmp_path, kind, port):
     """Sharded Buffer + global index / noise streams: 1, 2 and 4 ranks give the same
     TD3 / SAC update as one process holding the whole buffer."""
@@ -58,8 +58,10 @@ def test_offpolicy_two_ranks_equal_single_process(tmp_path, kind, port):
     for world in (2, 4):
         b = np.load(outs[world])
         np.testing.assert_allclose(b['infos'], a['infos'], rtol=1e-4, atol=1e-5)
+        if kind == 'mpo':
+            np.testing.assert_allclose(b['actor_infos'], a['actor_infos'], rtol=2e-4, atol=2e-5)
         for key in a.files:
-            if key == 'infos':
+            if key in ('infos', 'actor_infos'):
                 continue
             # Adam turns a gradient element at float32-noise level into a +-lr step whose sign
             # depends on the summation order, so a handful of elements may
@@ -182,7 +184,7 @@ LEARNING_WORKER = os.path.join(ROOT, 'tests', 'mp_learning_worker.py')
 
 
 @pytest.mark.parametrize('case,port', [('PPO', 29811), ('TD3', 29821), ('SAC', 29831), ('TRPO', 29841),
-                                       ('A2C', 29851)])
+                                       ('A2C', 29851), ('MPO', 29861)])
 def test_two_ranks_learn_like_the_single_process_reference(tmp_path, case, port):
     """Whole training runs with one process per "GPU" (two ranks sharing this box's GPU, gloo):
     each rank steps HALF of the workers through the Trainer — rank-offset environment seeds, the

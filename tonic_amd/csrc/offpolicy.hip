@@ -367,11 +367,16 @@ __global__ __launch_bounds__(256) void mpo_state_kernel(
 // stats [7 + 2 A + 2] = {policy_mean_loss, policy_std_loss, kl_mean_loss, kl_std_loss, alpha_mean_loss,
 // alpha_std_loss, temperature_loss, temperature, alpha_mean[A], alpha_std[A], penalty_temperature};
 // dual_grads [2 A + 2 + 8]: d loss / d log-duals + the statistics slot of the optimizer step.
+//
+// Several ranks (each holds B of the B_norm states of the global batch): everything below is a
+// function of the column MEANS, so the kernel runs in two halves around one all-reduce —
+// out_sums != null: only the local column sums [6 + 2 A] (float64) are written; in_sums != null: the
+// columns are taken from there (the all-reduced sums) instead of the per-state arrays.
 __global__ void mpo_dual_kernel(const float* part, const float* klm, const float* kls,
                                 const float* duals, int penalize, float epsilon,
                                 float epsilon_penalty, float epsilon_mean, float epsilon_std,
                                 float* dual_grads, float* stats, float* actor_stats, int B, int A,
-                                int S) {
+                                int S, const double* in_sums, double* out_sums, int B_norm) {
   __shared__ double col[2 * 64 + 6];
   const int tid = threadIdx.x;
   // column means in fixed order: columns 0..5 the six partials, 6..6+A-1 kl_mean, then kl_std; one
@@ -379,12 +384,20 @@ __global__ void mpo_dual_kernel(const float* part, const float* klm, const float
   const int columns = 6 + 2 * A, lane = tid & 63, waves = blockDim.x >> 6;
   for (int c = tid >> 6; c < columns; c += waves) {
     double sum = 0;
-    for (int m = lane; m < B; m += 64)
-      sum += c < 6 ? part[(int64_t)m * kMpoStats + c]
-                   : c < 6 + A ? klm[(int64_t)m * A + (c - 6)] : kls[(int64_t)m * A + (c - 6 - A)];
-    sum = wave_sum(sum);
-    if (lane == 0) col[c] = sum / B;
+    if (in_sums != nullptr) {
+      sum = in_sums[c];
+    } else {
+      for (int m = lane; m < B; m += 64)
+        sum += c < 6 ? part[(int64_t)m * kMpoStats + c]
+                     : c < 6 + A ? klm[(int64_t)m * A + (c - 6)] : kls[(int64_t)m * A + (c - 6 - A)];
+      sum = wave_sum(sum);
+    }
+    if (lane == 0) {
+      if (out_sums != nullptr) out_sums[c] = sum;
+      col[c] = sum / B_norm;
+    }
   }
+  if (out_sums != nullptr) return;                    // (uniform)
   __syncthreads();
   if (tid >= 64) return;                              // wave 0: lane = action dimension
   const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
@@ -1266,16 +1279,18 @@ extern "C" int tonic_expected_sarsa_grad(
   return TONIC_OK;
 }
 
-extern "C" int tonic_mpo_actor_grad(
+namespace {
+int mpo_actor_grad(
     const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
     const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
     const float* d_observations, const float* d_eps, float* d_grad_sums, float* d_dual_grads,
     float* d_stats, int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, double epsilon,
     double epsilon_penalty, double epsilon_mean, double epsilon_std, int32_t action_penalization,
-    void* d_workspace, int64_t workspace_bytes, void* stream) {
+    void* d_workspace, int64_t workspace_bytes, void* stream, double* d_column_sums) {
   TONIC_REQUIRE(d_actor_params && d_target_actor && d_target_critic && d_duals && d_norm_mean &&
-                    d_norm_std && d_observations && d_eps && d_grad_sums && d_dual_grads &&
-                    d_stats && d_workspace && B > 0 && S >= 1 && S <= kMpoMaxSamples && A <= 64,
+                    d_norm_std && d_observations && d_eps && d_grad_sums &&
+                    (d_column_sums || (d_dual_grads && d_stats)) &&
+                    d_workspace && B > 0 && S >= 1 && S <= kMpoMaxSamples && A <= 64,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_mpo_actor_grad: bad argument");
   TONIC_REQUIRE(workspace_bytes >= tonic_mpo_workspace_bytes(B, O, A, H, S), TONIC_ERR_WORKSPACE,
                 "tonic_mpo_actor_grad: workspace too small");
@@ -1293,10 +1308,56 @@ extern "C" int tonic_mpo_actor_grad(
   hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(1024), 0, st, w.part, w.klm, w.kls, d_duals,
                      action_penalization, (float)epsilon, (float)epsilon_penalty,
                      (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats,
-                     d_grad_sums + actor_count(as), B, A, S);
+                     d_grad_sums + actor_count(as), B, A, S, (const double*)nullptr, d_column_sums,
+                     B);
   TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, w.o_h1, w.o_h2, w.dloc,
                             w.dspre, ldh, w.da_h2, w.da_h1, d_grad_sums, nullptr, 0, 0, st));
   TONIC_CHECK_LAUNCH("tonic_mpo_actor_grad");
+  return TONIC_OK;
+}
+}  // namespace
+
+extern "C" int tonic_mpo_actor_grad(
+    const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
+    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    const float* d_observations, const float* d_eps, float* d_grad_sums, float* d_dual_grads,
+    float* d_stats, int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, double epsilon,
+    double epsilon_penalty, double epsilon_mean, double epsilon_std, int32_t action_penalization,
+    void* d_workspace, int64_t workspace_bytes, void* stream) {
+  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, d_norm_mean,
+                        d_norm_std, norm_clip, d_observations, d_eps, d_grad_sums, d_dual_grads,
+                        d_stats, B, O, H, A, S, epsilon, epsilon_penalty, epsilon_mean, epsilon_std,
+                        action_penalization, d_workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int tonic_mpo_actor_grad_shard(
+    const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
+    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    const float* d_observations, const float* d_eps, float* d_grad_sums, double* d_column_sums,
+    int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, int32_t action_penalization,
+    void* d_workspace, int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_column_sums != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_mpo_actor_grad_shard: null column sums");
+  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, d_norm_mean,
+                        d_norm_std, norm_clip, d_observations, d_eps, d_grad_sums, nullptr, nullptr,
+                        B, O, H, A, S, 0.0, 0.0, 0.0, 0.0, action_penalization, d_workspace,
+                        workspace_bytes, stream, d_column_sums);
+}
+
+extern "C" int tonic_mpo_dual_step(const double* d_column_sums, const float* d_duals,
+                                   float* d_dual_grads, float* d_stats, float* d_actor_stats,
+                                   int32_t B, int32_t B_global, int32_t A, int32_t S,
+                                   double epsilon, double epsilon_penalty, double epsilon_mean,
+                                   double epsilon_std, int32_t action_penalization, void* stream) {
+  TONIC_REQUIRE(d_column_sums && d_duals && d_dual_grads && d_stats && d_actor_stats && B >= 0 &&
+                    B_global > 0 && A >= 1 && A <= 64 && S >= 1,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_mpo_dual_step: bad argument");
+  hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(1024), 0, as_stream(stream),
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, d_duals,
+                     action_penalization, (float)epsilon, (float)epsilon_penalty,
+                     (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats, d_actor_stats,
+                     B, A, S, d_column_sums, (double*)nullptr, B_global);
+  TONIC_CHECK_LAUNCH("tonic_mpo_dual_step");
   return TONIC_OK;
 }
 

@@ -730,9 +730,12 @@ class DDPG(Agent):
             # single-process one on the global buffer.
             indices, positions, counts = self.replay.shard_indices(indices)
             local_eps = np.zeros_like(eps)
+            draws, per_sample = eps.shape[1], eps.shape[2] // global_batch
             for it in range(iterations):
+                # (MPO: S sampled actions per state, row s * B + m -> row s * c + j of the shard)
                 c = counts[it]
-                local_eps[it, :, :c] = eps[it][:, positions[it, :c]]
+                kept = eps[it].reshape(draws, per_sample, global_batch, -1)[:, :, positions[it, :c]]
+                local_eps[it, :, :per_sample * c] = kept.reshape(draws, per_sample * c, -1)
             eps = local_eps
         # everything a captured graph bakes in: shapes, the replay's storage, the updaters'
         # hyper-parameters and schedules — a change of any of them re-captures
@@ -770,7 +773,7 @@ class DDPG(Agent):
                     if c > 0:
                         self._enqueue_actor(batch['observations'], actor_eps, it, n_global, targets)
                     else:
-                        self.actor_updater.enqueue_empty(self._infos[1, it], n_global, targets)
+                        self._enqueue_actor(None, None, it, n_global, targets)
 
         from tonic_amd import parallel
         if not graph or parallel.exchanging():      # collectives sit between the kernels
@@ -788,6 +791,9 @@ class DDPG(Agent):
         return self._infos
 
     def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
+        if observations is None:                    # this rank drew none of the global batch
+            self.actor_updater.enqueue_empty(self._infos[1, iteration], n_global, targets)
+            return
         self.actor_updater.enqueue(observations, eps, self._infos[1, iteration], n_global, targets)
 
     def _graph_signature(self):
@@ -904,6 +910,10 @@ class MPO(DDPG):
         return super().enqueue_update(indices, eps, graph)
 
     def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
+        if observations is None:                    # this rank drew none of the global batch
+            self.actor_updater.enqueue_empty(self._infos[1, iteration], n_global, targets,
+                                             stats_row=self._mpo_stats[iteration])
+            return
         self.actor_updater.enqueue(observations, eps, self._infos[1, iteration], n_global, targets,
                                    stats_row=self._mpo_stats[iteration])
 

@@ -668,9 +668,6 @@ class ExpectedSARSA(_TwinCriticQLearning):
 
     def enqueue(self, batch, eps, info_row, n_global=None):
         """eps: the [num_samples * B, A] standard-normal draws of `rsample((num_samples,))`."""
-        from tonic_amd import parallel
-        if parallel.exchanging():
-            raise NotImplementedError('the MPO updaters run on one rank')
         B = batch['observations'].shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -801,6 +798,7 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
         self.dual_state = torch.zeros(4, dtype=torch.int32, device=device)
         self.mpo_stats = torch.zeros(9 + 2 * A, dtype=torch.float32, device=device)
         self.dual_info = torch.zeros(INFO_WIDTH, dtype=torch.float32, device=device)
+        self.column_sums = torch.zeros(6 + 2 * A, dtype=torch.float64, device=device)
 
     def _offpolicy_workspace(self, batch):
         need = self.lib.tonic_mpo_workspace_bytes(batch, self.observation_size, self.action_size,
@@ -811,22 +809,45 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
 
     def enqueue(self, observations, eps, info_row, n_global=None, targets=None, stats_row=None):
         from tonic_amd import parallel
-        if parallel.exchanging():
-            raise NotImplementedError('the MPO updaters run on one rank')
-        B = observations.shape[0]
-        ws = self._offpolicy_workspace(B)
-        mean, std = self.norm_tensors()
         p = _lib.ptr
         self.duals.clamp_(min=self.min_log_dual)                           # actors.py:347-356
         stats = stats_row if stats_row is not None else self.mpo_stats
-        _lib.check(self.lib.tonic_mpo_actor_grad(
-            p(self.flat.flat), p(self.model.flat_target_actor.flat),
-            p(self.model.flat_target_critics.flat), p(self.duals), p(mean), p(std),
-            self.norm_clip(), p(observations), p(eps), p(self.grad_sums), p(self.dual_grads),
-            p(stats), B, self.observation_size, self.hidden, self.action_size, self.num_samples,
-            float(self.epsilon), float(self.epsilon_penalty), float(self.epsilon_mean),
-            float(self.epsilon_std), int(bool(self.action_penalization)), p(ws), ws.numel(),
-            _lib.current_stream()), 'tonic_mpo_actor_grad')
+        B = 0 if observations is None else observations.shape[0]
+        if parallel.exchanging():
+            # this rank's part of the global batch (possibly nothing): the actor's gradient sums and
+            # the column sums of the per-state terms; the dual step needs their GLOBAL means
+            if B > 0:
+                ws = self._offpolicy_workspace(B)
+                mean, std = self.norm_tensors()
+                _lib.check(self.lib.tonic_mpo_actor_grad_shard(
+                    p(self.flat.flat), p(self.model.flat_target_actor.flat),
+                    p(self.model.flat_target_critics.flat), p(self.duals), p(mean), p(std),
+                    self.norm_clip(), p(observations), p(eps), p(self.grad_sums),
+                    p(self.column_sums), B, self.observation_size, self.hidden, self.action_size,
+                    self.num_samples, int(bool(self.action_penalization)), p(ws), ws.numel(),
+                    _lib.current_stream()), 'tonic_mpo_actor_grad_shard')
+            else:
+                self.grad_sums.zero_()
+                self.column_sums.zero_()
+            torch.distributed.all_reduce(self.column_sums)
+            _lib.check(self.lib.tonic_mpo_dual_step(
+                p(self.column_sums), p(self.duals), p(self.dual_grads), p(stats),
+                p(self.grad_sums[self.count:]), B, n_global, self.action_size, self.num_samples,
+                float(self.epsilon), float(self.epsilon_penalty), float(self.epsilon_mean),
+                float(self.epsilon_std), int(bool(self.action_penalization)),
+                _lib.current_stream()), 'tonic_mpo_dual_step')
+        else:
+            ws = self._offpolicy_workspace(B)
+            mean, std = self.norm_tensors()
+            _lib.check(self.lib.tonic_mpo_actor_grad(
+                p(self.flat.flat), p(self.model.flat_target_actor.flat),
+                p(self.model.flat_target_critics.flat), p(self.duals), p(mean), p(std),
+                self.norm_clip(), p(observations), p(eps), p(self.grad_sums), p(self.dual_grads),
+                p(stats), B, self.observation_size, self.hidden, self.action_size,
+                self.num_samples, float(self.epsilon), float(self.epsilon_penalty),
+                float(self.epsilon_mean), float(self.epsilon_std),
+                int(bool(self.action_penalization)), p(ws), ws.numel(), _lib.current_stream()),
+                'tonic_mpo_actor_grad')
         self._step(n_global or B, info_row, targets=targets)
         h = self.dual_hyper
         _lib.check(self.lib.tonic_adam_step(
@@ -834,6 +855,10 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
             p(self.dual_state), self.duals.numel(), 1.0, h['lr'], h['betas'][0], h['betas'][1],
             h['eps'], 0, 0.0, 0.0, None, p(self.dual_info), None, _lib.current_stream()),
             'tonic_adam_step (duals)')
+
+    def enqueue_empty(self, info_row, n_global, targets=None, stats_row=None):
+        """This rank drew none of the global batch: zero sums, the same dual and actor steps."""
+        self.enqueue(None, None, info_row, n_global, targets, stats_row)
 
     def infos(self, stats):
         """The reference's return dict (actors.py:449-464) from one statistics row (host array)."""
