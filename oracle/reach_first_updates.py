@@ -1,4 +1,4 @@
-"""Developer check: the first learner updates of a case of tests/reach_task.py with the reference
+"""TEST INFRASTRUCTURE ONLY — developer check: the first learner updates of a case of tests/reach_task.py with the reference
 (`ref`: build container, CPU) or this package (`amd`: GPU) — trains for `steps` environment steps
 and dumps the model, so that the two can be compared parameter by parameter (how the target-support
 semantics of the distributional critic step were found).
