@@ -189,3 +189,21 @@ def test_explorations_and_scripted_agents_follow_the_reference_streams():
             outcome = (observations, np.zeros(4), resets, resets, steps)
             theirs.update(*outcome), ours.update(*outcome)
             theirs.test_update(*outcome), ours.test_update(*outcome)
+
+
+def test_learning_curve_fixture_is_what_the_reference_does(tmp_path):
+    """tests/golden/learning_curves.json (what tests/test_gpu_learning.py holds this package's agents
+    against) is regenerated for one cheap case by training the unmodified reference here, and must
+    come out identical: the fixture is pinned on the reference, not on a past run of this package."""
+    import json
+    import reach_task
+    tonic = reference_loader.load_reference()
+    import tonic.torch
+    import torch
+    torch.set_num_threads(8)                    # as oracle/make_learning_curves.py
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                                         'learning_curves.json')))
+    assert set(golden['curves']) == set(reach_task.CASES)
+    agent = reach_task.build_agent(tonic, tonic.torch.agents, 'A2C')
+    curve = reach_task.train(tonic, agent, 'A2C', str(tmp_path))
+    np.testing.assert_allclose(curve, golden['curves']['A2C'], rtol=0, atol=1e-6)
