@@ -346,3 +346,32 @@ def test_ranks_partition_the_single_process_run(monkeypatch):
     trainer.initialize(agent, env)
     trainer.run()
     assert agent.steps == [0, 12, 24, 36]
+
+
+def test_shard_noise_keeps_the_owned_rows_in_sample_major_order():
+    """agents.shard_noise (several ranks, global noise stream): element by element against the
+    definition, for one draw per state and for MPO's S draws per state; the ranks' parts together
+    are the global draws."""
+    from tonic_amd.torch.agents import shard_noise
+    rng = np.random.RandomState(4)
+    for S in (1, 5):
+        iterations, draws, B, A, world = 3, 2, 7, 2, 3
+        eps = rng.standard_normal((iterations, draws, S * B, A)).astype(np.float32)
+        owner = rng.randint(world, size=(iterations, B))
+        rebuilt = np.zeros_like(eps)
+        for rank in range(world):
+            counts = (owner == rank).sum(1)
+            positions = np.zeros((iterations, B), int)
+            for it in range(iterations):
+                positions[it, :counts[it]] = np.nonzero(owner[it] == rank)[0]
+            local = shard_noise(eps, positions, counts, B)
+            assert local.shape == eps.shape
+            for it in range(iterations):
+                c = counts[it]
+                assert not local[it, :, S * c:].any()
+                for s in range(S):
+                    for j in range(c):
+                        m = positions[it, j]
+                        assert np.array_equal(local[it, :, s * c + j], eps[it, :, s * B + m])
+                        rebuilt[it, :, s * B + m] = local[it, :, s * c + j]
+        assert np.array_equal(rebuilt, eps)

@@ -574,6 +574,21 @@ def log_ppo_update(infos):
 
 # ----------------------------------------------------------------- off-policy (SAC / TD3)
 
+def shard_noise(eps, positions, counts, global_batch):
+    """The rows of the GLOBAL noise draws that belong to this rank's part of each batch.
+    eps [iterations, draws, S * B, A]: S draws per state of the global batch, sample-major (row
+    s * B + m; S = 1 for everything but MPO).  positions[it, :counts[it]] = the batch positions m
+    this rank owns.  Returns the same shape with row s * c + j = eps row s * B + positions[j]
+    (c = counts[it]) in front and zeros behind: what the kernels see as a batch of c states."""
+    local = np.zeros_like(eps)
+    draws, per_sample = eps.shape[1], eps.shape[2] // global_batch
+    for it in range(eps.shape[0]):
+        c = counts[it]
+        kept = eps[it].reshape(draws, per_sample, global_batch, -1)[:, :, positions[it, :c]]
+        local[it, :, :per_sample * c] = kept.reshape(draws, per_sample * c, -1)
+    return local
+
+
 def _twin_model(head):
     return models.ActorTwinCriticWithTargets(
         actor=models.Actor(
@@ -729,14 +744,7 @@ class DDPG(Agent):
             # gradient SUMS are all-reduced and scaled by 1 / B_global, so the update equals the
             # single-process one on the global buffer.
             indices, positions, counts = self.replay.shard_indices(indices)
-            local_eps = np.zeros_like(eps)
-            draws, per_sample = eps.shape[1], eps.shape[2] // global_batch
-            for it in range(iterations):
-                # (MPO: S sampled actions per state, row s * B + m -> row s * c + j of the shard)
-                c = counts[it]
-                kept = eps[it].reshape(draws, per_sample, global_batch, -1)[:, :, positions[it, :c]]
-                local_eps[it, :, :per_sample * c] = kept.reshape(draws, per_sample * c, -1)
-            eps = local_eps
+            eps = shard_noise(eps, positions, counts, global_batch)
         # everything a captured graph bakes in: shapes, the replay's storage, the updaters'
         # hyper-parameters and schedules — a change of any of them re-captures
         key = (iterations, tuple(eps.shape), self.replay.buffers['observations'].data_ptr(),
