@@ -584,8 +584,9 @@ def shard_noise(eps, positions, counts, global_batch):
     draws, per_sample = eps.shape[1], eps.shape[2] // global_batch
     for it in range(eps.shape[0]):
         c = counts[it]
-        kept = eps[it].reshape(draws, per_sample, global_batch, -1)[:, :, positions[it, :c]]
-        local[it, :, :per_sample * c] = kept.reshape(draws, per_sample * c, -1)
+        width = eps.shape[3]
+        kept = eps[it].reshape(draws, per_sample, global_batch, width)[:, :, positions[it, :c]]
+        local[it, :, :per_sample * c] = kept.reshape(draws, per_sample * c, width)   # (c may be 0)
     return local
 
 
