@@ -31,6 +31,7 @@ def run(out_path):
     torch.cuda.synchronize()
     comm.check()
     np.savez(out_path + f'.rank{rank}.npz', chain=chain.cpu().numpy(),
+             device=np.int64(torch.cuda.current_device()),
              **{f'call{i}': r for i, r in enumerate(results)})
     if world > 1:
         torch.distributed.barrier()

@@ -37,6 +37,9 @@ CASES = {
     'SAC-wide': ('SAC', dict(shape=(40, 10))),
     'MPO-wide': ('MPO', dict(shape=(40, 10))),
     'PPO-humanoid-shapes': ('PPO', dict(shape=(376, 17))),
+    # the reference's own run is unstable here (its reward dips far below zero before it recovers):
+    # held against the reference up to and including the dip (see tests/test_gpu_learning.py)
+    'D4PG-wide': ('D4PG', dict(shape=(40, 10))),
 }
 
 

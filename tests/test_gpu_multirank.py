@@ -120,6 +120,32 @@ def test_one_shot_allreduce_is_the_rank_ordered_sum(tmp_path, world):
     np.testing.assert_allclose(ranks[0]['chain'], (world + 1) / 2, rtol=1e-5)
 
 
+def test_one_shot_allreduce_between_peer_devices(tmp_path):
+    """The same exchange with every rank on its OWN device (LOCAL_RANK -> cuda:r): the windows are
+    peer memory reached over xGMI — the path tonic_allreduce_f32 exists for.  Needs a box with at
+    least two GPUs (the 1-GPU boxes of the test tier skip it; the 8-GPU scaling node runs it)."""
+    import torch
+    devices = torch.cuda.device_count()
+    if devices < 2:
+        pytest.skip('one GPU on this box: peer windows need two')
+    world = min(devices, 8)
+    out = str(tmp_path / 'peer')
+    launch(world, out, 29720 + world, command=(ALLREDUCE_WORKER,),
+           extra_env={'TONIC_AMD_BACKEND': 'nccl'})
+    ranks = [np.load(out + f'.rank{r}.npz') for r in range(world)]
+    assert sorted(int(r['device']) for r in ranks) == list(range(world))
+    for call, n in enumerate((11101, 7, 177666, 4096, 11101, 11101, 1, 65536)):
+        want = None
+        for r in range(world):
+            rng = np.random.RandomState(1000 * call + r)
+            mine = (rng.standard_normal(n) * 10.0 ** rng.randint(-3, 4)).astype(np.float32)
+            want = mine if want is None else (want + mine).astype(np.float32)
+        for r in range(world):
+            assert np.array_equal(ranks[r][f'call{call}'], want), (call, r)
+    for r in range(1, world):
+        assert np.array_equal(ranks[r]['chain'], ranks[0]['chain'])
+
+
 def test_two_ranks_with_the_one_shot_allreduce_equal_single_process(tmp_path):
     """The sharded PPO update with TONIC_AMD_ALLREDUCE=oneshot (tonic_allreduce_f32 instead of
     torch.distributed for the per-iteration gradient exchange) against the single-process update."""
@@ -203,4 +229,4 @@ def test_two_ranks_learn_like_the_single_process_reference(tmp_path, case, port)
     golden = os.path.join(ROOT, 'tests', 'golden', 'learning_curves.json')
     reference = np.array(json.load(open(golden))['curves'][case])
     print('LEARN 2 ranks', case, ' '.join(f'{x:.3f}' for x in curve))
-    np.testing.assert_allclose(curve, reference, rtol=0, atol=0.03, err_msg=case)
+    np.testing.assert_allclose(curve, reference, rtol=0, atol=0.01, err_msg=case)

@@ -92,6 +92,35 @@ def test_parallel_equals_sequential():
             assert np.array_equal(ia[key], ib[key]), key
 
 
+def test_step_outputs_are_read_only_views_or_copies():
+    """The zero-copy step outputs alias the shared block (the next step and the GPU overwrite
+    them in place): they are handed out read-only, the same objects every step; with
+    copy_outputs=True the caller gets fresh writable arrays like the reference returns."""
+    from tonic_amd import environments
+
+    def builder():
+        return environments.Synthetic(5, 3, max_episode_steps=4)
+    env = environments.distribute(builder, 1, 3)
+    env.initialize(seed=1)
+    first = env.start()
+    obs, infos = env.step(np.zeros((3, 3), np.float32))
+    assert obs is first and not obs.flags.writeable
+    with pytest.raises(ValueError):
+        obs[0, 0] = 1.0
+    for value in infos.values():
+        assert not value.flags.writeable
+    again, infos2 = env.step(np.zeros((3, 3), np.float32))
+    assert again is obs and all(infos2[k] is infos[k] for k in infos)
+    copying = environments.distribute(builder, 1, 3, copy_outputs=True)
+    copying.initialize(seed=1)
+    kept = copying.start()
+    obs, infos = copying.step(np.zeros((3, 3), np.float32))
+    assert obs is not kept and obs.flags.writeable and infos['rewards'].flags.writeable
+    before = kept.copy()
+    copying.step(np.zeros((3, 3), np.float32))
+    assert np.array_equal(kept, before)
+
+
 def test_synthetic_batch_protocol():
     from tonic_amd.environments import SyntheticBatch
     env = SyntheticBatch(8, 17, 6, max_episode_steps=3, termination_probability=0.2)

@@ -207,3 +207,28 @@ def test_learning_curve_fixture_is_what_the_reference_does(tmp_path):
     agent = reach_task.build_agent(tonic, tonic.torch.agents, 'A2C')
     curve = reach_task.train(tonic, agent, 'A2C', str(tmp_path))
     np.testing.assert_allclose(curve, golden['curves']['A2C'], rtol=0, atol=1e-6)
+
+
+def test_committed_goldens_are_what_their_generator_writes(tmp_path):
+    """oracle/make_golden.py run NOW on the unmodified reference (in a subprocess: one torch
+    thread, its own generator state) writes exactly tests/golden/*.npz — same keys, same bits.
+    A generator that gained a field (or a reference / torch build that computes something else)
+    fails here instead of leaving the committed fixtures silently behind."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path.insert(0, %r); import make_golden; make_golden.OUT = %r; '
+            'sys.argv = sys.argv[:1]; make_golden.main()'
+            % (os.path.join(root, 'oracle'), str(tmp_path)))
+    subprocess.run([sys.executable, '-c', code], check=True, capture_output=True, timeout=600)
+    committed = os.path.join(root, 'tests', 'golden')
+    fresh = sorted(f for f in os.listdir(tmp_path) if f.endswith('.npz'))
+    assert fresh == sorted(f for f in os.listdir(committed) if f.endswith('.npz'))
+    for name in fresh:
+        got = np.load(os.path.join(tmp_path, name), allow_pickle=True)
+        want = np.load(os.path.join(committed, name), allow_pickle=True)
+        assert sorted(got.files) == sorted(want.files), name
+        for key in got.files:
+            a, b = got[key], want[key]
+            same = (np.array_equal(a, b, equal_nan=True) if a.dtype.kind in 'fc'
+                    else np.array_equal(a, b))
+            assert same, (name, key)

@@ -56,9 +56,22 @@ class Block:
         self.eps = (view('eps0', (W, A)), view('eps1', (W, A)))
         self.resets_bool = view('resets_u8', (W,), np.bool_)
         self.terminations_bool = view('terminations_u8', (W,), np.bool_)
-        # what `environment.step` hands out when it writes into this block (persistent views)
-        self.infos = dict(observations=self.next_observations, rewards=self.rewards,
-                          resets=self.resets_bool, terminations=self.terminations_bool)
+        # What `environment.step` hands out when it writes into this block: persistent READ-ONLY
+        # views (the same objects every step).  They alias memory the next step — and the GPU —
+        # overwrites in place: a caller that keeps step outputs across steps must copy them (or ask
+        # the environment for `copy_outputs=True`); a caller that writes into them gets a
+        # ValueError instead of silently corrupting the simulator's record.
+        def handout(array):
+            out = array.view()
+            out.setflags(write=False)
+            return out
+        self.out_observations = handout(self.observations)
+        self.out_next_observations = handout(self.next_observations)
+        self.out_rewards = handout(self.rewards)
+        self.out_resets = handout(self.resets_bool)
+        self.out_terminations = handout(self.terminations_bool)
+        self.infos = dict(observations=self.out_next_observations, rewards=self.out_rewards,
+                          resets=self.out_resets, terminations=self.out_terminations)
         # GPU handles that page-locked this mapping.  They MUST be destroyed (hipHostUnregister)
         # before the mapping goes away: a later mmap may reuse the address range, and a stale
         # registration would make the GPU read the old physical pages.  The finalizer runs
@@ -79,7 +92,7 @@ class Block:
     def owner_of(cls, observations):
         """The live block whose `observations` view this very array is (None otherwise)."""
         for block in cls._live:
-            if block.observations is observations:
+            if block.out_observations is observations or block.observations is observations:
                 return block
         return None
 

@@ -15,6 +15,7 @@
 // contributions are pushed with plain stores + ONE system-scope release per workgroup, flags are
 // system-scope atomics, and the slots are read back with system-scope loads (their lines may still
 // sit in this XCD's L2 from two calls ago).
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -195,6 +196,23 @@ extern "C" int tonic_comm_connect(tonic_comm_t* c, const void* all_handles) {
   return TONIC_OK;
 }
 
+// How long a rank waits for its peers' flags before it gives up with an error status (never a
+// hang): TONIC_AMD_ALLREDUCE_TIMEOUT_S seconds, default 120 — the first exchange of an update has
+// to absorb whatever skew the ranks have (module load, a checkpoint save on rank 0, a slow
+// simulator), and a rank that gives up leaves the sums unreduced, which the learner turns into an
+// exception at its next read-back (tonic_comm_status).
+static unsigned long long comm_timeout_ticks() {
+  static const unsigned long long ticks = [] {
+    double seconds = 120.0;
+    if (const char* env = getenv("TONIC_AMD_ALLREDUCE_TIMEOUT_S")) {
+      const double v = atof(env);
+      if (v > 0.0) seconds = v;
+    }
+    return (unsigned long long)(seconds * 1e8);          // 100 MHz wall clock
+  }();
+  return ticks;
+}
+
 extern "C" int tonic_allreduce_f32(tonic_comm_t* c, float* d_buffer, int64_t n, void* stream) {
   TONIC_REQUIRE(c && d_buffer && n > 0, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_allreduce_f32: bad argument");
@@ -213,7 +231,7 @@ extern "C" int tonic_allreduce_f32(tonic_comm_t* c, float* d_buffer, int64_t n, 
   a.status_offset = l.status_offset;
   a.rank = c->rank; a.world = c->world;
   a.sequence = ++c->sequence;
-  a.timeout_ticks = 500000000ull;          // 5 s
+  a.timeout_ticks = comm_timeout_ticks();
   hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(kCommBlocks), dim3(kCommThreads), 0,
                      as_stream(stream), a);
   TONIC_CHECK_LAUNCH("tonic_allreduce_f32");
@@ -227,7 +245,8 @@ extern "C" int tonic_comm_status(tonic_comm_t* c) {
   TONIC_HIP(hipMemcpy(&failed_at, c->window + l.status_offset, 4, hipMemcpyDeviceToHost),
             "hipMemcpy");
   if (failed_at != 0) {
-    set_error("tonic_allreduce_f32: a peer did not arrive within 5 s (call number %u)", failed_at);
+    set_error("tonic_allreduce_f32: a peer did not arrive within %.0f s (call number %u)",
+              (double)comm_timeout_ticks() / 1e8, failed_at);
     return TONIC_ERR_TIMEOUT;
   }
   return TONIC_OK;

@@ -11,8 +11,10 @@ Queue, distributed.py:136-155):
   * all workers write observations / rewards / flags straight into ONE shared float32 block
     (``tonic_amd.collector.Block``: an anonymous shared mapping created before ``fork``) — no
     serialisation, no per-step allocation;
-  * ``start`` / ``step`` return persistent VIEWS of that block (the same array objects every
-    step, like a simulator that re-uses its output buffers).  The agents of ``tonic_amd.torch``
+  * ``start`` / ``step`` return persistent READ-ONLY VIEWS of that block (the same array objects
+    every step, like a simulator that re-uses its output buffers; the next step — and the GPU —
+    overwrite the memory behind them in place, so a caller that keeps step outputs across steps
+    must copy them).  The agents of ``tonic_amd.torch``
     recognise them by identity and page-lock the block (``tonic_collector_create``), so the
     GPU reads the workers' memory and writes the actions back without a host copy.  Callers
     that keep step outputs across steps ask for ``copy_outputs=True`` (or set
@@ -53,7 +55,7 @@ def _step_group(environments, lengths, max_episode_steps, block, first, actions)
 
 def _outputs(block, copy):
     if not copy:
-        return block.observations, dict(block.infos)      # fresh dict, persistent arrays
+        return block.out_observations, dict(block.infos)      # fresh dict, persistent read-only views
     return block.observations.copy(), {k: v.copy() for k, v in block.infos.items()}
 
 
@@ -87,7 +89,7 @@ class Sequential:
         for i, environment in enumerate(self.environments):
             self.block.observations[i] = environment.reset()
         self.lengths = np.zeros(workers, int)
-        return self.block.observations.copy() if self.copy_outputs else self.block.observations
+        return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
 
     def step(self, actions):
         _step_group(self.environments, self.lengths, self.max_episode_steps, self.block, 0,
@@ -164,7 +166,7 @@ class Parallel:
         assert not self.started
         self.started = True
         self._wait()
-        return self.block.observations.copy() if self.copy_outputs else self.block.observations
+        return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
 
     def step(self, actions):
         if actions is not self.block.actions:

@@ -82,13 +82,13 @@ class SyntheticBatch:
         self._quiet = 0                  # steps taken since `lengths` was last brought up to date
         self._flags_set = False
         self.block.observations[:] = self._observe()
-        return self.block.observations.copy() if self.copy_outputs else self.block.observations
+        return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
 
     def _outputs(self):
         block = self.block
         if self.copy_outputs:
             return block.observations.copy(), {k: v.copy() for k, v in block.infos.items()}
-        return block.observations, dict(block.infos)
+        return block.out_observations, dict(block.infos)
 
     def _write_flags(self, resets, terminations):
         block = self.block

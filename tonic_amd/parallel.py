@@ -122,8 +122,21 @@ def one_shot(max_floats):
     if os.environ.get('TONIC_AMD_ALLREDUCE', '') != 'oneshot' or world_size() == 1:
         return None
     if _one_shot is None or _one_shot.max_floats < max_floats:
+        if _one_shot is not None:           # regrown windows: the old communicator is released
+            torch.cuda.synchronize()
+            _one_shot.check()
+            _one_shot.close()
         _one_shot = OneShotAllReduce(max(max_floats, 1 << 18))
     return _one_shot
+
+
+def check_one_shot():
+    """Raises if a peer missed some tonic_allreduce_f32 since the last check (the kernel then
+    returned with its sums unreduced and an error status instead of hanging).  The learners call
+    this once per update, right after the read-back that already synchronises the stream, so
+    diverged replicas never survive an update silently."""
+    if _one_shot is not None:
+        _one_shot.check()
 
 
 class OneShotAllReduce:

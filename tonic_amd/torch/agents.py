@@ -24,7 +24,7 @@ import random
 import numpy as np
 import torch
 
-from tonic_amd import _lib, agents, explorations, logger, replays
+from tonic_amd import _lib, agents, explorations, logger, parallel, replays
 from tonic_amd.collector import Block, Collector
 from tonic_amd.torch import models, normalizers, updaters
 
@@ -56,7 +56,6 @@ class Agent(agents.Agent):
     """tonic/torch/agents/agent.py:10-26 (seeding and .pt checkpoints)."""
 
     def initialize(self, seed=None):
-        from tonic_amd import parallel
         parallel.init_from_env()          # one process per GPU under torch.distributed.run; else no-op
         self.seed = seed
         if seed is not None:
@@ -66,23 +65,39 @@ class Agent(agents.Agent):
 
     def _replicate(self, buffers, own_noise):
         """Several ranks: rank 0's parameters everywhere (replicas must not hinge on equal seeds),
-        then — `own_noise`, the on-policy agents, whose torch generator only feeds the action
-        noise — a generator of this rank's own, unless TONIC_AMD_GLOBAL_NOISE asks for the
-        single-process stream (parallel.global_noise)."""
-        from tonic_amd import parallel
+        then the ACTING noise of this rank's workers gets a stream of its own (seed + rank), unless
+        TONIC_AMD_GLOBAL_NOISE asks for the single-process stream (parallel.global_noise):
+        `own_noise` — the on-policy agents, whose torch generator feeds nothing but the action
+        noise — re-seeds the global generator; the off-policy agents keep the global generator for
+        the update's replicated noise stream (`_draw_noise`, which must stay in step across ranks)
+        and act from a dedicated per-rank generator — otherwise worker i of every rank would
+        explore with the very same draws."""
         self.rank, self.world = parallel.rank(), parallel.world_size()
         self.global_noise = self.world > 1 and parallel.global_noise()
+        self._acting_generator = None
         if self.world == 1:
             return
         parallel.broadcast_from_first(buffers)
-        if own_noise and not self.global_noise and self.seed is not None and self.rank > 0:
-            torch.manual_seed(self.seed + self.rank)
+        if self.global_noise:
+            return
+        if own_noise:
+            if self.seed is not None and self.rank > 0:
+                torch.manual_seed(self.seed + self.rank)
+            return
+        self._acting_generator = torch.Generator()
+        if self.seed is not None:
+            self._acting_generator.manual_seed(self.seed + self.rank)
+        else:
+            self._acting_generator.seed()
 
     def _randn(self, workers, width, out=None):
         """Standard-normal action noise for this rank's `workers` workers (global_noise: rows
         [rank * workers, (rank + 1) * workers) of the draw for all of them)."""
-        if not self.global_noise:
-            return torch.randn(workers, width, out=out) if out is not None else torch.randn(workers, width)
+        if not getattr(self, 'global_noise', False):
+            generator = getattr(self, '_acting_generator', None)
+            if out is not None:
+                return torch.randn(workers, width, out=out, generator=generator)
+            return torch.randn(workers, width, generator=generator)
         rows = torch.randn(self.world * workers, width)[self.rank * workers:(self.rank + 1) * workers]
         return rows if out is None else out.copy_(rows)
 
@@ -289,7 +304,7 @@ class A2C(Agent):
             self._settle()
             self._bind(observations)
             block = self._block
-        fed = observations is block.observations
+        fed = observations is block.out_observations or observations is block.observations
         if not fed:
             np.copyto(block.observations, observations)
         collector = self._collector
@@ -354,9 +369,9 @@ class A2C(Agent):
             return self._update_staged(observations, rewards, resets, terminations)
         block, replay = self._block, self.replay
         # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
-        if (self._block_fed and observations is block.next_observations
-                and rewards is block.rewards and resets is block.resets_bool
-                and terminations is block.terminations_bool):
+        if (self._block_fed and observations is block.out_next_observations
+                and rewards is block.out_rewards and resets is block.out_resets
+                and terminations is block.out_terminations):
             # The environment lives in the block: the outcome is in place and so are the next
             # step's observations (distributed.py:136-155 returns them with these infos).  With
             # its noise drawn ahead, the next step's launch goes out FIRST — the rest of this call,
@@ -366,13 +381,15 @@ class A2C(Agent):
                 self._collector.ppo_step(replay.index + 1, self._slot, True)
                 self._speculated = True
         else:
-            if observations is not block.next_observations:
+            if (observations is not block.out_next_observations
+                    and observations is not block.next_observations):
                 np.copyto(block.next_observations, observations)
-            if rewards is not block.rewards:
+            if rewards is not block.out_rewards and rewards is not block.rewards:
                 np.copyto(block.rewards, rewards)
-            if resets is not block.resets_bool:
+            if resets is not block.out_resets and resets is not block.resets_bool:
                 np.copyto(block.resets, resets)             # bool -> float32 (segments.py:33)
-            if terminations is not block.terminations_bool:
+            if terminations is not block.out_terminations and \
+                    terminations is not block.terminations_bool:
                 np.copyto(block.terminations, terminations)
         if self.model.return_normalizer:
             raise NotImplementedError('return normalisers are not supported (never enabled by '
@@ -417,6 +434,7 @@ class A2C(Agent):
 
     def _update(self):
         infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+        parallel.check_one_shot()
         for i, key in enumerate(updaters.ACTOR_INFO):
             if key in ('loss', 'kl', 'entropy', 'std'):
                 logger.store('actor/' + key, infos[0, 0, i])
@@ -453,6 +471,7 @@ class TRPO(A2C):
         for it, (obs, _, _, _, returns) in enumerate(replay.learner_batches()):
             critic.enqueue(obs, returns, infos[it])
         infos = infos.cpu().numpy()
+        parallel.check_one_shot()
         for row in infos:
             logger.store('critic/loss', row[0])
             logger.store('critic/v', row[1])
@@ -484,7 +503,6 @@ class PPO(A2C):
         # Full batch (ppo.py:40-47 over segments.py:55-57) or shuffled minibatches
         # (segments.py:58-65); the advantages stay raw and are normalised in-register with the
         # GLOBAL statistics, exactly what get_full computes before the reference slices.
-        from tonic_amd import parallel
         if not parallel.exchanging():
             for it, (obs, act, raw_adv, log_probs, returns) in enumerate(replay.learner_batches()):
                 actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
@@ -550,6 +568,7 @@ class PPO(A2C):
 
     def _update(self):
         infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+        parallel.check_one_shot()
         log_ppo_update(infos)
         self.last_infos = infos
         if self.model.observation_normalizer:
@@ -784,7 +803,6 @@ class DDPG(Agent):
                     else:
                         self._enqueue_actor(None, None, it, n_global, targets)
 
-        from tonic_amd import parallel
         if not graph or parallel.exchanging():      # collectives sit between the kernels
             enqueue()
             return self._infos
@@ -827,6 +845,7 @@ class DDPG(Agent):
         indices = replay.sample_indices()
         eps = self._draw_noise(indices.shape[0])
         infos = self.enqueue_update(indices, eps).cpu().numpy()
+        parallel.check_one_shot()
         replay.last_steps = steps
         twin = hasattr(self.model, 'critic_2')
         for row in infos[0]:
@@ -932,6 +951,7 @@ class MPO(DDPG):
         eps = self._draw_noise(indices.shape[0])
         infos = self.enqueue_update(indices, eps).cpu().numpy()
         stats = self._mpo_stats.cpu().numpy()
+        parallel.check_one_shot()
         replay.last_steps = steps
         for row, actor_row in zip(infos[0], stats):                 # mpo.py:92-97
             logger.store('critic/loss', row[0])

@@ -799,6 +799,8 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
         self.mpo_stats = torch.zeros(9 + 2 * A, dtype=torch.float32, device=device)
         self.dual_info = torch.zeros(INFO_WIDTH, dtype=torch.float32, device=device)
         self.column_sums = torch.zeros(6 + 2 * A, dtype=torch.float64, device=device)
+        self.dual_clip_workspace = torch.zeros(
+            self.lib.tonic_clip_workspace_bytes(2 * A + 2), dtype=torch.uint8, device=device)
 
     def _offpolicy_workspace(self, batch):
         need = self.lib.tonic_mpo_workspace_bytes(batch, self.observation_size, self.action_size,
@@ -850,6 +852,13 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
                 'tonic_mpo_actor_grad')
         self._step(n_global or B, info_row, targets=targets)
         h = self.dual_hyper
+        if self.gradient_clip > 0:
+            # actors.py:441-445 clips the dual variables' gradient norm as well (the penalty
+            # temperature's entry is zero without action penalisation, so it does not count)
+            _lib.check(self.lib.tonic_clip_grad_norm(
+                p(self.dual_grads), self.duals.numel(), 1.0, self.gradient_clip, None,
+                p(self.dual_clip_workspace), self.dual_clip_workspace.numel(),
+                _lib.current_stream()), 'tonic_clip_grad_norm (duals)')
         _lib.check(self.lib.tonic_adam_step(
             p(self.duals), p(self.dual_grads), p(self.dual_exp_avg), p(self.dual_exp_avg_sq),
             p(self.dual_state), self.duals.numel(), 1.0, h['lr'], h['betas'][0], h['betas'][1],
