@@ -71,18 +71,41 @@ DTYPE = 'f32 (64x64 products of the grad kernels bf16x3-emulated: exact 3-term s
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json: FETCH_SIZE
+    """HBM bytes per launch from the committed PMC passes (profiles/rNN_traffic.json: FETCH_SIZE
     and WRITE_SIZE collected separately, gfx950 read correction applied) — PMC counters cannot be
-    collected from inside the timed run, so the summary of the same kernels is quoted."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_traffic.json')
+    collected from inside the timed run, so the summary of the same kernels is quoted (the newest
+    round's file that has the kernel)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ('r03_traffic.json', 'r02_traffic.json'):
+        try:
+            with open(os.path.join(here, 'profiles', name)) as f:
+                table = json.load(f)['kernels']
+            entry = next(v for k, v in table.items() if k.startswith(prefix))
+        except (OSError, StopIteration, KeyError, ValueError):
+            continue
+        return dict(traffic=entry['read_bytes'] + entry['write_bytes'], traffic_unit='B/launch',
+                    traffic_source='profiles/' + name)
+    return dict(traffic=None)
+
+
+def rocprof_us(prefix):
+    """Average duration (us) of a kernel in the committed rocprofv3 --kernel-trace --stats summary of
+    `python bench.py` (profiles/r03_kernel_us.json, written by scripts/kernel_us.py from the
+    stats csv of the same round), next to the HIP-event figure measured live."""
+    here = os.path.dirname(os.path.abspath(__file__))
     try:
-        with open(path) as f:
+        with open(os.path.join(here, 'profiles', 'r03_kernel_us.json')) as f:
             table = json.load(f)['kernels']
-        entry = next(v for k, v in table.items() if k.startswith(prefix))
+        return next(v for k, v in table.items() if k.startswith(prefix))
     except (OSError, StopIteration, KeyError, ValueError):
-        return dict(traffic=None)
-    return dict(traffic=entry['read_bytes'] + entry['write_bytes'], traffic_unit='B/launch',
-                traffic_source='profiles/r02_traffic.json')
+        return None
+
+
+# The ceiling the shipped arithmetic has: 23 % of the grad kernel's flops run at the fp32 MFMA rate,
+# 77 % as six bf16 MFMAs per product = 2.667 x the fp32 rate (DESIGN.md §4.2)
+def mixed_ceiling_tflops(bf16x3_share):
+    return 1.0 / ((1.0 - bf16x3_share) / FP32_MFMA_PEAK_TFLOPS
+                  + bf16x3_share / (FP32_MFMA_PEAK_TFLOPS * 8.0 / 3.0))
 
 
 def kernel_rooflines(agent):
@@ -137,9 +160,13 @@ def kernel_rooflines(agent):
                   + (', dW2: 77 %' if shipped == 3 else ': 52 %') + ' of the flops) as six bf16 MFMAs per '
                   'product on exact hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak '
                   'stays the fp32 MFMA peak: what the same arithmetic costs without the split')
+    share = {0: 0.0, 1: 0.0, 2: 0.52, 3: 0.77}[shipped]
     roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
+                frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share), 4),
+                mixed_ceiling_tflops=round(mixed_ceiling_tflops(share), 1),
+                rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
                 ms_per_launch=round(ms_a, 4), samples_per_launch=n,
                 flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=shipped, arithmetic=arithmetic,
                 variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
@@ -245,25 +272,22 @@ def cpu_baseline():
                 runs=runs, os_cpu_count=os.cpu_count())
 
 
-def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=True):
-    """cfg 3 / cfg 4 of BASELINE.json (not the headline metric).  Default: SAC, O=111, A=8, default
-    256-wide networks, 1 M-transition HBM Buffer, B=1024, 50 iterations per update call.  Reports
-    learner updates (batch iterations) per second on the GPU, eager and hipGraph-replayed, and
-    the reference's torch-CPU path (oracle/torch_port.OffPolicyPort) on a 5-iteration sample."""
+def build_offpolicy(kind, o_dim, a_dim, batch, workers, iterations=50, rows=1000000, seed=0,
+                    fill_seed=0):
+    """An off-policy agent of this package whose HBM Buffer (this rank's `workers` columns of the
+    global [rows // W_global, W_global] store) is full of synthetic transitions (SURVEY §8d cfg 3:
+    obs ~ N(0, 1), actions ~ U(-1, 1), rewards ~ N(0, 1), terminations ~ Bernoulli(1e-3))."""
     import torch
     import tonic_amd
     import tonic_amd.torch as tt
     from tonic_amd.environments import Box
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import torch_port
-    iterations, rows = 50, 1000000
     replay = tonic_amd.replays.Buffer(size=rows, batch_iterations=iterations, batch_size=batch)
     agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, d4pg=tt.agents.D4PG,
                  mpo=tt.agents.MPO)[kind](replay=replay)
-    agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=0)
+    agent.initialize(Box(-np.inf, np.inf, (o_dim,)), Box(-1, 1, (a_dim,)), seed=seed)
     replay._allocate(workers, o_dim, a_dim)
     gen = torch.Generator(device=agent.device)
-    gen.manual_seed(0)
+    gen.manual_seed(fill_seed)
     for key, buf in replay.buffers.items():
         if key in ('resets', 'terminations'):
             buf.copy_((torch.rand(buf.shape, device=agent.device, generator=gen) < 1e-3).float())
@@ -274,6 +298,33 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
         else:
             buf.copy_(torch.randn(buf.shape, device=agent.device, generator=gen))
     replay.size, replay.index = replay.max_size, 0
+    return agent, replay
+
+
+def offpolicy_flop_per_iteration(kind, o_dim, a_dim, batch, H=256):
+    """Dense fp32 contractions of one learner iteration, 2 FLOP per MAC; TD3 steps
+    its actor every second iteration."""
+    heads = 2 if kind == 'sac' else 1
+    actor_fwd = 2 * (o_dim * H + H * H + heads * H * a_dim)
+    critic_fwd = 2 * ((o_dim + a_dim) * H + H * H + H)
+    critic_dx_hidden = 2 * (H * H + H)
+    critic_step = actor_fwd + 4 * critic_fwd + 2 * critic_fwd + 2 * critic_dx_hidden
+    used = 2 if kind == 'sac' else 1                     # critics behind the actor's loss
+    actor_step = (actor_fwd + used * critic_fwd + used * 2 * (H + H * H + H * a_dim)
+                  + actor_fwd + 2 * (H * H + heads * H * a_dim))
+    return batch * (critic_step + (actor_step if kind == 'sac' else actor_step / 2))
+
+
+def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=True):
+    """cfg 3 / cfg 4 of BASELINE.json (not the headline metric).  Default: SAC, O=111, A=8, default
+    256-wide networks, 1 M-transition HBM Buffer, B=1024, 50 iterations per update call.  Reports
+    learner updates (batch iterations) per second on the GPU, eager and hipGraph-replayed, and
+    the reference's torch-CPU path (oracle/torch_port.OffPolicyPort) on a 5-iteration sample."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch_port
+    iterations, rows = 50, 1000000
+    agent, replay = build_offpolicy(kind, o_dim, a_dim, batch, workers, iterations, rows)
 
     def one_update(graph):
         indices = replay.sample_indices()
@@ -300,15 +351,7 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
         out['us_per_iteration'] = round(out['hip_graph']['ms_per_update_call'] * 1e3 / iterations, 1)
         return out
     # roofline of one learner iteration: dense fp32 contractions, 2 FLOP per MAC
-    H, heads = 256, (2 if kind == 'sac' else 1)
-    actor_fwd = 2 * (o_dim * H + H * H + heads * H * a_dim)
-    critic_fwd = 2 * ((o_dim + a_dim) * H + H * H + H)
-    critic_dx_hidden = 2 * (H * H + H)
-    critic_step = actor_fwd + 4 * critic_fwd + 2 * critic_fwd + 2 * critic_dx_hidden
-    used = 2 if kind == 'sac' else 1                     # critics behind the actor's loss
-    actor_step = (actor_fwd + used * critic_fwd + used * 2 * (H + H * H + H * a_dim)
-                  + actor_fwd + 2 * (H * H + heads * H * a_dim))
-    per_iteration = batch * (critic_step + (actor_step if kind == 'sac' else actor_step / 2))
+    per_iteration = offpolicy_flop_per_iteration(kind, o_dim, a_dim, batch)
     seconds = out['hip_graph']['ms_per_update_call'] * 1e-3 / iterations
     tflops = per_iteration / seconds / 1e12
     out['roofline'] = dict(bound='mfma (latency-bound in practice: ~14 dependent launches of '
@@ -397,6 +440,40 @@ class HostLoop:
                     steps=environment_steps, transport=agent.transport)
 
 
+def parallel_workers_loop(agent, groups=8, per_group=32, steps=512):
+    """The trainer's loop body with the worker-PROCESS transport of the reference's `Parallel`
+    (tonic/environments/distributed.py:136-155): distribute(builder, 8, 32) = 8 forked groups of 32
+    Python environments writing into the shared block the GPU reads in place, two futex words per
+    step.  us per environment step of 256 workers (the simulators are 256 Python objects here, so
+    this is mostly their cost: 32 sequential `Synthetic.step` calls per group)."""
+    from tonic_amd import environments
+    env = environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=1000),
+                                  groups, per_group)
+    env.initialize(seed=3)
+    observations = env.start()
+    replay = agent.replay
+    assert replay.index == 0, 'call right after a learner update'
+    clock, parts, count = time.perf_counter, np.zeros(3), 0
+    for t in range(steps + 32):
+        t0 = clock()
+        actions = agent.step(observations, t * groups * per_group)
+        t1 = clock()
+        observations, infos = env.step(actions)
+        t2 = clock()
+        agent.update(**infos, steps=t * groups * per_group)
+        if t >= 32:
+            parts += (t1 - t0, t2 - t1, clock() - t2)
+            count += 1
+    us = parts / count * 1e6
+    env.close()
+    # finish the segment through the in-process loop's environment is the caller's business:
+    # the agent is dropped after this measurement
+    return dict(worker_groups=groups, workers_per_group=per_group,
+                us_per_env_step=round(float(us.sum()), 1), agent_step_us=round(float(us[0]), 1),
+                env_step_us=round(float(us[1]), 1), agent_update_us=round(float(us[2]), 1),
+                env_steps_per_sec=round(groups * per_group * 1e6 / float(us.sum()), 1), steps=count)
+
+
 def timed_steps(run_one, steps, warmup, world):
     """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time."""
     import torch
@@ -446,6 +523,179 @@ def measure_job(workers, rank, world, steps, warmup, capture, device_too=True):
     return agent, loop, rollout, out
 
 
+def spawn_ranks(gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the
+    driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...), pass rank 0's
+    JSON line through and fail loudly unless it reports n_gpus == N.  On a box with fewer devices
+    than ranks the ranks share the devices under the gloo backend (a functional run of the N-rank
+    path, not a scaling measurement: the line then says `ranks_share_devices`)."""
+    import socket
+    import subprocess
+    import torch
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    devices = torch.cuda.device_count()
+    if devices < gpus:
+        env.setdefault('TONIC_AMD_BACKEND', 'gloo')
+        env['TONIC_AMD_BENCH_SHARED_DEVICES'] = str(max(devices, 1))
+    command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+               str(gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+    done = subprocess.run(command, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [line for line in done.stdout.splitlines() if line.startswith('{')]
+    if done.returncode != 0 or len(lines) != 1:
+        sys.stdout.write(done.stdout)
+        sys.exit(f'bench.py --gpus {gpus}: the {gpus}-rank launch failed (exit code '
+                 f'{done.returncode}, {len(lines)} JSON lines)')
+    n = json.loads(lines[0]).get('n_gpus')
+    if n != gpus:
+        sys.exit(f'bench.py --gpus {gpus}: the line reports n_gpus = {n}')
+    print(lines[0])
+
+
+def allreduce_latency(floats, world):
+    """us per in-place sum all-reduce of `floats` float32 on this job's process group (RCCL over
+    xGMI on a multi-GPU node), and of tonic_allreduce_f32 (one-shot peer windows) beside it."""
+    import torch
+    from tonic_amd import parallel
+    if world == 1:
+        return None
+    buffer = torch.zeros(floats, device='cuda')
+    out = dict(floats=floats, bytes=4 * floats, backend=torch.distributed.get_backend())
+
+    def rccl():
+        torch.distributed.all_reduce(buffer)
+    for _ in range(5):
+        rccl()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        rccl()
+    torch.cuda.synchronize()
+    out['process_group_us'] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    try:
+        comm = parallel.OneShotAllReduce(floats)
+        out['one_shot_us'] = round(time_events(lambda: comm.all_reduce(buffer), 50) * 1e3, 1)
+        comm.check()
+        torch.distributed.barrier()
+        comm.close()
+    except Exception as error:                        # (no peer access on this box, ...)
+        out['one_shot_error'] = str(error)[:200]
+    return out
+
+
+def cfg4_main(args, rank, world):
+    """BASELINE config 4: TD3 on humanoid-walk shapes (O=67, A=21), parallel=512 workers SHARDED
+    over the ranks: every rank holds 512 / N worker columns of the global
+    [1953, 512] Buffer in HBM, draws the same global index / noise streams, gathers the samples of
+    its own columns (binomial split of the batch), all-reduces the gradient SUMS of every
+    optimizer step and scales by 1 / B_global.  One step = one learner update call = 50 batch
+    iterations (25 actor steps, TD3's delay of 2).  value = iterations / s of the whole job —
+    strong scaling: the global batch is fixed."""
+    import torch
+    kind, o_dim, a_dim, global_workers, iterations = 'td3', 67, 21, 512, 50
+    assert global_workers % world == 0, (global_workers, world)
+    workers = global_workers // world
+    results = {}
+    agent = None
+    for batch in (100, 1024):             # the reference's default batch, and the batch of cfg 3
+        del agent
+        torch.cuda.empty_cache()
+        agent, replay = build_offpolicy(kind, o_dim, a_dim, batch, workers, iterations,
+                                        fill_seed=rank)
+
+        def run_one():
+            indices = replay.sample_indices()              # the GLOBAL stream, same on every rank
+            eps = agent._draw_noise(iterations)
+            agent.enqueue_update(indices, eps).cpu()       # one read-back per update call
+        elapsed = timed_steps(run_one, args.steps, max(args.warmup, 2), world)
+        results[batch] = dict(elapsed=elapsed, ms_per_step=elapsed / args.steps * 1e3,
+                              value=iterations * args.steps / elapsed)
+    main_run = results[100]
+    critic_floats = agent.critic_updater.count + 8
+    actor_floats = agent.actor_updater.count + 8
+    flop = offpolicy_flop_per_iteration(kind, o_dim, a_dim, 100)
+    seconds = main_run['elapsed'] / (args.steps * iterations)
+    result = {
+        'metric': 'learner updates/sec, TD3 humanoid-walk parallel=512 sharded',
+        'value': round(main_run['value'], 1), 'unit': 'updates/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': max(args.warmup, 2),
+        'ms_per_step': round(main_run['ms_per_step'], 3), 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'TD3 dm_control humanoid-walk shapes (O={o_dim}, A={a_dim}), 256-wide '
+                               f'networks, parallel={global_workers} workers sharded = {workers} '
+                               f'columns per GPU of the global [{replay.max_size}, {global_workers}] '
+                               f'Buffer (1 M transitions, {sum(b.numel() for b in replay.buffers.values()) * 4 / 1e9:.2f} '
+                               'GB per GPU resident), global batch B=100 (reference default) drawn as '
+                               'one global index stream and split by worker column, 50 iterations + '
+                               '25 actor steps per update call, gradient sums all-reduced per '
+                               'optimizer step',
+                   'workers_per_gpu': workers, 'global_workers': global_workers,
+                   'global_batch': 100, 'batch_iterations': iterations,
+                   'parallelism': f'dp{world} (worker-axis shard of the Buffer, all-reduce of flat '
+                                  'gradient sums)'},
+        'us_per_iteration': round(seconds * 1e6, 1),
+        'allreduce_bytes_per_iteration': 4 * critic_floats + 2 * actor_floats,
+        'allreduce_floats': dict(critics_every_iteration=critic_floats,
+                                 actor_every_second=actor_floats),
+        'roofline': dict(bound='mfma (latency-bound at B=100: 7 row tiles)', flop_per_iteration=int(flop),
+                         achieved=round(flop / seconds / 1e12, 3), peak=FP32_MFMA_PEAK_TFLOPS,
+                         unit='TFLOP/s', frac=round(flop / seconds / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
+                         traffic=None),
+        'B=1024': dict(updates_per_sec=round(results[1024]['value'], 1),
+                       us_per_iteration=round(results[1024]['elapsed'] / (args.steps * iterations) * 1e6, 1)),
+    }
+    if world > 1:
+        flat = agent.model.flat_online
+        low, high = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(low, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(high, op=torch.distributed.ReduceOp.MAX)
+        identical = bool(torch.equal(low, high))
+        assert identical, 'parameters diverged across ranks'
+        result['ranks_hold_identical_parameters'] = identical
+        result['rccl_ranks'] = world if torch.distributed.get_backend() == 'nccl' else 0
+        result['backend'] = torch.distributed.get_backend()
+        result['allreduce_us'] = allreduce_latency(critic_floats, world)
+        if os.environ.get('TONIC_AMD_BENCH_SHARED_DEVICES'):
+            result['ranks_share_devices'] = int(os.environ['TONIC_AMD_BENCH_SHARED_DEVICES'])
+    elif not args.no_extras:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import torch_port
+        state = {'pre/' + k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items()}
+        port_ = torch_port.OffPolicyPort(kind, state, 'pre/')
+        rng = np.random.RandomState(0)
+        sample_rows = 4096
+        host = dict(observations=rng.standard_normal((sample_rows, 1, o_dim)),
+                    actions=rng.uniform(-1, 1, (sample_rows, 1, a_dim)),
+                    next_observations=rng.standard_normal((sample_rows, 1, o_dim)),
+                    rewards=rng.standard_normal((sample_rows, 1)),
+                    discounts=np.full((sample_rows, 1), 0.99))
+        host = {k: v.astype(np.float32) for k, v in host.items()}
+        count = 201
+        idx = rng.randint(sample_rows, size=(count, 100))
+        eps = rng.standard_normal((count, 1, 100, a_dim)).astype(np.float32)
+        threads = min(torch.get_num_threads(), 16)
+        before = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        port_.update(host, 1, idx[:1], eps[:1])
+        t0 = time.perf_counter()
+        port_.update(host, 1, idx[1:], eps[1:])
+        dt = (time.perf_counter() - t0) / (count - 1)
+        torch.set_num_threads(before)
+        result['cpu_baseline'] = dict(value=round(1 / dt, 1), unit='updates/s', cores=threads,
+                                      kind='port',
+                                      sample=f'{count - 1} TD3 iterations (critic step, actor + '
+                                             'polyak every second) at B=100 through '
+                                             'oracle/torch_port.OffPolicyPort')
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
@@ -457,11 +707,15 @@ def main():
     parser.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
                         help='weak (default): the configured workers PER GPU; strong: the '
                              'configured workers are the global count, split over the ranks')
-    parser.add_argument('--workload', default='cfg2', choices=('cfg2', 'cfg5'),
+    parser.add_argument('--workload', default='cfg2', choices=('cfg2', 'cfg4', 'cfg5'),
                         help='cfg2 (default, the headline metric): HalfCheetah shapes, 256 workers; '
                              'cfg5: AntBullet shapes (O=28, A=8), 1280 workers per GPU under weak '
-                             'scaling = BASELINE config 5 at 8 GPUs (10 240 global under strong)')
+                             'scaling = BASELINE config 5 at 8 GPUs (10 240 global under strong); '
+                             'cfg4: TD3 humanoid-walk shapes, 512 workers sharded over the ranks, '
+                             'learner updates/s (BASELINE config 4)')
     args = parser.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args.gpus)                 # no launcher: start the ranks ourselves
     global O, A, W
     if args.workload == 'cfg5':
         O, A, W = 28, 8, 1280
@@ -474,16 +728,20 @@ def main():
     import torch
     from tonic_amd import parallel
     rank, world = parallel.init_from_env()
-    assert world == max(args.gpus, 1) or world == 1, (world, args.gpus)
+    if world != max(args.gpus, 1):
+        sys.exit(f'bench.py --gpus {args.gpus} runs as {world} rank(s): the line would claim '
+                 f'n_gpus = {world} (WORLD_SIZE={os.environ.get("WORLD_SIZE")})')
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    from tonic_amd.utils import logger
+    logger.get_current_logger().store = lambda *a, **k: None      # no log accumulation here
+    if args.workload == 'cfg4':
+        return cfg4_main(args, rank, world)
     capture = not args.no_graph
     global_workers = W * world if args.scaling == 'weak' else (W if args.workload == 'cfg2' else 10240)
     assert global_workers % world == 0, (global_workers, world)
     workers = global_workers // world
 
-    from tonic_amd.utils import logger
-    logger.get_current_logger().store = lambda *a, **k: None      # no log accumulation here
     # (the device-resident leg replays a hipGraph: single-process only — a capture next to
     #  RCCL's watchdog threads is not worth risking the multi-GPU line for)
     agent, loop, rollout, main_run = measure_job(workers, rank, world, args.steps, args.warmup,
@@ -524,6 +782,12 @@ def main():
         assert identical, 'parameters diverged across ranks'
         result['ranks_hold_identical_parameters'] = identical
         result['backend'] = torch.distributed.get_backend()
+        result['rccl_ranks'] = world if result['backend'] == 'nccl' else 0
+        if os.environ.get('TONIC_AMD_BENCH_SHARED_DEVICES'):
+            result['ranks_share_devices'] = int(os.environ['TONIC_AMD_BENCH_SHARED_DEVICES'])
+        # the per-iteration exchange of this job: [actor sums | 8 | critic sums | 8] floats
+        result['allreduce_us'] = allreduce_latency(
+            agent.actor_updater.count + agent.critic_updater.count + 16, world)
         if args.scaling == 'weak' and args.workload == 'cfg2' and W % world == 0:
             # the metric's own configuration: 256 workers in total, split over the ranks
             # (the first job's agent — Segment, collector, pinned block — is released first: with it
@@ -557,6 +821,7 @@ def main():
         result['roofline_critic'] = roof_c
         result['roofline_gae'] = roof_g
         result['cpu_baseline'] = cpu_baseline()
+        result['parallel_workers'] = parallel_workers_loop(agent)
         result['offpolicy_sac'] = offpolicy_rates()
         # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
         # reference's default batch of 100 and the batch of cfg 3
@@ -571,6 +836,19 @@ def main():
                                                 us_per_iteration=rates['us_per_iteration'])
         result['speedup_vs_cpu_baseline'] = round(
             main_run['value'] / result['cpu_baseline']['value'], 1)
+        # BASELINE config 5's per-GPU share (AntBullet shapes, 1 280 workers): 2 steps, same harness
+        del agent, loop, rollout
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        O, A, W = 28, 8, 1280
+        _, _, _, share = measure_job(W, rank, world, 2, 1, capture, device_too=False)
+        result['cfg5_share'] = dict(
+            workload='PPO AntBulletEnv-v0 shapes (O=28, A=8), 1280 workers on this GPU (config 5 = '
+                     '10 240 workers over 8 GPUs), T=4096: N = 5 242 880 transitions per step',
+            env_steps_per_sec=round(share['value'], 1), ms_per_step=round(share['ms_per_step'], 3),
+            steps=2)
+        O, A, W = 17, 6, 256
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

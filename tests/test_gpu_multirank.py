@@ -181,29 +181,56 @@ def test_exchange_schedule_over_rccl_with_one_rank(tmp_path, worker, args, sched
         assert np.array_equal(a[key], b[key]), key
 
 
-def test_bench_runs_under_two_ranks(tmp_path):
-    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (the driver's launch line
-    for the scaling runs; gloo here, both ranks on this box's GPU): ONE JSON line on rank 0's
-    stdout, the replicated parameters bit-identical across ranks after the updates, and the
-    strong-scaling leg (the metric's 256 workers split over the ranks) in the same ballpark as the
-    weak one."""
+def _bench(*arguments, timeout=900):
     import json
-    env = dict(os.environ, TONIC_AMD_BACKEND='gloo')
-    out = subprocess.run(
-        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-         '--master-addr', '127.0.0.1', '--master-port', '29791', os.path.join(ROOT, 'bench.py'),
-         '--gpus', '2', '--steps', '1', '--warmup', '1'],
-        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *arguments],
+                         env=dict(os.environ), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [line for line in out.stdout.splitlines() if line.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
-    result = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts the two ranks itself with the
+    driver's launch line (python -m torch.distributed.run --nproc-per-node 2 ...; on this one-GPU
+    box the ranks share the device under gloo and the line says so): ONE JSON line with n_gpus = 2,
+    the replicated parameters bit-identical across ranks after the updates, and the strong-scaling
+    leg (the metric's 256 workers split over the ranks) in the same ballpark as the weak one."""
+    result = _bench('--gpus', '2', '--steps', '1', '--warmup', '1')
     assert result['n_gpus'] == 2 and result['scaling'] == 'weak'
     assert result['ranks_hold_identical_parameters'] is True
     assert result['config']['global_workers'] == 512
+    assert 'allreduce_us' in result and result['allreduce_us']['process_group_us'] > 0
     strong = result['strong_scaling']
     assert strong['global_workers'] == 256 and strong['workers_per_gpu'] == 128
     assert strong['ms_per_step'] < 2 * result['ms_per_step']
+
+
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """A launcher environment that disagrees with --gpus must not produce a line claiming n_gpus."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps',
+                          '1', '--warmup', '0', '--no-extras'], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode != 0 and 'n_gpus' in out.stderr
+    assert not [line for line in out.stdout.splitlines() if line.startswith('{')]
+
+
+@pytest.mark.parametrize('gpus', [1, 2])
+def test_bench_cfg4_td3_sharded(gpus):
+    """BASELINE config 4 through bench.py: TD3 humanoid-walk shapes, 512 workers sharded over the
+    ranks, global index stream — one rank, and two ranks started by bench.py itself."""
+    result = _bench('--workload', 'cfg4', '--gpus', str(gpus), '--steps', '2', '--warmup', '2',
+                    '--no-extras')
+    assert result['n_gpus'] == gpus and result['unit'] == 'updates/s' and result['value'] > 0
+    assert result['scaling'] == 'strong'
+    assert result['config']['workers_per_gpu'] == 512 // gpus
+    assert result['allreduce_floats']['critics_every_iteration'] >= 177666 + 8   # (padded rows)
+    if gpus > 1:
+        assert result['ranks_hold_identical_parameters'] is True
+        assert result['ranks_share_devices'] == 1 or result['rccl_ranks'] == gpus
 
 
 LEARNING_WORKER = os.path.join(ROOT, 'tests', 'mp_learning_worker.py')

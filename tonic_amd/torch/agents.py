@@ -305,6 +305,18 @@ class A2C(Agent):
             self._bind(observations)
             block = self._block
         fed = observations is block.out_observations or observations is block.observations
+        if not fed and self.replay.index == 0 and not self._rollout_open:
+            # between two rollouts: another environment of tonic_amd.environments took over (its
+            # observations are the view of ANOTHER live block) -> adopt that block, stay zero-copy
+            owner = Block.owner_of(observations)
+            if owner is not None and owner is not block:
+                self._settle()
+                eps_ahead = self._eps_ahead and self._eps[self._slot].clone()
+                self._bind(observations)
+                block, fed = self._block, True
+                if eps_ahead is not False:        # the noise drawn ahead moves along (same stream)
+                    self._eps[self._slot].copy_(eps_ahead)
+                    self._eps_ahead = True
         if not fed:
             np.copyto(block.observations, observations)
         collector = self._collector
