@@ -514,6 +514,53 @@ int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d
                        int32_t B, int32_t O, int32_t H, int32_t A, double entropy_coeff,
                        void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- one whole learner iteration of DDPG / TD3 / SAC in 8 launches (4 when the actor is not due).
+ * replaces: the body of DDPG._update's loop (tonic/torch/agents/ddpg.py:95-112; td3.py:38-55 with
+ *   delay_steps) for one batch: critic_updater(**batch) -> [actor_updater(observations) ->
+ *   model.update_targets()], i.e. tonic_twin_q_grad + tonic_adam_step [+ tonic_actor_q_grad +
+ *   tonic_adam_polyak_step] with the launches of the two steps merged where they do not depend on
+ *   each other (both policy passes are one launch; the head backward rides in the actor's backward
+ *   launch) and torch.optim.Adam [+ the polyak update] applied in the epilogue of the
+ *   weight-gradient launches (same expressions as tonic_adam_step / tonic_polyak_update).
+ *   Single rank and no gradient clipping: several ranks (an all-reduce sits between the gradients
+ *   and the step) and `gradient_clip` use the split entry points.  kind as tonic_twin_q_grad
+ *   (0 TD3, 1 SAC, 2 DDPG).  Statistics rows as tonic_adam_step writes them (stats_kind 3 / 4).
+ *   All pointers are device memory unless noted; asynchronous on `stream`. */
+typedef struct tonic_q_optimizer {
+  float* d_grad_sums;          /* [count + 8]: the gradient sums + statistic slots (written) */
+  float* d_exp_avg;            /* Adam moments of the block (same layout as the parameters)   */
+  float* d_exp_avg_sq;
+  int32_t* d_state;            /* {step_count, -, -, arrivals}                                */
+  float* d_info_row;           /* [8] logged statistics of this step (may be NULL)            */
+  const float* d_step_constants; /* [2] {lr / (1 - beta1^t), sqrt(1 - beta2^t)} of THIS step t as
+                                  float32 of the float64 values (adam.py:530-536), formed by the
+                                  host; NULL: formed on the device from d_state's counter       */
+  double lr, beta1, beta2, eps;
+} tonic_q_optimizer;
+
+typedef struct tonic_q_iteration_t {
+  int32_t kind, actor_due;     /* actor_due: this iteration also steps the actor and the targets */
+  int32_t B, O, H, A;
+  int64_t global_batch;        /* gradient scale 1 / global_batch (0: B)                      */
+  float* d_actor;              /* online parameter blocks (padded off-policy layout)          */
+  float* d_critics;            /* [critic_1 | critic_2] (DDPG: one critic)                    */
+  float* d_target_actor;
+  float* d_target_critics;
+  const float* d_norm_mean; const float* d_norm_std; double norm_clip;
+  const float* d_observations; const float* d_actions; const float* d_next_observations;
+  const float* d_rewards; const float* d_discounts;
+  const float* d_eps_critic;   /* [B, A] TD3: target-action noise, SAC: the next action's draw */
+  const float* d_eps_actor;    /* [B, A] SAC: the actor step's draw (else NULL)               */
+  double critic_entropy_coeff, actor_entropy_coeff, noise_scale, noise_clip, target_coeff;
+  tonic_q_optimizer critic, actor;
+  void* d_workspace; int64_t workspace_bytes;
+} tonic_q_iteration_t;
+
+int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);
+/* 1 when tonic_q_iteration serves these shapes (heads: 1 deterministic, 2 Gaussian policy) */
+int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads);
+int tonic_q_iteration(const tonic_q_iteration_t* iteration, void* stream);
+
 /* ---- D4PG: distributional critic (tonic/torch/models/critics.py:23-66, agents/d4pg.py).
  *   The critic is an actor-shaped network on the encoded input [normalised observation | action]:
  *   parameters in the layout of tonic_mlp_actor_param_count(O + A, H, NA, 1) — W1 [H, O + A], b1,

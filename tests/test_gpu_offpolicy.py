@@ -300,6 +300,72 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B, support)
         np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)
 
 
+@pytest.mark.parametrize('kind,O,A,W,B,hidden', [
+    ('sac', 111, 8, 1, 1024, 256), ('td3', 67, 21, 64, 100, 256), ('ddpg', 17, 6, 4, 100, 256),
+    ('sac', 11, 3, 4, 24, 32), ('td3', 9, 4, 3, 37, 48), ('sac', 40, 30, 2, 50, 256)])
+def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O, A, W, B, hidden):
+    """tonic_q_iteration (both policy passes in one launch, head backward folded into the actor's
+    backward launch, Adam + polyak in the epilogue of the weight-gradient launches, all batches
+    gathered up front) against tonic_twin_q_grad + tonic_adam_step + tonic_actor_q_grad +
+    tonic_adam_polyak_step: the same expressions in the same order, so online and target
+    parameters, Adam moments, step counters and logged statistics must agree BIT FOR BIT after six
+    iterations (TD3: three actor steps) — eager and replayed from a hipGraph."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    rng = np.random.RandomState(11)
+    rows, iterations = 48, 6
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    draws = 2 if kind == 'sac' else 1
+    eps = rng.normal(size=(iterations, draws, B, A)).astype(np.float32)
+    indices = rng.randint(rows * W, size=(iterations, B))
+    results = {}
+    for mode, env, graph in (('split', '0', False), ('fused', '1', False), ('fused-graph', '1', True)):
+        monkeypatch.setenv('TONIC_AMD_FUSED_ITERATION', env)
+        relu = torch.nn.ReLU
+        head = (tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
+                                             distribution=tt.models.SquashedMultivariateNormalDiag)
+                if kind == 'sac' else tt.models.DeterministicPolicyHead())
+        container = (tt.models.ActorCriticWithTargets if kind == 'ddpg'
+                     else tt.models.ActorTwinCriticWithTargets)
+        model = container(
+            actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
+                                  torso=tt.models.MLP((hidden, hidden), relu), head=head),
+            critic=tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
+                                    torso=tt.models.MLP((hidden, hidden), relu),
+                                    head=tt.models.ValueHead()),
+            observation_normalizer=tt.normalizers.MeanStd())
+        replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B)
+        agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG)[kind](
+            model=model, replay=replay)
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+        assert (agent._fused_kind() is not None) == (mode != 'split')
+        norm = agent.model.observation_normalizer
+        norm._mean.data.copy_(dev(np.random.RandomState(1).normal(size=O) * 0.3))
+        norm._std.data.copy_(dev(np.abs(np.random.RandomState(2).normal(size=O)) + 0.5))
+        for t in range(rows):
+            replay.store(**{k: dev(v[t]) for k, v in host.items()})
+        infos = [agent.enqueue_update(indices, eps, graph=graph).cpu().numpy().copy()
+                 for _ in range(2)]                       # twice: the second call replays the graph
+        results[mode] = dict(
+            infos0=infos[0], infos1=infos[1], online=agent.model.flat_online.cpu().numpy(),
+            target=agent.model.flat_target.cpu().numpy(),
+            critic_m=agent.critic_updater.exp_avg.cpu().numpy(),
+            critic_v=agent.critic_updater.exp_avg_sq.cpu().numpy(),
+            actor_m=agent.actor_updater.exp_avg.cpu().numpy(),
+            actor_v=agent.actor_updater.exp_avg_sq.cpu().numpy(),
+            steps=np.array([int(agent.critic_updater.state[0]), int(agent.actor_updater.state[0])]))
+    due = iterations if kind != 'td3' else iterations // 2
+    assert list(results['split']['steps']) == [2 * iterations, 2 * due]
+    assert np.abs(results['split']['online']).max() > 0 and np.isfinite(results['split']['online']).all()
+    for mode in ('fused', 'fused-graph'):
+        for key, want in results['split'].items():
+            assert np.array_equal(results[mode][key], want), (mode, key)
+
+
 def test_adam_polyak_step_equals_the_two_calls(lib):
     """tonic_adam_polyak_step == tonic_adam_step on the block followed by tonic_polyak_update of
     the whole target buffer, bit for bit (block at the start, in the middle, at the end)."""

@@ -13,6 +13,30 @@ LIBRARY_PATH = os.path.join(_HERE, 'libtonic_hip.so')
 c_float_p = ctypes.c_void_p   # device pointers travel as plain integers
 c_i32, c_i64, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
+class QOptimizer(ctypes.Structure):
+    """tonic_q_optimizer of include/tonic_hip.h."""
+    _fields_ = [('d_grad_sums', c_vp), ('d_exp_avg', c_vp), ('d_exp_avg_sq', c_vp),
+                ('d_state', c_vp), ('d_info_row', c_vp), ('d_step_constants', c_vp),
+                ('lr', c_f64), ('beta1', c_f64), ('beta2', c_f64), ('eps', c_f64)]
+
+
+class QIteration(ctypes.Structure):
+    """tonic_q_iteration_t of include/tonic_hip.h (field for field)."""
+    _fields_ = [('kind', c_i32), ('actor_due', c_i32),
+                ('B', c_i32), ('O', c_i32), ('H', c_i32), ('A', c_i32),
+                ('global_batch', c_i64),
+                ('d_actor', c_vp), ('d_critics', c_vp), ('d_target_actor', c_vp),
+                ('d_target_critics', c_vp),
+                ('d_norm_mean', c_vp), ('d_norm_std', c_vp), ('norm_clip', c_f64),
+                ('d_observations', c_vp), ('d_actions', c_vp), ('d_next_observations', c_vp),
+                ('d_rewards', c_vp), ('d_discounts', c_vp),
+                ('d_eps_critic', c_vp), ('d_eps_actor', c_vp),
+                ('critic_entropy_coeff', c_f64), ('actor_entropy_coeff', c_f64),
+                ('noise_scale', c_f64), ('noise_clip', c_f64), ('target_coeff', c_f64),
+                ('critic', QOptimizer), ('actor', QOptimizer),
+                ('d_workspace', c_vp), ('workspace_bytes', c_i64)]
+
+
 # name -> (restype, argtypes); mirrors include/tonic_hip.h one to one.
 SIGNATURES = {
     'tonic_last_error': (ctypes.c_char_p, []),
@@ -53,6 +77,9 @@ SIGNATURES = {
     'tonic_ppo_collect_step_packed': (ctypes.c_int, [c_vp] * 16 + [c_i64, c_i64, c_i32, c_i32, c_vp]),
     'tonic_ppo_collect_steps_packed': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i64, c_i32, c_i32,
                                                                     c_vp]),
+    'tonic_q_iteration_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    'tonic_q_iteration_supported': (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    'tonic_q_iteration': (ctypes.c_int, [c_vp, c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
     'tonic_adam_polyak_step': (ctypes.c_int, [c_vp] * 5 + [c_i64] * 3 + [c_f64] * 5 + [c_i32, c_vp, c_vp,
                                                                                c_f64, c_vp]),

@@ -44,15 +44,39 @@ struct GemmArgs {
 
 constexpr int kGemmGroupMax = 4;
 
+// Optional optimizer epilogue of the weight-gradient group (gemm_tn_group_kernel): the outputs of
+// the group are the tensors of ONE network's flat gradient-sum block, so the offset of an output
+// element from `grads` also addresses its parameter, its Adam moments and its target copy.  The
+// workgroup that forms a tile of gradient sums applies torch.optim.Adam's step to the tile's
+// parameters right away (same expressions as adam_kernel in optim.hip -> same bits) and, with
+// `target`, the polyak update of the same entries; the last workgroup to arrive bumps the step
+// counter and writes the logged statistics (adam_finalize).  Saves the optimizer launch and one
+// round trip of the gradients through HBM.  Single rank, no gradient clipping (both need the
+// complete gradient before the step).
+struct AdamFold {
+  const float* grads;        // base of the flat gradient-sum block the outputs live in
+  float* params; float* exp_avg; float* exp_avg_sq;
+  float* target;             // polyak target of the same block (null: none)
+  int32_t* state;            // {step_count, stop_flag, -, arrivals}
+  const float* consts;       // {step_size, bias_correction2_sqrt} of THIS step (null: formed from state[0])
+  int64_t n;                 // parameters in the block: the 8 statistic sums follow at grads + n
+  float grad_scale, beta2, eps, polyak_keep, polyak_mix;
+  double beta1_d, beta2_d, lr_d;
+  int stats_kind;            // 3 twin Q critics, 4 Q actor (see adam_finalize in optim.hip)
+  float* info_row;
+  int on;
+};
+
 struct GemmGroup {
   GemmArgs problem[kGemmGroupMax];
   int first[kGemmGroupMax + 1];      // workgroup ranges of the problems
   int count;
+  AdamFold adam;
 };
 
 int launch_gemm(char mode_a, char mode_b, const GemmArgs& g, int batch, hipStream_t stream);
 // `count` (<= kGemmGroupMax) GEMMs of the same layout and K in one launch (see gemm16.hip).
 int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count, int batch,
-                      hipStream_t stream);
+                      hipStream_t stream, const AdamFold* adam = nullptr);
 
 }  // namespace tonic

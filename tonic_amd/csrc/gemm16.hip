@@ -181,8 +181,69 @@ __device__ __forceinline__ void tn_load(const float* __restrict__ base, unsigned
   }
 }
 
+// The step's constants (adam.py:530-547: float64 bias corrections, then rounded) — the expressions
+// of adam_kernel.
+struct AdamConsts { float step_size, bias2_sqrt, w1, w2; };
+
+__device__ __forceinline__ AdamConsts adam_consts(const AdamFold& f) {
+  if (f.consts != nullptr) {          // formed by the host in float64 like the reference's Python
+    AdamConsts c;                     // floats (adam.py:530-536): no float64 pow on the device
+    c.step_size = f.consts[0]; c.bias2_sqrt = f.consts[1];
+    c.w1 = (float)(1.0 - f.beta1_d); c.w2 = (float)(1.0 - f.beta2_d);
+    return c;
+  }
+  const int step = f.state[0] + 1;
+  const double bias1 = 1.0 - pow(f.beta1_d, (double)step);
+  const double bias2 = 1.0 - pow(f.beta2_d, (double)step);
+  AdamConsts c;
+  c.step_size = (float)(f.lr_d / bias1);
+  c.bias2_sqrt = (float)sqrt(bias2);
+  c.w1 = (float)(1.0 - f.beta1_d); c.w2 = (float)(1.0 - f.beta2_d);
+  return c;
+}
+
+// One element: the gradient SUM just formed -> new parameter (moments updated in place).
+__device__ __forceinline__ float adam_element(float sum, float p, float& m, float& v,
+                                              const AdamFold& f, const AdamConsts& c) {
+  const float gr = sum * f.grad_scale;
+  m = m + c.w1 * (gr - m);                                         // lerp_, adam.py:457
+  v = v * f.beta2 + c.w2 * (gr * gr);                              // mul_().addcmul_(), :476
+  const float denom = sqrtf(v) / c.bias2_sqrt + f.eps;             // :545
+  return p - c.step_size * (m / denom);                            // addcdiv_, :547
+}
+
+__device__ __forceinline__ void adam_apply(const AdamFold& f, const AdamConsts& c, int64_t off,
+                                           float sum) {
+  float m = f.exp_avg[off], v = f.exp_avg_sq[off];
+  const float p = adam_element(sum, f.params[off], m, v, f, c);
+  f.params[off] = p; f.exp_avg[off] = m; f.exp_avg_sq[off] = v;
+  if (f.target != nullptr) f.target[off] = f.target[off] * f.polyak_keep + f.polyak_mix * p;
+}
+
+// The last workgroup of the launch: step counter and logged statistics (adam_finalize, optim.hip).
+__device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned total) {
+  unsigned* arrivals = reinterpret_cast<unsigned*>(f.state + 3);
+  const unsigned before = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  if (before != total - 1) return;
+  __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f.state[0] += 1;
+  if (f.info_row == nullptr) return;
+  const float* st = f.grads + f.n;
+  if (f.stats_kind == 3) {
+    f.info_row[0] = st[0] * f.grad_scale;      // loss_1 + loss_2 (critics.py:172,224)
+    f.info_row[1] = st[1] * f.grad_scale;      // mean q1
+    f.info_row[2] = st[2] * f.grad_scale;      // mean q2
+    f.info_row[6] = 1.f;
+  } else if (f.stats_kind == 4) {
+    f.info_row[0] = st[0] * f.grad_scale;      // actor loss (actors.py:179,257)
+    f.info_row[6] = 1.f;
+  }
+}
+
 template <bool EDGE>
-__device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, float* part) {
+__device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, float* part,
+                                             const AdamFold& fold, unsigned total_blocks) {
   const int lane = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);       // scalar: uniform control flow
   const int i = lane & 15, kg = lane >> 4;
@@ -240,6 +301,14 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
 #pragma unroll
     for (int d = 0; d < kTnDepth; ++d) request(d, d);
   }
+  // optimizer epilogue: the step's constants (two float64 pow: ~1 us of VALU work) are formed HERE,
+  // by every wave, while the first operand chunks are in flight
+  AdamConsts consts{};
+  if (fold.on) {
+    __builtin_amdgcn_sched_barrier(0);
+    consts = adam_consts(fold);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int first = 0; first < mine; first += kTnDepth) {
 #pragma unroll
     for (int d = 0; d < kTnDepth; ++d) {
@@ -278,44 +347,98 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       for (int r = 0; r < 4; ++r) slot[(2 * jm + jn) * 4 + r] = acc[jm][jn][r];
   slot[16] = colsum[0]; slot[17] = colsum[1];
   __syncthreads();
-  if (w != 0) return;
-  for (int o = 1; o < kTnWaves; ++o) {                           // fixed order: bit-reproducible
-    const float* other = part + (o * 64 + lane) * kTnPart;
+  // Epilogue, spread over the four waves: wave w finishes register row r = w of the four MFMA tiles
+  // (rows m0 + 2 (4 kg + w) + {0, 1}, columns cb, cb + 1).  Every wave adds the four partials in
+  // wave order — ((p0 + p1) + p2) + p3, bit-reproducible — so the 32 x 32 tile's stores and the
+  // optimizer arithmetic (~60 instructions per element) are not left to one wave of four.
+  const int64_t goff = fold.on ? (g.C + z * g.strideC) - fold.grads : 0;      // tile base in the block
+  float fin[2][2];
 #pragma unroll
-    for (int jm = 0; jm < 2; ++jm)
+  for (int jm = 0; jm < 2; ++jm) {
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < 2; ++jn) {
+      float v = part[lane * kTnPart + (2 * jm + jn) * 4 + w];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jm][jn][r] += other[(2 * jm + jn) * 4 + r];
-    colsum[0] += other[16]; colsum[1] += other[17];
+      for (int o = 1; o < kTnWaves; ++o) v += part[(o * 64 + lane) * kTnPart + (2 * jm + jn) * 4 + w];
+      fin[jm][jn] = v;
+    }
   }
-
-  if (g.colsum != nullptr && tn == 0) {
+  if (w == 0) {
+    if (fold.on && lane == 0) adam_fold_arrive(fold, total_blocks);   // (state / constants were read)
+    if (g.colsum != nullptr && tn == 0) {
+#pragma unroll
+      for (int jm = 0; jm < 2; ++jm) {
+        float v = colsum[jm];
+        for (int o = 1; o < kTnWaves; ++o) v += part[(o * 64 + lane) * kTnPart + 16 + jm];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (kg == 0 && ca + jm < g.M) {
+          g.colsum[z * g.strideColsum + ca + jm] = v;
+          if (fold.on)
+            adam_apply(fold, consts, (g.colsum + z * g.strideColsum + ca + jm) - fold.grads, v);
+        }
+      }
+    }
+  }
+  // optimizer epilogue: parameter / moment / target loads of this wave's two rows first
+  const bool polyak = fold.on && fold.target != nullptr;
+  float pm[2][4][2];
+  if (fold.on) {
 #pragma unroll
     for (int jm = 0; jm < 2; ++jm) {
-      float v = colsum[jm];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (kg == 0 && ca + jm < g.M) g.colsum[z * g.strideColsum + ca + jm] = v;
+      const int m = min(m0 + 2 * (4 * kg + w) + jm, g.M - 1);
+      const int64_t off = goff + (int64_t)m * g.ldc + min(cb, g.N - 1);
+      const float* src[4] = {fold.params + off, fold.exp_avg + off, fold.exp_avg_sq + off,
+                             (polyak ? fold.target : fold.params) + off};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!EDGE) {
+          const f32x2_dword v = *reinterpret_cast<const f32x2_dword*>(src[q]);
+          pm[jm][q][0] = v[0]; pm[jm][q][1] = v[1];
+        } else {
+          pm[jm][q][0] = src[q][0];
+          pm[jm][q][1] = cb + 1 < g.N ? src[q][1] : 0.f;
+        }
+      }
     }
   }
   // D layout: lane (column index i, group kg), register r <-> row index 4 kg + r of the MFMA tile
 #pragma unroll
   for (int jm = 0; jm < 2; ++jm) {
+    const int m = m0 + 2 * (4 * kg + w) + jm;
+    if (m >= g.M) continue;
+    float* dst = C + (int64_t)m * g.ldc + cb;
+    float v0 = fin[jm][0] * g.alpha, v1 = fin[jm][1] * g.alpha;
+    if (cb + 1 < g.N) {
+      if (g.accumulate) {
+        const f32x2_dword old = *reinterpret_cast<const f32x2_dword*>(dst);
+        v0 += old[0]; v1 += old[1];
+      }
+      *reinterpret_cast<f32x2_dword*>(dst) = f32x2_dword{v0, v1};
+    } else if (cb < g.N) {
+      v0 = g.accumulate ? dst[0] + v0 : v0;
+      dst[0] = v0;
+    }
+    if (!fold.on) continue;
+    // ---- Adam (+ polyak) on the two elements just formed
+    const float sum[2] = {v0, v1};
+    const int64_t off = goff + (int64_t)m * g.ldc + cb;
+    float out[4][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 2 * (4 * kg + r) + jm;
-      if (m >= g.M) continue;
-      float* dst = C + (int64_t)m * g.ldc + cb;
-      float v0 = acc[jm][0][r] * g.alpha, v1 = acc[jm][1][r] * g.alpha;
+    for (int e = 0; e < 2; ++e) {
+      float mo = pm[jm][1][e], vo = pm[jm][2][e];
+      const float p = adam_element(sum[e], pm[jm][0][e], mo, vo, fold, consts);
+      out[0][e] = p; out[1][e] = mo; out[2][e] = vo;
+      out[3][e] = pm[jm][3][e] * fold.polyak_keep + fold.polyak_mix * p;
+    }
+    float* to[4] = {fold.params + off, fold.exp_avg + off, fold.exp_avg_sq + off, fold.target + off};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == 3 && !polyak) continue;
       if (cb + 1 < g.N) {
-        if (g.accumulate) {
-          const f32x2_dword old = *reinterpret_cast<const f32x2_dword*>(dst);
-          v0 += old[0]; v1 += old[1];
-        }
-        *reinterpret_cast<f32x2_dword*>(dst) = f32x2_dword{v0, v1};
+        *reinterpret_cast<f32x2_dword*>(to[q]) = f32x2_dword{out[q][0], out[q][1]};
       } else if (cb < g.N) {
-        dst[0] = g.accumulate ? dst[0] + v0 : v0;
+        to[q][0] = out[q][0];
       }
     }
   }
@@ -332,8 +455,9 @@ __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup 
   // Tiles that reach past the last row / column of C still take the vector loads when the
   // operand ROWS are long enough (padded pitch: what is read beyond M / N only feeds outputs that
   // are never stored); clamped scalar loads only where a load would leave the row.
-  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part);   // uniform
-  else gemm_tn_tile<false>(g, tm, tn, part);
+  const unsigned total = gridDim.x * gridDim.z;
+  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part, G.adam, total);   // uniform
+  else gemm_tn_tile<false>(g, tm, tn, part, G.adam, total);
 }
 
 namespace {
@@ -350,11 +474,15 @@ int waves_per_tile(int K, int64_t tiles_total) {
 }  // namespace
 
 int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count, int batch,
-                      hipStream_t stream) {
+                      hipStream_t stream, const AdamFold* adam) {
   TONIC_REQUIRE(list && count >= 1 && count <= kGemmGroupMax && batch > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "gemm group: %d problems", count);
   GemmGroup G{};
   G.count = count;
+  if (adam != nullptr) {
+    G.adam = *adam;
+    G.adam.on = 1;
+  }
   int64_t tiles_total = 0;
   for (int p = 0; p < count; ++p) {
     const GemmArgs& g = list[p];
@@ -381,6 +509,8 @@ int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count,
       return TONIC_OK;
     }
   }
+  TONIC_REQUIRE(adam == nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "gemm group: the optimizer epilogue needs the plain TN weight-gradient form");
   const int S = waves_per_tile(list[0].K, tiles_total * batch);
   const int per_block = S >= 4 ? 1 : 4 / S;
   int blocks = 0;

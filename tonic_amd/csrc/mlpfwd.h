@@ -98,7 +98,18 @@ struct MlpFwdArgs {
   float enc_clip;                                                       // MeanStd(clip): +inf = none
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
+  int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
+  // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
+  // the second input — has a tail of its own with its own outputs (the fused learner iteration
+  // runs the policy passes of the critic step AND of the actor step as one launch: SAC the online
+  // actor on s' and on s, TD3 the target actor on s' and the online actor on s).  The encoder's
+  // statistics (enc_mean / enc_std / enc_clip / enc_O / enc_ld) are shared.
+  struct Tail2 {
+    int post;
+    const float* eps; float* actions; float* sigma; float* logp;
+    const float* enc_obs; float* enc_out;
+  } tail2;
 };
 
 // Input-gradient chain of the same network (see mlp_backward_kernel in mlpfwd.hip).
@@ -132,6 +143,15 @@ struct MlpBwdArgs {
   const float* l_q; float* l_stats;
   float l_alpha;
   int l_nets, l_Bp;
+  // heads >= 1, hb_dxa0 != null: the gradients at the head outputs are not given but FORMED here
+  // from the critics' action-column input gradients (actor_head_backward_kernel folded into this
+  // launch, same expressions -> same bits) and written to dhead[0] / dhead[1] for the
+  // weight-gradient GEMM.  hb_sac: squashed-Gaussian head (SAC), else the tanh head (TD3 / DDPG).
+  const float* hb_dxa0; const float* hb_dxa1;      // [B, hb_ldxa]; dxa1 null: one critic
+  const float* hb_act; const float* hb_eps; const float* hb_sigma;   // [B, NH] dense
+  const float* hb_spre;                            // [B, ldh] pre-softplus scale head (SAC)
+  int hb_ldxa, hb_sac;
+  float hb_alpha;
 };
 enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 

@@ -46,6 +46,7 @@ __device__ __forceinline__ f32x4 load_k4_tail(const float* row, int k, int K) {
 
 constexpr int kRows = 16;          // batch rows per workgroup
 constexpr int kPostPitch = 64;     // head outputs per row in the policy tail (NH <= 64)
+constexpr int kHeadPitch = kPostPitch + 4;   // LDS rows of the folded head backward (16-byte aligned)
 constexpr int kMaxTiles = 4;       // 16-feature tiles per wave: H <= 256
 
 // One layer for the TILES 16-feature tiles a wave owns (rows wrow[j] of W), contraction over K.
@@ -188,6 +189,19 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   const int row = min(r0 + m, a.B - 1);               // batch row of this lane (clamped)
   const bool row_ok = r0 + m < a.B;
   const bool second = net >= a.split;                 // scalar
+  // what follows the heads: the first network's tail, or (second parameter set / input) tail2 —
+  // selects on a scalar condition, not indexing (a runtime index into the kernel arguments would
+  // go to scratch)
+  const int post = second ? a.tail2.post : a.post;
+  const float* post_eps = second ? a.tail2.eps : a.post_eps;
+  float* post_actions = second ? a.tail2.actions : a.post_actions;
+  float* post_sigma = second ? a.tail2.sigma : a.post_sigma;
+  float* post_logp = second ? a.tail2.logp : a.post_logp;
+  const float* enc_obs = second ? a.tail2.enc_obs : a.enc_obs;
+  float* enc_out = second ? a.tail2.enc_out : a.enc_out;
+  const float* enc_obs2 = second ? nullptr : a.enc_obs2;
+  const float* enc_act2 = second ? nullptr : a.enc_act2;
+  float* enc_out2 = second ? nullptr : a.enc_out2;
   const int64_t poff = net * a.stride_params + (second ? a.second_params : 0);
   const float* W1 = a.W1 + poff;
   const float* b1 = a.b1 + poff;
@@ -336,17 +350,17 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
         float v = out[0][e] + hbias[e];
         if (act == ACT_TANH) v = tanhf(v);
         if (row_ok) dst[o] = v;
-        if (a.post != POST_NONE) lds[(head * kRows + m) * kPostPitch + o] = v;   // hx is free now
+        if (post != POST_NONE) lds[a.tail_offset + (head * kRows + m) * kPostPitch + o] = v;   // (H >= 188: hx, free now)
       }
     }
   }
   stamp(6);
-  if (a.post == POST_NONE) return;                    // scalar
+  if (post == POST_NONE) return;                    // scalar
 
   // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
   __syncthreads();
-  const float* headbuf = lds;                         // [2 heads][16 rows][kPostPitch]
-  float* terms = lds + 2 * kRows * kPostPitch;        // [16 rows][kPostPitch] log-prob terms
+  const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
+  float* terms = lds + a.tail_offset + 2 * kRows * kPostPitch;      // [16 rows][kPostPitch] log-prob terms
   const int prow = tid >> 4, slot = tid & 15, A = a.NH;
   const int64_t grow = r0 + prow;
   const bool ok = grow < a.B;
@@ -355,44 +369,44 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
     float term = 0.f, action = 0.f;
     if (aa < A) {
       const float first = headbuf[prow * kPostPitch + aa];
-      if (a.post == POST_SQUASHED_SAMPLE) {
-        const bool has_eps = a.post_eps != nullptr;
-        const float eps = (has_eps && ok) ? a.post_eps[grow * A + aa] : 0.f;
+      if (post == POST_SQUASHED_SAMPLE) {
+        const bool has_eps = post_eps != nullptr;
+        const float eps = (has_eps && ok) ? post_eps[grow * A + aa] : 0.f;
         const SquashedSample sm =
             squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
         term = sm.logp_term;
         if (ok) {
-          a.post_actions[grow * A + aa] = sm.action;
-          if (a.post_sigma != nullptr) a.post_sigma[grow * A + aa] = sm.sigma;
+          post_actions[grow * A + aa] = sm.action;
+          if (post_sigma != nullptr) post_sigma[grow * A + aa] = sm.sigma;
         }
         action = sm.action;
       } else if (ok) {
-        action = a.post == POST_TARGET_NOISE
-                     ? noisy_target_action(first, a.post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
+        action = post == POST_TARGET_NOISE
+                     ? noisy_target_action(first, post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
                      : first;
-        a.post_actions[grow * A + aa] = action;
+        post_actions[grow * A + aa] = action;
       }
-      if (ok && a.enc_out != nullptr) {               // the critics' input: action columns
-        a.enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
-        if (a.enc_out2 != nullptr)
-          a.enc_out2[grow * a.enc_ld + a.enc_O + aa] = a.enc_act2[grow * A + aa];
+      if (ok && enc_out != nullptr) {               // the critics' input: action columns
+        enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
+        if (enc_out2 != nullptr)
+          enc_out2[grow * a.enc_ld + a.enc_O + aa] = enc_act2[grow * A + aa];
       }
     }
     terms[prow * kPostPitch + aa] = term;
   }
-  if (a.enc_out != nullptr) {
+  if (enc_out != nullptr) {
     // ... and the normalised observation columns, eight 16-column strips at a time: all loads
     // first, through clamped addresses (a load under a lane-predicated branch waits for itself)
     const int O = a.enc_O;
     const int64_t src = min(grow, (int64_t)a.B - 1);
-    const bool second = a.enc_out2 != nullptr;
+    const bool pair = enc_out2 != nullptr;
     for (int c0 = 0; c0 < O; c0 += 8 * 16) {
       float x[8], y[8], mean[8], sdev[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int c = min(c0 + 16 * u + slot, O - 1);
-        x[u] = a.enc_obs[src * O + c];
-        y[u] = second ? a.enc_obs2[src * O + c] : 0.f;
+        x[u] = enc_obs[src * O + c];
+        y[u] = pair ? enc_obs2[src * O + c] : 0.f;
         mean[u] = a.enc_mean[c];
         sdev[u] = a.enc_std[c];
       }
@@ -400,16 +414,16 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
       for (int u = 0; u < 8; ++u) {
         const int c = c0 + 16 * u + slot;
         if (ok && c < O) {
-          a.enc_out[grow * a.enc_ld + c] =
+          enc_out[grow * a.enc_ld + c] =
               __builtin_amdgcn_fmed3f((x[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
-          if (second)
-            a.enc_out2[grow * a.enc_ld + c] =
+          if (pair)
+            enc_out2[grow * a.enc_ld + c] =
                 __builtin_amdgcn_fmed3f((y[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
         }
       }
     }
   }
-  if (a.post != POST_SQUASHED_SAMPLE || a.post_logp == nullptr) return;
+  if (post != POST_SQUASHED_SAMPLE || post_logp == nullptr) return;
   __syncthreads();
   if (tid < kRows && r0 + tid < a.B) {
     // the fold of sac_sample_kernel, re-played: G lanes, lane j summing terms j, j + G, ...
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
     for (int aa = G; aa < A; ++aa) v[aa % G] += v[aa];
     for (int off = G >> 1; off >= 1; off >>= 1)
       for (int j = 0; j < off; ++j) v[j] += v[j + off];
-    a.post_logp[r0 + tid] = v[0];
+    post_logp[r0 + tid] = v[0];
   }
   stamp(7);
 }
@@ -456,6 +470,38 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) tile_of[j] = min(wave + 4 * j, tiles - 1);
 
+  // The folded head backward, part 1 (first thing in the kernel): its operands are requested
+  // through clamped addresses, no branch around a load, so that they return before the mask /
+  // weight loads requested below — which then fly during the arithmetic of part 2.
+  const bool formed = a.heads > 0 && a.hb_dxa0 != nullptr;      // scalar
+  float* dhl = lds + 2 * kRows * pitch;             // [2 heads][16 rows][kHeadPitch] (formed only)
+  constexpr int kHeadSlots = kPostPitch / 16;
+  float hb_da[kHeadSlots], hb_t[kHeadSlots], hb_sg[kHeadSlots], hb_ep[kHeadSlots], hb_pre[kHeadSlots];
+  const int hb_row = tid >> 4, hb_slot = tid & 15;
+  if (formed) {
+    const int A = a.NH;
+    const int64_t src = min((int64_t)r0 + hb_row, (int64_t)a.B - 1);
+    const float* dxa1 = a.hb_dxa1 != nullptr ? a.hb_dxa1 : a.hb_dxa0;
+    const float* sgp = a.hb_sac ? a.hb_sigma : a.hb_act;
+    const float* epp = a.hb_sac ? a.hb_eps : a.hb_act;
+    const float* prep = a.hb_sac ? a.hb_spre : a.hb_act;
+    const int64_t pre_ld = a.hb_sac ? a.ldh : A;
+    float second[kHeadSlots];
+#pragma unroll
+    for (int u = 0; u < kHeadSlots; ++u) {
+      const int aa = min(hb_slot + 16 * u, A - 1);
+      hb_da[u] = a.hb_dxa0[src * a.hb_ldxa + aa];
+      second[u] = dxa1[src * a.hb_ldxa + aa];
+      hb_t[u] = a.hb_act[src * A + aa];
+      hb_sg[u] = sgp[src * A + aa];
+      hb_ep[u] = epp[src * A + aa];
+      hb_pre[u] = prep[src * pre_ld + aa];
+    }
+    if (a.hb_dxa1 != nullptr) {
+#pragma unroll
+      for (int u = 0; u < kHeadSlots; ++u) hb_da[u] = hb_da[u] + second[u];
+    }
+  }
   // ReLU masks of both layers (forward activations of this lane's rows / features), up front
   // H = 256: the dz1 product runs on INTERLEAVED tiles — wave w owns features [64 w, 64 w + 64),
   // tile j of them the features 64 w + 4 i + j — because W2^T is contiguous along the OUTPUT
@@ -529,16 +575,57 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
       for (int e = 0; e < 4; ++e) acc[j][e] = dq * w[e];
     }
   } else {                                            // actor: sum over the heads of dhead . Wh
+    if (formed) {
+      // part 2: actor_head_backward_kernel for the 16 rows of this workgroup, thread = (row, action
+      // slot): the same expressions, so the same bits as the stand-alone launch; -> LDS (B operand
+      // of the head products below) and -> dhead[.] in HBM (the weight-gradient GEMM contracts them)
+      const int A = a.NH;
+      const int64_t grow = r0 + hb_row;
+      const bool ok = grow < a.B;
+#pragma unroll
+      for (int u = 0; u < kHeadSlots; ++u) {
+        const int aa = hb_slot + 16 * u;
+        float dloc = 0.f, dspre = 0.f;
+        if (aa < A) {
+          const float da = hb_da[u], t = hb_t[u];
+          const float one_m = 1.f - t * t;
+          if (!a.hb_sac) {
+            dloc = da * one_m;
+          } else {
+            const float du = da * one_m + a.hb_alpha * (2.f * t * one_m / (one_m + kSacLogEps));
+            const float dsigma = du * hb_ep[u] - a.hb_alpha / hb_sg[u];
+            const float pre = hb_pre[u];
+            const float raw = softplus_f(pre);
+            const bool inside = raw >= 1e-4f && raw <= 1.0f;
+            dloc = du;
+            dspre = inside ? dsigma / (1.f + expf(-pre)) : 0.f;
+          }
+          if (ok) {
+            const_cast<float*>(a.dhead[0])[grow * a.ldh + aa] = dloc;
+            if (a.hb_sac) const_cast<float*>(a.dhead[1])[grow * a.ldh + aa] = dspre;
+          }
+        }
+        dhl[hb_row * kHeadPitch + aa] = dloc;
+        dhl[(kRows + hb_row) * kHeadPitch + aa] = dspre;
+      }
+      __syncthreads();
+    }
     for (int h = 0; h < a.heads; ++h) {
       const float* Wh = (h == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
       const float* dh = (h == 0 ? a.dhead[0] : a.dhead[1]) + (int64_t)row * a.ldh;
+      const float* dl = dhl + (h * kRows + m) * kHeadPitch;
       const float* colsh[kMaxTiles];
 #pragma unroll
       for (int j = 0; j < kMaxTiles; ++j) colsh[j] = Wh + 16 * tile_of[j] + m;
       Layer<kMaxTiles, true> lh;
       lh.start(colsh, a.NH, kg, a.ldw2);
-      auto from_dh = [&](int k) { return load_k4(dh, k); };       // rows are padded to ldh >= 16
-      lh.run(kg, acc, from_dh, from_dh);
+      if (formed) {
+        auto from_dl = [&](int k) { return *reinterpret_cast<const f32x4*>(dl + k); };
+        lh.run(kg, acc, from_dl, from_dl);
+      } else {
+        auto from_dh = [&](int k) { return load_k4(dh, k); };     // rows are padded to ldh >= 16
+        lh.run(kg, acc, from_dh, from_dh);
+      }
     }
   }
   finish(acc, mask2, dz2g, hx);
@@ -645,9 +732,12 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 
 std::atomic<int> g_policy_tail{1};
 
-// the tail's three [16][kPostPitch] images live in the first hidden image (the second is being read)
-bool mlp_policy_tail_supported(int H, int NH) {
-  return NH <= kPostPitch && 3 * kRows * kPostPitch <= kRows * (H + 4);
+// The tail's three [16][kPostPitch] images live in the first hidden image where they fit (H >= 188:
+// the second image is still being read by other head waves), else behind both images.
+bool mlp_policy_tail_supported(int H, int NH) { return H >= 16 && NH <= kPostPitch; }
+
+static int policy_tail_offset(int H) {
+  return 3 * kRows * kPostPitch <= kRows * (H + 4) ? 0 : 2 * kRows * (H + 4) + 4 * kRows;
 }
 
 bool mlp_forward_supported(int H, int NH, int heads) {
@@ -676,8 +766,15 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
                      a.enc_ld >= a.enc_O + a.NH && (a.enc_out2 == nullptr || (a.enc_obs2 && a.enc_act2))),
                 TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: encoder in the policy tail (O=%d ld=%d)",
                 a.enc_O, a.enc_ld);
+  TONIC_REQUIRE(a.tail2.post == POST_NONE ||
+                    (nets == 2 && a.split == 1 && a.post != POST_NONE && a.tail2.actions != nullptr &&
+                     (a.tail2.enc_out == nullptr || (a.tail2.enc_obs && a.enc_mean && a.enc_std)) &&
+                     (a.tail2.post == POST_SQUASHED_SAMPLE ? a.heads == 2
+                                                           : a.heads == 1 && (a.tail2.post == POST_COPY || a.tail2.eps))),
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: second policy tail %d (nets=%d split=%d)",
+                a.tail2.post, nets, a.split);
   TONIC_REQUIRE(a.post == POST_NONE ||
-                    (nets == 1 && a.NH <= kPostPitch && a.post_actions != nullptr &&
+                    ((nets == 1 || a.tail2.post != POST_NONE) && a.NH <= kPostPitch && a.post_actions != nullptr &&
                      mlp_policy_tail_supported(a.H, a.NH) &&
                      (a.post == POST_SQUASHED_SAMPLE ? a.heads == 2
                                                      : a.heads == 1 && (a.post == POST_COPY || a.post_eps))),
@@ -685,8 +782,14 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
                 a.post, a.heads, a.NH, a.H);
   TONIC_REQUIRE(a.split >= nets || a.X2 != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_forward: split=%d of %d networks without a second input", a.split, nets);
-  const size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);
+  size_t lds = (2 * (size_t)kRows * (a.H + 4) + 4 * kRows) * sizeof(float);
   MlpFwdArgs launch = a;
+  launch.tail_offset = 0;
+  if (a.post != POST_NONE) {
+    launch.tail_offset = policy_tail_offset(a.H);
+    const size_t need = ((size_t)launch.tail_offset + 3 * kRows * kPostPitch) * sizeof(float);
+    if (need > lds) lds = need;
+  }
   launch.stamps = nullptr;
   if (unsigned long long* base = g_forward_stamps.load()) {      // developer probe: ring of 8 launches
     launch.stamps = base + 8 * (g_forward_launches.fetch_add(1) % 8);
@@ -709,7 +812,13 @@ int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
   TONIC_REQUIRE(a.ldw2 >= a.H && (a.xa_count == 0 || a.ldw1 >= a.K1) && a.ldhid >= a.H &&
                     a.ldhid % 4 == 0, TONIC_ERR_INVALID_ARGUMENT,
                 "mlp_backward: strides %d / %d / %d", a.ldw1, a.ldw2, a.ldhid);
-  const size_t lds = 2 * (size_t)kRows * (a.H + 4) * sizeof(float);
+  TONIC_REQUIRE(a.hb_dxa0 == nullptr ||
+                    (a.heads >= 1 && nets == 1 && a.NH <= kPostPitch && a.hb_act && a.dhead[0] &&
+                     (!a.hb_sac || (a.heads == 2 && a.hb_eps && a.hb_sigma && a.hb_spre && a.dhead[1]))),
+                TONIC_ERR_INVALID_ARGUMENT, "mlp_backward: folded head backward (heads=%d NH=%d)",
+                a.heads, a.NH);
+  const size_t lds = (2 * (size_t)kRows * (a.H + 4) +
+                      (a.hb_dxa0 != nullptr ? 2 * (size_t)kRows * kHeadPitch : 0)) * sizeof(float);
   hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);
   TONIC_CHECK_LAUNCH("mlp_backward_kernel");

@@ -761,7 +761,7 @@ struct StepLoss {
 int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                      int Bp, const float* h1, const float* h2, float* dq, float* dh2,
                      float* dh1, float* grads, float* dxa, hipStream_t st,
-                     const StepLoss* loss = nullptr) {
+                     const StepLoss* loss = nullptr, const AdamFold* fold = nullptr) {
   const CriticOffsets o(s);
   const bool one_launch = mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0);
   if (loss && !one_launch) {
@@ -825,7 +825,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
     w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
     w[2].strideA = hs; w[2].strideC = o.count;
-    TRY(launch_gemm_group('s', 's', w, 3, nets, st));
+    TRY(launch_gemm_group('s', 's', w, 3, nets, st, fold));
   }
   return TONIC_OK;
 }
@@ -1006,7 +1006,8 @@ namespace {
 int actor_shaped_backward(const float* params, ActorShape as, const float* X, int ldx, int B,
                           const float* a_h1, const float* a_h2, const float* dloc,
                           const float* dspre, int ldh, float* da_h2, float* da_h1, float* grads,
-                          float* dxa, int xa_first, int xa_count, hipStream_t st) {
+                          float* dxa, int xa_first, int xa_count, hipStream_t st,
+                          const MlpBwdArgs* head_fold = nullptr, const AdamFold* fold = nullptr) {
   const int H = as.H, A = as.A, HP = weight_ld(H);
   ActorParams p(params, as);
   GemmArgs g;
@@ -1021,6 +1022,11 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
     b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = dxa; b.ldhid = HP;
     b.ldxa = pad16(xa_count > 0 ? xa_count : 1);
     b.B = B; b.H = H;
+    if (head_fold != nullptr) {          // dloc / dspre are FORMED by this launch (hb_* of MlpBwdArgs)
+      b.hb_dxa0 = head_fold->hb_dxa0; b.hb_dxa1 = head_fold->hb_dxa1; b.hb_ldxa = head_fold->hb_ldxa;
+      b.hb_act = head_fold->hb_act; b.hb_eps = head_fold->hb_eps; b.hb_sigma = head_fold->hb_sigma;
+      b.hb_spre = head_fold->hb_spre; b.hb_sac = head_fold->hb_sac; b.hb_alpha = head_fold->hb_alpha;
+    }
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
@@ -1052,13 +1058,184 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
   w[count++].colsum = gp.b2;
   w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
   w[count++].colsum = gp.b1;
-  return launch_gemm_group('s', 's', w, count, 1, st);
+  return launch_gemm_group('s', 's', w, count, 1, st, fold);
 }
 
 }  // namespace
 
 // Actor gradient through the (frozen) critics.  kind 0 = DeterministicPolicyGradient on
 // critic_1 only (actors.py:170-189 with td3.py:36), 1 = TwinCriticSoftDeterministicPolicyGradient
+
+// ------------------------------------------------------------------ one whole learner iteration
+// ddpg.py:95-112 / td3.py:38-55 / sac.py with the launches of the two updaters merged where they do
+// not depend on each other, and the optimizer steps folded into the weight-gradient launches:
+//   1  policy passes of BOTH steps: net 0 = the critic step's policy on s' (TD3 / DDPG: target actor
+//      [+ clipped noise], SAC: online actor sample + log-prob) whose tail also encodes the critics'
+//      inputs (s', a') and (s, a); net 1 (actor due) = the online actor on s with the actor step's
+//      sample, whose tail encodes (s, a_new).  The critic step does not touch the actor, so net 1
+//      sees the parameters the reference's actor step would see.
+//   2  target critics on (s', a') + online critics on (s, a)
+//   3  TD loss + the online critics' input-gradient chain
+//   4  the critics' weight gradients + Adam [+ polyak of the critics when the targets move]
+//   5  (actor due) the UPDATED critics on (s, a_new)
+//   6  actor objective + the critics' chain down to the action columns
+//   7  head backward + the actor's input-gradient chain
+//   8  the actor's weight gradients + Adam + polyak of the actor
+// 13 launches of the split path (gather, 4 forwards, 3 backwards, head backward, 2 weight-gradient
+// groups, 2 optimizer launches) become 8 (4 when the actor is not due).
+namespace {
+
+int64_t q_iteration_floats(int B, int O, int A, int H) {
+  const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
+  return 2 * (2 * Bp * HP + 2 * Bp * ldh)           // policy passes: h1, h2, two head outputs, x2
+         + 3 * Bp * A + 2 * Bp                      // next actions, new actions, sigma, two log-probs
+         + 3 * Bp * ldx                             // X (s', a'), X2 (s, a), X3 (s, a_new)
+         + 2 * 4 * Bp * HP + 4 * Bp                 // four-critic forward: h1, h2, values
+         + 2 * Bp + 2 * 2 * Bp * HP                 // dq, dz2, dz1 of two critics
+         + 2 * Bp * ldh + 2 * Bp * ldh              // dxa (two critics), dloc, dspre
+         + 2 * Bp * HP;                             // actor dz2, dz1
+}
+
+}  // namespace
+
+extern "C" int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H) {
+  return (q_iteration_floats(B, O, A, H) + 64 * 40) * 4;
+}
+
+extern "C" int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads) {
+  return mlp_forward_supported(H, A, heads) && mlp_policy_tail_supported(H, A) &&
+         mlp_forward_supported(H, 1, 1) && mlp_backward_supported(H, 1, 0, A) &&
+         mlp_backward_supported(H, A, heads, 0) && O > 0 ? 1 : 0;
+}
+
+extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
+  TONIC_REQUIRE(it != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_q_iteration: null arguments");
+  const tonic_q_iteration_t& a = *it;
+  const int kind = a.kind, B = a.B, O = a.O, H = a.H, A = a.A;
+  const bool due = a.actor_due != 0;
+  TONIC_REQUIRE(kind >= 0 && kind <= 2 && B > 0 && a.d_actor && a.d_critics && a.d_target_actor &&
+                    a.d_target_critics && a.d_norm_mean && a.d_norm_std && a.d_observations &&
+                    a.d_actions && a.d_next_observations && a.d_rewards && a.d_discounts &&
+                    (a.d_eps_critic || kind == 2) && (a.d_eps_actor || kind != 1 || !due) &&
+                    a.critic.d_grad_sums && a.critic.d_exp_avg && a.critic.d_exp_avg_sq &&
+                    a.critic.d_state && a.actor.d_grad_sums && a.actor.d_exp_avg &&
+                    a.actor.d_exp_avg_sq && a.actor.d_state && a.d_workspace,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_q_iteration: bad argument");
+  const int heads = kind == 1 ? 2 : 1;
+  TONIC_REQUIRE(tonic_q_iteration_supported(O, H, A, heads), TONIC_ERR_UNSUPPORTED_SHAPE,
+                "tonic_q_iteration: O=%d H=%d A=%d outside the fused kernels", O, H, A);
+  TONIC_REQUIRE(a.workspace_bytes >= tonic_q_iteration_workspace_bytes(B, O, A, H),
+                TONIC_ERR_WORKSPACE, "tonic_q_iteration: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
+  const int nets = kind == 2 ? 1 : 2;                  // critics
+  const CriticShape cs{O, A, H};
+  const ActorShape as{O, H, A, heads};
+  const int64_t Pc = critic_count(cs), Pa = actor_count(as), hs = (int64_t)Bp * HP;
+  Workspace ws{static_cast<char*>(a.d_workspace), 0, a.workspace_bytes};
+  // policy passes [net 0 | net 1]
+  float* p_h1 = ws.take(2 * hs); float* p_h2 = ws.take(2 * hs);
+  float* head0 = ws.take(2LL * Bp * ldh); float* head1 = ws.take(2LL * Bp * ldh);
+  float* next_act = ws.take((int64_t)Bp * A); float* logp_next = ws.take(Bp);
+  float* act = ws.take((int64_t)Bp * A); float* sigma = ws.take((int64_t)Bp * A);
+  float* logp = ws.take(Bp);
+  float* X = ws.take((int64_t)Bp * ldx); float* X2 = ws.take((int64_t)Bp * ldx);
+  float* X3 = ws.take((int64_t)Bp * ldx);
+  float* h1_all = ws.take(4 * hs); float* h2_all = ws.take(4 * hs);
+  float* q_all = ws.take(4LL * Bp);
+  float* c_h1 = h1_all + nets * hs; float* c_h2 = h2_all + nets * hs;
+  float* tq = q_all; float* q = q_all + (int64_t)nets * Bp;
+  float* dq = ws.take(2LL * Bp);
+  float* dh2 = ws.take(2 * hs); float* dh1 = ws.take(2 * hs);
+  float* dxa = ws.take(2LL * Bp * ldh);
+  float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
+  float* da_h2 = ws.take(hs); float* da_h1 = ws.take(hs);
+
+  // ---- 1: the policy passes
+  {
+    const float* policy = kind == 1 ? a.d_actor : a.d_target_actor;
+    ActorParams p(policy, as);
+    MlpFwdArgs f{};
+    f.X = a.d_next_observations; f.ldx = O; f.K1 = O;
+    f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2; f.ldw1 = p.ld1; f.ldw2 = p.ldH;
+    f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
+    f.Wh[1] = p.head_w(heads - 1); f.bh[1] = p.head_b(heads - 1);
+    f.heads = heads; f.NH = A;
+    f.h1 = p_h1; f.h2 = p_h2; f.ldh = HP;
+    f.out[0] = head0; f.out[1] = heads == 2 ? head1 : head0; f.ldo = ldh;
+    f.act[0] = kind != 1 ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
+    f.B = B; f.H = H; f.split = 1 << 30;
+    f.stride_hidden = hs; f.stride_out = (int64_t)Bp * ldh;
+    f.post = kind == 0 ? POST_TARGET_NOISE : kind == 2 ? POST_COPY : POST_SQUASHED_SAMPLE;
+    f.post_eps = a.d_eps_critic; f.post_actions = next_act;
+    f.post_logp = kind == 1 ? logp_next : nullptr;
+    f.noise_scale = (float)a.noise_scale; f.noise_clip = (float)a.noise_clip;
+    f.enc_obs = a.d_next_observations; f.enc_obs2 = a.d_observations; f.enc_act2 = a.d_actions;
+    f.enc_mean = a.d_norm_mean; f.enc_std = a.d_norm_std; f.enc_clip = clip_bound(a.norm_clip);
+    f.enc_out = X; f.enc_out2 = X2; f.enc_O = O; f.enc_ld = ldx;
+    if (due) {
+      f.split = 1;
+      f.second_params = a.d_actor - policy;            // (0 for SAC: the same network on s)
+      f.X2 = a.d_observations;
+      f.tail2.post = kind == 1 ? POST_SQUASHED_SAMPLE : POST_COPY;
+      f.tail2.eps = kind == 1 ? a.d_eps_actor : nullptr;
+      f.tail2.actions = act; f.tail2.sigma = kind == 1 ? sigma : nullptr;
+      f.tail2.logp = kind == 1 ? logp : nullptr;
+      f.tail2.enc_obs = a.d_observations; f.tail2.enc_out = X3;
+    }
+    TRY(launch_mlp_forward(f, due ? 2 : 1, st));
+  }
+  // ---- 2: targets on (s', a') and online critics on (s, a)
+  TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
+                      a.d_critics, X2));
+  // ---- 3 + 4: TD loss, backward chain, weight gradients + Adam (+ polyak of the critics)
+  const float grad_scale = (float)(1.0 / (a.global_batch > 0 ? a.global_batch : B));
+  AdamFold cf{};
+  cf.grads = a.critic.d_grad_sums; cf.params = a.d_critics; cf.exp_avg = a.critic.d_exp_avg;
+  cf.exp_avg_sq = a.critic.d_exp_avg_sq; cf.state = a.critic.d_state; cf.n = nets * Pc;
+  cf.grad_scale = grad_scale; cf.beta2 = (float)a.critic.beta2; cf.eps = (float)a.critic.eps;
+  cf.beta1_d = a.critic.beta1; cf.beta2_d = a.critic.beta2; cf.lr_d = a.critic.lr;
+  cf.stats_kind = 3; cf.info_row = a.critic.d_info_row; cf.consts = a.critic.d_step_constants;
+  if (due) {
+    cf.target = a.d_target_critics;
+    cf.polyak_keep = (float)(1.0 - a.target_coeff); cf.polyak_mix = (float)a.target_coeff;
+  }
+  const StepLoss td{LOSS_TD, a.d_rewards, a.d_discounts, tq,
+                    kind == 1 ? logp_next : (const float*)nullptr, (float)a.critic_entropy_coeff, q,
+                    a.critic.d_grad_sums + nets * Pc};
+  TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
+                       a.critic.d_grad_sums, nullptr, st, &td, &cf));
+  if (!due) {
+    TONIC_CHECK_LAUNCH("tonic_q_iteration");
+    return TONIC_OK;
+  }
+  // ---- 5 + 6: the updated critics on (s, a_new), the actor objective, down to the action columns
+  const int used = kind == 1 ? 2 : 1;                  // TD3 / DDPG: critic_1 only (td3.py:36)
+  TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st));
+  const StepLoss objective{LOSS_ACTOR, nullptr, nullptr, nullptr, logp,
+                           (float)a.actor_entropy_coeff, q, a.actor.d_grad_sums + Pa};
+  TRY(critics_backward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr,
+                       dxa, st, &objective));
+  // ---- 7 + 8: head backward + actor chain, weight gradients + Adam + polyak of the actor
+  MlpBwdArgs hb{};
+  hb.hb_dxa0 = dxa; hb.hb_dxa1 = used == 2 ? dxa + (int64_t)Bp * ldh : nullptr; hb.hb_ldxa = ldh;
+  hb.hb_act = act; hb.hb_eps = a.d_eps_actor; hb.hb_sigma = sigma;
+  hb.hb_spre = head1 + (int64_t)Bp * ldh;              // net 1's scale head
+  hb.hb_sac = kind == 1 ? 1 : 0; hb.hb_alpha = (float)a.actor_entropy_coeff;
+  AdamFold af{};
+  af.grads = a.actor.d_grad_sums; af.params = a.d_actor; af.exp_avg = a.actor.d_exp_avg;
+  af.exp_avg_sq = a.actor.d_exp_avg_sq; af.state = a.actor.d_state; af.n = Pa;
+  af.grad_scale = grad_scale; af.beta2 = (float)a.actor.beta2; af.eps = (float)a.actor.eps;
+  af.beta1_d = a.actor.beta1; af.beta2_d = a.actor.beta2; af.lr_d = a.actor.lr;
+  af.stats_kind = 4; af.info_row = a.actor.d_info_row; af.consts = a.actor.d_step_constants;
+  af.target = a.d_target_actor;
+  af.polyak_keep = (float)(1.0 - a.target_coeff); af.polyak_mix = (float)a.target_coeff;
+  TRY(actor_shaped_backward(a.d_actor, as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
+                            kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
+                            nullptr, 0, 0, st, &hb, &af));
+  TONIC_CHECK_LAUNCH("tonic_q_iteration");
+  return TONIC_OK;
+}
 
 // ------------------------------------------------------------------ D4PG (distributional critic)
 // The critic is an actor-shaped network: input [normalised observation | action] (O + A columns),

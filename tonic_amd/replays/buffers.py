@@ -135,6 +135,25 @@ class Buffer:
             return {k: v[:count] for k, v in out.items()}
         return out
 
+    def gather_many(self, device_indices):
+        """All batches of one learner update in ONE launch: int64 device indices [iterations, B] ->
+        {key: [iterations, B, ...]} (the store does not change while an update runs, so the
+        gathers of its iterations need not be interleaved with them)."""
+        iterations, count = device_indices.shape
+        store = getattr(self, '_many', None)
+        if store is None or store['rewards'].shape != (iterations, count):
+            store = self._many = {
+                k: torch.empty((iterations, count) + tuple(v.shape[1:]), dtype=v.dtype,
+                               device=self.device) for k, v in self.batch.items()}
+        b, p = self.buffers, _lib.ptr
+        _lib.check(self.lib.tonic_buffer_gather(
+            p(device_indices), p(b['observations']), p(b['actions']), p(b['next_observations']),
+            p(b['rewards']), p(b['discounts']), p(store['observations']), p(store['actions']),
+            p(store['next_observations']), p(store['rewards']), p(store['discounts']),
+            self.num_workers, iterations * count, self.observation_size, self.action_size,
+            _lib.current_stream()), 'tonic_buffer_gather')
+        return store
+
     def get(self, *keys, steps):
         """Generator form of the reference API (buffers.py:81-91): yields device-tensor batches.
         With several ranks every rank draws the same global index stream and yields ITS part of

@@ -48,6 +48,7 @@ class _FlatUpdater:
         self.exp_avg = torch.zeros(self.count, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.count, dtype=torch.float32, device=device)
         self.state = torch.zeros(4, dtype=torch.int32, device=device)   # {step, stop, -, -}
+        self.steps_enqueued = 0     # host mirror of state[0] (off-policy: every enqueued step is taken)
         self.workspace = None
         self.scratch_info = torch.zeros(INFO_WIDTH, dtype=torch.float32, device=device)
         self.gradient_clip = float(getattr(self, 'gradient_clip', 0) or 0)
@@ -95,6 +96,7 @@ class _FlatUpdater:
         polyak update of ALL targets rides in the same launch (update_targets right after the
         step, as ddpg.py:105-112 orders them)."""
         from tonic_amd import parallel
+        self.steps_enqueued += 1
         if parallel.exchanging() and allreduce:
             one_shot = parallel.one_shot(self.count + INFO_WIDTH)
             if one_shot is not None:
@@ -119,6 +121,15 @@ class _FlatUpdater:
             h['lr'], h['betas'][0], h['betas'][1], h['eps'], self.stats_kind,
             float(kl_threshold), float(entropy_coeff), _lib.ptr(adv_stats),
             _lib.ptr(info_row), skip, _lib.current_stream()), 'tonic_adam_step')
+
+
+def adam_step_constants(hyper, step):
+    """{step_size, bias_correction2_sqrt} of optimizer step `step` (1-based) as float32 of the
+    float64 values torch.optim.Adam forms in Python (adam.py:530-536)."""
+    beta1, beta2 = hyper['betas']
+    bias_correction1 = 1 - beta1 ** step
+    bias_correction2 = 1 - beta2 ** step
+    return hyper['lr'] / bias_correction1, bias_correction2 ** 0.5
 
 
 def enqueue_step_pair(actor, critic, n_local, adv_stats, actor_info, critic_info):
