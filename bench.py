@@ -702,6 +702,8 @@ def main():
     parser.add_argument('--steps', type=int, default=3)
     parser.add_argument('--warmup', type=int, default=1)
     parser.add_argument('--no-graph', action='store_true', help='eager launches, no hipGraph')
+    parser.add_argument('--quick-extras', action='store_true',
+                        help='only the phase split and the host-loop breakdown')
     parser.add_argument('--no-extras', action='store_true',
                         help='skip roofline / cpu_baseline / off-policy measurements')
     parser.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
@@ -816,6 +818,7 @@ def main():
         result['update_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
         result['host_loop'] = loop.breakdown()
         loop.run(T - loop.agent.replay.index)             # finish the segment
+    if rank == 0 and not args.no_extras and not args.quick_extras and world == 1:
         roof, roof_c, roof_g = kernel_rooflines(agent)
         result['roofline'] = roof
         result['roofline_critic'] = roof_c

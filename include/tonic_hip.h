@@ -353,6 +353,13 @@ int64_t tonic_collector_block_bytes(int64_t W, int32_t O, int32_t A);
 int tonic_collector_block_init(void* block, int64_t bytes, int64_t W, int32_t O, int32_t A,
                                int32_t worker_groups);
 int64_t tonic_collector_block_offset(const void* block, int32_t field);   /* bytes; < 0: error */
+/* A vectorised simulator's step record in one host call (no reference counterpart: the per-worker
+ * loop of tonic/environments/distributed.py:28-58 for the zero-cost synthetic benchmark
+ * environment of SURVEY.md §8d): next_observations [W,O] -> the NEXT_OBSERVATIONS and OBSERVATIONS
+ * fields, rewards[w] = -sum_a actions[w][a]^2 (float32, left to right).  actions == NULL: the
+ * block's ACTIONS field.  Flags are the caller's business. */
+int tonic_collector_synthetic_step(void* block, const float* next_observations,
+                                   const float* actions);
 int64_t tonic_collector_worker_wait(void* block, int64_t seen_sequence, double timeout_s);
 int tonic_collector_worker_done(void* block);
 int tonic_collector_submit_actions(void* block);

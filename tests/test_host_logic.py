@@ -121,6 +121,39 @@ def test_step_outputs_are_read_only_views_or_copies():
     assert np.array_equal(kept, before)
 
 
+def test_noise_drawn_ahead_is_the_reference_stream():
+    """_NoiseAhead (the collect loop's action noise, drawn 64 steps per call by a helper thread)
+    hands out exactly the draws of consecutive torch.randn(W, A) calls, and `rewind` leaves the
+    generator where those calls would have left it — with and without an unconsumed draw, across
+    buffer swaps; shapes the block draw cannot reproduce fall back to one draw per step."""
+    import torch
+    from tonic_amd.torch.agents import _NoiseAhead
+
+    class Agent:
+        global_noise, _acting_generator = False, None
+
+        def _randn(self, workers, width, out=None):
+            return torch.randn(workers, width, out=out)
+    for workers, width, bulk in ((256, 6, True), (16, 1, True), (8, 6, True), (5, 3, False)):
+        torch.manual_seed(3)
+        reference = [torch.randn(workers, width).numpy().copy() for _ in range(200)]
+        after = torch.randn(4).numpy().copy()
+        torch.manual_seed(3)
+        noise = _NoiseAhead(Agent(), workers, width)
+        assert noise.bulk == bulk
+        out = np.zeros((workers, width), np.float32)
+        for t in range(150):
+            noise.take(out)
+            assert np.array_equal(out, reference[t]), (workers, width, t)
+        noise.rewind(1)                      # the 150th draw has not been consumed: un-draw it
+        assert np.array_equal(torch.randn(workers, width).numpy(), reference[149])
+        for t in range(150, 200):
+            noise.take(out)
+            assert np.array_equal(out, reference[t]), (workers, width, t)
+        noise.rewind(0)
+        assert np.array_equal(torch.randn(4).numpy(), after)
+
+
 def test_synthetic_batch_protocol():
     from tonic_amd.environments import SyntheticBatch
     env = SyntheticBatch(8, 17, 6, max_episode_steps=3, termination_probability=0.2)

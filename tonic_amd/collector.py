@@ -65,6 +65,7 @@ class Block:
             out = array.view()
             out.setflags(write=False)
             return out
+        self.out_actions = handout(self.actions)
         self.out_observations = handout(self.observations)
         self.out_next_observations = handout(self.next_observations)
         self.out_rewards = handout(self.rewards)

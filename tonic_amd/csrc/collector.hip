@@ -147,6 +147,32 @@ extern "C" int64_t tonic_collector_block_offset(const void* block, int32_t field
   return h->offset[field];
 }
 
+// A vectorised simulator's step record in one call (tonic_amd.environments.SyntheticBatch: the
+// zero-cost benchmark environment of SURVEY §8d, obs from a pre-generated pool, reward = -|a|^2):
+// next_observations -> the NEXT_OBSERVATIONS and OBSERVATIONS fields, rewards[w] = -sum_a a[w][a]^2
+// in float32, left to right.  actions == NULL: the block's ACTIONS field, where the act kernel
+// wrote them.  Host code only (no HIP call): five NumPy calls per step otherwise.
+extern "C" int tonic_collector_synthetic_step(void* block, const float* next_observations,
+                                              const float* actions) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr && next_observations != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_synthetic_step: bad argument");
+  char* base = static_cast<char*>(block);
+  const size_t bytes = (size_t)h->W * h->O * sizeof(float);
+  memcpy(base + h->offset[TONIC_COLLECTOR_NEXT_OBSERVATIONS], next_observations, bytes);
+  memcpy(base + h->offset[TONIC_COLLECTOR_OBSERVATIONS], next_observations, bytes);
+  const float* a = actions != nullptr ? actions
+                                      : reinterpret_cast<const float*>(base + h->offset[TONIC_COLLECTOR_ACTIONS]);
+  float* rewards = reinterpret_cast<float*>(base + h->offset[TONIC_COLLECTOR_REWARDS]);
+  const int A = h->A;
+  for (int64_t w = 0; w < h->W; ++w) {
+    float sum = 0.f;
+    for (int k = 0; k < A; ++k) sum += a[w * A + k] * a[w * A + k];
+    rewards[w] = -sum;
+  }
+  return TONIC_OK;
+}
+
 extern "C" int64_t tonic_collector_worker_wait(void* block, int64_t seen, double timeout_s) {
   BlockHeader* h = header_of(block);
   if (h == nullptr) return -3;

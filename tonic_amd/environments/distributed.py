@@ -169,7 +169,7 @@ class Parallel:
         return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
 
     def step(self, actions):
-        if actions is not self.block.actions:
+        if actions is not self.block.out_actions and actions is not self.block.actions:
             self.block.actions[:] = actions
         self.block.submit_actions()
         self._wait()

@@ -82,6 +82,10 @@ class SyntheticBatch:
         self._quiet = 0                  # steps taken since `lengths` was last brought up to date
         self._flags_set = False
         self.block.observations[:] = self._observe()
+        if self.pool:
+            self._synthetic_step = self.block.lib.tonic_collector_synthetic_step
+            self._block_address = self.block.address
+            self._pool_rows = [row.ctypes.data for row in self._pool]      # (bound once: hot path)
         return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
 
     def _outputs(self):
@@ -99,11 +103,17 @@ class SyntheticBatch:
 
     def step(self, actions):
         block = self.block
-        next_observations = self._observe()
-        np.copyto(block.next_observations, next_observations)
-        np.copyto(block.observations, next_observations)
-        np.einsum('ij,ij->i', actions, actions, out=block.rewards, casting='same_kind')
-        np.negative(block.rewards, out=block.rewards)
+        if self.pool and actions is block.out_actions:
+            # the agent handed the block's own actions over: the whole record is one host call
+            # (tonic_collector_synthetic_step) instead of five NumPy calls
+            self._cursor = (self._cursor + 1) % self.pool
+            self._synthetic_step(self._block_address, self._pool_rows[self._cursor], None)
+        else:
+            next_observations = self._observe()
+            np.copyto(block.next_observations, next_observations)
+            np.copyto(block.observations, next_observations)
+            np.einsum('ij,ij->i', actions, actions, out=block.rewards, casting='same_kind')
+            np.negative(block.rewards, out=block.rewards)
         if self.termination_probability <= 0 and \
                 self._quiet + 1 + self.lengths.max() < self.max_episode_steps:
             # nobody can time out at this step: the flags stay all False

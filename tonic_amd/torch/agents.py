@@ -177,6 +177,104 @@ class _Staging:
             pass
 
 
+class _NoiseAhead:
+    """The action noise of the collect loop, off its critical path (a2c.py:81 draws
+    ``Normal.sample()`` = one ``torch.randn(W, A)`` per environment step: 5 - 9 us of host time per
+    step at W = 256).  The draws of DEPTH steps are made by ONE call — the generator's stream is the
+    same: ``normal_`` fills its output with consecutive uniforms and transforms them in blocks of
+    16, so a [DEPTH * W, A] draw equals DEPTH consecutive [W, A] draws bit for bit as long as W * A
+    is a multiple of 16 — into one of two buffers; a helper thread fills the next buffer (the GIL
+    is released inside the draw) while the loop consumes the current one, 0.7 us per step for the
+    copy into the block's noise slot.  The generator runs up to 2 * DEPTH steps ahead of the noise
+    the agent has consumed; ``rewind`` puts it back where the reference's stream is (state at the
+    start of the current buffer, re-advanced by the rows consumed) before anybody else — a test
+    episode — draws from it.  Shapes the block draw does not reproduce (W * A not a multiple of
+    16), several ranks slicing a global draw, or TONIC_AMD_NOISE_AHEAD=0: one draw per step with
+    the generator state kept before it, as before."""
+
+    DEPTH = 64
+
+    def __init__(self, agent, workers, width):
+        import threading
+        self.agent, self.workers, self.width = agent, workers, width
+        n = workers * width
+        self.bulk = (n % 16 == 0 and n >= 16 and not agent.global_noise
+                     and os.environ.get('TONIC_AMD_NOISE_AHEAD', '1') != '0')
+        self.generator = getattr(agent, '_acting_generator', None)
+        self.mark = None                    # per-step mode: generator state before the last draw
+        if not self.bulk:
+            return
+        self.buffers = [torch.empty(self.DEPTH * workers, width) for _ in range(2)]
+        self.rows = [b.numpy().reshape(self.DEPTH, workers, width) for b in self.buffers]
+        self.states = [None, None]          # generator state before each buffer was drawn
+        self.current, self.taken, self.valid = 0, self.DEPTH, False
+        self.filling = False                # the helper owns buffers[current ^ 1]
+        self.request, self.ready = threading.Event(), threading.Event()
+        self.thread = threading.Thread(target=self._helper, daemon=True, name='tonic-noise-ahead')
+        self.thread.start()
+
+    def _state(self):
+        return self.generator.get_state() if self.generator is not None else torch.get_rng_state()
+
+    def _set_state(self, state):
+        if self.generator is not None:
+            self.generator.set_state(state)
+        else:
+            torch.set_rng_state(state)
+
+    def _fill(self, index):
+        self.states[index] = self._state()
+        torch.randn(self.buffers[index].shape, out=self.buffers[index], generator=self.generator)
+
+    def _helper(self):
+        while True:
+            self.request.wait()
+            self.request.clear()
+            self._fill(self.current ^ 1)
+            self.ready.set()
+
+    def _settle(self):
+        if self.filling:
+            self.ready.wait()
+            self.ready.clear()
+            self.filling = False
+
+    def take(self, out):
+        """The next step's draws -> `out` (the block's noise slot, a NumPy view [W, A])."""
+        if not self.bulk:
+            self.mark = self._state()
+            self.agent._randn(self.workers, self.width, out=torch.from_numpy(out))
+            return
+        if self.taken == self.DEPTH:
+            if self.valid:                  # the buffer drawn ahead takes over
+                self._settle()
+                self.current ^= 1
+            else:                           # first use / after a rewind: draw here, once
+                self._fill(self.current)
+                self.valid = True
+            self.taken = 0
+            self.filling = True             # and the helper draws the one after it
+            self.request.set()
+        np.copyto(out, self.rows[self.current][self.taken])
+        self.taken += 1
+
+    def rewind(self, unconsumed):
+        """Generator back to the state right after the draws of the steps the agent has executed
+        (`unconsumed`: 1 if the last `take` was for a step that has not run yet)."""
+        if not self.bulk:
+            if unconsumed and self.mark is not None:
+                self._set_state(self.mark)
+            return
+        if not self.valid:
+            return
+        self._settle()
+        consumed = self.taken - unconsumed
+        self._set_state(self.states[self.current])
+        if consumed > 0:
+            torch.randn(consumed * self.workers, self.width, generator=self.generator)
+        self.taken, self.valid = self.DEPTH, False
+
+
 class A2C(Agent):
     """Acting / storing half shared by the on-policy agents (a2c.py:20-99)."""
 
@@ -251,6 +349,11 @@ class A2C(Agent):
         if replay.buffers is None or replay.num_workers != W:
             replay._allocate(W, O, A)
         self._eps = (torch.from_numpy(block.eps[0]), torch.from_numpy(block.eps[1]))
+        noise = getattr(self, '_noise', None)
+        if noise is None or (noise.workers, noise.width) != (W, A):
+            if noise is not None:
+                noise.rewind(0)
+            self._noise = _NoiseAhead(self, W, A)
         self._slot, self._eps_ahead, self._pending, self._rollout_open = 0, False, False, False
         # update() may issue the NEXT step's launch itself (see there): whether it did, and whether
         # the caller has been handing over the block's own arrays so far
@@ -340,18 +443,19 @@ class A2C(Agent):
                 collector.begin_rollout(self.model.flat_actor.flat)
                 self._rollout_open = True
             if not self._eps_ahead:
-                self._randn(*self._eps[self._slot].shape, out=self._eps[self._slot])    # a2c.py:81
+                self._noise.take(block.eps[self._slot])                                # a2c.py:81
             collector.ppo_step(self.replay.index, self._slot, self._pending)
             self._pending = False
         slot = self._slot
-        # The next step's noise, drawn while the GPU works on this one.  The generator state
-        # before the draw is kept: test_step rewinds to it (its own draws come first in the
+        # The next step's noise goes into the other slot while the GPU works on this one (drawn
+        # ahead by _NoiseAhead; test_step rewinds the generator: its own draws come first in the
         # reference's stream order).
-        self._rng_mark = torch.get_rng_state()
-        self._randn(*self._eps[slot ^ 1].shape, out=self._eps[slot ^ 1])
+        self._noise.take(block.eps[slot ^ 1])
         self._slot, self._eps_ahead = slot ^ 1, True
         collector.wait_actions()
-        actions = block.actions.copy()
+        # An environment that lives in the block consumes the actions at once (and may take them
+        # from the block itself): it gets the block's read-only view; anybody else a fresh array.
+        actions = block.out_actions if fed else block.actions.copy()
         self._block_fed = fed
         self.last_observations = observations
         self.last_actions = actions
@@ -365,8 +469,10 @@ class A2C(Agent):
             self._speculated = False
 
     def test_step(self, observations, steps):
-        if getattr(self, '_eps_ahead', False):
-            torch.set_rng_state(self._rng_mark)
+        noise = getattr(self, '_noise', None)
+        if noise is not None:
+            self._settle()          # (a step issued ahead reads the slot: let it finish first)
+            noise.rewind(1 if self._eps_ahead else 0)
             self._eps_ahead = False
         observations = np.asarray(observations, np.float32)
         if getattr(self, '_test_workers', None) != observations.shape[0]:
