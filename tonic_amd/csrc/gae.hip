@@ -9,6 +9,9 @@
 // the reference's float32 operation order (compiled with -ffp-contract=off): returns bit-identical
 // to the reference.  With more chunks T is cut into 128- or 64-row segments that run concurrently and
 // exchange affine carries (gae_onepass_kernel below): one pass over the data, ~1e-6 relative.
+#include <atomic>
+#include <type_traits>
+
 #include "common.h"
 
 namespace tonic {
@@ -29,6 +32,7 @@ struct GaeArgs {
   double* block_sums; // [blocks, 4] = {sum, sum_sq, min, max}
   int64_t T, W;
   float gamma, lambda, one_minus_lambda;
+  int probe;          // developer probe of gae_stream_kernel (tuning key gae_stream = 2): helpers idle
 };
 
 // ---- more than one chunk: ONE pass over the data (28 B / transition) ------------------------------
@@ -340,6 +344,407 @@ __global__ __launch_bounds__(kGaeThreads) void gae_scan_kernel(GaeArgs g) {
   }
 }
 
+// ---- one chunk, few columns: the exact chain at the speed of its own dependent instructions ------
+// The reference recurrence is 7 dependent float32 operations per time row and column.  A lane =
+// column scan like gae_scan_kernel above needs W alone to fill the chip: at W = 256 (BASELINE cfg 2)
+// four waves issue every load of the 29 MB and wait for each batch of 8 rows — 620 us whatever the
+// size below W ~ 10 k, ten times the chain's own ~60 us.  Here a workgroup owns 16 columns over
+// the WHOLE time axis (W / 16 workgroups: 16 at cfg 2, 80 at cfg 5's per-GPU share) and splits the
+// work by role instead of by data:
+//   * four helper waves stream the rows through LDS, 64 rows (one chunk) per barrier: they request
+//     chunk i + 4 from HBM, turn chunk i + 2 — requested two barriers ago, so ~2 chunk times of
+//     latency cover — into the operands the chain needs ((1 - lambda) nv, 1 - resets, resets nv,
+//     1 - terminations: the reference's own intermediate roundings, utils.py:13-17) and write them
+//     in the chain's read order, and store chunk i - 1's returns / advantages and fold their
+//     float64 moments;
+//   * ONE wave walks the chain: per row 7 dependent VALU instructions + 1.5 LDS instructions
+//     (operands come as one ds_read_b128 per row + one per four rows, returns leave as one
+//     ds_write_b128 per four rows) — a single wave issues one instruction per ~5 cycles, so every
+//     instruction it does not execute is time: ~8.5 x 5 cycles x T rows = 75 us at T = 4096.
+// Returns are bit-identical to the lane = column scan (same float32 operations in the same order).
+constexpr int kStreamCols = 16, kStreamRows = 64, kStreamDepth = 4;
+constexpr int kStreamThreads = 512;      // wave 0: the chain, alone on its SIMD; waves 1, 2, 3, 5: helpers; 4, 6, 7 idle
+constexpr int kStreamGroups = kStreamRows / 4;                       // groups of four rows
+// One chunk in LDS: six planes [group of four rows][column][row in the group] — (1 - lambda) nv, r,
+// 1 - resets, resets nv, 1 - terminations, values.  A ds_read costs a lone wave ~19 cycles whatever
+// it fetches (scripts/ubench/chain.hip: 7.3 ns per row from registers, 19.5 ns with one 16-byte
+// read per row), so every operand comes as ONE 16-byte read per FOUR rows, and a plain chunk —
+// nobody resets or terminates — reads only the first two planes.
+// (a row group is 17 sixteen-byte slots apart, not 16: the loaders of gae_stream16_kernel hold
+//  4 rows x 4 columns per lane and write one slot per column — with 16 the 64 lanes of a store hit
+//  8 of the 32 banks)
+constexpr int kStreamGroupPitch = kStreamCols + 1;                  // 16-byte slots per row group
+constexpr int kStreamPlane = kStreamGroups * kStreamGroupPitch * 4; // floats
+enum StreamPlane : int { P_C1 = 0, P_R = 1, P_M1 = 2, P_C2 = 3, P_M2 = 4, P_V = 5 };
+constexpr int kStreamSlot = 6 * kStreamPlane;
+constexpr int kStreamLds = kStreamDepth * kStreamSlot + 3 * kStreamPlane +
+                          kStreamDepth * kStreamGroups;          // + ret ring, dump, plain-group flags
+
+// Barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier and
+// the fence waits for every outstanding GLOBAL access too (s_waitcnt vmcnt(0)): the helper waves
+// would then sit out a full HBM round trip per chunk for loads they only need two chunks later.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The chain wave of the streamed scans below (see gae_stream_kernel).  flag_sets: how many words per
+// row group the helpers publish (the group is plain when all of them are set).
+template <int kFlagSets>
+__device__ __forceinline__ void stream_chain(const GaeArgs& g, float* lds, float* ret_ring, int tid,
+                                             int64_t w0, int chunks) {
+  const int col = tid & (kStreamCols - 1);
+  const int64_t wc = min(w0 + col, g.W - 1);
+  float last = g.next_values[(g.T - 1) * g.W + wc];               // utils.py:11
+  const float lambda = g.lambda, gamma = g.gamma;
+  __syncthreads();                                                // chunks 0 and 1 are in LDS
+  for (int i = 0; i < chunks; ++i) {
+    const float* slot = lds + (i % kStreamDepth) * kStreamSlot;
+    const f32x4* planes = reinterpret_cast<const f32x4*>(slot) + col;            // [plane][group][col]
+    // (lanes 16 .. 63 mirror the 16 columns; their copies of the returns go to a dump area so that
+    //  the stores need no lane mask: saving / restoring exec costs three instructions per group)
+    f32x4* out = reinterpret_cast<f32x4*>(tid < kStreamCols ? ret_ring + (i & 1) * kStreamPlane
+                                                            : ret_ring + 2 * kStreamPlane) + col;
+    // one word per row group, written by the helpers: non-zero = the four rows are plain (below);
+    // lane l fetches word l & 15, the ballot makes the mask scalar
+    const int* flags = reinterpret_cast<const int*>(ret_ring + 3 * kStreamPlane) +
+                       (i % kStreamDepth) * kStreamGroups;
+    bool group_plain = flags[col] != 0;
+    if (kFlagSets == 2) group_plain = group_plain && flags[kStreamDepth * kStreamGroups + col] != 0;
+    const unsigned plain = (unsigned)__ballot(group_plain) & 0xffffu;
+    // Straight-line code per chunk — a taken branch costs a single wave more than a row of the
+    // chain (instruction fetch restarts), so the choice between the two forms of the recurrence
+    // is made ONCE per chunk of 64 rows: `walk<true>` when every row group of the chunk is plain
+    // (nobody resets or terminates: 1 - resets == 1, resets * nv == 0, 1 - terminations == 1
+    // everywhere, checked on the operands themselves — lines 15-17 of utils.py then return their
+    // input, x * 1 and x + 0: exact up to the sign of a zero).  Operands of three row groups live
+    // in registers: group g is computed from set g % 3 while the reads of group g + 2 are in
+    // flight; they are requested INSIDE the dependent chain (sched_group_barrier pins the
+    // interleaving), where an independent instruction issues in the shadow of a stall.
+    auto walk = [&](auto plain_chunk) {
+      constexpr bool kPlain = decltype(plain_chunk)::value;
+      constexpr int kPlanes = kPlain ? 2 : 5;
+      f32x4 op[3][5];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int k = 0; k < kPlanes; ++k) op[b][k] = planes[(k * kStreamGroups + b) * kStreamGroupPitch];
+      }
+#pragma unroll
+      for (int grp = 0; grp < kStreamGroups; ++grp) {
+        const int cur = grp % 3, nxt = (grp + 2) % 3;
+        if (grp + 2 < kStreamGroups) {
+#pragma unroll
+          for (int k = 0; k < kPlanes; ++k)
+            op[nxt][k] = planes[(k * kStreamGroups + grp + 2) * kStreamGroupPitch];
+        }
+        f32x4 ret;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float boot = op[cur][P_C1][p] + lambda * last;            // utils.py:13-14
+          if (!kPlain) {
+            boot = boot * op[cur][P_M1][p];                         // :15
+            boot = boot + op[cur][P_C2][p];                         // :16
+            boot = boot * op[cur][P_M2][p];                         // :17
+          }
+          last = op[cur][P_R][p] + gamma * boot;                    // :18
+          ret[p] = last;
+        }
+#pragma unroll
+        for (int k = 0; k < kPlanes; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x002, kPlain ? 6 : 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        out[grp * kStreamGroupPitch] = ret;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (plain == 0xffffu || g.probe == 1) walk(std::true_type{});   // (probe: the chain's own time)
+    else walk(std::false_type{});
+    lds_barrier();
+  }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void gae_stream_kernel(GaeArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ double red[4][kStreamThreads / 64];
+  double sum = 0.0, sum_sq = 0.0;                                   // (helpers only; the chain: neutral)
+  float lo = INFINITY, hi = -INFINITY;
+  float* ret_ring = lds + kStreamDepth * kStreamSlot;               // [2][groups][cols][4]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t w0 = (int64_t)blockIdx.x * kStreamCols;
+  const int chunks = (int)((g.T + kStreamRows - 1) / kStreamRows);
+  // position j of chunk k <-> time row T - 1 - 64 k - j (the chain runs from the end of time)
+  if (wave == 0) {
+    stream_chain<1>(g, lds, ret_ring, tid, w0, chunks);
+  } else if (wave == 4 || wave > 5) {
+    // Idle waves: waves land on SIMD (wave % 4), so wave 4 would share the chain's SIMD — every
+    // instruction it issued would take an issue slot from the chain.  These waves only keep the
+    // barrier count (1 + chunks, like everybody).
+    __syncthreads();
+    for (int i = 0; i < chunks; ++i) lds_barrier();
+  } else {
+  // -------------------------------------------------------------------- the helpers
+  const int h = (wave == 5 ? 3 : wave - 1) * 64 + (tid & 63);
+  const bool probe_idle = g.probe == 1;
+  const int col = h & (kStreamCols - 1), sub = h >> 4;              // rows 4 sub .. 4 sub + 3 of a chunk
+  const int64_t w = w0 + col, wc = min(w, g.W - 1);
+  const bool column = w < g.W;
+  // Four register sets used in turn: chunk c travels in set c % 4, requested SIX barriers before the
+  // chain needs it (four in flight + two in LDS): ~6 chunk times (8 us) of cover for HBM latency.
+  // The loop below is unrolled by four so that the set is a compile-time choice (a run-time index
+  // would turn every load into load + select, i.e. a wait).
+  struct Rows { float nv[4], rw[4], rs[4], tm[4], vl[4]; } set0, set1, set2, set3;
+  auto request = [&](Rows& s, int chunk) {
+    if (chunk >= chunks) return;                                    // uniform
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t t = max(g.T - 1 - (int64_t)kStreamRows * chunk - (4 * sub + p), (int64_t)0);
+      const int64_t at = t * g.W + wc;
+      s.nv[p] = __builtin_nontemporal_load(g.next_values + at);
+      s.rw[p] = __builtin_nontemporal_load(g.rewards + at);
+      s.rs[p] = __builtin_nontemporal_load(g.resets + at);
+      s.tm[p] = __builtin_nontemporal_load(g.terminations + at);
+      s.vl[p] = __builtin_nontemporal_load(g.values + at);
+    }
+  };
+  auto publish = [&](const Rows& s, int chunk) {
+    if (chunk >= chunks) return;
+    float* slot = lds + (chunk % kStreamDepth) * kStreamSlot;
+    f32x4 plane[6];
+    bool plain = true;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      plane[P_C1][p] = g.one_minus_lambda * s.nv[p];
+      plane[P_R][p] = s.rw[p];
+      plane[P_M1][p] = 1.f - s.rs[p];
+      plane[P_C2][p] = s.rs[p] * s.nv[p];
+      plane[P_M2][p] = 1.f - s.tm[p];
+      plane[P_V][p] = s.vl[p];
+      plain = plain && plane[P_M1][p] == 1.f && plane[P_C2][p] == 0.f && plane[P_M2][p] == 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      reinterpret_cast<f32x4*>(slot + k * kStreamPlane)[sub * kStreamGroupPitch + col] = plane[k];
+    // the 16 columns of this row group are 16 consecutive lanes of one wave
+    const unsigned long long votes = __ballot(plain);
+    if (col == 0) {
+      int* flags = reinterpret_cast<int*>(ret_ring + 3 * kStreamPlane) +
+                   (chunk % kStreamDepth) * kStreamGroups;
+      flags[sub] = ((votes >> (16 * (sub & 3))) & 0xffffull) == 0xffffull ? 1 : 0;
+    }
+  };
+  auto retire = [&](int chunk) {                                    // returns / advantages of a chunk
+    const float* slot = lds + (chunk % kStreamDepth) * kStreamSlot;
+    const f32x4 ret = reinterpret_cast<const f32x4*>(
+        ret_ring + (chunk & 1) * kStreamPlane)[sub * kStreamGroupPitch + col];
+    const f32x4 v4 = reinterpret_cast<const f32x4*>(slot + P_V * kStreamPlane)[sub * kStreamGroupPitch + col];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t t = g.T - 1 - (int64_t)kStreamRows * chunk - (4 * sub + p);
+      if (t < 0 || !column) continue;
+      const float adv = ret[p] - v4[p];                             // segments.py:42
+      __builtin_nontemporal_store(ret[p], g.returns + t * g.W + w);
+      __builtin_nontemporal_store(adv, g.advantages + t * g.W + w);
+      sum += (double)adv;
+      sum_sq += (double)adv * (double)adv;
+      lo = fminf(lo, adv);
+      hi = fmaxf(hi, adv);
+    }
+  };
+  request(set0, 0);
+  request(set1, 1);
+  publish(set0, 0);
+  publish(set1, 1);
+  request(set2, 2);
+  request(set3, 3);
+  request(set0, 4);
+  request(set1, 5);
+  __syncthreads();
+  auto turn = [&](Rows& s, int i) {             // one barrier interval of the helpers
+    if (!probe_idle) {                          // (developer probe: the chain's time alone)
+      publish(s, i + 2);                        // requested four barriers ago
+      request(s, i + 6);
+      if (i > 0) retire(i - 1);
+    }
+    lds_barrier();
+  };
+  for (int i = 0; i < chunks; i += 4) {
+    turn(set2, i);
+    if (i + 1 < chunks) turn(set3, i + 1);
+    if (i + 2 < chunks) turn(set0, i + 2);
+    if (i + 3 < chunks) turn(set1, i + 3);
+  }
+  retire(chunks - 1);
+  }
+  // block partial -> HBM (deterministic: fixed lane / wave order, no atomics)
+  sum = wave_sum(sum);
+  sum_sq = wave_sum(sum_sq);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+  }
+  if ((tid & 63) == 0) { red[0][wave] = sum; red[1][wave] = sum_sq; red[2][wave] = lo; red[3][wave] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    double s0 = 0.0, s1 = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (int i = 1; i < kStreamThreads / 64; ++i) {
+      s0 += red[0][i]; s1 += red[1][i];
+      mn = fmin(mn, red[2][i]); mx = fmax(mx, red[3][i]);
+    }
+    const int64_t b = blockIdx.x;
+    g.block_sums[4 * b] = s0;
+    g.block_sums[4 * b + 1] = s1;
+    g.block_sums[4 * b + 2] = mn;
+    g.block_sums[4 * b + 3] = mx;
+  }
+}
+
+// The same pipeline for W % 16 == 0 (every BASELINE size): the helpers move 16 bytes per lane and
+// instruction.  With one dword per lane (above) a chunk costs the CU 112 vector-memory instructions
+// of 4 x 64 bytes each — at the ~8 ns the memory pipe spends on an instruction whatever it fetches
+// that alone is ~1 us per 64 rows, as long as the chain needs.  Here a loader lane holds 4 rows x 4
+// columns of every array (20 loads per lane and chunk): ONE wave requests a whole chunk, waves 1
+// and 2 take the even and the odd chunks (two register sets each: four chunk times of cover), turn
+// them into the chain's operands and publish them, one 16-byte slot [four rows] per column and
+// plane; wave 3 retires the chain's returns (two 16-byte stores per row and column quad); wave 0
+// is the chain, alone on its SIMD.
+typedef float f32x4_row __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int kStream16Threads = 256;
+
+__global__ __launch_bounds__(kStream16Threads) void gae_stream16_kernel(GaeArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ret_ring = lds + kStreamDepth * kStreamSlot;               // [2][groups][cols][4] + dump
+  int* flag_words = reinterpret_cast<int*>(ret_ring + 3 * kStreamPlane);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * kStreamCols;
+  const int chunks = (int)((g.T + kStreamRows - 1) / kStreamRows);
+  const int cq = lane & 3, rg = lane >> 2;                          // columns 4 cq .., rows 4 rg ..
+  if (wave == 0) {
+    stream_chain<1>(g, lds, ret_ring, tid, w0, chunks);
+  } else if (wave < 3) {
+    // ------------------------------------------------------------------ the two loader waves
+    const int mine = wave - 1;                                      // parity of this wave's chunks
+    const bool idle = g.probe == 1;                                 // developer probe: barriers only
+    struct Rows { f32x4 nv[4], rw[4], rs[4], tm[4], vl[4]; } set0, set1;
+    auto request = [&](Rows& s, int chunk) {
+      if (chunk >= chunks || idle) return;                          // uniform
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int64_t t = max(g.T - 1 - (int64_t)kStreamRows * chunk - (4 * rg + p), (int64_t)0);
+        const int64_t at = t * g.W + w0 + 4 * cq;
+        auto load = [&](const float* base) {
+          const f32x4_row v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_row*>(base + at));
+          return f32x4{v[0], v[1], v[2], v[3]};
+        };
+        s.nv[p] = load(g.next_values); s.rw[p] = load(g.rewards); s.rs[p] = load(g.resets);
+        s.tm[p] = load(g.terminations); s.vl[p] = load(g.values);
+      }
+    };
+    auto publish = [&](const Rows& s, int chunk) {
+      if (chunk >= chunks || idle) return;
+      float* slot = lds + (chunk % kStreamDepth) * kStreamSlot;
+      bool plain = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                                 // column 4 cq + k: four rows per slot
+        f32x4 plane[6];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          plane[P_C1][p] = g.one_minus_lambda * s.nv[p][k];
+          plane[P_R][p] = s.rw[p][k];
+          plane[P_M1][p] = 1.f - s.rs[p][k];
+          plane[P_C2][p] = s.rs[p][k] * s.nv[p][k];
+          plane[P_M2][p] = 1.f - s.tm[p][k];
+          plane[P_V][p] = s.vl[p][k];
+          plain = plain && plane[P_M1][p] == 1.f && plane[P_C2][p] == 0.f && plane[P_M2][p] == 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          reinterpret_cast<f32x4*>(slot + q * kStreamPlane)[rg * kStreamGroupPitch + 4 * cq + k] = plane[q];
+      }
+      // the four column quads of this row group are four consecutive lanes
+      const unsigned long long votes = __ballot(plain);
+      if (cq == 0)
+        flag_words[(chunk % kStreamDepth) * kStreamGroups + rg] =
+            ((votes >> (4 * rg)) & 0xfull) == 0xfull ? 1 : 0;
+    };
+    // chunk c belongs to wave c & 1 and travels in its set (c >> 1) & 1: requested at barrier
+    // c - 6, published at c - 2, walked by the chain at c
+    request(set0, mine);
+    publish(set0, mine);
+    request(set1, mine + 2);
+    request(set0, mine + 4);
+    __syncthreads();
+    for (int i = 0; i < chunks; i += 4) {       // barriers i .. i + 3; this wave works at two of them
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i + k >= chunks) break;
+        if ((k & 1) == mine) {
+          if (k < 2) { publish(set1, i + k + 2); request(set1, i + k + 6); }
+          else { publish(set0, i + k + 2); request(set0, i + k + 6); }
+        }
+        lds_barrier();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ the retiring wave
+    double sum = 0.0, sum_sq = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
+    auto retire = [&](int chunk) {                                  // returns / advantages of a chunk
+      const float* slot = lds + (chunk % kStreamDepth) * kStreamSlot;
+      const f32x4* rets = reinterpret_cast<const f32x4*>(ret_ring + (chunk & 1) * kStreamPlane) +
+                          rg * kStreamGroupPitch + 4 * cq;
+      const f32x4* vals = reinterpret_cast<const f32x4*>(slot + P_V * kStreamPlane) +
+                          rg * kStreamGroupPitch + 4 * cq;
+      f32x4 ret[4], val[4];                                         // [column k][row p]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ret[k] = rets[k]; val[k] = vals[k]; }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int64_t t = g.T - 1 - (int64_t)kStreamRows * chunk - (4 * rg + p);
+        if (t < 0) continue;
+        f32x4_row r, a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          r[k] = ret[k][p];
+          a[k] = ret[k][p] - val[k][p];                             // segments.py:42
+          sum += (double)a[k];
+          sum_sq += (double)a[k] * (double)a[k];
+          lo = fminf(lo, a[k]);
+          hi = fmaxf(hi, a[k]);
+        }
+        const int64_t at = t * g.W + w0 + 4 * cq;
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4_row*>(g.returns + at));
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4_row*>(g.advantages + at));
+      }
+    };
+    __syncthreads();
+    for (int i = 0; i < chunks; ++i) {
+      if (i > 0 && g.probe == 0) retire(i - 1);
+      lds_barrier();
+    }
+    retire(chunks - 1);
+    // block partial -> HBM (deterministic: fixed lane order, no atomics)
+    sum = wave_sum(sum);
+    sum_sq = wave_sum(sum_sq);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if (lane == 0) {
+      const int64_t b = blockIdx.x;
+      g.block_sums[4 * b] = sum;
+      g.block_sums[4 * b + 1] = sum_sq;
+      g.block_sums[4 * b + 2] = lo;
+      g.block_sums[4 * b + 3] = hi;
+    }
+  }
+}
+
 // {mean, std, all_zero, normalise}: segments.py:43-46 and updaters/actors.py:71.
 __device__ __forceinline__ void write_adv_stats(double s0, double s1, double mn, double mx,
                                                 double count, float* adv_stats) {
@@ -402,6 +807,8 @@ __global__ __launch_bounds__(kStatsThreads) void gae_stats_kernel(const double* 
   }
 }
 
+std::atomic<int> g_gae_stream{1};   // tuning key "gae_stream": 0 keeps the lane = column scan for one chunk
+
 namespace {
 
 // chunks: 1 = the exact single-chain scan; 0 = the library's choice; > 1 = the segmented pass
@@ -413,8 +820,13 @@ bool use_onepass(int64_t T, int64_t W, int chunks) {
   return W < 65536;
 }
 
+// the exact chain for few columns: one workgroup per 16 columns (gae_stream_kernel)
+bool use_stream(int64_t T, int64_t W, int chunks) {
+  return !use_onepass(T, W, chunks) && W < 16384 && g_gae_stream.load() != 0;
+}
+
 struct GaeLayout {
-  bool onepass;
+  bool onepass, stream;
   int chunks, tiles;
   int64_t col_blocks, scan_blocks;
   int64_t off_a, off_b, off_incl, off_flags, off_sums, bytes, flag_bytes;
@@ -427,7 +839,9 @@ GaeLayout gae_layout(int64_t T, int64_t W, int chunks) {
   l.chunks = l.onepass ? (int)((T + seg_rows - 1) / seg_rows) : 1;
   l.tiles = (int)((W + 63) / 64);
   l.col_blocks = (W + kGaeThreads - 1) / kGaeThreads;
-  l.scan_blocks = l.onepass ? (int64_t)l.chunks * l.tiles : l.col_blocks;
+  l.stream = use_stream(T, W, chunks);
+  l.scan_blocks = l.onepass ? (int64_t)l.chunks * l.tiles
+                  : l.stream ? (W + kStreamCols - 1) / kStreamCols : l.col_blocks;
   const int64_t cw = round_up((int64_t)l.chunks * W * 4, 256);
   l.off_a = 0;
   l.off_b = cw;
@@ -480,6 +894,7 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
   // trace_decay` is formed in float64 first (utils.py:14), hence the double arguments.
   g.gamma = (float)discount_factor; g.lambda = (float)trace_decay;
   g.one_minus_lambda = (float)(1.0 - trace_decay);
+  g.probe = g_gae_stream.load() == 2 ? 1 : g_gae_stream.load() == 4 ? 2 : 0;   // 4: loaders only (no retiring)
   hipStream_t st = as_stream(stream);
   if (l.onepass) {
     GaeOnePass p{};
@@ -495,6 +910,23 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
     const dim3 grid((unsigned)(l.chunks * l.tiles));
     if (seg_waves(W) == 4) hipLaunchKernelGGL(gae_onepass_kernel<4>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(gae_onepass_kernel<8>, grid, dim3(512), 0, st, p);
+  } else if (l.stream) {
+    static const bool lds_ok = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(gae_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        kStreamLds * (int)sizeof(float)) == hipSuccess;
+    TONIC_REQUIRE(lds_ok, TONIC_ERR_LAUNCH, "gae_stream_kernel: %d bytes of LDS refused",
+                  kStreamLds * (int)sizeof(float));
+    static const bool lds16_ok = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(gae_stream16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        kStreamLds * (int)sizeof(float)) == hipSuccess;
+    TONIC_REQUIRE(lds16_ok, TONIC_ERR_LAUNCH, "gae_stream16_kernel: %d bytes of LDS refused",
+                  kStreamLds * (int)sizeof(float));
+    if (W % kStreamCols == 0 && g_gae_stream.load() != 3)
+      hipLaunchKernelGGL(gae_stream16_kernel, dim3((unsigned)l.scan_blocks), dim3(kStream16Threads),
+                         kStreamLds * sizeof(float), st, g);
+    else
+      hipLaunchKernelGGL(gae_stream_kernel, dim3((unsigned)l.scan_blocks), dim3(kStreamThreads),
+                         kStreamLds * sizeof(float), st, g);
   } else {
     hipLaunchKernelGGL(gae_scan_kernel, dim3((unsigned)l.col_blocks), dim3(kGaeThreads), 0, st, g);
   }

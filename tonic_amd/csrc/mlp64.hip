@@ -33,6 +33,8 @@
 #include "mlp64.h"
 #include "mlpfwd.h"
 
+namespace tonic { extern std::atomic<int> g_gae_stream; }      // gae.hip (tuning key "gae_stream")
+
 namespace tonic {
 
 constexpr int TS = 36;  // floats per row of the per-wave transpose scratch
@@ -867,6 +869,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_policy_tail = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "gae_stream") == 0) {
+    TONIC_REQUIRE(value >= 0 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
+                  "gae_stream must be 0, 1, 2 (developer probe) or 3 (dword helpers), got %d", value);
+    g_gae_stream = value;
+    return TONIC_OK;
+  }
   set_error("tonic_set_tuning: unknown key '%s'", key);
   return TONIC_ERR_INVALID_ARGUMENT;
 }
@@ -878,6 +886,7 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
   if (strcmp(key, "grad_skew") == 0) { *value = g_grad_skew; return TONIC_OK; }
   if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
+  if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
   set_error("tonic_get_tuning: unknown key '%s'", key);
   return TONIC_ERR_INVALID_ARGUMENT;
 }
