@@ -230,7 +230,7 @@ def golden_sequential(tonic):
 
 def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
             reward_scale=1.0, updates=1, batch_size=None, actor_clip=0, critic_clip=0,
-            normalizer_clip=None, algorithm='PPO', entropy_coeff=0):
+            normalizer_clip=None, algorithm='PPO', entropy_coeff=0, torso=None):
     """tonic/torch/agents/{a2c.py:41-73, ppo.py:20-67}: acts with the reference agent on
     a synthetic env for `steps` time steps so the real store/record/update path runs."""
     def builder():
@@ -252,6 +252,17 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 observation_normalizer=norms.MeanStd(clip=normalizer_clip)),
             actor_updater=tonic.torch.updaters.ClippedRatio(gradient_clip=actor_clip),
             critic_updater=tonic.torch.updaters.VRegression(gradient_clip=critic_clip))
+    if torso is not None:           # any MLP(sizes, activation) (models/utils.py:4-23)
+        sizes, activation = torso
+        models, norms = tonic.torch.models, tonic.torch.normalizers
+        act = getattr(torch.nn, activation)
+        kwargs['model'] = models.ActorCritic(
+            actor=models.Actor(encoder=models.ObservationEncoder(),
+                               torso=models.MLP(tuple(sizes), act),
+                               head=models.DetachedScaleGaussianPolicyHead()),
+            critic=models.Critic(encoder=models.ObservationEncoder(),
+                                 torso=models.MLP(tuple(sizes), act), head=models.ValueHead()),
+            observation_normalizer=norms.MeanStd())
     if algorithm == 'A2C':          # a2c.py:20-127 with StochasticPolicyGradient (actors.py:9-51)
         kwargs['actor_updater'] = tonic.torch.updaters.StochasticPolicyGradient(
             entropy_coeff=entropy_coeff)
@@ -263,6 +274,8 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
     out['entropy_coeff'] = np.float64(entropy_coeff)
     out['clips'] = np.array([actor_clip, critic_clip, normalizer_clip or 0], np.float64)
     out['batch_size'] = np.int64(batch_size or 0)
+    out['torso_sizes'] = np.array(torso[0] if torso else (64, 64), np.int64)
+    out['torso_activation'] = np.array(torso[1] if torso else 'Tanh')
     recorder = RecordingLogger()
     tonic.logger.current_logger = recorder
     observations = env.start()
@@ -309,7 +322,7 @@ def run_ppo(tonic, name, obs_dim, act_dim, workers, steps, seed, iterations=80,
                 out[pre + 'info/' + k] = np.array(v)
         recorder.records.clear()
         out[pre + 'norm/count'] = np.int64(norm.count)
-        if update == 0 and batch_size is None and not clipped and algorithm == 'PPO':
+        if update == 0 and batch_size is None and not clipped and algorithm == 'PPO' and not torso:
             out.update(first_update_probes(tonic, builder, seed, seg, iterations))
     out['act/observations'] = np.array(obs_all)
     out['act/eps'] = np.array(eps_all)
@@ -361,7 +374,7 @@ def first_update_probes(tonic, builder, seed, seg, iterations):
 
 def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32, batch=24,
                   iterations=6, seed=0, loop_steps=16, atoms=(-6.0, 6.0, 21), return_steps=1,
-                  samples=4):
+                  samples=4, torso=None):
     """tonic/torch/agents/{ddpg.py:45-112, td3.py:38-55, sac.py:40-51} driven through the
     reference agent on a synthetic env (small custom torso so the fixture stays small).  The
     first learner update is captured completely: buffer contents, the index stream of
@@ -369,6 +382,9 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
     generator state and checked), per-iteration infos, parameters before / after."""
     models, updaters = tonic.torch.models, tonic.torch.updaters
     relu = torch.nn.ReLU
+    sizes = (hidden, hidden)
+    if torso is not None:           # any MLP(sizes, activation) (models/utils.py:4-23)
+        sizes, relu = tuple(torso[0]), getattr(torch.nn, torso[1])
 
     def builder():
         return rl.SyntheticEnvironment(obs_dim, act_dim, max_episode_steps=5)
@@ -377,7 +393,7 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
     critic_head = (models.DistributionalValueHead(*atoms) if kind == 'd4pg'     # d4pg.py:15-17
                    else models.ValueHead())
     critic = models.Critic(encoder=models.ObservationActionEncoder(),
-                           torso=models.MLP((hidden, hidden), relu), head=critic_head)
+                           torso=models.MLP(sizes, relu), head=critic_head)
     if kind == 'sac':
         head = models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                          distribution=models.SquashedMultivariateNormalDiag)
@@ -389,7 +405,7 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
                  else models.ActorTwinCriticWithTargets)
     model = container(
         actor=models.Actor(encoder=models.ObservationEncoder(),
-                           torso=models.MLP((hidden, hidden), relu), head=head),
+                           torso=models.MLP(sizes, relu), head=head),
         critic=critic, observation_normalizer=tonic.torch.normalizers.MeanStd())
     replay = tonic.replays.Buffer(size=400, batch_iterations=iterations, batch_size=batch,
                                   steps_before_batches=workers * 10, steps_between_batches=workers * 10,
@@ -481,6 +497,8 @@ def run_offpolicy(tonic, name, kind, obs_dim=11, act_dim=3, workers=4, hidden=32
     out['act/actions'] = np.array(act_all)
     out['act/policy_eps'] = np.array(policy_eps)
     out['buffer_size'] = np.int64(captured['size'])
+    out['torso_sizes'] = np.array(sizes, np.int64)
+    out['torso_activation'] = np.array(torso[1] if torso else 'ReLU')
     out['cfg'] = np.array([obs_dim, act_dim, workers, hidden, batch, iterations, seed,
                            loop_steps], np.int64)
     out['atoms'] = np.array(atoms, np.float64)
@@ -521,6 +539,18 @@ def main():
             elif name == 'ppo_humanoid_wide':
                 run_ppo(tonic, 'ppo_humanoid_wide', 376, 17, workers=4, steps=12, seed=12,
                         iterations=6, updates=1)
+            elif name == 'ppo_relu256_small':
+                run_ppo(tonic, 'ppo_relu256_small', 17, 6, workers=8, steps=24, seed=21,
+                        iterations=10, updates=1, torso=((256, 256), 'ReLU'))
+            elif name == 'ppo_tanh3_small':
+                run_ppo(tonic, 'ppo_tanh3_small', 11, 3, workers=6, steps=20, seed=22,
+                        iterations=8, updates=1, torso=((96, 48, 32), 'Tanh'))
+            elif name == 'sac_uneven_small':
+                run_offpolicy(tonic, 'sac_uneven_small', 'sac', obs_dim=11, act_dim=3, workers=4,
+                              batch=24, seed=23, torso=((100, 60), 'ReLU'))
+            elif name == 'td3_elu_small':
+                run_offpolicy(tonic, 'td3_elu_small', 'td3', obs_dim=9, act_dim=4, workers=3,
+                              batch=20, seed=24, torso=((48, 40), 'ELU'))
             elif name == 'ppo_halfcheetah_w256':
                 run_ppo(tonic, 'ppo_halfcheetah_w256', 17, 6, workers=256, steps=3, seed=6,
                         updates=1)
@@ -559,6 +589,17 @@ def main():
     # TRPO (trpo.py:7-97, actors.py:115-156, optimizers.py:25-115): conjugate gradient + backtracking
     run_ppo(tonic, 'trpo_small', 17, 6, workers=8, steps=24, seed=13, iterations=6, updates=2,
             algorithm='TRPO', reward_scale=2.0)
+    # torsos outside the hand-written kernels' shapes (stock torch operators on the device):
+    # PPO with MLP((256, 256), ReLU) and with three tanh layers, SAC with unequal ReLU layers
+    # (100, 60: the (400, 300) class at fixture size), TD3 with unequal ELU layers
+    run_ppo(tonic, 'ppo_relu256_small', 17, 6, workers=8, steps=24, seed=21, iterations=10,
+            updates=1, torso=((256, 256), 'ReLU'))
+    run_ppo(tonic, 'ppo_tanh3_small', 11, 3, workers=6, steps=20, seed=22, iterations=8, updates=1,
+            torso=((96, 48, 32), 'Tanh'))
+    run_offpolicy(tonic, 'sac_uneven_small', 'sac', obs_dim=11, act_dim=3, workers=4, batch=24,
+                  seed=23, torso=((100, 60), 'ReLU'))
+    run_offpolicy(tonic, 'td3_elu_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=24,
+                  torso=((48, 40), 'ELU'))
     run_offpolicy(tonic, 'sac_small', 'sac')
     run_offpolicy(tonic, 'td3_small', 'td3', obs_dim=9, act_dim=4, workers=3, batch=20, seed=3)
     run_offpolicy(tonic, 'ddpg_small', 'ddpg', obs_dim=7, act_dim=2, workers=2, batch=16, seed=5)

@@ -37,6 +37,10 @@ CASES = {
     'SAC-wide': ('SAC', dict(shape=(40, 10))),
     'MPO-wide': ('MPO', dict(shape=(40, 10))),
     'PPO-humanoid-shapes': ('PPO', dict(shape=(376, 17))),
+    # torsos outside the hand-written kernels' shapes (any MLP(sizes, activation), run as stock
+    # torch operators on the device): PPO with a ReLU torso, SAC with the (400, 300) class
+    'PPO-relu-torso': ('PPO', dict(torso=((128, 128), 'ReLU'))),
+    'SAC-uneven-torso': ('SAC', dict(torso=((96, 64), 'ReLU'))),
     # the reference's own run is unstable here (its reward dips far below zero before it recovers):
     # held against the reference up to and including the dip (see tests/test_gpu_learning.py)
     'D4PG-wide': ('D4PG', dict(shape=(40, 10))),
@@ -95,6 +99,16 @@ def build_agent(tonic, torch_agents, case):
                                      torso=models.MLP((64, 64), torch.nn.Tanh),
                                      head=models.ValueHead()),
                 observation_normalizer=package.normalizers.MeanStd(clip=normalizer_clip))
+        if 'torso' in options:
+            sizes, activation = options['torso']
+            act = getattr(torch.nn, activation)
+            kwargs['model'] = models.ActorCritic(
+                actor=models.Actor(encoder=models.ObservationEncoder(),
+                                   torso=models.MLP(sizes, act),
+                                   head=models.DetachedScaleGaussianPolicyHead()),
+                critic=models.Critic(encoder=models.ObservationEncoder(),
+                                     torso=models.MLP(sizes, act), head=models.ValueHead()),
+                observation_normalizer=package.normalizers.MeanStd())
         return getattr(torch_agents, name)(
             replay=tonic.replays.Segment(**dict(SEGMENT, **options.get('segment', {}))), **kwargs)
     extra = dict(return_steps=3) if name in ('D4PG', 'MPO') else {}
@@ -114,6 +128,18 @@ def build_agent(tonic, torch_agents, case):
             critic=models.Critic(encoder=models.ObservationActionEncoder(),
                                  torso=models.MLP((256, 256), torch.nn.ReLU),
                                  head=models.DistributionalValueHead(*D4PG_SUPPORT)),
+            observation_normalizer=package.normalizers.MeanStd())
+    if 'torso' in options and name == 'SAC':
+        sizes, activation = options['torso']
+        act = getattr(torch.nn, activation)
+        model = models.ActorTwinCriticWithTargets(
+            actor=models.Actor(
+                encoder=models.ObservationEncoder(), torso=models.MLP(sizes, act),
+                head=models.GaussianPolicyHead(
+                    loc_activation=torch.nn.Identity,
+                    distribution=models.SquashedMultivariateNormalDiag)),
+            critic=models.Critic(encoder=models.ObservationActionEncoder(),
+                                 torso=models.MLP(sizes, act), head=models.ValueHead()),
             observation_normalizer=package.normalizers.MeanStd())
     return cls(model=model, replay=replay, exploration=noise(start_steps=START_STEPS))
 

@@ -109,11 +109,15 @@ def _agent_from_golden(g, kind):
     from tonic_amd.environments import Box
     O, A, W, hidden, B, iterations, seed, loop_steps = (int(x) for x in g['cfg'])
     relu = torch.nn.ReLU
+    sizes = (hidden, hidden)
+    if 'torso_sizes' in g.files:
+        sizes = tuple(int(x) for x in g['torso_sizes'])
+        relu = getattr(torch.nn, str(g['torso_activation']))
     critic_head = (tt.models.DistributionalValueHead(*[int(v) if i == 2 else float(v)
                                                         for i, v in enumerate(g['atoms'])])
                    if kind == 'd4pg' else tt.models.ValueHead())
     critic = tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
-                              torso=tt.models.MLP((hidden, hidden), relu), head=critic_head)
+                              torso=tt.models.MLP(sizes, relu), head=critic_head)
     if kind == 'sac':
         head = tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
                                             distribution=tt.models.SquashedMultivariateNormalDiag)
@@ -125,7 +129,7 @@ def _agent_from_golden(g, kind):
                  else tt.models.ActorTwinCriticWithTargets)
     model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
-                              torso=tt.models.MLP((hidden, hidden), relu), head=head),
+                              torso=tt.models.MLP(sizes, relu), head=head),
         critic=critic, observation_normalizer=tt.normalizers.MeanStd())
     replay = tonic_amd.replays.Buffer(size=400, batch_iterations=iterations, batch_size=B,
                                       steps_before_batches=W * 10, steps_between_batches=W * 10,
@@ -147,8 +151,11 @@ def _agent_from_golden(g, kind):
     return agent
 
 
+# (the last two: torsos outside the hand-written kernels' shapes — unequal widths, ELU — which run
+#  as stock torch operators on the device, updaters._StockTorch)
 OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg'),
-                   ('d4pg_small', 'd4pg'), ('mpo_small', 'mpo')]
+                   ('d4pg_small', 'd4pg'), ('mpo_small', 'mpo'), ('sac_uneven_small', 'sac'),
+                   ('td3_elu_small', 'td3')]
 
 
 @pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
@@ -333,7 +340,7 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                      else tt.models.ActorTwinCriticWithTargets)
         model = container(
             actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
-                                  torso=tt.models.MLP((hidden, hidden), relu), head=head),
+                                  torso=tt.models.MLP(sizes, relu), head=head),
             critic=tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
                                     torso=tt.models.MLP((hidden, hidden), relu),
                                     head=tt.models.ValueHead()),

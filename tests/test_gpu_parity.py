@@ -1113,3 +1113,75 @@ def test_wide_shapes_agent_end_to_end(lib, O, A):
                                    err_msg=key)
     np.testing.assert_allclose(agent.last_infos[1][:, 0],
                                [i['critic']['loss'] for i in infos], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------- torsos outside the hand-written kernels' shapes
+
+def _generic_ppo_agent(g, steps, iterations):
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    O, A, seed = int(g['cfg'][0]), int(g['cfg'][1]), int(g['cfg'][4])
+    sizes = tuple(int(x) for x in g['torso_sizes'])
+    activation = getattr(torch.nn, str(g['torso_activation']))
+    model = tt.models.ActorCritic(
+        actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
+                              torso=tt.models.MLP(sizes, activation),
+                              head=tt.models.DetachedScaleGaussianPolicyHead()),
+        critic=tt.models.Critic(encoder=tt.models.ObservationEncoder(),
+                                torso=tt.models.MLP(sizes, activation), head=tt.models.ValueHead()),
+        observation_normalizer=tt.normalizers.MeanStd())
+    agent = tt.agents.PPO(model=model, replay=tonic_amd.replays.Segment(
+        size=steps, batch_iterations=iterations))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=seed)
+    return agent
+
+
+@pytest.mark.parametrize('name', ['ppo_relu256_small', 'ppo_tanh3_small'])
+def test_ppo_with_any_torso_matches_reference(golden, lib, name):
+    """models/utils.py:4-23 accepts any MLP(sizes, activation): PPO with MLP((256, 256), ReLU) and
+    with three tanh layers (96, 48, 32) — shapes the hand-written kernels do not serve, run as
+    stock torch operators on the device — replays the reference agent's run: identical
+    initialisation from the seed, the acting trajectory (actions, log-probabilities), and one whole
+    learner update (returns, per-iteration statistics, KL stop, parameter deltas)."""
+    g = golden(name)
+    W, steps, iterations = int(g['cfg'][2]), int(g['cfg'][3]), int(g['cfg'][5])
+    agent = _generic_ppo_agent(g, steps, iterations)
+    assert agent.actor_updater.stock and agent.critic_updater.stock
+    state = agent.model.state_dict()
+    for key in state:       # identical initialisation from the same seed (CPU init parity)
+        np.testing.assert_array_equal(state[key].cpu().numpy(), g['init/' + key], err_msg=key)
+    # acting: the reference's observations and noise draws -> its actions and log-probabilities
+    for t in range(3):
+        eps = g['act/eps'][t]
+        agent._randn = lambda workers, width, out=None, e=eps: torch.as_tensor(e)
+        actions = agent.step(g['act/observations'][t], t * W)
+        np.testing.assert_allclose(actions, g['act/actions'][t], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(agent._out.host_view('log_probs'), g['act/log_probs'][t],
+                                   rtol=1e-5, atol=1e-5)
+    # one whole update from the reference's segment and pre-update parameters
+    agent = _generic_ppo_agent(g, steps, iterations)
+    agent.model.load_state_dict({k[len('pre0/'):]: torch.as_tensor(g[k]) for k in g.files
+                                 if k.startswith('pre0/')})
+    before = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    _fill_segment(agent, g, 0)
+    infos = agent.enqueue_update().cpu().numpy()
+    b = agent.replay.buffers
+    np.testing.assert_allclose(b['returns'].cpu().numpy(), g['u0/segment/returns'], rtol=1e-5, atol=1e-5)
+    ran = infos[0][:, 6] > 0
+    n_actor = int(g['u0/info/actor/iterations'][0])
+    assert ran.sum() == n_actor and ran[:n_actor].all(), 'KL early stop'
+    for i, key in enumerate(('loss', 'kl', 'entropy', 'clip_fraction', 'std')):
+        np.testing.assert_allclose(infos[0][:n_actor, i], g[f'u0/info/actor/{key}'],
+                                   rtol=1e-5, atol=1e-5, err_msg=key)
+    assert np.array_equal(infos[0][:n_actor, 5] > 0.5, g['u0/info/actor/stop'])
+    np.testing.assert_allclose(infos[1][:, 0], g['u0/info/critic/loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(infos[1][:, 1], g['u0/info/critic/v_mean'], rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, start in before.items():
+        if 'normalizer' in key:
+            continue
+        diff = np.abs((after[key].detach().cpu().numpy() - start) - (g['post0/' + key] - start))
+        # (float32 summation order differs between torch-CPU and the device: a few Adam steps turn
+        #  a gradient element at rounding level into a step of its own — DESIGN.md §2)
+        assert (diff <= 2e-5).mean() >= 0.999 and diff.max() <= 2e-4, (key, diff.max())

@@ -321,6 +321,25 @@ class A2C(Agent):
         draw = self._randn if want_log_probs else torch.randn
         stage_in.host_view('eps')[:] = draw(W, A).numpy()
         stage_in.upload()
+        if getattr(self.actor_updater, 'stock', False):
+            # any MLP(sizes, activation): the policy's forward as stock torch operators on the
+            # device, the sample and its log-probability as a2c.py:75-85 forms them
+            # (mapped staging hands the kernels pinned host fields: torch operators want device
+            #  tensors, and write their results back with an asynchronous copy)
+            with torch.no_grad():
+                observations = stage_in.device_view('observations').to(self.device, non_blocking=True)
+                eps = stage_in.device_view('eps').to(self.device, non_blocking=True)
+                distribution = self.model.actor(observations)
+                actions = distribution.loc + distribution.scale * eps
+                stage_out.device_view('actions').copy_(actions, non_blocking=True)
+                if want_log_probs:
+                    stage_out.device_view('log_probs').copy_(
+                        distribution.log_prob(actions).sum(dim=-1), non_blocking=True)
+            stage_out.download()
+            stage_out.mark()
+            stage_in.done = stage_out.done
+            stage_out.wait()
+            return stage_out.host_view('actions').copy()
         p = _lib.ptr
         need = self.lib.tonic_ppo_workspace_bytes(W, self.observation_size, A, 1)
         if getattr(self, '_act_workspace', None) is None or self._act_workspace.numel() < need:
@@ -365,8 +384,10 @@ class A2C(Agent):
         """Shapes beyond the fused act kernel go through the collector as well (layer-by-layer
         launches per step on the mapped block, csrc/mlpwide.hip wide_collect_step);
         TONIC_AMD_WIDE_STAGED=1 keeps the older path of staged copies and separate launches."""
-        return ((self.observation_size > 32 or self.action_size > 8)
-                and os.environ.get('TONIC_AMD_WIDE_STAGED', '0') == '1')
+        # (torsos outside the kernels' shapes act through stock torch operators, staged as well)
+        return getattr(self.actor_updater, 'stock', False) or (
+            (self.observation_size > 32 or self.action_size > 8)
+            and os.environ.get('TONIC_AMD_WIDE_STAGED', '0') == '1')
 
     def _step_staged(self, observations):
         observations = np.asarray(observations, np.float32)
@@ -792,8 +813,8 @@ class DDPG(Agent):
         W = observations.shape[0]
         io = self._policy_io.get(W)
         if io is None:
-            need = self.lib.tonic_offpolicy_workspace_bytes(W, self.observation_size,
-                                                            self.action_size, self.hidden)
+            need = 16 if self.hidden is None else self.lib.tonic_offpolicy_workspace_bytes(
+                W, self.observation_size, self.action_size, self.hidden)
             io = (_Staging([('observations', (W, self.observation_size)),
                             ('eps', (W, self.action_size))], self.device),
                   _Staging([('actions', (W, self.action_size))], self.device),
@@ -804,6 +825,26 @@ class DDPG(Agent):
         if stochastic:      # Normal.sample() of sac.py:43 == loc + scale * randn
             stage_in.host_view('eps')[:] = self._randn(W, self.action_size).numpy()
         stage_in.upload()
+        if self.hidden is None:
+            # any MLP(sizes, activation): the policy's forward as stock torch operators (updaters.
+            # _StockTorch); kind 0 tanh head, 1 squashed Gaussian (greedy: its loc), 2 Gaussian
+            with torch.no_grad():
+                out = self.model.actor(
+                    stage_in.device_view('observations').to(self.device, non_blocking=True))
+                eps = stage_in.device_view('eps').to(self.device, non_blocking=True)
+                if kind == 0:
+                    actions = out
+                elif kind == 1:
+                    normal = out._distribution
+                    actions = torch.tanh(normal.mean + normal.stddev * eps) if stochastic else out.loc
+                else:
+                    actions = out.loc + out.scale * eps if stochastic else out.loc
+                stage_out.device_view('actions').copy_(actions, non_blocking=True)
+            stage_out.download()
+            stage_out.mark()
+            stage_in.done = stage_out.done
+            stage_out.wait()
+            return stage_out.host_view('actions').copy()
         p = _lib.ptr
         _lib.check(self.lib.tonic_policy_forward(
             p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
@@ -946,7 +987,8 @@ class DDPG(Agent):
                     else:
                         self._enqueue_actor(None, None, it, n_global, targets)
 
-        if not graph or parallel.exchanging():      # collectives sit between the kernels
+        stock = self.critic_updater.stock or self.actor_updater.stock    # (autograd: no capture)
+        if not graph or stock or parallel.exchanging():      # collectives sit between the kernels
             enqueue()
             return self._infos
         if self._graph is None:
@@ -981,7 +1023,7 @@ class DDPG(Agent):
         TONIC_AMD_FUSED_ITERATION=0 keeps the split entry points (the tests compare the two)."""
         critic, actor = self.critic_updater, self.actor_updater
         kind, actor_class = self._FUSED.get(type(critic), (None, None))
-        if kind is None or type(actor) is not actor_class:
+        if kind is None or type(actor) is not actor_class or critic.stock or actor.stock:
             return None
         if os.environ.get('TONIC_AMD_FUSED_ITERATION', '1') == '0' or parallel.exchanging():
             return None

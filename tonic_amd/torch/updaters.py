@@ -35,7 +35,54 @@ def adam_hyperparameters(factory, default_lr):
     return dict(lr=float(d['lr']), betas=tuple(float(b) for b in d['betas']), eps=float(d['eps']))
 
 
-class _FlatUpdater:
+def fused_ppo_torso(torso):
+    """The hand-written PPO kernels (csrc/mlp64x16.hip, mlpwide.hip) serve the reference's default
+    torso, MLP((64, 64), Tanh); every other ``MLP(sizes, activation)`` runs the same arithmetic as
+    stock PyTorch-ROCm operators on the HBM-resident data (see `_StockTorch`)."""
+    return tuple(torso.sizes) == (64, 64) and torso.activation is torch.nn.Tanh
+
+
+class _StockTorch:
+    """Networks outside the shapes of the hand-written kernels (tonic/torch/models/utils.py:4-23
+    accepts any ``MLP(sizes, activation)``): forward, loss, autograd backward and the optimizer
+    step are stock PyTorch-ROCm operators on the device-resident Segment / Buffer batches and on
+    the very parameter views of the flat buffers — same data layout, same agent loops, same
+    statistics rows as the fused path; still no CPU path (the agents refuse to initialise without
+    a GPU).  Slower than the fused kernels and with one host read-back per step for the flags the
+    fused path keeps on the device; pinned on goldens of the reference's agents with such torsos
+    (tests/golden/ppo_relu256_small.npz, sac_uneven_small.npz)."""
+
+    stock = False
+
+    def _stock_setup(self, factory, default_lr):
+        self.stock = True
+        variables = [p for p in self.variables]
+        for p in variables:
+            p.requires_grad_(True)
+        self.torch_optimizer = (factory(variables) if factory is not None
+                                else torch.optim.Adam(variables, lr=default_lr))
+
+    def _stock_reduce(self):
+        """Several ranks (equal shards): the per-rank mean gradients are averaged."""
+        from tonic_amd import parallel
+        if not parallel.exchanging():
+            return
+        world = parallel.world_size()
+        for p in self.variables:
+            if p.grad is not None:
+                torch.distributed.all_reduce(p.grad)
+                p.grad /= world
+
+    def _stock_apply(self):
+        self._stock_reduce()
+        if self.gradient_clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.variables, self.gradient_clip)
+        self.torch_optimizer.step()
+        self.steps_enqueued += 1
+        self.state[0] += 1
+
+
+class _FlatUpdater(_StockTorch):
     stats_kind = 0
 
     def _setup(self, flat, hyper):
@@ -136,7 +183,7 @@ def enqueue_step_pair(actor, critic, n_local, adv_stats, actor_info, critic_info
     """The optimizer steps of a PPO iteration (ppo.py:33-46: actor, then critic) as ONE launch
     pair.  The gradient sums are final (all-reduced by the caller when world > 1)."""
     ha, hc = actor.hyper, critic.hyper
-    if (ha['betas'], ha['eps']) != (hc['betas'], hc['eps']):        # separate launches then
+    if actor.stock or critic.stock or (ha['betas'], ha['eps']) != (hc['betas'], hc['eps']):   # separately
         actor.enqueue_step(n_local, adv_stats, actor_info, allreduce=False)
         critic.enqueue_step(n_local, critic_info, allreduce=False)
         return
@@ -171,8 +218,62 @@ class ClippedRatio(_FlatUpdater):
         self.variables = model.flat_actor.params
         self.observation_size = model.actor.torso.model[0].in_features
         self.action_size = model.actor.head.log_scale.shape[1]
-        if tuple(model.actor.torso.sizes) != (64, 64):
-            raise NotImplementedError('the fused PPO kernels need a (64, 64) tanh torso')
+        if not fused_ppo_torso(model.actor.torso):
+            self._stock_setup(self.optimizer, 3e-4)
+
+    def _stock_grad(self, observations, actions, advantages, adv_stats, log_probs):
+        """actors.py:70-112 up to the optimizer step (ClippedRatio; ratio_clip < 0: the plain
+        policy gradient of actors.py:22-51).  `advantages` are raw: normalised here with the
+        segment's statistics like `get_full` does (segments.py:41-46)."""
+        self._stock_row = None
+        if int(self.state[1]) != 0:                      # stopped earlier in this update
+            return
+        mean, std, all_zero, normalise = (float(v) for v in adv_stats.tolist())
+        if normalise:
+            advantages = (advantages - mean) / std
+        zero = torch.zeros((), device=observations.device)
+        if all_zero:                                      # actors.py:71-75 / 23-26
+            with torch.no_grad():
+                distributions = self.model.actor(observations)
+                self._stock_row = (zero, zero, distributions.entropy().mean(), zero,
+                                   distributions.stddev.mean(), False)
+            return
+        self.torch_optimizer.zero_grad()
+        distributions = self.model.actor(observations)
+        new_log_probs = distributions.log_prob(actions).sum(dim=-1)
+        entropy = distributions.entropy().mean()
+        if self.ratio_clip >= 0:
+            ratios_1 = torch.exp(new_log_probs - log_probs)
+            surrogates_1 = advantages * ratios_1
+            ratios_2 = torch.clamp(ratios_1, 1 - self.ratio_clip, 1 + self.ratio_clip)
+            loss = -torch.min(surrogates_1, advantages * ratios_2).mean()
+        else:
+            loss = -(advantages * new_log_probs).mean()
+        if self.entropy_coeff != 0:
+            loss = loss - self.entropy_coeff * entropy
+        loss.backward()
+        with torch.no_grad():
+            kl = (log_probs - new_log_probs).mean()
+            if self.ratio_clip >= 0:
+                clipped = ratios_1.gt(1 + self.ratio_clip) | ratios_1.lt(1 - self.ratio_clip)
+                clip_fraction = clipped.float().mean()
+            else:
+                clip_fraction = zero
+            self._stock_row = (loss.detach(), kl, entropy.detach(), clip_fraction,
+                               distributions.stddev.mean().detach(), True)
+
+    def _stock_step(self, info_row):
+        if self._stock_row is None:
+            return
+        loss, kl, entropy, clip_fraction, std, step = self._stock_row
+        if step:
+            self._stock_apply()
+        stop = bool(kl > self.kl_threshold)               # actors.py:112
+        info_row[:5] = torch.stack([loss, kl, entropy, clip_fraction, std])
+        info_row[5] = float(stop)
+        info_row[6] = 1.0
+        if stop:
+            self.state[1] = 1
 
     def stop_flag_ptr(self):
         return self.state.data_ptr() + 4
@@ -181,6 +282,8 @@ class ClippedRatio(_FlatUpdater):
         self.state[1:2].zero_()
 
     def enqueue_grad(self, observations, actions, advantages, adv_stats, log_probs):
+        if self.stock:
+            return self._stock_grad(observations, actions, advantages, adv_stats, log_probs)
         n = observations.shape[0]
         ws = self._workspace_for(n)
         p = _lib.ptr
@@ -191,6 +294,8 @@ class ClippedRatio(_FlatUpdater):
             ws.numel(), _lib.current_stream()), 'tonic_ppo_actor_grad')
 
     def enqueue_step(self, n_local, adv_stats, info_row, allreduce=True):
+        if self.stock:
+            return self._stock_step(info_row)
         self._step(n_local * self.world_size, info_row, adv_stats, self.stop_flag_ptr(),
                    self.kl_threshold, self.entropy_coeff, allreduce)
 
@@ -386,8 +491,8 @@ class VRegression(_FlatUpdater):
         self.variables = model.flat_critic.params
         self.observation_size = model.critic.torso.model[0].in_features
         self.normalizer = model.observation_normalizer
-        if tuple(model.critic.torso.sizes) != (64, 64):
-            raise NotImplementedError('the fused PPO kernels need a (64, 64) tanh torso')
+        if not fused_ppo_torso(model.critic.torso):
+            self._stock_setup(self.optimizer, 1e-3)
         if self.normalizer is None:
             device = self.grad_sums.device
             self._unit_mean = torch.zeros(self.observation_size, device=device)
@@ -403,6 +508,10 @@ class VRegression(_FlatUpdater):
         return float(getattr(self.normalizer, 'clip', None) or 0.0)
 
     def forward_values(self, observations, out):
+        if self.stock:
+            with torch.no_grad():
+                out.copy_(self.model.critic(observations))
+            return out
         mean, std = self.norm_tensors()
         p = _lib.ptr
         ws = self._workspace_for(observations.shape[0])
@@ -413,6 +522,13 @@ class VRegression(_FlatUpdater):
         return out
 
     def enqueue_grad(self, observations, returns):
+        if self.stock:                                    # critics.py:18-28
+            self.torch_optimizer.zero_grad()
+            values = self.model.critic(observations)
+            loss = torch.nn.functional.mse_loss(values, returns)
+            loss.backward()
+            self._stock_row = (loss.detach(), values.detach().mean())
+            return
         n = observations.shape[0]
         ws = self._workspace_for(n)
         mean, std = self.norm_tensors()
@@ -424,6 +540,11 @@ class VRegression(_FlatUpdater):
             'tonic_value_regression_grad')
 
     def enqueue_step(self, n_local, info_row, allreduce=True):
+        if self.stock:
+            self._stock_apply()
+            info_row[:2] = torch.stack(self._stock_row)
+            info_row[6] = 1.0
+            return
         self._step(n_local * self.world_size, info_row, allreduce=allreduce)
 
     def enqueue(self, observations, returns, info_row):
@@ -453,19 +574,34 @@ def _torso_width(torso):
 class _QUpdater(_FlatUpdater):
     """Shared plumbing of the four off-policy updaters: shapes, normaliser tensors, workspace."""
 
+    # updaters whose stock-torch form exists (`_stock_enqueue`): the others keep raising for torsos
+    # outside the fused kernels
+    stock_capable = False
+
     def _shapes(self, model):
         self.model = model
         self.observation_size = model.actor.torso.model[0].in_features
-        self.hidden = _torso_width(model.actor.torso)
         critic = model.critic_1 if hasattr(model, 'critic_1') else model.critic
-        if _torso_width(critic.torso) != self.hidden:
-            raise NotImplementedError('actor and critic torsos must have the same width')
+        try:
+            self.hidden = _torso_width(model.actor.torso)
+            if _torso_width(critic.torso) != self.hidden:
+                raise NotImplementedError('actor and critic torsos must have the same width')
+        except NotImplementedError:
+            if not self.stock_capable:
+                raise
+            self.hidden = None           # any MLP(sizes, activation): stock torch operators
         head = model.actor.head
         self.sac = hasattr(head, 'scale_layer')
         layer = head.loc_layer if self.sac else head.action_layer
         self.action_size = layer[0].out_features
         self.normalizer = model.observation_normalizer
         device = model.flat_online.device
+        self.atoms = getattr(critic.head, 'num_atoms', 0)
+        if self.normalizer is None:
+            self._unit = (torch.zeros(self.observation_size, device=device),
+                          torch.ones(self.observation_size, device=device))
+        if self.hidden is None:
+            return
         # the C side walks the flat blocks by its own offsets: both must agree on the layout
         heads = 2 if self.sac else 1
         lib = _lib.load()
@@ -538,7 +674,18 @@ class TargetActionNoise:
         self.scale, self.clip = scale, clip
 
 
+def squashed_sample(distribution, eps):
+    """SquashedMultivariateNormalDiag.rsample_with_log_prob (models/actors.py:11-16) with the
+    standard-normal draws given: tanh(loc + scale * eps) and its summed log-probability."""
+    normal = distribution._distribution
+    raw = normal.mean + normal.stddev * eps
+    squashed = torch.tanh(raw)
+    log_probs = normal.log_prob(raw) - torch.log(1 - squashed ** 2 + 1e-6)
+    return squashed, log_probs.sum(dim=-1)
+
+
 class _TwinCriticQLearning(_QUpdater):
+    stock_capable = True
     stats_kind = 3          # {loss, q1 mean, q2 mean}
     default_lr = 1e-3
     kind = 0
@@ -547,11 +694,60 @@ class _TwinCriticQLearning(_QUpdater):
         self._shapes(model)
         self._setup(model.flat_critics, adam_hyperparameters(self.optimizer, self.default_lr))
         self.variables = model.flat_critics.params
+        if self.hidden is None:
+            self._stock_setup(self.optimizer, self.default_lr)
 
     def _policy_params(self):
         raise NotImplementedError
 
+    def _stock_enqueue(self, batch, eps, info_row, n_global):
+        """critics.py:68-86 (kind 2), :156-182 (kind 0), :202-235 (kind 1) as stock torch operators;
+        `eps` are the standard-normal draws the reference makes inside (target-action noise /
+        the next action's rsample), in its order.  Losses are formed as SUMS over this rank's part
+        of the batch divided by the global batch size, so that several ranks add up to the mean."""
+        from tonic_amd import parallel
+        model, B = self.model, batch['observations'].shape[0]
+        n = float(n_global or B)
+        twin = hasattr(model, 'critic_1')
+        with torch.no_grad():
+            if self.kind == 1:
+                actions, log_probs = squashed_sample(model.actor(batch['next_observations']), eps)
+            else:
+                actions = model.target_actor(batch['next_observations'])
+                if self.kind == 0:
+                    noise = self.target_action_noise
+                    actions = actions + torch.clamp(noise.scale * eps, -noise.clip, noise.clip)
+                    actions = torch.clamp(actions, -1, 1)
+            if twin:
+                next_values = torch.min(
+                    model.target_critic_1(batch['next_observations'], actions),
+                    model.target_critic_2(batch['next_observations'], actions))
+            else:
+                next_values = model.target_critic(batch['next_observations'], actions)
+            if self.kind == 1:
+                next_values = next_values - self.entropy_coeff * log_probs
+            returns = batch['rewards'] + batch['discounts'] * next_values
+        self.torch_optimizer.zero_grad()
+        critics = (model.critic_1, model.critic_2) if twin else (model.critic,)
+        values = [critic(batch['observations'], batch['actions']) for critic in critics]
+        loss = sum(((v - returns) ** 2).sum() for v in values) / n
+        loss.backward()
+        row = torch.stack([loss.detach()] + [v.detach().sum() / n for v in values])
+        if parallel.exchanging():
+            torch.distributed.all_reduce(row)
+            for p in self.variables:
+                torch.distributed.all_reduce(p.grad)
+        if self.gradient_clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.variables, self.gradient_clip)
+        self.torch_optimizer.step()
+        self.steps_enqueued += 1
+        self.state[0] += 1
+        info_row[:row.numel()] = row
+        info_row[6] = 1.0
+
     def enqueue(self, batch, eps, info_row, n_global=None):
+        if self.stock:
+            return self._stock_enqueue(batch, eps, info_row, n_global)
         B = batch['observations'].shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -627,6 +823,7 @@ class TwinCriticSoftQLearning(_TwinCriticQLearning):
 class DistributionalDeterministicQLearning(_TwinCriticQLearning):
     """critics.py:89-122 (D4PG): cross-entropy of the online critic's categorical distribution
     against the projected target distribution (tonic_distributional_q_grad)."""
+    stock_capable = False
     stats_kind = 4          # {loss}
 
     def __init__(self, optimizer=None, gradient_clip=0):
@@ -663,6 +860,7 @@ class ExpectedSARSA(_TwinCriticQLearning):
     """critics.py:238-282 (MPO): one critic regressed on r + discount * the mean target value of
     `num_samples` actions drawn from the target actor (tonic_expected_sarsa_grad)."""
     default_lr = 3e-4
+    stock_capable = False
 
     def __init__(self, num_samples=20, loss=None, optimizer=None, gradient_clip=0):
         _check_plain(loss, gradient_clip)
@@ -701,6 +899,7 @@ class ExpectedSARSA(_TwinCriticQLearning):
 
 
 class _ActorQGradient(_QUpdater):
+    stock_capable = True
     stats_kind = 4          # {loss}
     default_lr = 1e-3
     kind = 0
@@ -709,8 +908,45 @@ class _ActorQGradient(_QUpdater):
         self._shapes(model)
         self._setup(model.flat_actor, adam_hyperparameters(self.optimizer, self.default_lr))
         self.variables = model.flat_actor.params
+        if self.hidden is None:
+            self._stock_setup(self.optimizer, self.default_lr)
+
+    def _stock_enqueue(self, observations, eps, info_row, n_global, targets):
+        """actors.py:170-189 (kind 0: -mean q of `model.critic`) / :238-267 (kind 1: mean of
+        alpha log-prob - min q) as stock torch operators; only the actor's variables receive
+        gradients (the reference freezes the critics around its backward)."""
+        from tonic_amd import parallel
+        model, B = self.model, observations.shape[0]
+        n = float(n_global or B)
+        if self.kind == 1:
+            actions, log_probs = squashed_sample(model.actor(observations), eps)
+            values = torch.min(model.critic_1(observations, actions),
+                               model.critic_2(observations, actions))
+            loss = (self.entropy_coeff * log_probs - values).sum() / n
+        else:
+            critic = model.critic if hasattr(model, 'critic') else model.critic_1
+            loss = -critic(observations, model.actor(observations)).sum() / n
+        grads = torch.autograd.grad(loss, self.variables)
+        row = loss.detach().reshape(1)
+        for p, grad in zip(self.variables, grads):
+            p.grad = grad
+        if parallel.exchanging():
+            torch.distributed.all_reduce(row)
+            for p in self.variables:
+                torch.distributed.all_reduce(p.grad)
+        if self.gradient_clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.variables, self.gradient_clip)
+        self.torch_optimizer.step()
+        self.steps_enqueued += 1
+        self.state[0] += 1
+        info_row[0] = row[0]
+        info_row[6] = 1.0
+        if targets is not None:                         # update_targets right after (ddpg.py:112)
+            model.update_targets()
 
     def enqueue(self, observations, eps, info_row, n_global=None, targets=None):
+        if self.stock:
+            return self._stock_enqueue(observations, eps, info_row, n_global, targets)
         B = observations.shape[0]
         ws = self._offpolicy_workspace(B)
         mean, std = self.norm_tensors()
@@ -742,6 +978,7 @@ class DeterministicPolicyGradient(_ActorQGradient):
 class DistributionalDeterministicPolicyGradient(_ActorQGradient):
     """actors.py:192-224 (D4PG): ascend the mean of the critic's value distribution
     (tonic_distributional_actor_grad)."""
+    stock_capable = False
 
     def __init__(self, optimizer=None, gradient_clip=0):
         self.optimizer = optimizer
@@ -776,6 +1013,7 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
     log_penalty_temperature} — one flat device vector with its own Adam state (actors.py:289-316;
     like the reference, the dual optimizer is Adam(lr=1e-2) unless `actor_optimizer` is given)."""
     default_lr = 3e-4
+    stock_capable = False
 
     def __init__(self, num_samples=20, epsilon=1e-1, epsilon_penalty=1e-3, epsilon_mean=1e-3,
                  epsilon_std=1e-6, initial_log_temperature=1., initial_log_alpha_mean=1.,
