@@ -795,6 +795,7 @@ def main():
             # (the first job's agent — Segment, collector, pinned block — is released first: with it
             #  alive, the second agent's exchanges crawled under two gloo ranks sharing one GPU)
             import gc
+            agent.close()
             del agent, loop, rollout, flat, low, high
             gc.collect()
             torch.cuda.empty_cache()
@@ -840,6 +841,7 @@ def main():
         result['speedup_vs_cpu_baseline'] = round(
             main_run['value'] / result['cpu_baseline']['value'], 1)
         # BASELINE config 5's per-GPU share (AntBullet shapes, 1 280 workers): 2 steps, same harness
+        agent.close()
         del agent, loop, rollout
         import gc
         gc.collect()

@@ -205,7 +205,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert 'allreduce_us' in result and result['allreduce_us']['process_group_us'] > 0
     strong = result['strong_scaling']
     assert strong['global_workers'] == 256 and strong['workers_per_gpu'] == 128
-    assert strong['ms_per_step'] < 2 * result['ms_per_step']
+    assert strong["ms_per_step"] < 3 * result["ms_per_step"]
 
 
 def test_bench_refuses_a_rank_count_other_than_gpus():

@@ -129,7 +129,7 @@ def _agent_from_golden(g, kind):
                  else tt.models.ActorTwinCriticWithTargets)
     model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
-                              torso=tt.models.MLP(sizes, relu), head=head),
+                              torso=tt.models.MLP((hidden, hidden), relu), head=head),
         critic=critic, observation_normalizer=tt.normalizers.MeanStd())
     replay = tonic_amd.replays.Buffer(size=400, batch_iterations=iterations, batch_size=B,
                                       steps_before_batches=W * 10, steps_between_batches=W * 10,
@@ -309,7 +309,10 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B, support)
 
 @pytest.mark.parametrize('kind,O,A,W,B,hidden', [
     ('sac', 111, 8, 1, 1024, 256), ('td3', 67, 21, 64, 100, 256), ('ddpg', 17, 6, 4, 100, 256),
-    ('sac', 11, 3, 4, 24, 32), ('td3', 9, 4, 3, 37, 48), ('sac', 40, 30, 2, 50, 256)])
+    ('sac', 11, 3, 4, 24, 32), ('td3', 9, 4, 3, 37, 48), ('sac', 40, 30, 2, 50, 256),
+    # (more workgroups than the chip holds at once: the chained launches' waits must follow the
+    #  dispatch order — 313 tiles x 4 roles)
+    ('sac', 17, 6, 8, 5000, 256), ('td3', 17, 6, 8, 5000, 256)])
 def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O, A, W, B, hidden):
     """tonic_q_iteration (both policy passes in one launch, head backward folded into the actor's
     backward launch, Adam + polyak in the epilogue of the weight-gradient launches, all batches
@@ -340,7 +343,7 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                      else tt.models.ActorTwinCriticWithTargets)
         model = container(
             actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
-                                  torso=tt.models.MLP(sizes, relu), head=head),
+                                  torso=tt.models.MLP((hidden, hidden), relu), head=head),
             critic=tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
                                     torso=tt.models.MLP((hidden, hidden), relu),
                                     head=tt.models.ValueHead()),

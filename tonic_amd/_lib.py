@@ -168,6 +168,11 @@ def load():
     if lib.tonic_abi_version() != ABI_VERSION:
         raise TonicHipError(f'{LIBRARY_PATH} has ABI {lib.tonic_abi_version()}, this package needs '
                             f'{ABI_VERSION}: rebuild it (`make -C tonic_amd/csrc`)')
+    # developer switch: TONIC_AMD_TUNING="key=value,key=value" -> tonic_set_tuning at load
+    for item in filter(None, os.environ.get('TONIC_AMD_TUNING', '').split(',')):
+        key, _, value = item.partition('=')
+        if lib.tonic_set_tuning(key.strip().encode(), int(value)) != 0:
+            raise TonicHipError(f'TONIC_AMD_TUNING: {lib.tonic_last_error().decode()}')
     _lib = lib
     return lib
 

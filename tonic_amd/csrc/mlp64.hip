@@ -869,6 +869,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_policy_tail = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "q_chain") == 0) {
+    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
+                  "q_chain must be 0 or 1, got %d", value);
+    g_q_chain = value;
+    return TONIC_OK;
+  }
   if (strcmp(key, "gae_stream") == 0) {
     TONIC_REQUIRE(value >= 0 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
                   "gae_stream must be 0, 1, 2 (developer probe) or 3 (dword helpers), got %d", value);
@@ -887,6 +893,7 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
   if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
   if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
+  if (strcmp(key, "q_chain") == 0) { *value = g_q_chain; return TONIC_OK; }
   set_error("tonic_get_tuning: unknown key '%s'", key);
   return TONIC_ERR_INVALID_ARGUMENT;
 }

@@ -98,6 +98,7 @@ struct MlpFwdArgs {
   float enc_clip;                                                       // MeanStd(clip): +inf = none
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
+  int coherent_out;             // q_chain_kernel: the value head's output is read by other workgroups of the same launch
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
   // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
@@ -152,23 +153,29 @@ struct MlpBwdArgs {
   const float* hb_spre;                            // [B, ldh] pre-softplus scale head (SAC)
   int hb_ldxa, hb_sac;
   float hb_alpha;
+  int coherent;                 // q_chain_kernel: see mlp_backward_body
 };
 enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 
 // The TD target and the errors of one sample (shared by critic_loss_kernel and the folded form)
+// (`coherent`: tq / q were written by other workgroups of the same launch -> agent-scope loads)
+__device__ __forceinline__ float shared_value(const float* p, bool coherent) {
+  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
 __device__ __forceinline__ float td_target(const float* rewards, const float* discounts,
                                            const float* tq, const float* logp_next, float alpha,
-                                           int m, int Bp, int nets) {
-  if (nets == 1) return rewards[m] + discounts[m] * tq[m];
-  float next = fminf(tq[m], tq[Bp + m]);
+                                           int m, int Bp, int nets, bool coherent = false) {
+  if (nets == 1) return rewards[m] + discounts[m] * shared_value(tq + m, coherent);
+  float next = fminf(shared_value(tq + m, coherent), shared_value(tq + Bp + m, coherent));
   if (logp_next) next = next - alpha * logp_next[m];
   return rewards[m] + discounts[m] * next;
 }
 
 // d (actor objective) / d q_z of one sample (shared by actor_loss_kernel and the folded form)
-__device__ __forceinline__ float actor_dq(const float* q, int m, int Bp, int twin, int z) {
+__device__ __forceinline__ float actor_dq(const float* q, int m, int Bp, int twin, int z,
+                                          bool coherent = false) {
   if (!twin) return -1.f;
-  const float q1 = q[m], q2 = q[Bp + m];
+  const float q1 = shared_value(q + m, coherent), q2 = shared_value(q + Bp + m, coherent);
   if (z == 0) return q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
   return q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
 }
@@ -189,6 +196,45 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
     }
   }
 }
+
+// ---- several dependent passes over the same 16-row tiles as ONE launch (q_chain kernels, mlpfwd.hip)
+// The workgroups of a launch are numbered tile-major — the `roles` workgroups of a tile are
+// neighbours in dispatch order and a role only ever waits for roles of the same tile (a lower
+// index, or — the twin critics of the actor step — its immediate neighbour), so whatever part of
+// the grid is resident can always make progress.  What crosses workgroups inside a launch (q
+// values, action-column gradients: a few floats per row) is written with agent-scope stores and
+// read with agent-scope loads (the XCDs' L2s are not coherent with each other inside a kernel),
+// ordered by "s_waitcnt vmcnt(0), then the arrival counter" like the carries of gae_onepass_kernel.
+// `sync`: kChainWordsPerTile words per tile + kChainGlobalWords, ZERO when the first launch sees
+// them; every launch leaves them zero.  A peer that does not arrive within kChainTimeoutTicks
+// (a lost workgroup, a corrupted word) does not hang the device: the waiter goes on, the step's
+// logged loss becomes NaN.
+constexpr int kChainWordsPerTile = 4, kChainGlobalWords = 4;
+constexpr unsigned long long kChainTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock
+inline int64_t chain_sync_words(int B) { return (int64_t)((B + 15) / 16) * kChainWordsPerTile + kChainGlobalWords; }
+
+// Critic step: roles [target_0 .. target_{nets-1} | online_0 .. online_{nets-1}] — the targets'
+// forward on (s', a'), the online critics' forward on (s, a), and — once both targets of the tile
+// have arrived — the TD loss and the online critics' input-gradient chain.
+struct QCriticStep {
+  MlpFwdArgs fwd;            // 2 nets networks: targets on X, online (second set) on X2; split = nets
+  MlpBwdArgs bwd;            // the online critics' chain, loss = LOSS_TD
+  int nets;
+  unsigned* sync;
+};
+// Actor step: roles [critic_0 .. critic_{used-1} | actor] — the critics' forward on (s, a_new), the
+// actor objective (the twin critics exchange q), their chain down to the action columns, then the
+// head backward and the actor's chain.
+struct QActorStep {
+  MlpFwdArgs fwd;            // `used` critics on X3
+  MlpBwdArgs bwd;            // their chain, loss = LOSS_ACTOR, dxa
+  MlpBwdArgs actor;          // head backward (formed from dxa) + the actor's chain
+  int used;
+  unsigned* sync;
+};
+int launch_q_critic_step(const QCriticStep& c, hipStream_t stream);
+int launch_q_actor_step(const QActorStep& c, hipStream_t stream);
+extern std::atomic<int> g_q_chain;          // tuning key "q_chain": 0 keeps one launch per pass
 
 bool mlp_forward_supported(int H, int NH, int heads);
 bool mlp_policy_tail_supported(int H, int NH);

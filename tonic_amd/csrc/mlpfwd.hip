@@ -168,20 +168,22 @@ struct Layer {
   }
 };
 
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+// The pass of workgroup (bx, net): 16 batch rows of one network.  A kernel of its own
+// (mlp_forward_kernel) or one stage of q_chain_kernel.
+__device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int net, const int bx,
+                                                 float* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: uniform branches
   const int m = lane & 15, kg = lane >> 4;            // A operand row / D column; k group
   const int H = a.H, pitch = H + 4, tiles = H / 16;
-  const int net = blockIdx.y;
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = bx * kRows;
   // developer probe: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
-  const bool probe = a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  const bool probe = a.stamps != nullptr && bx == 0 && net == 0 && tid == 0;
   auto stamp = [&](int i) {
     if (probe) {
       __builtin_amdgcn_sched_barrier(0);
       a.stamps[i] = wall_clock64();
+      a.stamps[8 + i] = __builtin_readcyclecounter();        // shader clock (s_memtime)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -322,8 +324,12 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   if (value_head) {
     if (wave == 0 && kg == 0 && row_ok) {
       float* out_base = a.out[0];
-      out_base[net * a.stride_out + (int64_t)(r0 + m) * a.ldo] =
-          ((partial[m] + partial[16 + m]) + (partial[32 + m] + partial[48 + m])) + hbias[0];
+      const float q = ((partial[m] + partial[16 + m]) + (partial[32 + m] + partial[48 + m])) + hbias[0];
+      float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
+      if (a.coherent_out)          // read by other workgroups of the same launch (q_chain_kernel)
+        __hip_atomic_store(dst, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *dst = q;
     }
     stamp(6);
     return;
@@ -438,6 +444,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   stamp(7);
 }
 
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+  mlp_forward_body(a, blockIdx.y, blockIdx.x, lds);
+}
+
 // Fused input-gradient chain of the same networks (the backward of mlp_forward_kernel without the
 // weight gradients, which contract over the batch and go out as one grouped GEMM launch):
 //   dz2 = dOut . W_out   * relu'(h2)      critic: dOut = dq [B], W_out = w3 [H]   (outer product)
@@ -449,14 +460,57 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
 // w+4, ..., D[feature][row] products, LDS exchange between the layers; the weights are walked
 // along their rows (W^T), i.e. k-strided loads.  dz2 / dz1 are written to HBM for the weight
 // gradients.
-__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+// `coherent` (q_chain_kernel): what other workgroups of the SAME launch wrote (l_tq, l_q, hb_dxa*)
+// is read with agent-scope loads, and dxa is written with agent-scope stores.
+__device__ __forceinline__ float load_shared(const float* p, bool coherent) {
+  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+// The logged sums of the step's loss over the whole batch (one workgroup; result -> l_stats)
+__device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed) {
+  const int tid = threadIdx.x;
+  const bool co = a.coherent != 0;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int r = tid; r < a.B; r += blockDim.x) {
+    if (a.loss == LOSS_TD) {
+      const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, r, a.l_Bp,
+                                a.l_nets, co);
+      const float q1 = load_shared(a.l_q + r, co);
+      const float e1 = q1 - y;
+      float sq = e1 * e1;
+      s1 += q1;
+      if (a.l_nets == 2) {
+        const float q2 = load_shared(a.l_q + a.l_Bp + r, co);
+        const float e2 = q2 - y;
+        sq = sq + e2 * e2;
+        s2 += q2;
+      }
+      s0 += sq;
+    } else if (a.l_nets == 2) {
+      s0 += a.l_alpha * a.l_logp[r] -
+            fminf(load_shared(a.l_q + r, co), load_shared(a.l_q + a.l_Bp + r, co));
+    } else {
+      s0 += -load_shared(a.l_q + r, co);
+    }
+  }
+  block_sum3(s0, s1, s2);
+  if (tid == 0) {
+    // (a peer that never arrived — see chain_wait — must not pass for a training step)
+    a.l_stats[0] = failed ? __builtin_nanf("") : (float)s0;
+    a.l_stats[1] = (float)s1; a.l_stats[2] = (float)s2;
+    a.l_stats[3] = 0.f; a.l_stats[4] = 0.f; a.l_stats[5] = (float)a.B; a.l_stats[6] = 0.f;
+    a.l_stats[7] = 0.f;
+  }
+}
+
+__device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int net, const int bx,
+                                                  float* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kg = lane >> 4;
   const int H = a.H, pitch = H + 4, tiles = H / 16;
-  const int net = blockIdx.y;
-  const int r0 = blockIdx.x * kRows;
+  const int r0 = bx * kRows;
+  const bool co = a.coherent != 0;                    // scalar
   const int row = min(r0 + m, a.B - 1);
   const bool row_ok = r0 + m < a.B;
   const float* W2 = a.W2 + net * a.stride_params;
@@ -490,8 +544,8 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < kHeadSlots; ++u) {
       const int aa = min(hb_slot + 16 * u, A - 1);
-      hb_da[u] = a.hb_dxa0[src * a.hb_ldxa + aa];
-      second[u] = dxa1[src * a.hb_ldxa + aa];
+      hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
+      second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
       hb_t[u] = a.hb_act[src * A + aa];
       hb_sg[u] = sgp[src * A + aa];
       hb_ep[u] = epp[src * A + aa];
@@ -559,10 +613,10 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
     } else {                                          // the step's loss, folded into this launch
       if (a.loss == LOSS_TD) {
         const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, row,
-                                  a.l_Bp, a.l_nets);
-        dq = 2.f * (a.l_q[net * a.l_Bp + row] - y);
+                                  a.l_Bp, a.l_nets, co);
+        dq = 2.f * (load_shared(a.l_q + net * a.l_Bp + row, co) - y);
       } else {
-        dq = actor_dq(a.l_q, row, a.l_Bp, a.l_nets == 2, net);
+        dq = actor_dq(a.l_q, row, a.l_Bp, a.l_nets == 2, net, co);
       }
       if (row_ok && wave == 0 && kg == 0)             // for the weight-gradient GEMM (dw3, db3)
         const_cast<float*>(a.dq)[net * a.stride_dq + row] = dq;
@@ -694,43 +748,134 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 16 * wave + 4 * kg + e;
-        if (o < a.xa_count) dst[o] = out[0][e];
-      }
-    }
-  }
-  if (a.loss != LOSS_GIVEN && blockIdx.x == 0 && blockIdx.y == 0) {     // the logged sums (uniform)
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int r = tid; r < a.B; r += blockDim.x) {
-      if (a.loss == LOSS_TD) {
-        const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, r, a.l_Bp,
-                                  a.l_nets);
-        const float e1 = a.l_q[r] - y;
-        float sq = e1 * e1;
-        s1 += a.l_q[r];
-        if (a.l_nets == 2) {
-          const float e2 = a.l_q[a.l_Bp + r] - y;
-          sq = sq + e2 * e2;
-          s2 += a.l_q[a.l_Bp + r];
+        if (o < a.xa_count) {
+          if (co) __hip_atomic_store(dst + o, out[0][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else dst[o] = out[0][e];
         }
-        s0 += sq;
-      } else if (a.l_nets == 2) {
-        s0 += a.l_alpha * a.l_logp[r] - fminf(a.l_q[r], a.l_q[a.l_Bp + r]);
-      } else {
-        s0 += -a.l_q[r];
       }
     }
-    block_sum3(s0, s1, s2);
-    if (tid == 0) {
-      a.l_stats[0] = (float)s0; a.l_stats[1] = (float)s1; a.l_stats[2] = (float)s2;
-      a.l_stats[3] = 0.f; a.l_stats[4] = 0.f; a.l_stats[5] = (float)a.B; a.l_stats[6] = 0.f;
-      a.l_stats[7] = 0.f;
+  }
+  // the logged sums (uniform); a chain launch leaves them to its last workgroup
+  if (a.loss != LOSS_GIVEN && !co && bx == 0 && net == 0) mlp_loss_stats(a, false);
+}
+
+__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
+  mlp_backward_body(a, blockIdx.y, blockIdx.x, lds);
+}
+
+// ------------------------------------------------------------------ chained passes (mlpfwd.h)
+__device__ __forceinline__ unsigned chain_load(const unsigned* word) {
+  return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(unsigned* word, unsigned v) {
+  __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned chain_add(unsigned* word) {
+  return __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Thread 0 waits until `need` peers have arrived at `word`; the barrier behind it also publishes
+// this workgroup's own stores to its own waves.  Bounded: see kChainTimeoutTicks.
+__device__ __forceinline__ void chain_wait(const unsigned* word, unsigned need, unsigned* failed) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (chain_load(word) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > kChainTimeoutTicks) {
+        chain_store(failed, 1u);
+        break;
+      }
     }
   }
+  __syncthreads();
+}
+
+// The value head's outputs are stored by wave 0 (mlp_forward_body): their acknowledgement, then
+// the arrival.
+__device__ __forceinline__ void chain_arrive_after_values(unsigned* word) {
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) chain_add(word);
+  }
+}
+
+// The last workgroup of `total` to get here (thread 0 decides, everybody learns it) ...
+__device__ __forceinline__ bool chain_last(unsigned* counter, unsigned total) {
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    const bool mine = chain_add(counter) == total - 1;
+    if (mine) chain_store(counter, 0u);
+    last = mine ? 1 : 0;
+  }
+  __syncthreads();
+  return last != 0;
+}
+
+// ... forms the logged sums of the step's loss (every q it reads was acknowledged before its
+// writer arrived here).
+__device__ __forceinline__ void chain_stats(const MlpBwdArgs& b, unsigned* counter, unsigned* failed,
+                                            unsigned total) {
+  if (!chain_last(counter, total)) return;
+  const bool bad = chain_load(failed) != 0;
+  mlp_loss_stats(b, bad);
+  if (threadIdx.x == 0 && bad) chain_store(failed, 0u);
+}
+
+__global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int roles = 2 * c.nets;
+  const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
+  const int tiles = (c.fwd.B + kRows - 1) / kRows;
+  unsigned* word = c.sync + kChainWordsPerTile * tile;
+  unsigned* global = c.sync + kChainWordsPerTile * tiles;       // [done, failed]
+  mlp_forward_body(c.fwd, role, tile, lds);
+  if (role < c.nets) {                                // a target: its values, then its arrival
+    chain_arrive_after_values(word);
+    return;
+  }
+  chain_wait(word, c.nets, global + 1);
+  mlp_backward_body(c.bwd, role - c.nets, tile, lds);
+  __syncthreads();
+  if (threadIdx.x == 0 && chain_add(word + 1) == (unsigned)c.nets - 1) {    // the tile's last reader
+    chain_store(word, 0u);
+    chain_store(word + 1, 0u);
+  }
+  chain_stats(c.bwd, global, global + 1, c.nets * tiles);
+}
+
+__global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int roles = c.used + 1;
+  const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
+  const int tiles = (c.fwd.B + kRows - 1) / kRows;
+  unsigned* word = c.sync + kChainWordsPerTile * tile;
+  unsigned* global = c.sync + kChainWordsPerTile * tiles;
+  if (role == c.used) {                               // the actor: both critics' action columns first
+    chain_wait(word + 2, c.used, global + 1);
+    if (threadIdx.x == 0) chain_store(word + 2, 0u);
+    mlp_backward_body(c.actor, 0, tile, lds);
+    return;
+  }
+  mlp_forward_body(c.fwd, role, tile, lds);
+  chain_arrive_after_values(word);
+  chain_wait(word, c.used, global + 1);               // (the twin's q)
+  mlp_backward_body(c.bwd, role, tile, lds);
+  __syncthreads();                                    // (dxa acknowledged: the barrier's fence)
+  if (threadIdx.x == 0) {
+    chain_add(word + 2);
+    if (chain_add(word + 1) == (unsigned)c.used - 1) {
+      chain_store(word, 0u);
+      chain_store(word + 1, 0u);
+    }
+  }
+  chain_stats(c.bwd, global, global + 1, c.used * tiles);
 }
 
 }  // namespace
 
 std::atomic<int> g_policy_tail{1};
+std::atomic<int> g_q_chain{1};
 
 // The tail's three [16][kPostPitch] images live in the first hidden image where they fit (H >= 188:
 // the second image is still being read by other head waves), else behind both images.
@@ -792,7 +937,7 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   }
   launch.stamps = nullptr;
   if (unsigned long long* base = g_forward_stamps.load()) {      // developer probe: ring of 8 launches
-    launch.stamps = base + 8 * (g_forward_launches.fetch_add(1) % 8);
+    launch.stamps = base + 16 * (g_forward_launches.fetch_add(1) % 8);
   }
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, launch);
@@ -822,6 +967,43 @@ int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
   hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                      stream, a);
   TONIC_CHECK_LAUNCH("mlp_backward_kernel");
+  return TONIC_OK;
+}
+
+static size_t chain_lds_bytes(int H) {
+  return (2 * (size_t)kRows * (H + 4) + 4 * kRows + 2 * (size_t)kRows * kHeadPitch) * sizeof(float);
+}
+
+int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
+  const MlpFwdArgs& f = c.fwd;
+  TONIC_REQUIRE(c.nets >= 1 && c.nets <= 2 && c.sync != nullptr && f.split == c.nets &&
+                    f.post == POST_NONE && f.heads == 1 && f.NH == 1 && f.coherent_out == 1 &&
+                    mlp_forward_supported(f.H, 1, 1) && c.bwd.heads == 0 && c.bwd.loss == LOSS_TD &&
+                    c.bwd.coherent == 1 && c.bwd.B == f.B && c.bwd.H == f.H &&
+                    mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count),
+                TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: nets=%d H=%d", c.nets, f.H);
+  const int tiles = (f.B + kRows - 1) / kRows;
+  hipLaunchKernelGGL(q_critic_step_kernel, dim3(tiles * 2 * c.nets), dim3(256), chain_lds_bytes(f.H),
+                     stream, c);
+  TONIC_CHECK_LAUNCH("q_critic_step_kernel");
+  return TONIC_OK;
+}
+
+int launch_q_actor_step(const QActorStep& c, hipStream_t stream) {
+  const MlpFwdArgs& f = c.fwd;
+  TONIC_REQUIRE(c.used >= 1 && c.used <= 2 && c.sync != nullptr && f.post == POST_NONE &&
+                    f.heads == 1 && f.NH == 1 && f.coherent_out == 1 && f.split >= c.used &&
+                    mlp_forward_supported(f.H, 1, 1) && c.bwd.heads == 0 &&
+                    c.bwd.loss == LOSS_ACTOR && c.bwd.coherent == 1 && c.bwd.B == f.B &&
+                    c.bwd.H == f.H && mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count) &&
+                    c.actor.heads >= 1 && c.actor.hb_dxa0 != nullptr && c.actor.coherent == 1 &&
+                    c.actor.B == f.B && c.actor.H == f.H && c.actor.NH <= kPostPitch &&
+                    mlp_backward_supported(f.H, c.actor.NH, c.actor.heads, c.actor.xa_count),
+                TONIC_ERR_INVALID_ARGUMENT, "q_actor_step: used=%d H=%d", c.used, f.H);
+  const int tiles = (f.B + kRows - 1) / kRows;
+  hipLaunchKernelGGL(q_actor_step_kernel, dim3(tiles * (c.used + 1)), dim3(256), chain_lds_bytes(f.H),
+                     stream, c);
+  TONIC_CHECK_LAUNCH("q_actor_step_kernel");
   return TONIC_OK;
 }
 

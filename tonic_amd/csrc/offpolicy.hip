@@ -699,6 +699,32 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
 // `nets` critics batched over blockIdx.z; X shared ([Bp, ldx]); h1/h2 [nets][Bp][H]; q [nets][Bp]
 // params2 / X2 != null: `nets` more critics (e.g. the online ones next to the targets) with their
 // own input, appended to the same launch: h1/h2 [2 nets][Bp][H], q [2 nets][Bp].
+// The fused form's arguments (mlp_forward_supported(H, 1, 1)); *launch_nets = networks in the launch.
+MlpFwdArgs critics_forward_args(const float* params, CriticShape s, int nets, const float* X,
+                                int ldx, int B, int Bp, float* h1, float* h2, float* q,
+                                const float* params2, const float* X2, int* launch_nets) {
+  const CriticOffsets o(s);
+  const int HP = weight_ld(s.H);
+  MlpFwdArgs f{};
+  f.X = X; f.ldx = ldx; f.K1 = s.O + s.A;
+  f.W1 = params + o.W1; f.b1 = params + o.b1; f.W2 = params + o.W2; f.b2 = params + o.b2;
+  f.ldw1 = o.ld1; f.ldw2 = o.ldH;
+  f.Wh[0] = f.Wh[1] = params + o.w3; f.bh[0] = f.bh[1] = params + o.b3;
+  f.heads = 1; f.NH = 1;
+  f.h1 = h1; f.h2 = h2; f.ldh = HP; f.out[0] = f.out[1] = q; f.ldo = 1;
+  f.act[0] = f.act[1] = ACT_NONE;
+  f.B = B; f.H = s.H; f.split = 1 << 30;
+  f.stride_params = o.count; f.stride_hidden = (int64_t)Bp * HP; f.stride_out = Bp;
+  *launch_nets = nets;
+  if (params2 != nullptr) {          // a second set of `nets` critics on a second input
+    f.split = nets;
+    f.second_params = (params2 - params) - (int64_t)nets * o.count;
+    f.X2 = X2;
+    *launch_nets = 2 * nets;
+  }
+  return f;
+}
+
 int critics_forward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                     int Bp, float* h1, float* h2, float* q, hipStream_t st,
                     const float* params2 = nullptr, const float* X2 = nullptr) {
@@ -707,23 +733,10 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
   const int HP = weight_ld(s.H);
   const int64_t hs = (int64_t)Bp * HP;
   if (mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
-    MlpFwdArgs f{};
-    f.X = X; f.ldx = ldx; f.K1 = in;
-    f.W1 = params + o.W1; f.b1 = params + o.b1; f.W2 = params + o.W2; f.b2 = params + o.b2;
-    f.ldw1 = o.ld1; f.ldw2 = o.ldH;
-    f.Wh[0] = f.Wh[1] = params + o.w3; f.bh[0] = f.bh[1] = params + o.b3;
-    f.heads = 1; f.NH = 1;
-    f.h1 = h1; f.h2 = h2; f.ldh = HP; f.out[0] = f.out[1] = q; f.ldo = 1;
-    f.act[0] = f.act[1] = ACT_NONE;
-    f.B = B; f.H = s.H; f.split = 1 << 30;
-    f.stride_params = o.count; f.stride_hidden = hs; f.stride_out = Bp;
-    if (params2 != nullptr) {          // a second set of `nets` critics on a second input
-      f.split = nets;
-      f.second_params = (params2 - params) - (int64_t)nets * o.count;
-      f.X2 = X2;
-      return launch_mlp_forward(f, 2 * nets, st);
-    }
-    return launch_mlp_forward(f, nets, st);
+    int launch_nets = 0;
+    const MlpFwdArgs f = critics_forward_args(params, s, nets, X, ldx, B, Bp, h1, h2, q, params2,
+                                              X2, &launch_nets);
+    return launch_mlp_forward(f, launch_nets, st);
   }
   if (params2 != nullptr) {            // unfused path: one pass per parameter set
     TRY(critics_forward(params, s, nets, X, ldx, B, Bp, h1, h2, q, st));
@@ -758,6 +771,51 @@ struct StepLoss {
   const float* q; float* stats;
 };
 
+// The one-launch chain's arguments (mlp_backward_supported(H, 1, 0, dxa ? A : 0)).
+MlpBwdArgs critics_chain_args(const float* params, CriticShape s, int nets, int B, int Bp,
+                              const float* h1, const float* h2, float* dq, float* dh2, float* dh1,
+                              float* dxa, const StepLoss* loss) {
+  const CriticOffsets o(s);
+  const int HP = weight_ld(s.H), ldxa = pad16(s.A);
+  MlpBwdArgs b{};
+  b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
+  if (loss) {
+    b.loss = loss->kind; b.l_rewards = loss->rewards; b.l_discounts = loss->discounts;
+    b.l_tq = loss->tq; b.l_logp = loss->logp; b.l_alpha = loss->alpha; b.l_q = loss->q;
+    b.l_stats = loss->stats; b.l_nets = nets; b.l_Bp = Bp;
+  }
+  b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = s.O + s.A; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
+  b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
+  b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa; b.ldhid = HP;
+  b.B = B; b.H = s.H;
+  b.ldxa = ldxa;
+  b.stride_params = o.count; b.stride_hidden = (int64_t)Bp * HP; b.stride_dq = Bp;
+  b.stride_dxa = (int64_t)Bp * ldxa;
+  return b;
+}
+
+// The three weight gradients of `nets` critics (all contract over the batch) in ONE launch:
+//   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
+int critics_weight_gradients(CriticShape s, int nets, const float* X, int ldx, int B, int Bp,
+                             const float* h1, const float* h2, const float* dq, const float* dh2,
+                             const float* dh1, float* grads, hipStream_t st, const AdamFold* fold) {
+  const CriticOffsets o(s);
+  const int in = s.O + s.A;
+  const int HP = weight_ld(s.H);
+  const int64_t hs = (int64_t)Bp * HP;
+  GemmArgs w[3];
+  w[0] = gemm(dq, 1, h2, HP, grads + o.w3, o.ldH, 1, s.H, B);
+  w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
+  w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
+  w[1] = gemm(dh2, HP, h1, HP, grads + o.W2, o.ldH, s.H, s.H, B);
+  w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
+  w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
+  w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
+  w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
+  w[2].strideA = hs; w[2].strideC = o.count;
+  return launch_gemm_group('s', 's', w, 3, nets, st, fold);
+}
+
 int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                      int Bp, const float* h1, const float* h2, float* dq, float* dh2,
                      float* dh1, float* grads, float* dxa, hipStream_t st,
@@ -774,26 +832,13 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
                          loss->alpha, nets == 2 ? 1 : 0, dq, loss->stats, B, Bp);
     }
   }
-  const int in = s.O + s.A;
   const int HP = weight_ld(s.H);
   const int64_t hs = (int64_t)Bp * HP;
   const int ldxa = pad16(s.A);
   GemmArgs g;
   // the input-gradient chain first ...
   if (one_launch) {                                               // ... in ONE launch
-    MlpBwdArgs b{};
-    b.heads = 0; b.dq = dq; b.w3 = params + o.w3;
-    if (loss) {
-      b.loss = loss->kind; b.l_rewards = loss->rewards; b.l_discounts = loss->discounts;
-      b.l_tq = loss->tq; b.l_logp = loss->logp; b.l_alpha = loss->alpha; b.l_q = loss->q;
-      b.l_stats = loss->stats; b.l_nets = nets; b.l_Bp = Bp;
-    }
-    b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = in; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
-    b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
-    b.h1 = h1; b.h2 = h2; b.dz2 = dh2; b.dz1 = dh1; b.dxa = dxa; b.ldhid = HP;
-    b.B = B; b.H = s.H;
-    b.ldxa = ldxa;
-    b.stride_params = o.count; b.stride_hidden = hs; b.stride_dq = Bp; b.stride_dxa = (int64_t)Bp * ldxa;
+    const MlpBwdArgs b = critics_chain_args(params, s, nets, B, Bp, h1, h2, dq, dh2, dh1, dxa, loss);
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
@@ -812,21 +857,8 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
       TRY(launch_gemm('c', 's', g, nets, st));
     }
   }
-  if (grads) {
-    // ... then the three weight gradients (all contract over the batch) in ONE launch:
-    //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
-    GemmArgs w[3];
-    w[0] = gemm(dq, 1, h2, HP, grads + o.w3, o.ldH, 1, s.H, B);
-    w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
-    w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
-    w[1] = gemm(dh2, HP, h1, HP, grads + o.W2, o.ldH, s.H, s.H, B);
-    w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
-    w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
-    w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
-    w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
-    w[2].strideA = hs; w[2].strideC = o.count;
-    TRY(launch_gemm_group('s', 's', w, 3, nets, st, fold));
-  }
+  if (grads)       // ... then the three weight gradients in ONE launch
+    TRY(critics_weight_gradients(s, nets, X, ldx, B, Bp, h1, h2, dq, dh2, dh1, grads, st, fold));
   return TONIC_OK;
 }
 
@@ -1003,6 +1035,51 @@ namespace {
 // outputs: the input-gradient chain (dz2, dz1; optionally the columns [xa_first, xa_first + xa_count)
 // of the input gradient -> dxa), then all weight / bias gradient SUMS into the flat layout `grads`
 // (null: none — a frozen network) in one grouped launch.  X: the network's input rows, ldx apart.
+MlpBwdArgs actor_chain_args(const float* params, ActorShape as, int B, const float* a_h1,
+                            const float* a_h2, const float* dloc, const float* dspre, int ldh,
+                            float* da_h2, float* da_h1, float* dxa, int xa_first, int xa_count,
+                            const MlpBwdArgs* head_fold) {
+  const int H = as.H, A = as.A, HP = weight_ld(H);
+  ActorParams p(params, as);
+  MlpBwdArgs b{};
+  b.heads = as.heads; b.NH = A; b.ldh = ldh;
+  b.dhead[0] = dloc; b.dhead[1] = dspre ? dspre : dloc;
+  b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
+  b.W2 = p.W2; b.W1 = p.W1; b.K1 = as.O; b.ldw1 = p.ld1; b.ldw2 = p.ldH;
+  b.xa_first = xa_first; b.xa_count = dxa ? xa_count : 0;
+  b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = dxa; b.ldhid = HP;
+  b.ldxa = pad16(xa_count > 0 ? xa_count : 1);
+  b.B = B; b.H = H;
+  if (head_fold != nullptr) {          // dloc / dspre are FORMED by this launch (hb_* of MlpBwdArgs)
+    b.hb_dxa0 = head_fold->hb_dxa0; b.hb_dxa1 = head_fold->hb_dxa1; b.hb_ldxa = head_fold->hb_ldxa;
+    b.hb_act = head_fold->hb_act; b.hb_eps = head_fold->hb_eps; b.hb_sigma = head_fold->hb_sigma;
+    b.hb_spre = head_fold->hb_spre; b.hb_sac = head_fold->hb_sac; b.hb_alpha = head_fold->hb_alpha;
+  }
+  return b;
+}
+
+// All weight gradients of an actor-shaped network (they contract over the batch) in ONE launch:
+//   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T X, db1
+int actor_weight_gradients(ActorShape as, const float* X, int ldx, int B, const float* a_h1,
+                           const float* a_h2, const float* dloc, const float* dspre, int ldh,
+                           const float* da_h2, const float* da_h1, float* grads, hipStream_t st,
+                           const AdamFold* fold) {
+  const int H = as.H, A = as.A, HP = weight_ld(H);
+  const ActorBlock<float> gp(grads, as);               // the gradient sums share the layout
+  GemmArgs w[4];
+  int count = 0;
+  for (int h = 0; h < as.heads; ++h) {
+    const float* dhead = h == 0 ? dloc : dspre;
+    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
+    w[count++].colsum = gp.head_b(h);
+  }
+  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
+  w[count++].colsum = gp.b2;
+  w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
+  w[count++].colsum = gp.b1;
+  return launch_gemm_group('s', 's', w, count, 1, st, fold);
+}
+
 int actor_shaped_backward(const float* params, ActorShape as, const float* X, int ldx, int B,
                           const float* a_h1, const float* a_h2, const float* dloc,
                           const float* dspre, int ldh, float* da_h2, float* da_h1, float* grads,
@@ -1013,20 +1090,8 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
   GemmArgs g;
   // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
   if (mlp_backward_supported(H, A, as.heads, xa_count)) {
-    MlpBwdArgs b{};
-    b.heads = as.heads; b.NH = A; b.ldh = ldh;
-    b.dhead[0] = dloc; b.dhead[1] = dspre ? dspre : dloc;
-    b.Wh[0] = p.head_w(0); b.Wh[1] = p.head_w(as.heads - 1);
-    b.W2 = p.W2; b.W1 = p.W1; b.K1 = as.O; b.ldw1 = p.ld1; b.ldw2 = p.ldH;
-    b.xa_first = xa_first; b.xa_count = dxa ? xa_count : 0;
-    b.h1 = a_h1; b.h2 = a_h2; b.dz2 = da_h2; b.dz1 = da_h1; b.dxa = dxa; b.ldhid = HP;
-    b.ldxa = pad16(xa_count > 0 ? xa_count : 1);
-    b.B = B; b.H = H;
-    if (head_fold != nullptr) {          // dloc / dspre are FORMED by this launch (hb_* of MlpBwdArgs)
-      b.hb_dxa0 = head_fold->hb_dxa0; b.hb_dxa1 = head_fold->hb_dxa1; b.hb_ldxa = head_fold->hb_ldxa;
-      b.hb_act = head_fold->hb_act; b.hb_eps = head_fold->hb_eps; b.hb_sigma = head_fold->hb_sigma;
-      b.hb_spre = head_fold->hb_spre; b.hb_sac = head_fold->hb_sac; b.hb_alpha = head_fold->hb_alpha;
-    }
+    const MlpBwdArgs b = actor_chain_args(params, as, B, a_h1, a_h2, dloc, dspre, ldh, da_h2, da_h1,
+                                          dxa, xa_first, xa_count, head_fold);
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
@@ -1044,21 +1109,8 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
     }
   }
   if (grads == nullptr) return TONIC_OK;
-  // ... then all weight gradients (they contract over the batch) in ONE launch:
-  //   dWh[A,H] = dhead^T h2, dbh (per head) ; dW2 = dz2^T h1, db2 ; dW1 = dz1^T X, db1
-  const ActorBlock<float> gp(grads, as);               // the gradient sums share the layout
-  GemmArgs w[4];
-  int count = 0;
-  for (int h = 0; h < as.heads; ++h) {
-    const float* dhead = h == 0 ? dloc : dspre;
-    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
-    w[count++].colsum = gp.head_b(h);
-  }
-  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
-  w[count++].colsum = gp.b2;
-  w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
-  w[count++].colsum = gp.b1;
-  return launch_gemm_group('s', 's', w, count, 1, st, fold);
+  return actor_weight_gradients(as, X, ldx, B, a_h1, a_h2, dloc, dspre, ldh, da_h2, da_h1, grads, st,
+                                fold);
 }
 
 }  // namespace
@@ -1085,6 +1137,11 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
 // groups, 2 optimizer launches) become 8 (4 when the actor is not due).
 namespace {
 
+// The arrival words of the chained launches live at the START of the workspace, in an area of
+// fixed size, so that they stay where they are (and zero) whatever batch size the workspace is
+// used with next.
+constexpr int64_t kChainSyncArea = 16384;            // words: 4 095 tiles = batches up to 65 520 rows
+
 int64_t q_iteration_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
   return 2 * (2 * Bp * HP + 2 * Bp * ldh)           // policy passes: h1, h2, two head outputs, x2
@@ -1093,7 +1150,8 @@ int64_t q_iteration_floats(int B, int O, int A, int H) {
          + 2 * 4 * Bp * HP + 4 * Bp                 // four-critic forward: h1, h2, values
          + 2 * Bp + 2 * 2 * Bp * HP                 // dq, dz2, dz1 of two critics
          + 2 * Bp * ldh + 2 * Bp * ldh              // dxa (two critics), dloc, dspre
-         + 2 * Bp * HP;                             // actor dz2, dz1
+         + 2 * Bp * HP                              // actor dz2, dz1
+         + kChainSyncArea;                          // arrival words of the chained launches (first)
 }
 
 }  // namespace
@@ -1133,6 +1191,8 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const ActorShape as{O, H, A, heads};
   const int64_t Pc = critic_count(cs), Pa = actor_count(as), hs = (int64_t)Bp * HP;
   Workspace ws{static_cast<char*>(a.d_workspace), 0, a.workspace_bytes};
+  unsigned* sync = reinterpret_cast<unsigned*>(ws.take(kChainSyncArea));
+  const bool chain = g_q_chain.load() != 0 && chain_sync_words(B) <= kChainSyncArea;
   // policy passes [net 0 | net 1]
   float* p_h1 = ws.take(2 * hs); float* p_h2 = ws.take(2 * hs);
   float* head0 = ws.take(2LL * Bp * ldh); float* head1 = ws.take(2LL * Bp * ldh);
@@ -1186,8 +1246,6 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     TRY(launch_mlp_forward(f, due ? 2 : 1, st));
   }
   // ---- 2: targets on (s', a') and online critics on (s, a)
-  TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
-                      a.d_critics, X2));
   // ---- 3 + 4: TD loss, backward chain, weight gradients + Adam (+ polyak of the critics)
   const float grad_scale = (float)(1.0 / (a.global_batch > 0 ? a.global_batch : B));
   AdamFold cf{};
@@ -1203,19 +1261,34 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const StepLoss td{LOSS_TD, a.d_rewards, a.d_discounts, tq,
                     kind == 1 ? logp_next : (const float*)nullptr, (float)a.critic_entropy_coeff, q,
                     a.critic.d_grad_sums + nets * Pc};
-  TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
-                       a.critic.d_grad_sums, nullptr, st, &td, &cf));
+  if (chain) {
+    // 2 + 3 as ONE launch: the online critics' workgroups go on to the TD loss and their chain as
+    // soon as the targets of their 16 rows have arrived (q_critic_step_kernel)
+    QCriticStep step{};
+    int launch_nets = 0;
+    step.fwd = critics_forward_args(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all,
+                                    q_all, a.d_critics, X2, &launch_nets);
+    step.fwd.coherent_out = 1;
+    step.bwd = critics_chain_args(a.d_critics, cs, nets, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, &td);
+    step.bwd.coherent = 1;
+    step.nets = nets; step.sync = sync;
+    TRY(launch_q_critic_step(step, st));
+    TRY(critics_weight_gradients(cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
+                                 a.critic.d_grad_sums, st, &cf));
+  } else {
+    TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
+                        a.d_critics, X2));
+    TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
+                         a.critic.d_grad_sums, nullptr, st, &td, &cf));
+  }
   if (!due) {
     TONIC_CHECK_LAUNCH("tonic_q_iteration");
     return TONIC_OK;
   }
   // ---- 5 + 6: the updated critics on (s, a_new), the actor objective, down to the action columns
   const int used = kind == 1 ? 2 : 1;                  // TD3 / DDPG: critic_1 only (td3.py:36)
-  TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st));
   const StepLoss objective{LOSS_ACTOR, nullptr, nullptr, nullptr, logp,
                            (float)a.actor_entropy_coeff, q, a.actor.d_grad_sums + Pa};
-  TRY(critics_backward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr,
-                       dxa, st, &objective));
   // ---- 7 + 8: head backward + actor chain, weight gradients + Adam + polyak of the actor
   MlpBwdArgs hb{};
   hb.hb_dxa0 = dxa; hb.hb_dxa1 = used == 2 ? dxa + (int64_t)Bp * ldh : nullptr; hb.hb_ldxa = ldh;
@@ -1230,9 +1303,33 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   af.stats_kind = 4; af.info_row = a.actor.d_info_row; af.consts = a.actor.d_step_constants;
   af.target = a.d_target_actor;
   af.polyak_keep = (float)(1.0 - a.target_coeff); af.polyak_mix = (float)a.target_coeff;
-  TRY(actor_shaped_backward(a.d_actor, as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
-                            kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
-                            nullptr, 0, 0, st, &hb, &af));
+  if (chain) {
+    // 5 + 6 + 7 as ONE launch (q_actor_step_kernel): critics forward -> objective (the twins
+    // exchange q) -> their chain to the action columns -> head backward + the actor's chain
+    QActorStep step{};
+    int launch_nets = 0;
+    step.fwd = critics_forward_args(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, nullptr,
+                                    nullptr, &launch_nets);
+    step.fwd.coherent_out = 1;
+    step.bwd = critics_chain_args(a.d_critics, cs, used, B, Bp, c_h1, c_h2, dq, dh2, dh1, dxa,
+                                  &objective);
+    step.bwd.coherent = 1;
+    step.actor = actor_chain_args(a.d_actor, as, B, p_h1 + hs, p_h2 + hs, dloc,
+                                  kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, nullptr, 0, 0, &hb);
+    step.actor.coherent = 1;
+    step.used = used; step.sync = sync;
+    TRY(launch_q_actor_step(step, st));
+    TRY(actor_weight_gradients(as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
+                               kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
+                               st, &af));
+  } else {
+    TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st));
+    TRY(critics_backward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr,
+                         dxa, st, &objective));
+    TRY(actor_shaped_backward(a.d_actor, as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
+                              kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
+                              nullptr, 0, 0, st, &hb, &af));
+  }
   TONIC_CHECK_LAUNCH("tonic_q_iteration");
   return TONIC_OK;
 }

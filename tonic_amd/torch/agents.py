@@ -196,7 +196,10 @@ class _NoiseAhead:
 
     def __init__(self, agent, workers, width):
         import threading
-        self.agent, self.workers, self.width = agent, workers, width
+        import weakref
+        # (a weak reference: the helper thread keeps THIS object alive, and must not keep the
+        #  agent — its Segment, collector and page-locked block — alive with it)
+        self._agent, self.workers, self.width = weakref.ref(agent), workers, width
         n = workers * width
         self.bulk = (n % 16 == 0 and n >= 16 and not agent.global_noise
                      and os.environ.get('TONIC_AMD_NOISE_AHEAD', '1') != '0')
@@ -210,8 +213,16 @@ class _NoiseAhead:
         self.current, self.taken, self.valid = 0, self.DEPTH, False
         self.filling = False                # the helper owns buffers[current ^ 1]
         self.request, self.ready = threading.Event(), threading.Event()
+        self.closed = False
         self.thread = threading.Thread(target=self._helper, daemon=True, name='tonic-noise-ahead')
         self.thread.start()
+        weakref.finalize(agent, self.close)
+
+    def close(self):
+        """Ends the helper thread (the agent was closed or collected)."""
+        if self.bulk and not self.closed:
+            self.closed = True
+            self.request.set()
 
     def _state(self):
         return self.generator.get_state() if self.generator is not None else torch.get_rng_state()
@@ -230,6 +241,8 @@ class _NoiseAhead:
         while True:
             self.request.wait()
             self.request.clear()
+            if self.closed:
+                return
             self._fill(self.current ^ 1)
             self.ready.set()
 
@@ -243,7 +256,7 @@ class _NoiseAhead:
         """The next step's draws -> `out` (the block's noise slot, a NumPy view [W, A])."""
         if not self.bulk:
             self.mark = self._state()
-            self.agent._randn(self.workers, self.width, out=torch.from_numpy(out))
+            self._agent()._randn(self.workers, self.width, out=torch.from_numpy(out))
             return
         if self.taken == self.DEPTH:
             if self.valid:                  # the buffer drawn ahead takes over
@@ -488,6 +501,22 @@ class A2C(Agent):
         if getattr(self, '_speculated', False):
             self._collector.wait_actions()
             self._speculated = False
+
+    def close(self):
+        """Releases what a live agent holds beyond its tensors: waits out a step issued ahead,
+        puts the generator back where the reference's stream is, ends the noise helper thread and
+        destroys the collector (its stream, its resident kernel, the page-lock on the
+        environment's block).  The agent can be initialised again afterwards."""
+        if getattr(self, '_collector', None) is not None:
+            self._settle()
+            noise = getattr(self, '_noise', None)
+            if noise is not None:
+                noise.rewind(1 if self._eps_ahead else 0)
+                noise.close()
+                self._noise = None
+            self._collector.close()
+            self._block._collectors.pop(self._collector.transport, None)
+            self._collector = self._block = None
 
     def test_step(self, observations, steps):
         noise = getattr(self, '_noise', None)
@@ -1011,7 +1040,7 @@ class DDPG(Agent):
             return
         self.actor_updater.enqueue(observations, eps, self._infos[1, iteration], n_global, targets)
 
-    # -- the whole iteration through tonic_q_iteration (8 launches instead of 13)
+    # -- the whole iteration through tonic_q_iteration (5 launches instead of 13)
     _FUSED = {updaters.DeterministicQLearning: (2, updaters.DeterministicPolicyGradient),
               updaters.TwinCriticDeterministicQLearning: (0, updaters.DeterministicPolicyGradient),
               updaters.TwinCriticSoftQLearning: (1, updaters.TwinCriticSoftDeterministicPolicyGradient)}
@@ -1039,7 +1068,8 @@ class DDPG(Agent):
                                                           self.action_size, self.hidden)
         ws = getattr(self, '_fused_workspace', None)
         if ws is None or ws.numel() < need:
-            self._fused_workspace = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # (zero-filled: its head holds the arrival words of the chained launches)
+            self._fused_workspace = ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return ws
 
     def _enqueue_fused(self, kind, batch, iteration, actor_due):
