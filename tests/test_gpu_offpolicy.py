@@ -129,7 +129,7 @@ def _agent_from_golden(g, kind):
                  else tt.models.ActorTwinCriticWithTargets)
     model = container(
         actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
-                              torso=tt.models.MLP((hidden, hidden), relu), head=head),
+                              torso=tt.models.MLP(sizes, relu), head=head),
         critic=critic, observation_normalizer=tt.normalizers.MeanStd())
     replay = tonic_amd.replays.Buffer(size=400, batch_iterations=iterations, batch_size=B,
                                       steps_before_batches=W * 10, steps_between_batches=W * 10,
