@@ -41,7 +41,9 @@ int tonic_debug_grad16_phases(const float* d_actor_params, const float* d_observ
 /* Developer tool: wall-clock stamps (10 ns ticks) of workgroup (0, 0) of the fused off-policy
  * forward at its phase boundaries {entry, loads issued, layer 1, epilogue + barrier, layer 2,
  * epilogue + barrier, heads / output, policy tail}; d_stamps = uint64[8 launches][16] (wall clock | shader cycles), filled in
- * rotation by the launches that follow; null switches the probe off (scripts/forward_stamps.py). */
+ * rotation by the launches that follow, then uint64[8 launches][8] of the weight-gradient group
+ * {entry, requests out, main loop, partials exchanged, folded, -, end}; null switches the probe off
+ * (scripts/forward_stamps.py). */
 int tonic_debug_forward_stamps(uint64_t* d_stamps);
 
 /* Developer / test entry: one GEMM of the small-batch fp32 MFMA building block

@@ -20,20 +20,30 @@ lib = _lib.load()
 for _ in range(3):
     agent.enqueue_update(replay.sample_indices(), agent._draw_noise(iters), graph=False)
 torch.cuda.synchronize()
-stamps = torch.zeros(8 * 16, dtype=torch.int64, device='cuda')
+stamps = torch.zeros(8 * 16 + 8 * 8, dtype=torch.int64, device='cuda')
 lib.tonic_debug_forward_stamps(stamps.data_ptr())
 agent.enqueue_update(replay.sample_indices(), agent._draw_noise(iters), graph=False)   # 16 forwards
 torch.cuda.synchronize()
 lib.tonic_debug_forward_stamps(None)
-both = stamps.cpu().numpy().reshape(8, 16)
+raw = stamps.cpu().numpy()
+both, tn = raw[:128].reshape(8, 16), raw[128:].reshape(8, 8)
 s, cycles = both[:, :8], both[:, 8:]
 names = ['target actor', 'four critics', 'online actor', 'two critics'] * 2
 labels = ['loads issued', 'layer 1', 'epilogue+barrier', 'layer 2', 'epilogue+barrier', 'heads/out', 'tail']
 print('B', B)
 for i in range(8):
     t = s[i]
+    if not t.any():
+        continue
     d = [(t[j + 1] - t[j]) * 0.01 if t[j + 1] else 0.0 for j in range(7)]
     last = max(j for j in range(8) if t[j])
     print(f'{names[i]:13s}', ' '.join(f'{l} {x:5.2f}' for l, x in zip(labels, d)),
           f'| total {(t[last] - t[0]) * 0.01:5.2f} us',
           f'| shader clock {(cycles[i][last] - cycles[i][0]) / max((t[last] - t[0]) * 10.0, 1):5.2f} GHz')
+for i in range(8):
+    t = tn[i]
+    if not t.any():
+        continue
+    print('weight gradients', ' '.join(f'{l} {(t[j + 1] - t[j]) * 0.01:5.2f}' for j, l in enumerate(
+        ['requests+consts', 'main loop', 'exchange', 'fold+operands', 'adam+stores'])),
+        f'| total {(t[5] - t[0]) * 0.01:5.2f} us')

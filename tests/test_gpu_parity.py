@@ -127,7 +127,10 @@ def test_ppo_act_golden(lib, golden, name):
     np.testing.assert_allclose(actions.cpu().numpy(), loc, rtol=0, atol=3e-6)
 
 
-@pytest.mark.parametrize('O,n', [(17, 1000), (3, 31), (28, 4097), (1, 64), (32, 65)])
+# (from 32 768 rows — a whole Segment — the values come from the forward half of the regression
+#  kernel, mlp64_grad16_kernel<..., FWD>: ragged tails, every observation bucket)
+@pytest.mark.parametrize('O,n', [(17, 1000), (3, 31), (28, 4097), (1, 64), (32, 65), (17, 40000),
+                                 (3, 33001), (28, 32768), (1, 32769), (32, 50001), (20, 36000)])
 def test_value_forward_vs_oracle(lib, O, n):
     from tonic_amd import _lib
     rng = np.random.RandomState(O * 1000 + n)

@@ -21,6 +21,7 @@
 // fetches two neighbouring output columns per load and a wave owns a 32 x 32 tile of 2 x 2
 // interleaved MFMA tiles, four waves splitting K.
 #pragma once
+#include <atomic>
 #include "common.h"
 
 namespace tonic {
@@ -41,6 +42,8 @@ struct GemmArgs {
   int accumulate;        // C += result instead of C = result
   float alpha;           // result scale (applied before bias)
 };
+
+extern std::atomic<unsigned long long*> g_forward_stamps;    // developer probe, see tonic_debug_forward_stamps
 
 constexpr int kGemmGroupMax = 4;
 
@@ -68,6 +71,7 @@ struct AdamFold {
 };
 
 struct GemmGroup {
+  unsigned long long* stamps;        // developer probe: workgroup 0's phase stamps (null in the product path)
   GemmArgs problem[kGemmGroupMax];
   int first[kGemmGroupMax + 1];      // workgroup ranges of the problems
   int count;

@@ -243,7 +243,18 @@ __device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned tot
 
 template <bool EDGE>
 __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, float* part,
-                                             const AdamFold& fold, unsigned total_blocks) {
+                                             const AdamFold& fold, unsigned total_blocks,
+                                             unsigned long long* stamps) {
+  const bool probe = stamps != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0 &&
+                     threadIdx.y == 0;
+  auto stamp = [&](int k) {
+    if (probe) {
+      __builtin_amdgcn_sched_barrier(0);
+      stamps[k] = wall_clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
   const int lane = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);       // scalar: uniform control flow
   const int i = lane & 15, kg = lane >> 4;
@@ -309,6 +320,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
     consts = adam_consts(fold);
     __builtin_amdgcn_sched_barrier(0);
   }
+  stamp(1);                                         // first requests out, constants formed
   for (int first = 0; first < mine; first += kTnDepth) {
 #pragma unroll
     for (int d = 0; d < kTnDepth; ++d) {
@@ -338,6 +350,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
     multiply(a, b);
   }
 
+  stamp(2);                                         // main loop done
   float* slot = part + (w * 64 + lane) * kTnPart;
 #pragma unroll
   for (int jm = 0; jm < 2; ++jm)
@@ -347,6 +360,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       for (int r = 0; r < 4; ++r) slot[(2 * jm + jn) * 4 + r] = acc[jm][jn][r];
   slot[16] = colsum[0]; slot[17] = colsum[1];
   __syncthreads();
+  stamp(3);                                         // partials exchanged
   // Epilogue, spread over the four waves: wave w finishes register row r = w of the four MFMA tiles
   // (rows m0 + 2 (4 kg + w) + {0, 1}, columns cb, cb + 1).  Every wave adds the four partials in
   // wave order — ((p0 + p1) + p2) + p3, bit-reproducible — so the 32 x 32 tile's stores and the
@@ -402,6 +416,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       }
     }
   }
+  stamp(4);                                         // folded, optimizer operands requested
   // D layout: lane (column index i, group kg), register r <-> row index 4 kg + r of the MFMA tile
 #pragma unroll
   for (int jm = 0; jm < 2; ++jm) {
@@ -442,6 +457,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       }
     }
   }
+  stamp(5);
 }
 
 __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup G) {
@@ -456,8 +472,8 @@ __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup 
   // operand ROWS are long enough (padded pitch: what is read beyond M / N only feeds outputs that
   // are never stored); clamped scalar loads only where a load would leave the row.
   const unsigned total = gridDim.x * gridDim.z;
-  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part, G.adam, total);   // uniform
-  else gemm_tn_tile<false>(g, tm, tn, part, G.adam, total);
+  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part, G.adam, total, G.stamps);   // uniform
+  else gemm_tn_tile<false>(g, tm, tn, part, G.adam, total, G.stamps);
 }
 
 namespace {
@@ -503,6 +519,10 @@ int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count,
         blocks += ((list[p].M + 31) / 32) * ((list[p].N + 31) / 32);
       }
       G.first[count] = blocks;
+      if (unsigned long long* base = g_forward_stamps.load()) {      // developer probe: ring of 8 launches
+        static std::atomic<unsigned> launches{0};
+        G.stamps = base + 8 * 16 + 8 * (launches.fetch_add(1) % 8);
+      }
       hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks, 1, batch), dim3(64, kTnWaves), 0,
                          stream, G);
       TONIC_CHECK_LAUNCH("gemm_tn_group");

@@ -63,5 +63,6 @@ bool grad16_supported(int O, int A, bool actor);
 int grad16_blocks(int64_t n);
 int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain);
 int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args);
+int launch_values16(int blocks, hipStream_t stream, const MlpArgs& args, int chain);
 
 }  // namespace tonic

@@ -1053,6 +1053,8 @@ extern "C" int tonic_ppo_collect_step(
   });
 }
 
+constexpr int64_t kValues16MinRows = 32768;
+
 extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
                                    const float* d_norm_std, double norm_clip,
                                    const float* d_observations,
@@ -1065,10 +1067,18 @@ extern "C" int tonic_value_forward(const float* d_critic_params, const float* d_
   a.params = d_critic_params; a.obs = d_observations; a.norm_mean = d_norm_mean;
   a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
   a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
+  hipStream_t st = as_stream(stream);
+  // A whole Segment (a2c.py:92-99 evaluates T x W observations twice per update): the forward half
+  // of the regression kernel — 16-sample MFMA tiles with the inputs prefetched a tile ahead —
+  // instead of the per-step kernel below, which is built around the latency of ONE step's rows.
+  const int variant = g_grad_variant;
+  if (n >= kValues16MinRows && variant >= 1 && grad16_supported(O, 1, false)) {
+    a.out1 = d_values;
+    return launch_values16(grad16_blocks(n), st, a, variant - 1);
+  }
   const int64_t tiles = (n + 31) / 32;
   int blocks = (int)((tiles + kFwdWaves - 1) / kFwdWaves);
   if (blocks > 1024) blocks = 1024;
-  hipStream_t st = as_stream(stream);
   return dispatch_ks1(ks1_bucket(O), [&](auto ks) {
     return launch_value<decltype(ks)::value>(blocks, st, a);
   });

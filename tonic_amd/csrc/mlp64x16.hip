@@ -325,8 +325,13 @@ __device__ __forceinline__ unsigned long long probe_clock() {
     }                                                         \
   } while (0)
 
-template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, int CH, bool PROBE = false>
+// FWD (critic only): the forward half alone — values -> a.out1, nothing else is formed or written
+// (tonic_value_forward on a whole Segment: the same tile loop, input prefetch and layer arithmetic
+// as the regression step that follows it).
+template <int KS1, int XT, int XR, int AP, bool ACTOR, bool EXACT, int CH, bool PROBE = false,
+          bool FWD = false>
 __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs a) {
+  static_assert(!FWD || !ACTOR, "the forward-only form serves the critic");
   using L = Lds16<KS1, AP, CH>;
   constexpr int TS16 = L::TS;
   // CH 2: dW2 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 on bf16x3 terms — the 16 samples of a tile
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       for (int aa = 0; aa < AP; ++aa) in.act[aa] = a.actions[nc * A + (aa < A ? aa : A - 1)];
       in.adv = a.adv[nc];
       in.lp = a.old_logp[nc];
-    } else {
+    } else if (!FWD) {
       in.ret = a.returns[nc];
     }
   };
@@ -505,6 +510,11 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       }
     }
 
+    if constexpr (FWD) {
+      if (counted) a.out1[ns] = z[0];
+      cur = nxt;
+      continue;
+    }
     const float cw = counted ? 1.f : 0.f;            // arithmetic mask: no lane branches below
     if (ACTOR) {
       float logp = 0.f, loc[AP], dif[AP], dsg[AP];
@@ -719,6 +729,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out1) + wave * 12;
     for (int k = 0; k < 12; ++k) dst[k] = ph[k];
   }
+  if constexpr (FWD) return;
 
   // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
   // `G[i] += v` per wave in turn would be a dependent LDS read-modify-write per element (the
@@ -1426,6 +1437,35 @@ int go16(int blocks, hipStream_t stream, const MlpArgs& args) {
 }
 
 template <int KS1, int XT, int XR, int CH>
+int go16_values(int blocks, hipStream_t stream, const MlpArgs& args) {
+  auto kernel = mlp64_grad16_kernel<KS1, XT, XR, 1, false, true, CH, false, true>;
+  constexpr int lds_bytes = Lds16<KS1, 1, CH>::BYTES;
+  static thread_local bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      set_error("mlp64_grad16<values>: hipFuncSetAttribute(%d B LDS): %s", lds_bytes,
+                hipGetErrorString(e));
+      return TONIC_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWaves16 * 64), lds_bytes, stream, args);
+  TONIC_CHECK_LAUNCH("mlp64_grad16_kernel<values>");
+  return TONIC_OK;
+}
+
+template <int CH>
+int values_by_inputs(int blocks, hipStream_t stream, const MlpArgs& args) {
+  if (args.O <= 4) return go16_values<1, 0, 4, CH>(blocks, stream, args);
+  if (args.O <= 16) return go16_values<4, 1, 0, CH>(blocks, stream, args);
+  if (args.O == 17) return go16_values<5, 1, 1, CH>(blocks, stream, args);
+  if (args.O <= 20) return go16_values<5, 1, 4, CH>(blocks, stream, args);
+  return go16_values<8, 2, 0, CH>(blocks, stream, args);
+}
+
+template <int KS1, int XT, int XR, int CH>
 int by_heads(bool actor, int blocks, hipStream_t st, const MlpArgs& a) {
   if (!actor) return go16<KS1, XT, XR, 1, false, true, CH>(blocks, st, a);
   if (a.A == 1) return go16<KS1, XT, XR, 1, true, true, CH>(blocks, st, a);
@@ -1456,6 +1496,13 @@ int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kWaves16 * 64), lds_bytes, stream, args);
   TONIC_CHECK_LAUNCH("mlp64_grad16_kernel<probe>");
   return TONIC_OK;
+}
+
+// The critic's forward over a whole batch: values -> args.out1 (chain as launch_grad16)
+int launch_values16(int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
+  if (chain == 2) return values_by_inputs<2>(blocks, stream, args);
+  return chain == 1 ? values_by_inputs<1>(blocks, stream, args)
+                    : values_by_inputs<0>(blocks, stream, args);
 }
 
 int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain) {

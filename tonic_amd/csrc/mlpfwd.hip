@@ -890,7 +890,7 @@ bool mlp_forward_supported(int H, int NH, int heads) {
          heads * ((NH + 15) / 16) <= 4;
 }
 
-static std::atomic<unsigned long long*> g_forward_stamps{nullptr};
+std::atomic<unsigned long long*> g_forward_stamps{nullptr};      // (gemm16.hip stamps its weight-gradient launches behind the forward ring)
 static std::atomic<unsigned> g_forward_launches{0};
 
 extern "C" int tonic_debug_forward_stamps(uint64_t* d_stamps) {
