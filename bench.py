@@ -354,8 +354,8 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
     per_iteration = offpolicy_flop_per_iteration(kind, o_dim, a_dim, batch)
     seconds = out['hip_graph']['ms_per_update_call'] * 1e-3 / iterations
     tflops = per_iteration / seconds / 1e12
-    out['roofline'] = dict(bound='mfma (latency-bound in practice: ~14 dependent launches of '
-                                 '5-16 us per iteration at B=1024)',
+    out['roofline'] = dict(bound='mfma (latency-bound in practice: 5 dependent launches of '
+                                 '15-40 us per iteration at B=1024, 3 when the actor is not due)',
                            flop_per_iteration=int(per_iteration), achieved=round(tflops, 2),
                            peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                            frac=round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -223,6 +223,9 @@ __device__ __forceinline__ void adam_apply(const AdamFold& f, const AdamConsts& 
 // The last workgroup of the launch: step counter and logged statistics (adam_finalize, optim.hip).
 __device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned total) {
   unsigned* arrivals = reinterpret_cast<unsigned*>(f.state + 3);
+  // (this wave's loads of the step's state / constants have returned before it arrives: the
+  //  finaliser's write of the step counter races with nobody, see adam_kernel in optim.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned before = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
   if (before != total - 1) return;

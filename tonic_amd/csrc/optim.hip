@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPair pair) {
   }
   // The LAST optimizer workgroup to get here finalises (step counter, logged statistics, KL stop
   // flag) — it used to be a launch of its own (4.6 us for an 8-float row).  Every workgroup has
-  // read state[0] / the skip flag before it arrives, so the writes below race with nobody.
+  // read state[0] / the skip flag before it arrives, so the writes below race with nobody: the
+  // barrier in front of the arrival is a workgroup-scope fence (s_waitcnt vmcnt(0) in every wave:
+  // all of this workgroup's loads have returned and its stores are acknowledged by L2) and the
+  // counter is an agent-scope atomic performed at L2; what the finaliser READS was written by
+  // earlier launches.  (A release / acquire pair at agent scope instead would be an L2 write-back
+  // + invalidate per workgroup.)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* arrivals = reinterpret_cast<unsigned*>(a.state + 3);
