@@ -1145,7 +1145,14 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     const int64_t ns = t * 16 + s;
     const bool valid = ns < W;
     const int64_t nc = valid ? ns : W - 1;
-    float xr[KS1], ep[AP];
+    // Wave 0 finishes the step: lane (s, g) forms actions g and g + 4 of sample s (the four lane
+    // groups used to repeat all AP of them: the one wave everybody waits for ran 6 dependent
+    // tanh / log-density chains in a row where 2 do)
+    constexpr int kMine = (AP + 3) / 4;
+    int mine[kMine];
+#pragma unroll
+    for (int u = 0; u < kMine; ++u) mine[u] = min(g + 4 * u, AP - 1);
+    float xr[KS1], ep[kMine];
     // HOST: the tile's observation and noise rows cross PCIe exactly once, as 16-byte requests
     // that are all in flight together; they meet in LDS (SO / SE) further down.
     const int tile_rows = (int)min<int64_t>(16, W - t * 16);
@@ -1174,14 +1181,14 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       // (noise and head constants are wave 0's alone: every load instruction costs the CU's
       //  memory pipe 5 - 10 ns, and the four waves share it)
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa)
-        ep[aa] = (wave == 0 && c.eps != nullptr) ? c.eps[nc * A + (aa < A ? aa : A - 1)] : 0.f;
+      for (int u = 0; u < kMine; ++u)
+        ep[u] = (wave == 0 && c.eps != nullptr) ? c.eps[nc * A + min(mine[u], A - 1)] : 0.f;
     }
     // this tile's weight operands, all requested up front
     const f32x4 bias1 = reinterpret_cast<const f32x4*>(P + L.B1P + g * 16)[wave];
     const f32x4 bias2 = reinterpret_cast<const f32x4*>(P + L.B2P + g * 16)[wave];
     float wl[KS1];
-    f32x4 w2[4], w3[AP], hcA[AP];
+    f32x4 w2[4], w3[AP], hcM[kMine];
 #pragma unroll
     for (int st = 0; st < KS1; ++st) wl[st] = P[L.W1I + (wave * KS1 + st) * 64 + lane];
 #pragma unroll
@@ -1190,8 +1197,11 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       w3[aa] = reinterpret_cast<const f32x4*>(P + L.W3P)[(aa * 4 + g) * 4 + wave];
-      hcA[aa] = wave == 0 ? *reinterpret_cast<const f32x4*>(P + L.HC + aa * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int u = 0; u < kMine; ++u)
+      hcM[u] = wave == 0 ? *reinterpret_cast<const f32x4*>(P + L.HC + mine[u] * 8)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (HOST) {
       float* SO = tile + 2048;                     // [16][O] observation rows of the tile
       float* SE = tile + 2048 + 512;               // [16][A] noise rows
@@ -1220,8 +1230,8 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         xr[st] = SO[sr * O + (k < O ? k : O - 1)];
       }
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa)
-        ep[aa] = (wave == 0 && c.eps != nullptr) ? SE[sr * A + (aa < A ? aa : A - 1)] : 0.f;
+      for (int u = 0; u < kMine; ++u)
+        ep[u] = (wave == 0 && c.eps != nullptr) ? SE[sr * A + min(mine[u], A - 1)] : 0.f;
     } else {
       // the tile's 16 observation rows -> Segment row (contiguous, coalesced)
       for (int64_t i = tid; i < o_count; i += 256)
@@ -1273,39 +1283,43 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       // stores under ONE branch.  (Stores inside the per-action loop made every action its own
       // exec-masked block: read -> wait -> tanh chain -> store, six times in a row, 1.4 us of
       // the step's 5.8 us on the one wave everybody waits for.)
-      float zp[AP][4], actv[AP];
+      float zp[kMine][4], actv[kMine], term[kMine];
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
+      for (int u = 0; u < kMine; ++u) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) zp[aa][w] = ZP[(w * AP + aa) * 16 + s];
+        for (int w = 0; w < 4; ++w) zp[u][w] = ZP[(w * AP + mine[u]) * 16 + s];
       }
+#pragma unroll
+      for (int u = 0; u < kMine; ++u) {
+        const float z = (zp[u][0] + zp[u][1]) + (zp[u][2] + zp[u][3]);
+        const f32x4 hc = hcM[u];
+        const float loc = tanh_fast(z + hc[0]);
+        actv[u] = c.eps != nullptr ? loc + hc[1] * ep[u] : loc;
+        const float d = actv[u] - loc;
+        term[u] = g + 4 * u < A ? -(d * d) * hc[2] - hc[3] : 0.f;
+      }
+      // the log-probability: the terms of all actions, added in action order like before
       float logp = 0.f;
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
-        const float z = (zp[aa][0] + zp[aa][1]) + (zp[aa][2] + zp[aa][3]);
-        const f32x4 hc = hcA[aa];
-        const float loc = tanh_fast(z + hc[0]);
-        actv[aa] = c.eps != nullptr ? loc + hc[1] * ep[aa] : loc;
-        const float d = actv[aa] - loc;
-        logp += aa < A ? -(d * d) * hc[2] - hc[3] : 0.f;
-      }
-      if (valid && g == 0) {
+      for (int aa = 0; aa < AP; ++aa) logp += __shfl(term[aa >> 2], s + 16 * (aa & 3), 64);
+      if (valid) {
 #pragma unroll
-        for (int aa = 0; aa < AP; ++aa) {
+        for (int u = 0; u < kMine; ++u) {
+          const int aa = g + 4 * u;
           if (aa < A) {
-            c.seg_act[(c.row * W + ns) * A + aa] = actv[aa];
+            c.seg_act[(c.row * W + ns) * A + aa] = actv[u];
             if (c.actions_out != nullptr) {
 #if TONIC_COLLECT_SC1
               if constexpr (HOST)
-                __hip_atomic_store(c.actions_out + ns * A + aa, actv[aa], __ATOMIC_RELAXED,
+                __hip_atomic_store(c.actions_out + ns * A + aa, actv[u], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
               else
 #endif
-                c.actions_out[ns * A + aa] = actv[aa];
+                c.actions_out[ns * A + aa] = actv[u];
             }
           }
         }
-        c.seg_lp[c.row * W + ns] = logp;
+        if (g == 0) c.seg_lp[c.row * W + ns] = logp;
       }
       // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
       // only then may the completion word go out (scripts/collector_stress.py: without the
