@@ -460,6 +460,34 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
 // w+4, ..., D[feature][row] products, LDS exchange between the layers; the weights are walked
 // along their rows (W^T), i.e. k-strided loads.  dz2 / dz1 are written to HBM for the weight
 // gradients.
+// ---- arrival words of the chained launches (mlpfwd.h, q_critic_step_kernel / q_actor_step_kernel)
+__device__ __forceinline__ unsigned chain_load(const unsigned* word) {
+  return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(unsigned* word, unsigned v) {
+  __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned chain_add(unsigned* word) {
+  return __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Thread 0 waits until `need` peers have arrived at `word`; the barrier behind it also publishes
+// this workgroup's own stores to its own waves.  Bounded: see kChainTimeoutTicks.
+__device__ __forceinline__ void chain_wait(const unsigned* word, unsigned need, unsigned* failed) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (chain_load(word) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > kChainTimeoutTicks) {
+        chain_store(failed, 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+
 // `coherent` (q_chain_kernel): what other workgroups of the SAME launch wrote (l_tq, l_q, hb_dxa*)
 // is read with agent-scope loads, and dxa is written with agent-scope stores.
 __device__ __forceinline__ float load_shared(const float* p, bool coherent) {
@@ -503,8 +531,14 @@ __device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed)
   }
 }
 
+// `wait_word` (chained launches): the peers whose values this pass consumes — the TD target's q,
+// the twin's q, the critics' action-column gradients — are awaited HERE, after everything that
+// does not depend on them (ReLU masks, the first weight operands, the head backward's own
+// operands) has been requested: the hand-over's latency runs under those loads.
 __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int net, const int bx,
-                                                  float* lds) {
+                                                  float* lds, const unsigned* wait_word = nullptr,
+                                                  unsigned wait_need = 0,
+                                                  unsigned* wait_failed = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kg = lane >> 4;
@@ -530,7 +564,8 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
   const bool formed = a.heads > 0 && a.hb_dxa0 != nullptr;      // scalar
   float* dhl = lds + 2 * kRows * pitch;             // [2 heads][16 rows][kHeadPitch] (formed only)
   constexpr int kHeadSlots = kPostPitch / 16;
-  float hb_da[kHeadSlots], hb_t[kHeadSlots], hb_sg[kHeadSlots], hb_ep[kHeadSlots], hb_pre[kHeadSlots];
+  float hb_da[kHeadSlots], hb_second[kHeadSlots], hb_t[kHeadSlots], hb_sg[kHeadSlots],
+      hb_ep[kHeadSlots], hb_pre[kHeadSlots];
   const int hb_row = tid >> 4, hb_slot = tid & 15;
   if (formed) {
     const int A = a.NH;
@@ -540,20 +575,17 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
     const float* epp = a.hb_sac ? a.hb_eps : a.hb_act;
     const float* prep = a.hb_sac ? a.hb_spre : a.hb_act;
     const int64_t pre_ld = a.hb_sac ? a.ldh : A;
-    float second[kHeadSlots];
 #pragma unroll
     for (int u = 0; u < kHeadSlots; ++u) {
       const int aa = min(hb_slot + 16 * u, A - 1);
-      hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
-      second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+      if (wait_word == nullptr) {                     // (scalar; else: after the wait below)
+        hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
+        hb_second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+      }
       hb_t[u] = a.hb_act[src * A + aa];
       hb_sg[u] = sgp[src * A + aa];
       hb_ep[u] = epp[src * A + aa];
       hb_pre[u] = prep[src * pre_ld + aa];
-    }
-    if (a.hb_dxa1 != nullptr) {
-#pragma unroll
-      for (int u = 0; u < kHeadSlots; ++u) hb_da[u] = hb_da[u] + second[u];
     }
   }
   // ReLU masks of both layers (forward activations of this lane's rows / features), up front
@@ -603,6 +635,24 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
   if (wide) wfill(wa, 0);
   else l1.start(cols2, H, kg, a.ldw2);
 
+  if (wait_word != nullptr) {                         // scalar
+    chain_wait(wait_word, wait_need, wait_failed);
+    if (formed) {
+      const int A = a.NH;
+      const int64_t src = min((int64_t)r0 + hb_row, (int64_t)a.B - 1);
+      const float* dxa1 = a.hb_dxa1 != nullptr ? a.hb_dxa1 : a.hb_dxa0;
+#pragma unroll
+      for (int u = 0; u < kHeadSlots; ++u) {
+        const int aa = min(hb_slot + 16 * u, A - 1);
+        hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
+        hb_second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+      }
+    }
+  }
+  if (formed && a.hb_dxa1 != nullptr) {
+#pragma unroll
+    for (int u = 0; u < kHeadSlots; ++u) hb_da[u] = hb_da[u] + hb_second[u];
+  }
   f32x4 acc[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -765,61 +815,31 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 }
 
 // ------------------------------------------------------------------ chained passes (mlpfwd.h)
-__device__ __forceinline__ unsigned chain_load(const unsigned* word) {
-  return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void chain_store(unsigned* word, unsigned v) {
-  __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned chain_add(unsigned* word) {
-  return __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Thread 0 waits until `need` peers have arrived at `word`; the barrier behind it also publishes
-// this workgroup's own stores to its own waves.  Bounded: see kChainTimeoutTicks.
-__device__ __forceinline__ void chain_wait(const unsigned* word, unsigned need, unsigned* failed) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    while (chain_load(word) < need) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > kChainTimeoutTicks) {
-        chain_store(failed, 1u);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // The value head's outputs are stored by wave 0 (mlp_forward_body): their acknowledgement, then
 // the arrival.
-__device__ __forceinline__ void chain_arrive_after_values(unsigned* word) {
+__device__ __forceinline__ void chain_arrive_after_values(unsigned* tile_word, unsigned* all_word) {
   if (threadIdx.x < 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) chain_add(word);
+    if (threadIdx.x == 0) {
+      if (tile_word != nullptr) chain_add(tile_word);
+      chain_add(all_word);
+    }
   }
 }
 
-// The last workgroup of `total` to get here (thread 0 decides, everybody learns it) ...
-__device__ __forceinline__ bool chain_last(unsigned* counter, unsigned total) {
-  __shared__ int last;
-  if (threadIdx.x == 0) {
-    const bool mine = chain_add(counter) == total - 1;
-    if (mine) chain_store(counter, 0u);
-    last = mine ? 1 : 0;
-  }
-  __syncthreads();
-  return last != 0;
-}
-
-// ... forms the logged sums of the step's loss (every q it reads was acknowledged before its
-// writer arrived here).
-__device__ __forceinline__ void chain_stats(const MlpBwdArgs& b, unsigned* counter, unsigned* failed,
-                                            unsigned total) {
-  if (!chain_last(counter, total)) return;
+// The launch's LAST workgroup is nobody's tile: it waits until every value of the launch has been
+// published (`all_word` counts the publishers) and forms the logged sums of the step's loss while
+// the other workgroups run their chains — in a launch of their own they were the by-product of
+// workgroup (0, 0); at the end of the last chain they would be 2 - 3 us of the critical path.
+__device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b, unsigned* all_word,
+                                                 unsigned* failed, unsigned publishers) {
+  chain_wait(all_word, publishers, failed);
   const bool bad = chain_load(failed) != 0;
   mlp_loss_stats(b, bad);
-  if (threadIdx.x == 0 && bad) chain_store(failed, 0u);
+  if (threadIdx.x == 0) {
+    chain_store(all_word, 0u);
+    if (bad) chain_store(failed, 0u);
+  }
 }
 
 __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
@@ -828,20 +848,23 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
   unsigned* word = c.sync + kChainWordsPerTile * tile;
-  unsigned* global = c.sync + kChainWordsPerTile * tiles;       // [done, failed]
-  mlp_forward_body(c.fwd, role, tile, lds);
-  if (role < c.nets) {                                // a target: its values, then its arrival
-    chain_arrive_after_values(word);
+  unsigned* global = c.sync + kChainWordsPerTile * tiles;       // [-, failed, values published]
+  if (tile == tiles) {                                // the extra workgroup: the logged sums
+    chain_stats_role(c.bwd, global + 2, global + 1, roles * tiles);
     return;
   }
-  chain_wait(word, c.nets, global + 1);
-  mlp_backward_body(c.bwd, role - c.nets, tile, lds);
-  __syncthreads();
+  mlp_forward_body(c.fwd, role, tile, lds);
+  if (role < c.nets) {                                // a target: its values, then its arrival
+    chain_arrive_after_values(word, global + 2);
+    return;
+  }
+  chain_arrive_after_values(nullptr, global + 2);
+  __syncthreads();                                    // (the forward's LDS images are free)
+  mlp_backward_body(c.bwd, role - c.nets, tile, lds, word, c.nets, global + 1);
   if (threadIdx.x == 0 && chain_add(word + 1) == (unsigned)c.nets - 1) {    // the tile's last reader
     chain_store(word, 0u);
     chain_store(word + 1, 0u);
   }
-  chain_stats(c.bwd, global, global + 1, c.nets * tiles);
 }
 
 __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
@@ -851,16 +874,19 @@ __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
   unsigned* word = c.sync + kChainWordsPerTile * tile;
   unsigned* global = c.sync + kChainWordsPerTile * tiles;
+  if (tile == tiles) {
+    chain_stats_role(c.bwd, global + 2, global + 1, c.used * tiles);
+    return;
+  }
   if (role == c.used) {                               // the actor: both critics' action columns first
-    chain_wait(word + 2, c.used, global + 1);
+    mlp_backward_body(c.actor, 0, tile, lds, word + 2, c.used, global + 1);
     if (threadIdx.x == 0) chain_store(word + 2, 0u);
-    mlp_backward_body(c.actor, 0, tile, lds);
     return;
   }
   mlp_forward_body(c.fwd, role, tile, lds);
-  chain_arrive_after_values(word);
-  chain_wait(word, c.used, global + 1);               // (the twin's q)
-  mlp_backward_body(c.bwd, role, tile, lds);
+  chain_arrive_after_values(word, global + 2);
+  __syncthreads();
+  mlp_backward_body(c.bwd, role, tile, lds, word, c.used, global + 1);     // (waits for the twin's q)
   __syncthreads();                                    // (dxa acknowledged: the barrier's fence)
   if (threadIdx.x == 0) {
     chain_add(word + 2);
@@ -869,7 +895,6 @@ __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
       chain_store(word + 1, 0u);
     }
   }
-  chain_stats(c.bwd, global, global + 1, c.used * tiles);
 }
 
 }  // namespace
@@ -983,8 +1008,8 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
                     mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: nets=%d H=%d", c.nets, f.H);
   const int tiles = (f.B + kRows - 1) / kRows;
-  hipLaunchKernelGGL(q_critic_step_kernel, dim3(tiles * 2 * c.nets), dim3(256), chain_lds_bytes(f.H),
-                     stream, c);
+  hipLaunchKernelGGL(q_critic_step_kernel, dim3(tiles * 2 * c.nets + 1), dim3(256),
+                     chain_lds_bytes(f.H), stream, c);
   TONIC_CHECK_LAUNCH("q_critic_step_kernel");
   return TONIC_OK;
 }
@@ -1001,8 +1026,8 @@ int launch_q_actor_step(const QActorStep& c, hipStream_t stream) {
                     mlp_backward_supported(f.H, c.actor.NH, c.actor.heads, c.actor.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_actor_step: used=%d H=%d", c.used, f.H);
   const int tiles = (f.B + kRows - 1) / kRows;
-  hipLaunchKernelGGL(q_actor_step_kernel, dim3(tiles * (c.used + 1)), dim3(256), chain_lds_bytes(f.H),
-                     stream, c);
+  hipLaunchKernelGGL(q_actor_step_kernel, dim3(tiles * (c.used + 1) + 1), dim3(256),
+                     chain_lds_bytes(f.H), stream, c);
   TONIC_CHECK_LAUNCH("q_actor_step_kernel");
   return TONIC_OK;
 }
