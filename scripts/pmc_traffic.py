@@ -26,6 +26,19 @@ for _ in range(3):
 torch.cuda.synchronize()
 del arrs, resets, terms, values, ret, adv
 
+# the bit-exact scan at the metric's own size (gae_stream16_kernel: T = 4096, W = 256; 29.4 MB)
+T2, W2 = 4096, 256
+small = [torch.randn(T2, W2, device='cuda', generator=g) for _ in range(3)]       # next_values, rewards, values
+rs2 = (torch.rand(T2, W2, device='cuda', generator=g) < 1e-3).float()
+tm2 = rs2 * (torch.rand(T2, W2, device='cuda', generator=g) < 0.5).float()
+ret2, adv2 = torch.empty(T2, W2, device='cuda'), torch.empty(T2, W2, device='cuda')
+ws2 = torch.empty(max(lib.tonic_gae_workspace_bytes(T2, W2, 1), 16), dtype=torch.uint8, device='cuda')
+for _ in range(3):
+    _lib.check(lib.tonic_gae_lambda_returns(
+        p(small[0]), p(small[1]), p(rs2), p(tm2), p(small[2]), p(ret2), p(adv2), p(stats), None,
+        T2, W2, 0.99, 0.97, 1, p(ws2), ws2.numel(), None), 'gae small')
+torch.cuda.synchronize()
+
 O, A, n = 17, 6, 4096 * 256
 P = lib.tonic_ppo_actor_param_count(O, A)
 Pc = lib.tonic_v_critic_param_count(O)
@@ -45,5 +58,9 @@ for _ in range(3):
                                         n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), None), 'actor')
     _lib.check(lib.tonic_value_regression_grad(p(cparams), p(mean), p(std), 0.0, p(obs), p(rets), p(outc),
                                                n, O, p(ws), ws.numel(), None), 'critic')
+# the critic's forward over the whole Segment (mlp64_grad16_kernel<..., FWD>: 68 B read + 4 B written per row)
+vals = torch.empty(n, device='cuda')
+for _ in range(3):
+    _lib.check(lib.tonic_value_forward(p(cparams), p(mean), p(std), 0.0, p(obs), p(vals), n, O, None), 'values')
 torch.cuda.synchronize()
 print('done')
