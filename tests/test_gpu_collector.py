@@ -232,6 +232,53 @@ def test_test_step_keeps_the_reference_noise_order(lib):
         np.testing.assert_allclose(got_actions, want, rtol=0, atol=3e-6)
 
 
+def test_a_closed_agent_lets_go_and_leaves_the_generator_where_the_reference_has_it(lib):
+    """agent.close(): the noise helper thread ends and no longer keeps the agent (its Segment, its
+    collector, the page-locked block) alive — bench.py's second job on a shared device crawled behind
+    the first one's leftovers — the generator is rewound to the draws the agent has consumed (the
+    helper runs up to 128 steps ahead), and the agent works again after a new bind."""
+    import gc
+    import threading
+    import weakref
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd.environments import Box
+    O, A, W = 5, 2, 8                                   # W * A = 16: the block-draw mode
+    rng = np.random.RandomState(1)
+    obs = rng.standard_normal((5, W, O)).astype(np.float32)
+
+    def helpers():
+        return [t for t in threading.enumerate() if t.name == 'tonic-noise-ahead' and t.is_alive()]
+
+    before = len(helpers())
+    agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=64))
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+    after_init = torch.get_rng_state()
+    first = []
+    for t in range(3):
+        first.append(agent.step(obs[t], t * W).copy())
+        agent.update(obs[t + 1], np.zeros(W, np.float32), np.zeros(W, bool), np.zeros(W, bool),
+                     steps=t * W)
+    assert len(helpers()) == before + 1
+    agent.close()
+    consumed = torch.get_rng_state()
+    torch.set_rng_state(after_init)
+    for _ in range(3):                                  # the three steps' draws, nothing more
+        torch.randn(W, A)
+    assert torch.equal(torch.get_rng_state(), consumed)
+    # ... the agent binds again and goes on with the stream
+    again = agent.step(obs[3], 3 * W)
+    assert np.isfinite(again).all() and again.shape == (W, A)
+    agent.close()
+    ref = weakref.ref(agent)
+    del agent
+    gc.collect()
+    assert ref() is None, 'a closed agent is still referenced (helper thread?)'
+    for thread in helpers():
+        thread.join(timeout=2.0)
+    assert len(helpers()) == before
+
+
 def test_step_issued_from_update_is_bit_identical(lib, monkeypatch):
     """With a block-backed environment `agent.update` issues the next step's launch itself
     (the observations are already in the block, the noise is drawn ahead) and `agent.step` only
