@@ -527,8 +527,8 @@ int tonic_actor_q_grad(int32_t kind, const float* d_actor_params, const float* d
  *   model.update_targets()], i.e. tonic_twin_q_grad + tonic_adam_step [+ tonic_actor_q_grad +
  *   tonic_adam_polyak_step] with the launches of the two steps merged where they do not depend on
  *   each other (both policy passes are one launch; forward, loss and input-gradient chain of a step
- *   are one launch whose workgroups hand the few floats that cross them over through agent-scope
- *   stores and arrival words: 5 launches with the actor due, 3 without) and torch.optim.Adam [+ the polyak update] applied in the epilogue of the
+ *   are one launch whose workgroups hand the few floats that cross them over through an exchange
+ *   area polled with agent-scope loads: 5 launches with the actor due, 3 without) and torch.optim.Adam [+ the polyak update] applied in the epilogue of the
  *   weight-gradient launches (same expressions as tonic_adam_step / tonic_polyak_update).
  *   Single rank and no gradient clipping: several ranks (an all-reduce sits between the gradients
  *   and the step) and `gradient_clip` use the split entry points.  kind as tonic_twin_q_grad
@@ -562,10 +562,13 @@ typedef struct tonic_q_iteration_t {
   double critic_entropy_coeff, actor_entropy_coeff, noise_scale, noise_clip, target_coeff;
   tonic_q_optimizer critic, actor;
   void* d_workspace; int64_t workspace_bytes;   /* ZERO-FILLED when first handed over: its first
-                                  64 KB hold the arrival words through which the workgroups of the
-                                  chained launches (critic step: targets -> online critics' loss and
-                                  chain; actor step: critics -> objective -> chain -> actor chain)
-                                  wait for each other; every call leaves them zero                */
+                                  word is the failure flag of the chained launches (critic step:
+                                  targets -> online critics' loss and chain; actor step: critics ->
+                                  objective -> chain -> actor chain), whose workgroups hand the few
+                                  floats that cross them over through an exchange area in the
+                                  workspace: written once per iteration with agent-scope stores, read
+                                  with agent-scope loads until they are no longer the "empty" pattern
+                                  the iteration's first launch fills the area with                  */
 } tonic_q_iteration_t;
 
 int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);

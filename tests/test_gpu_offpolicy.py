@@ -373,7 +373,12 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
     assert np.abs(results['split']['online']).max() > 0 and np.isfinite(results['split']['online']).all()
     for mode in ('fused', 'fused-graph'):
         for key, want in results['split'].items():
-            assert np.array_equal(results[mode][key], want), (mode, key)
+            got = results[mode][key]
+            if not np.array_equal(got, want):           # (say WHERE: NaN counts as a mismatch)
+                where = np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
+                first = tuple(where[0]) if len(where) else ()
+                raise AssertionError((mode, key, len(where), first,
+                                      got[first] if first else None, want[first] if first else None))
 
 
 def test_adam_polyak_step_equals_the_two_calls(lib):

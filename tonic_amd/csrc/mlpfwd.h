@@ -57,6 +57,25 @@ __host__ __device__ inline int sample_group(int A) { int g = 1; while (g < A && 
 
 enum PolicyPost : int { POST_NONE = 0, POST_SQUASHED_SAMPLE = 1, POST_TARGET_NOISE = 2, POST_COPY = 3 };
 
+// Where value z (a network of the launch) of batch row r lives: z * net + (r / 16) * tile + r % 16.
+// Dense arrays [nets][Bp]: {Bp, 16}.  The EXCHANGE LINES of the chained launches (q_chain kernels):
+// 128-byte lines per 16-row tile, ONE WRITER per line and ONE WRITE per line between two resets (the
+// critic step and the actor step of an iteration have lines of their own: a reader must find a line
+// either empty or final) —
+//   line z      the 16 values of network z of the launch's first parameter set (the targets of the
+//               critic step, the critics of the actor step): {32, 128}
+//   line 2 + z  the 16 values of network z of the second set (the online critics): {32, 128} from + 64
+// A line is only ever read after its writer has published it, and nobody else writes into it: the
+// loads are agent-scope, but a line that sits in an XCD's L2 is served from there — so a line that
+// two workgroups share (two tiles' values, or the twin critics' halves) reaches a reader's L2, or the
+// L2 of a writer that reads it back, with the other half still unwritten (seen as stale q values
+// in the logged sums and in the twin critics' objective when the lines were shared).
+struct ValueLines {
+  int net, tile;
+  __host__ __device__ int index(int z, int r) const { return z * net + (r >> 4) * tile + (r & 15); }
+};
+constexpr int kExchangeTileFloats = 256;               // 8 lines of 32 floats: 0 - 3 the critic step's, 4 - 5 the actor step's
+
 struct MlpFwdArgs {
   const float* X;            // [B, ldx] inputs, K1 columns used
   int ldx, K1;
@@ -98,7 +117,9 @@ struct MlpFwdArgs {
   float enc_clip;                                                       // MeanStd(clip): +inf = none
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
-  int coherent_out;             // q_chain_kernel: the value head's output is read by other workgroups of the same launch
+  float* reset_area; int64_t reset_floats;   // the launch AHEAD of the chained ones: fill with kExchangeEmpty
+  float* xq;                    // chained launches: the value head's outputs ALSO go (agent-scope stores) to the launch's
+                                //   exchange lines, see ValueLines; null: none
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
   // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
@@ -144,6 +165,7 @@ struct MlpBwdArgs {
   const float* l_q; float* l_stats;
   float l_alpha;
   int l_nets, l_Bp;
+  ValueLines l_tq_at, l_q_at;   // where value z of row r lives in l_tq / l_q (dense: {Bp, 16})
   // heads >= 1, hb_dxa0 != null: the gradients at the head outputs are not given but FORMED here
   // from the critics' action-column input gradients (actor_head_backward_kernel folded into this
   // launch, same expressions -> same bits) and written to dhead[0] / dhead[1] for the
@@ -153,29 +175,64 @@ struct MlpBwdArgs {
   const float* hb_spre;                            // [B, ldh] pre-softplus scale head (SAC)
   int hb_ldxa, hb_sac;
   float hb_alpha;
-  int coherent;                 // q_chain_kernel: see mlp_backward_body
+  unsigned* exchange_failed;    // chained launches: l_tq / l_q / hb_dxa* are exchange words (exchange_read), dxa is
+                                //   written with exchange_write; the word a reader sets when a value never came
 };
 enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 
 // The TD target and the errors of one sample (shared by critic_loss_kernel and the folded form)
-// (`coherent`: tq / q were written by other workgroups of the same launch -> agent-scope loads)
-__device__ __forceinline__ float shared_value(const float* p, bool coherent) {
-  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+// ---- hand-over between the workgroups of a chained launch: "the data is its own flag"
+// An exchanged float is written ONCE per launch with an agent-scope store and read with agent-scope
+// loads until it is no longer kExchangeEmpty — the pattern every exchanged word holds when the launch
+// starts (the launch ahead of the chained ones fills the exchange area with it).  Each location is
+// coherent by itself (a relaxed atomic at agent scope); nothing is assumed about the ORDER in which
+// two locations become visible.  (An arrival counter behind `s_waitcnt vmcnt(0)` is not enough on
+// gfx950: the data's write-through may still be on its way when the counter — an atomic performed at
+// the memory side — is already seen: 1 run in 3 of the bit-identity test read a stale q; and a release
+// fence that waits for it is an L2 write-back of everything the XCD has dirtied: +13 % per iteration.)
+constexpr unsigned kExchangeEmpty = 0x7fa5c3e1u;       // a signalling-NaN pattern no arithmetic produces
+constexpr unsigned long long kChainTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock
+
+__device__ __forceinline__ float exchange_read(const float* p, unsigned* failed) {
+  const unsigned* word = reinterpret_cast<const unsigned*>(p);
+  unsigned bits = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bits == kExchangeEmpty) {
+    const unsigned long long t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(1);
+      bits = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wall_clock64() - t0 > kChainTimeoutTicks) {         // a lost workgroup must not hang the device
+        __hip_atomic_store(failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    } while (bits == kExchangeEmpty);
+  }
+  return __uint_as_float(bits);
+}
+__device__ __forceinline__ void exchange_write(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (`exchange`: tq / q are written by other workgroups of the same launch; null: plain loads)
+__device__ __forceinline__ float shared_value(const float* p, unsigned* exchange) {
+  return exchange != nullptr ? exchange_read(p, exchange) : *p;
 }
 __device__ __forceinline__ float td_target(const float* rewards, const float* discounts,
                                            const float* tq, const float* logp_next, float alpha,
-                                           int m, int Bp, int nets, bool coherent = false) {
-  if (nets == 1) return rewards[m] + discounts[m] * shared_value(tq + m, coherent);
-  float next = fminf(shared_value(tq + m, coherent), shared_value(tq + Bp + m, coherent));
+                                           int m, ValueLines at, int nets,
+                                           unsigned* coherent = nullptr) {
+  if (nets == 1) return rewards[m] + discounts[m] * shared_value(tq + at.index(0, m), coherent);
+  float next = fminf(shared_value(tq + at.index(0, m), coherent),
+                     shared_value(tq + at.index(1, m), coherent));
   if (logp_next) next = next - alpha * logp_next[m];
   return rewards[m] + discounts[m] * next;
 }
 
 // d (actor objective) / d q_z of one sample (shared by actor_loss_kernel and the folded form)
-__device__ __forceinline__ float actor_dq(const float* q, int m, int Bp, int twin, int z,
-                                          bool coherent = false) {
+__device__ __forceinline__ float actor_dq(const float* q, int m, ValueLines at, int twin, int z,
+                                          unsigned* coherent = nullptr) {
   if (!twin) return -1.f;
-  const float q1 = shared_value(q + m, coherent), q2 = shared_value(q + Bp + m, coherent);
+  const float q1 = shared_value(q + at.index(0, m), coherent),
+              q2 = shared_value(q + at.index(1, m), coherent);
   if (z == 0) return q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
   return q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
 }
@@ -199,28 +256,19 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
 
 // ---- several dependent passes over the same 16-row tiles as ONE launch (q_chain kernels, mlpfwd.hip)
 // The workgroups of a launch are numbered tile-major — the `roles` workgroups of a tile are
-// neighbours in dispatch order and a role only ever waits for roles of the same tile (a lower
-// index, or — the twin critics of the actor step — its immediate neighbour), so whatever part of
-// the grid is resident can always make progress.  What crosses workgroups inside a launch (q
-// values, action-column gradients: a few floats per row) is written with agent-scope stores and
-// read with agent-scope loads (the XCDs' L2s are not coherent with each other inside a kernel),
-// ordered by "s_waitcnt vmcnt(0), then the arrival counter" like the carries of gae_onepass_kernel.
-// `sync`: kChainWordsPerTile words per tile + kChainGlobalWords, ZERO when the first launch sees
-// them; every launch leaves them zero.  A peer that does not arrive within kChainTimeoutTicks
-// (a lost workgroup, a corrupted word) does not hang the device: the waiter goes on, the step's
-// logged loss becomes NaN.
-constexpr int kChainWordsPerTile = 4, kChainGlobalWords = 4;
-constexpr unsigned long long kChainTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock
-inline int64_t chain_sync_words(int B) { return (int64_t)((B + 15) / 16) * kChainWordsPerTile + kChainGlobalWords; }
-
-// Critic step: roles [target_0 .. target_{nets-1} | online_0 .. online_{nets-1}] — the targets'
-// forward on (s', a'), the online critics' forward on (s, a), and — once both targets of the tile
-// have arrived — the TD loss and the online critics' input-gradient chain.
+// neighbours in dispatch order and a role only ever waits for values of roles of the same tile (a
+// lower index, or — the twin critics of the actor step — its immediate neighbour), so whatever part
+// of the grid is resident can always make progress.  What crosses workgroups inside a launch (q
+// values, action-column gradients: a few floats per row) goes through the launch's exchange area:
+// see exchange_read / ValueLines.  A value that does not come within kChainTimeoutTicks (a lost
+// workgroup) does not hang the device: the reader goes on, the step's logged loss becomes NaN.
+// Critic step: roles [target_0 .. target_{nets-1} | online_0 .. online_{nets-1}] (+ one workgroup
+// for the logged sums) — the targets' forward on (s', a'), the online critics' forward on (s, a),
+// and — with the targets' values of the tile — the TD loss and the online critics' input-gradient chain.
 struct QCriticStep {
   MlpFwdArgs fwd;            // 2 nets networks: targets on X, online (second set) on X2; split = nets
   MlpBwdArgs bwd;            // the online critics' chain, loss = LOSS_TD
   int nets;
-  unsigned* sync;
 };
 // Actor step: roles [critic_0 .. critic_{used-1} | actor] — the critics' forward on (s, a_new), the
 // actor objective (the twin critics exchange q), their chain down to the action columns, then the
@@ -230,7 +278,6 @@ struct QActorStep {
   MlpBwdArgs bwd;            // their chain, loss = LOSS_ACTOR, dxa
   MlpBwdArgs actor;          // head backward (formed from dxa) + the actor's chain
   int used;
-  unsigned* sync;
 };
 int launch_q_critic_step(const QCriticStep& c, hipStream_t stream);
 int launch_q_actor_step(const QActorStep& c, hipStream_t stream);

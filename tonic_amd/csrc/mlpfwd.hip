@@ -63,96 +63,132 @@ constexpr int kHalf = 2;
 
 // KS = false: the weight rows are k-contiguous (forward: W[out][k]); KS = true: k-strided
 // (backward through W^T: element (out, k) lives at W[k][out], i.e. base + k * ld + out).
+//
+// Addressing: BUFFER loads — the tensor as a buffer resource (four SGPRs), off[j] this lane's 32-bit
+// byte offset inside it (tile j's row / column + its k group) and the chunk's byte offset as the
+// scalar offset operand: a load costs no vector address arithmetic at all.  (Per-lane 64-bit row
+// pointers cost a v_lshl_add_u64 per load — also in the `scalar base + zero-extended offset` form,
+// once the zero-extension has been hoisted out of the loop — and VALU instructions do not overlap
+// fp32 MFMAs on gfx950: ~50 of them per 64 MFMAs of the layer loops, profiles/r03_offpolicy_phases.md.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_buffer(const float* tensor) {
+  // raw buffer (stride 0), no bound in practice; 0x00020000: 32-bit float data format (gfx9)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tensor), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buffer4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned chunk_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, chunk_bytes, 0));
+}
+__device__ __forceinline__ float buffer1(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned chunk_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, chunk_bytes, 0));
+}
+
 template <int TILES, bool KS = false>
 struct Layer {
-  const float* wrow[TILES];      // KS: column pointers W + out
-  int K, nfull, ld;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned off[TILES];           // BYTES: !KS 4 (row_j * ld + 4 kg);  KS 4 (4 kg * ld + column_j)
+  int K, nfull, ld, kg;
 
-  __device__ __forceinline__ f32x4 weights(const float* w, int k) const {
-    if (!KS) return load_w4(w, k);
+  // chunk c (k = 16 c .. 16 c + 15) of tile j: this lane's four k
+  __device__ __forceinline__ f32x4 weights(int j, int c) const {
+    if (!KS) return buffer4(rsrc, off[j], 64u * (unsigned)c);
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)(k + e) * ld];
+    for (int e = 0; e < 4; ++e) v[e] = buffer1(rsrc, off[j], 4u * (unsigned)((16 * c + e) * ld));
     return v;
   }
-  __device__ __forceinline__ f32x4 weights_tail(const float* w, int k) const {
+  __device__ __forceinline__ f32x4 weights_tail(int j) const {
     // (k-contiguous rows are padded to a multiple of 4 floats: the chunk is clamped into the
     //  row, whatever lies at k >= K meets a zeroed B operand)
-    if (!KS) return load_w4(w, min(k, (K + 3) / 4 * 4 - 4));
+    const int k = 16 * nfull + 4 * kg;
+    if (!KS) return buffer4(rsrc, off[j] + 4u * (unsigned)(min(k, (K + 3) / 4 * 4 - 4) - 4 * kg), 0u);
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = w[(int64_t)min(k + e, K - 1) * ld];
+    for (int e = 0; e < 4; ++e)
+      v[e] = buffer1(rsrc, off[j] + 4u * (unsigned)((min(k + e, K - 1) - 4 * kg) * ld), 0u);
     return v;
   }
 
   f32x4 a0[kHalf][TILES];        // weight operands of the first set
   f32x4 at[TILES];               // weight operands of the ragged last chunk (K % 16 != 0)
 
-  __device__ __forceinline__ void start(const float* const (&rows)[TILES], int K_, int kg,
-                                        int ld_ = 0) {
-    K = K_; nfull = K / 16; ld = ld_;
+  // lane_first[j]: !KS the first element of tile j's row of this lane (row * ld); KS its column
+  __device__ __forceinline__ void start(const float* tensor, const unsigned (&lane_first)[TILES],
+                                        int K_, int kg_, int ld_) {
+    rsrc = weight_buffer(tensor); K = K_; nfull = K / 16; ld = ld_; kg = kg_;
 #pragma unroll
-    for (int j = 0; j < TILES; ++j) wrow[j] = rows[j];
+    for (int j = 0; j < TILES; ++j) off[j] = 4u * (lane_first[j] + (KS ? 4 * kg * ld : 4 * kg));
 #pragma unroll
     for (int q = 0; q < kHalf; ++q) {
-      const int k = 16 * min(q, max(nfull - 1, 0)) + 4 * kg;
+      const int c = min(q, max(nfull - 1, 0));
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) a0[q][j] = nfull > 0 ? weights(wrow[j], k) : f32x4{0, 0, 0, 0};
+      for (int j = 0; j < TILES; ++j) a0[q][j] = nfull > 0 ? weights(j, c) : f32x4{0, 0, 0, 0};
     }
     if (K % 16 != 0) {
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) at[j] = weights_tail(wrow[j], 16 * nfull + 4 * kg);
+      for (int j = 0; j < TILES; ++j) at[j] = weights_tail(j);
+    }
+  }
+
+  // EXACT: nfull is a multiple of the four chunks of a round — no chunk of the loop is a re-read,
+  // so the B operands go to the MFMAs as they come (else: times 1 / 0, four VALU instructions per
+  // chunk in the MFMA stream)
+  template <bool EXACT, typename BFull>
+  __device__ __forceinline__ void loop(f32x4 (&acc)[TILES], BFull bfull) {
+    f32x4 aA[kHalf][TILES], aB[kHalf][TILES], bA[kHalf], bB[kHalf];
+    auto fill_a = [&](f32x4 (&a)[kHalf][TILES], int first) {
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) {
+        const int c = min(first + q, nfull - 1);
+#pragma unroll
+        for (int j = 0; j < TILES; ++j) a[q][j] = weights(j, c);
+      }
+    };
+    auto fill_b = [&](f32x4 (&b)[kHalf], int first) {
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) b[q] = bfull(16 * min(first + q, nfull - 1) + 4 * kg);
+    };
+    auto compute = [&](const f32x4 (&a)[kHalf][TILES], const f32x4 (&b)[kHalf], int first) {
+#pragma unroll
+      for (int q = 0; q < kHalf; ++q) {
+        f32x4 bb = b[q];
+        if (!EXACT) {
+          const float live = first + q < nfull ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[e] = b[q][e] * live;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {               // e outer: the tiles are independent chains
+#pragma unroll
+          for (int j = 0; j < TILES; ++j) acc[j] = mfma16(a[q][j][e], bb[e], acc[j]);
+        }
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < kHalf; ++q) {
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) aA[q][j] = a0[q][j];
+    }
+    fill_b(bA, 0);
+    const int rounds = (nfull + 2 * kHalf - 1) / (2 * kHalf);
+    for (int r = 0; r < rounds; ++r) {
+      const int c = 2 * kHalf * r;
+      fill_a(aB, c + kHalf); fill_b(bB, c + kHalf);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(aA, bA, c);
+      __builtin_amdgcn_sched_barrier(0);
+      fill_a(aA, c + 2 * kHalf); fill_b(bA, c + 2 * kHalf);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(aB, bB, c + kHalf);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   template <typename BFull, typename BTail>
-  __device__ __forceinline__ void run(int kg, f32x4 (&acc)[TILES], BFull bfull, BTail btail) {
+  __device__ __forceinline__ void run(f32x4 (&acc)[TILES], BFull bfull, BTail btail) {
     if (nfull > 0) {
-      f32x4 aA[kHalf][TILES], aB[kHalf][TILES], bA[kHalf], bB[kHalf];
-      auto fill_a = [&](f32x4 (&a)[kHalf][TILES], int first) {
-#pragma unroll
-        for (int q = 0; q < kHalf; ++q) {
-          const int k = 16 * min(first + q, nfull - 1) + 4 * kg;
-#pragma unroll
-          for (int j = 0; j < TILES; ++j) a[q][j] = weights(wrow[j], k);
-        }
-      };
-      auto fill_b = [&](f32x4 (&b)[kHalf], int first) {
-#pragma unroll
-        for (int q = 0; q < kHalf; ++q) b[q] = bfull(16 * min(first + q, nfull - 1) + 4 * kg);
-      };
-      auto compute = [&](const f32x4 (&a)[kHalf][TILES], const f32x4 (&b)[kHalf], int first) {
-#pragma unroll
-        for (int q = 0; q < kHalf; ++q) {
-          const float live = first + q < nfull ? 1.f : 0.f;
-          f32x4 bb;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bb[e] = b[q][e] * live;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {               // e outer: the tiles are independent chains
-#pragma unroll
-            for (int j = 0; j < TILES; ++j) acc[j] = mfma16(a[q][j][e], bb[e], acc[j]);
-          }
-        }
-      };
-#pragma unroll
-      for (int q = 0; q < kHalf; ++q) {
-#pragma unroll
-        for (int j = 0; j < TILES; ++j) aA[q][j] = a0[q][j];
-      }
-      fill_b(bA, 0);
-      const int rounds = (nfull + 2 * kHalf - 1) / (2 * kHalf);
-      for (int r = 0; r < rounds; ++r) {
-        const int c = 2 * kHalf * r;
-        fill_a(aB, c + kHalf); fill_b(bB, c + kHalf);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(aA, bA, c);
-        __builtin_amdgcn_sched_barrier(0);
-        fill_a(aA, c + 2 * kHalf); fill_b(bA, c + 2 * kHalf);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(aB, bB, c + kHalf);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (nfull % (2 * kHalf) == 0) loop<true>(acc, bfull);      // scalar
+      else loop<false>(acc, bfull);
     }
     if (K % 16 != 0) {                                // ragged last chunk
       const int k = 16 * nfull + 4 * kg;
@@ -213,6 +249,14 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
   float* h2g = a.h2 + net * a.stride_hidden;
   float* hx = lds;
   float* hy = lds + kRows * pitch;
+  if (a.reset_area != nullptr) {
+    // the launch AHEAD of the chained ones empties their exchange area (kExchangeEmpty everywhere):
+    // plain stores, published by the kernel boundary
+    const int64_t first = ((int64_t)net * gridDim.x + bx) * blockDim.x + tid;
+    const int64_t stride = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+    unsigned* area = reinterpret_cast<unsigned*>(a.reset_area);
+    for (int64_t i = first; i < a.reset_floats; i += stride) area[i] = kExchangeEmpty;
+  }
   // wave w owns tiles w, w + 4, w + 8, w + 12; an index beyond the layer is clamped (the wave
   // then recomputes the last tile and drops it: no branch around an MFMA)
   int tile_of[kMaxTiles];
@@ -263,25 +307,24 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
     }
   };
 
-  const float* rows1[kMaxTiles];
-  const float* rows2[kMaxTiles];
+  unsigned rows1[kMaxTiles], rows2[kMaxTiles];       // first element of this lane's weight rows
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) {
-    rows1[j] = W1 + (int64_t)(16 * tile_of[j] + m) * a.ldw1;
-    rows2[j] = W2 + (int64_t)(16 * tile_of[j] + m) * a.ldw2;
+    rows1[j] = (unsigned)(16 * tile_of[j] + m) * a.ldw1;
+    rows2[j] = (unsigned)(16 * tile_of[j] + m) * a.ldw2;
   }
   f32x4 acc[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* xrow = (second ? a.X2 : a.X) + (int64_t)row * a.ldx;
   Layer<kMaxTiles> l1;
-  l1.start(rows1, a.K1, kg);
+  l1.start(W1, rows1, a.K1, kg, a.ldw1);
   stamp(1);
-  l1.run(kg, acc, [&](int k) { return load_k4(xrow, k); },
+  l1.run(acc, [&](int k) { return load_k4(xrow, k); },
          [&](int k) { return load_k4_tail(xrow, k, a.K1); });
   stamp(2);
   Layer<kMaxTiles> l2;
-  l2.start(rows2, H, kg);                             // W2's first operands fly over the epilogue
+  l2.start(W2, rows2, H, kg, a.ldw2);                 // W2's first operands fly over the epilogue
   finish(acc, bias1, h1g, hx);
   __syncthreads();
   stamp(3);
@@ -289,7 +332,7 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto from_hx = [&](int k) { return *reinterpret_cast<const f32x4*>(hx + m * pitch + k); };
-  l2.run(kg, acc, from_hx, from_hx);
+  l2.run(acc, from_hx, from_hx);
   stamp(4);
   // A head tile is one dependent chain of H / 4 MFMAs on one wave with nothing to hide a load
   // behind: its whole weight row (H <= 256: 16 loads per lane) is requested here, over the
@@ -325,11 +368,11 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
     if (wave == 0 && kg == 0 && row_ok) {
       float* out_base = a.out[0];
       const float q = ((partial[m] + partial[16 + m]) + (partial[32 + m] + partial[48 + m])) + hbias[0];
-      float* dst = out_base + net * a.stride_out + (int64_t)(r0 + m) * a.ldo;
-      if (a.coherent_out)          // read by other workgroups of the same launch (q_chain_kernel)
-        __hip_atomic_store(dst, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        *dst = q;
+      out_base[net * a.stride_out + (int64_t)(r0 + m) * a.ldo] = q;
+      if (a.xq != nullptr) {       // read by other workgroups of the same launch (ValueLines)
+        const int slot = net < a.split ? 32 * net : 32 * (2 + net - a.split);     // one line per writer
+        exchange_write(a.xq + (int64_t)bx * kExchangeTileFloats + slot + m, q);
+      }
     }
     stamp(6);
     return;
@@ -460,55 +503,27 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
 // w+4, ..., D[feature][row] products, LDS exchange between the layers; the weights are walked
 // along their rows (W^T), i.e. k-strided loads.  dz2 / dz1 are written to HBM for the weight
 // gradients.
-// ---- arrival words of the chained launches (mlpfwd.h, q_critic_step_kernel / q_actor_step_kernel)
-__device__ __forceinline__ unsigned chain_load(const unsigned* word) {
-  return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void chain_store(unsigned* word, unsigned v) {
-  __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned chain_add(unsigned* word) {
-  return __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Thread 0 waits until `need` peers have arrived at `word`; the barrier behind it also publishes
-// this workgroup's own stores to its own waves.  Bounded: see kChainTimeoutTicks.
-__device__ __forceinline__ void chain_wait(const unsigned* word, unsigned need, unsigned* failed) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    while (chain_load(word) < need) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > kChainTimeoutTicks) {
-        chain_store(failed, 1u);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-
-// `coherent` (q_chain_kernel): what other workgroups of the SAME launch wrote (l_tq, l_q, hb_dxa*)
-// is read with agent-scope loads, and dxa is written with agent-scope stores.
-__device__ __forceinline__ float load_shared(const float* p, bool coherent) {
-  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+// Chained launches: what other workgroups of the SAME launch wrote (l_tq, l_q, hb_dxa*) is read
+// with exchange_read, and dxa is written with exchange_write (mlpfwd.h).
+__device__ __forceinline__ float load_shared(const float* p, unsigned* exchange_failed) {
+  return exchange_failed != nullptr ? exchange_read(p, exchange_failed) : *p;
 }
 
 // The logged sums of the step's loss over the whole batch (one workgroup; result -> l_stats)
 __device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed) {
   const int tid = threadIdx.x;
-  const bool co = a.coherent != 0;
+  unsigned* co = a.exchange_failed;                   // null: plain loads
   double s0 = 0, s1 = 0, s2 = 0;
   for (int r = tid; r < a.B; r += blockDim.x) {
     if (a.loss == LOSS_TD) {
-      const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, r, a.l_Bp,
+      const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, r, a.l_tq_at,
                                 a.l_nets, co);
-      const float q1 = load_shared(a.l_q + r, co);
+      const float q1 = load_shared(a.l_q + a.l_q_at.index(0, r), co);
       const float e1 = q1 - y;
       float sq = e1 * e1;
       s1 += q1;
       if (a.l_nets == 2) {
-        const float q2 = load_shared(a.l_q + a.l_Bp + r, co);
+        const float q2 = load_shared(a.l_q + a.l_q_at.index(1, r), co);
         const float e2 = q2 - y;
         sq = sq + e2 * e2;
         s2 += q2;
@@ -516,9 +531,10 @@ __device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed)
       s0 += sq;
     } else if (a.l_nets == 2) {
       s0 += a.l_alpha * a.l_logp[r] -
-            fminf(load_shared(a.l_q + r, co), load_shared(a.l_q + a.l_Bp + r, co));
+            fminf(load_shared(a.l_q + a.l_q_at.index(0, r), co),
+                  load_shared(a.l_q + a.l_q_at.index(1, r), co));
     } else {
-      s0 += -load_shared(a.l_q + r, co);
+      s0 += -load_shared(a.l_q + a.l_q_at.index(0, r), co);
     }
   }
   block_sum3(s0, s1, s2);
@@ -531,20 +547,18 @@ __device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed)
   }
 }
 
-// `wait_word` (chained launches): the peers whose values this pass consumes — the TD target's q,
-// the twin's q, the critics' action-column gradients — are awaited HERE, after everything that
-// does not depend on them (ReLU masks, the first weight operands, the head backward's own
-// operands) has been requested: the hand-over's latency runs under those loads.
+// Chained launches (a.exchange_failed != null): what this pass consumes of its peers — the TD
+// target's q, the twin's q, the critics' action-column gradients — is read (exchange_read) AFTER
+// everything that does not depend on them (ReLU masks, the first weight operands, the head
+// backward's own operands) has been requested: the hand-over's latency runs under those loads.
 __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int net, const int bx,
-                                                  float* lds, const unsigned* wait_word = nullptr,
-                                                  unsigned wait_need = 0,
-                                                  unsigned* wait_failed = nullptr) {
+                                                  float* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kg = lane >> 4;
   const int H = a.H, pitch = H + 4, tiles = H / 16;
   const int r0 = bx * kRows;
-  const bool co = a.coherent != 0;                    // scalar
+  unsigned* co = a.exchange_failed;                   // scalar; null: plain loads / stores
   const int row = min(r0 + m, a.B - 1);
   const bool row_ok = r0 + m < a.B;
   const float* W2 = a.W2 + net * a.stride_params;
@@ -578,9 +592,9 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
 #pragma unroll
     for (int u = 0; u < kHeadSlots; ++u) {
       const int aa = min(hb_slot + 16 * u, A - 1);
-      if (wait_word == nullptr) {                     // (scalar; else: after the wait below)
-        hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
-        hb_second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+      if (co == nullptr) {                            // (scalar; chained: further down)
+        hb_da[u] = a.hb_dxa0[src * a.hb_ldxa + aa];
+        hb_second[u] = dxa1[src * a.hb_ldxa + aa];
       }
       hb_t[u] = a.hb_act[src * A + aa];
       hb_sg[u] = sgp[src * A + aa];
@@ -618,25 +632,28 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
     }
   };
 
-  const float* cols2[kMaxTiles];
+  unsigned cols2[kMaxTiles];
 #pragma unroll
-  for (int j = 0; j < kMaxTiles; ++j) cols2[j] = W2 + 16 * tile_of[j] + m;
+  for (int j = 0; j < kMaxTiles; ++j) cols2[j] = 16 * tile_of[j] + m;
   Layer<kMaxTiles, true> l1;                          // dz1 = W2^T dz2: requested before dz2 exists
-  const float* wcol = W2 + 64 * wave + 4 * m;         // wide: this lane's four output columns
+  // wide: this lane's four output columns of row 4 kg (+ e) of a chunk — scalar row base + one
+  // 32-bit lane offset (see Layer)
+  const unsigned wcol = 4u * ((unsigned)(4 * kg) * a.ldw2 + 64 * wave + 4 * m);       // bytes
+  const __amdgpu_buffer_rsrc_t w2_buffer = weight_buffer(W2);
   f32x4 wa[kHalf][4], wb[kHalf][4];                   // wide operand sets: [chunk][e] -> tiles 0..3
   auto wfill = [&](f32x4 (&w)[kHalf][4], int first) {
 #pragma unroll
     for (int q = 0; q < kHalf; ++q) {
-      const int k = 16 * min(first + q, tiles - 1) + 4 * kg;      // past the end: re-read, unused
+      const int c = min(first + q, tiles - 1);                    // past the end: re-read, unused
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[q][e] = load_w4(wcol + (int64_t)(k + e) * a.ldw2, 0);
+      for (int e = 0; e < 4; ++e)
+        w[q][e] = buffer4(w2_buffer, wcol, 4u * (unsigned)((16 * c + e) * a.ldw2));
     }
   };
   if (wide) wfill(wa, 0);
-  else l1.start(cols2, H, kg, a.ldw2);
+  else l1.start(W2, cols2, H, kg, a.ldw2);
 
-  if (wait_word != nullptr) {                         // scalar
-    chain_wait(wait_word, wait_need, wait_failed);
+  if (co != nullptr) {                                // scalar
     if (formed) {
       const int A = a.NH;
       const int64_t src = min((int64_t)r0 + hb_row, (int64_t)a.B - 1);
@@ -663,10 +680,10 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
     } else {                                          // the step's loss, folded into this launch
       if (a.loss == LOSS_TD) {
         const float y = td_target(a.l_rewards, a.l_discounts, a.l_tq, a.l_logp, a.l_alpha, row,
-                                  a.l_Bp, a.l_nets, co);
-        dq = 2.f * (load_shared(a.l_q + net * a.l_Bp + row, co) - y);
+                                  a.l_tq_at, a.l_nets, co);
+        dq = 2.f * (load_shared(a.l_q + a.l_q_at.index(net, row), co) - y);
       } else {
-        dq = actor_dq(a.l_q, row, a.l_Bp, a.l_nets == 2, net, co);
+        dq = actor_dq(a.l_q, row, a.l_q_at, a.l_nets == 2, net, co);
       }
       if (row_ok && wave == 0 && kg == 0)             // for the weight-gradient GEMM (dw3, db3)
         const_cast<float*>(a.dq)[net * a.stride_dq + row] = dq;
@@ -718,17 +735,14 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
       const float* Wh = (h == 0 ? a.Wh[0] : a.Wh[1]) + net * a.stride_params;
       const float* dh = (h == 0 ? a.dhead[0] : a.dhead[1]) + (int64_t)row * a.ldh;
       const float* dl = dhl + (h * kRows + m) * kHeadPitch;
-      const float* colsh[kMaxTiles];
-#pragma unroll
-      for (int j = 0; j < kMaxTiles; ++j) colsh[j] = Wh + 16 * tile_of[j] + m;
       Layer<kMaxTiles, true> lh;
-      lh.start(colsh, a.NH, kg, a.ldw2);
+      lh.start(Wh, cols2, a.NH, kg, a.ldw2);
       if (formed) {
         auto from_dl = [&](int k) { return *reinterpret_cast<const f32x4*>(dl + k); };
-        lh.run(kg, acc, from_dl, from_dl);
+        lh.run(acc, from_dl, from_dl);
       } else {
         auto from_dh = [&](int k) { return load_k4(dh, k); };     // rows are padded to ldh >= 16
-        lh.run(kg, acc, from_dh, from_dh);
+        lh.run(acc, from_dh, from_dh);
       }
     }
   }
@@ -766,13 +780,12 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
-    l1.run(kg, acc, from_hx, from_hx);
+    l1.run(acc, from_hx, from_hx);
   }
   Layer<1, true> lx;
   const bool xa_wave = 16 * wave < a.xa_count;      // one 16-column tile per wave
-  const float* colsx[1] = {a.W1 + net * a.stride_params + a.xa_first +
-                           min(16 * wave + m, max(a.xa_count - 1, 0))};
-  if (xa_wave) lx.start(colsx, H, kg, a.ldw1);
+  const unsigned colsx[1] = {(unsigned)(a.xa_first + min(16 * wave + m, max(a.xa_count - 1, 0)))};
+  if (xa_wave) lx.start(a.W1 + net * a.stride_params, colsx, H, kg, a.ldw1);
   if (wide) {                                         // register e of tile j: feature .. + 4 e + j
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -792,21 +805,21 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
   if (xa_wave) {                                      // [16 action columns][16 rows] of dz1 . W1
     f32x4 out[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
     auto from_hy = [&](int k) { return *reinterpret_cast<const f32x4*>(hy + m * pitch + k); };
-    lx.run(kg, out, from_hy, from_hy);
+    lx.run(out, from_hy, from_hy);
     if (row_ok) {
       float* dst = a.dxa + net * a.stride_dxa + (int64_t)(r0 + m) * a.ldxa;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 16 * wave + 4 * kg + e;
         if (o < a.xa_count) {
-          if (co) __hip_atomic_store(dst + o, out[0][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (co != nullptr) exchange_write(dst + o, out[0][e]);
           else dst[o] = out[0][e];
         }
       }
     }
   }
   // the logged sums (uniform); a chain launch leaves them to its last workgroup
-  if (a.loss != LOSS_GIVEN && !co && bx == 0 && net == 0) mlp_loss_stats(a, false);
+  if (a.loss != LOSS_GIVEN && co == nullptr && bx == 0 && net == 0) mlp_loss_stats(a, false);
 }
 
 __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
@@ -815,30 +828,19 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 }
 
 // ------------------------------------------------------------------ chained passes (mlpfwd.h)
-// The value head's outputs are stored by wave 0 (mlp_forward_body): their acknowledgement, then
-// the arrival.
-__device__ __forceinline__ void chain_arrive_after_values(unsigned* tile_word, unsigned* all_word) {
-  if (threadIdx.x < 64) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      if (tile_word != nullptr) chain_add(tile_word);
-      chain_add(all_word);
-    }
-  }
-}
-
-// The launch's LAST workgroup is nobody's tile: it waits until every value of the launch has been
-// published (`all_word` counts the publishers) and forms the logged sums of the step's loss while
-// the other workgroups run their chains — in a launch of their own they were the by-product of
-// workgroup (0, 0); at the end of the last chain they would be 2 - 3 us of the critical path.
-__device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b, unsigned* all_word,
-                                                 unsigned* failed, unsigned publishers) {
-  chain_wait(all_word, publishers, failed);
-  const bool bad = chain_load(failed) != 0;
-  mlp_loss_stats(b, bad);
+// The launch's LAST workgroup is nobody's tile: it forms the logged sums of the step's loss from the
+// exchanged values (waiting for each as it goes) while the other workgroups run their chains — in a
+// launch of their own they were the by-product of workgroup (0, 0); at the end of the last chain
+// they would be 2 - 3 us of the critical path.
+__device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b) {
+  __shared__ int bad;
+  mlp_loss_stats(b, false);                           // (reads every value: all published after it)
   if (threadIdx.x == 0) {
-    chain_store(all_word, 0u);
-    if (bad) chain_store(failed, 0u);
+    bad = __hip_atomic_load(b.exchange_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (bad) {                                        // a value that never came: not a training step
+      b.l_stats[0] = __builtin_nanf("");
+      __hip_atomic_store(b.exchange_failed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -847,24 +849,14 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
   const int roles = 2 * c.nets;
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
-  unsigned* word = c.sync + kChainWordsPerTile * tile;
-  unsigned* global = c.sync + kChainWordsPerTile * tiles;       // [-, failed, values published]
   if (tile == tiles) {                                // the extra workgroup: the logged sums
-    chain_stats_role(c.bwd, global + 2, global + 1, roles * tiles);
+    chain_stats_role(c.bwd);
     return;
   }
-  mlp_forward_body(c.fwd, role, tile, lds);
-  if (role < c.nets) {                                // a target: its values, then its arrival
-    chain_arrive_after_values(word, global + 2);
-    return;
-  }
-  chain_arrive_after_values(nullptr, global + 2);
+  mlp_forward_body(c.fwd, role, tile, lds);           // (its values -> the tile's exchange lines)
+  if (role < c.nets) return;                          // a target
   __syncthreads();                                    // (the forward's LDS images are free)
-  mlp_backward_body(c.bwd, role - c.nets, tile, lds, word, c.nets, global + 1);
-  if (threadIdx.x == 0 && chain_add(word + 1) == (unsigned)c.nets - 1) {    // the tile's last reader
-    chain_store(word, 0u);
-    chain_store(word + 1, 0u);
-  }
+  mlp_backward_body(c.bwd, role - c.nets, tile, lds);
 }
 
 __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
@@ -872,29 +864,17 @@ __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
   const int roles = c.used + 1;
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
-  unsigned* word = c.sync + kChainWordsPerTile * tile;
-  unsigned* global = c.sync + kChainWordsPerTile * tiles;
   if (tile == tiles) {
-    chain_stats_role(c.bwd, global + 2, global + 1, c.used * tiles);
+    chain_stats_role(c.bwd);
     return;
   }
-  if (role == c.used) {                               // the actor: both critics' action columns first
-    mlp_backward_body(c.actor, 0, tile, lds, word + 2, c.used, global + 1);
-    if (threadIdx.x == 0) chain_store(word + 2, 0u);
+  if (role == c.used) {                               // the actor: both critics' action columns
+    mlp_backward_body(c.actor, 0, tile, lds);
     return;
   }
   mlp_forward_body(c.fwd, role, tile, lds);
-  chain_arrive_after_values(word, global + 2);
   __syncthreads();
-  mlp_backward_body(c.bwd, role, tile, lds, word, c.used, global + 1);     // (waits for the twin's q)
-  __syncthreads();                                    // (dxa acknowledged: the barrier's fence)
-  if (threadIdx.x == 0) {
-    chain_add(word + 2);
-    if (chain_add(word + 1) == (unsigned)c.used - 1) {
-      chain_store(word, 0u);
-      chain_store(word + 1, 0u);
-    }
-  }
+  mlp_backward_body(c.bwd, role, tile, lds);          // (the twin's q; dxa -> the exchange area)
 }
 
 }  // namespace
@@ -1001,10 +981,10 @@ static size_t chain_lds_bytes(int H) {
 
 int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
   const MlpFwdArgs& f = c.fwd;
-  TONIC_REQUIRE(c.nets >= 1 && c.nets <= 2 && c.sync != nullptr && f.split == c.nets &&
-                    f.post == POST_NONE && f.heads == 1 && f.NH == 1 && f.coherent_out == 1 &&
+  TONIC_REQUIRE(c.nets >= 1 && c.nets <= 2 && c.bwd.exchange_failed != nullptr && f.split == c.nets &&
+                    f.post == POST_NONE && f.heads == 1 && f.NH == 1 && f.xq != nullptr &&
                     mlp_forward_supported(f.H, 1, 1) && c.bwd.heads == 0 && c.bwd.loss == LOSS_TD &&
-                    c.bwd.coherent == 1 && c.bwd.B == f.B && c.bwd.H == f.H &&
+                    c.bwd.B == f.B && c.bwd.H == f.H &&
                     mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: nets=%d H=%d", c.nets, f.H);
   const int tiles = (f.B + kRows - 1) / kRows;
@@ -1016,12 +996,13 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
 
 int launch_q_actor_step(const QActorStep& c, hipStream_t stream) {
   const MlpFwdArgs& f = c.fwd;
-  TONIC_REQUIRE(c.used >= 1 && c.used <= 2 && c.sync != nullptr && f.post == POST_NONE &&
-                    f.heads == 1 && f.NH == 1 && f.coherent_out == 1 && f.split >= c.used &&
+  TONIC_REQUIRE(c.used >= 1 && c.used <= 2 && c.bwd.exchange_failed != nullptr && f.post == POST_NONE &&
+                    f.heads == 1 && f.NH == 1 && f.xq != nullptr && f.split >= c.used &&
                     mlp_forward_supported(f.H, 1, 1) && c.bwd.heads == 0 &&
-                    c.bwd.loss == LOSS_ACTOR && c.bwd.coherent == 1 && c.bwd.B == f.B &&
+                    c.bwd.loss == LOSS_ACTOR && c.bwd.B == f.B &&
                     c.bwd.H == f.H && mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count) &&
-                    c.actor.heads >= 1 && c.actor.hb_dxa0 != nullptr && c.actor.coherent == 1 &&
+                    c.actor.heads >= 1 && c.actor.hb_dxa0 != nullptr &&
+                    c.actor.exchange_failed != nullptr &&
                     c.actor.B == f.B && c.actor.H == f.H && c.actor.NH <= kPostPitch &&
                     mlp_backward_supported(f.H, c.actor.NH, c.actor.heads, c.actor.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_actor_step: used=%d H=%d", c.used, f.H);

@@ -101,7 +101,7 @@ __global__ void critic_loss_kernel(const float* rewards, const float* discounts,
                                    int nets) {
   float s_loss = 0.f, s_q1 = 0.f, s_q2 = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
-    const float y = td_target(rewards, discounts, tq, logp_next, alpha, m, Bp, nets);
+    const float y = td_target(rewards, discounts, tq, logp_next, alpha, m, ValueLines{Bp, 16}, nets);
     if (nets == 1) {
       const float e1 = q[m] - y;
       dq[m] = 2.f * e1;
@@ -132,9 +132,9 @@ __global__ void actor_loss_kernel(const float* q, const float* logp, float alpha
   float s = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
     const float q1 = q[m];
-    dq[m] = actor_dq(q, m, Bp, twin, 0);
+    dq[m] = actor_dq(q, m, ValueLines{Bp, 16}, twin, 0);
     if (twin) {
-      dq[Bp + m] = actor_dq(q, m, Bp, twin, 1);
+      dq[Bp + m] = actor_dq(q, m, ValueLines{Bp, 16}, twin, 1);
       s += alpha * logp[m] - fminf(q1, q[Bp + m]);
     } else {
       s += -q1;
@@ -783,6 +783,7 @@ MlpBwdArgs critics_chain_args(const float* params, CriticShape s, int nets, int 
     b.loss = loss->kind; b.l_rewards = loss->rewards; b.l_discounts = loss->discounts;
     b.l_tq = loss->tq; b.l_logp = loss->logp; b.l_alpha = loss->alpha; b.l_q = loss->q;
     b.l_stats = loss->stats; b.l_nets = nets; b.l_Bp = Bp;
+    b.l_tq_at = b.l_q_at = ValueLines{Bp, 16};
   }
   b.W2 = params + o.W2; b.W1 = params + o.W1; b.K1 = s.O + s.A; b.ldw1 = o.ld1; b.ldw2 = o.ldH;
   b.xa_first = s.O; b.xa_count = dxa ? s.A : 0;
@@ -1137,10 +1138,10 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
 // groups, 2 optimizer launches) become 8 (4 when the actor is not due).
 namespace {
 
-// The arrival words of the chained launches live at the START of the workspace, in an area of
-// fixed size, so that they stay where they are (and zero) whatever batch size the workspace is
-// used with next.
-constexpr int64_t kChainSyncArea = 16384;            // words: 4 095 tiles = batches up to 65 520 rows
+// The one word of the chained launches that must be ZERO when a launch starts (a reader sets it when
+// a value never came, the launch's last workgroup reports and clears it) lives at the START of the
+// workspace, so that it stays where it is whatever batch size the workspace is used with next.
+constexpr int64_t kChainSyncArea = 64;               // floats
 
 int64_t q_iteration_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
@@ -1151,7 +1152,8 @@ int64_t q_iteration_floats(int B, int O, int A, int H) {
          + 2 * Bp + 2 * 2 * Bp * HP                 // dq, dz2, dz1 of two critics
          + 2 * Bp * ldh + 2 * Bp * ldh              // dxa (two critics), dloc, dspre
          + 2 * Bp * HP                              // actor dz2, dz1
-         + kChainSyncArea;                          // arrival words of the chained launches (first)
+         + kChainSyncArea                           // the chained launches' failure word (first)
+         + (Bp / 16) * kExchangeTileFloats;         // their value lines
 }
 
 }  // namespace
@@ -1191,8 +1193,13 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const ActorShape as{O, H, A, heads};
   const int64_t Pc = critic_count(cs), Pa = actor_count(as), hs = (int64_t)Bp * HP;
   Workspace ws{static_cast<char*>(a.d_workspace), 0, a.workspace_bytes};
-  unsigned* sync = reinterpret_cast<unsigned*>(ws.take(kChainSyncArea));
-  const bool chain = g_q_chain.load() != 0 && chain_sync_words(B) <= kChainSyncArea;
+  unsigned* failed = reinterpret_cast<unsigned*>(ws.take(kChainSyncArea));
+  // the chained launches' exchange area: the value lines of the tiles, then the critics' action-
+  // column gradients — ONE span, emptied by the policy launch (launch 1) of every iteration
+  float* xq = ws.take((int64_t)(Bp / 16) * kExchangeTileFloats);
+  float* dxa = ws.take(2LL * Bp * ldh);
+  float* exchange_end = ws.take(0);
+  const bool chain = g_q_chain.load() != 0;
   // policy passes [net 0 | net 1]
   float* p_h1 = ws.take(2 * hs); float* p_h2 = ws.take(2 * hs);
   float* head0 = ws.take(2LL * Bp * ldh); float* head1 = ws.take(2LL * Bp * ldh);
@@ -1207,7 +1214,6 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   float* tq = q_all; float* q = q_all + (int64_t)nets * Bp;
   float* dq = ws.take(2LL * Bp);
   float* dh2 = ws.take(2 * hs); float* dh1 = ws.take(2 * hs);
-  float* dxa = ws.take(2LL * Bp * ldh);
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take(hs); float* da_h1 = ws.take(hs);
 
@@ -1233,6 +1239,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     f.enc_obs = a.d_next_observations; f.enc_obs2 = a.d_observations; f.enc_act2 = a.d_actions;
     f.enc_mean = a.d_norm_mean; f.enc_std = a.d_norm_std; f.enc_clip = clip_bound(a.norm_clip);
     f.enc_out = X; f.enc_out2 = X2; f.enc_O = O; f.enc_ld = ldx;
+    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; }
     if (due) {
       f.split = 1;
       f.second_params = a.d_actor - policy;            // (0 for SAC: the same network on s)
@@ -1268,10 +1275,12 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     int launch_nets = 0;
     step.fwd = critics_forward_args(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all,
                                     q_all, a.d_critics, X2, &launch_nets);
-    step.fwd.coherent_out = 1;
+    step.fwd.xq = xq;
     step.bwd = critics_chain_args(a.d_critics, cs, nets, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, &td);
-    step.bwd.coherent = 1;
-    step.nets = nets; step.sync = sync;
+    step.bwd.exchange_failed = failed;   // targets: lines 0, 1 of the tile; the online critics: lines 2, 3
+    step.bwd.l_tq = xq; step.bwd.l_tq_at = ValueLines{32, kExchangeTileFloats};
+    step.bwd.l_q = xq + 64; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
+    step.nets = nets;
     TRY(launch_q_critic_step(step, st));
     TRY(critics_weight_gradients(cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
                                  a.critic.d_grad_sums, st, &cf));
@@ -1310,14 +1319,15 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     int launch_nets = 0;
     step.fwd = critics_forward_args(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, nullptr,
                                     nullptr, &launch_nets);
-    step.fwd.coherent_out = 1;
+    step.fwd.xq = xq + 128;              // the critics' q: lines 4, 5 of the tile
     step.bwd = critics_chain_args(a.d_critics, cs, used, B, Bp, c_h1, c_h2, dq, dh2, dh1, dxa,
                                   &objective);
-    step.bwd.coherent = 1;
+    step.bwd.exchange_failed = failed;
+    step.bwd.l_q = xq + 128; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
     step.actor = actor_chain_args(a.d_actor, as, B, p_h1 + hs, p_h2 + hs, dloc,
                                   kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, nullptr, 0, 0, &hb);
-    step.actor.coherent = 1;
-    step.used = used; step.sync = sync;
+    step.actor.exchange_failed = failed;
+    step.used = used;
     TRY(launch_q_actor_step(step, st));
     TRY(actor_weight_gradients(as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
                                kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
