@@ -139,7 +139,8 @@ def test_noise_drawn_ahead_is_the_reference_stream():
         reference = [torch.randn(workers, width).numpy().copy() for _ in range(200)]
         after = torch.randn(4).numpy().copy()
         torch.manual_seed(3)
-        noise = _NoiseAhead(Agent(), workers, width)
+        agent = Agent()                      # (kept alive: the helper thread ends with its agent)
+        noise = _NoiseAhead(agent, workers, width)
         assert noise.bulk == bulk
         out = np.zeros((workers, width), np.float32)
         for t in range(150):
@@ -150,6 +151,18 @@ def test_noise_drawn_ahead_is_the_reference_stream():
         for t in range(150, 200):
             noise.take(out)
             assert np.array_equal(out, reference[t]), (workers, width, t)
+        noise.rewind(0)
+        assert np.array_equal(torch.randn(4).numpy(), after)
+        # a helper whose agent is gone (closed) draws nothing ahead: same stream, drawn in place,
+        # also when the close comes while a buffer drawn ahead is pending
+        torch.manual_seed(3)
+        agent = Agent()
+        noise = _NoiseAhead(agent, workers, width)
+        for t in range(200):
+            if t == 70:
+                noise.close()
+            noise.take(out)
+            assert np.array_equal(out, reference[t]), (workers, width, t, 'closed')
         noise.rewind(0)
         assert np.array_equal(torch.randn(4).numpy(), after)
 

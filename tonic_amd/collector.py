@@ -13,6 +13,7 @@ block views (any other environment) are copied into a private block first — sa
 """
 import ctypes
 import mmap
+import os
 import weakref
 
 import numpy as np
@@ -79,11 +80,16 @@ class Block:
         # before the instance dictionary (and with it the mmap) is released.
         self._handles = []
         self._collectors = {}
-        weakref.finalize(self, Block._release, self._handles, lib)
+        weakref.finalize(self, Block._release, self._handles, lib, os.getpid())
         Block._live.add(self)
 
     @staticmethod
-    def _release(handles, lib):
+    def _release(handles, lib, owner):
+        # (a forked environment worker inherits this finalizer and runs it at ITS exit: the GPU
+        #  handles belong to the process that made them — touching them there is a segmentation
+        #  fault in the HIP runtime)
+        if os.getpid() != owner:
+            return
         for cell in handles:
             if cell[0] is not None:
                 lib.tonic_collector_destroy(cell[0])

@@ -63,11 +63,26 @@ constexpr int kFarSegments = 64;    // later segments whose maps a workgroup can
 struct GaeOnePass {
   GaeArgs g;
   unsigned* ticket;     // zero at launch
-  unsigned* flags;      // [segments, tiles], zero at launch: 1 = the segment's map is published,
-                        //   2 = also `inclusive`, the carry LEAVING the segment towards earlier rows
-  float* inclusive;     // [segments, W]
+  // carry_a / carry_b (the segment's map) and `inclusive` (the carry LEAVING the segment towards
+  // earlier rows), [segments, W] each, are all-ones words (kCarryEmpty) at launch: every value is
+  // written once with an agent-scope store and read with agent-scope loads until it is no longer
+  // empty — the data is its own flag (mlpfwd.h, exchange_read: a flag word behind
+  // `s_waitcnt vmcnt(0)`, round 2's protocol, can be seen before the data's write-through has
+  // landed; a release fence in front of it costs 5x at W = 65 536).
+  float* inclusive;
   int tiles, segments;
 };
+
+constexpr unsigned kCarryEmpty = 0xffffffffu;         // (hipMemsetAsync 0xFF; no carry is this NaN)
+__device__ __forceinline__ unsigned carry_peek(const float* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float carry_wait(const float* p) {
+  unsigned bits;
+  while ((bits = carry_peek(p)) == kCarryEmpty) __builtin_amdgcn_s_sleep(2);
+  return __uint_as_float(bits);
+}
 
 template <int kSegWaves>
 __global__ __launch_bounds__(kSegWaves * 64, 4) void gae_onepass_kernel(GaeOnePass p) {
@@ -126,20 +141,11 @@ __global__ __launch_bounds__(kSegWaves * 64, 4) void gae_onepass_kernel(GaeOnePa
       sa = map_a[k][lane] + map_b[k][lane] * sa;
       sb = map_b[k][lane] * sb;
     }
-    if (seg > 0) {
-      // Agent-scope stores (written through to where the other XCDs read) + a plain wait for
-      // their acknowledgement order the map before its flag; a release / acquire FENCE pair here
-      // is an L2 write-back / invalidate per wave and cost 2x the whole kernel.
-      if (column) {
-        __hip_atomic_store(g.carry_a + (int64_t)seg * g.W + w, sa, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g.carry_b + (int64_t)seg * g.W + w, sb, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_store(p.flags + (int64_t)seg * p.tiles + tile, 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (seg > 0 && column) {                // agent-scope stores: the values are their own flags
+      __hip_atomic_store(g.carry_a + (int64_t)seg * g.W + w, sa, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.carry_b + (int64_t)seg * g.W + w, sb, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
     seg_a = sa;
     seg_b = sb;
@@ -159,20 +165,17 @@ __global__ __launch_bounds__(kSegWaves * 64, 4) void gae_onepass_kernel(GaeOnePa
       const int s2 = seg + 1 + d;
       // the LDS stash is full at distance kFarSegments - 1: that segment must hand over its carry
       const unsigned need = (d >= kFarSegments - 1 && d < later - 1) ? 2u : 1u;
-      const unsigned* flag = p.flags + (int64_t)s2 * p.tiles + tile;
-      unsigned state;
-      while ((state = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need)
-        __builtin_amdgcn_s_sleep(2);
-      asm volatile("" ::: "memory");
       if (d < kFarSegments) {
-        far_a[d][lane] = __hip_atomic_load(g.carry_a + (int64_t)s2 * g.W + wc, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-        far_b[d][lane] = __hip_atomic_load(g.carry_b + (int64_t)s2 * g.W + wc, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+        far_a[d][lane] = carry_wait(g.carry_a + (int64_t)s2 * g.W + wc);
+        far_b[d][lane] = carry_wait(g.carry_b + (int64_t)s2 * g.W + wc);
       }
-      if (state == 2u)
-        far_incl[wave][lane] = __hip_atomic_load(p.inclusive + (int64_t)s2 * g.W + wc,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // `inclusive`: taken when ALL columns of the tile have it (the walk below is the tile's, not
+      // the lane's) — awaited only where the LDS stash ends
+      const float* incl = p.inclusive + (int64_t)s2 * g.W + wc;
+      unsigned bits = carry_peek(incl);
+      if (need == 2u) bits = __float_as_uint(carry_wait(incl));
+      const unsigned state = __all(bits != kCarryEmpty) ? 2u : 1u;
+      if (state == 2u) far_incl[wave][lane] = __uint_as_float(bits);
       if (lane == 0) far_state[wave] = (int)state;
     } else if (lane == 0) {
       far_state[wave] = 0;
@@ -200,15 +203,9 @@ __global__ __launch_bounds__(kSegWaves * 64, 4) void gae_onepass_kernel(GaeOnePa
     }
     for (int d = from; d >= 0; --d) carry = far_a[d][lane] + far_b[d][lane] * carry;
     carry_in[lane] = carry;
-    if (seg > 0) {                        // what this segment hands on to the earlier ones
-      if (column)
-        __hip_atomic_store(p.inclusive + (int64_t)seg * g.W + w, seg_a + seg_b * carry,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_store(p.flags + (int64_t)seg * p.tiles + tile, 2u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (seg > 0 && column)                // what this segment hands on to the earlier ones
+      __hip_atomic_store(p.inclusive + (int64_t)seg * g.W + w, seg_a + seg_b * carry,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   // 4. the later waves of this segment, then the exact recurrence over this wave's rows
@@ -899,11 +896,12 @@ extern "C" int tonic_gae_lambda_returns(const float* d_next_values, const float*
   if (l.onepass) {
     GaeOnePass p{};
     p.g = g;
-    p.flags = reinterpret_cast<unsigned*>(ws + l.off_flags);
     p.inclusive = reinterpret_cast<float*>(ws + l.off_incl);
-    p.ticket = p.flags + (int64_t)l.chunks * l.tiles;
+    p.ticket = reinterpret_cast<unsigned*>(ws + l.off_flags);
     p.tiles = l.tiles; p.segments = l.chunks;
-    if (hipMemsetAsync(p.flags, 0, (size_t)l.flag_bytes, st) != hipSuccess) {
+    // the maps and the handed-on carries start EMPTY (all-ones words), the ticket at zero
+    if (hipMemsetAsync(ws + l.off_a, 0xFF, (size_t)(l.off_flags - l.off_a), st) != hipSuccess ||
+        hipMemsetAsync(p.ticket, 0, (size_t)l.flag_bytes, st) != hipSuccess) {
       set_error("tonic_gae_lambda_returns: hipMemsetAsync failed");
       return TONIC_ERR_LAUNCH;
     }

@@ -210,8 +210,9 @@ class _NoiseAhead:
         self.buffers = [torch.empty(self.DEPTH * workers, width) for _ in range(2)]
         self.rows = [b.numpy().reshape(self.DEPTH, workers, width) for b in self.buffers]
         self.states = [None, None]          # generator state before each buffer was drawn
-        self.current, self.taken, self.valid = 0, self.DEPTH, False
+        self.current, self.taken, self.valid, self.ahead = 0, self.DEPTH, False, False
         self.filling = False                # the helper owns buffers[current ^ 1]
+        self.pending = False                # a fill has been asked for and not started yet
         self.request, self.ready = threading.Event(), threading.Event()
         self.closed = False
         self.thread = threading.Thread(target=self._helper, daemon=True, name='tonic-noise-ahead')
@@ -241,10 +242,12 @@ class _NoiseAhead:
         while True:
             self.request.wait()
             self.request.clear()
+            if self.pending:                # (a fill asked for before close() is still delivered)
+                self.pending = False
+                self._fill(self.current ^ 1)
+                self.ready.set()
             if self.closed:
                 return
-            self._fill(self.current ^ 1)
-            self.ready.set()
 
     def _settle(self):
         if self.filling:
@@ -259,15 +262,18 @@ class _NoiseAhead:
             self._agent()._randn(self.workers, self.width, out=torch.from_numpy(out))
             return
         if self.taken == self.DEPTH:
-            if self.valid:                  # the buffer drawn ahead takes over
+            if self.valid and self.ahead:   # the buffer drawn ahead takes over
                 self._settle()
                 self.current ^= 1
-            else:                           # first use / after a rewind: draw here, once
+            else:                           # first use / after a rewind / no helper: draw here
                 self._fill(self.current)
                 self.valid = True
             self.taken = 0
-            self.filling = True             # and the helper draws the one after it
-            self.request.set()
+            self.ahead = not self.closed    # (a closed helper draws nothing ahead)
+            if self.ahead:
+                self.filling = True         # the helper draws the buffer after this one
+                self.pending = True
+                self.request.set()
         np.copyto(out, self.rows[self.current][self.taken])
         self.taken += 1
 
@@ -285,7 +291,7 @@ class _NoiseAhead:
         self._set_state(self.states[self.current])
         if consumed > 0:
             torch.randn(consumed * self.workers, self.width, generator=self.generator)
-        self.taken, self.valid = self.DEPTH, False
+        self.taken, self.valid, self.ahead = self.DEPTH, False, False
 
 
 class A2C(Agent):
