@@ -130,10 +130,11 @@ struct Layer {
     }
   }
 
-  // EXACT: nfull is a multiple of the four chunks of a round — no chunk of the loop is a re-read,
-  // so the B operands go to the MFMAs as they come (else: times 1 / 0, four VALU instructions per
-  // chunk in the MFMA stream)
-  template <bool EXACT, typename BFull>
+  // Whole rounds of four chunks — two operand sets, the loads of one issued before the MFMAs of the
+  // other — then the one to three chunks that are left, straight-line under scalar conditions.
+  // (Round 2 ran ceil(nfull / 4) rounds and multiplied the B operands of the re-read chunks by
+  // zero: four VALU instructions per chunk in the MFMA stream, which fp32 MFMAs do not hide.)
+  template <typename BFull>
   __device__ __forceinline__ void loop(f32x4 (&acc)[TILES], BFull bfull) {
     f32x4 aA[kHalf][TILES], aB[kHalf][TILES], bA[kHalf], bB[kHalf];
     auto fill_a = [&](f32x4 (&a)[kHalf][TILES], int first) {
@@ -148,20 +149,11 @@ struct Layer {
 #pragma unroll
       for (int q = 0; q < kHalf; ++q) b[q] = bfull(16 * min(first + q, nfull - 1) + 4 * kg);
     };
-    auto compute = [&](const f32x4 (&a)[kHalf][TILES], const f32x4 (&b)[kHalf], int first) {
+    auto chunk = [&](const f32x4 (&a)[TILES], const f32x4& b) {
 #pragma unroll
-      for (int q = 0; q < kHalf; ++q) {
-        f32x4 bb = b[q];
-        if (!EXACT) {
-          const float live = first + q < nfull ? 1.f : 0.f;
+      for (int e = 0; e < 4; ++e) {                 // e outer: the tiles are independent chains
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bb[e] = b[q][e] * live;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {               // e outer: the tiles are independent chains
-#pragma unroll
-          for (int j = 0; j < TILES; ++j) acc[j] = mfma16(a[q][j][e], bb[e], acc[j]);
-        }
+        for (int j = 0; j < TILES; ++j) acc[j] = mfma16(a[j][e], b[e], acc[j]);
       }
     };
 #pragma unroll
@@ -170,26 +162,35 @@ struct Layer {
       for (int j = 0; j < TILES; ++j) aA[q][j] = a0[q][j];
     }
     fill_b(bA, 0);
-    const int rounds = (nfull + 2 * kHalf - 1) / (2 * kHalf);
+    const int rounds = nfull / (2 * kHalf), rest = nfull % (2 * kHalf);
     for (int r = 0; r < rounds; ++r) {
       const int c = 2 * kHalf * r;
       fill_a(aB, c + kHalf); fill_b(bB, c + kHalf);
       __builtin_amdgcn_sched_barrier(0);
-      compute(aA, bA, c);
+      chunk(aA[0], bA[0]); chunk(aA[1], bA[1]);
       __builtin_amdgcn_sched_barrier(0);
-      fill_a(aA, c + 2 * kHalf); fill_b(bA, c + 2 * kHalf);
+      fill_a(aA, c + 2 * kHalf); fill_b(bA, c + 2 * kHalf);      // (the last round: the rest's first two)
       __builtin_amdgcn_sched_barrier(0);
-      compute(aB, bB, c + kHalf);
+      chunk(aB[0], bB[0]); chunk(aB[1], bB[1]);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rest > 0) {                                   // scalar: chunks 4 rounds .. nfull - 1
+      if (rest > 2) {
+        const int c = nfull - 1;
+#pragma unroll
+        for (int j = 0; j < TILES; ++j) aB[0][j] = weights(j, c);
+        bB[0] = bfull(16 * c + 4 * kg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(aA[0], bA[0]);
+      if (rest > 1) chunk(aA[1], bA[1]);
+      if (rest > 2) chunk(aB[0], bB[0]);
     }
   }
 
   template <typename BFull, typename BTail>
   __device__ __forceinline__ void run(f32x4 (&acc)[TILES], BFull bfull, BTail btail) {
-    if (nfull > 0) {
-      if (nfull % (2 * kHalf) == 0) loop<true>(acc, bfull);      // scalar
-      else loop<false>(acc, bfull);
-    }
+    if (nfull > 0) loop(acc, bfull);
     if (K % 16 != 0) {                                // ragged last chunk
       const int k = 16 * nfull + 4 * kg;
       f32x4 b = btail(k);
@@ -317,10 +318,13 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* xrow = (second ? a.X2 : a.X) + (int64_t)row * a.ldx;
+  // the full k-chunks of the input row as buffer loads as well (lane: row and k group, scalar: the chunk)
+  const __amdgpu_buffer_rsrc_t xbuffer = weight_buffer(second ? a.X2 : a.X);
+  const unsigned xlane = 4u * ((unsigned)row * (unsigned)a.ldx + 4u * kg);
   Layer<kMaxTiles> l1;
   l1.start(W1, rows1, a.K1, kg, a.ldw1);
   stamp(1);
-  l1.run(acc, [&](int k) { return load_k4(xrow, k); },
+  l1.run(acc, [&](int k) { return buffer4(xbuffer, xlane, 4u * (unsigned)(k - 4 * kg)); },
          [&](int k) { return load_k4_tail(xrow, k, a.K1); });
   stamp(2);
   Layer<kMaxTiles> l2;
