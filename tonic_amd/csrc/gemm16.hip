@@ -167,6 +167,20 @@ typedef float f32x2_dword __attribute__((ext_vector_type(2), aligned(4)));
 // offset is an addressing mode of global_load): the load needs no vector address arithmetic.
 // EDGE (compile-time: a run-time flag, even a wave-uniform one, puts a branch around every
 // load): tiles that reach past the last row / column of C take clamped scalar loads.
+// Inside the main loop the non-EDGE form is a BUFFER load (tn_buffer below): the operand as a
+// buffer resource, the lane's byte offset, the chunk's byte offset as the scalar operand — the
+// compiler hoists the zero-extension of `offset` out of the loop and then adds scalar base and
+// 64-bit vector offset with a v_lshl_add_u64 per load, which fp32 MFMAs do not hide.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_buffer(const float* tensor) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tensor), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void tn_buffer_load(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes,
+                                               unsigned chunk_bytes, float (&v)[2]) {
+  const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, chunk_bytes, 0);
+  v[0] = __uint_as_float(q[0]); v[1] = __uint_as_float(q[1]);
+}
+
 template <bool EDGE>
 __device__ __forceinline__ void tn_load(const float* __restrict__ base, unsigned offset, int col,
                                         int cols, float (&v)[2]) {
@@ -244,7 +258,9 @@ __device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned tot
   }
 }
 
-template <bool EDGE>
+// COLSUM: this tile also forms the column sums of A (the bias gradient: the tiles of the first tile
+// column) — a compile-time flag, or the six additions per chunk run (selected away) in every tile
+template <bool EDGE, bool COLSUM>
 __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, float* part,
                                              const AdamFold& fold, unsigned total_blocks,
                                              unsigned long long* stamps) {
@@ -282,6 +298,9 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) acc[jm][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
   float colsum[2] = {0.f, 0.f};
+  // (the bias gradients = column sums of A are the business of the tiles of the first tile column)
+  constexpr bool want_colsum = COLSUM;
+  const __amdgpu_buffer_rsrc_t bufA = tn_buffer(A), bufB = tn_buffer(B);
 
   auto multiply = [&](const float (&a)[4][2], const float (&b)[4][2]) {
 #pragma unroll
@@ -292,8 +311,10 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
         for (int jn = 0; jn < 2; ++jn) acc[jm][jn] = mfma16(a[t][jm], b[t][jn], acc[jm][jn]);
       }
     }
+    if (want_colsum) {
 #pragma unroll
-    for (int jm = 0; jm < 2; ++jm) colsum[jm] += (a[0][jm] + a[1][jm]) + (a[2][jm] + a[3][jm]);
+      for (int jm = 0; jm < 2; ++jm) colsum[jm] += (a[0][jm] + a[1][jm]) + (a[2][jm] + a[3][jm]);
+    }
   };
 
   // ---- full chunks: kTnDepth chunks in flight in rotating register slots; the loads that
@@ -303,12 +324,21 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
   float a[kTnDepth][4][2], b[kTnDepth][4][2];
   auto request = [&](int slot, int index) {
     const int c = min(w + kTnWaves * index, full - 1);           // past the end: re-read, unused
-    const float* Ac = A + (int64_t)16 * c * g.lda;               // scalar arithmetic
-    const float* Bc = B + (int64_t)16 * c * g.ldb;
+    if (!EDGE) {
+      const unsigned sa = 64u * (unsigned)(c * g.lda), sb = 64u * (unsigned)(c * g.ldb);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      tn_load<EDGE>(Ac, offa[t], ca, g.M, a[slot][t]);
-      tn_load<EDGE>(Bc, offb[t], cb, g.N, b[slot][t]);
+      for (int t = 0; t < 4; ++t) {
+        tn_buffer_load(bufA, 4u * offa[t], sa, a[slot][t]);
+        tn_buffer_load(bufB, 4u * offb[t], sb, b[slot][t]);
+      }
+    } else {
+      const float* Ac = A + (int64_t)16 * c * g.lda;             // scalar arithmetic
+      const float* Bc = B + (int64_t)16 * c * g.ldb;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        tn_load<EDGE>(Ac, offa[t], ca, g.M, a[slot][t]);
+        tn_load<EDGE>(Bc, offb[t], cb, g.N, b[slot][t]);
+      }
     }
   };
   if (mine > 0) {
@@ -475,8 +505,14 @@ __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup 
   // operand ROWS are long enough (padded pitch: what is read beyond M / N only feeds outputs that
   // are never stored); clamped scalar loads only where a load would leave the row.
   const unsigned total = gridDim.x * gridDim.z;
-  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) gemm_tn_tile<true>(g, tm, tn, part, G.adam, total, G.stamps);   // uniform
-  else gemm_tn_tile<false>(g, tm, tn, part, G.adam, total, G.stamps);
+  const bool sums = g.colsum != nullptr && tn == 0;               // uniform, like the next condition
+  if (32 * tm + 32 > g.lda || 32 * tn + 32 > g.ldb) {
+    if (sums) gemm_tn_tile<true, true>(g, tm, tn, part, G.adam, total, G.stamps);
+    else gemm_tn_tile<true, false>(g, tm, tn, part, G.adam, total, G.stamps);
+  } else {
+    if (sums) gemm_tn_tile<false, true>(g, tm, tn, part, G.adam, total, G.stamps);
+    else gemm_tn_tile<false, false>(g, tm, tn, part, G.adam, total, G.stamps);
+  }
 }
 
 namespace {
