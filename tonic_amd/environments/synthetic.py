@@ -78,6 +78,7 @@ class SyntheticBatch:
         self.block = Block(self.workers, self.observation_space.shape[0],
                            self.action_space.shape[0])
         self.lengths = np.zeros(self.workers, int)
+        self._longest = 0                # max(lengths), kept by hand: a reduction per step is ~1 us
         self._flags = np.zeros(self.workers, bool)
         self._quiet = 0                  # steps taken since `lengths` was last brought up to date
         self._flags_set = False
@@ -115,7 +116,7 @@ class SyntheticBatch:
             np.einsum('ij,ij->i', actions, actions, out=block.rewards, casting='same_kind')
             np.negative(block.rewards, out=block.rewards)
         if self.termination_probability <= 0 and \
-                self._quiet + 1 + self.lengths.max() < self.max_episode_steps:
+                self._quiet + 1 + self._longest < self.max_episode_steps:
             # nobody can time out at this step: the flags stay all False
             self._quiet += 1
             if self._flags_set:
@@ -132,6 +133,7 @@ class SyntheticBatch:
         if resets.any():
             block.observations[resets] = self._observe()[resets]
             self.lengths[resets] = 0
+        self._longest = int(self.lengths.max())
         self._write_flags(resets, terminations)
         self._flags_set = True
         return self._outputs()

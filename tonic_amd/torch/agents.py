@@ -317,7 +317,8 @@ class A2C(Agent):
         self.observation_size = observation_space.shape[0]
         self.action_size = action_space.shape[0]
         self._replicate([self.model.flat_actor.flat, self.model.flat_critic.flat], own_noise=True)
-        self._collector = None
+        self._collector = self._block = None
+        self._speculated = self._eps_ahead = self._block_fed = False
         # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
         # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
         # around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per round trip)
@@ -441,6 +442,19 @@ class A2C(Agent):
             self._update()
 
     def step(self, observations, steps):
+        # The steady state of a block-fed loop first (every attribute lookup of this call is host
+        # time between the simulator's step and the next command to the GPU): update() has issued
+        # this step with the block's own observations and the noise drawn ahead.
+        if self._speculated and self._eps_ahead and observations is self._block.out_observations:
+            block, slot = self._block, self._slot
+            self._speculated = False
+            self._noise.take(block.eps[slot ^ 1])      # the step after this one
+            self._slot = slot ^ 1
+            self._collector.wait_actions()
+            self._block_fed = True
+            self.last_observations = observations
+            self.last_actions = actions = block.out_actions
+            return actions
         if self._wide():
             return self._step_staged(observations)
         block = getattr(self, '_block', None)
@@ -523,6 +537,7 @@ class A2C(Agent):
             self._collector.close()
             self._block._collectors.pop(self._collector.transport, None)
             self._collector = self._block = None
+            self._speculated = self._eps_ahead = self._block_fed = False
 
     def test_step(self, observations, steps):
         noise = getattr(self, '_noise', None)
@@ -540,9 +555,24 @@ class A2C(Agent):
     def update(self, observations, rewards, resets, terminations, steps):
         """a2c.py:58-73.  The outcome stays in the block; the NEXT step's launch (or
         end_rollout) moves it into the Segment row of the step it belongs to."""
+        block, replay = self._block, self.replay
+        if self._block_fed and observations is block.out_next_observations \
+                and rewards is block.out_rewards and resets is block.out_resets \
+                and terminations is block.out_terminations and self._eps_ahead and self._speculate \
+                and replay.index + 2 < replay.max_size and not self.model.return_normalizer:
+            # the steady state of a block-fed loop (the general form is below): the next step's
+            # command goes out first, the bookkeeping runs while the GPU works
+            index = replay.index
+            self._collector.ppo_step(index + 1, self._slot, True)
+            self._speculated = True
+            replay.index = index + 1
+            normalizer = self.model.observation_normalizer
+            if normalizer:
+                normalizer.new_count += block.workers             # (note_device_rows)
+            self._pending = False
+            return
         if self._wide():
             return self._update_staged(observations, rewards, resets, terminations)
-        block, replay = self._block, self.replay
         # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
         if (self._block_fed and observations is block.out_next_observations
                 and rewards is block.out_rewards and resets is block.out_resets
