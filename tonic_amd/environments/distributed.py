@@ -102,7 +102,24 @@ class Sequential:
             return np.array(outs)
 
 
-def _worker(builder, max_episode_steps, workers, first, seed, block):
+def _worker(*args):
+    """Process entry of one worker group.  The process is a fork of the trainer: it has inherited
+    GPU handles, page-locked blocks and device tensors that it must never touch — not even to
+    release them (the HIP runtime of a forked child is not usable: a finalizer or the garbage
+    collector running at interpreter exit ends in a segmentation fault).  So the worker leaves
+    through os._exit once its loop is over; what it owns is released with the process."""
+    status = 1
+    try:
+        _worker_loop(*args)
+        status = 0
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+    finally:
+        os._exit(status)
+
+
+def _worker_loop(builder, max_episode_steps, workers, first, seed, block):
     environments = [builder() for _ in range(workers)]
     for j, environment in enumerate(environments):
         environment.seed(seed + j)
