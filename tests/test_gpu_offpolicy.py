@@ -381,6 +381,52 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                                       got[first] if first else None, want[first] if first else None))
 
 
+def test_a_lost_workgroup_of_a_chained_launch_is_a_nan_loss_not_a_hang(lib):
+    """The workgroups of the chained launches wait for each other's values (exchange_read,
+    csrc/mlpfwd.h).  A value that never comes — here: the first target workgroup of ONE critic
+    step returns without a word (tuning key `chain_fault`) — must not hang the device: its readers
+    give up after 50 ms and the logged critic loss of that iteration is NaN (so is what they
+    computed from the empty words); the device stays usable: a fresh agent reproduces the first
+    update bit for bit."""
+    import time
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd import _lib
+    from tonic_amd.environments import Box
+    O, A, W, B, rows, iterations = 17, 6, 4, 64, 48, 2
+
+    def make():
+        rng = np.random.RandomState(3)
+        replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B)
+        agent = tt.agents.TD3(replay=replay)
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=1)
+        assert agent._fused_kind() is not None
+        for _ in range(rows):
+            replay.store(observations=dev(rng.normal(size=(W, O)).astype(np.float32)),
+                         actions=dev(rng.uniform(-1, 1, (W, A)).astype(np.float32)),
+                         next_observations=dev(rng.normal(size=(W, O)).astype(np.float32)),
+                         rewards=dev(rng.normal(size=W).astype(np.float32)),
+                         resets=dev(np.zeros(W, np.float32)),
+                         terminations=dev(np.zeros(W, np.float32)))
+        return agent
+    rng = np.random.RandomState(4)
+    eps = rng.normal(size=(iterations, 1, B, A)).astype(np.float32)
+    indices = rng.randint(rows * W, size=(iterations, B))
+    agent = make()
+    good = agent.enqueue_update(indices, eps, graph=False).cpu().numpy().copy()
+    assert np.isfinite(good[0][:, 0]).all()
+    _lib.check(lib.tonic_set_tuning(b'chain_fault', 1), 'tuning')
+    start = time.perf_counter()
+    bad = agent.enqueue_update(indices, eps, graph=False).cpu().numpy().copy()
+    elapsed = time.perf_counter() - start
+    assert np.isnan(bad[0][0, 0]), bad[0][:, 0]         # (what was read instead of the value is
+    #                                                     an empty word: the parameters are gone too)
+    assert 0.03 < elapsed < 5.0, elapsed                # the 50 ms bound, not a watchdog reset
+    # the device and the library are fine: a fresh agent reproduces the first update bit for bit
+    again = make().enqueue_update(indices, eps, graph=False).cpu().numpy()
+    assert np.array_equal(again, good)
+
+
 def test_adam_polyak_step_equals_the_two_calls(lib):
     """tonic_adam_polyak_step == tonic_adam_step on the block followed by tonic_polyak_update of
     the whole target buffer, bit for bit (block at the start, in the middle, at the end)."""

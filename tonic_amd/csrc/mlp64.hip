@@ -869,6 +869,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_policy_tail = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "chain_fault") == 0) {
+    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
+                  "chain_fault must be 0 or 1, got %d", value);
+    g_chain_fault = value;
+    return TONIC_OK;
+  }
   if (strcmp(key, "q_chain") == 0) {
     TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
                   "q_chain must be 0 or 1, got %d", value);

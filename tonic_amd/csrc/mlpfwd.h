@@ -269,6 +269,7 @@ struct QCriticStep {
   MlpFwdArgs fwd;            // 2 nets networks: targets on X, online (second set) on X2; split = nets
   MlpBwdArgs bwd;            // the online critics' chain, loss = LOSS_TD
   int nets;
+  int lose_first_target;     // test hook (tuning key "chain_fault"): workgroup 0 returns without a word
 };
 // Actor step: roles [critic_0 .. critic_{used-1} | actor] — the critics' forward on (s, a_new), the
 // actor objective (the twin critics exchange q), their chain down to the action columns, then the
@@ -281,6 +282,7 @@ struct QActorStep {
 };
 int launch_q_critic_step(const QCriticStep& c, hipStream_t stream);
 int launch_q_actor_step(const QActorStep& c, hipStream_t stream);
+extern std::atomic<int> g_chain_fault;
 extern std::atomic<int> g_q_chain;          // tuning key "q_chain": 0 keeps one launch per pass
 
 bool mlp_forward_supported(int H, int NH, int heads);

@@ -514,7 +514,7 @@ __device__ __forceinline__ float load_shared(const float* p, unsigned* exchange_
 }
 
 // The logged sums of the step's loss over the whole batch (one workgroup; result -> l_stats)
-__device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed) {
+__device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a) {
   const int tid = threadIdx.x;
   unsigned* co = a.exchange_failed;                   // null: plain loads
   double s0 = 0, s1 = 0, s2 = 0;
@@ -543,9 +543,7 @@ __device__ __forceinline__ void mlp_loss_stats(const MlpBwdArgs& a, bool failed)
   }
   block_sum3(s0, s1, s2);
   if (tid == 0) {
-    // (a peer that never arrived — see chain_wait — must not pass for a training step)
-    a.l_stats[0] = failed ? __builtin_nanf("") : (float)s0;
-    a.l_stats[1] = (float)s1; a.l_stats[2] = (float)s2;
+    a.l_stats[0] = (float)s0; a.l_stats[1] = (float)s1; a.l_stats[2] = (float)s2;
     a.l_stats[3] = 0.f; a.l_stats[4] = 0.f; a.l_stats[5] = (float)a.B; a.l_stats[6] = 0.f;
     a.l_stats[7] = 0.f;
   }
@@ -823,7 +821,7 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
     }
   }
   // the logged sums (uniform); a chain launch leaves them to its last workgroup
-  if (a.loss != LOSS_GIVEN && co == nullptr && bx == 0 && net == 0) mlp_loss_stats(a, false);
+  if (a.loss != LOSS_GIVEN && co == nullptr && bx == 0 && net == 0) mlp_loss_stats(a);
 }
 
 __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
@@ -837,14 +835,11 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
 // launch of their own they were the by-product of workgroup (0, 0); at the end of the last chain
 // they would be 2 - 3 us of the critical path.
 __device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b) {
-  __shared__ int bad;
-  mlp_loss_stats(b, false);                           // (reads every value: all published after it)
-  if (threadIdx.x == 0) {
-    bad = __hip_atomic_load(b.exchange_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (bad) {                                        // a value that never came: not a training step
-      b.l_stats[0] = __builtin_nanf("");
-      __hip_atomic_store(b.exchange_failed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  mlp_loss_stats(b);                                  // (waits for every value it reads)
+  if (threadIdx.x == 0 &&
+      __hip_atomic_load(b.exchange_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    b.l_stats[0] = __builtin_nanf("");                // a value that never came: not a training step
+    __hip_atomic_store(b.exchange_failed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -857,6 +852,7 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
     chain_stats_role(c.bwd);
     return;
   }
+  if (c.lose_first_target != 0 && blockIdx.x == 0) return;    // test hook: a workgroup that never answers
   mlp_forward_body(c.fwd, role, tile, lds);           // (its values -> the tile's exchange lines)
   if (role < c.nets) return;                          // a target
   __syncthreads();                                    // (the forward's LDS images are free)
@@ -885,6 +881,7 @@ __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
 
 std::atomic<int> g_policy_tail{1};
 std::atomic<int> g_q_chain{1};
+std::atomic<int> g_chain_fault{0};     // tuning key "chain_fault": the NEXT critic step loses its first workgroup (test hook)
 
 // The tail's three [16][kPostPitch] images live in the first hidden image where they fit (H >= 188:
 // the second image is still being read by other head waves), else behind both images.
@@ -992,8 +989,10 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
                     mlp_backward_supported(f.H, 1, 0, c.bwd.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: nets=%d H=%d", c.nets, f.H);
   const int tiles = (f.B + kRows - 1) / kRows;
+  QCriticStep launch = c;
+  launch.lose_first_target = g_chain_fault.exchange(0);      // (one launch, then off again)
   hipLaunchKernelGGL(q_critic_step_kernel, dim3(tiles * 2 * c.nets + 1), dim3(256),
-                     chain_lds_bytes(f.H), stream, c);
+                     chain_lds_bytes(f.H), stream, launch);
   TONIC_CHECK_LAUNCH("q_critic_step_kernel");
   return TONIC_OK;
 }
