@@ -411,15 +411,35 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
   if (post == POST_NONE) return;                    // scalar
 
   // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
-  __syncthreads();
-  const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
-  float* terms = lds + a.tail_offset + 2 * kRows * kPostPitch;      // [16 rows][kPostPitch] log-prob terms
   const int prow = tid >> 4, slot = tid & 15, A = a.NH;
   const int64_t grow = r0 + prow;
   const bool ok = grow < a.B;
+  // The encoder's operands (raw observations, statistics: lines nobody has touched in this launch)
+  // are requested FIRST — they fly over the barrier and the sampling arithmetic below.
+  const int O = a.enc_O;
+  const int64_t src = min(grow, (int64_t)a.B - 1);
+  const bool pair = enc_out2 != nullptr;
+  float x[8], y[8], mean[8], sdev[8];
+  if (enc_out != nullptr) {                           // scalar
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = min(16 * u + slot, O - 1);
+      x[u] = enc_obs[src * O + c];
+      y[u] = pair ? enc_obs2[src * O + c] : 0.f;
+      mean[u] = a.enc_mean[c];
+      sdev[u] = a.enc_std[c];
+    }
+  }
+  __syncthreads();
+  const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
   const int padded = (A + 15) / 16 * 16;
-  for (int aa = slot; aa < padded; aa += 16) {
-    float term = 0.f, action = 0.f;
+  // this thread's log-probability terms: actions slot, slot + 16, slot + 32, slot + 48
+  float term4[kPostPitch / 16] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < kPostPitch / 16; ++u) {
+    const int aa = slot + 16 * u;
+    if (aa >= padded) break;                          // scalar
+    float action = 0.f;
     if (aa < A) {
       const float first = headbuf[prow * kPostPitch + aa];
       if (post == POST_SQUASHED_SAMPLE) {
@@ -427,7 +447,7 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
         const float eps = (has_eps && ok) ? post_eps[grow * A + aa] : 0.f;
         const SquashedSample sm =
             squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
-        term = sm.logp_term;
+        term4[u] = sm.logp_term;
         if (ok) {
           post_actions[grow * A + aa] = sm.action;
           if (post_sigma != nullptr) post_sigma[grow * A + aa] = sm.sigma;
@@ -445,23 +465,21 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
           enc_out2[grow * a.enc_ld + a.enc_O + aa] = enc_act2[grow * A + aa];
       }
     }
-    terms[prow * kPostPitch + aa] = term;
   }
   if (enc_out != nullptr) {
-    // ... and the normalised observation columns, eight 16-column strips at a time: all loads
-    // first, through clamped addresses (a load under a lane-predicated branch waits for itself)
-    const int O = a.enc_O;
-    const int64_t src = min(grow, (int64_t)a.B - 1);
-    const bool pair = enc_out2 != nullptr;
+    // ... and the normalised observation columns, eight 16-column strips at a time (the first
+    // eight were requested above): all loads first, through clamped addresses (a load under a
+    // lane-predicated branch waits for itself)
     for (int c0 = 0; c0 < O; c0 += 8 * 16) {
-      float x[8], y[8], mean[8], sdev[8];
+      if (c0 > 0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = min(c0 + 16 * u + slot, O - 1);
-        x[u] = enc_obs[src * O + c];
-        y[u] = pair ? enc_obs2[src * O + c] : 0.f;
-        mean[u] = a.enc_mean[c];
-        sdev[u] = a.enc_std[c];
+        for (int u = 0; u < 8; ++u) {
+          const int c = min(c0 + 16 * u + slot, O - 1);
+          x[u] = enc_obs[src * O + c];
+          y[u] = pair ? enc_obs2[src * O + c] : 0.f;
+          mean[u] = a.enc_mean[c];
+          sdev[u] = a.enc_std[c];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -477,17 +495,19 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
     }
   }
   if (post != POST_SQUASHED_SAMPLE || post_logp == nullptr) return;
-  __syncthreads();
-  if (tid < kRows && r0 + tid < a.B) {
-    // the fold of sac_sample_kernel, re-played: G lanes, lane j summing terms j, j + G, ...
-    // in turn, then a xor tree (lane j adds lane j ^ off)
-    float* v = terms + tid * kPostPitch;
-    const int G = sample_group(A);
-    for (int aa = G; aa < A; ++aa) v[aa % G] += v[aa];
-    for (int off = G >> 1; off >= 1; off >>= 1)
-      for (int j = 0; j < off; ++j) v[j] += v[j + off];
-    post_logp[r0 + tid] = v[0];
-  }
+  // The fold of sac_sample_kernel, re-played on the registers of the row's 16 threads: there G
+  // lanes (G = sample_group(A) <= 32) hold one sample, lane j sums terms j, j + G, ... in turn,
+  // then a xor tree runs (lane j adds lane j ^ off).  Thread `slot` holds the terms of lanes slot
+  // and slot + 16 (and what the first loop adds to them): the tree's level 16 is one addition in
+  // the thread, the levels below are shuffles among the row's 16 lanes — the same additions with
+  // the same operands in the same order, no LDS, no second barrier.
+  const int G = sample_group(A);
+  float lo = term4[0], hi = term4[1];
+  if (slot + 32 < A) lo = lo + term4[2];              // (first loop: v[aa % 32] += v[aa], A > 32)
+  if (slot + 48 < A) hi = hi + term4[3];
+  float val = G == 32 ? lo + hi : lo;                 // (level 16)
+  for (int off = min(G, 16) >> 1; off >= 1; off >>= 1) val = val + __shfl_xor(val, off, 16);
+  if (slot == 0 && ok) post_logp[grow] = val;
   stamp(7);
 }
 
