@@ -14,6 +14,8 @@ struct PackedActor {
   }
 };
 
+constexpr int64_t kRecordFromSegment = 16384;     // floats of one step's observations
+
 struct Collect16Args {
   const float* packed; const float* obs; const float* eps;
   const float* next_obs; const float* rewards; const float* resets; const float* terminations;
@@ -41,6 +43,13 @@ struct Collect16Args {
   // (pinned host memory) once all of its reads of the pinned block and its writes to it are
   // complete; the host spins on those words instead of synchronising the stream.
   unsigned* done_flags; unsigned done_seq;
+  // Many workers (the step's observations are more than a staging tile: W * O >= kRecordFromSegment):
+  // MeanStd.record does not pull the whole observation block over PCIe a second time — at 1 280
+  // workers the step is bound by PCIe bytes (obs + eps for the actor tiles, obs again for the record,
+  // next obs for the outcome: 38 us of a 42 us round trip were the record role) — but reads the
+  // Segment row the actor tiles have just written: tile_done[b] (device memory) = done_seq once
+  // workgroup b's row stores are released.  null: the record reads the pinned block itself.
+  unsigned* tile_done;
   // Developer probe (null: off; TONIC_AMD_COLLECTOR_STAMPS=1): 100 MHz wall-clock stamps of one
   // actor workgroup, the record workgroup and one copy workgroup, summed per phase:
   // stamps[role * 8 + phase] += now - t0 (t0 = the moment the role saw its command), [.. + 7] counts.

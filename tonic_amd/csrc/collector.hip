@@ -264,6 +264,7 @@ struct tonic_collector {
   bool actor_packed, waiting;
   // transport 2: the resident collect kernel
   unsigned* d_relay;
+  unsigned* d_tile_done;         // [4096] device words: see Collect16Args::tile_done
   bool live;
   double park_us;
   unsigned long long* d_stamps;   // developer probe (TONIC_AMD_COLLECTOR_STAMPS=1)
@@ -372,7 +373,9 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   const int64_t packed = PackedActor(collect16_ks1(c->O), collect16_ap(c->A)).total;
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_packed), packed * 4)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess)
+      (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_done), 4096 * 4)) != hipSuccess ||
+      (e = hipMemset(c->d_tile_done, 0, 4096 * 4)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
   if (c->wide) {
     c->wide_ws_bytes = wide_collect_workspace_bytes(c->W, c->O, c->A);
@@ -421,6 +424,7 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (c->d_packed) (void)hipFree(c->d_packed);
   if (c->staged) (void)hipFree(c->staged);
   if (c->d_relay) (void)hipFree(c->d_relay);
+  if (c->d_tile_done) (void)hipFree(c->d_tile_done);
   if (c->learner_done) (void)hipEventDestroy(c->learner_done);
   if (c->collect_done) (void)hipEventDestroy(c->collect_done);
   if (c->actions_out) (void)hipEventDestroy(c->actions_out);
@@ -491,8 +495,10 @@ Collect16Args step_arguments(tonic_collector* c) {
   a.norm_stride = 2 * c->O;
   a.actions_out = field(c, TONIC_COLLECTOR_ACTIONS);
   a.W = c->W; a.O = c->O; a.A = c->A;
-  if (c->transport != 1)
+  if (c->transport != 1) {
     a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+    if ((int64_t)c->W * c->O >= kRecordFromSegment && c->norm_acc != nullptr) a.tile_done = c->d_tile_done;
+  }
   a.stamps = c->d_stamps;
   return a;
 }

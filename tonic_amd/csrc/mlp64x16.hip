@@ -899,6 +899,14 @@ __device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Actor role, many workers: this workgroup's rows of the Segment's observation row are released
+// (the system-scope release in front of the completion word wrote them back) — tell the record role.
+__device__ __forceinline__ void collect_signal_rows(const Collect16Args& c) {
+  if (c.tile_done != nullptr && threadIdx.x == 0)
+    __hip_atomic_store(c.tile_done + blockIdx.x, c.done_seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void collect_stamp(const Collect16Args& c, int role, int phase) {
   if (c.stamps != nullptr && threadIdx.x == 0) {
     // (no-return atomics: a read-modify-write would park the wave for an L2 round trip per stamp)
@@ -1069,6 +1077,20 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     if (c.norm_acc == nullptr) { collect_signal_done(c); return; }
     constexpr int kHalf = kCollectLds / 2;
     const int lane = tid & 63, wave = tid >> 6;
+    const bool from_segment = HOST && c.tile_done != nullptr;      // scalar (see Collect16Args)
+    if (from_segment) {
+      // every actor workgroup's rows of this step (each thread watches a share of the words;
+      // bounded like every wait of the collector: 50 ms, then whatever is there)
+      const unsigned long long t0 = wall_clock64();
+      for (int b = tid; b < act_blocks; b += 256) {
+        while (__hip_atomic_load(c.tile_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+               c.done_seq) {
+          __builtin_amdgcn_s_sleep(2);
+          if (wall_clock64() - t0 > 5000000ull) break;
+        }
+      }
+      __syncthreads();
+    }
     // The next launch's record reads this step's next observations (trainer.py:44-56 hands them
     // back as the observations of step t + 1): touch them now, from the workgroup slot that will
     // need them, so that the sequential chain does not start behind an HBM round trip.
@@ -1085,7 +1107,9 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       __syncthreads();
       if (HOST) {
         // the whole chunk (<= 32 KB) as 16-byte requests, all in flight: ONE PCIe round trip
-        const float* src = c.obs + w0 * O;
+        // (from_segment: the same system-scope loads on the Segment row — they do not trust an
+        //  L2 line that this resident kernel may have touched before the row was written)
+        const float* src = (from_segment ? c.seg_obs + c.row * W * O : c.obs) + w0 * O;
         const int64_t count = rows * O, vecs = count >> 2;
         f32x4 v[8];
 #pragma unroll
@@ -1334,6 +1358,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
   }
   retire_touches(eps_sink, c.seg_lp);
   collect_signal_done(c);
+  collect_signal_rows(c);
   if (blockIdx.x == 0) collect_stamp(c, 0, 6);       // flag out
 }
 
