@@ -357,9 +357,15 @@ int64_t tonic_collector_block_offset(const void* block, int32_t field);   /* byt
  * loop of tonic/environments/distributed.py:28-58 for the zero-cost synthetic benchmark
  * environment of SURVEY.md §8d): next_observations [W,O] -> the NEXT_OBSERVATIONS and OBSERVATIONS
  * fields, rewards[w] = -sum_a actions[w][a]^2 (float32, left to right).  actions == NULL: the
- * block's ACTIONS field.  Flags are the caller's business. */
+ * block's ACTIONS field.  Flags are the caller's business; ring != 0: they are final as well, the
+ * record is complete -> tonic_collector_ring from inside the call. */
 int tonic_collector_synthetic_step(void* block, const float* next_observations,
-                                   const float* actions);
+                                   const float* actions, int32_t ring);
+/* The environment's side of an ARMED step (tonic_collector_arm below): the step record in the block
+ * is complete — issue the command the agent has prepared for exactly this moment.  Host stores only
+ * (no HIP): callable from a forked worker; tonic_collector_worker_done of the LAST worker group does
+ * it itself, before it wakes the parent.  Returns 1 if a command went out, 0 if nothing was armed. */
+int tonic_collector_ring(void* block);
 int64_t tonic_collector_worker_wait(void* block, int64_t seen_sequence, double timeout_s);
 int tonic_collector_worker_done(void* block);
 int tonic_collector_submit_actions(void* block);
@@ -385,6 +391,18 @@ int tonic_collector_begin_rollout(tonic_collector_t* collector, const float* d_a
 int tonic_collector_ppo_step(tonic_collector_t* collector, int64_t row, int32_t eps_slot,
                              int32_t store_previous);
 int tonic_collector_wait_actions(tonic_collector_t* collector, double timeout_s);
+/* tonic_collector_arm: the command of tonic_collector_ppo_step(row, eps_slot, store_previous), NOT
+ * issued but left in the block's header for the environment side to issue (tonic_collector_ring) the
+ * moment its step record is complete — the trainer's path from `environment.step` returning to
+ * `agent.update` / `agent.step` (tonic/utils/trainer.py:44-56) then runs while the GPU works instead
+ * of in front of it.  Returns 1 (armed), 0 (not possible now: only a resident kernel, transport 2,
+ * past the first step of its rollout, can be commanded by a process that cannot launch), < 0 errors.
+ * tonic_collector_claim: 1 = the environment issued it, the step is in flight (wait_actions next);
+ * 0 = it did not (the command is withdrawn; issue tonic_collector_ppo_step yourself).  Every other
+ * entry point claims first, so an armed command can never be issued behind the handle's back. */
+int tonic_collector_arm(tonic_collector_t* collector, int64_t row, int32_t eps_slot,
+                        int32_t store_previous);
+int tonic_collector_claim(tonic_collector_t* collector);
 int tonic_collector_end_rollout(tonic_collector_t* collector, int64_t last_row,
                                 void* learner_stream);
 

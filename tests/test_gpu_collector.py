@@ -329,6 +329,72 @@ def test_step_issued_from_update_is_bit_identical(lib, monkeypatch):
         assert torch.equal(state_a[key], state_b[key]), key
 
 
+@pytest.mark.parametrize('kind', ['sequential', 'parallel', 'batch'])
+def test_step_issued_by_the_environment_is_bit_identical(lib, monkeypatch, kind):
+    """In the steady state of a block-fed loop `agent.step` leaves the NEXT step's command in the
+    block's header and the environment issues it the moment its step record is complete
+    (Sequential / SyntheticBatch: at the end of their step; Parallel: the last worker group, before
+    the parent wakes up); `agent.update` only confirms.  Everything a rollout leaves behind must be
+    bit-identical to the run in which update() issues the command itself (TONIC_AMD_ARM=0) — with
+    test episodes, foreign observations and episode ends in between."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments
+    O, A, W, T = 6, 3, 12, 10
+
+    def build():
+        if kind == 'batch':
+            return environments.SyntheticBatch(W, O, A, max_episode_steps=7, pool=5)
+        groups = 2 if kind == 'parallel' else 1
+        return environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=4),
+                                       groups, W // groups)
+
+    def run(arm):
+        monkeypatch.setenv('TONIC_AMD_ARM', '1' if arm else '0')
+        env = build()
+        env.initialize(seed=3)
+        agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T, batch_iterations=2))
+        agent.initialize(env.observation_space, env.action_space, seed=9)
+        observations = env.start()
+        rng = np.random.RandomState(1)
+        test_obs = rng.standard_normal((2, O)).astype(np.float32)
+        trace = []
+        for t in range(2 * T + 3):
+            if t == 5:                                   # foreign observations: a copy of the block's
+                observations = observations.copy()
+            actions = agent.step(observations, t * W)
+            trace.append(actions.copy())
+            observations, infos = env.step(actions)
+            if t == 15:                                  # foreign infos after the environment rang
+                infos = {k: v.copy() for k, v in infos.items()}
+            if t == 17:                                  # a test episode between step and update
+                trace.append(agent.test_step(test_obs, t * W))
+            agent.update(**infos, steps=t * W)
+            if t in (2, 7, 13):                          # test episodes between update and step
+                trace.append(agent.test_step(test_obs, t * W))
+            if t == T - 2:
+                kept = {k: v.clone() for k, v in agent.replay.buffers.items()}
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+        rung = agent.steps_issued_by_environment
+        agent.close()
+        if hasattr(env, 'close'):
+            env.close()
+        return trace, kept, state, rung
+
+    armed, kept_a, state_a, rung = run(True)
+    plain, kept_b, state_b, none = run(False)
+    assert rung >= 6 and none == 0, 'the environment must actually have issued steps'
+    assert len(armed) == len(plain)
+    for a, b in zip(armed, plain):
+        assert np.array_equal(a, b)
+    for key in ('observations', 'actions', 'next_observations', 'rewards', 'resets', 'terminations',
+                'log_probs'):
+        assert torch.equal(kept_a[key][:T - 2], kept_b[key][:T - 2]), key
+    for key in state_a:                                  # two learner updates incl. the normaliser
+        assert torch.equal(state_a[key], state_b[key]), key
+
+
 def test_completion_words_order_the_actions(lib):
     """The host must never read actions older than the completion words it waited for: many
     steps, host copy of the block's actions / rewards against what the kernels stored."""

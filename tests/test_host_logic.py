@@ -181,6 +181,60 @@ def test_synthetic_batch_protocol():
         assert np.array_equal(obs[keep], infos['observations'][keep])
 
 
+def test_environments_ring_the_block_when_their_step_record_is_complete():
+    """tonic_collector_ring / the `ring` argument of tonic_collector_synthetic_step / the last
+    worker group's tonic_collector_worker_done issue the command an agent has ARMED in the block's
+    header (tonic_collector_arm, GPU side) — host stores only.  Without a GPU the arming side is
+    played by hand: a word in the header's `armed` field must move to `command` exactly once, at the
+    step whose record it waits for, and nothing happens when nothing is armed."""
+    from tonic_amd import _lib, environments
+    lib = _lib.load()
+    O, A, W = 5, 2, 6
+
+    def words(block):
+        # (BlockHeader, csrc/collector.hip: 64-byte aligned words behind the offsets table)
+        return np.frombuffer(block.memory, np.uint64, 512, 0)
+
+    for kind in ('batch', 'sequential', 'parallel'):
+        if kind == 'batch':
+            env = environments.SyntheticBatch(W, O, A, max_episode_steps=4, pool=3)
+        else:
+            env = environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=4),
+                                          2 if kind == 'parallel' else 1, W // 2 if kind == 'parallel' else W)
+        env.initialize(seed=1)
+        env.start()
+        block = env.block
+        head = words(block)
+        assert lib.tonic_collector_ring(block.address) == 0          # nothing armed
+        # find the two words: arm a recognisable pattern through every 64-byte slot that is zero and
+        # see which one a ring moves (keeps this test independent of the header's exact layout)
+        armed_at = command_at = None
+        for slot in range(16, 512, 8):
+            if head[slot] != 0:
+                continue
+            before = head.copy()
+            head[slot] = (7 << 32) | 0x106
+            if lib.tonic_collector_ring(block.address) == 1:
+                changed = [i for i in range(512) if head[i] != before[i]]
+                armed_at = slot
+                command_at = [i for i in changed if head[i] == (7 << 32) | 0x106][0]
+                break
+            head[slot] = 0
+        assert armed_at is not None and head[armed_at] == 0, kind
+        # an environment step rings exactly once, whoever completes the record
+        for t in range(6):
+            head[command_at] = 0
+            head[armed_at] = ((8 + t) << 32) | 0x206
+            actions = block.out_actions if kind == 'batch' else np.zeros((W, A), np.float32)
+            env.step(actions)
+            assert head[armed_at] == 0 and head[command_at] == ((8 + t) << 32) | 0x206, (kind, t)
+            head[command_at] = 0
+            assert lib.tonic_collector_ring(block.address) == 0
+            assert head[command_at] == 0
+        if hasattr(env, 'close'):
+            env.close()
+
+
 def test_trainer_bookkeeping(tmp_path):
     import tonic_amd
     from tonic_amd import agents, environments, logger

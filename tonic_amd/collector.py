@@ -126,6 +126,11 @@ class Block:
     def shutdown(self):
         self.lib.tonic_collector_shutdown(self.address)
 
+    def ring(self):
+        """The step record is complete: issues the command the agent armed for this moment (if
+        any).  An environment calls this once its observations, outcome and flags are in place."""
+        return self.lib.tonic_collector_ring(self.address)
+
 
 class Collector:
     """GPU side of a block: fused act + store launches on the collector's own stream."""
@@ -140,6 +145,8 @@ class Collector:
         self.transport = transport
         self._step = lib.tonic_collector_ppo_step          # bound once: the per-step hot calls
         self._wait = lib.tonic_collector_wait_actions
+        self._arm = lib.tonic_collector_arm
+        self._claim = lib.tonic_collector_claim
 
     @property
     def handle(self):
@@ -176,6 +183,17 @@ class Collector:
         status = self._step(self._cell[0], row, eps_slot, store_previous)
         if status != 0:
             _lib.check(status, 'tonic_collector_ppo_step')
+
+    def arm(self, row, eps_slot, store_previous):
+        """Leaves the step's command with the environment (see Block.ring); False: not possible now."""
+        status = self._arm(self._cell[0], row, eps_slot, store_previous)
+        if status < 0:
+            _lib.check(status, 'tonic_collector_arm')
+        return status == 1
+
+    def claim(self):
+        """True: the environment issued the armed step (it is in flight); False: withdrawn."""
+        return self._claim(self._cell[0]) == 1
 
     def wait_actions(self, timeout=60.0):
         status = self._wait(self._cell[0], timeout)

@@ -49,6 +49,10 @@ struct BlockHeader {
   alignas(64) uint32_t act_seq;                    // sequence number of the last act command
   alignas(64) uint64_t command;                    // transport 2: the host's next command word
   alignas(64) uint32_t parked;                     // transport 2: written by the resident kernel
+  // transport 2: the NEXT command, prepared by the agent (tonic_collector_arm) and issued by
+  // whoever completes the step record it acts on (tonic_collector_ring: the environment's step
+  // call, or the last worker group in tonic_collector_worker_done); 0 = nothing armed
+  alignas(64) uint64_t armed;
 };
 static_assert(sizeof(BlockHeader) <= kHeaderBytes, "header does not fit its page");
 
@@ -107,6 +111,17 @@ bool wait_change(uint32_t* word, uint32_t seen, double timeout_s, int spin_itera
   }
 }
 
+// Issues the command the agent has armed, if any (host stores only: callable from a forked worker).
+// The exchange makes ring and claim / cancel mutually exclusive: exactly one side gets the word.
+int ring_armed(BlockHeader* h) {
+  if (__atomic_load_n(&h->armed, __ATOMIC_RELAXED) == 0) return 0;
+  const uint64_t word = __atomic_exchange_n(&h->armed, (uint64_t)0, __ATOMIC_ACQ_REL);
+  if (word == 0) return 0;
+  __atomic_store_n(&h->act_seq, (uint32_t)(word >> 32), __ATOMIC_RELEASE);
+  __atomic_store_n(&h->command, word, __ATOMIC_RELEASE);
+  return 1;
+}
+
 }  // namespace
 }  // namespace tonic
 
@@ -153,7 +168,7 @@ extern "C" int64_t tonic_collector_block_offset(const void* block, int32_t field
 // in float32, left to right.  actions == NULL: the block's ACTIONS field, where the act kernel
 // wrote them.  Host code only (no HIP call): five NumPy calls per step otherwise.
 extern "C" int tonic_collector_synthetic_step(void* block, const float* next_observations,
-                                              const float* actions) {
+                                              const float* actions, int32_t ring) {
   BlockHeader* h = header_of(block);
   TONIC_REQUIRE(h != nullptr && next_observations != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_synthetic_step: bad argument");
@@ -170,7 +185,16 @@ extern "C" int tonic_collector_synthetic_step(void* block, const float* next_obs
     for (int k = 0; k < A; ++k) sum += a[w * A + k] * a[w * A + k];
     rewards[w] = -sum;
   }
+  // ring: the caller knows that the flags in the block are final too (nobody resets at this
+  // step) -> the record is complete, the agent's armed command goes out from here
+  if (ring) ring_armed(h);
   return TONIC_OK;
+}
+
+extern "C" int tonic_collector_ring(void* block) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_ring: bad block");
+  return ring_armed(h);
 }
 
 extern "C" int64_t tonic_collector_worker_wait(void* block, int64_t seen, double timeout_s) {
@@ -193,7 +217,11 @@ extern "C" int tonic_collector_worker_done(void* block) {
   BlockHeader* h = header_of(block);
   TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_worker_done: bad block");
   const uint32_t before = __atomic_fetch_add(&h->done_count, 1u, __ATOMIC_ACQ_REL);
-  if (before + 1 == (uint32_t)h->groups) futex(&h->done_count, FUTEX_WAKE, 1, nullptr);
+  if (before + 1 == (uint32_t)h->groups) {
+    // the step record is complete: the GPU starts on it before the parent has even woken up
+    ring_armed(h);
+    futex(&h->done_count, FUTEX_WAKE, 1, nullptr);
+  }
   return TONIC_OK;
 }
 
@@ -262,6 +290,8 @@ struct tonic_collector {
   int64_t rows;
   unsigned seq;
   bool actor_packed, waiting;
+  bool armed;                   // tonic_collector_arm left a command in the block's header
+  int64_t armed_row;
   // transport 2: the resident collect kernel
   unsigned* d_relay;
   unsigned* d_tile_done;         // [4096] device words: see Collect16Args::tile_done
@@ -280,6 +310,18 @@ namespace {
       return TONIC_ERR_LAUNCH;                                                      \
     }                                                                               \
   } while (0)
+
+// Takes the armed command back.  1: the environment has issued it meanwhile — the step is in
+// flight and the handle's bookkeeping catches up; 0: it was never issued (or nothing was armed).
+int claim_armed(tonic_collector* c) {
+  if (!c->armed) return 0;
+  c->armed = false;
+  if (__atomic_exchange_n(&c->host->armed, (uint64_t)0, __ATOMIC_ACQ_REL) != 0) return 0;
+  c->seq += 1;
+  c->last_row = c->armed_row;
+  c->waiting = true;
+  return 1;
+}
 
 // Where the kernels read / write field `f`: the mapped block (transport 0) or its device copy.
 float* field(tonic_collector* c, int f) {
@@ -399,6 +441,7 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
 extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (c == nullptr) return TONIC_OK;
   // teardown: nothing useful can be done about a failing release
+  if (claim_armed(c)) (void)tonic_collector_wait_actions(c, 1.0);   // (issued by the environment)
   if (c->live) {                     // a stop command (nothing to store) ends the resident kernel
     c->seq += 1;
     __atomic_store_n(&c->host->command, ((uint64_t)c->seq << 32) | 8u, __ATOMIC_RELEASE);
@@ -521,6 +564,29 @@ int launch_resident(tonic_collector* c, unsigned first_seq) {
 
 }  // namespace
 
+extern "C" int tonic_collector_arm(tonic_collector_t* c, int64_t row, int32_t eps_slot,
+                                   int32_t store_previous) {
+  TONIC_REQUIRE(c && c->seg[0] && c->actor_packed && row >= 0 && row < c->rows && eps_slot >= -1 &&
+                    eps_slot <= 1 && (!store_previous || row > 0) && !c->armed,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_arm: bad row %lld / slot %d",
+                (long long)row, eps_slot);
+  // only a RESIDENT kernel can be commanded by somebody who cannot launch (a worker process)
+  if (c->transport != 2 || !c->live || c->wide || (c->norm_acc != nullptr && !c->hist_loaded))
+    return 0;
+  const uint64_t word = ((uint64_t)(c->seq + 1) << 32) | ((uint64_t)row << 8) |
+                        (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
+                        (eps_slot == 1 ? 1u : 0u);
+  c->armed = true;
+  c->armed_row = row;
+  __atomic_store_n(&c->host->armed, word, __ATOMIC_RELEASE);
+  return 1;
+}
+
+extern "C" int tonic_collector_claim(tonic_collector_t* c) {
+  TONIC_REQUIRE(c != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_claim: bad argument");
+  return claim_armed(c);
+}
+
 extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32_t eps_slot,
                                         int32_t store_previous) {
   TONIC_REQUIRE(c && c->seg[0] && c->actor_packed, TONIC_ERR_INVALID_ARGUMENT,
@@ -529,6 +595,7 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
                     (!store_previous || row > 0),
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_ppo_step: bad row %lld / slot %d",
                 (long long)row, eps_slot);
+  claim_armed(c);
   TONIC_REQUIRE(!c->waiting, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_ppo_step: the previous step's actions were never waited for");
   if (c->transport == 1) {
@@ -654,6 +721,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
 
 extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_row,
                                            void* learner_stream) {
+  if (c != nullptr) claim_armed(c);
   TONIC_REQUIRE(c && c->seg[0] && last_row < c->rows && !c->waiting, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_end_rollout: bad argument");
   const int64_t final_row = last_row;          // the last row that belongs to the rollout

@@ -94,6 +94,7 @@ class Sequential:
     def step(self, actions):
         _step_group(self.environments, self.lengths, self.max_episode_steps, self.block, 0,
                     np.asarray(actions))
+        self.block.ring()           # the record is complete (Parallel: the last worker group rings)
         return _outputs(self.block, self.copy_outputs)
 
     def render(self, mode='human', *args, **kwargs):

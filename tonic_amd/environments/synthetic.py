@@ -104,24 +104,31 @@ class SyntheticBatch:
 
     def step(self, actions):
         block = self.block
+        # nobody can time out at this step: the flags stay all False
+        quiet = self.termination_probability <= 0 and \
+            self._quiet + 1 + self._longest < self.max_episode_steps
+        rung = False
         if self.pool and actions is block.out_actions:
             # the agent handed the block's own actions over: the whole record is one host call
-            # (tonic_collector_synthetic_step) instead of five NumPy calls
+            # (tonic_collector_synthetic_step) instead of five NumPy calls — and when the flags in
+            # the block are final too, the record is complete inside that call, which then issues
+            # the command the agent has armed for this moment (Block.ring)
+            rung = quiet and not self._flags_set
             self._cursor = (self._cursor + 1) % self.pool
-            self._synthetic_step(self._block_address, self._pool_rows[self._cursor], None)
+            self._synthetic_step(self._block_address, self._pool_rows[self._cursor], None, rung)
         else:
             next_observations = self._observe()
             np.copyto(block.next_observations, next_observations)
             np.copyto(block.observations, next_observations)
             np.einsum('ij,ij->i', actions, actions, out=block.rewards, casting='same_kind')
             np.negative(block.rewards, out=block.rewards)
-        if self.termination_probability <= 0 and \
-                self._quiet + 1 + self._longest < self.max_episode_steps:
-            # nobody can time out at this step: the flags stay all False
+        if quiet:
             self._quiet += 1
             if self._flags_set:
                 self._write_flags(self._flags, self._flags)
                 self._flags_set = False
+            if not rung:
+                block.ring()
             return self._outputs()
         self.lengths += self._quiet + 1
         self._quiet = 0
@@ -136,4 +143,5 @@ class SyntheticBatch:
         self._longest = int(self.lengths.max())
         self._write_flags(resets, terminations)
         self._flags_set = True
+        block.ring()
         return self._outputs()

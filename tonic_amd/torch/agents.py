@@ -318,7 +318,7 @@ class A2C(Agent):
         self.action_size = action_space.shape[0]
         self._replicate([self.model.flat_actor.flat, self.model.flat_critic.flat], own_noise=True)
         self._collector = self._block = None
-        self._speculated = self._eps_ahead = self._block_fed = False
+        self._speculated = self._eps_ahead = self._block_fed = self._armed = False
         # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
         # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
         # around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per round trip)
@@ -398,6 +398,11 @@ class A2C(Agent):
         # the caller has been handing over the block's own arrays so far
         self._speculated, self._block_fed = False, False
         self._speculate = os.environ.get('TONIC_AMD_SPECULATE', '1') != '0'
+        # step() may leave the next command with the environment (Block.ring issues it)
+        self._armed = False
+        self.steps_issued_by_environment = 0
+        self._arm_steps = (self._speculate and not self.model.return_normalizer
+                           and os.environ.get('TONIC_AMD_ARM', '1') != '0')
 
     # -- shapes beyond the fused act kernel (O > 32 or A > 8): staged copies + separate launches
     def _wide(self):
@@ -450,6 +455,11 @@ class A2C(Agent):
             self._speculated = False
             self._noise.take(block.eps[slot ^ 1])      # the step after this one
             self._slot = slot ^ 1
+            # ... whose command is left with the ENVIRONMENT: it issues it the moment its step
+            # record is complete (Block.ring), update() only confirms (see there)
+            replay = self.replay
+            if self._arm_steps and replay.index + 2 < replay.max_size:
+                self._armed = self._collector.arm(replay.index + 1, slot ^ 1, True)
             self._collector.wait_actions()
             self._block_fed = True
             self.last_observations = observations
@@ -457,6 +467,7 @@ class A2C(Agent):
             return actions
         if self._wide():
             return self._step_staged(observations)
+        self._claim()
         block = getattr(self, '_block', None)
         if self._collector is None or block.workers != len(observations):
             self._settle()
@@ -518,9 +529,18 @@ class A2C(Agent):
     def _settle(self):
         """Waits out a step that update() issued early and nobody asked for yet (the Segment row it
         wrote lies beyond the rows stored so far and is rewritten by the real step)."""
+        self._claim()
         if getattr(self, '_speculated', False):
             self._collector.wait_actions()
             self._speculated = False
+
+    def _claim(self):
+        """Takes back a command that step() left with the environment: issued meanwhile = a step
+        in flight like one update() issued early; not issued = withdrawn."""
+        if getattr(self, '_armed', False):
+            self._armed = False
+            if self._collector.claim():
+                self._speculated = True
 
     def close(self):
         """Releases what a live agent holds beyond its tensors: waits out a step issued ahead,
@@ -563,7 +583,16 @@ class A2C(Agent):
             # the steady state of a block-fed loop (the general form is below): the next step's
             # command goes out first, the bookkeeping runs while the GPU works
             index = replay.index
-            self._collector.ppo_step(index + 1, self._slot, True)
+            if self._armed:
+                # step() left this command with the environment, which normally has issued it
+                # from inside its own step call, before the trainer's loop even got here
+                self._armed = False
+                if self._collector.claim():
+                    self.steps_issued_by_environment += 1
+                else:
+                    self._collector.ppo_step(index + 1, self._slot, True)
+            else:
+                self._collector.ppo_step(index + 1, self._slot, True)
             self._speculated = True
             replay.index = index + 1
             normalizer = self.model.observation_normalizer
@@ -573,6 +602,7 @@ class A2C(Agent):
             return
         if self._wide():
             return self._update_staged(observations, rewards, resets, terminations)
+        self._claim()
         # (identity: the arrays tonic_amd.environments hand out ARE the block's fields)
         if (self._block_fed and observations is block.out_next_observations
                 and rewards is block.out_rewards and resets is block.out_resets
@@ -582,10 +612,12 @@ class A2C(Agent):
             # its noise drawn ahead, the next step's launch goes out FIRST — the rest of this call,
             # the trainer's bookkeeping and the head of the next agent.step run while the GPU
             # works.  step() issues it again if it turns out to be obsolete.
-            if (self._eps_ahead and self._speculate and replay.index + 2 <= replay.max_size):
+            if (self._eps_ahead and self._speculate and replay.index + 2 <= replay.max_size
+                    and not self._speculated):
                 self._collector.ppo_step(replay.index + 1, self._slot, True)
                 self._speculated = True
         else:
+            self._settle()      # (a step the environment issued reads the block: not under it)
             if (observations is not block.out_next_observations
                     and observations is not block.next_observations):
                 np.copyto(block.next_observations, observations)
