@@ -353,6 +353,14 @@ int64_t tonic_collector_block_bytes(int64_t W, int32_t O, int32_t A);
 int tonic_collector_block_init(void* block, int64_t bytes, int64_t W, int32_t O, int32_t A,
                                int32_t worker_groups);
 int64_t tonic_collector_block_offset(const void* block, int32_t field);   /* bytes; < 0: error */
+/* The environment's promise about the rows it writes (tonic/environments/distributed.py:41-57: a
+ * worker's `observations` row of step t + 1 IS its `next_observations` row of step t unless it reset,
+ * in which case it is the reset observation): with it, steps of many workers (W * O >= 16 384 floats,
+ * where the step is bound by PCIe bytes) fetch each observation row ONCE — the act launch writes the
+ * rows of the workers whose reset flag is 0 to the previous Segment row's next_observations from the
+ * copy it holds anyway, only the rows of workers that reset are read from NEXT_OBSERVATIONS.  Off by
+ * default: a block filled by anybody else keeps the two fields independent. */
+int tonic_collector_block_carry_over(void* block, int32_t promised);
 /* A vectorised simulator's step record in one host call (no reference counterpart: the per-worker
  * loop of tonic/environments/distributed.py:28-58 for the zero-cost synthetic benchmark
  * environment of SURVEY.md §8d): next_observations [W,O] -> the NEXT_OBSERVATIONS and OBSERVATIONS

@@ -94,6 +94,53 @@ def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     collector.close()
 
 
+@pytest.mark.parametrize('transport,O,A,W', [(t, O, A, W) for t in (0, 2)
+                                             for O, A, W in ((28, 8, 1280), (17, 6, 1024), (3, 2, 6000))])
+def test_carried_over_rows_cross_pcie_once(lib, transport, O, A, W):
+    """Many workers + a block whose writer promised carry-over (tonic_collector_block_carry_over):
+    the act launch stores the observation rows of the workers that did NOT reset as the previous
+    step's next observations, the copy role fetches the rows of those that did.  The Segment must
+    hold bit-exact copies of what an environment following the reference's protocol
+    (distributed.py:41-57) wrote — including rows that reset and a last row stored by end_rollout."""
+    from tonic_amd.collector import Block, Collector
+    T = 6
+    rng = np.random.RandomState(O * 1000 + W)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in _actor(O, A, 7)])).cuda()
+    block = Block(W, O, A)
+    block.promise_carry_over()
+    collector = Collector(block, transport)
+    seg = _segment(T, W, O, A)
+    sums = torch.zeros(2 * O, device='cuda')
+    collector.bind_segment(seg, sums, T)
+    torch.cuda.synchronize()
+    collector.begin_rollout(flat)
+    want = {k: np.full(tuple(v.shape), np.nan, np.float32) for k, v in seg.items()}
+    observations = rng.standard_normal((W, O)).astype(np.float32)
+    for t in range(T):
+        block.observations[:] = observations
+        block.eps[t & 1][:] = rng.standard_normal((W, A)).astype(np.float32)
+        collector.ppo_step(t, t & 1, t > 0)
+        collector.wait_actions()
+        want['observations'][t] = observations
+        # the environment's answer: next observations, flags; reset workers start over
+        next_observations = rng.standard_normal((W, O)).astype(np.float32)
+        resets = rng.uniform(size=W) < (0.0 if t == 2 else 0.3 if t != 3 else 1.0)
+        outcome = dict(next_observations=next_observations,
+                       rewards=rng.standard_normal(W).astype(np.float32),
+                       resets=resets.astype(np.float32),
+                       terminations=(resets & (rng.uniform(size=W) < 0.5)).astype(np.float32))
+        for key, value in outcome.items():
+            getattr(block, key)[:] = value
+            want[key][t] = value
+        observations = next_observations.copy()
+        observations[resets] = rng.standard_normal((int(resets.sum()), O)).astype(np.float32)
+    collector.end_rollout(T - 1)
+    torch.cuda.synchronize()
+    for key in ('observations', 'next_observations', 'rewards', 'resets', 'terminations'):
+        assert np.array_equal(seg[key].cpu().numpy(), want[key]), key
+    collector.close()
+
+
 def test_collector_equals_device_resident_collect(lib):
     """The host-in-the-loop launch is the device-resident packed collect kernel with the outcome
     deferred by one step: identical Segment bits for identical inputs, both transports."""

@@ -116,6 +116,7 @@ SIGNATURES = {
     'tonic_collector_block_offset': (c_i64, [c_vp, c_i32]),
     'tonic_collector_synthetic_step': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32]),
     'tonic_collector_ring': (ctypes.c_int, [c_vp]),
+    'tonic_collector_block_carry_over': (ctypes.c_int, [c_vp, c_i32]),
     'tonic_collector_arm': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
     'tonic_collector_claim': (ctypes.c_int, [c_vp]),
     'tonic_collector_worker_wait': (c_i64, [c_vp, c_i64, c_f64]),

@@ -126,6 +126,16 @@ class Block:
     def shutdown(self):
         self.lib.tonic_collector_shutdown(self.address)
 
+    def promise_carry_over(self, promised=True):
+        """The writer of this block guarantees: a worker's `observations` row IS its
+        `next_observations` row of the step before unless its reset flag is set (what every
+        environment of tonic_amd.environments writes).  Many-worker steps then move each
+        observation row over PCIe once (tonic_collector_block_carry_over)."""
+        if os.environ.get('TONIC_AMD_CARRY_OVER', '1') == '0':        # (developer switch: A/B runs)
+            promised = False
+        _lib.check(self.lib.tonic_collector_block_carry_over(self.address, 1 if promised else 0),
+                   'tonic_collector_block_carry_over')
+
     def ring(self):
         """The step record is complete: issues the command the agent armed for this moment (if
         any).  An environment calls this once its observations, outcome and flags are in place."""

@@ -50,6 +50,12 @@ struct Collect16Args {
   // Segment row the actor tiles have just written: tile_done[b] (device memory) = done_seq once
   // workgroup b's row stores are released.  null: the record reads the pinned block itself.
   unsigned* tile_done;
+  // ... and the outcome's next observations do not cross PCIe a second time either when the
+  // environment has promised (tonic_collector_block_carry_over) that a worker's next observation IS
+  // its observation of the following step unless it reset: the actor tiles, which hold this step's
+  // observation rows anyway, write them to the PREVIOUS row's next_observations for the workers
+  // whose reset flag is 0; the copy role fetches only the rows of the workers that did reset.
+  int next_from_obs;
   // Developer probe (null: off; TONIC_AMD_COLLECTOR_STAMPS=1): 100 MHz wall-clock stamps of one
   // actor workgroup, the record workgroup and one copy workgroup, summed per phase:
   // stamps[role * 8 + phase] += now - t0 (t0 = the moment the role saw its command), [.. + 7] counts.

@@ -40,7 +40,8 @@ constexpr int kFields = TONIC_COLLECTOR_FIELD_COUNT;
 struct BlockHeader {
   uint32_t magic, version;
   int64_t W;
-  int32_t O, A, groups, reserved;
+  int32_t O, A, groups;
+  int32_t carry_over;          // the environment's promise (tonic_collector_block_carry_over)
   int64_t total_bytes;
   int64_t offset[kFields];                         // bytes from the start of the block
   alignas(64) uint32_t go_seq;                     // futex: bumped once per environment step
@@ -188,6 +189,14 @@ extern "C" int tonic_collector_synthetic_step(void* block, const float* next_obs
   // ring: the caller knows that the flags in the block are final too (nobody resets at this
   // step) -> the record is complete, the agent's armed command goes out from here
   if (ring) ring_armed(h);
+  return TONIC_OK;
+}
+
+extern "C" int tonic_collector_block_carry_over(void* block, int32_t promised) {
+  BlockHeader* h = header_of(block);
+  TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_block_carry_over: bad block");
+  __atomic_store_n(&h->carry_over, promised ? 1 : 0, __ATOMIC_RELEASE);
   return TONIC_OK;
 }
 
@@ -541,6 +550,9 @@ Collect16Args step_arguments(tonic_collector* c) {
   if (c->transport != 1) {
     a.done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
     if ((int64_t)c->W * c->O >= kRecordFromSegment && c->norm_acc != nullptr) a.tile_done = c->d_tile_done;
+    // (read per step: the environment may make its promise after the collector was created)
+    a.next_from_obs = (int64_t)c->W * c->O >= kRecordFromSegment &&
+                      __atomic_load_n(&c->host->carry_over, __ATOMIC_ACQUIRE) != 0;
   }
   a.stamps = c->d_stamps;
   return a;

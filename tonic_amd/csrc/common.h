@@ -116,6 +116,36 @@ __device__ __forceinline__ void add_rows(const float* column, int stride, int ro
   for (int w = 16 * full; w < rows; ++w) acc = acc + column[w * stride];
 }
 
+// The same chain over rows that are a CONSTANT 32 floats apart: the row distance is an immediate, so
+// two rows come with one ds_read2_b32 — an LDS instruction costs a lone wave ~19 cycles whatever it
+// fetches (scripts/ubench/chain.hip), and one per row was 5/6 of the chain's time.
+__device__ __forceinline__ void add_rows32(const float* column, int rows, float& acc) {
+  constexpr int kPitch = 32;
+  const int full = rows / 16;
+  float a[16], b[16];
+  auto fetch = [&](float (&v)[16], int batch) {
+    const float* first = column + 16 * kPitch * min(batch, max(full - 1, 0));      // past the end: re-read
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = first[u * kPitch];
+  };
+  auto fold = [&](const float (&v)[16]) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = acc + v[u];
+  };
+  if (full > 0) fetch(a, 0);
+  for (int batch = 0; batch < full; batch += 2) {
+    fetch(b, batch + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fold(a);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(a, batch + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (batch + 1 < full) fold(b);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int w = 16 * full; w < rows; ++w) acc = acc + column[w * kPitch];
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // MeanStd(clip) as passed through the C ABI (<= 0: no clipping) -> the bound the kernels clamp to.

@@ -1028,8 +1028,15 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
           term[u] = host_load1<SYS>(c.terminations, i);
         }
       }
-      for (int64_t f = f0; f < f1; f += 8 * 256 * 4)
-        wide_copy<SYS>(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
+      // (carry-over rows come from the actor tiles, see Collect16Args::next_from_obs: only the
+      //  rows of workers that reset are fetched here, behind their flags)
+      auto reset_row = [&](int64_t i) {
+        for (int k = 0; k < O; ++k) dst[i * O + k] = host_load1<SYS>(c.next_obs, i * O + k);
+      };
+      if (!c.next_from_obs) {
+        for (int64_t f = f0; f < f1; f += 8 * 256 * 4)
+          wide_copy<SYS>(c.next_obs + f, dst + f, nullptr, min<int64_t>(8 * 256 * 4, f1 - f), tid, 256);
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int64_t i = i0 + u * stride;
@@ -1037,6 +1044,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
           c.seg_rew[c.outcome_row * W + i] = rew[u];
           c.seg_rst[c.outcome_row * W + i] = rst[u];
           c.seg_term[c.outcome_row * W + i] = term[u];
+          if (c.next_from_obs && rst[u] != 0.f) reset_row(i);
         }
       }
       for (int64_t i = i0 + 2 * stride; i < W; i += stride) {          // (W > 2048)
@@ -1045,6 +1053,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         c.seg_rew[c.outcome_row * W + i] = r;
         c.seg_rst[c.outcome_row * W + i] = x;
         c.seg_term[c.outcome_row * W + i] = t;
+        if (c.next_from_obs && x != 0.f) reset_row(i);
       }
     } else if (c.outcome_row >= 0) {
       // all of this thread's loads first, then the stores (a plain copy loop waits per element)
@@ -1078,19 +1087,6 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     constexpr int kHalf = kCollectLds / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const bool from_segment = HOST && c.tile_done != nullptr;      // scalar (see Collect16Args)
-    if (from_segment) {
-      // every actor workgroup's rows of this step (each thread watches a share of the words;
-      // bounded like every wait of the collector: 50 ms, then whatever is there)
-      const unsigned long long t0 = wall_clock64();
-      for (int b = tid; b < act_blocks; b += 256) {
-        while (__hip_atomic_load(c.tile_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-               c.done_seq) {
-          __builtin_amdgcn_s_sleep(2);
-          if (wall_clock64() - t0 > 5000000ull) break;
-        }
-      }
-      __syncthreads();
-    }
     // The next launch's record reads this step's next observations (trainer.py:44-56 hands them
     // back as the observations of step t + 1): touch them now, from the workgroup slot that will
     // need them, so that the sequential chain does not start behind an HBM round trip.
@@ -1102,31 +1098,107 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     float* acc_out = c.norm_acc + (c.row + 1) * c.norm_stride;
     if (wave < 2 && lane < O) acc = acc_in[wave * O + lane];
     const int64_t rows_per_chunk = (kHalf / O) & ~3;            // (x4 rows: 16-byte aligned chunks)
-    for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
-      const int64_t rows = min(rows_per_chunk, W - w0);
-      __syncthreads();
-      if (HOST) {
-        // the whole chunk (<= 32 KB) as 16-byte requests, all in flight: ONE PCIe round trip
-        // (from_segment: the same system-scope loads on the Segment row — they do not trust an
-        //  L2 line that this resident kernel may have touched before the row was written)
-        const float* src = (from_segment ? c.seg_obs + c.row * W * O : c.obs) + w0 * O;
-        const int64_t count = rows * O, vecs = count >> 2;
-        f32x4 v[8];
+    if constexpr (HOST) {
+      // A chunk (<= 32 KB) is ONE batch of 16-byte requests, all in flight — one PCIe round trip, or
+      // (from_segment) one trip to the Segment row the actor tiles have just released, with the
+      // same system-scope loads: they do not trust an L2 line this resident kernel may have touched
+      // before the row was written.  TWO chunks are in flight at any time (two register sets): the
+      // trip of chunk i + 2 runs under the staging and the chains of chunks i and i + 1; waves 0
+      // and 1 request AFTER their chain, waves 2 and 3 at once.
+      // Staged at a row pitch of 32 floats whatever O is (<= 32 here): the chain then reads two rows
+      // per LDS instruction (add_rows32).
+      constexpr int kPitch = 32;
+      constexpr int64_t rows_per_chunk = kHalf / kPitch;           // 256 rows, <= 32 KB of requests
+      const unsigned row_magic = 0xffffffffu / (unsigned)O + 1u;   // floor(e / O) = umulhi(e, magic), e < 2^27
+      const bool whole = (O & 3) == 0;                             // a 16-byte request stays inside a row
+      const float* base = from_segment ? c.seg_obs + c.row * W * O : c.obs;
+      const int64_t chunks = (W + rows_per_chunk - 1) / rows_per_chunk;
+      if (from_segment) {
+        // every actor workgroup's rows of this step, ONE poller per word (they all finish within a
+        // microsecond or two of each other: their inputs cross PCIe together); bounded like every
+        // wait of the collector: 50 ms, then whatever is there
+        const unsigned long long t0 = wall_clock64();
+        for (int b = tid; b < act_blocks; b += 256) {
+          while (__hip_atomic_load(c.tile_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                 c.done_seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 5000000ull) break;
+          }
+        }
+        __syncthreads();
+      }
+      collect_stamp(c, 1, 2);                        // (probe) the actor tiles' rows are released
+      struct Set { f32x4 v[8]; float tail; };
+      auto request = [&](Set& set, int64_t chunk) {
+        if (chunk >= chunks) return;                               // scalar
+        const int64_t w0 = chunk * rows_per_chunk, rows = min(rows_per_chunk, W - w0);
+        const int64_t first = w0 * O, count = rows * O, vecs = count >> 2;
+        const int64_t ti = (vecs << 2) + tid;
+        const float* src = base + first;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (tid + u * 256 < vecs) v[u] = host_load4<SYS>(src, tid + u * 256);
-        const int64_t ti = (vecs << 2) + tid;
-        float tail = 0.f;
-        if (ti < count) tail = host_load1<SYS>(src, ti);
+          if (tid + u * 256 < vecs) set.v[u] = host_load4<SYS>(src, tid + u * 256);
+        set.tail = 0.f;
+        if (ti < count) set.tail = host_load1<SYS>(src, ti);
+      };
+      auto stage = [&](const Set& set, int64_t chunk) {
+        const int64_t w0 = chunk * rows_per_chunk, rows = min(rows_per_chunk, W - w0);
+        const int64_t count = rows * O, vecs = count >> 2;
+        auto put = [&](unsigned e, float v) {                      // element e of the chunk
+          const unsigned r = O == 1 ? e : __umulhi(e, row_magic);
+          const unsigned at = r * kPitch + (e - r * (unsigned)O);
+          tile[at] = v;
+          tile[kHalf + at] = v * v;
+        };
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (tid + u * 256 < vecs) {
-            const int64_t i = 4 * (int64_t)(tid + u * 256);
+            const unsigned e = 4u * (unsigned)(tid + u * 256);
+            const f32x4 v = set.v[u];
+            if (whole) {
+              // (one 16-byte write each: four dword writes at a 16-byte lane stride are 8-way bank
+              //  conflicts, 2 us per chunk)
+              const unsigned r = __umulhi(e, row_magic);
+              const unsigned at = r * kPitch + (e - r * (unsigned)O);
+              *reinterpret_cast<f32x4*>(tile + at) = v;
+              *reinterpret_cast<f32x4*>(tile + kHalf + at) =
+                  f32x4{v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]};
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { tile[i + e] = v[u][e]; tile[kHalf + i + e] = v[u][e] * v[u][e]; }
+              for (int j = 0; j < 4; ++j) put(e + j, v[j]);
+            }
           }
-        if (ti < count) { tile[ti] = tail; tile[kHalf + ti] = tail * tail; }
-      } else {  // staging with eight loads in flight per thread (a plain loop waits for every load)
+        const int64_t ti = (vecs << 2) + tid;
+        if (ti < count) put((unsigned)ti, set.tail);
+      };
+      auto turn = [&](Set& set, int64_t chunk) {
+        if (chunk >= chunks) return;                               // scalar
+        const int64_t rows = min(rows_per_chunk, W - chunk * rows_per_chunk);
+        __syncthreads();                                           // the previous chain has left the tile
+        if (chunk == 1) collect_stamp(c, 1, 5);                    // (probe) first chain over
+        stage(set, chunk);
+        if (chunk == 0) collect_stamp(c, 1, 3);                    // (probe) first chunk arrived, staged
+        __syncthreads();
+        if (chunk == 0) collect_stamp(c, 1, 4);
+        if (wave >= 2) {
+          request(set, chunk + 2);
+        } else {
+          if (lane < O) add_rows32(tile + wave * kHalf + lane, (int)rows, acc);
+          request(set, chunk + 2);
+        }
+      };
+      Set even, odd;
+      request(even, 0);
+      request(odd, 1);
+      for (int64_t chunk = 0; chunk < chunks; chunk += 2) {
+        turn(even, chunk);
+        turn(odd, chunk + 1);
+      }
+    } else {
+      for (int64_t w0 = 0; w0 < W; w0 += rows_per_chunk) {
+        const int64_t rows = min(rows_per_chunk, W - w0);
+        __syncthreads();
+        // staging with eight loads in flight per thread (a plain loop waits for every load)
         const float* src = c.obs + w0 * O;
         const int64_t count = rows * O;
         int64_t i = tid;
@@ -1142,9 +1214,9 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
           tile[i] = v;
           tile[kHalf + i] = v * v;
         }
+        __syncthreads();
+        if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
       }
-      __syncthreads();
-      if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
     }
     if (wave < 2 && lane < O) acc_out[wave * O + lane] = acc;
     retire_touches(sink, c.norm_acc);
@@ -1185,7 +1257,11 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     const int etid = (tid + 128) & 255;                           // noise on the other two waves
     f32x4 vo = {0.f, 0.f, 0.f, 0.f}, ve = {0.f, 0.f, 0.f, 0.f};
     float to = 0.f, te = 0.f;
+    // carry-over (Collect16Args::next_from_obs): the reset flags of the tile's workers ride along
+    const bool carry = HOST && c.next_from_obs != 0 && c.outcome_row >= 0;        // scalar
+    float reset_flag = 1.f;
     if constexpr (HOST) {
+      if (carry && tid < tile_rows) reset_flag = host_load1<SYS>(c.resets, t * 16 + tid);
       if (tid < o_vecs)
         vo = host_load4<SYS>(c.obs + o_first, tid);
       if ((o_vecs << 2) + tid < o_count)
@@ -1245,7 +1321,25 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         }
         if ((e_vecs << 2) + etid < e_count) SE[(e_vecs << 2) + etid] = te;
       }
+      float* SR = tile + 2048 + 512 + 128;         // [16] reset flags of the tile's workers
+      if (carry && tid < tile_rows) SR[tid] = reset_flag;
       __syncthreads();
+      if (carry) {
+        // the rows of the workers that did not reset ARE the previous step's next observations
+        // (floor(at / O) = umulhi(at, ceil(2^32 / O)): at < 16 O)
+        float* carried = c.seg_next + c.outcome_row * W * O + o_first;
+        const unsigned row_magic = 0xffffffffu / (unsigned)O + 1u;
+        auto row_of = [&](unsigned at) { return O == 1 ? at : __umulhi(at, row_magic); };
+        if (tid < o_vecs) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned at = 4u * (unsigned)tid + e;
+            if (SR[row_of(at)] == 0.f) carried[at] = vo[e];
+          }
+        }
+        const unsigned at = (unsigned)(o_vecs << 2) + (unsigned)tid;
+        if (at < (unsigned)o_count && SR[row_of(at)] == 0.f) carried[at] = to;
+      }
       if (blockIdx.x == 0) collect_stamp(c, 0, 0);   // inputs in LDS
       const int sr = s < tile_rows ? s : tile_rows - 1;
 #pragma unroll
@@ -1365,7 +1459,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
 // One launch per environment step.
 template <int KS1, int AP, bool HOST>
 __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
-  __shared__ float tile[kCollectLds];
+  __shared__ __attribute__((aligned(16))) float tile[kCollectLds];
   collect16_step<KS1, AP, HOST, false>(c, tile);
 }
 
@@ -1386,7 +1480,7 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
 template <int KS1, int AP>
 __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args c,
                                                                    CollectResident r) {
-  __shared__ float tile[kCollectLds];
+  __shared__ __attribute__((aligned(16))) float tile[kCollectLds];
   __shared__ unsigned long long command;
   const bool leader = blockIdx.x == gridDim.x - 1;
   const int act_blocks = (int)gridDim.x - 1 - kCollectCopyBlocks;
@@ -1426,6 +1520,7 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
     step.done_seq = expect;
     step.stamp_t0 = wall_clock64();
     if (word & 8) {                                // stop: only the pending outcome is stored
+      step.next_from_obs = 0;                      // (nobody acts: no observation rows to carry over)
       if (copy_role) collect16_step<KS1, AP, true, true>(step, tile);
       else collect_signal_done(step);
       return;

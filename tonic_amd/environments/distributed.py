@@ -86,6 +86,7 @@ class Sequential:
     def start(self):
         workers = len(self.environments)
         self.block = Block(workers, self.observation_space.shape[0], self.action_space.shape[0])
+        self.block.promise_carry_over()              # (_step_group writes exactly that)
         for i, environment in enumerate(self.environments):
             self.block.observations[i] = environment.reset()
         self.lengths = np.zeros(workers, int)
@@ -162,6 +163,7 @@ class Parallel:
         seed += _rank_offset(workers)                       # (see Sequential.initialize)
         self.block = Block(workers, self.observation_space.shape[0],
                            self.action_space.shape[0], worker_groups=self.worker_groups)
+        self.block.promise_carry_over()              # (_step_group writes exactly that)
         context = multiprocessing.get_context('fork')      # builders are closures (Q12)
         self.processes = []
         for i in range(self.worker_groups):

@@ -77,6 +77,7 @@ class SyntheticBatch:
         from tonic_amd.collector import Block
         self.block = Block(self.workers, self.observation_space.shape[0],
                            self.action_space.shape[0])
+        self.block.promise_carry_over()      # (step: observations = next observations | reset rows)
         self.lengths = np.zeros(self.workers, int)
         self._longest = 0                # max(lengths), kept by hand: a reduction per step is ~1 us
         self._flags = np.zeros(self.workers, bool)

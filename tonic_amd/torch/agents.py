@@ -21,6 +21,7 @@ generator, a2c.py:87-90) first rewinds the generator to where the reference woul
 import ctypes
 import os
 import random
+import weakref
 
 import numpy as np
 import torch
@@ -218,6 +219,21 @@ class _NoiseAhead:
         self.thread = threading.Thread(target=self._helper, daemon=True, name='tonic-noise-ahead')
         self.thread.start()
         weakref.finalize(agent, self.close)
+        # (a daemon thread that is inside torch.randn when the interpreter finalises is killed in
+        #  C++ code — "terminate called without an active exception": end the helpers first)
+        _NoiseAhead._live.add(self)
+        if not _NoiseAhead._at_exit:
+            import atexit
+            atexit.register(_NoiseAhead._end_all)
+            _NoiseAhead._at_exit = True
+
+    _live, _at_exit = weakref.WeakSet(), False
+
+    @staticmethod
+    def _end_all():
+        for helper in list(_NoiseAhead._live):
+            helper.close()
+            helper.thread.join(timeout=5.0)
 
     def close(self):
         """Ends the helper thread (the agent was closed or collected)."""
