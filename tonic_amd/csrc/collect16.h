@@ -66,6 +66,8 @@ struct Collect16Args {
 struct CollectResident {
   const unsigned long long* command;   // pinned host memory: the host's next command word
   unsigned* relay;                     // device memory, zero at launch: the leader's park notice
+  int poll_depth;                      // 1, 2 or 4 polls of the command word in flight per workgroup
+  int poll_sleep;                      // pause between two rounds of polls, units of ~0.25 us
   unsigned* parked;                    // pinned host memory: sequence number the leader parked at
   const float* eps0; const float* eps1;
   unsigned first_seq;

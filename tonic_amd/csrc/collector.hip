@@ -560,7 +560,7 @@ Collect16Args step_arguments(tonic_collector* c) {
 
 // transport 2: (re)starts the resident kernel; it waits for command number `first_seq`.
 int launch_resident(tonic_collector* c, unsigned first_seq) {
-  TONIC_HIP(hipMemsetAsync(c->d_relay, 0, 4, c->stream), "hipMemsetAsync");
+  TONIC_HIP(hipMemsetAsync(c->d_relay, 0, 16, c->stream), "hipMemsetAsync");
   CollectResident r{};
   r.command = reinterpret_cast<const unsigned long long*>(c->mapped + offsetof(BlockHeader, command));
   r.relay = c->d_relay;
@@ -569,6 +569,10 @@ int launch_resident(tonic_collector* c, unsigned first_seq) {
   r.eps1 = field(c, TONIC_COLLECTOR_EPS1);
   r.first_seq = first_seq;
   r.park_ticks = (unsigned long long)(c->park_us * 100.0);        // 100 MHz wall clock
+  const char* polls = getenv("TONIC_AMD_COLLECTOR_POLLS");
+  const char* pause = getenv("TONIC_AMD_COLLECTOR_POLL_SLEEP");
+  r.poll_sleep = pause != nullptr ? atoi(pause) : 1;
+  r.poll_depth = polls != nullptr && atoi(polls) >= 4 ? 4 : polls != nullptr && atoi(polls) >= 2 ? 2 : 1;
   const int status = launch_collect_resident(step_arguments(c), r, c->stream);
   if (status == TONIC_OK) c->live = true;
   return status;

@@ -1487,11 +1487,36 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
   const bool copy_role = (int)blockIdx.x >= act_blocks && !leader;
   for (unsigned expect = r.first_seq;; ++expect) {
     if (threadIdx.x == 0) {
-      unsigned long long word;
+      // Up to four polls of the command word in flight (r.poll_depth; a poll is a PCIe read round
+      // trip, ~1.9 us; loads return in order, so looking at the oldest paces the loop at a fraction
+      // of a round trip).  Measured (scripts/collect_polls.py): see DESIGN 4.3a.  The leader's park
+      // notice (device memory) is looked at only after 20 us without a command: a load that is
+      // waited for drains the polls in flight.
+      unsigned long long word = 0;
       const unsigned long long t0 = wall_clock64();
+      const int depth = r.poll_depth;                              // scalar
+      auto poll = [&]() {
+        return __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      };
+      unsigned long long w0 = poll(), w1 = 0, w2 = 0, w3 = 0;
+      if (depth >= 2) { __builtin_amdgcn_s_sleep(16); w1 = poll(); }
+      if (depth >= 4) {
+        __builtin_amdgcn_s_sleep(16); w2 = poll();
+        __builtin_amdgcn_s_sleep(16); w3 = poll();
+      }
       for (;;) {
-        word = __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(word >> 32) == expect) break;
+        word = w0; if ((unsigned)(word >> 32) == expect) break;
+        w0 = poll();
+        if (depth >= 2) {
+          word = w1; if ((unsigned)(word >> 32) == expect) break;
+          w1 = poll();
+        }
+        if (depth >= 4) {
+          word = w2; if ((unsigned)(word >> 32) == expect) break;
+          w2 = poll();
+          word = w3; if ((unsigned)(word >> 32) == expect) break;
+          w3 = poll();
+        }
         const unsigned long long waited = wall_clock64() - t0;
         if (leader) {
           if (waited > r.park_ticks) {
@@ -1500,12 +1525,14 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
             word = 8;                              // leave
             break;
           }
-        } else if (__hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                   waited > 5000 * r.park_ticks) {
-          word = 8;
-          break;
+        } else if (waited > 2000) {
+          if (__hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              waited > 5000 * r.park_ticks) {
+            word = 8;
+            break;
+          }
         }
-        __builtin_amdgcn_s_sleep(8);
+        for (int i = 0; i < r.poll_sleep; ++i) __builtin_amdgcn_s_sleep(8);      // (~0.25 us each)
       }
       command = word;
     }
