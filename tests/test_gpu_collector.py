@@ -442,6 +442,53 @@ def test_step_issued_by_the_environment_is_bit_identical(lib, monkeypatch, kind)
         assert torch.equal(state_a[key], state_b[key]), key
 
 
+def test_critic_iterations_under_the_next_rollout_are_bit_identical(lib, monkeypatch):
+    """On one GPU with full-batch iterations `PPO.update` runs the actor's iterations, leaves the
+    critic's to a second stream behind them and returns; they run while the next rollout is
+    collected (into a spare observation buffer, with a snapshot of the normaliser).  Three rollouts
+    + updates must leave exactly what the interleaved launches leave (TONIC_AMD_CRITIC_OVERLAP=0):
+    actions, parameters incl. the normaliser, and every logged row — the critic's rows land in the
+    logger before anything reads them (settle(): `last_infos`, the next update, the logger's dump)."""
+    import tonic_amd
+    import tonic_amd.torch
+    from tonic_amd import environments
+    O, A, W, T = 17, 6, 32, 24
+
+    def run(overlap):
+        monkeypatch.setenv('TONIC_AMD_CRITIC_OVERLAP', '1' if overlap else '0')
+        env = environments.SyntheticBatch(W, O, A, max_episode_steps=10, pool=7)
+        env.initialize(seed=3)
+        agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T, batch_iterations=6))
+        agent.initialize(env.observation_space, env.action_space, seed=9)
+        observations = env.start()
+        trace, rows, overlapped = [], [], 0
+        for t in range(3 * T + 5):
+            actions = agent.step(observations, t * W)
+            trace.append(actions.copy())
+            observations, infos = env.step(actions)
+            agent.update(**infos, steps=t * W)
+            if (t + 1) % T == 0:
+                overlapped += getattr(agent, '_critic_pending', None) is not None
+                if (t + 1) // T == 2:
+                    rows.append(np.array(agent.last_infos))          # settles
+        torch.cuda.synchronize()
+        agent.settle()
+        rows.append(np.array(agent.last_infos))
+        state = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+        agent.close()
+        return trace, rows, state, overlapped
+
+    with_overlap, rows_a, state_a, overlapped = run(True)
+    plain, rows_b, state_b, none = run(False)
+    assert overlapped == 3 and none == 0, 'the overlap must actually be exercised'
+    for a, b in zip(with_overlap, plain):
+        assert np.array_equal(a, b)
+    for a, b in zip(rows_a, rows_b):
+        assert np.array_equal(a, b)
+    for key in state_a:
+        assert torch.equal(state_a[key], state_b[key]), key
+
+
 def test_completion_words_order_the_actions(lib):
     """The host must never read actions older than the completion words it waited for: many
     steps, host copy of the block's actions / rewards against what the kernels stored."""

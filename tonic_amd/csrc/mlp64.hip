@@ -765,6 +765,10 @@ std::atomic<int> g_grad_waves{4};
 // dW2 on bf16x3 terms as well (2 x 2 tiles of v_mfma_f32_32x32x16_bf16; CH = 2).
 constexpr int kDefaultGradVariant = 3;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
+// Workgroups of the fused grad launches enqueued from now on (<= 256 = one per CU).  A caller that
+// runs one network's iterations UNDER another kernel that must keep its compute units — the PPO
+// critic under the next rollout's resident collect kernel, agents.py — leaves those units free.
+std::atomic<int> g_grad_blocks{256};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
@@ -857,6 +861,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_grad_skew = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "grad_blocks") == 0) {
+    TONIC_REQUIRE(value >= 8 && value <= 256, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_blocks must be in [8, 256], got %d", value);
+    g_grad_blocks = value;
+    return TONIC_OK;
+  }
   if (strcmp(key, "grad_variant") == 0) {
     TONIC_REQUIRE(value >= -1 && value <= 3, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_variant must be 0 .. 3 or -1 (default), got %d", value);
@@ -897,6 +907,7 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
   if (strcmp(key, "grad_waves") == 0) { *value = g_grad_waves; return TONIC_OK; }
   if (strcmp(key, "grad_skew") == 0) { *value = g_grad_skew; return TONIC_OK; }
   if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
+  if (strcmp(key, "grad_blocks") == 0) { *value = g_grad_blocks; return TONIC_OK; }
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
   if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
   if (strcmp(key, "q_chain") == 0) { *value = g_q_chain; return TONIC_OK; }
@@ -1101,7 +1112,8 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
                     void* d_workspace, int64_t workspace_bytes, void* stream) {
   const int variant = g_grad_variant;
   const bool use16 = variant >= 1 && grad16_supported(a.O, a.A, ACTOR);
-  const int blocks = use16 ? grad16_blocks(a.n) : grad_blocks(a.n);
+  const int all = use16 ? grad16_blocks(a.n) : grad_blocks(a.n), cap = g_grad_blocks;
+  const int blocks = all < cap ? all : cap;
   const int64_t pstride = round_up(P + kStatSlots, 64);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= blocks * pstride * (int64_t)sizeof(float),
                 TONIC_ERR_WORKSPACE, "grad workspace too small: %lld < %lld",

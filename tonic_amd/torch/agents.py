@@ -744,6 +744,7 @@ class PPO(A2C):
 
     def enqueue_update(self):
         """Enqueues one whole learner update on the current stream (no host sync)."""
+        self.settle()
         replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
         values, next_values = self._evaluate()
         replay.compute_returns(values, next_values)
@@ -819,11 +820,122 @@ class PPO(A2C):
             critic.enqueue_step(pending[1], pending[2], allreduce=False)
         return self._infos
 
+    # -- the critic's iterations under the next rollout ---------------------------------------
+    # The two networks of an update share nothing (ppo.py:33-46: advantages and returns are formed
+    # before the first iteration), and a rollout needs the ACTOR only — the critic is not asked
+    # again before the next update's evaluation.  So on one GPU with full-batch iterations update()
+    # runs the actor's 80 iterations, hands the critic's 80 to a second HIP stream BEHIND them and
+    # returns: the critic's kernels (on 232 of the 256 compute units: the resident collect kernel
+    # keeps its own) run while the host drives the next rollout, whose collect loop is latency-
+    # bound and leaves the GPU idle.  Everything that reads the critic waits first (settle():
+    # the next update, save / load, close, `last_infos`, the logger's dump), and what the critic
+    # still reads is kept out of the rollout's way: the Segment's observation buffer is swapped
+    # for a spare, the normaliser's mean / std (updated in place after the update, a2c.py:126-127)
+    # are snapshot.  TONIC_AMD_CRITIC_OVERLAP=0: the interleaved launches of enqueue_update.
+    OVERLAP_BLOCKS = 232
+
+    def _overlap(self):
+        return (os.environ.get('TONIC_AMD_CRITIC_OVERLAP', '1') != '0'
+                and self.replay.batch_size is None and not parallel.exchanging()
+                and not self.actor_updater.stock and not self.critic_updater.stock
+                and self.observation_size <= 32 and self.action_size <= 8
+                and getattr(self, '_collector', None) is not None)
+
+    @property
+    def last_infos(self):
+        self.settle()
+        return self._last_infos
+
+    @last_infos.setter
+    def last_infos(self, value):
+        self._last_infos = value
+
+    def settle(self):
+        """Waits for the critic iterations a previous update left running and logs their rows."""
+        pending = getattr(self, '_critic_pending', None)
+        if pending is None:
+            return
+        self._critic_pending = None
+        done, infos, _ = pending
+        torch.cuda.current_stream().wait_event(done)     # whoever reads the critic next is behind it
+        rows = infos[1].cpu().numpy()
+        for row in rows:
+            logger.store('critic/loss', row[0])
+            logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
+        logger.store('critic/iterations', len(rows))
+        if getattr(self, '_last_infos', None) is not None:
+            self._last_infos[1] = rows
+
+    def save(self, path):
+        self.settle()
+        super().save(path)
+
+    def load(self, path):
+        self.settle()
+        super().load(path)
+
+    def close(self):
+        self.settle()
+        super().close()
+
     def _update(self):
-        infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+        if not self._overlap():
+            self.settle()
+            infos = self.enqueue_update().cpu().numpy()          # the only sync of the update
+            parallel.check_one_shot()
+            log_ppo_update(infos)
+            self.last_infos = infos
+            if self.model.observation_normalizer:
+                self.model.observation_normalizer.update()
+            return
+        self.settle()
+        replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
+        values, next_values = self._evaluate()
+        replay.compute_returns(values, next_values)
+        updates = replay.updates_per_get()
+        infos = torch.zeros(2, updates, updaters.INFO_WIDTH, device=self.device)
+        actor.reset_stop()
+        buffers = replay.buffers
+        obs, act, raw_adv, log_probs, returns = (
+            replays.flatten_batch(buffers[k]) for k in replays.segments.LEARNER_KEYS)
+        replay.index = 0
+        n = obs.shape[0]
+        for it in range(updates):
+            actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
+            actor.enqueue_step(n, replay.adv_stats, infos[0, it])
+        # the critic's iterations: same inputs, the normaliser as it is NOW, their own stream
+        snapshot = tuple(t.clone() for t in critic.norm_tensors())
+        ready = torch.cuda.Event()
+        ready.record()
+        if getattr(self, '_critic_stream', None) is None:
+            self._critic_stream = torch.cuda.Stream()
+            logger.before_dump(self, 'settle')
+        side = self._critic_stream
+        side.wait_event(ready)
+        _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', self.OVERLAP_BLOCKS), 'tonic_set_tuning')
+        try:
+            with torch.cuda.stream(side):
+                for it in range(updates):
+                    critic.enqueue_grad(obs, returns, norm=snapshot)
+                    critic.enqueue_step(n, infos[1, it])
+                done = torch.cuda.Event()
+                done.record(side)
+        finally:
+            _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', 256), 'tonic_set_tuning')
+        self._critic_pending = (done, infos, (obs, returns, snapshot))
+        # the next rollout's observations go to the other buffer
+        spare = getattr(self, '_spare_observations', None)
+        if spare is None or spare.shape != buffers['observations'].shape:
+            spare = torch.empty_like(buffers['observations'])
+        self._spare_observations, buffers['observations'] = buffers['observations'], spare
+        rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
         parallel.check_one_shot()
-        log_ppo_update(infos)
-        self.last_infos = infos
+        actor_rows = rows[rows[:, 6] > 0]
+        for row in actor_rows:
+            for i, key in enumerate(updaters.ACTOR_INFO):
+                logger.store('actor/' + key, row[i] > 0.5 if key == 'stop' else row[i])
+        logger.store('actor/iterations', len(actor_rows))
+        self._last_infos = np.stack([rows, np.zeros_like(rows)])
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
 

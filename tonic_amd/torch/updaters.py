@@ -521,7 +521,9 @@ class VRegression(_FlatUpdater):
             _lib.current_stream()), 'tonic_value_forward_wide')
         return out
 
-    def enqueue_grad(self, observations, returns):
+    def enqueue_grad(self, observations, returns, norm=None):
+        """`norm`: (mean, std) to use instead of the normaliser's tensors — a snapshot, for
+        iterations that run while the normaliser is being updated (agents.PPO._update)."""
         if self.stock:                                    # critics.py:18-28
             self.torch_optimizer.zero_grad()
             values = self.model.critic(observations)
@@ -531,7 +533,7 @@ class VRegression(_FlatUpdater):
             return
         n = observations.shape[0]
         ws = self._workspace_for(n)
-        mean, std = self.norm_tensors()
+        mean, std = norm if norm is not None else self.norm_tensors()
         p = _lib.ptr
         _lib.check(self.lib.tonic_value_regression_grad(
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(returns),

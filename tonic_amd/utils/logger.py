@@ -84,6 +84,7 @@ class Logger:
 
     def dump(self):
         """Prints the epoch table and appends a row to log.csv (rewritten when new keys appear)."""
+        _run_before_dump()
         self._reduce()
         new_keys = [k for k in self.epoch_dict if k not in self.known_keys]
         first_row = not self.known_keys
@@ -145,6 +146,39 @@ class Logger:
         self.last_epoch_progress = progress
 
 
+# Agents that log part of an update late (the PPO critic's rows, whose iterations run under the
+# next rollout) register here: their rows are stored before the epoch they belong to is reduced —
+# also under the REFERENCE's logger, whose module-level `dump` gets the same prologue the first time
+# this module forwards to it.
+_before_dump = []
+
+
+def before_dump(owner, method):
+    import weakref
+    _before_dump.append((weakref.ref(owner), method))
+
+
+def _run_before_dump():
+    for ref, method in list(_before_dump):
+        owner = ref()
+        if owner is None:
+            _before_dump.remove((ref, method))
+        else:
+            getattr(owner, method)()
+
+
+def _hook_host(host):
+    if getattr(host, '_tonic_amd_dump_hooked', False) or not hasattr(host, 'dump'):
+        return
+    plain = host.dump
+
+    def dump(*args, **kwargs):
+        _run_before_dump()
+        return plain(*args, **kwargs)
+    host.dump = dump
+    host._tonic_amd_dump_hooked = True
+
+
 def initialize(*args, **kwargs):
     global current_logger
     current_logger = Logger(*args, **kwargs)
@@ -185,6 +219,7 @@ def get_current_logger():
     global current_logger
     host = _host()
     if host is not None:
+        _hook_host(host)
         return host.get_current_logger()
     if current_logger is None:
         current_logger = Logger()
