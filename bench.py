@@ -766,7 +766,12 @@ def main():
                    'global_workers': global_workers,
                    'parallelism': f'dp{world} (worker-axis shard, RCCL all-reduce of flat '
                                   'gradient sums)',
-                   'collector_transport': agent.transport},
+                   'collector_transport': agent.transport,
+                   # one GPU, full-batch iterations: the critic's 80 iterations of an update run on a
+                   # second stream UNDER the next rollout (agents.PPO._update; every step still
+                   # contains one whole update, the last one's tail lies inside the timed region)
+                   'critic_under_next_rollout': bool(getattr(agent, '_critic_stream', None) is not None
+                                                     and agent._overlap())},
         'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
         'actor_iterations_last_update': main_run['actor_iterations'],
     }
