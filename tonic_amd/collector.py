@@ -205,7 +205,7 @@ class Collector:
         """True: the environment issued the armed step (it is in flight); False: withdrawn."""
         return self._claim(self._cell[0]) == 1
 
-    def wait_actions(self, timeout=60.0):
+    def wait_actions(self, timeout=float(os.environ.get('TONIC_AMD_COLLECTOR_TIMEOUT', '60'))):
         status = self._wait(self._cell[0], timeout)
         if status != 0:
             _lib.check(status, 'tonic_collector_wait_actions')

@@ -726,7 +726,10 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
         }
       }
       if (now_s() > deadline) {
-        set_error("tonic_collector_wait_actions: no actions within %.1f s", timeout_s);
+        set_error("tonic_collector_wait_actions: no actions within %.1f s (command %u: %d of %d "
+                  "completion words, parked at %u, stream %s)", timeout_s, c->seq, arrived, words,
+                  c->transport == 2 ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u,
+                  hipStreamQuery(c->stream) == hipSuccess ? "idle" : "busy");
         return TONIC_ERR_TIMEOUT;
       }
     }

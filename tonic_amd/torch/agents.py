@@ -825,21 +825,39 @@ class PPO(A2C):
     # before the first iteration), and a rollout needs the ACTOR only — the critic is not asked
     # again before the next update's evaluation.  So on one GPU with full-batch iterations update()
     # runs the actor's 80 iterations, hands the critic's 80 to a second HIP stream BEHIND them and
-    # returns: the critic's kernels (on 232 of the 256 compute units: the resident collect kernel
-    # keeps its own) run while the host drives the next rollout, whose collect loop is latency-
+    # returns: the critic's kernels (on the compute units the resident collect kernel leaves, less 16
+    # to spare: 219 of 256 at 256 workers) run while the host drives the next rollout, whose collect loop is latency-
     # bound and leaves the GPU idle.  Everything that reads the critic waits first (settle():
     # the next update, save / load, close, `last_infos`, the logger's dump), and what the critic
     # still reads is kept out of the rollout's way: the Segment's observation buffer is swapped
     # for a spare, the normaliser's mean / std (updated in place after the update, a2c.py:126-127)
     # are snapshot.  TONIC_AMD_CRITIC_OVERLAP=0: the interleaved launches of enqueue_update.
-    OVERLAP_BLOCKS = 232
+    OVERLAP_BLOCKS = None       # (developer override of the critic's workgroups per launch)
+
+    def _critic_blocks(self):
+        """Workgroups of the critic's launches while a rollout is collected: what the resident
+        collect kernel leaves of the 256 compute units (one workgroup per 16 workers + 4 copy + 1
+        record, and a few to spare)."""
+        if self.OVERLAP_BLOCKS is not None:
+            return int(self.OVERLAP_BLOCKS)
+        return 256 - self._collect_workgroups() - 16
+
+    def _collect_workgroups(self):
+        workers = getattr(self.replay, 'num_workers', None) or 0
+        return (workers + 15) // 16 + 5
 
     def _overlap(self):
         return (os.environ.get('TONIC_AMD_CRITIC_OVERLAP', '1') != '0'
                 and self.replay.batch_size is None and not parallel.exchanging()
                 and not self.actor_updater.stock and not self.critic_updater.stock
                 and self.observation_size <= 32 and self.action_size <= 8
-                and getattr(self, '_collector', None) is not None)
+                and getattr(self, '_collector', None) is not None
+                # every workgroup of the resident collect kernel must find a compute unit of its own
+                # next to the critic's launches, with room to spare: the resident protocol has no
+                # place for a workgroup that starts late (1 280 workers = 85 workgroups beside 168 of
+                # the critic's: the last five did not get in, the leader parked, the step never
+                # completed — measured, hence the bound)
+                and self._collect_workgroups() <= 64)
 
     @property
     def last_infos(self):
@@ -912,7 +930,7 @@ class PPO(A2C):
             logger.before_dump(self, 'settle')
         side = self._critic_stream
         side.wait_event(ready)
-        _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', self.OVERLAP_BLOCKS), 'tonic_set_tuning')
+        _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', self._critic_blocks()), 'tonic_set_tuning')
         try:
             with torch.cuda.stream(side):
                 for it in range(updates):
