@@ -726,8 +726,15 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
         }
       }
       if (now_s() > deadline) {
+        char missing[160] = "";
+        int at = 0;
+        for (int w = 0; w < words && at < 130 && c->transport != 1; ++w) {
+          const uint32_t value = __atomic_load_n(flags + w, __ATOMIC_ACQUIRE);
+          if (value != c->seq) at += snprintf(missing + at, sizeof(missing) - at, " [%d]=%u", w, value);
+        }
         set_error("tonic_collector_wait_actions: no actions within %.1f s (command %u: %d of %d "
-                  "completion words, parked at %u, stream %s)", timeout_s, c->seq, arrived, words,
+                  "completion words in order, others:%s; parked at %u, stream %s)", timeout_s, c->seq,
+                  arrived, words, missing,
                   c->transport == 2 ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u,
                   hipStreamQuery(c->stream) == hipSuccess ? "idle" : "busy");
         return TONIC_ERR_TIMEOUT;

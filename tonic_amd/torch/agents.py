@@ -857,7 +857,8 @@ class PPO(A2C):
                 # place for a workgroup that starts late (1 280 workers = 85 workgroups beside 168 of
                 # the critic's: the last five did not get in, the leader parked, the step never
                 # completed — measured, hence the bound)
-                and self._collect_workgroups() <= 64)
+                and (self._collect_workgroups() <= 64
+                     or os.environ.get('TONIC_AMD_CRITIC_OVERLAP') == 'force'))
 
     @property
     def last_infos(self):
