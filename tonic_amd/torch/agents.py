@@ -654,7 +654,13 @@ class A2C(Agent):
         if replay.ready():
             self._collector.end_rollout(replay.index - 1)
             self._pending, self._rollout_open = False, False
-            self._update()
+            # (this rollout came through the collector, which binds the Segment's buffers anew at
+            #  every rollout: the update may swap them — see PPO._update)
+            self._host_rollout = True
+            try:
+                self._update()
+            finally:
+                self._host_rollout = False
 
     def _evaluate(self):
         """a2c.py:92-99 on the HBM-resident segment: fills values / next_values in place."""
@@ -852,6 +858,10 @@ class PPO(A2C):
                 and not self.actor_updater.stock and not self.critic_updater.stock
                 and self.observation_size <= 32 and self.action_size <= 8
                 and getattr(self, '_collector', None) is not None
+                # only behind a rollout that came through the collector (it binds the Segment's
+                # buffers anew every rollout; anybody else — rollout.DeviceRollout's captured graph —
+                # may hold their addresses, and the overlap swaps the observation buffer)
+                and getattr(self, '_host_rollout', False)
                 # every workgroup of the resident collect kernel must find a compute unit of its own
                 # next to the critic's launches, with room to spare: the resident protocol has no
                 # place for a workgroup that starts late (1 280 workers = 85 workgroups beside 168 of
