@@ -184,9 +184,11 @@ class Collector:
             p(buffers['terminations']), p(buffers['log_probs']), p(norm_acc), rows),
             'tonic_collector_bind_segment')
 
-    def begin_rollout(self, actor_params):
+    def begin_rollout(self, actor_params, stream=None):
+        """`stream`: the stream whose work the rollout is ordered behind (default: the current one)."""
         _lib.check(self.lib.tonic_collector_begin_rollout(
-            self.handle, _lib.ptr(actor_params), _lib.current_stream()),
+            self.handle, _lib.ptr(actor_params),
+            _lib.current_stream() if stream is None else stream),
             'tonic_collector_begin_rollout')
 
     def ppo_step(self, row, eps_slot, store_previous):

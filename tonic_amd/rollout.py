@@ -87,6 +87,9 @@ class DeviceRollout:
 
     def collect(self, capture=False):
         """Fills the agent's Segment with T steps (asynchronous; no host sync)."""
+        settle = getattr(self.agent, 'settle', None)
+        if settle is not None:
+            settle()        # (a PPO update may have left its critic iterations reading the Segment)
         if capture and not getattr(self, 'capture_failed', False):
             if self.graph is None:
                 if self.packed and getattr(self, 'packed_actor', None) is None:

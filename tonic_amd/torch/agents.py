@@ -518,10 +518,21 @@ class A2C(Agent):
         if not launched:
             if not self._rollout_open:
                 norm = self.model.observation_normalizer
+                behind = None
+                if getattr(self, '_rollout_behind', None) is not None:
+                    # PPO._update left the critic's iterations running: this rollout writes its
+                    # observations to the spare buffer and is ordered behind what it depends on
+                    # (the actor, the normaliser) — the current stream waits for the critic as well
+                    behind, self._rollout_behind = self._rollout_behind.cuda_stream, None
+                    buffers = self.replay.buffers
+                    spare = getattr(self, '_spare_observations', None)
+                    if spare is None or spare.shape != buffers['observations'].shape:
+                        spare = torch.empty_like(buffers['observations'])
+                    self._spare_observations, buffers['observations'] = buffers['observations'], spare
                 collector.bind_segment(self.replay.buffers,
                                        norm.device_sums if norm is not None else None,
                                        self.replay.max_size)
-                collector.begin_rollout(self.model.flat_actor.flat)
+                collector.begin_rollout(self.model.flat_actor.flat, behind)
                 self._rollout_open = True
             if not self._eps_ahead:
                 self._noise.take(block.eps[self._slot])                                # a2c.py:81
@@ -834,10 +845,11 @@ class PPO(A2C):
     # returns: the critic's kernels (on the compute units the resident collect kernel leaves, less 16
     # to spare: 219 of 256 at 256 workers) run while the host drives the next rollout, whose collect loop is latency-
     # bound and leaves the GPU idle.  Everything that reads the critic waits first (settle():
-    # the next update, save / load, close, `last_infos`, the logger's dump), and what the critic
-    # still reads is kept out of the rollout's way: the Segment's observation buffer is swapped
-    # for a spare, the normaliser's mean / std (updated in place after the update, a2c.py:126-127)
-    # are snapshot.  TONIC_AMD_CRITIC_OVERLAP=0: the interleaved launches of enqueue_update.
+    # the next update, save / load, close, `last_infos`, the logger's dump — and the current stream
+    # itself waits, so parameters read through torch are final), and what the critic still reads is
+    # kept out of the rollout's way: the next rollout writes its observations to a spare buffer
+    # (swapped in when it starts), the normaliser's mean / std (updated in place after the update,
+    # a2c.py:126-127) are snapshot.  TONIC_AMD_CRITIC_OVERLAP=0: the interleaved launches of enqueue_update.
     OVERLAP_BLOCKS = None       # (developer override of the critic's workgroups per launch)
 
     def _critic_blocks(self):
@@ -952,11 +964,6 @@ class PPO(A2C):
         finally:
             _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', 256), 'tonic_set_tuning')
         self._critic_pending = (done, infos, (obs, returns, snapshot))
-        # the next rollout's observations go to the other buffer
-        spare = getattr(self, '_spare_observations', None)
-        if spare is None or spare.shape != buffers['observations'].shape:
-            spare = torch.empty_like(buffers['observations'])
-        self._spare_observations, buffers['observations'] = buffers['observations'], spare
         rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
         parallel.check_one_shot()
         actor_rows = rows[rows[:, 6] > 0]
@@ -967,6 +974,19 @@ class PPO(A2C):
         self._last_infos = np.stack([rows, np.zeros_like(rows)])
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
+        # What the next rollout depends on — the actor, the normaliser — is on the current stream up
+        # to here: a stream of its own carries that point to the collector (step() -> begin_rollout),
+        # which also moves the rollout's observations to the spare buffer.  Everything ELSE that
+        # follows on the current stream waits for the critic's iterations as well, so whoever reads
+        # the critic's parameters after update() returned — state_dict(), a checkpoint, another
+        # forward pass — reads them final, as after the reference's update.
+        if getattr(self, '_rollout_marker', None) is None:
+            self._rollout_marker = torch.cuda.Stream()
+        ordered = torch.cuda.Event()
+        ordered.record()
+        self._rollout_marker.wait_event(ordered)
+        self._rollout_behind = self._rollout_marker
+        torch.cuda.current_stream().wait_event(done)
 
 
 def log_ppo_update(infos):
