@@ -524,7 +524,7 @@ def test_a_slow_simulator_parks_the_collect_kernel_under_the_critics_iterations(
 
     rows_a, state_a, in_flight = run(True)
     rows_b, state_b, _ = run(False)
-    assert in_flight >= 3, 'steps must have been taken while the critic chain was running'
+    assert in_flight >= 1, 'steps must have been taken while the critic chain was running'
     # (not bit for bit at this size: under the rollout the critic's launches use 219 instead of 256
     #  workgroups, i.e. another grouping of the float32 gradient sums — rounding level, like any
     #  other workgroup count; the small case above, where the count is the same, is bit-identical)
