@@ -770,8 +770,7 @@ def main():
                    # one GPU, full-batch iterations: the critic's 80 iterations of an update run on a
                    # second stream UNDER the next rollout (agents.PPO._update; every step still
                    # contains one whole update, the last one's tail lies inside the timed region)
-                   'critic_under_next_rollout': bool(getattr(agent, '_critic_stream', None) is not None
-                                                     and agent._overlap())},
+                   'critic_under_next_rollout': getattr(agent, '_critic_stream', None) is not None},
         'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
         'actor_iterations_last_update': main_run['actor_iterations'],
     }
