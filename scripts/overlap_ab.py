@@ -13,11 +13,14 @@ for r in range(rounds):
         agent, loop, rollout, out = bench.measure_job(256, 0, 1, 1, 0, True, device_too=False)
         loop.run(bench.T - agent.replay.index)
         torch.cuda.synchronize()
-        for _ in range(3):
+        for _ in range(2):
+            # (like bench.py: several steps between two device syncs — a sync after every step would
+            #  wait for the critic's chain each time and measure no overlap at all)
             t0 = time.perf_counter()
-            loop.run(bench.T)
+            for _ in range(4):
+                loop.run(bench.T)
             torch.cuda.synchronize()
-            times[v].append((time.perf_counter() - t0) * 1e3)
+            times[v].append((time.perf_counter() - t0) * 1e3 / 4)
         print('overlap', v, loop.breakdown(), flush=True)
         agent.close()
         del agent, loop, rollout
