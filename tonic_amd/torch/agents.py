@@ -335,6 +335,8 @@ class A2C(Agent):
         self._replicate([self.model.flat_actor.flat, self.model.flat_critic.flat], own_noise=True)
         self._collector = self._block = None
         self._speculated = self._eps_ahead = self._block_fed = self._armed = False
+        self._critic_pending = self._rollout_behind = None       # (PPO: see _update)
+        self._host_rollout = False
         # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
         # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
         # around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per round trip)
@@ -585,6 +587,7 @@ class A2C(Agent):
             self._block._collectors.pop(self._collector.transport, None)
             self._collector = self._block = None
             self._speculated = self._eps_ahead = self._block_fed = False
+            self._rollout_behind = None
 
     def test_step(self, observations, steps):
         noise = getattr(self, '_noise', None)
