@@ -235,6 +235,84 @@ def test_environments_ring_the_block_when_their_step_record_is_complete():
             env.close()
 
 
+def test_late_rows_reach_the_logger_before_it_reduces_an_epoch():
+    """An agent that stores part of an update late (PPO: the critic's rows, whose iterations run
+    under the next rollout) registers with `logger.before_dump`: its rows must be stored before the
+    epoch is reduced — by this package's logger and by a HOST logger (the reference's, when it owns
+    the run), whose module-level `dump` gets the same prologue exactly once."""
+    import types
+    from tonic_amd.utils import logger
+
+    class Late:
+        def __init__(self):
+            self.flushed = 0
+
+        def settle(self):
+            self.flushed += 1
+            logger.store('critic/loss', 1.5)
+
+    late = Late()
+    logger.before_dump(late, 'settle')
+    try:
+        calls = []
+        host = types.SimpleNamespace(
+            store=lambda *a, **k: calls.append(('store',) + a),
+            dump=lambda: calls.append(('dump',)),
+            get_current_logger=lambda: host)
+        logger.use(host)
+        logger.get_current_logger()                  # forwards -> hooks the host's dump
+        logger.get_current_logger()                  # ... once
+        host.dump()
+        assert late.flushed == 1
+        assert calls == [('store', 'critic/loss', 1.5), ('dump',)], calls
+        host.dump()
+        assert late.flushed == 2 and calls[-1] == ('dump',) and len(calls) == 4
+    finally:
+        logger.use(None)
+        logger._before_dump[:] = [(ref, m) for ref, m in logger._before_dump if ref() is not late]
+    # an owner that is gone is dropped, not called
+    gone = Late()
+    logger.before_dump(gone, 'settle')
+    count = len(logger._before_dump)
+    del gone
+    logger._run_before_dump()
+    assert len(logger._before_dump) == count - 1
+
+
+def test_environments_promise_carry_over_rows(monkeypatch):
+    """Sequential / Parallel / SyntheticBatch write `observations` of step t + 1 = `next_observations`
+    of step t for every worker that did not reset (distributed.py:41-57) and say so in the block's
+    header (tonic_collector_block_carry_over), which lets many-worker steps move each observation
+    row over PCIe once; a block made by anybody else promises nothing; TONIC_AMD_CARRY_OVER=0 is the
+    developer switch."""
+    from tonic_amd import environments
+    from tonic_amd.collector import Block
+    O, A, W = 5, 2, 6
+
+    def promised(block):
+        # int32 header words: magic, version, W (8 bytes), O, A, groups, carry_over
+        return int(np.frombuffer(block.memory, np.int32, 8, 0)[7])
+
+    assert promised(Block(W, O, A)) == 0
+    env = environments.SyntheticBatch(W, O, A, max_episode_steps=3, termination_probability=0.3)
+    env.initialize(seed=0)
+    observations = env.start()
+    assert promised(env.block) == 1
+    for t in range(12):                              # ... and keep the promise
+        observations, infos = env.step(np.zeros((W, A), np.float32))
+        kept = ~infos['resets']
+        assert np.array_equal(observations[kept], infos['observations'][kept])
+    sequential = environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=3), 1, W)
+    sequential.initialize(seed=0)
+    sequential.start()
+    assert promised(sequential.block) == 1
+    monkeypatch.setenv('TONIC_AMD_CARRY_OVER', '0')
+    env = environments.SyntheticBatch(W, O, A)
+    env.initialize(seed=0)
+    env.start()
+    assert promised(env.block) == 0
+
+
 def test_trainer_bookkeeping(tmp_path):
     import tonic_amd
     from tonic_amd import agents, environments, logger
