@@ -28,6 +28,17 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIBRARY_PATH)
     for name in declared:
         assert hasattr(lib, name), f'{name} missing from libtonic_hip.so'
+    # ... and every prototype has as many parameters as its ctypes entry passes (an argument added on
+    # one side only would still load and then read garbage)
+    counted = 0
+    for text in (header, developer):
+        for name, params in re.findall(r'\b(tonic_[a-z0-9_]+)\s*\(([^;{}()]*)\)\s*;', text):
+            params = re.sub(r'/\*.*?\*/', '', params, flags=re.S).strip()
+            count = 0 if params in ('', 'void') else params.count(',') + 1
+            assert count == len(_lib.SIGNATURES[name][1]), \
+                f'{name}: {count} parameters in the header, {len(_lib.SIGNATURES[name][1])} in _lib.py'
+            counted += 1
+    assert counted >= len(declared) - 2, (counted, len(declared))
     loaded = _lib.load()
     assert loaded.tonic_abi_version() == _lib.ABI_VERSION
     assert loaded.tonic_target_arch() == b'gfx950'
