@@ -48,7 +48,9 @@ typedef enum tonic_status {
 /* ---- library ------------------------------------------------------------------------ */
 const char* tonic_last_error(void);
 /* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks,
- * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries)
+ * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
+ * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
+ * tonic_collector_synthetic_step)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);

@@ -146,7 +146,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 4        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 5        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):
