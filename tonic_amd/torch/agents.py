@@ -903,9 +903,7 @@ class PPO(A2C):
         done, infos, _ = pending
         torch.cuda.current_stream().wait_event(done)     # whoever reads the critic next is behind it
         rows = infos[1].cpu().numpy()
-        for row in rows:
-            logger.store('critic/loss', row[0])
-            logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
+        log_ppo_critic_rows(rows)
         logger.store('critic/iterations', len(rows))
         if getattr(self, '_last_infos', None) is not None:
             self._last_infos[1] = rows
@@ -969,11 +967,7 @@ class PPO(A2C):
         self._critic_pending = (done, infos, (obs, returns, snapshot))
         rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
         parallel.check_one_shot()
-        actor_rows = rows[rows[:, 6] > 0]
-        for row in actor_rows:
-            for i, key in enumerate(updaters.ACTOR_INFO):
-                logger.store('actor/' + key, row[i] > 0.5 if key == 'stop' else row[i])
-        logger.store('actor/iterations', len(actor_rows))
+        logger.store('actor/iterations', log_ppo_actor_rows(rows))
         self._last_infos = np.stack([rows, np.zeros_like(rows)])
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
@@ -996,16 +990,26 @@ def log_ppo_update(infos):
     """The keys ppo.py:46-67 logs for one learner update, from the statistics rows the device
     wrote: infos[0] = actor rows {loss, kl, entropy, clip_fraction, std, stop, ran}, one per
     iteration that ran before the KL stop; infos[1] = critic rows {loss, v}."""
-    actor_rows = infos[0][infos[0][:, 6] > 0]
+    ran = log_ppo_actor_rows(infos[0])
+    log_ppo_critic_rows(infos[1])
+    logger.store('actor/iterations', ran)
+    logger.store('critic/iterations', len(infos[1]))
+
+
+def log_ppo_actor_rows(rows):
+    """Stores the rows of the iterations that ran before the KL stop; returns how many did."""
+    actor_rows = rows[rows[:, 6] > 0]
     for row in actor_rows:
         for i, key in enumerate(updaters.ACTOR_INFO):
             value = row[i] > 0.5 if key == 'stop' else row[i]
             logger.store('actor/' + key, value)
-    for row in infos[1]:
+    return len(actor_rows)
+
+
+def log_ppo_critic_rows(rows):
+    for row in rows:
         logger.store('critic/loss', row[0])
         logger.store('critic/v', row[1])      # mean of the value batch (log-equivalent)
-    logger.store('actor/iterations', len(actor_rows))
-    logger.store('critic/iterations', len(infos[1]))
 
 
 # ----------------------------------------------------------------- off-policy (SAC / TD3)
