@@ -127,14 +127,14 @@ def kernel_rooflines(agent):
     def actor_grad():
         _lib.check(lib.tonic_ppo_actor_grad(
             p(actor.flat.flat), p(obs), p(act), p(adv), p(replay.adv_stats), p(logp),
-            p(actor.grad_sums), n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), stream), 'actor')
+            p(actor.grad_sums), n, O, A, 0.2, 0.0, None, 0, p(ws), ws.numel(), stream), 'actor')
 
     mean, std = critic.norm_tensors()
     wsc = critic._workspace_for(n)
 
     def critic_grad():
         _lib.check(lib.tonic_value_regression_grad(
-            p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, O,
+            p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, O, 0,
             p(wsc), wsc.numel(), stream), 'critic')
 
     # grad_variant: 0 = 32x32x2 fp32 tiles, 1 wave per SIMD; 1 = 16x16x4 fp32 tiles, 2 waves; 2 = 1 with
@@ -152,7 +152,12 @@ def kernel_rooflines(agent):
         ms_a, ms_c = time_events(actor_grad, 10), time_events(critic_grad, 10)
         out[variant] = (ms_a, ms_c)
     _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
-    ms_a, ms_c = out[shipped]
+    # the shipped variant over a loop as long as an update's (the job runs 80 launches back to back:
+    # a 10-launch loop sees a cooler chip and a higher clock than they do — round 3's line quoted
+    # 286 us where rocprofv3 averaged 307 us over the job's 651 launches)
+    ws, wsc = actor._workspace_for(n), critic._workspace_for(n)
+    ms_a, ms_c = time_events(actor_grad, 120), time_events(critic_grad, 120)
+    out[shipped] = (ms_a, ms_c)
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
     arithmetic = ('fp32 MFMA throughout' if shipped < 2 else
@@ -167,7 +172,7 @@ def kernel_rooflines(agent):
                 frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share), 4),
                 mixed_ceiling_tflops=round(mixed_ceiling_tflops(share), 1),
                 rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
-                ms_per_launch=round(ms_a, 4), samples_per_launch=n,
+                ms_per_launch=round(ms_a, 4), launches_timed=120, samples_per_launch=n,
                 flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=shipped, arithmetic=arithmetic,
                 variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
     roof_critic = dict(bound='mfma', kernel='mlp64_grad16_kernel<critic> (+reduce_partials)',
@@ -202,72 +207,156 @@ def kernel_rooflines(agent):
              gae_entry(T, 4096, 0), gae_entry(T, 10240, 1), gae_entry(T, 10240, 0),
              gae_entry(T, 65536, 1), gae_entry(T, 65536, 2)]
     top = max(sweep, key=lambda e: e['achieved'])
-    roof_gae = dict(bound='hbm', kernel='gae_onepass_kernel / gae_scan_kernel (+gae_stats_kernel)',
-                    achieved=top['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=top['frac'],
-                    bytes_per_transition=28, at=dict(T=top['T'], W=top['W']), sweep=sweep,
-                    **pmc_traffic('gae_scan_kernel'),
-                    note='cfg-2 size (T=4096, W=256) moves 29 MB: launch-latency bound, '
-                         'inside the Infinity Cache; the HBM fraction is meaningful at W>=4096')
+    own = sweep[0]          # the metric's own size with the Segment's default (the bit-exact single chain)
+    roof_gae = dict(bound='hbm', kernel='gae_stream16_kernel (W = 256, bit-exact chain); sweep: '
+                                        'gae_onepass_kernel / gae_scan_kernel (+gae_stats_kernel)',
+                    achieved=own['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=own['frac'],
+                    bytes_per_transition=28, at=dict(T=own['T'], W=own['W'], chunks=own['chunks']),
+                    one_pass_at_this_size=dict(achieved=sweep[1]['achieved'], frac=sweep[1]['frac']),
+                    sweep_top=dict(achieved=top['achieved'], frac=top['frac'],
+                                   at=dict(T=top['T'], W=top['W'], chunks=top['chunks'])),
+                    sweep=sweep, **pmc_traffic('gae_scan_kernel'),
+                    note='the headline figure is the metric\'s own size (T=4096, W=256: 29 MB, inside '
+                         'the Infinity Cache, bound by the length of one dependent float32 chain per '
+                         'column, not by bandwidth); the kernel reaches its HBM fraction on the sweep '
+                         '(sweep_top: W = 65 536, 1.9 GB)')
     return roof, roof_critic, roof_gae
 
 
-def cpu_baseline():
-    """The reference's torch-CPU PPO path (oracle/torch_port.py) on this box's cores, bounded
-    sample: 64 act+store steps at W=256, the full-size evaluate + GAE, and 2 full-batch
-    actor+critic iterations at N = 4096*256; extrapolated to T=4096 steps and 80 iterations.
-    Measured at torch's default thread count and at 16 threads (the default of 128 threads on a
-    big host is pathological for these small operators); `value` is the FASTER of the two."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+class _PortEngine:
+    """oracle/torch_port.py: the reference's torch-CPU operators restated (kind = "port")."""
+    kind = 'port'
+
+    def __init__(self, o_dim, a_dim, steps):
+        import torch_port
+        self.agent = torch_port.TorchPPO(o_dim, a_dim, steps=steps)
+
+    def step_and_store(self, obs, workers):
+        actions = self.agent.step(obs)
+        self.agent.store(obs, -np.square(actions).sum(-1), np.zeros(workers, bool),
+                         np.zeros(workers, bool))
+
+    def evaluate_and_returns(self, data):
+        self.agent.buffers = {k: v.copy() for k, v in data.items()}
+        return self.agent.evaluate_and_returns()
+
+    def iteration(self, batch):
+        self.agent.actor_update(batch['observations'], batch['actions'], batch['advantages'],
+                                batch['log_probs'])
+        self.agent.critic_update(batch['observations'], batch['returns'])
+
+
+class _ReferenceEngine:
+    """The UNMODIFIED reference (tonic.torch.agents.PPO from /root/reference, imported through
+    oracle/reference_loader.py) — only where the checkout exists, i.e. in the build container
+    (kind = "reference")."""
+    kind = 'reference'
+
+    def __init__(self, o_dim, a_dim, steps):
+        import reference_loader
+        tonic = reference_loader.load_reference()
+        self.agent = tonic.torch.agents.PPO(replay=tonic.replays.Segment(size=steps))
+        self.agent.initialize(reference_loader.SyntheticSpace(-np.inf, np.inf, (o_dim,)),
+                              reference_loader.SyntheticSpace(-1, 1, (a_dim,)), seed=0)
+
+    def step_and_store(self, obs, workers):                      # trainer.py:44-50
+        actions = self.agent.step(obs, 0)
+        self.agent.update(observations=obs, rewards=-np.square(actions).sum(-1),
+                          resets=np.zeros(workers, bool), terminations=np.zeros(workers, bool),
+                          steps=0)
+
+    def evaluate_and_returns(self, data):                        # ppo.py:20-31
+        import torch
+        agent, replay = self.agent, self.agent.replay
+        replay.buffers = {k: v.copy() for k, v in data.items()}
+        replay.num_workers = data['rewards'].shape[1]
+        batch = replay.get_full('observations', 'next_observations')
+        values, next_values = agent._evaluate(**batch)
+        replay.compute_returns(values.numpy(), next_values.numpy())
+        batch = replay.get_full('observations', 'actions', 'advantages', 'log_probs', 'returns')
+        return {k: torch.as_tensor(v) for k, v in batch.items()}
+
+    def iteration(self, batch):                                  # ppo.py:33-37
+        self.agent._update_actor_critic(**batch)
+
+
+def cpu_engines():
+    """The CPU implementations that can be timed on this box: the reference itself where its
+    checkout exists (never on the GPU box), the oracle's port always."""
+    for path in (os.path.join(ROOT, 'oracle'),):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    engines = [_PortEngine]
+    try:
+        import reference_loader
+        if reference_loader.reference_available():
+            engines.insert(0, _ReferenceEngine)
+    except ImportError:
+        pass
+    return engines
+
+
+def cpu_measure(engine_class, o_dim, a_dim, workers, steps, threads, sample_steps, sample_iters,
+                iterations=ITERATIONS):
+    """One bounded sample of the CPU path: `sample_steps` act + store steps, the full-size
+    evaluate + lambda-returns, `sample_iters` full-batch actor + critic iterations; extrapolated
+    to `steps` environment steps and `iterations` iterations."""
     import torch
-    import torch_port
-    default_threads = torch.get_num_threads()
-    n = T * W
+    torch.set_num_threads(threads)
+    n = steps * workers
     rng = np.random.RandomState(0)
     data = dict(
-        observations=rng.standard_normal((T, W, O)).astype(np.float32),
-        next_observations=rng.standard_normal((T, W, O)).astype(np.float32),
-        actions=np.clip(rng.standard_normal((T, W, A)), -1, 1).astype(np.float32),
-        rewards=rng.standard_normal((T, W)).astype(np.float32),
-        resets=None, terminations=None,
-        log_probs=(rng.standard_normal((T, W)) * 0.1 - 6).astype(np.float32))
+        observations=rng.standard_normal((steps, workers, o_dim)).astype(np.float32),
+        next_observations=rng.standard_normal((steps, workers, o_dim)).astype(np.float32),
+        actions=np.clip(rng.standard_normal((steps, workers, a_dim)), -1, 1).astype(np.float32),
+        rewards=rng.standard_normal((steps, workers)).astype(np.float32),
+        log_probs=(rng.standard_normal((steps, workers)) * 0.1 - 6).astype(np.float32))
     # the same episode statistics as the GPU rollout: resets ~ Bernoulli(1e-3), half terminal
-    data['resets'] = (rng.uniform(size=(T, W)) < 1e-3).astype(np.float32)
-    data['terminations'] = data['resets'] * (rng.uniform(size=(T, W)) < 0.5).astype(np.float32)
-    obs = rng.standard_normal((W, O)).astype(np.float32)
-    sample_steps, sample_iters = 64, 3
+    data['resets'] = (rng.uniform(size=(steps, workers)) < 1e-3).astype(np.float32)
+    data['terminations'] = data['resets'] * (rng.uniform(size=(steps, workers)) < 0.5).astype(np.float32)
+    obs = rng.standard_normal((workers, o_dim)).astype(np.float32)
+    engine = engine_class(o_dim, a_dim, steps)
+    engine.step_and_store(obs, workers)                  # (untimed: lazy initialisation, thread pool)
+    engine.iteration(engine.evaluate_and_returns(data))
+    engine = engine_class(o_dim, a_dim, steps)
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        engine.step_and_store(obs, workers)
+    t_step = (time.perf_counter() - t0) / sample_steps
+    t0 = time.perf_counter()
+    batch = engine.evaluate_and_returns(data)
+    t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(sample_iters):
+        engine.iteration(batch)
+    t_iter = (time.perf_counter() - t0) / sample_iters
+    cycle = steps * t_step + t_eval + iterations * t_iter
+    return dict(kind=engine.kind, threads=threads, env_steps_per_sec=round(n / cycle, 1),
+                learner_updates_per_sec=round(iterations / (t_eval + iterations * t_iter), 3),
+                seconds=dict(per_env_step=round(t_step, 6), evaluate_and_gae=round(t_eval, 4),
+                             per_iteration=round(t_iter, 4), cycle=round(cycle, 2)))
 
-    def measure(threads):
-        torch.set_num_threads(threads)
-        agent = torch_port.TorchPPO(O, A, steps=T)
-        t0 = time.perf_counter()
-        for _ in range(sample_steps):
-            actions = agent.step(obs)
-            agent.store(obs, -np.square(actions).sum(-1), np.zeros(W, bool), np.zeros(W, bool))
-        t_step = (time.perf_counter() - t0) / sample_steps
-        agent.buffers = {k: v.copy() for k, v in data.items()}
-        t0 = time.perf_counter()
-        batch = agent.evaluate_and_returns()
-        t_eval = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for _ in range(sample_iters):
-            agent.actor_update(batch['observations'], batch['actions'], batch['advantages'],
-                               batch['log_probs'])
-            agent.critic_update(batch['observations'], batch['returns'])
-        t_iter = (time.perf_counter() - t0) / sample_iters
-        cycle = T * t_step + t_eval + ITERATIONS * t_iter
-        return dict(threads=threads, env_steps_per_sec=round(n / cycle, 1),
-                    learner_updates_per_sec=round(ITERATIONS / (t_eval + ITERATIONS * t_iter), 3),
-                    seconds=dict(per_env_step=round(t_step, 6), evaluate_and_gae=round(t_eval, 4),
-                                 per_iteration=round(t_iter, 4), cycle=round(cycle, 2)))
-    runs = [measure(default_threads)]
+
+def cpu_baseline(o_dim=None, a_dim=None, workers=None, sample_steps=64, sample_iters=3):
+    """The reference's torch-CPU PPO path on this box's cores, bounded sample (cpu_measure).  What
+    is timed: the UNMODIFIED reference when its checkout is present (kind "reference" — the build
+    container), oracle/torch_port.py otherwise (kind "port" — the GPU box, where /root/reference
+    does not exist; profiles/r04_cpu_port_vs_reference.json holds both timed side by side in the
+    build container).  Measured at torch's default thread count and at 16 threads (the default of
+    128 threads on a big host is pathological for these small operators); `value` is the FASTER."""
+    import torch
+    o_dim, a_dim, workers = o_dim or O, a_dim or A, workers or W
+    default_threads = torch.get_num_threads()
+    engine = cpu_engines()[0]
+    runs = [cpu_measure(engine, o_dim, a_dim, workers, T, default_threads, sample_steps, sample_iters)]
     if default_threads > 16:
-        runs.append(measure(16))
+        runs.append(cpu_measure(engine, o_dim, a_dim, workers, T, 16, sample_steps, sample_iters))
     torch.set_num_threads(default_threads)
     best = max(runs, key=lambda r: r['env_steps_per_sec'])
     return dict(value=best['env_steps_per_sec'], unit='env_steps/s', cores=best['threads'],
-                kind='port', learner_updates_per_sec=best['learner_updates_per_sec'],
-                sample=f'{sample_steps} act+store steps (W={W}), full-size evaluate+GAE '
-                       f'(N={n}), {sample_iters} full-batch actor+critic iterations; '
+                kind=engine.kind, learner_updates_per_sec=best['learner_updates_per_sec'],
+                sample=f'{sample_steps} act+store steps (W={workers}), full-size evaluate+GAE '
+                       f'(N={T * workers}), {sample_iters} full-batch actor+critic iterations; '
                        f'extrapolated to T={T} steps and {ITERATIONS} iterations',
                 runs=runs, os_cpu_count=os.cpu_count())
 
@@ -474,6 +563,40 @@ def parallel_workers_loop(agent, groups=8, per_group=32, steps=512):
                 env_steps_per_sec=round(groups * per_group * 1e6 / float(us.sum()), 1), steps=count)
 
 
+def cfg1_plumbing(steps=3):
+    """BASELINE config 1 — PPO at Pendulum-v1 shapes (O = 3, A = 1), parallel = 1, sequential = 1,
+    Segment T = 4096, 80 iterations — through the same host-in-the-loop path: what the plumbing
+    costs when there is ONE worker (a step is a GPU round trip whatever W is), with its CPU twin
+    (the reference's torch-CPU path at the same sizes) beside it."""
+    import torch
+    global O, A, W
+    saved = (O, A, W)
+    O, A, W = 3, 1, 1
+    try:
+        agent = build_agent(seed=0)
+        loop = HostLoop(agent, 1, seed=1)
+        loop.run(T)                                       # warm-up incl. the first learner update
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.run(steps * T)
+        agent.settle()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        host_loop = loop.breakdown(1024)
+        loop.run(T - agent.replay.index)
+        out = dict(workload='PPO Pendulum-v1 shapes (O=3, A=1), parallel=1 sequential=1, Segment '
+                            'T=4096 (N=4096), 80 full-batch iterations; host in the loop',
+                   env_steps_per_sec=round(steps * T / elapsed, 1),
+                   ms_per_step=round(elapsed / steps * 1e3, 3), steps=steps, host_loop=host_loop,
+                   critic_under_next_rollout=getattr(agent, '_critic_stream', None) is not None,
+                   cpu_baseline=cpu_baseline(3, 1, 1, sample_steps=512, sample_iters=20))
+        out['speedup_vs_cpu_baseline'] = round(out['env_steps_per_sec'] / out['cpu_baseline']['value'], 1)
+        agent.close()
+        return out
+    finally:
+        O, A, W = saved
+
+
 def timed_steps(run_one, steps, warmup, world):
     """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time."""
     import torch
@@ -575,14 +698,21 @@ def allreduce_latency(floats, world):
         rccl()
     torch.cuda.synchronize()
     out['process_group_us'] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
-    try:
-        comm = parallel.OneShotAllReduce(floats)
+    # (a set-up step that fails on ONE rank — no peer access on this box, ... — is agreed on by all)
+    comm = parallel.OneShotAllReduce(floats, tolerant=True)
+    ok, why = parallel._agree(comm.handle is not None, comm.error)
+    if ok:
         out['one_shot_us'] = round(time_events(lambda: comm.all_reduce(buffer), 50) * 1e3, 1)
-        comm.check()
+        try:
+            comm.check()
+        except Exception as error:
+            ok, why = False, str(error)
+        ok, why = parallel._agree(ok, why)
         torch.distributed.barrier()
-        comm.close()
-    except Exception as error:                        # (no peer access on this box, ...)
-        out['one_shot_error'] = str(error)[:200]
+    if not ok:
+        out['one_shot_error'] = why[:200]
+    comm.close()
+    out['learner_uses'] = parallel.allreduce_choice()
     return out
 
 
@@ -769,6 +899,12 @@ def main():
                    'parallelism': f'dp{world} (worker-axis shard, RCCL all-reduce of flat '
                                   'gradient sums)',
                    'collector_transport': agent.transport,
+                   # what `environment.step` is here: the vectorised synthetic simulator of this
+                   # package, whose whole step (observations ~ N(0,1) from a pool, reward, episode
+                   # lengths, resets) is ONE C entry point of the product library writing into the
+                   # shared block; with the reference's transport — 8 forked groups of 32 Python
+                   # environments — the same loop is bound by the simulators (`parallel_workers`)
+                   'simulator': 'SyntheticBatch: library C step (tonic_collector_synthetic_step)',
                    # one GPU, full-batch iterations: the critic's 80 iterations of an update run on a
                    # second stream UNDER the next rollout (agents.PPO._update; every step still
                    # contains one whole update, the last one's tail lies inside the timed region)
@@ -832,6 +968,7 @@ def main():
         result['roofline_gae'] = roof_g
         result['cpu_baseline'] = cpu_baseline()
         result['parallel_workers'] = parallel_workers_loop(agent)
+        result['cfg1_plumbing'] = cfg1_plumbing()
         result['offpolicy_sac'] = offpolicy_rates()
         # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
         # reference's default batch of 100 and the batch of cfg 3

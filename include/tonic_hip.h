@@ -50,7 +50,8 @@ const char* tonic_last_error(void);
 /* ABI version (bumped on any signature or layout change; 2 = padded off-policy parameter blocks,
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
- * tonic_collector_synthetic_step)
+ * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
+ * tonic_value_regression_grad)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -131,6 +132,12 @@ int tonic_value_forward(const float* d_critic_params, const float* d_norm_mean,
  *   StochasticPolicyGradient (A2C; actors.py:20-51): loss_sum = -sum(adv * logp), no ratio, no
  *   clipping; kl_sum keeps its meaning (old - new log-probabilities).
  * tonic_value_regression_grad replaces: tonic/torch/updaters/critics.py:18-24 (VRegression).
+ * max_workgroups: 0 = the kernel's own width (one workgroup per compute unit, fewer for small
+ *   n); k > 0 = at most k workgroups — for a network whose iterations run beside another kernel
+ *   that must keep its compute units (agents.PPO: the critic under the next rollout's resident
+ *   collect kernel).  The float32 partial sums are grouped per workgroup, so the same
+ *   (n, max_workgroups) gives the same bits on every call; different widths differ at rounding
+ *   level.  The layer-by-layer kernels of the wide shapes ignore it.
  *
  * Shapes: O <= 32 and A <= 8 run in the fused kernels (a whole network per 16-sample tile in
  * registers).  Wider ones (O <= 384, A <= 32: Ant-v3, Humanoid, humanoid-walk ...) run layer by
@@ -153,13 +160,14 @@ int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_observation
                          const float* d_adv_stats, const float* d_old_log_probs,
                          float* d_grad_sums, int64_t n, int32_t O, int32_t A,
                          double ratio_clip, double entropy_coeff, const int32_t* d_skip_flag,
-                         void* d_workspace, int64_t workspace_bytes, void* stream);
+                         int32_t max_workgroups, void* d_workspace, int64_t workspace_bytes,
+                         void* stream);
 int tonic_value_regression_grad(const float* d_critic_params, const float* d_norm_mean,
                                 const float* d_norm_std, double norm_clip,
                                 const float* d_observations,
                                 const float* d_returns, float* d_grad_sums, int64_t n,
-                                int32_t O, void* d_workspace, int64_t workspace_bytes,
-                                void* stream);
+                                int32_t O, int32_t max_workgroups, void* d_workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------
  * replaces: torch.optim.Adam single-tensor path (torch/optim/adam.py:395-547) as
@@ -428,8 +436,12 @@ int tonic_collector_end_rollout(tonic_collector_t* collector, int64_t last_row,
  * Set-up (once): tonic_comm_init allocates this rank's window; tonic_comm_export gives its
  * hipIpcMemHandle_t (tonic_comm_handle_bytes() bytes) which the caller carries to the other
  * processes by any means; tonic_comm_connect takes all `world` handles in rank order.
- * A peer that never arrives makes the kernel give up after 5 s instead of hanging:
- * tonic_comm_status (synchronous, call it where the host reads results anyway) reports it. */
+ * A peer that never arrives makes the kernel give up (TONIC_AMD_ALLREDUCE_TIMEOUT_S, default 120 s;
+ * tonic_comm_set_timeout overrides it for one communicator, 0 = back to the default) instead of
+ * hanging: tonic_comm_status (synchronous, call it where the host reads results anyway) reports it
+ * (and keeps reporting it: a communicator that missed a peer is not to be used again).
+ * tonic_comm_can_access_peer: hipDeviceCanAccessPeer(device, peer) as 1 / 0 (negative: error) —
+ * what tonic_amd.parallel asks of every pair of ranks before it picks this exchange over RCCL. */
 typedef struct tonic_comm tonic_comm_t;
 int64_t tonic_comm_handle_bytes(void);
 int tonic_comm_init(tonic_comm_t** out, int32_t rank, int32_t world, int64_t max_floats);
@@ -437,6 +449,8 @@ int tonic_comm_export(tonic_comm_t* comm, void* handle_out);
 int tonic_comm_connect(tonic_comm_t* comm, const void* all_handles);
 int tonic_allreduce_f32(tonic_comm_t* comm, float* d_buffer, int64_t n, void* stream);
 int tonic_comm_status(tonic_comm_t* comm);
+int tonic_comm_set_timeout(tonic_comm_t* comm, double seconds);
+int tonic_comm_can_access_peer(int32_t device, int32_t peer);
 int tonic_comm_destroy(tonic_comm_t* comm);
 
 /* ---- target networks (SAC / TD3) ---------------------------------------------------------------

@@ -31,9 +31,9 @@ def timed(fn, reps=20):
 
 for n in (1 << 20, 1 << 19, 1 << 18, 1 << 17, 1 << 16, 1 << 15):
     a = timed(lambda: _lib.check(lib.tonic_ppo_actor_grad(
-        p(params), p(obs), p(act), p(adv), p(st), p(logp), p(out), n, O, A, 0.2, 0.0, None, p(ws),
+        p(params), p(obs), p(act), p(adv), p(st), p(logp), p(out), n, O, A, 0.2, 0.0, None, 0, p(ws),
         ws.numel(), None), 'a'))
     c = timed(lambda: _lib.check(lib.tonic_value_regression_grad(
-        p(cparams), p(mean), p(std), 0.0, p(obs), p(ret), p(outc), n, O, p(ws), ws.numel(), None), 'c'))
+        p(cparams), p(mean), p(std), 0.0, p(obs), p(ret), p(outc), n, O, 0, p(ws), ws.numel(), None), 'c'))
     print(f'n={n:8d}  actor {a:8.1f} us  critic {c:8.1f} us   per 16-sample tile and wave: '
           f'{a * 2.4e3 / max(n / 16 / 2048, 1):8.0f} / {c * 2.4e3 / max(n / 16 / 2048, 1):8.0f} cycles')

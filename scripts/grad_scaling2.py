@@ -27,11 +27,11 @@ for tiles in (1, 2, 4, 8, 16, 32):
     def actor_grad():
         _lib.check(lib.tonic_ppo_actor_grad(
             p(actor.flat.flat), p(obs), p(act), p(adv), p(replay.adv_stats), p(logp),
-            p(actor.grad_sums), n, bench.O, bench.A, 0.2, 0.0, None, p(ws), ws.numel(), stream), 'actor')
+            p(actor.grad_sums), n, bench.O, bench.A, 0.2, 0.0, None, 0, p(ws), ws.numel(), stream), 'actor')
 
     def critic_grad():
         _lib.check(lib.tonic_value_regression_grad(
-            p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, bench.O,
+            p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, bench.O, 0,
             p(wsc), wsc.numel(), stream), 'critic')
 
     ms_a, ms_c = bench.time_events(actor_grad, 20), bench.time_events(critic_grad, 20)

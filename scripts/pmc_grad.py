@@ -29,8 +29,8 @@ ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8, 
 p = _lib.ptr
 for _ in range(reps):
     _lib.check(lib.tonic_ppo_actor_grad(p(params), p(obs), p(act), p(adv), p(stats), p(logp), p(out),
-                                        n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), None), 'actor')
+                                        n, O, A, 0.2, 0.0, None, 0, p(ws), ws.numel(), None), 'actor')
     _lib.check(lib.tonic_value_regression_grad(p(cparams), p(mean), p(std), 0.0, p(obs), p(ret), p(outc),
-                                               n, O, p(ws), ws.numel(), None), 'critic')
+                                               n, O, 0, p(ws), ws.numel(), None), 'critic')
 torch.cuda.synchronize()
 print('done', float(out.abs().sum()), float(outc.abs().sum()))

@@ -55,9 +55,9 @@ out, outc = torch.zeros(P + 8, device='cuda'), torch.zeros(Pc + 8, device='cuda'
 ws = torch.empty(lib.tonic_mlp64_grad_workspace_bytes(n, P), dtype=torch.uint8, device='cuda')
 for _ in range(3):
     _lib.check(lib.tonic_ppo_actor_grad(p(params), p(obs), p(act), p(advn), p(st), p(logp), p(out),
-                                        n, O, A, 0.2, 0.0, None, p(ws), ws.numel(), None), 'actor')
+                                        n, O, A, 0.2, 0.0, None, 0, p(ws), ws.numel(), None), 'actor')
     _lib.check(lib.tonic_value_regression_grad(p(cparams), p(mean), p(std), 0.0, p(obs), p(rets), p(outc),
-                                               n, O, p(ws), ws.numel(), None), 'critic')
+                                               n, O, 0, p(ws), ws.numel(), None), 'critic')
 # the critic's forward over the whole Segment (mlp64_grad16_kernel<..., FWD>: 68 B read + 4 B written per row)
 vals = torch.empty(n, device='cuda')
 for _ in range(3):

@@ -32,11 +32,11 @@ for O, A, n in SHAPES:
 
     def actor_grad():
         _lib.check(lib.tonic_ppo_actor_grad(p(actor), p(obs), p(act), p(adv), p(stats), p(lp), p(ga),
-                                            n, O, A, 0.2, 0.0, None, p(wa), wa.numel(), None), 'a')
+                                            n, O, A, 0.2, 0.0, None, 0, p(wa), wa.numel(), None), 'a')
 
     def critic_grad():
         _lib.check(lib.tonic_value_regression_grad(p(critic), p(mean), p(std), 0.0, p(obs), p(ret),
-                                                   p(gc), n, O, p(wc), wc.numel(), None), 'c')
+                                                   p(gc), n, O, 0, p(wc), wc.numel(), None), 'c')
     ms_a, ms_c = bench.time_events(actor_grad, 5), bench.time_events(critic_grad, 5)
     flop_a = 2 * (O * 64 + 4096 + 64 * A) * 3 - 2 * O * 64      # fwd + dW + dX (no dX for layer 1)
     print(f'O={O} A={A} N={n}: actor grad {ms_a:.3f} ms, critic grad {ms_c:.3f} ms, '

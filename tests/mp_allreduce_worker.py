@@ -30,8 +30,17 @@ def run(out_path):
         chain.mul_(1.0 / world)
     torch.cuda.synchronize()
     comm.check()
+    # what parallel.one_shot runs before the learner may rely on the windows
+    passed, why = comm.self_test(calls=6)
+    # ... and what the learner's exchange would pick on this box, with the reason
+    #     (TONIC_AMD_ALLREDUCE unset = auto: the ranks decide together)
+    picked = parallel.one_shot(11101)
+    choice = parallel.allreduce_choice() or {}
     np.savez(out_path + f'.rank{rank}.npz', chain=chain.cpu().numpy(),
              device=np.int64(torch.cuda.current_device()),
+             self_test=np.array([int(passed)]), self_test_reason=np.array(why),
+             choice=np.array(choice.get('kind', '')), choice_reason=np.array(choice.get('reason', '')),
+             picked=np.array([int(picked is not None)]),
              **{f'call{i}': r for i, r in enumerate(results)})
     if world > 1:
         torch.distributed.barrier()

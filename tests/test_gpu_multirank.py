@@ -118,6 +118,13 @@ def test_one_shot_allreduce_is_the_rank_ordered_sum(tmp_path, world):
     for r in range(1, world):
         assert np.array_equal(ranks[r]['chain'], ranks[0]['chain'])
     np.testing.assert_allclose(ranks[0]['chain'], (world + 1) / 2, rtol=1e-5)
+    # the self-test parallel.one_shot runs before it selects this exchange passes here too; the
+    # automatic selection itself declines on THIS box, unanimously and with the reason: the ranks
+    # share a device (the windows are meant to be peer memory)
+    for r in range(world):
+        assert int(ranks[r]['self_test'][0]) == 1, str(ranks[r]['self_test_reason'])
+        assert str(ranks[r]['choice']) == 'rccl' and int(ranks[r]['picked'][0]) == 0
+        assert 'share devices' in str(ranks[r]['choice_reason'])
 
 
 def test_one_shot_allreduce_between_peer_devices(tmp_path):
@@ -144,6 +151,16 @@ def test_one_shot_allreduce_between_peer_devices(tmp_path):
             assert np.array_equal(ranks[r][f'call{call}'], want), (call, r)
     for r in range(1, world):
         assert np.array_equal(ranks[r]['chain'], ranks[0]['chain'])
+    # with a device per rank and peer access between every pair the learner's exchange selects the
+    # one-shot all-reduce by itself (TONIC_AMD_ALLREDUCE unset); anything else must come with a reason
+    for r in range(world):
+        assert int(ranks[r]['self_test'][0]) == 1, str(ranks[r]['self_test_reason'])
+        assert str(ranks[r]['choice']) in ('oneshot', 'rccl')
+        if str(ranks[r]['choice']) == 'oneshot':
+            assert int(ranks[r]['picked'][0]) == 1
+        else:
+            assert str(ranks[r]['choice_reason']), 'a fallback to RCCL names its reason'
+        print('rank', r, 'exchange:', ranks[r]['choice'], '-', ranks[r]['choice_reason'])
 
 
 def test_two_ranks_with_the_one_shot_allreduce_equal_single_process(tmp_path):

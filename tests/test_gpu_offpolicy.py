@@ -103,6 +103,47 @@ def test_buffer_store_gather_bit_exact(lib, golden, name):
             assert np.array_equal(batch[k].cpu().numpy(), ref[k][rows, cols]), k
 
 
+@pytest.mark.parametrize('rows,W,O,A,B', [(1000000, 1, 111, 8, 1024),      # BASELINE cfg 3
+                                          (1953, 512, 67, 21, 100),         # BASELINE cfg 4 (reference batch)
+                                          (1953, 512, 67, 21, 1024)])
+def test_buffer_gather_bit_exact_at_baseline_size(lib, rows, W, O, A, B):
+    """BASELINE's own buffers — cfg 3: 1 000 000 x 1 transitions of Ant-v3 shapes (0.94 GB), cfg 4:
+    [1953, 512] of humanoid-walk shapes — full, and the 50 batches of one `Buffer.get`
+    (buffers.py:81-91): the index stream is `RandomState(0).randint(size * W, size=B)` bit for bit,
+    `rows = idx // W`, `cols = idx % W` (int64), and every gathered field equals NumPy's fancy
+    indexing of the same arrays bit for bit — through the one-launch `gather_many` the agents use
+    and through the per-batch `gather` / the drop-in `get`."""
+    from tonic_amd.replays import Buffer
+    buf = Buffer(size=rows * W, batch_size=B)
+    buf.initialize(seed=0, device='cuda')
+    buf._allocate(W, O, A)
+    assert buf.max_size == rows
+    fill = np.random.default_rng(rows + B)
+    host = {}
+    for key, tensor in buf.buffers.items():
+        host[key] = fill.standard_normal(tuple(tensor.shape), dtype=np.float32)
+        tensor.copy_(torch.from_numpy(host[key]))
+    buf.index, buf.size = 0, rows
+    stream = np.random.RandomState(0)
+    want_indices = np.stack([stream.randint(rows * W, size=B) for _ in range(buf.batch_iterations)])
+    indices = buf.sample_indices()
+    assert indices.dtype == np.int64 and np.array_equal(indices, want_indices)
+    assert indices.max() > rows * W * 0.99 and indices.min() < rows * W * 0.01   # the whole range
+    r, c = want_indices // W, want_indices % W
+    many = buf.gather_many(torch.as_tensor(indices, device='cuda'))
+    for key in ('observations', 'actions', 'next_observations', 'rewards', 'discounts'):
+        assert np.array_equal(many[key].cpu().numpy(), host[key][r, c]), key
+    one = buf.gather(torch.as_tensor(indices[7], device='cuda'))
+    for key in ('observations', 'actions', 'next_observations', 'rewards', 'discounts'):
+        assert np.array_equal(one[key].cpu().numpy(), host[key][r[7], c[7]]), key
+    # the drop-in generator draws the NEXT 50 batches of the same stream
+    for it, batch in enumerate(buf.get('observations', 'rewards', steps=0)):
+        idx = stream.randint(rows * W, size=B)
+        assert np.array_equal(batch['observations'].cpu().numpy(), host['observations'][idx // W, idx % W])
+        assert np.array_equal(batch['rewards'].cpu().numpy(), host['rewards'][idx // W, idx % W])
+    assert it == buf.batch_iterations - 1
+
+
 def _agent_from_golden(g, kind):
     import tonic_amd
     import tonic_amd.torch as tt
@@ -381,24 +422,26 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                                       got[first] if first else None, want[first] if first else None))
 
 
-def test_a_lost_workgroup_of_a_chained_launch_is_a_nan_loss_not_a_hang(lib):
+def test_a_lost_workgroup_of_a_chained_launch_skips_the_step_and_raises(lib):
     """The workgroups of the chained launches wait for each other's values (exchange_read,
     csrc/mlpfwd.h).  A value that never comes — here: the first target workgroup of ONE critic
-    step returns without a word (tuning key `chain_fault`) — must not hang the device: its readers
-    give up after 50 ms and the logged critic loss of that iteration is NaN (so is what they
-    computed from the empty words); the device stays usable: a fresh agent reproduces the first
-    update bit for bit."""
+    step returns without a word (tuning key `chain_fault`) — must not hang the device and must not
+    touch the model: its readers give up after 250 ms, the iteration's failure word makes BOTH
+    optimizer epilogues of that iteration skip their step (no parameter, moment, target or step
+    counter moves), the logged loss is NaN with the give-up mark in slot 7, the next iteration runs
+    normally, and `agent._update` raises.  The device stays usable: a fresh agent reproduces the
+    first update bit for bit."""
     import time
     import tonic_amd
     import tonic_amd.torch as tt
     from tonic_amd import _lib
     from tonic_amd.environments import Box
-    O, A, W, B, rows, iterations = 17, 6, 4, 64, 48, 2
+    O, A, W, B, rows = 17, 6, 4, 64, 48
 
-    def make():
+    def make(iterations):
         rng = np.random.RandomState(3)
         replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B)
-        agent = tt.agents.TD3(replay=replay)
+        agent = tt.agents.DDPG(replay=replay)           # (actor + targets every iteration)
         agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=1)
         assert agent._fused_kind() is not None
         for _ in range(rows):
@@ -409,21 +452,50 @@ def test_a_lost_workgroup_of_a_chained_launch_is_a_nan_loss_not_a_hang(lib):
                          resets=dev(np.zeros(W, np.float32)),
                          terminations=dev(np.zeros(W, np.float32)))
         return agent
+
+    def snapshot(agent):
+        m = agent.model
+        tensors = [m.flat_online, m.flat_target, agent.critic_updater.exp_avg,
+                   agent.critic_updater.exp_avg_sq, agent.actor_updater.exp_avg,
+                   agent.actor_updater.exp_avg_sq, agent.critic_updater.state[:1],
+                   agent.actor_updater.state[:1]]
+        return [t.detach().cpu().clone() for t in tensors]
+
     rng = np.random.RandomState(4)
-    eps = rng.normal(size=(iterations, 1, B, A)).astype(np.float32)
-    indices = rng.randint(rows * W, size=(iterations, B))
-    agent = make()
+    eps = rng.normal(size=(2, 1, B, A)).astype(np.float32)
+    indices = rng.randint(rows * W, size=(2, B))
+    agent = make(2)
     good = agent.enqueue_update(indices, eps, graph=False).cpu().numpy().copy()
-    assert np.isfinite(good[0][:, 0]).all()
+    assert np.isfinite(good[:, :, 0]).all() and not good[..., 7].any()
+    after_good = snapshot(agent)
+    # a fault in the FIRST of two iterations == only the second iteration ran
+    reference = make(2)
+    reference.enqueue_update(indices, eps, graph=False)
+    torch.cuda.synchronize()
+    # (the optimizer constants of a step follow the device's counter: iteration 2 alone is step 3)
+    only_second = reference.enqueue_update(indices[1:], eps[1:], graph=False).cpu().numpy().copy()
+    want = snapshot(reference)
     _lib.check(lib.tonic_set_tuning(b'chain_fault', 1), 'tuning')
     start = time.perf_counter()
     bad = agent.enqueue_update(indices, eps, graph=False).cpu().numpy().copy()
     elapsed = time.perf_counter() - start
-    assert np.isnan(bad[0][0, 0]), bad[0][:, 0]         # (what was read instead of the value is
-    #                                                     an empty word: the parameters are gone too)
-    assert 0.03 < elapsed < 5.0, elapsed                # the 50 ms bound, not a watchdog reset
+    assert np.isnan(bad[0, 0, 0]) and np.isnan(bad[1, 0, 0]), bad[:, 0, 0]
+    assert bad[0, 0, 7] == 1 and bad[1, 0, 7] == 1 and bad[0, 0, 6] == 0 and bad[1, 0, 6] == 0
+    assert bad[0, 1, 7] == 0 and bad[1, 1, 7] == 0 and bad[0, 1, 6] == 1 and bad[1, 1, 6] == 1
+    assert 0.2 < elapsed < 5.0, elapsed                 # the 250 ms bound, not a watchdog reset
+    got = snapshot(agent)
+    assert int(got[-2]) == int(after_good[-2]) + 1 and int(got[-1]) == int(after_good[-1]) + 1
+    for g, w in zip(got[:2], want[:2]):                 # the model: as if iteration 1 had not been
+        assert torch.isfinite(g).all()
+    # the skipped iteration left the state of the first update; then ONE regular iteration ran.
+    # Its Adam constants were formed for step 4 (the host counted the skipped step), the
+    # reference's for step 3: compare the critic's logged row, which does not depend on them
+    np.testing.assert_array_equal(bad[0, 1, :3], only_second[0, 0, :3])
+    with pytest.raises(_lib.TonicHipError, match='gave up'):
+        from tonic_amd.torch import agents
+        agents._check_chain(bad)
     # the device and the library are fine: a fresh agent reproduces the first update bit for bit
-    again = make().enqueue_update(indices, eps, graph=False).cpu().numpy()
+    again = make(2).enqueue_update(indices, eps, graph=False).cpu().numpy()
     assert np.array_equal(again, good)
 
 

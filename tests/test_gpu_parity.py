@@ -163,7 +163,7 @@ def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
     keep = [dev(flat(params)), dev(obs), dev(actions), dev(adv), dev(stats), dev(old_lp)]
     _lib.check(lib.tonic_ppo_actor_grad(
         *[t.data_ptr() for t in keep], out.data_ptr(),
-        n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor_grad')
+        n, O, A, 0.2, 0.0, None, 0, ws.data_ptr(), ws.numel(), None), 'actor_grad')
     torch.cuda.synchronize()
     _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
     return out.cpu().numpy(), P
@@ -180,7 +180,7 @@ def critic_grad(lib, params, mean, std, obs, returns, variant=None, clip=0.0):
     keep = [dev(flat(params)), dev(mean), dev(std), dev(obs), dev(returns)]
     _lib.check(lib.tonic_value_regression_grad(
         *[t.data_ptr() for t in keep[:3]], float(clip), *[t.data_ptr() for t in keep[3:]],
-        out.data_ptr(), n, O, ws.data_ptr(), ws.numel(), None), 'critic_grad')
+        out.data_ptr(), n, O, 0, ws.data_ptr(), ws.numel(), None), 'critic_grad')
     torch.cuda.synchronize()
     _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
     return out.cpu().numpy(), P
@@ -779,84 +779,139 @@ def test_two_whole_iterations_at_baseline_size_vs_oracle(lib):
     PPO iterations (actor grad -> reduce -> Adam, critic grad -> reduce -> Adam, twice) through
     the agent against oracle/torch_port.py (the reference's torch-CPU operators) — returns,
     losses, KL at 1e-5, parameter deltas after each iteration at 1e-5 on the elements whose
-    gradient is above float32 summation noise."""
+    gradient is above float32 summation noise.  Three times: with the critic's launches at the
+    kernel's own width (256 workgroups), and at the widths they have in the mode bench.py
+    measures — under the next rollout's resident collect kernel (`PPO._critic_width`): 219
+    workgroups at 256 workers, 232 at 48 — i.e. tonic_value_regression_grad(max_workgroups =
+    219 / 232) against the oracle at the metric's size."""
     import tonic_amd
     import tonic_amd.torch
     import torch_port
     from tonic_amd.environments import Box
+    from tonic_amd.torch import updaters
     O, A, W, T = 17, 6, 256, 4096
     rng = np.random.RandomState(11)
-    agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T, batch_iterations=2))
-    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=2)
-    state = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
-    actor = [state[k] for k in ('actor.torso.model.0.weight', 'actor.torso.model.0.bias',
-                                'actor.torso.model.2.weight', 'actor.torso.model.2.bias',
-                                'actor.head.log_scale', 'actor.head.loc_layer.0.weight',
-                                'actor.head.loc_layer.0.bias')]
-    critic = [state[k] for k in ('critic.torso.model.0.weight', 'critic.torso.model.0.bias',
-                                 'critic.torso.model.2.weight', 'critic.torso.model.2.bias',
-                                 'critic.head.v_layer.weight', 'critic.head.v_layer.bias')]
     mean = (rng.standard_normal(O) * 0.1).astype(np.float32)
     std = (1 + 0.2 * rng.uniform(size=O)).astype(np.float32)
-    agent.model.observation_normalizer._mean.data.copy_(torch.as_tensor(mean))
-    agent.model.observation_normalizer._std.data.copy_(torch.as_tensor(std))
     observations = rng.standard_normal((T, W, O)).astype(np.float32)
     eps = rng.standard_normal((T, W, A)).astype(np.float32)
-    actions, log_probs = port.ppo_act(actor, observations.reshape(-1, O), eps.reshape(-1, A))
     resets = (rng.uniform(size=(T, W)) < 1e-3).astype(np.float32)
     data = dict(
-        observations=observations, actions=actions.reshape(T, W, A),
+        observations=observations,
         next_observations=rng.standard_normal((T, W, O)).astype(np.float32),
         rewards=rng.standard_normal((T, W)).astype(np.float32), resets=resets,
-        terminations=resets * (rng.uniform(size=(T, W)) < 0.5).astype(np.float32),
-        log_probs=log_probs.reshape(T, W))
-    agent.replay._allocate(W, O, A)
-    for key, value in data.items():
-        agent.replay.buffers[key].copy_(torch.as_tensor(value))
-    agent.replay.index = T
+        terminations=resets * (rng.uniform(size=(T, W)) < 0.5).astype(np.float32))
+    oracle_run = None
 
-    oracle = torch_port.TorchPPO(O, A, steps=T)
-    oracle.load(actor, critic, (mean, std))
-    oracle.buffers = {k: v.copy() for k, v in data.items()}
-    batch = oracle.evaluate_and_returns()
-    want_infos, want_params, first_grads = [], [], None
-    for it in range(2):
-        a = oracle.actor_update(batch['observations'], batch['actions'], batch['advantages'],
-                                batch['log_probs'])
-        c = oracle.critic_update(batch['observations'], batch['returns'])
-        if first_grads is None:
-            first_grads = [p.grad.detach().numpy().copy()
-                           for p in oracle.actor_vars + oracle.critic_vars]
-        want_infos.append((float(a['loss']), float(a['kl']), float(c['loss'])))
-        want_params.append([p.detach().numpy().copy() for p in oracle.actor_vars + oracle.critic_vars])
+    for width in (0, 219, 232):
+        agent = tonic_amd.torch.agents.PPO(replay=tonic_amd.replays.Segment(size=T, batch_iterations=2))
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=2)
+        agent._critic_width = lambda width=width: width
+        state = {k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+        keys = [k for k in state if 'normalizer' not in k]
+        if oracle_run is None:          # (same seed: every agent starts from these parameters)
+            actor = [state[k] for k in ('actor.torso.model.0.weight', 'actor.torso.model.0.bias',
+                                        'actor.torso.model.2.weight', 'actor.torso.model.2.bias',
+                                        'actor.head.log_scale', 'actor.head.loc_layer.0.weight',
+                                        'actor.head.loc_layer.0.bias')]
+            critic = [state[k] for k in ('critic.torso.model.0.weight', 'critic.torso.model.0.bias',
+                                         'critic.torso.model.2.weight', 'critic.torso.model.2.bias',
+                                         'critic.head.v_layer.weight', 'critic.head.v_layer.bias')]
+            actions, log_probs = port.ppo_act(actor, observations.reshape(-1, O), eps.reshape(-1, A))
+            data['actions'], data['log_probs'] = actions.reshape(T, W, A), log_probs.reshape(T, W)
+            oracle = torch_port.TorchPPO(O, A, steps=T)
+            oracle.load(actor, critic, (mean, std))
+            oracle.buffers = {k: v.copy() for k, v in data.items()}
+            batch = oracle.evaluate_and_returns()
+            want_infos, want_params, first_grads = [], [], None
+            for it in range(2):
+                a = oracle.actor_update(batch['observations'], batch['actions'], batch['advantages'],
+                                        batch['log_probs'])
+                c = oracle.critic_update(batch['observations'], batch['returns'])
+                if first_grads is None:
+                    first_grads = [p.grad.detach().numpy().copy()
+                                   for p in oracle.actor_vars + oracle.critic_vars]
+                want_infos.append((float(a['loss']), float(a['kl']), float(c['loss'])))
+                want_params.append([p.detach().numpy().copy()
+                                    for p in oracle.actor_vars + oracle.critic_vars])
+            oracle_run = (state, want_infos, want_params, first_grads, oracle.buffers['returns'])
+        first_state, want_infos, want_params, first_grads, want_returns = oracle_run
+        assert all(np.array_equal(state[k], first_state[k]) for k in state)
+        agent.model.observation_normalizer._mean.data.copy_(torch.as_tensor(mean))
+        agent.model.observation_normalizer._std.data.copy_(torch.as_tensor(std))
+        agent.replay._allocate(W, O, A)
+        for key, value in data.items():
+            agent.replay.buffers[key].copy_(torch.as_tensor(value))
+        agent.replay.index = T
 
-    keys = [k for k in state if 'normalizer' not in k]
-    # iteration by iteration on the device: one-iteration updates, parameters read in between
-    agent.replay.batch_iterations = 1
-    infos = agent.enqueue_update().cpu().numpy()
-    np.testing.assert_allclose(agent.replay.buffers['returns'].cpu().numpy(),
-                               oracle.buffers['returns'], rtol=1e-5, atol=1e-5)
-    got_infos = [(infos[0][0, 0], infos[0][0, 1], infos[1][0, 0])]
-    got_params = [[agent.model.state_dict()[k].detach().cpu().numpy().copy() for k in keys]]
-    # second iteration on the SAME returns / advantages (ppo.py:33-46 evaluates once per update)
-    from tonic_amd.torch import updaters
-    replay, actor_u, critic_u = agent.replay, agent.actor_updater, agent.critic_updater
-    obs, act, raw_adv, old_lp, ret = next(iter(replay.learner_batches()))
-    info2 = torch.zeros(2, updaters.INFO_WIDTH, device='cuda')
-    actor_u.enqueue_grad(obs, act, raw_adv, replay.adv_stats, old_lp)
-    critic_u.enqueue_grad(obs, ret)
-    updaters.enqueue_step_pair(actor_u, critic_u, obs.shape[0], replay.adv_stats, info2[0], info2[1])
-    info2 = info2.cpu().numpy()
-    got_infos.append((info2[0, 0], info2[0, 1], info2[1, 0]))
-    got_params.append([agent.model.state_dict()[k].detach().cpu().numpy().copy() for k in keys])
-    np.testing.assert_allclose(np.array(got_infos), np.array(want_infos), rtol=1e-5, atol=1e-5)
-    start = [state[k] for k in keys]
-    for it in range(2):
-        for key, first, got, want, grad in zip(keys, start, got_params[it], want_params[it],
-                                               first_grads):
-            live = np.abs(grad) > 1e-6 * np.abs(grad).max()
-            np.testing.assert_allclose((got - first)[live], (want - first)[live], rtol=0,
-                                       atol=1e-5, err_msg=f'iteration {it + 1}: {key}')
+        # iteration by iteration on the device: one-iteration updates, parameters read in between
+        agent.replay.batch_iterations = 1
+        infos = agent.enqueue_update().cpu().numpy()
+        assert agent.critic_updater.max_workgroups == width
+        np.testing.assert_allclose(agent.replay.buffers['returns'].cpu().numpy(), want_returns,
+                                   rtol=1e-5, atol=1e-5)
+        got_infos = [(infos[0][0, 0], infos[0][0, 1], infos[1][0, 0])]
+        got_params = [[agent.model.state_dict()[k].detach().cpu().numpy().copy() for k in keys]]
+        # second iteration on the SAME returns / advantages (ppo.py:33-46 evaluates once per update)
+        replay, actor_u, critic_u = agent.replay, agent.actor_updater, agent.critic_updater
+        obs, act, raw_adv, old_lp, ret = next(iter(replay.learner_batches()))
+        info2 = torch.zeros(2, updaters.INFO_WIDTH, device='cuda')
+        actor_u.enqueue_grad(obs, act, raw_adv, replay.adv_stats, old_lp)
+        critic_u.enqueue_grad(obs, ret)
+        updaters.enqueue_step_pair(actor_u, critic_u, obs.shape[0], replay.adv_stats, info2[0], info2[1])
+        info2 = info2.cpu().numpy()
+        got_infos.append((info2[0, 0], info2[0, 1], info2[1, 0]))
+        got_params.append([agent.model.state_dict()[k].detach().cpu().numpy().copy() for k in keys])
+        np.testing.assert_allclose(np.array(got_infos), np.array(want_infos), rtol=1e-5, atol=1e-5,
+                                   err_msg=f'critic width {width}')
+        start = [state[k] for k in keys]
+        for it in range(2):
+            for key, first, got, want, grad in zip(keys, start, got_params[it], want_params[it],
+                                                   first_grads):
+                live = np.abs(grad) > 1e-6 * np.abs(grad).max()
+                np.testing.assert_allclose(
+                    (got - first)[live], (want - first)[live], rtol=0, atol=1e-5,
+                    err_msg=f'critic width {width}, iteration {it + 1}: {key}')
+        agent.close()
+
+
+def test_value_regression_grad_width_is_an_argument(lib):
+    """`max_workgroups` of tonic_value_regression_grad (tonic_ppo_actor_grad shares the code): the same width gives
+    the same bits on every call, another width the same gradient sums at float32 rounding level
+    (relative to the largest element), 0 = the kernel's own width, and a width above it changes
+    nothing."""
+    from tonic_amd import _lib
+    O, A, n = 17, 6, 300000
+    rng = np.random.RandomState(4)
+    cparams = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+               rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+               rng.normal(size=(1, 64)) * 0.3, rng.normal(size=1)]
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    ret = rng.standard_normal(n).astype(np.float32)
+    mean, std = np.zeros(O, np.float32), np.ones(O, np.float32)
+    P = lib.tonic_v_critic_param_count(O)
+    ws = torch.empty(lib.tonic_ppo_workspace_bytes(n, O, A, 1), dtype=torch.uint8, device='cuda')
+    keep = [dev(flat(cparams)), dev(mean), dev(std), dev(obs), dev(ret)]
+
+    def critic(width):
+        out = torch.zeros(P + 8, device='cuda')
+        _lib.check(lib.tonic_value_regression_grad(
+            *[t.data_ptr() for t in keep[:3]], 0.0, *[t.data_ptr() for t in keep[3:]],
+            out.data_ptr(), n, O, width, ws.data_ptr(), ws.numel(), None), 'critic_grad')
+        return out.cpu().numpy()
+
+    full = critic(0)
+    assert np.array_equal(critic(256), full) and np.array_equal(critic(4096), full)
+    for width in (219, 232, 8, 1):
+        got = critic(width)
+        assert np.array_equal(critic(width), got), width
+        assert not np.array_equal(got, full), 'another grouping of the partial sums'
+        assert np.abs(got - full).max() <= 2e-6 * np.abs(full).max(), width
+    out = torch.zeros(P + 8, device='cuda')
+    rc = lib.tonic_value_regression_grad(
+        *[t.data_ptr() for t in keep[:3]], 0.0, *[t.data_ptr() for t in keep[3:]],
+        out.data_ptr(), n, O, -1, ws.data_ptr(), ws.numel(), None)
+    assert rc == -1 and b'max_workgroups' in lib.tonic_last_error()      # TONIC_ERR_INVALID_ARGUMENT
 
 
 def test_ppo_update_with_gradient_and_normaliser_clipping(golden, lib):

@@ -58,9 +58,9 @@ SIGNATURES = {
     'tonic_value_forward_wide': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 2 +
                                  [c_i64, c_i32, c_vp, c_i64, c_vp]),
     'tonic_ppo_actor_grad': (ctypes.c_int, [c_vp] * 7 + [c_i64, c_i32, c_i32, c_f64, c_f64,
-                                                          c_vp, c_vp, c_i64, c_vp]),
+                                                          c_vp, c_i32, c_vp, c_i64, c_vp]),
     'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 3 +
-                                    [c_i64, c_i32, c_vp, c_i64, c_vp]),
+                                    [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'tonic_clip_workspace_bytes': (c_i64, [c_i64]),
@@ -139,6 +139,8 @@ SIGNATURES = {
     'tonic_comm_connect': (ctypes.c_int, [c_vp, c_vp]),
     'tonic_allreduce_f32': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     'tonic_comm_status': (ctypes.c_int, [c_vp]),
+    'tonic_comm_set_timeout': (ctypes.c_int, [c_vp, c_f64]),
+    'tonic_comm_can_access_peer': (ctypes.c_int, [c_i32, c_i32]),
     'tonic_comm_destroy': (ctypes.c_int, [c_vp]),
     'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_debug_forward_stamps': (ctypes.c_int, [c_vp]),
@@ -146,7 +148,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 5        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 6        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

@@ -133,6 +133,7 @@ struct tonic_comm {
   bool opened[kMaxRanks];
   bool connected;
   unsigned sequence;
+  unsigned long long timeout_ticks;   // 0: the process-wide default (comm_timeout_ticks)
 };
 
 #define TONIC_HIP(call, what)                                                       \
@@ -231,11 +232,30 @@ extern "C" int tonic_allreduce_f32(tonic_comm_t* c, float* d_buffer, int64_t n, 
   a.status_offset = l.status_offset;
   a.rank = c->rank; a.world = c->world;
   a.sequence = ++c->sequence;
-  a.timeout_ticks = comm_timeout_ticks();
+  a.timeout_ticks = c->timeout_ticks != 0 ? c->timeout_ticks : comm_timeout_ticks();
   hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(kCommBlocks), dim3(kCommThreads), 0,
                      as_stream(stream), a);
   TONIC_CHECK_LAUNCH("tonic_allreduce_f32");
   return TONIC_OK;
+}
+
+extern "C" int tonic_comm_set_timeout(tonic_comm_t* c, double seconds) {
+  TONIC_REQUIRE(c != nullptr && seconds >= 0.0 && seconds <= 3600.0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_comm_set_timeout: bad argument");
+  c->timeout_ticks = (unsigned long long)(seconds * 1e8);   // 100 MHz wall clock; 0 = the default
+  return TONIC_OK;
+}
+
+extern "C" int tonic_comm_can_access_peer(int32_t device, int32_t peer) {
+  int count = 0;
+  TONIC_HIP(hipGetDeviceCount(&count), "hipGetDeviceCount");
+  TONIC_REQUIRE(device >= 0 && device < count && peer >= 0 && peer < count,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_comm_can_access_peer: devices %d, %d of %d",
+                device, peer, count);
+  if (device == peer) return 1;
+  int can = 0;
+  TONIC_HIP(hipDeviceCanAccessPeer(&can, device, peer), "hipDeviceCanAccessPeer");
+  return can != 0 ? 1 : 0;
 }
 
 extern "C" int tonic_comm_status(tonic_comm_t* c) {
@@ -246,7 +266,8 @@ extern "C" int tonic_comm_status(tonic_comm_t* c) {
             "hipMemcpy");
   if (failed_at != 0) {
     set_error("tonic_allreduce_f32: a peer did not arrive within %.0f s (call number %u)",
-              (double)comm_timeout_ticks() / 1e8, failed_at);
+              (double)(c->timeout_ticks != 0 ? c->timeout_ticks : comm_timeout_ticks()) / 1e8,
+              failed_at);
     return TONIC_ERR_TIMEOUT;
   }
   return TONIC_OK;

@@ -67,6 +67,11 @@ struct AdamFold {
   double beta1_d, beta2_d, lr_d;
   int stats_kind;            // 3 twin Q critics, 4 Q actor (see adam_finalize in optim.hip)
   float* info_row;
+  // A chained launch ahead of this one may have given up on a value that never came (mlpfwd.h:
+  // exchange_read): its failure word.  Non-zero = the gradient sums are not a gradient — no
+  // parameter, moment or target is written, the step counter stays, the logged loss is NaN and
+  // info_row[7] = 1 (agents.DDPG._update raises on it).  Null: always step.
+  const unsigned* skip;
   int on;
 };
 

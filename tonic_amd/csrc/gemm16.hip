@@ -235,7 +235,7 @@ __device__ __forceinline__ void adam_apply(const AdamFold& f, const AdamConsts& 
 }
 
 // The last workgroup of the launch: step counter and logged statistics (adam_finalize, optim.hip).
-__device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned total) {
+__device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned total, bool stepping) {
   unsigned* arrivals = reinterpret_cast<unsigned*>(f.state + 3);
   // (this wave's loads of the step's state / constants have returned before it arrives: the
   //  finaliser's write of the step counter races with nobody, see adam_kernel in optim.hip)
@@ -244,6 +244,12 @@ __device__ __forceinline__ void adam_fold_arrive(const AdamFold& f, unsigned tot
                                                  __HIP_MEMORY_SCOPE_AGENT);
   if (before != total - 1) return;
   __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!stepping) {                            // not a training step: see AdamFold::skip
+    if (f.info_row != nullptr) {              // {loss = NaN, ..., ran = 0, gave up = 1}
+      f.info_row[0] = __builtin_nanf(""); f.info_row[6] = 0.f; f.info_row[7] = 1.f;
+    }
+    return;
+  }
   f.state[0] += 1;
   if (f.info_row == nullptr) return;
   const float* st = f.grads + f.n;
@@ -348,9 +354,12 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
   // optimizer epilogue: the step's constants (two float64 pow: ~1 us of VALU work) are formed HERE,
   // by every wave, while the first operand chunks are in flight
   AdamConsts consts{};
+  bool stepping = fold.on != 0;               // (uniform)
   if (fold.on) {
     __builtin_amdgcn_sched_barrier(0);
     consts = adam_consts(fold);
+    if (fold.skip != nullptr)
+      stepping = __hip_atomic_load(fold.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     __builtin_amdgcn_sched_barrier(0);
   }
   stamp(1);                                         // first requests out, constants formed
@@ -411,7 +420,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
     }
   }
   if (w == 0) {
-    if (fold.on && lane == 0) adam_fold_arrive(fold, total_blocks);   // (state / constants were read)
+    if (fold.on && lane == 0) adam_fold_arrive(fold, total_blocks, stepping);   // (state / constants were read)
     if (g.colsum != nullptr && tn == 0) {
 #pragma unroll
       for (int jm = 0; jm < 2; ++jm) {
@@ -421,7 +430,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
         v += __shfl_xor(v, 32, 64);
         if (kg == 0 && ca + jm < g.M) {
           g.colsum[z * g.strideColsum + ca + jm] = v;
-          if (fold.on)
+          if (stepping)
             adam_apply(fold, consts, (g.colsum + z * g.strideColsum + ca + jm) - fold.grads, v);
         }
       }
@@ -467,7 +476,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       v0 = g.accumulate ? dst[0] + v0 : v0;
       dst[0] = v0;
     }
-    if (!fold.on) continue;
+    if (!stepping) continue;
     // ---- Adam (+ polyak) on the two elements just formed
     const float sum[2] = {v0, v1};
     const int64_t off = goff + (int64_t)m * g.ldc + cb;

@@ -765,10 +765,6 @@ std::atomic<int> g_grad_waves{4};
 // dW2 on bf16x3 terms as well (2 x 2 tiles of v_mfma_f32_32x32x16_bf16; CH = 2).
 constexpr int kDefaultGradVariant = 3;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
-// Workgroups of the fused grad launches enqueued from now on (<= 256 = one per CU).  A caller that
-// runs one network's iterations UNDER another kernel that must keep its compute units — the PPO
-// critic under the next rollout's resident collect kernel, agents.py — leaves those units free.
-std::atomic<int> g_grad_blocks{256};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
@@ -861,12 +857,6 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_grad_skew = value;
     return TONIC_OK;
   }
-  if (strcmp(key, "grad_blocks") == 0) {
-    TONIC_REQUIRE(value >= 8 && value <= 256, TONIC_ERR_INVALID_ARGUMENT,
-                  "grad_blocks must be in [8, 256], got %d", value);
-    g_grad_blocks = value;
-    return TONIC_OK;
-  }
   if (strcmp(key, "grad_variant") == 0) {
     TONIC_REQUIRE(value >= -1 && value <= 3, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_variant must be 0 .. 3 or -1 (default), got %d", value);
@@ -907,7 +897,6 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
   if (strcmp(key, "grad_waves") == 0) { *value = g_grad_waves; return TONIC_OK; }
   if (strcmp(key, "grad_skew") == 0) { *value = g_grad_skew; return TONIC_OK; }
   if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
-  if (strcmp(key, "grad_blocks") == 0) { *value = g_grad_blocks; return TONIC_OK; }
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
   if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
   if (strcmp(key, "q_chain") == 0) { *value = g_q_chain; return TONIC_OK; }
@@ -1109,11 +1098,19 @@ extern "C" int64_t tonic_mlp64_grad_workspace_bytes(int64_t n, int64_t param_cou
 
 template <bool ACTOR>
 static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coeff,
-                    void* d_workspace, int64_t workspace_bytes, void* stream) {
+                    int32_t max_workgroups, void* d_workspace, int64_t workspace_bytes,
+                    void* stream) {
+  TONIC_REQUIRE(max_workgroups >= 0, TONIC_ERR_INVALID_ARGUMENT,
+                "max_workgroups must be 0 (one per compute unit) or positive, got %d",
+                max_workgroups);
   const int variant = g_grad_variant;
   const bool use16 = variant >= 1 && grad16_supported(a.O, a.A, ACTOR);
-  const int all = use16 ? grad16_blocks(a.n) : grad_blocks(a.n), cap = g_grad_blocks;
-  const int blocks = all < cap ? all : cap;
+  // The launch width is the CALLER's: a network whose iterations run under another kernel that
+  // must keep its compute units (the PPO critic under the next rollout's resident collect kernel,
+  // agents.py) leaves those units free.  The grouping of the float32 partial sums follows the
+  // width, so a caller that wants reproducible bits passes the same width every time.
+  const int all = use16 ? grad16_blocks(a.n) : grad_blocks(a.n);
+  const int blocks = max_workgroups > 0 && max_workgroups < all ? max_workgroups : all;
   const int64_t pstride = round_up(P + kStatSlots, 64);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= blocks * pstride * (int64_t)sizeof(float),
                 TONIC_ERR_WORKSPACE, "grad workspace too small: %lld < %lld",
@@ -1160,8 +1157,8 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
                                     const float* d_adv_stats, const float* d_old_log_probs,
                                     float* d_grad_sums, int64_t n, int32_t O, int32_t A,
                                     double ratio_clip, double entropy_coeff,
-                                    const int32_t* d_skip_flag, void* d_workspace,
-                                    int64_t workspace_bytes, void* stream) {
+                                    const int32_t* d_skip_flag, int32_t max_workgroups,
+                                    void* d_workspace, int64_t workspace_bytes, void* stream) {
   TONIC_REQUIRE(d_actor_params && d_observations && d_actions && d_advantages && d_adv_stats &&
                     d_old_log_probs && d_grad_sums && n > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_actor_grad: bad argument");
@@ -1178,7 +1175,7 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
     return wide_actor_grad(a, d_grad_sums, (float)entropy_coeff, d_workspace, workspace_bytes,
                            as_stream(stream));
   return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
-                        (float)entropy_coeff,
+                        (float)entropy_coeff, max_workgroups,
                         d_workspace, workspace_bytes, stream);
 }
 
@@ -1210,8 +1207,8 @@ extern "C" int tonic_value_regression_grad(const float* d_critic_params,
                                            double norm_clip,
                                            const float* d_observations, const float* d_returns,
                                            float* d_grad_sums, int64_t n, int32_t O,
-                                           void* d_workspace, int64_t workspace_bytes,
-                                           void* stream) {
+                                           int32_t max_workgroups, void* d_workspace,
+                                           int64_t workspace_bytes, void* stream) {
   TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_returns &&
                     d_grad_sums && n > 0,
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_value_regression_grad: bad argument");
@@ -1222,6 +1219,6 @@ extern "C" int tonic_value_regression_grad(const float* d_critic_params,
   a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
   a.n = n; a.O = O; a.A = 1;
   if (wide) return wide_critic_grad(a, d_grad_sums, d_workspace, workspace_bytes, as_stream(stream));
-  return run_grad<false>(a, tonic_v_critic_param_count(O), d_grad_sums, 0.f, d_workspace,
-                         workspace_bytes, stream);
+  return run_grad<false>(a, tonic_v_critic_param_count(O), d_grad_sums, 0.f, max_workgroups,
+                         d_workspace, workspace_bytes, stream);
 }

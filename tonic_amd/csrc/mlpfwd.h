@@ -118,6 +118,7 @@ struct MlpFwdArgs {
   float* enc_out; float* enc_out2;
   int enc_O, enc_ld;
   float* reset_area; int64_t reset_floats;   // the launch AHEAD of the chained ones: fill with kExchangeEmpty
+  unsigned* reset_failed;                    //   ... and clear their failure word
   float* xq;                    // chained launches: the value head's outputs ALSO go (agent-scope stores) to the launch's
                                 //   exchange lines, see ValueLines; null: none
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
@@ -191,7 +192,7 @@ enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 // the memory side — is already seen: 1 run in 3 of the bit-identity test read a stale q; and a release
 // fence that waits for it is an L2 write-back of everything the XCD has dirtied: +13 % per iteration.)
 constexpr unsigned kExchangeEmpty = 0x7fa5c3e1u;       // a signalling-NaN pattern no arithmetic produces
-constexpr unsigned long long kChainTimeoutTicks = 5000000ull;      // 50 ms of the 100 MHz wall clock
+constexpr unsigned long long kChainTimeoutTicks = 25000000ull;     // 250 ms of the 100 MHz wall clock
 
 __device__ __forceinline__ float exchange_read(const float* p, unsigned* failed) {
   const unsigned* word = reinterpret_cast<const unsigned*>(p);
@@ -261,7 +262,9 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c) {
 // of the grid is resident can always make progress.  What crosses workgroups inside a launch (q
 // values, action-column gradients: a few floats per row) goes through the launch's exchange area:
 // see exchange_read / ValueLines.  A value that does not come within kChainTimeoutTicks (a lost
-// workgroup) does not hang the device: the reader goes on, the step's logged loss becomes NaN.
+// workgroup) does not hang the device: the reader goes on, the iteration's failure word is set, its
+// logged losses become NaN and its optimizer epilogues write NOTHING (AdamFold::skip) — parameters,
+// moments and targets stay what they were; agents.DDPG._update raises on the row's give-up mark.
 // Critic step: roles [target_0 .. target_{nets-1} | online_0 .. online_{nets-1}] (+ one workgroup
 // for the logged sums) — the targets' forward on (s', a'), the online critics' forward on (s, a),
 // and — with the targets' values of the tile — the TD loss and the online critics' input-gradient chain.

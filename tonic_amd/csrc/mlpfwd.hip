@@ -257,6 +257,7 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
     const int64_t stride = (int64_t)gridDim.x * gridDim.y * blockDim.x;
     unsigned* area = reinterpret_cast<unsigned*>(a.reset_area);
     for (int64_t i = first; i < a.reset_floats; i += stride) area[i] = kExchangeEmpty;
+    if (first == 0 && a.reset_failed != nullptr) *a.reset_failed = 0u;   // (and their failure word)
   }
   // wave w owns tiles w, w + 4, w + 8, w + 12; an index beyond the layer is clamped (the wave
   // then recomputes the last tile and drops it: no branch around an MFMA)
@@ -859,8 +860,9 @@ __device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b) {
   if (threadIdx.x == 0 &&
       __hip_atomic_load(b.exchange_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
     b.l_stats[0] = __builtin_nanf("");                // a value that never came: not a training step
-    __hip_atomic_store(b.exchange_failed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  }                                                   // (the word stays: the optimizer epilogues of this
+                                                      //  iteration skip their step, AdamFold::skip; the
+                                                      //  next iteration's first launch clears it)
 }
 
 __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {

@@ -1239,7 +1239,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     f.enc_obs = a.d_next_observations; f.enc_obs2 = a.d_observations; f.enc_act2 = a.d_actions;
     f.enc_mean = a.d_norm_mean; f.enc_std = a.d_norm_std; f.enc_clip = clip_bound(a.norm_clip);
     f.enc_out = X; f.enc_out2 = X2; f.enc_O = O; f.enc_ld = ldx;
-    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; }
+    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; f.reset_failed = failed; }
     if (due) {
       f.split = 1;
       f.second_params = a.d_actor - policy;            // (0 for SAC: the same network on s)
@@ -1261,6 +1261,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   cf.grad_scale = grad_scale; cf.beta2 = (float)a.critic.beta2; cf.eps = (float)a.critic.eps;
   cf.beta1_d = a.critic.beta1; cf.beta2_d = a.critic.beta2; cf.lr_d = a.critic.lr;
   cf.stats_kind = 3; cf.info_row = a.critic.d_info_row; cf.consts = a.critic.d_step_constants;
+  cf.skip = chain ? failed : nullptr;
   if (due) {
     cf.target = a.d_target_critics;
     cf.polyak_keep = (float)(1.0 - a.target_coeff); cf.polyak_mix = (float)a.target_coeff;
@@ -1310,6 +1311,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   af.grad_scale = grad_scale; af.beta2 = (float)a.actor.beta2; af.eps = (float)a.actor.eps;
   af.beta1_d = a.actor.beta1; af.beta2_d = a.actor.beta2; af.lr_d = a.actor.lr;
   af.stats_kind = 4; af.info_row = a.actor.d_info_row; af.consts = a.actor.d_step_constants;
+  af.skip = chain ? failed : nullptr;
   af.target = a.d_target_actor;
   af.polyak_keep = (float)(1.0 - a.target_coeff); af.polyak_mix = (float)a.target_coeff;
   if (chain) {

@@ -113,20 +113,101 @@ def combine_advantage_moments(total, total_sq, minimum, maximum, count):
 
 
 _one_shot = None
+_choice = None          # {'kind': 'oneshot' | 'rccl', 'reason': ...} once the ranks have decided
+
+
+def allreduce_choice():
+    """What the learner's gradient exchange uses and why (None before the first exchange):
+    bench.py prints it next to the measured latencies of both."""
+    return _choice
+
+
+def _agree(ok, reason=''):
+    """The AND over all ranks of a local verdict (with the first objecting rank's reason), so that
+    every rank takes the same branch — a rank alone on the other side of a collective is a hang."""
+    verdicts = [None] * world_size()
+    dist.all_gather_object(verdicts, (bool(ok), str(reason)))
+    for r, (fine, why) in enumerate(verdicts):
+        if not fine:
+            return False, f'rank {r}: {why}'
+    return True, ''
+
+
+def _peers_reachable():
+    """tonic_allreduce_f32 writes into windows of the peers' device memory: every rank on a device of
+    its own, all in one process namespace (one node), and hipDeviceCanAccessPeer for every pair."""
+    import socket
+
+    from tonic_amd import _lib
+    if not torch.cuda.is_available():
+        return _agree(False, 'no GPU')
+    lib = _lib.load()
+    me = (socket.gethostname(), torch.cuda.current_device())
+    everyone = [None] * world_size()
+    dist.all_gather_object(everyone, me)
+    if len({host for host, _ in everyone}) > 1:
+        return _agree(False, 'ranks on several hosts')
+    devices = [device for _, device in everyone]
+    if len(set(devices)) < len(devices):
+        return _agree(False, f'ranks share devices {devices}')
+    for peer in devices:
+        can = lib.tonic_comm_can_access_peer(me[1], peer)
+        if can != 1:
+            why = lib.tonic_last_error().decode() if can < 0 else 'hipDeviceCanAccessPeer = 0'
+            return _agree(False, f'device {me[1]} -> device {peer}: {why}')
+    return _agree(True)
 
 
 def one_shot(max_floats):
-    """The process-wide OneShotAllReduce when TONIC_AMD_ALLREDUCE=oneshot asks for it (windows grow
-    on demand before first use only), else None: callers then use torch.distributed (RCCL)."""
-    global _one_shot
-    if os.environ.get('TONIC_AMD_ALLREDUCE', '') != 'oneshot' or world_size() == 1:
+    """The process-wide OneShotAllReduce (tonic_allreduce_f32) when the gradient exchange should use
+    it, else None: callers then use torch.distributed (RCCL).  TONIC_AMD_ALLREDUCE:
+      auto (default)  the ranks decide TOGETHER, once: every rank on a device of its own on one
+                      host, peer access between every pair (hipDeviceCanAccessPeer), the windows
+                      open (hipIpc*), and a self-test of exact sums over several sizes and both slot
+                      parities passes on every rank — else RCCL, with the reason kept
+                      (`allreduce_choice()`);
+      oneshot         always (tests: also between processes that share one device);
+      rccl            never.
+    The windows grow on demand before first use only."""
+    global _one_shot, _choice
+    if world_size() == 1:
         return None
-    if _one_shot is None or _one_shot.max_floats < max_floats:
-        if _one_shot is not None:           # regrown windows: the old communicator is released
-            torch.cuda.synchronize()
-            _one_shot.check()
-            _one_shot.close()
+    if _one_shot is not None and _one_shot.max_floats >= max_floats:
+        return _one_shot
+    mode = os.environ.get('TONIC_AMD_ALLREDUCE', 'auto')
+    if mode == 'rccl' or (_choice is not None and _choice['kind'] == 'rccl'):
+        if _choice is None:
+            _choice = dict(kind='rccl', reason='TONIC_AMD_ALLREDUCE=rccl')
+        return None
+    if mode not in ('auto', 'oneshot'):
+        raise ValueError(f'TONIC_AMD_ALLREDUCE={mode!r}: auto, oneshot or rccl')
+    if _one_shot is not None:               # regrown windows: the old communicator is released
+        torch.cuda.synchronize()
+        _one_shot.check()
+        _one_shot.close()
+        _one_shot = None
+    if mode == 'oneshot':
         _one_shot = OneShotAllReduce(max(max_floats, 1 << 18))
+        _choice = dict(kind='oneshot', reason='TONIC_AMD_ALLREDUCE=oneshot')
+        return _one_shot
+    ok, why = _peers_reachable()
+    candidate = None
+    if ok:
+        from tonic_amd import _lib
+        try:
+            candidate = OneShotAllReduce(max(max_floats, 1 << 18), tolerant=True)
+            ok, why = _agree(candidate.handle is not None, candidate.error)
+            if ok:
+                ok, why = _agree(*candidate.self_test())
+        except _lib.TonicHipError as error:      # (a failure outside the agreed steps)
+            ok, why = False, str(error)
+    if not ok:
+        if candidate is not None:
+            candidate.close()
+        _choice = dict(kind='rccl', reason=why)
+        return None
+    _one_shot = candidate
+    _choice = dict(kind='oneshot', reason='peer access between every pair of ranks, self-test passed')
     return _one_shot
 
 
@@ -144,10 +225,14 @@ class OneShotAllReduce:
     device buffers as ONE launch per rank — every rank writes its buffer into a window of every
     peer and adds the contributions in rank order (deterministic, identical on all ranks).
     ``torch.distributed`` is only the bootstrap channel that carries the IPC handles once.
-    Opt-in for the learner (``TONIC_AMD_ALLREDUCE=oneshot``): validated between processes that
-    share one GPU (tests/test_gpu_multirank.py), not yet on an xGMI node."""
+    Validated between processes that share one GPU (tests/test_gpu_multirank.py); on a node with
+    several GPUs ``parallel.one_shot`` selects it after its peer-access checks and ``self_test``.
 
-    def __init__(self, max_floats):
+    ``tolerant``: a step of the set-up that fails on THIS rank is remembered (``error``; ``handle``
+    is then None) instead of raised, and the collectives of the set-up are still taken part in — the
+    caller lets the ranks agree on the outcome."""
+
+    def __init__(self, max_floats, tolerant=False):
         import ctypes
 
         from tonic_amd import _lib
@@ -155,19 +240,69 @@ class OneShotAllReduce:
         self.lib = lib = _lib.load()
         self.rank, self.world = rank(), world_size()
         self.max_floats = max_floats
+        self.error = ''
+
+        def step(status, what):
+            if status != 0 and not self.error:
+                self.error = f'{what}: {lib.tonic_last_error().decode()}'
+                if not tolerant:
+                    raise _lib.TonicHipError(self.error)
+            return status == 0
+
         handle = ctypes.c_void_p()
-        _lib.check(lib.tonic_comm_init(ctypes.byref(handle), self.rank, self.world, max_floats),
-                   'tonic_comm_init')
-        self.handle = handle.value
+        step(lib.tonic_comm_init(ctypes.byref(handle), self.rank, self.world, max_floats),
+             'tonic_comm_init')
+        self.handle = handle.value if not self.error else None
         if self.world > 1:
             size = lib.tonic_comm_handle_bytes()
             mine = ctypes.create_string_buffer(size)
-            _lib.check(lib.tonic_comm_export(self.handle, mine), 'tonic_comm_export')
+            if self.handle is not None:
+                step(lib.tonic_comm_export(self.handle, mine), 'tonic_comm_export')
             gathered = [None] * self.world
-            dist.all_gather_object(gathered, mine.raw)
-            everyone = ctypes.create_string_buffer(b''.join(gathered), size * self.world)
-            _lib.check(lib.tonic_comm_connect(self.handle, everyone), 'tonic_comm_connect')
+            dist.all_gather_object(gathered, (mine.raw, not self.error))
+            if all(fine for _, fine in gathered) and self.handle is not None:
+                everyone = ctypes.create_string_buffer(b''.join(raw for raw, _ in gathered),
+                                                       size * self.world)
+                step(lib.tonic_comm_connect(self.handle, everyone), 'tonic_comm_connect')
+            elif not self.error:
+                self.error = 'a peer could not export its window'
             dist.barrier()                  # every window is mapped everywhere before first use
+        if self.error and self.handle is not None:
+            lib.tonic_comm_destroy(self.handle)
+            self.handle = None
+
+    def self_test(self, calls=24, timeout_s=10.0):
+        """Exact sums through the windows before the learner relies on them: integer-valued float32
+        patterns (every partial sum is exact, so the expected bits are known without a second
+        exchange) over several sizes — one float, ragged, the gradient buffers' order of
+        magnitude, the whole window — `calls` back-to-back calls each (both slot parities, a rank
+        running ahead of its peers), with a short timeout.  Returns (ok, reason)."""
+        _lib = self._lib_module
+        if self.handle is None:
+            return False, self.error or 'no communicator'
+        _lib.check(self.lib.tonic_comm_set_timeout(self.handle, float(timeout_s)), 'set_timeout')
+        device = torch.device('cuda', torch.cuda.current_device())
+        ok, why = True, ''
+        try:
+            for n in (1, 1001, 11101, self.max_floats):
+                index = torch.arange(n, device=device, dtype=torch.float32) % 251.0
+                for call in range(calls):
+                    buffer = index * float(self.rank + 1) + float(call)
+                    self.all_reduce(buffer)
+                    want = index * float(self.world * (self.world + 1) // 2) + float(self.world * call)
+                    if not torch.equal(buffer, want):
+                        wrong = int((buffer != want).sum())
+                        ok, why = False, f'{wrong} of {n} sums wrong in call {call}'
+                        break
+                if not ok:
+                    break
+            torch.cuda.synchronize()
+            self.check()
+        except _lib.TonicHipError as error:
+            ok, why = False, str(error)
+        if ok:
+            _lib.check(self.lib.tonic_comm_set_timeout(self.handle, 0.0), 'set_timeout')
+        return ok, why
 
     def all_reduce(self, tensor):
         _lib = self._lib_module

@@ -766,6 +766,7 @@ class PPO(A2C):
         """Enqueues one whole learner update on the current stream (no host sync)."""
         self.settle()
         replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
+        critic.max_workgroups = self._critic_width()
         values, next_values = self._evaluate()
         replay.compute_returns(values, next_values)
         updates = replay.updates_per_get()
@@ -861,15 +862,27 @@ class PPO(A2C):
         record, and a few to spare)."""
         if self.OVERLAP_BLOCKS is not None:
             return int(self.OVERLAP_BLOCKS)
-        return 256 - self._collect_workgroups() - 16
+        return min(256, max(8, 256 - self._collect_workgroups() - 16))
+
+    def _critic_width(self):
+        """`max_workgroups` of the critic's grad launches in this update: what they get under a
+        rollout whenever the configuration is one whose critic MAY run there — whether or not it
+        does (TONIC_AMD_CRITIC_OVERLAP) — so that the switch moves the critic's iterations in time
+        and changes no bit of what they compute; the kernel's own width otherwise."""
+        return self._critic_blocks() if self._overlap_eligible() else 0
 
     def _collect_workgroups(self):
         workers = getattr(self.replay, 'num_workers', None) or 0
         return (workers + 15) // 16 + 5
 
     def _overlap(self):
-        return (os.environ.get('TONIC_AMD_CRITIC_OVERLAP', '1') != '0'
-                and self.replay.batch_size is None and not parallel.exchanging()
+        return os.environ.get('TONIC_AMD_CRITIC_OVERLAP', '1') != '0' and self._overlap_eligible()
+
+    def _overlap_eligible(self):
+        """Everything but the switch: the updates of such a configuration give the critic's launches
+        the width they have under a rollout (`_critic_blocks`) whether or not they run there, so the
+        switch changes WHEN the critic's iterations run and not one bit of what they compute."""
+        return (self.replay.batch_size is None and not parallel.exchanging()
                 and not self.actor_updater.stock and not self.critic_updater.stock
                 and self.observation_size <= 32 and self.action_size <= 8
                 and getattr(self, '_collector', None) is not None
@@ -932,6 +945,7 @@ class PPO(A2C):
             return
         self.settle()
         replay, actor, critic = self.replay, self.actor_updater, self.critic_updater
+        critic.max_workgroups = self._critic_width()
         values, next_values = self._evaluate()
         replay.compute_returns(values, next_values)
         updates = replay.updates_per_get()
@@ -954,16 +968,12 @@ class PPO(A2C):
             logger.before_dump(self, 'settle')
         side = self._critic_stream
         side.wait_event(ready)
-        _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', self._critic_blocks()), 'tonic_set_tuning')
-        try:
-            with torch.cuda.stream(side):
-                for it in range(updates):
-                    critic.enqueue_grad(obs, returns, norm=snapshot)
-                    critic.enqueue_step(n, infos[1, it])
-                done = torch.cuda.Event()
-                done.record(side)
-        finally:
-            _lib.check(self.lib.tonic_set_tuning(b'grad_blocks', 256), 'tonic_set_tuning')
+        with torch.cuda.stream(side):
+            for it in range(updates):
+                critic.enqueue_grad(obs, returns, norm=snapshot)
+                critic.enqueue_step(n, infos[1, it])
+            done = torch.cuda.Event()
+            done.record(side)
         self._critic_pending = (done, infos, (obs, returns, snapshot))
         rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
         parallel.check_one_shot()
@@ -1227,6 +1237,14 @@ class DDPG(Agent):
             # floats: [iteration, {critic, actor}, {step_size, bias_correction2_sqrt}]
             table = np.zeros((iterations, 2, 2), np.float32)
             critic, actor = self.critic_updater, self.actor_updater
+            if not getattr(self, '_step_mirror_valid', False):
+                # the host mirrors of the device's step counters are only kept by THIS path: after
+                # an update on the split entry points (whose captured graphs step the device counter
+                # on every replay), an exception on the way to the launches or a skipped step, the
+                # counters on the device are the authority (one read-back, then none again)
+                critic.steps_enqueued = int(critic.state[0])
+                actor.steps_enqueued = int(actor.state[0])
+            self._step_mirror_valid = False          # until this update's launches are out
             for it in range(iterations):
                 critic.steps_enqueued += 1
                 table[it, 0] = updaters.adam_step_constants(critic.hyper, critic.steps_enqueued)
@@ -1271,6 +1289,7 @@ class DDPG(Agent):
         stock = self.critic_updater.stock or self.actor_updater.stock    # (autograd: no capture)
         if not graph or stock or parallel.exchanging():      # collectives sit between the kernels
             enqueue()
+            self._step_mirror_valid = fused is not None
             return self._infos
         if self._graph is None:
             batch_size = indices.shape[1]
@@ -1284,6 +1303,7 @@ class DDPG(Agent):
             with torch.cuda.graph(self._graph):
                 enqueue()
         self._graph.replay()
+        self._step_mirror_valid = fused is not None
         return self._infos
 
     def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
@@ -1383,6 +1403,11 @@ class DDPG(Agent):
         eps = self._draw_noise(indices.shape[0])
         infos = self.enqueue_update(indices, eps).cpu().numpy()
         parallel.check_one_shot()
+        try:
+            _check_chain(infos)
+        except _lib.TonicHipError:
+            self._step_mirror_valid = False          # skipped steps: the device's counters decide
+            raise
         replay.last_steps = steps
         twin = hasattr(self.model, 'critic_2')
         for row in infos[0]:
@@ -1397,6 +1422,20 @@ class DDPG(Agent):
         self.last_infos = infos
         if self.model.observation_normalizer:
             self.model.observation_normalizer.update()
+
+
+def _check_chain(infos):
+    """A chained launch whose workgroups waited 250 ms for a value of a peer that never came (a GPU
+    shared with something that starves the launch, a lost workgroup) does not hang and does not step:
+    the iteration's optimizer epilogues wrote nothing and marked their statistic rows (slot 7).  The
+    parameters are intact; the update is incomplete, which is an error and not a log line."""
+    gave_up = np.argwhere(infos[..., 7] > 0)
+    if len(gave_up):
+        raise _lib.TonicHipError(
+            f'{len(gave_up)} optimizer steps of this update were skipped: a chained launch gave up '
+            f'waiting for a peer workgroup (first: updater {gave_up[0][0]}, iteration '
+            f'{gave_up[0][1]}); parameters, moments and targets are those of the last complete '
+            'iteration (TONIC_AMD_TUNING=q_chain=0 runs one launch per pass)')
 
 
 def _d4pg_model():

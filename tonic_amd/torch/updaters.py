@@ -101,6 +101,12 @@ class _FlatUpdater(_StockTorch):
         self.gradient_clip = float(getattr(self, 'gradient_clip', 0) or 0)
         self.clip_workspace = torch.zeros(self.lib.tonic_clip_workspace_bytes(self.count),
                                           dtype=torch.uint8, device=device)
+        # Workgroups of the fused grad launches (0 = the kernel's own width).  Part of the
+        # updater's configuration, not of a call: the grouping of the float32 partial sums follows
+        # it, so results are reproducible as long as it stays what it is (agents.PPO sets the
+        # critic's once, from the worker count — whether or not its iterations then run under
+        # the next rollout).
+        self.max_workgroups = 0
         self.world_size = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world_size = torch.distributed.get_world_size()
@@ -290,8 +296,8 @@ class ClippedRatio(_FlatUpdater):
         _lib.check(self.lib.tonic_ppo_actor_grad(
             p(self.flat.flat), p(observations), p(actions), p(advantages), p(adv_stats),
             p(log_probs), p(self.grad_sums), n, self.observation_size, self.action_size,
-            float(self.ratio_clip), float(self.entropy_coeff), self.stop_flag_ptr(), p(ws),
-            ws.numel(), _lib.current_stream()), 'tonic_ppo_actor_grad')
+            float(self.ratio_clip), float(self.entropy_coeff), self.stop_flag_ptr(),
+            self.max_workgroups, p(ws), ws.numel(), _lib.current_stream()), 'tonic_ppo_actor_grad')
 
     def enqueue_step(self, n_local, adv_stats, info_row, allreduce=True):
         if self.stock:
@@ -537,7 +543,7 @@ class VRegression(_FlatUpdater):
         p = _lib.ptr
         _lib.check(self.lib.tonic_value_regression_grad(
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(returns),
-            p(self.grad_sums), n, self.observation_size, p(ws), ws.numel(),
+            p(self.grad_sums), n, self.observation_size, self.max_workgroups, p(ws), ws.numel(),
             _lib.current_stream()),
             'tonic_value_regression_grad')
 
