@@ -507,6 +507,9 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
     O, A, W, T = 17, 6, 256, 1024
 
     def run(overlap):
+        import gc
+        gc.collect()                    # (agents of earlier tests: their close() synchronises the device)
+        torch.cuda.synchronize()
         monkeypatch.setenv('TONIC_AMD_CRITIC_OVERLAP', '1' if overlap else '0')
         env = environments.SyntheticBatch(W, O, A, max_episode_steps=1000, pool=5)
         env.initialize(seed=3)
@@ -534,17 +537,28 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
         agent.close()
         return first, rows, state, in_flight, widths
 
-    first_a, rows_a, state_a, in_flight, widths_a = run(True)
     first_b, rows_b, state_b, none, widths_b = run(False)
-    assert widths_a == widths_b == [256 - (W // 16 + 5) - 16] * 2
-    assert in_flight >= 1 and none == 0, 'the chain must actually have run under the rollout'
-    assert np.isfinite(rows_a).all() and (rows_a[1, :, 0] > 0).all()
-    # the first update: ten iterations the judge can read (critic loss / v), and all the others
-    assert np.array_equal(first_a[1, :10, :2], first_b[1, :10, :2])
-    assert np.array_equal(first_a, first_b)
-    assert np.array_equal(rows_a, rows_b)
-    for key in state_a:
-        assert torch.equal(state_a[key], state_b[key]), key
+    assert none == 0 and widths_b == [256 - (W // 16 + 5) - 16] * 2
+    seen = []
+    for attempt in range(3):
+        # EVERY overlapped run must give the interleaved run's bits; at least one of (at most) three
+        # must have had the host's polls find the chain still running under the rollout's steps
+        # (whether a poll falls inside the chain's ~6 ms depends on what else this process is doing:
+        # informative per run, required once)
+        first_a, rows_a, state_a, in_flight, widths_a = run(True)
+        seen.append(in_flight)
+        assert widths_a == widths_b
+        assert np.isfinite(rows_a).all() and (rows_a[1, :, 0] > 0).all()
+        # the first update: ten iterations a reader can check by eye (critic loss / v), then all rows
+        assert np.array_equal(first_a[1, :10, :2], first_b[1, :10, :2])
+        assert np.array_equal(first_a, first_b)
+        assert np.array_equal(rows_a, rows_b)
+        for key in state_a:
+            assert torch.equal(state_a[key], state_b[key]), key
+        if in_flight >= 1:
+            break
+    print('sampled steps that found the critic chain running:', seen)
+    assert max(seen) >= 1, 'the chain must actually have run under a rollout'
 
 
 def test_completion_words_order_the_actions(lib):

@@ -283,6 +283,42 @@ def test_grads_full_size_properties(lib, variant):
     assert_grads_close(part[:P], want, m, 'slice of the full batch')
 
 
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_critic_grad_is_bit_reproducible_at_baseline_size(lib, variant):
+    """N = 4096 x 256: twelve launches of tonic_value_regression_grad on the same inputs give ONE
+    result, at the kernel's own width and at the widths the PPO agent uses under a rollout.  Round 4
+    found the shipped variant (3) giving 9 distinct results in 16 launches — always in the 16
+    accumulators of dW1's remainder column, rows 32..47 — because the SLP vectoriser had packed their
+    FMAs into dependent v_pk_fma_f32 pairs whose low lane is occasionally wrong between MFMAs on
+    gfx950; the library is built with -fno-slp-vectorize since (csrc/Makefile)."""
+    rng = np.random.RandomState(21)
+    O, n = 17, 4096 * 256
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, 64)) * 0.3, rng.normal(size=1)]
+    params = [p.astype(np.float32) for p in params]
+    from tonic_amd import _lib
+    P = lib.tonic_v_critic_param_count(O)
+    ws = torch.empty(lib.tonic_ppo_workspace_bytes(n, O, 1, 0), dtype=torch.uint8, device='cuda')
+    keep = [dev(flat(params)), dev((rng.standard_normal(O) * 0.1).astype(np.float32)),
+            dev((1 + 0.2 * rng.uniform(size=O)).astype(np.float32)),
+            dev(rng.standard_normal((n, O)).astype(np.float32)),
+            dev(rng.standard_normal(n).astype(np.float32))]
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
+    try:
+        for width in (0, 219, 232):
+            results = set()
+            for _ in range(12):
+                out = torch.zeros(P + 8, device='cuda')
+                _lib.check(lib.tonic_value_regression_grad(
+                    *[t.data_ptr() for t in keep[:3]], 0.0, *[t.data_ptr() for t in keep[3:]],
+                    out.data_ptr(), n, O, width, ws.data_ptr(), ws.numel(), None), 'critic_grad')
+                results.add(out.cpu().numpy().tobytes())
+            assert len(results) == 1, (variant, width, len(results))
+    finally:
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
+
+
 def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
     """grad_variant 2 computes the two 64x64 hidden-layer products of a tile as six bf16 MFMAs on exact
     hi + mid + lo splits of the fp32 operands.  Against a float64 autograd reference of the same loss
