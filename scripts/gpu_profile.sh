@@ -9,5 +9,6 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o
 find /tmp/prof -type f | head -20
 STATS=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 cp "$STATS" $REPO/gpurun_out/prof_kernel_stats.csv
-head -30 "$STATS"
+gzip -c $(find /tmp/prof -name "*kernel_trace.csv" | head -1) > $REPO/gpurun_out/prof_kernel_trace.csv.gz
+head -12 "$STATS"
 tail -2 $REPO/gpurun_out/bench_prof.log | cut -c1-600

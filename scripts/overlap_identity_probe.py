@@ -25,18 +25,20 @@ def run(overlap, sleeps=True):
     agent.initialize(env.observation_space, env.action_space, seed=9)
     observations = env.start()
     in_flight, first, trace = 0, None, []
-    for t in range(2 * T + 40):
+    for t in range(3 * T + 40):
         actions = agent.step(observations, t * W)
-        if t in (0, T - 1, T, T + 1, 2 * T - 1):
+        if t in (0, T - 1, T, T + 1, 2 * T - 1, 2 * T, 3 * T - 1, 3 * T + 5):
             trace.append(actions.copy())
         observations, infos = env.step(actions)
-        if T <= t < T + 30 or 2 * T <= t < 2 * T + 30:
+        if t >= T and t % 16 == 0:
             pending = getattr(agent, '_critic_pending', None)
-            in_flight += pending is not None and not pending[0].query()
+            in_flight += (pending is not None and pending['done'] is not None
+                          and not pending['done'].query())
+        if T <= t < T + 30 or 2 * T <= t < 2 * T + 30:
             if sleeps:
                 time.sleep(0.0003)
         agent.update(**infos, steps=t * W)
-        if t == T + 35:
+        if t == 2 * T - 2:
             first = np.array(agent.last_infos)
     torch.cuda.synchronize()
     rows = np.array(agent.last_infos)

@@ -496,8 +496,10 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
     simulator time each, so that the resident collect kernel parks and is launched again under the
     chain).  The critic's launches have the same width in both modes (`PPO._critic_width`: 219 of
     256 workgroups at 256 workers), so the comparison with the interleaved launches
-    (TONIC_AMD_CRITIC_OVERLAP=0) is BIT FOR BIT — every logged row of the last update (80 actor
-    rows, 80 critic rows), every parameter and the normaliser after two rollouts + updates.  A race
+    (TONIC_AMD_CRITIC_OVERLAP=0) is BIT FOR BIT — every logged row of the first and the last update
+    (80 actor rows, 80 critic rows each), every parameter and the normaliser after three rollouts +
+    updates.  (From the second update on the chain goes out LATE in the rollout, so that it ends a
+    margin before the rollout does: PPO._critic_start_row.)  A race
     on the spare observation buffer, the normaliser snapshot or the Segment cannot hide behind a
     tolerance here."""
     import time
@@ -517,18 +519,20 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
         agent.initialize(env.observation_space, env.action_space, seed=9)
         observations = env.start()
         in_flight, widths, first = 0, [], None
-        for t in range(2 * T + 40):
+        for t in range(3 * T + 40):
             actions = agent.step(observations, t * W)
             observations, infos = env.step(actions)
+            if t >= T and t % 16 == 0:                          # somewhere under a rollout
+                pending = getattr(agent, '_critic_pending', None)
+                in_flight += (pending is not None and pending['done'] is not None
+                              and not pending['done'].query())
             if T <= t < T + 30 or 2 * T <= t < 2 * T + 30:      # right behind an update
-                in_flight += getattr(agent, '_critic_pending', None) is not None \
-                    and not agent._critic_pending[0].query()
                 time.sleep(0.0003)
             agent.update(**infos, steps=t * W)
             if t == T - 1:
                 widths.append(agent.critic_updater.max_workgroups)
-            if t == T + 35:                                      # well inside the second rollout
-                first = np.array(agent.last_infos)              # (settles: the first update's rows)
+            if t == 2 * T - 2:                                   # the end of the second rollout
+                first = np.array(agent.last_infos)              # (the first update's rows; settled long ago)
         torch.cuda.synchronize()
         rows = np.array(agent.last_infos)
         state = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}

@@ -913,9 +913,9 @@ class PPO(A2C):
         if pending is None:
             return
         self._critic_pending = None
-        done, infos, _ = pending
-        torch.cuda.current_stream().wait_event(done)     # whoever reads the critic next is behind it
-        rows = infos[1].cpu().numpy()
+        torch.cuda.current_stream().wait_event(pending['done'])   # whoever reads the critic next is behind it
+        rows = pending['infos'][1].cpu().numpy()
+        self.critic_chain_ms = pending['clock'].elapsed_time(pending['done'])    # (bench.py reports it)
         log_ppo_critic_rows(rows)
         logger.store('critic/iterations', len(rows))
         if getattr(self, '_last_infos', None) is not None:
@@ -966,15 +966,22 @@ class PPO(A2C):
         if getattr(self, '_critic_stream', None) is None:
             self._critic_stream = torch.cuda.Stream()
             logger.before_dump(self, 'settle')
+            self._guard_critic_readers()
         side = self._critic_stream
         side.wait_event(ready)
+        clock, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(side):
+            clock.record(side)
             for it in range(updates):
                 critic.enqueue_grad(obs, returns, norm=snapshot)
                 critic.enqueue_step(n, infos[1, it])
-            done = torch.cuda.Event()
             done.record(side)
-        self._critic_pending = (done, infos, (obs, returns, snapshot))
+        # (Enqueued HERE, while the GPU is busy with the actor's chain and the host has nothing else
+        #  to do.  Round 4 also tried it late — from agent.update at the Segment row from which the
+        #  chain just finishes before the rollout does, so that the next update's first launches find
+        #  the chip at its working clock (profiles/r04_clock_ramp.md): the 160 enqueues then sit on the
+        #  host-bound collect loop's critical path, 82.3 against 80.9 ms per step.)
+        self._critic_pending = dict(done=done, clock=clock, infos=infos, keep=(obs, returns, snapshot))
         rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
         parallel.check_one_shot()
         logger.store('actor/iterations', log_ppo_actor_rows(rows))
@@ -984,9 +991,10 @@ class PPO(A2C):
         # What the next rollout depends on — the actor, the normaliser — is on the current stream up
         # to here: a stream of its own carries that point to the collector (step() -> begin_rollout),
         # which also moves the rollout's observations to the spare buffer.  Everything ELSE that
-        # follows on the current stream waits for the critic's iterations as well, so whoever reads
-        # the critic's parameters after update() returned — state_dict(), a checkpoint, another
-        # forward pass — reads them final, as after the reference's update.
+        # follows on the current stream waits for the critic's iterations as well, and whoever reads
+        # the critic through torch — state_dict(), a checkpoint, a forward pass of the module — goes
+        # through settle() first (_guard_critic_readers), so the critic is read final, as after the
+        # reference's update.
         if getattr(self, '_rollout_marker', None) is None:
             self._rollout_marker = torch.cuda.Stream()
         ordered = torch.cuda.Event()
@@ -994,6 +1002,14 @@ class PPO(A2C):
         self._rollout_marker.wait_event(ordered)
         self._rollout_behind = self._rollout_marker
         torch.cuda.current_stream().wait_event(done)
+
+    def _guard_critic_readers(self):
+        """Whoever reads the critic through torch — a forward pass of the module, state_dict() —
+        finds it final: both settle first (the package's own readers call settle() themselves)."""
+        def before(*args, **kwargs):
+            self.settle()
+        self.model.critic.register_forward_pre_hook(before)
+        self.model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.settle())
 
 
 def log_ppo_update(infos):
