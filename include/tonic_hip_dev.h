@@ -25,6 +25,9 @@ extern "C" {
  *                          = 2 with the 64x64 weight-gradient product dW2 on bf16x3 terms as well;
  *                          -1 restores the default;
  *   "grad_skew" = 0..64    start delay of half of the waves of variant 1 (experiment, default 0);
+ *   "chain_fault" = 1      the NEXT chained critic step loses its first workgroup (test hook);
+ *   "q_chain" = 0 | 1      off-policy iteration as chained launches (1, default) or one launch per pass;
+ *   "gae_stream" = 0..4    which bit-exact GAE kernel serves small W (developer probe);
  *   "policy_tail" = 0 | 1  off-policy actors: sampling / target noise / dense copy in the tail of
  *                          the forward launch (1, default) or in their own launches (0); same bits. */
 int tonic_set_tuning(const char* key, int32_t value);
@@ -52,6 +55,12 @@ int tonic_gemm_f32(const char* mode, const float* d_a, const float* d_b, float* 
                    const float* d_bias, const float* d_mask, float* d_colsum, int32_t M,
                    int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t act,
                    int32_t accumulate, double alpha, void* stream);
+
+/* Test tool: `workgroups` workgroups that each hold a compute unit to themselves (100 KB of LDS:
+ * neither a collect nor a grad workgroup fits beside one) and spin for `milliseconds` of the
+ * 100 MHz wall clock — a foreign kernel that occupies part of the chip, for the tests of what the
+ * resident collect kernel does when not all of its workgroups find a compute unit. */
+int tonic_debug_occupy(int32_t workgroups, double milliseconds, void* stream);
 
 #ifdef __cplusplus
 }

@@ -442,7 +442,8 @@ def test_step_issued_by_the_environment_is_bit_identical(lib, monkeypatch, kind)
         assert torch.equal(state_a[key], state_b[key]), key
 
 
-def test_critic_iterations_under_the_next_rollout_are_bit_identical(lib, monkeypatch):
+@pytest.mark.parametrize('O,A,W,T', [(17, 6, 32, 24), (28, 8, 1280, 40)])
+def test_critic_iterations_under_the_next_rollout_are_bit_identical(lib, monkeypatch, O, A, W, T):
     """On one GPU with full-batch iterations `PPO.update` runs the actor's iterations, leaves the
     critic's to a second stream behind them and returns; they run while the next rollout is
     collected (into a spare observation buffer, with a snapshot of the normaliser).  Three rollouts
@@ -452,7 +453,6 @@ def test_critic_iterations_under_the_next_rollout_are_bit_identical(lib, monkeyp
     import tonic_amd
     import tonic_amd.torch
     from tonic_amd import environments
-    O, A, W, T = 17, 6, 32, 24
 
     def run(overlap):
         monkeypatch.setenv('TONIC_AMD_CRITIC_OVERLAP', '1' if overlap else '0')
@@ -622,6 +622,68 @@ def test_resident_kernel_parks_and_resumes(lib):
         results[transport] = {k: v.cpu().numpy() for k, v in seg.items()}
         results[transport]['sums'] = sums.cpu().numpy()
         collector.close()
+    for key, want in results[0].items():
+        assert np.array_equal(results[2][key], want), key
+
+
+@pytest.mark.parametrize('O,A,W,T,hog,hog_ms', [
+    (28, 8, 1280, 10, 250, 60.0),     # 85 slots, 6 compute units: the whole rollout under the foreign kernel
+    (28, 8, 1280, 160, 250, 4.0),     # ... which leaves in the middle: the late workgroups join
+    (17, 6, 256, 300, 253, 3.0),      # 21 slots, 3 compute units, then everybody
+    (3, 1, 5, 40, 255, 5.0)])         # 6 slots on ONE compute unit
+def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, O, A, W, T, hog, hog_ms):
+    """The resident collect kernel next to a FOREIGN kernel that holds most of the chip before the
+    first command (tonic_debug_occupy: `hog` workgroups of 100 KB LDS, one per compute unit): only
+    some of the launch's workgroups find a compute unit, the others get in when the foreign kernel
+    ends — or never during the rollout.  Every step still completes (the workgroups that are there
+    run the slots of those that are not, claim by claim; a late workgroup joins and skips what was
+    run for it) and the Segment, the normaliser sums and the actions are those of the undisturbed
+    launch-per-step transport, bit for bit."""
+    import time
+    from tonic_amd import _lib
+    from tonic_amd.collector import Block, Collector
+    rng = np.random.RandomState(O + W)
+    params = _actor(O, A, 3)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in params])).cuda()
+    obs = rng.standard_normal((T + 1, W, O)).astype(np.float32)
+    eps = rng.standard_normal((T, W, A)).astype(np.float32)
+    rewards = rng.standard_normal((T, W)).astype(np.float32)
+    resets = (rng.uniform(size=(T, W)) < 0.05).astype(np.float32)
+    results, under = {}, None
+    side = torch.cuda.Stream()
+    for transport in (0, 2):
+        block = Block(W, O, A)
+        collector = Collector(block, transport)
+        seg = _segment(T, W, O, A)
+        sums = torch.zeros(2 * O, device='cuda')
+        collector.bind_segment(seg, sums, T)
+        torch.cuda.synchronize()
+        gone = torch.cuda.Event()
+        if transport == 2:
+            _lib.check(lib.tonic_debug_occupy(hog, hog_ms, side.cuda_stream), 'occupy')
+            gone.record(side)
+            time.sleep(0.001)                      # (the foreign kernel is in before the first command)
+        collector.begin_rollout(flat)
+        actions = []
+        for t in range(T):
+            block.observations[:] = obs[t]
+            block.eps[t & 1][:] = eps[t]
+            collector.ppo_step(t, t & 1, t > 0)
+            collector.wait_actions()
+            actions.append(block.actions.copy())
+            block.next_observations[:] = obs[t + 1]
+            block.rewards[:] = rewards[t]
+            block.resets[:] = resets[t]
+            block.terminations[:] = 0
+            if transport == 2 and t == min(T, 10) - 1:
+                under = not gone.query()           # ten steps done and the foreign kernel still there
+        collector.end_rollout(T - 1)
+        torch.cuda.synchronize()
+        results[transport] = {k: v.cpu().numpy() for k, v in seg.items()}
+        results[transport]['sums'] = sums.cpu().numpy()
+        results[transport]['block_actions'] = np.stack(actions)
+        collector.close()
+    assert under, 'the first steps must have completed while the foreign kernel held the chip'
     for key, want in results[0].items():
         assert np.array_equal(results[2][key], want), key
 

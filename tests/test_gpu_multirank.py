@@ -95,6 +95,40 @@ def test_buffer_get_yields_each_ranks_part_of_the_global_batch(tmp_path):
         assert empty > 0, 'the case of a rank drawing nothing must be exercised'
 
 
+LOOP_WORKER = os.path.join(ROOT, 'tests', 'mp_ppo_loop_worker.py')
+
+
+@pytest.mark.parametrize('exchange', ['rccl', 'oneshot'])
+def test_two_ranks_keep_the_critic_under_the_next_rollout(tmp_path, exchange):
+    """World size 2, host in the loop: the actor's iterations and THEIR all-reduces on the current
+    stream, the critic's iterations and theirs on the second stream under the next rollout
+    (agents.PPO._update) — the schedule of the 2 / 4 / 8-GPU points of the headline metric.  Against
+    the same job with TONIC_AMD_CRITIC_OVERLAP=0 (the joint exchange of both networks' sums per
+    iteration, everything on one stream): three rollouts + updates leave the same bits on both ranks
+    — parameters, normaliser, every logged row (a two-rank sum does not depend on the order, and the
+    critic's launches have the same width in both modes) — through the process group and through
+    tonic_allreduce_f32."""
+    outs = {}
+    for overlap in ('1', '0'):
+        outs[overlap] = str(tmp_path / f'loop{overlap}')
+        launch(2, outs[overlap], 29760 + int(overlap) + (10 if exchange == 'oneshot' else 0),
+               command=(LOOP_WORKER,),
+               extra_env={'TONIC_AMD_CRITIC_OVERLAP': overlap, 'TONIC_AMD_ALLREDUCE': exchange})
+    for rank in (0, 1):
+        a = np.load(outs['1'] + f'.rank{rank}.npz')
+        b = np.load(outs['0'] + f'.rank{rank}.npz')
+        assert int(a['overlapped'][0]) == 3 and int(b['overlapped'][0]) == 0
+        assert str(a['exchange']) == exchange
+        for key in a.files:
+            if key in ('overlapped', 'exchange'):
+                continue
+            assert np.array_equal(a[key], b[key]), (rank, key)
+    first, second = (np.load(outs['1'] + f'.rank{r}.npz') for r in (0, 1))
+    for key in first.files:                                  # replicas: identical across the ranks
+        if key not in ('overlapped', 'exchange') and 'normalizer' not in key:
+            assert np.array_equal(first[key], second[key]), key
+
+
 ALLREDUCE_WORKER = os.path.join(ROOT, 'tests', 'mp_allreduce_worker.py')
 
 
@@ -218,6 +252,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     result = _bench('--gpus', '2', '--steps', '1', '--warmup', '1')
     assert result['n_gpus'] == 2 and result['scaling'] == 'weak'
     assert result['ranks_hold_identical_parameters'] is True
+    assert result['config']['critic_under_next_rollout'] is True        # also with two ranks
     assert result['config']['global_workers'] == 512
     assert 'allreduce_us' in result and result['allreduce_us']['process_group_us'] > 0
     strong = result['strong_scaling']

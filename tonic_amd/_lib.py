@@ -144,6 +144,7 @@ SIGNATURES = {
     'tonic_comm_destroy': (ctypes.c_int, [c_vp]),
     'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_debug_forward_stamps': (ctypes.c_int, [c_vp]),
+    'tonic_debug_occupy': (ctypes.c_int, [c_i32, c_f64, c_vp]),
     'tonic_gemm_f32': (ctypes.c_int, [ctypes.c_char_p] + [c_vp] * 6 + [c_i32] * 8 + [c_f64, c_vp]),
 }
 

@@ -65,10 +65,10 @@ struct Collect16Args {
 // What the resident form of the collect kernel needs besides the per-step arguments.
 struct CollectResident {
   const unsigned long long* command;   // pinned host memory: the host's next command word
-  unsigned* relay;                     // device memory, zero at launch: the leader's park notice
-  int poll_depth;                      // 1, 2 or 4 polls of the command word in flight per workgroup
-  int poll_sleep;                      // pause between two rounds of polls, units of ~0.25 us
-  unsigned* parked;                    // pinned host memory: sequence number the leader parked at
+  unsigned* relay;                     // device memory, zero at launch: the park notice among the workgroups
+  unsigned* claims;                    // device memory, zero at launch: [slot] = newest command claimed for it
+  int poll_sleep;                      // pause between two polls, units of ~0.25 us
+  unsigned* parked;                    // pinned host memory: the command the kernel was waiting for when it parked
   const float* eps0; const float* eps1;
   unsigned first_seq;
   unsigned long long park_ticks;       // 100 MHz ticks without a command before parking

@@ -36,6 +36,9 @@ namespace {
 constexpr uint32_t kBlockMagic = 0x544f4e43u;        // "TONC"
 constexpr int64_t kHeaderBytes = 4096;
 constexpr int kFields = TONIC_COLLECTOR_FIELD_COUNT;
+// transport 2, device memory zeroed at every launch of the resident kernel: the park notice (a
+// 256-byte line of its own) and one claim word per workgroup slot (<= 4096 tiles + copy + record)
+constexpr size_t kRelayBytes = 256 + 4 * (4096 + 8);
 
 struct BlockHeader {
   uint32_t magic, version;
@@ -424,7 +427,7 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   const int64_t packed = PackedActor(collect16_ks1(c->O), collect16_ap(c->A)).total;
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_packed), packed * 4)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->staged), (size_t)h->total_bytes)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), 256)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->d_relay), kRelayBytes)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_done), 4096 * 4)) != hipSuccess ||
       (e = hipMemset(c->d_tile_done, 0, 4096 * 4)) != hipSuccess)
     return fail("hipMalloc of the collector scratch", e);
@@ -560,19 +563,18 @@ Collect16Args step_arguments(tonic_collector* c) {
 
 // transport 2: (re)starts the resident kernel; it waits for command number `first_seq`.
 int launch_resident(tonic_collector* c, unsigned first_seq) {
-  TONIC_HIP(hipMemsetAsync(c->d_relay, 0, 16, c->stream), "hipMemsetAsync");
+  TONIC_HIP(hipMemsetAsync(c->d_relay, 0, kRelayBytes, c->stream), "hipMemsetAsync");
   CollectResident r{};
   r.command = reinterpret_cast<const unsigned long long*>(c->mapped + offsetof(BlockHeader, command));
   r.relay = c->d_relay;
+  r.claims = c->d_relay + 64;                     // (the park notice has a 256-byte line of its own)
   r.parked = reinterpret_cast<unsigned*>(c->mapped + offsetof(BlockHeader, parked));
   r.eps0 = field(c, TONIC_COLLECTOR_EPS0);
   r.eps1 = field(c, TONIC_COLLECTOR_EPS1);
   r.first_seq = first_seq;
   r.park_ticks = (unsigned long long)(c->park_us * 100.0);        // 100 MHz wall clock
-  const char* polls = getenv("TONIC_AMD_COLLECTOR_POLLS");
   const char* pause = getenv("TONIC_AMD_COLLECTOR_POLL_SLEEP");
   r.poll_sleep = pause != nullptr ? atoi(pause) : 1;
-  r.poll_depth = polls != nullptr && atoi(polls) >= 4 ? 4 : polls != nullptr && atoi(polls) >= 2 ? 2 : 1;
   const int status = launch_collect_resident(step_arguments(c), r, c->stream);
   if (status == TONIC_OK) c->live = true;
   return status;
@@ -793,3 +795,32 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
   c->actor_packed = false;            // the learner is about to change the parameters
   return TONIC_OK;
 }
+
+// ---- test tool (include/tonic_hip_dev.h)
+namespace {
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks) {
+  extern __shared__ float held[];
+  const unsigned long long t0 = wall_clock64();
+  if (threadIdx.x == 0) held[0] = 0.f;
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+
+extern "C" int tonic_debug_occupy(int32_t workgroups, double milliseconds, void* stream) {
+  TONIC_REQUIRE(workgroups >= 1 && workgroups <= 4096 && milliseconds > 0.0 && milliseconds <= 2000.0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_debug_occupy: %d workgroups for %.1f ms",
+                workgroups, milliseconds);
+  constexpr int kBytes = 100 * 1024;
+  static bool configured = false;
+  if (!configured) {
+    TONIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBytes),
+              "hipFuncSetAttribute");
+    configured = true;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), kBytes, as_stream(stream),
+                     (unsigned long long)(milliseconds * 1e5));
+  TONIC_CHECK_LAUNCH("tonic_debug_occupy");
+  return TONIC_OK;
+}
+

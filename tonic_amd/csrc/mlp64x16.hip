@@ -890,20 +890,20 @@ __device__ __forceinline__ void retire_touches(float sink, float* never_written)
 // from the pinned block have returned (s_waitcnt vmcnt(0)) and — actor role — its actions have
 // been released to the system (the fence above).  No cross-workgroup counter: a last-arriver
 // protocol costs every workgroup a system-scope fence and an atomic round trip.
-__device__ __forceinline__ void collect_signal_done(const Collect16Args& c) {
+__device__ __forceinline__ void collect_signal_done(const Collect16Args& c, int vb) {
   if (c.done_flags == nullptr) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's loads / stores are done
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_store(c.done_flags + blockIdx.x, c.done_seq, __ATOMIC_RELAXED,
+    __hip_atomic_store(c.done_flags + vb, c.done_seq, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Actor role, many workers: this workgroup's rows of the Segment's observation row are released
 // (the system-scope release in front of the completion word wrote them back) — tell the record role.
-__device__ __forceinline__ void collect_signal_rows(const Collect16Args& c) {
+__device__ __forceinline__ void collect_signal_rows(const Collect16Args& c, int vb) {
   if (c.tile_done != nullptr && threadIdx.x == 0)
-    __hip_atomic_store(c.tile_done + blockIdx.x, c.done_seq, __ATOMIC_RELAXED,
+    __hip_atomic_store(c.tile_done + vb, c.done_seq, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -986,18 +986,21 @@ __device__ __forceinline__ void wide_copy(const float* src, float* dst, float* l
 
 // HOST: the step inputs (observations, noise, previous outcome) live in pinned host memory that
 // the kernel reads in place over PCIe (pinned-host collector, transport 0).
+// `vb` of `nb`: the workgroup SLOT whose work this is — the launching grid's own index and size for
+// the one-launch-per-step forms; the resident form also runs the slots of workgroups that are not
+// there (yet).
 template <int KS1, int AP, bool HOST, bool SYS>
-__device__ __forceinline__ void collect16_step(const Collect16Args& c, float* tile) {
+__device__ __forceinline__ void collect16_step(const Collect16Args& c, float* tile, int vb, int nb) {
   const int64_t W = c.W;
   const int O = c.O, A = c.A;
   const int tid = threadIdx.x;
   // Workgroup roles: [0, act_blocks) actor tiles | kCollectCopyBlocks outcome-copy blocks | one
   // MeanStd.record block.  The three run side by side on different CUs, so a step costs the
   // longest of {actor chain, cold outcome copy, sequential record} instead of their sum.
-  const int act_blocks = (int)gridDim.x - 1 - kCollectCopyBlocks;
-  if ((int)blockIdx.x >= act_blocks && (int)blockIdx.x < act_blocks + kCollectCopyBlocks) {
+  const int act_blocks = nb - 1 - kCollectCopyBlocks;
+  if (vb >= act_blocks && vb < act_blocks + kCollectCopyBlocks) {
     // transition outcome (segments.py:27-36): next observations, rewards, resets, terminations
-    const int64_t part = (int)blockIdx.x - act_blocks, stride = 256 * kCollectCopyBlocks;
+    const int64_t part = vb - act_blocks, stride = 256 * kCollectCopyBlocks;
     float sink = 0.f;
     if (c.pf_next_obs != nullptr) {               // one touch per 64-byte line of the next step
       for (int64_t i = (part * 256 + tid) * 16; i < W * O; i += stride * 16)
@@ -1076,14 +1079,14 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     }
     retire_touches(sink, c.seg_next);
     if (part == 0) collect_stamp(c, 2, 0);           // copies issued
-    collect_signal_done(c);
+    collect_signal_done(c, vb);
     if (part == 0) collect_stamp(c, 2, 1);           // flag out
     return;
   }
-  if (blockIdx.x == gridDim.x - 1) {
+  if (vb == nb - 1) {
     // MeanStd.record (mean_stds.py:44-48): values and their squares staged side by side, the sum
     // chain on wave 0 and the sum-of-squares chain on wave 1
-    if (c.norm_acc == nullptr) { collect_signal_done(c); return; }
+    if (c.norm_acc == nullptr) { collect_signal_done(c, vb); return; }
     constexpr int kHalf = kCollectLds / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const bool from_segment = HOST && c.tile_done != nullptr;      // scalar (see Collect16Args)
@@ -1115,17 +1118,20 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       const int64_t chunks = (W + rows_per_chunk - 1) / rows_per_chunk;
       if (from_segment) {
         // every actor workgroup's rows of this step, ONE poller per word (they all finish within a
-        // microsecond or two of each other: their inputs cross PCIe together); bounded like every
-        // wait of the collector: 50 ms, then whatever is there
+        // microsecond or two of each other: their inputs cross PCIe together).  Bounded like every
+        // wait of the collector — 1 s — and a row that never came is NOT read: this slot then leaves
+        // without its completion word, which tonic_collector_wait_actions turns into
+        // TONIC_ERR_TIMEOUT (naming the word) instead of statistics built from a stale row.
         const unsigned long long t0 = wall_clock64();
+        bool never = false;
         for (int b = tid; b < act_blocks; b += 256) {
           while (__hip_atomic_load(c.tile_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
                  c.done_seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 5000000ull) break;
+            if (wall_clock64() - t0 > 100000000ull) { never = true; break; }
           }
         }
-        __syncthreads();
+        if (__syncthreads_or(never ? 1 : 0)) return;
       }
       collect_stamp(c, 1, 2);                        // (probe) the actor tiles' rows are released
       struct Set { f32x4 v[8]; float tail; };
@@ -1221,7 +1227,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     if (wave < 2 && lane < O) acc_out[wave * O + lane] = acc;
     retire_touches(sink, c.norm_acc);
     collect_stamp(c, 1, 0);                          // staged + chained
-    collect_signal_done(c);
+    collect_signal_done(c, vb);
     collect_stamp(c, 1, 1);
     return;
   }
@@ -1237,7 +1243,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
   f32x4* X1 = reinterpret_cast<f32x4*>(tile);                  // [4 tiles][64 lanes] h1 values
   float* ZP = tile + 1024;                                     // [4 waves][AP][16 samples]
   float eps_sink = 0.f;
-  for (int64_t t = blockIdx.x; t < ntiles; t += act_blocks) {
+  for (int64_t t = vb; t < ntiles; t += act_blocks) {
     const int64_t ns = t * 16 + s;
     const bool valid = ns < W;
     const int64_t nc = valid ? ns : W - 1;
@@ -1340,7 +1346,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         const unsigned at = (unsigned)(o_vecs << 2) + (unsigned)tid;
         if (at < (unsigned)o_count && SR[row_of(at)] == 0.f) carried[at] = to;
       }
-      if (blockIdx.x == 0) collect_stamp(c, 0, 0);   // inputs in LDS
+      if (vb == 0) collect_stamp(c, 0, 0);   // inputs in LDS
       const int sr = s < tile_rows ? s : tile_rows - 1;
 #pragma unroll
       for (int st = 0; st < KS1; ++st) {
@@ -1370,7 +1376,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     for (int e = 0; e < 4; ++e) h[e] = tanh_fast(acc[e]);
     X1[wave * 64 + lane] = h;
     __syncthreads();
-    if (blockIdx.x == 0) collect_stamp(c, 0, 1);     // layer 1 done (inputs arrived before)
+    if (vb == 0) collect_stamp(c, 0, 1);     // layer 1 done (inputs arrived before)
     f32x4 h1[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) h1[cc] = X1[cc * 64 + lane];
@@ -1385,7 +1391,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[e] = tanh_fast(even[e] + odd[e]);
-    if (blockIdx.x == 0) collect_stamp(c, 0, 2);     // layer 2 done
+    if (vb == 0) collect_stamp(c, 0, 2);     // layer 2 done
 #pragma unroll
     for (int aa = 0; aa < AP; ++aa) {
       float part = 0.f;
@@ -1395,7 +1401,7 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       if (g == 0) ZP[(wave * AP + aa) * 16 + s] = part;
     }
     __syncthreads();
-    if (blockIdx.x == 0) collect_stamp(c, 0, 3);     // head partials exchanged
+    if (vb == 0) collect_stamp(c, 0, 3);     // head partials exchanged
     if (wave == 0) {
       // Three straight-line stages — all LDS reads, then the AP independent head chains, then the
       // stores under ONE branch.  (Stores inside the per-action loop made every action its own
@@ -1442,118 +1448,165 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       // HOST: the actions sit in this XCD's L2 until a system-scope release writes them back;
       // only then may the completion word go out (scripts/collector_stress.py: without the
       // fence the host reads stale actions within a few thousand steps).
-      if (blockIdx.x == 0) collect_stamp(c, 0, 4);   // head, sample, stores issued
+      if (vb == 0) collect_stamp(c, 0, 4);   // head, sample, stores issued
 #if !TONIC_COLLECT_SC1
       if constexpr (HOST) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 #endif
-      if (blockIdx.x == 0) collect_stamp(c, 0, 5);   // released
+      if (vb == 0) collect_stamp(c, 0, 5);   // released
     }
     __syncthreads();                                 // X1 / ZP are reused by the next tile
   }
   retire_touches(eps_sink, c.seg_lp);
-  collect_signal_done(c);
-  collect_signal_rows(c);
-  if (blockIdx.x == 0) collect_stamp(c, 0, 6);       // flag out
+  collect_signal_done(c, vb);
+  collect_signal_rows(c, vb);
+  if (vb == 0) collect_stamp(c, 0, 6);       // flag out
 }
 
 // One launch per environment step.
 template <int KS1, int AP, bool HOST>
 __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
   __shared__ __attribute__((aligned(16))) float tile[kCollectLds];
-  collect16_step<KS1, AP, HOST, false>(c, tile);
+  collect16_step<KS1, AP, HOST, false>(c, tile, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // RESIDENT form for the pinned-host collector (transport 2): launched once per rollout, every
-// workgroup keeps its role and waits for the host's next command word instead of being launched
+// workgroup keeps its slot and waits for the host's next command word instead of being launched
 // again — the launch (3.4 us of host call + ~4 us until the first wave runs) and the cold start
 // of a fresh kernel leave the critical path of an environment step (17.7 -> ~9 us from command to
 // actions; scripts/ubench/pingpong.hip measures 5.4 us for the bare exchange of these bytes).
 //   command word (pinned host memory, written by the host with one 8-byte store):
 //     [63:32] sequence number | [31:8] Segment row | bit 3 stop | bit 2 store the previous
 //     outcome | bit 1 noise on | bit 0 noise slot
-// Thread 0 of every workgroup polls it with system-scope loads.  Nobody waits forever: after
-// `park_ticks` of the 100 MHz wall clock without a command the LEADER (the record workgroup, the
-// only role whose work is not idempotent) announces that it parks — to the other workgroups
-// through `relay` (device memory), to the host through `parked` — and exits; the host launches
-// the kernel again when it has the next command.  Workgroups that happened to see that command
-// before they saw the announcement execute it (same inputs, same outputs) and leave afterwards.
+// Thread 0 of every workgroup polls it with system-scope loads.
+//
+// Who runs a slot (round 4).  The grid has one workgroup per slot, but a slot's work does not wait
+// for ITS workgroup: on a GPU that is busy with other kernels some workgroups of the launch get a
+// compute unit late, or only when that other work ends.  Every (slot, command) is run exactly once
+// by whoever holds its claim — `claims[slot]` (device memory, zero at launch) is the newest command
+// claimed for the slot, moved with atomic max:
+//   * a workgroup that is there claims its own slot one command AHEAD, with a no-return atomic
+//     issued before it runs the current command — the host cannot issue the next command before
+//     this slot's completion word, which goes out behind that atomic — so the steady state has no
+//     atomic round trip on the step's critical path;
+//   * having run its own slot, a workgroup looks at the slots right before its own (cyclically):
+//     those whose claim is older than the command belong to workgroups that are not there; it
+//     claims and runs them in slot order (actor tiles before the copy and record slots, which wait
+//     for them) up to the first slot that is claimed.  One load of a neighbour's claim per command
+//     when everybody is there, after the completion word is out;
+//   * a workgroup that arrives late claims with a RETURNING atomic and skips what was already run
+//     for it (the host may have moved on: running a finished command again would read the block's
+//     next inputs).
+// Nobody waits forever: after `park_ticks` of the 100 MHz wall clock without a new command a
+// workgroup announces that the kernel parks — to the others through `relay` (device memory), to the
+// host through `parked` (the command it was waiting for) — and leaves; so does everybody who sees
+// the notice.  The host launches the kernel again (claims zeroed) when it has the next command; a
+// command that arrived during the announcement and was run by some is run again by the new launch
+// (a step is idempotent while the host still waits for it).
 template <int KS1, int AP>
 __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args c,
                                                                    CollectResident r) {
   __shared__ __attribute__((aligned(16))) float tile[kCollectLds];
   __shared__ unsigned long long command;
-  const bool leader = blockIdx.x == gridDim.x - 1;
-  const int act_blocks = (int)gridDim.x - 1 - kCollectCopyBlocks;
-  const bool copy_role = (int)blockIdx.x >= act_blocks && !leader;
-  for (unsigned expect = r.first_seq;; ++expect) {
+  __shared__ int verdict[2];                       // {run this slot?, slots to help with} from thread 0
+  const int nb = (int)gridDim.x, me = (int)blockIdx.x;
+  const int act_blocks = nb - 1 - kCollectCopyBlocks;
+  unsigned last = r.first_seq - 1u;                // the newest command this workgroup has dealt with
+  unsigned held = last;                            // ... and the newest one its own slot is claimed for
+  for (;;) {
     if (threadIdx.x == 0) {
-      // Up to four polls of the command word in flight (r.poll_depth; a poll is a PCIe read round
-      // trip, ~1.9 us; loads return in order, so looking at the oldest paces the loop at a fraction
-      // of a round trip).  Measured (scripts/collect_polls.py): see DESIGN 4.3a.  The leader's park
-      // notice (device memory) is looked at only after 20 us without a command: a load that is
-      // waited for drains the polls in flight.
-      unsigned long long word = 0;
+      unsigned long long word;
       const unsigned long long t0 = wall_clock64();
-      const int depth = r.poll_depth;                              // scalar
-      auto poll = [&]() {
-        return __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      };
-      unsigned long long w0 = poll(), w1 = 0, w2 = 0, w3 = 0;
-      if (depth >= 2) { __builtin_amdgcn_s_sleep(16); w1 = poll(); }
-      if (depth >= 4) {
-        __builtin_amdgcn_s_sleep(16); w2 = poll();
-        __builtin_amdgcn_s_sleep(16); w3 = poll();
-      }
       for (;;) {
-        word = w0; if ((unsigned)(word >> 32) == expect) break;
-        w0 = poll();
-        if (depth >= 2) {
-          word = w1; if ((unsigned)(word >> 32) == expect) break;
-          w1 = poll();
-        }
-        if (depth >= 4) {
-          word = w2; if ((unsigned)(word >> 32) == expect) break;
-          w2 = poll();
-          word = w3; if ((unsigned)(word >> 32) == expect) break;
-          w3 = poll();
-        }
+        word = __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)((unsigned)(word >> 32) - last) > 0) break;       // a command not dealt with yet
         const unsigned long long waited = wall_clock64() - t0;
-        if (leader) {
-          if (waited > r.park_ticks) {
-            __hip_atomic_store(r.relay, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(r.parked, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            word = 8;                              // leave
-            break;
-          }
-        } else if (waited > 2000) {
-          if (__hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-              waited > 5000 * r.park_ticks) {
-            word = 8;
-            break;
-          }
+        if (waited > r.park_ticks) {               // (every workgroup on its own clock: same notice)
+          __hip_atomic_store(r.relay, last + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(r.parked, last + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          word = 0;                                // leave (no command has sequence number 0)
+          break;
+        }
+        // the others' notice is looked at only after 20 us without a command: a load that is
+        // waited for delays the next poll
+        if (waited > 2000 &&
+            __hip_atomic_load(r.relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          word = 0;
+          break;
         }
         for (int i = 0; i < r.poll_sleep; ++i) __builtin_amdgcn_s_sleep(8);      // (~0.25 us each)
+      }
+      if (word != 0) {
+        // my own slot: claimed ahead (steady state: nothing to wait for), or asked for now
+        const unsigned seq = (unsigned)(word >> 32);
+        if ((int)(held - seq) >= 0) {
+          verdict[0] = 1;
+          (void)__hip_atomic_fetch_max(r.claims + me, seq + 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+          held = seq + 1u;
+        } else {
+          const unsigned old = __hip_atomic_fetch_max(r.claims + me, seq + 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+          verdict[0] = (int)(old - seq) < 0 ? 1 : 0;     // older than this command: nobody ran it for me
+          // (old == seq: somebody ran this one for me, the next is mine; old > seq: the host has
+          //  moved on and somebody holds that one too — ask again at the next command)
+          held = (int)(old - seq) > 0 ? seq - 1u : seq + 1u;
+        }
       }
       command = word;
     }
     __syncthreads();
     const unsigned long long word = command;
-    const bool in_time = (unsigned)(word >> 32) == expect;
-    if (!in_time) return;                          // parked
+    if (word == 0) return;                         // parked
+    const unsigned seq = (unsigned)(word >> 32);
     Collect16Args step = c;
     step.row = (int64_t)((word >> 8) & 0xffffff);
     step.outcome_row = (word & 4) ? step.row - 1 : -1;
     step.eps = (word & 2) ? ((word & 1) ? r.eps1 : r.eps0) : nullptr;
-    step.done_seq = expect;
+    step.done_seq = seq;
     step.stamp_t0 = wall_clock64();
-    if (word & 8) {                                // stop: only the pending outcome is stored
-      step.next_from_obs = 0;                      // (nobody acts: no observation rows to carry over)
-      if (copy_role) collect16_step<KS1, AP, true, true>(step, tile);
-      else collect_signal_done(step);
-      return;
+    const bool stop = (word & 8) != 0;             // stop: only the pending outcome is stored
+    if (stop) step.next_from_obs = 0;              // (nobody acts: no observation rows to carry over)
+    // this command: my own slot first, then the slots of workgroups that are not there
+    int vb = me, helping = -1, next = 0;
+    bool go = verdict[0] != 0;
+    for (;;) {
+      if (go) {
+        const bool copy_slot = vb >= act_blocks && vb < nb - 1;
+        if (stop && !copy_slot) collect_signal_done(step, vb);
+        else collect16_step<KS1, AP, true, true>(step, tile, vb, nb);
+      }
+      __syncthreads();                             // (`tile`, `verdict` are reused)
+      if (helping < 0) {
+        if (threadIdx.x == 0) {
+          int count = 0, b = me;
+          while (count < nb - 1) {
+            b = b == 0 ? nb - 1 : b - 1;
+            const unsigned theirs = __hip_atomic_load(r.claims + b, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(theirs - seq) >= 0) break;   // claimed: its holder also looks after the ones before it
+            ++count;
+          }
+          verdict[1] = count;
+        }
+        __syncthreads();
+        helping = verdict[1];
+        next = me - helping;                       // the run [me - helping, me), in slot order
+        if (next < 0) next += nb;
+      }
+      if (helping == 0) break;
+      vb = next;
+      next = next + 1 == nb ? 0 : next + 1;
+      --helping;
+      if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_max(r.claims + vb, seq, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        verdict[0] = (int)(old - seq) < 0 ? 1 : 0;
+      }
+      __syncthreads();
+      go = verdict[0] != 0;
     }
-    collect16_step<KS1, AP, true, true>(step, tile);
-    __syncthreads();                               // `command` / tile are reused
+    last = seq;
+    if (stop) return;
   }
 }
 

@@ -882,21 +882,14 @@ class PPO(A2C):
         """Everything but the switch: the updates of such a configuration give the critic's launches
         the width they have under a rollout (`_critic_blocks`) whether or not they run there, so the
         switch changes WHEN the critic's iterations run and not one bit of what they compute."""
-        return (self.replay.batch_size is None and not parallel.exchanging()
+        return (self.replay.batch_size is None
                 and not self.actor_updater.stock and not self.critic_updater.stock
                 and self.observation_size <= 32 and self.action_size <= 8
                 and getattr(self, '_collector', None) is not None
                 # only behind a rollout that came through the collector (it binds the Segment's
                 # buffers anew every rollout; anybody else — rollout.DeviceRollout's captured graph —
                 # may hold their addresses, and the overlap swaps the observation buffer)
-                and getattr(self, '_host_rollout', False)
-                # every workgroup of the resident collect kernel must find a compute unit of its own
-                # next to the critic's launches, with room to spare: the resident protocol has no
-                # place for a workgroup that starts late (1 280 workers = 85 workgroups beside 168 of
-                # the critic's: the last five did not get in, the leader parked, the step never
-                # completed — measured, hence the bound)
-                and (self._collect_workgroups() <= 64
-                     or os.environ.get('TONIC_AMD_CRITIC_OVERLAP') == 'force'))
+                and getattr(self, '_host_rollout', False))
 
     @property
     def last_infos(self):
