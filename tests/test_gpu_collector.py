@@ -19,6 +19,28 @@ def lib():
     return _lib.load()
 
 
+def _in_a_process_of_its_own(request):
+    """Runs the calling test in a fresh interpreter (pytest on its node id) and returns True when it
+    did — the outer call then has nothing left to do.  For tests whose POINT is that two kernels run
+    side by side: HIP maps the streams of a process onto a handful of hardware queues, a queue runs
+    its kernels one after the other, and in a process that has created dozens of streams (this file's
+    other tests) a foreign kernel and the collector's resident kernel may share one — then there is
+    no concurrency to test."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('TONIC_AMD_TEST_INNER') == '1':
+        return False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run(
+        [sys.executable, '-m', 'pytest', '-q', '-x', '-s', '-p', 'no:cacheprovider', '-m', 'gpu',
+         request.node.nodeid], cwd=root, env=dict(os.environ, TONIC_AMD_TEST_INNER='1'),
+        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(done.stdout[-1500:])
+    assert done.returncode == 0, done.stdout[-4000:]
+    return True
+
+
 def _actor(O, A, seed):
     rng = np.random.RandomState(seed)
     shapes = [(64, O), (64,), (64, 64), (64,), (1, A), (A, 64), (A,)]
@@ -489,7 +511,7 @@ def test_critic_iterations_under_the_next_rollout_are_bit_identical(lib, monkeyp
         assert torch.equal(state_a[key], state_b[key]), key
 
 
-def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monkeypatch):
+def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monkeypatch, request):
     """The mode bench.py measures, at a size where the critic's chain REALLY runs under the next
     rollout: an update of 262 144 transitions x 80 iterations leaves ~6 ms of critic launches on the
     second stream while the host drives the next rollout (whose first steps also take 0.3 ms of
@@ -502,6 +524,8 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
     margin before the rollout does: PPO._critic_start_row.)  A race
     on the spare observation buffer, the normaliser snapshot or the Segment cannot hide behind a
     tolerance here."""
+    if _in_a_process_of_its_own(request):
+        return
     import time
     import tonic_amd
     import tonic_amd.torch
@@ -627,11 +651,11 @@ def test_resident_kernel_parks_and_resumes(lib):
 
 
 @pytest.mark.parametrize('O,A,W,T,hog,hog_ms', [
-    (28, 8, 1280, 10, 250, 60.0),     # 85 slots, 6 compute units: the whole rollout under the foreign kernel
-    (28, 8, 1280, 160, 250, 4.0),     # ... which leaves in the middle: the late workgroups join
-    (17, 6, 256, 300, 253, 3.0),      # 21 slots, 3 compute units, then everybody
-    (3, 1, 5, 40, 255, 5.0)])         # 6 slots on ONE compute unit
-def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, O, A, W, T, hog, hog_ms):
+    (28, 8, 1280, 10, 200, 80.0),     # 85 slots, 56 compute units: the whole rollout beside the foreign kernel
+    (28, 8, 1280, 160, 200, 4.0),     # ... which leaves in the middle: the late workgroups join
+    (17, 6, 256, 300, 245, 3.0),      # 21 slots, 11 compute units, then everybody
+    (3, 1, 5, 40, 252, 5.0)])         # 6 slots, 4 compute units
+def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, request, O, A, W, T, hog, hog_ms):
     """The resident collect kernel next to a FOREIGN kernel that holds most of the chip before the
     first command (tonic_debug_occupy: `hog` workgroups of 100 KB LDS, one per compute unit): only
     some of the launch's workgroups find a compute unit, the others get in when the foreign kernel
@@ -639,6 +663,8 @@ def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, O, A, W, T, ho
     run the slots of those that are not, claim by claim; a late workgroup joins and skips what was
     run for it) and the Segment, the normaliser sums and the actions are those of the undisturbed
     launch-per-step transport, bit for bit."""
+    if _in_a_process_of_its_own(request):
+        return
     import time
     from tonic_amd import _lib
     from tonic_amd.collector import Block, Collector
@@ -649,43 +675,67 @@ def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, O, A, W, T, ho
     eps = rng.standard_normal((T, W, A)).astype(np.float32)
     rewards = rng.standard_normal((T, W)).astype(np.float32)
     resets = (rng.uniform(size=(T, W)) < 0.05).astype(np.float32)
-    results, under = {}, None
+    results, seen = {}, []
     side = torch.cuda.Stream()
-    for transport in (0, 2):
+
+    def rollout(transport, company):
         block = Block(W, O, A)
         collector = Collector(block, transport)
         seg = _segment(T, W, O, A)
         sums = torch.zeros(2 * O, device='cuda')
         collector.bind_segment(seg, sums, T)
         torch.cuda.synchronize()
-        gone = torch.cuda.Event()
-        if transport == 2:
+        came, gone = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if company:
+            came.record(side)
             _lib.check(lib.tonic_debug_occupy(hog, hog_ms, side.cuda_stream), 'occupy')
             gone.record(side)
             time.sleep(0.001)                      # (the foreign kernel is in before the first command)
         collector.begin_rollout(flat)
-        actions = []
+        actions, under, clock = [], None, time.perf_counter()
         for t in range(T):
             block.observations[:] = obs[t]
             block.eps[t & 1][:] = eps[t]
             collector.ppo_step(t, t & 1, t > 0)
             collector.wait_actions()
+            if company and t in (0, 9):
+                now = time.perf_counter()
+                print(f'step {t} done {(now - clock) * 1e6:.0f} us after the rollout began, foreign '
+                      f'kernel gone: {gone.query()}')
             actions.append(block.actions.copy())
             block.next_observations[:] = obs[t + 1]
             block.rewards[:] = rewards[t]
             block.resets[:] = resets[t]
             block.terminations[:] = 0
-            if transport == 2 and t == min(T, 10) - 1:
+            if company and t == min(T, 10) - 1:
                 under = not gone.query()           # ten steps done and the foreign kernel still there
         collector.end_rollout(T - 1)
         torch.cuda.synchronize()
-        results[transport] = {k: v.cpu().numpy() for k, v in seg.items()}
-        results[transport]['sums'] = sums.cpu().numpy()
-        results[transport]['block_actions'] = np.stack(actions)
+        if company:
+            print(f'the foreign kernel held its compute units for {came.elapsed_time(gone):.2f} ms')
+        out = {k: v.cpu().numpy() for k, v in seg.items()}
+        out['sums'] = sums.cpu().numpy()
+        out['block_actions'] = np.stack(actions)
         collector.close()
-    assert under, 'the first steps must have completed while the foreign kernel held the chip'
-    for key, want in results[0].items():
-        assert np.array_equal(results[2][key], want), key
+        return out, under
+
+    want, _ = rollout(0, False)
+    rollout(2, False)       # (the resident kernel once without company: its first launch in a process
+    #                          loads code, which the steps beside the foreign kernel must not wait for)
+    for attempt in range(4):
+        # EVERY run beside the foreign kernel must give the undisturbed run's bits.  Whether the
+        # launch gets compute units while the foreign kernel is there is the hardware dispatcher's
+        # choice (workgroups are placed in order, round-robin over the XCDs: when the FIRST one finds
+        # its XCD full, none gets in before the foreign kernel leaves — seen in about one run in
+        # three): required in one of at most four runs, reported for all.
+        got, under = rollout(2, True)
+        seen.append(under)
+        for key, value in want.items():
+            assert np.array_equal(got[key], value), (attempt, key)
+        if under:
+            break
+    print('ten steps done while the foreign kernel held the chip:', seen)
+    assert any(seen), 'no run made progress beside the foreign kernel'
 
 
 @pytest.mark.parametrize('name,golden_name,prefix', [

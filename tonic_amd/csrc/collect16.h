@@ -50,6 +50,10 @@ struct Collect16Args {
   // Segment row the actor tiles have just written: tile_done[b] (device memory) = done_seq once
   // workgroup b's row stores are released.  null: the record reads the pinned block itself.
   unsigned* tile_done;
+  // Resident form only (null otherwise): the kernel's park notice.  A slot that waits for the rows of
+  // other slots (the record) gives the command up when the notice is out — the workgroups it waits
+  // for may have left; the host starts the kernel again and every slot of the command is run anew.
+  const unsigned* abandon;
   // ... and the outcome's next observations do not cross PCIe a second time either when the
   // environment has promised (tonic_collector_block_carry_over) that a worker's next observation IS
   // its observation of the following step unless it reset: the actor tiles, which hold this step's

@@ -310,6 +310,7 @@ struct tonic_collector {
   bool live;
   double park_us;
   unsigned long long* d_stamps;   // developer probe (TONIC_AMD_COLLECTOR_STAMPS=1)
+  unsigned long long launches, relaunches;
 };
 
 namespace {
@@ -437,8 +438,8 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
       return fail("hipMalloc of the wide act workspace", e);
   }
   if (getenv("TONIC_AMD_COLLECTOR_STAMPS") != nullptr) {
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 24 * 8)) != hipSuccess ||
-        (e = hipMemset(c->d_stamps, 0, 24 * 8)) != hipSuccess)
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stamps), 32 * 8)) != hipSuccess ||
+        (e = hipMemset(c->d_stamps, 0, 32 * 8)) != hipSuccess)
       return fail("hipMalloc of the stamp buffer", e);
   }
   const char* park = getenv("TONIC_AMD_COLLECTOR_PARK_US");
@@ -461,8 +462,11 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->d_stamps) {
-    unsigned long long t[24];
+    unsigned long long t[32];
     if (hipMemcpy(t, c->d_stamps, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "collector: %llu launches of the resident kernel (%llu after a park), %llu slots run "
+              "by another workgroup, %llu commands skipped by a late workgroup, %llu park notices\n",
+              c->launches, c->relaunches, t[24], t[25], t[26]);
       const char* role[3] = {"actor tile 0", "record", "copy 0"};
       for (int r = 0; r < 3; ++r) {
         const double n = t[r * 8 + 7] > 0 ? (double)t[r * 8 + 7] : 1.0;
@@ -577,6 +581,7 @@ int launch_resident(tonic_collector* c, unsigned first_seq) {
   r.poll_sleep = pause != nullptr ? atoi(pause) : 1;
   const int status = launch_collect_resident(step_arguments(c), r, c->stream);
   if (status == TONIC_OK) c->live = true;
+  c->launches += 1;
   return status;
 }
 
@@ -699,13 +704,24 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
       while (arrived < words && __atomic_load_n(flags + arrived, __ATOMIC_ACQUIRE) == c->seq)
         ++arrived;
       done = arrived == words;
-      if (!done && c->transport == 2 &&
-          __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) == c->seq) {
+      const uint32_t parked = c->transport == 2 && !done
+                                  ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u;
+      // (a notice for another command while this one is incomplete: the kernel may be gone all the
+      //  same — a slot of this command gave up on rows of workgroups that had left — look at the stream)
+      if (parked != 0 && (parked == c->seq || hipStreamQuery(c->stream) == hipSuccess)) {
         // the resident kernel parked while this command was on its way: start it again (the
-        // command word still holds the command; work done twice is idempotent, see the kernel)
+        // command word still holds the command; work done twice is idempotent WHILE THE HOST WAITS,
+        // see the kernel).  Some slots of this command were run before their workgroups left and
+        // have their completion words out; the new launch runs every slot again, and none of them
+        // may still be reading the block when this call returns: all words start over.
         TONIC_HIP(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
         c->live = false;
+        c->relaunches += 1;
         __atomic_store_n(&c->host->parked, 0u, __ATOMIC_RELEASE);
+        for (int w = 0; w < words; ++w)
+          __atomic_store_n(const_cast<uint32_t*>(flags) + w, 0u, __ATOMIC_RELAXED);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        arrived = 0;
         const int status = launch_resident(c, c->seq);
         if (status != TONIC_OK) return status;
       }

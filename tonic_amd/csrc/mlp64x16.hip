@@ -1099,7 +1099,14 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
     float acc = 0.f;
     const float* acc_in = c.norm_acc + c.row * c.norm_stride;
     float* acc_out = c.norm_acc + (c.row + 1) * c.norm_stride;
-    if (wave < 2 && lane < O) acc = acc_in[wave * O + lane];
+    // (HOST: the entry was written by whoever ran this slot for the previous step — in the resident
+    //  kernel possibly another workgroup on another XCD: agent-scope accesses, coherent per location)
+    if (wave < 2 && lane < O) {
+      if constexpr (HOST)
+        acc = __hip_atomic_load(acc_in + wave * O + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        acc = acc_in[wave * O + lane];
+    }
     const int64_t rows_per_chunk = (kHalf / O) & ~3;            // (x4 rows: 16-byte aligned chunks)
     if constexpr (HOST) {
       // A chunk (<= 32 KB) is ONE batch of 16-byte requests, all in flight — one PCIe round trip, or
@@ -1119,16 +1126,23 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
       if (from_segment) {
         // every actor workgroup's rows of this step, ONE poller per word (they all finish within a
         // microsecond or two of each other: their inputs cross PCIe together).  Bounded like every
-        // wait of the collector — 1 s — and a row that never came is NOT read: this slot then leaves
-        // without its completion word, which tonic_collector_wait_actions turns into
-        // TONIC_ERR_TIMEOUT (naming the word) instead of statistics built from a stale row.
+        // wait of the collector — 1 s, or the resident kernel's park notice: the slots waited for may
+        // belong to workgroups that have left — and a row that never came is NOT read: this slot then
+        // leaves without its completion word; the host starts the kernel again on the notice, or
+        // tonic_collector_wait_actions reports TONIC_ERR_TIMEOUT (naming the word) — never statistics
+        // built from a stale row.
         const unsigned long long t0 = wall_clock64();
         bool never = false;
         for (int b = tid; b < act_blocks; b += 256) {
           while (__hip_atomic_load(c.tile_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
                  c.done_seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 100000000ull) { never = true; break; }
+            if (wall_clock64() - t0 > 100000000ull ||
+                (c.abandon != nullptr &&
+                 __hip_atomic_load(c.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              never = true;
+              break;
+            }
           }
         }
         if (__syncthreads_or(never ? 1 : 0)) return;
@@ -1224,7 +1238,12 @@ __device__ __forceinline__ void collect16_step(const Collect16Args& c, float* ti
         if (wave < 2 && lane < O) add_rows(tile + wave * kHalf + lane, O, (int)rows, acc);
       }
     }
-    if (wave < 2 && lane < O) acc_out[wave * O + lane] = acc;
+    if (wave < 2 && lane < O) {
+      if constexpr (HOST)
+        __hip_atomic_store(acc_out + wave * O + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        acc_out[wave * O + lane] = acc;
+    }
     retire_touches(sink, c.norm_acc);
     collect_stamp(c, 1, 0);                          // staged + chained
     collect_signal_done(c, vb);
@@ -1496,12 +1515,14 @@ __global__ __launch_bounds__(256) void ppo_collect16_kernel(Collect16Args c) {
 //   * a workgroup that arrives late claims with a RETURNING atomic and skips what was already run
 //     for it (the host may have moved on: running a finished command again would read the block's
 //     next inputs).
-// Nobody waits forever: after `park_ticks` of the 100 MHz wall clock without a new command a
-// workgroup announces that the kernel parks — to the others through `relay` (device memory), to the
-// host through `parked` (the command it was waiting for) — and leaves; so does everybody who sees
-// the notice.  The host launches the kernel again (claims zeroed) when it has the next command; a
-// command that arrived during the announcement and was run by some is run again by the new launch
-// (a step is idempotent while the host still waits for it).
+// Nobody waits forever: `park_ticks` of the 100 MHz wall clock after it has finished a command's LAST
+// slot (the record: it waits for the actor slots' rows, so the whole step is done by then) without a
+// new command, the workgroup that ran that slot announces that the kernel parks — to the others
+// through `relay` (device memory), to the host through `parked` (the command it was waiting for) —
+// and leaves; so does everybody who sees the notice (and, after 1 000 x as long, everybody anyway).
+// The host launches the kernel again (claims zeroed) when it has the next command; a command that
+// arrived during the announcement and was run by some is run again by the new launch (a step is
+// idempotent while the host still waits for it, and the host waits for every slot of the new launch).
 template <int KS1, int AP>
 __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args c,
                                                                    CollectResident r) {
@@ -1512,6 +1533,9 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
   const int act_blocks = nb - 1 - kCollectCopyBlocks;
   unsigned last = r.first_seq - 1u;                // the newest command this workgroup has dealt with
   unsigned held = last;                            // ... and the newest one its own slot is claimed for
+  // whoever ran the last slot of the newest command keeps the clock of the idle period behind it (at
+  // launch: that slot's own workgroup)
+  bool announcer = me == nb - 1;
   for (;;) {
     if (threadIdx.x == 0) {
       unsigned long long word;
@@ -1520,9 +1544,10 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
         word = __hip_atomic_load(r.command, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)((unsigned)(word >> 32) - last) > 0) break;       // a command not dealt with yet
         const unsigned long long waited = wall_clock64() - t0;
-        if (waited > r.park_ticks) {               // (every workgroup on its own clock: same notice)
+        if (waited > (announcer ? r.park_ticks : 1000ull * r.park_ticks)) {
           __hip_atomic_store(r.relay, last + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(r.parked, last + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (c.stamps != nullptr) __hip_atomic_fetch_add(c.stamps + 26, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           word = 0;                                // leave (no command has sequence number 0)
           break;
         }
@@ -1547,6 +1572,8 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
           const unsigned old = __hip_atomic_fetch_max(r.claims + me, seq + 1u, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT);
           verdict[0] = (int)(old - seq) < 0 ? 1 : 0;     // older than this command: nobody ran it for me
+          if (c.stamps != nullptr && verdict[0] == 0)
+            __hip_atomic_fetch_add(c.stamps + 25, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // (old == seq: somebody ran this one for me, the next is mine; old > seq: the host has
           //  moved on and somebody holds that one too — ask again at the next command)
           held = (int)(old - seq) > 0 ? seq - 1u : seq + 1u;
@@ -1559,6 +1586,7 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
     if (word == 0) return;                         // parked
     const unsigned seq = (unsigned)(word >> 32);
     Collect16Args step = c;
+    step.abandon = r.relay;
     step.row = (int64_t)((word >> 8) & 0xffffff);
     step.outcome_row = (word & 4) ? step.row - 1 : -1;
     step.eps = (word & 2) ? ((word & 1) ? r.eps1 : r.eps0) : nullptr;
@@ -1569,9 +1597,11 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
     // this command: my own slot first, then the slots of workgroups that are not there
     int vb = me, helping = -1, next = 0;
     bool go = verdict[0] != 0;
+    announcer = false;
     for (;;) {
       if (go) {
         const bool copy_slot = vb >= act_blocks && vb < nb - 1;
+        announcer = announcer || vb == nb - 1;
         if (stop && !copy_slot) collect_signal_done(step, vb);
         else collect16_step<KS1, AP, true, true>(step, tile, vb, nb);
       }
@@ -1601,6 +1631,8 @@ __global__ __launch_bounds__(256) void ppo_collect_resident_kernel(Collect16Args
         const unsigned old = __hip_atomic_fetch_max(r.claims + vb, seq, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
         verdict[0] = (int)(old - seq) < 0 ? 1 : 0;
+        if (c.stamps != nullptr && verdict[0] != 0)
+          __hip_atomic_fetch_add(c.stamps + 24, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       go = verdict[0] != 0;

@@ -45,6 +45,20 @@ def default_model():
         observation_normalizer=normalizers.MeanStd())
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(name):
+    """One stream per purpose and device for the whole process, not one per agent: HIP maps the
+    streams of a process onto a handful of hardware queues in creation order, and two streams on one
+    queue run one after the other — an agent whose critic stream landed on its collector's queue
+    would get no overlap at all (seen in a process that had built a dozen agents before)."""
+    key = (name, torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream()
+    return _SIDE_STREAMS[key]
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _lib.TonicHipError(
@@ -957,7 +971,7 @@ class PPO(A2C):
         ready = torch.cuda.Event()
         ready.record()
         if getattr(self, '_critic_stream', None) is None:
-            self._critic_stream = torch.cuda.Stream()
+            self._critic_stream = _side_stream('critic')
             logger.before_dump(self, 'settle')
             self._guard_critic_readers()
         side = self._critic_stream
@@ -989,7 +1003,7 @@ class PPO(A2C):
         # through settle() first (_guard_critic_readers), so the critic is read final, as after the
         # reference's update.
         if getattr(self, '_rollout_marker', None) is None:
-            self._rollout_marker = torch.cuda.Stream()
+            self._rollout_marker = _side_stream('rollout marker')
         ordered = torch.cuda.Event()
         ordered.record()
         self._rollout_marker.wait_event(ordered)
