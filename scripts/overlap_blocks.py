@@ -21,7 +21,7 @@ for v in ('0', '1'):
             t0 = time.perf_counter()
             loop.run(256)
             blocks.append((time.perf_counter() - t0) / 256 * 1e6)
-            if pending is not None and t_critic is None and pending[0].query():
+            if pending is not None and t_critic is None and pending['done'].query():
                 t_critic = (time.perf_counter() - t_start) * 1e3
         print('overlap', v, 'us per step by block of 256:', ' '.join(f'{x:.1f}' for x in blocks),
               '| critic chain done within', t_critic, 'ms', flush=True)
