@@ -87,9 +87,13 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_oneshot_kernel(ReduceA
   __syncthreads();
   if (tid < a.world) {
     const unsigned* flag = flag_of(a, a.rank, parity, tid, b);
+    // (a communicator that has missed a peer once does not wait again: every later call returns at
+    //  once with the status standing, so a caller that checks late has lost one timeout, not many)
+    const unsigned* status = reinterpret_cast<const unsigned*>(a.window[a.rank] + a.status_offset);
+    const bool broken = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.sequence) {
-      if (wall_clock64() - t0 > a.timeout_ticks) { failed = 1; break; }
+      if (broken || wall_clock64() - t0 > a.timeout_ticks) { failed = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }
