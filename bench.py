@@ -1003,22 +1003,12 @@ def main():
         result['roofline_gae'] = roof_g
         result['cpu_baseline'] = cpu_baseline()
         result['parallel_workers'] = parallel_workers_loop(agent)
-        result['cfg1_plumbing'] = cfg1_plumbing()
-        result['offpolicy_sac'] = offpolicy_rates()
-        # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
-        # reference's default batch of 100 and the batch of cfg 3
-        result['offpolicy_td3'] = {}
-        for b in (100, 1024):
-            rates = offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)
-            result['offpolicy_td3'][f'B={b}'] = dict(rates['hip_graph'], roofline=rates['roofline'])
-        # D4PG (51 atoms) and MPO (20 sampled actions per state) on the same shapes, default B=100
-        for other in ('d4pg', 'mpo'):
-            rates = offpolicy_rates(other, 67, 21, 100, workers=64, cpu=False)
-            result['offpolicy_' + other] = dict(rates['hip_graph'], workload=rates['workload'],
-                                                us_per_iteration=rates['us_per_iteration'])
         result['speedup_vs_cpu_baseline'] = round(
             main_run['value'] / result['cpu_baseline']['value'], 1)
-        # BASELINE config 5's per-GPU share (AntBullet shapes, 1 280 workers): 2 steps, same harness
+        # BASELINE config 5's per-GPU share (AntBullet shapes, 1 280 workers): 2 steps, same harness —
+        # BEFORE the off-policy legs: every agent built in this process creates HIP streams, the
+        # streams of a process share a handful of hardware queues, and a collector that lands on the
+        # queue of the critic's stream loses the overlap this leg is about
         agent.close()
         del agent, loop, rollout
         import gc
@@ -1032,6 +1022,22 @@ def main():
             env_steps_per_sec=round(share['value'], 1), ms_per_step=round(share['ms_per_step'], 3),
             steps=2)
         O, A, W = 17, 6, 256
+        del share
+        gc.collect()
+        torch.cuda.empty_cache()
+        result['cfg1_plumbing'] = cfg1_plumbing()
+        result['offpolicy_sac'] = offpolicy_rates()
+        # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
+        # reference's default batch of 100 and the batch of cfg 3
+        result['offpolicy_td3'] = {}
+        for b in (100, 1024):
+            rates = offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)
+            result['offpolicy_td3'][f'B={b}'] = dict(rates['hip_graph'], roofline=rates['roofline'])
+        # D4PG (51 atoms) and MPO (20 sampled actions per state) on the same shapes, default B=100
+        for other in ('d4pg', 'mpo'):
+            rates = offpolicy_rates(other, 67, 21, 100, workers=64, cpu=False)
+            result['offpolicy_' + other] = dict(rates['hip_graph'], workload=rates['workload'],
+                                                us_per_iteration=rates['us_per_iteration'])
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -738,6 +738,84 @@ def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, request, O, A,
     assert any(seen), 'no run made progress beside the foreign kernel'
 
 
+@pytest.mark.parametrize('O,A,W,T', [(28, 8, 1280, 500), (17, 6, 256, 1500)])
+def test_resident_kernel_under_random_foreign_bursts(lib, request, O, A, W, T):
+    """A long rollout while a second thread keeps launching foreign kernels of random width (40 – 250
+    compute units) and duration (0.1 – 2 ms) with random pauses: workgroups of the resident kernel are
+    absent, arrive, find their slots run, park (the host also sleeps now and then) and are launched
+    again in every order the bursts produce.  Segment, normaliser sums and the actions the host read
+    must be those of the undisturbed launch-per-step transport, bit for bit."""
+    if _in_a_process_of_its_own(request):
+        return
+    import threading
+    import time
+    from tonic_amd import _lib
+    from tonic_amd.collector import Block, Collector
+    rng = np.random.RandomState(7 * O + W)
+    params = _actor(O, A, 3)
+    flat = torch.as_tensor(np.concatenate([p.reshape(-1) for p in params])).cuda()
+    obs = rng.standard_normal((T + 1, W, O)).astype(np.float32)
+    eps = rng.standard_normal((T, W, A)).astype(np.float32)
+    rewards = rng.standard_normal((T, W)).astype(np.float32)
+    resets = (rng.uniform(size=(T, W)) < 0.05).astype(np.float32)
+    naps = set(rng.choice(T, size=T // 25, replace=False).tolist())      # host pauses > the park time
+
+    def rollout(transport, bursts):
+        block = Block(W, O, A)
+        collector = Collector(block, transport)
+        seg = _segment(T, W, O, A)
+        sums = torch.zeros(2 * O, device='cuda')
+        collector.bind_segment(seg, sums, T)
+        torch.cuda.synchronize()
+        stop, launched = threading.Event(), [0]
+
+        def company():
+            side = torch.cuda.Stream()
+            noise = np.random.RandomState(11)
+            while not stop.is_set():
+                _lib.check(lib.tonic_debug_occupy(int(noise.randint(40, 251)),
+                                                  float(noise.uniform(0.1, 2.0)), side.cuda_stream),
+                           'occupy')
+                launched[0] += 1
+                time.sleep(float(noise.uniform(0.0, 0.002)))
+                side.synchronize()
+        thread = threading.Thread(target=company, daemon=True)
+        if bursts:
+            thread.start()
+        collector.begin_rollout(flat)
+        actions = []
+        for t in range(T):
+            block.observations[:] = obs[t]
+            block.eps[t & 1][:] = eps[t]
+            collector.ppo_step(t, t & 1, t > 0)
+            collector.wait_actions()
+            actions.append(block.actions.copy())
+            block.next_observations[:] = obs[t + 1]
+            block.rewards[:] = rewards[t]
+            block.resets[:] = resets[t]
+            block.terminations[:] = 0
+            if bursts and t in naps:
+                time.sleep(0.0005)
+        collector.end_rollout(T - 1)
+        stop.set()
+        if bursts:
+            thread.join(timeout=10.0)
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in seg.items()}
+        out['sums'] = sums.cpu().numpy()
+        out['block_actions'] = np.stack(actions)
+        collector.close()
+        return out, launched[0]
+
+    want, _ = rollout(0, False)
+    for attempt in range(2):
+        got, launched = rollout(2, True)
+        print('foreign kernels launched during the rollout:', launched)
+        assert launched >= 5
+        for key, value in want.items():
+            assert np.array_equal(got[key], value), (attempt, key)
+
+
 @pytest.mark.parametrize('name,golden_name,prefix', [
     ('PPO', 'ppo_halfcheetah_small', 'init/'), ('SAC', 'sac_small', 'pre/'),
     ('TD3', 'td3_small', 'pre/'), ('DDPG', 'ddpg_small', 'pre/')])
