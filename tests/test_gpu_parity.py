@@ -319,6 +319,48 @@ def test_critic_grad_is_bit_reproducible_at_baseline_size(lib, variant):
         _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
 
 
+@pytest.mark.parametrize('O,A', [(3, 1), (28, 8), (20, 6), (32, 8)])
+def test_grads_are_bit_reproducible_in_every_shape_bucket(lib, O, A):
+    """The other template instances of the fused grad kernels (observation buckets 4 / 20 / 32 wide,
+    action buckets 1 / 6 / 8; remainder columns on VALU for O = 3 and O = 20, none for 28 and 32):
+    eight launches of the actor and of the critic kernel on the same 262 144 samples give one result
+    each, at the kernel's own width and at a narrower one."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(100 * O + A)
+    n = 262144
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              np.zeros((1, A)), rng.normal(size=(A, 64)) * 0.1, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    obs = dev(rng.standard_normal((n, O)).astype(np.float32))
+    actions = dev(np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32))
+    adv = dev(rng.standard_normal(n).astype(np.float32))
+    old_lp = dev((-6 + rng.standard_normal(n) * 0.2).astype(np.float32))
+    returns = dev(rng.standard_normal(n).astype(np.float32))
+    stats = dev(np.array([0, 1, 0, 0], np.float32))
+    mean, std = dev(np.zeros(O, np.float32)), dev(np.ones(O, np.float32))
+    pa, pc = dev(flat(params)), dev(flat(cparams))
+    Pa, Pc = lib.tonic_ppo_actor_param_count(O, A), lib.tonic_v_critic_param_count(O)
+    ws = torch.empty(lib.tonic_ppo_workspace_bytes(n, O, A, 1), dtype=torch.uint8, device='cuda')
+    for width in (0, 100):
+        seen_a, seen_c = set(), set()
+        for _ in range(8):
+            out_a = torch.zeros(Pa + 8, device='cuda')
+            out_c = torch.zeros(Pc + 8, device='cuda')
+            _lib.check(lib.tonic_ppo_actor_grad(
+                pa.data_ptr(), obs.data_ptr(), actions.data_ptr(), adv.data_ptr(), stats.data_ptr(),
+                old_lp.data_ptr(), out_a.data_ptr(), n, O, A, 0.2, 0.0, None, width, ws.data_ptr(),
+                ws.numel(), None), 'actor_grad')
+            _lib.check(lib.tonic_value_regression_grad(
+                pc.data_ptr(), mean.data_ptr(), std.data_ptr(), 0.0, obs.data_ptr(),
+                returns.data_ptr(), out_c.data_ptr(), n, O, width, ws.data_ptr(), ws.numel(), None),
+                'critic_grad')
+            seen_a.add(out_a.cpu().numpy().tobytes())
+            seen_c.add(out_c.cpu().numpy().tobytes())
+        assert len(seen_a) == 1 and len(seen_c) == 1, (O, A, width, len(seen_a), len(seen_c))
+
+
 def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
     """grad_variant 2 computes the two 64x64 hidden-layer products of a tile as six bf16 MFMAs on exact
     hi + mid + lo splits of the fp32 operands.  Against a float64 autograd reference of the same loss
