@@ -436,6 +436,48 @@ def test_two_rank_gradient_sum_exchange_gloo(tmp_path):
         assert f'rank {r} ok' in out
 
 
+CHOICE_WORKER = '''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from tonic_amd import parallel
+rank, world = parallel.init_from_env(backend='gloo')
+assert world == 2
+# every verdict is the AND over the ranks, with the first objecting rank's reason, on every rank
+assert parallel._agree(True) == (True, '')
+ok, why = parallel._agree(rank != 1, 'no window on this rank')
+assert not ok and why == 'rank 1: no window on this rank', (ok, why)
+# auto: no GPU here -> every rank declines together, with the reason; the learner then uses the
+# process group.  The decision is taken once.
+assert parallel.one_shot(1000) is None
+choice = parallel.allreduce_choice()
+assert choice['kind'] == 'rccl' and 'no GPU' in choice['reason'], choice
+assert parallel.one_shot(5000) is None and parallel.allreduce_choice() is choice
+dist.barrier()
+print('rank', rank, 'ok')
+'''
+
+
+def test_exchange_choice_is_unanimous_and_recorded_gloo(tmp_path):
+    """parallel.one_shot in its automatic mode on two CPU ranks: the ranks agree on every step of the
+    decision (`_agree`: the AND over the ranks + the first objecting rank's reason, identical
+    everywhere), decline the one-shot all-reduce together where it cannot work (no GPU) and keep the
+    reason (`allreduce_choice`) — the logic that selects tonic_allreduce_f32 on a multi-GPU node."""
+    script = tmp_path / 'choice.py'
+    script.write_text(CHOICE_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29613', WORLD_SIZE='2',
+               OMP_NUM_THREADS='1')
+    env.pop('TONIC_AMD_ALLREDUCE', None)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f'rank {r} ok' in out
+
+
 def test_buffer_shard_indices_partition_the_global_batch():
     """SURVEY §8e, off-policy: every rank draws the same GLOBAL index stream and keeps the samples
     whose worker column it owns.  The per-rank parts must partition the batch, and the local
