@@ -64,10 +64,11 @@ def time_events(fn, repeats):
 
 
 # The arithmetic type of the path.  Everything is fp32 in and fp32 out with fp32 accumulation; the
-# two 64x64 hidden-layer products of the fused grad kernels split each fp32 operand EXACTLY into three
-# bf16 terms and sum the six bf16 MFMAs that matter at fp32 precision ("bf16x3"; tests/test_gpu_parity.py
-# holds that variant to the same tolerances as the fp32-MFMA variants, tonic_set_tuning selects them).
-DTYPE = 'f32 (64x64 products of the grad kernels bf16x3-emulated: exact 3-term split, fp32 accumulate)'
+# three 64x64 products of the fused grad kernels split each fp32 operand (scaled by a power of two into
+# binary16's range) into two fp16 terms and sum the three fp16 MFMAs that matter at fp32 precision
+# ("fp16x2"; tests/test_gpu_parity.py holds that variant to the error of the fp32-MFMA variants against
+# float64, tonic_set_tuning selects them).
+DTYPE = 'f32 (64x64 products of the grad kernels fp16x2-emulated: hi+lo split below 2^-24, fp32 accumulate)'
 
 
 def pmc_traffic(prefix):
@@ -103,11 +104,11 @@ def rocprof_us(prefix):
     return None
 
 
-# The ceiling the shipped arithmetic has: 23 % of the grad kernel's flops run at the fp32 MFMA rate,
-# 77 % as six bf16 MFMAs per product = 2.667 x the fp32 rate
-def mixed_ceiling_tflops(bf16x3_share):
-    return 1.0 / ((1.0 - bf16x3_share) / FP32_MFMA_PEAK_TFLOPS
-                  + bf16x3_share / (FP32_MFMA_PEAK_TFLOPS * 8.0 / 3.0))
+# The ceiling the shipped arithmetic has: 23 % of the grad kernel's flops run at the fp32 MFMA rate, 77 %
+# as three fp16 MFMAs per product = 16 / 3 x the fp32 rate (six bf16 MFMAs: 8 / 3 x)
+def mixed_ceiling_tflops(split_share, rate=8.0 / 3.0):
+    return 1.0 / ((1.0 - split_share) / FP32_MFMA_PEAK_TFLOPS
+                  + split_share / (FP32_MFMA_PEAK_TFLOPS * rate))
 
 
 def kernel_rooflines(agent):
@@ -140,14 +141,15 @@ def kernel_rooflines(agent):
             p(wsc), wsc.numel(), stream), 'critic')
 
     # grad_variant: 0 = 32x32x2 fp32 tiles, 1 wave per SIMD; 1 = 16x16x4 fp32 tiles, 2 waves; 2 = 1 with
-    # the two 64x64 hidden-layer products on bf16x3 terms; 3 = 2 with dW2 on bf16x3 terms.  The roofline
+    # the two 64x64 hidden-layer products on bf16x3 terms; 3 = 2 with dW2 on bf16x3 terms; 4 = the three
+    # products on fp16x2 terms.  The roofline
     # entry is the variant the library ships as its default (the one the timed job above ran); the
     # others are listed beside it.
     shipped = ctypes.c_int32(-1)
     _lib.check(lib.tonic_get_tuning(b'grad_variant', ctypes.byref(shipped)), 'tuning')
     shipped = shipped.value
     out = {}
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
         ws = actor._workspace_for(n)
         wsc = critic._workspace_for(n)
@@ -182,15 +184,19 @@ def kernel_rooflines(agent):
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
     arithmetic = ('fp32 MFMA throughout' if shipped < 2 else
                   'fp32-equivalent: layer 1, dW1, dW3 on fp32 MFMA; the 64x64 products (h1->z2, dz2->dh1'
-                  + (', dW2: 77 %' if shipped == 3 else ': 52 %') + ' of the flops) as six bf16 MFMAs per '
-                  'product on exact hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak '
-                  'stays the fp32 MFMA peak: what the same arithmetic costs without the split')
-    share = {0: 0.0, 1: 0.0, 2: 0.52, 3: 0.77}[shipped]
+                  + (', dW2: 77 %' if shipped >= 3 else ': 52 %') + ' of the flops) as '
+                  + ('three fp16 MFMAs per product on hi+lo fp16 splits of the power-of-two-scaled fp32 '
+                     'operands (split residual and dropped term below 2^-24)' if shipped == 4 else
+                     'six bf16 MFMAs per product on exact hi+mid+lo bf16 splits of the fp32 operands')
+                  + ', fp32 accumulation.  peak stays the fp32 MFMA peak: what the same arithmetic costs '
+                  'without the split')
+    share = {0: 0.0, 1: 0.0, 2: 0.52, 3: 0.77, 4: 0.77}[shipped]
+    rate = 16.0 / 3.0 if shipped == 4 else 8.0 / 3.0
     roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
-                frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share), 4),
-                mixed_ceiling_tflops=round(mixed_ceiling_tflops(share), 1),
+                frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share, rate), 4),
+                mixed_ceiling_tflops=round(mixed_ceiling_tflops(share, rate), 1),
                 rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
                 ms_per_launch=round(ms_a, 4), launches_timed=2 * ITERATIONS,
                 timed_as='80 launches behind a 42 ms lightly loaded phase, twice (the job\'s pattern: the '

@@ -194,7 +194,7 @@ def assert_grads_close(got_sums, want_grads, n, what):
     assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('name', PPO_CASES)
 def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     g = golden(name)
@@ -230,7 +230,7 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 def test_grads_ratio_clipping_branches(lib, variant):
     """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
     the still-live ones; ragged n (not a multiple of the 32-sample tile)."""
@@ -253,7 +253,7 @@ def test_grads_ratio_clipping_branches(lib, variant):
     np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 def test_grads_full_size_properties(lib, variant):
     """BASELINE size (N = 4096 x 256): sums are additive over a split of the batch,
     bit-reproducible run to run, and agree with the oracle on a 4096-sample slice."""
@@ -283,7 +283,7 @@ def test_grads_full_size_properties(lib, variant):
     assert_grads_close(part[:P], want, m, 'slice of the full batch')
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_critic_grad_is_bit_reproducible_at_baseline_size(lib, variant):
     """N = 4096 x 256: twelve launches of tonic_value_regression_grad on the same inputs give ONE
     result, at the kernel's own width and at the widths the PPO agent uses under a rollout.  Round 4
@@ -399,7 +399,7 @@ def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
                         torch.autograd.grad(((v - ret_t) ** 2).sum(), pc)]).cpu().numpy()
 
     errors = {}
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         got_a, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32),
                               old_lp, variant)
         got_c, Pc = critic_grad(lib, cparams, mean, std, obs, returns, variant)
@@ -409,7 +409,59 @@ def test_bf16x3_hidden_layer_products_are_fp32_class(lib):
     for k in (0, 1):                                   # actor, critic
         fp32_class = max(errors[0][k], errors[1][k])
         assert fp32_class < 2e-6, errors
-        assert max(errors[2][k], errors[3][k]) <= 2.0 * fp32_class + 1e-8, errors
+        assert max(errors[2][k], errors[3][k], errors[4][k]) <= 2.0 * fp32_class + 1e-8, errors
+
+
+@pytest.mark.parametrize('case', ['rising', 'falling', 'mixed', 'zero', 'small_weights', 'large_weights',
+                                  'ragged'])
+def test_fp16x2_products_keep_their_unit_over_extreme_ranges(lib, case):
+    """grad_variant 4 scales everything behind the loss gradient by one power of two per wave that
+    follows the largest head gradient seen so far (csrc/mlp64x16.hip, Lds16 CH = 3): per-sample loss
+    gradients spread over 18 decades — rising along the batch (every wave rescales its accumulators
+    again and again), falling, shuffled —, all-zero gradients, weight matrices far from unit scale and
+    a ragged batch give the gradient sums of the fp32-MFMA variant (1: same tiles, same order of sums),
+    block by block, to fp32 rounding of each block's largest entry."""
+    rng = np.random.RandomState(31)
+    O, A = 17, 6
+    n = 16 * 8 * 40 + (5 if case == 'ragged' else 0)
+    w2, w3 = {'small_weights': (1e-6, 1e3), 'large_weights': (40.0, 1e-4)}.get(case, (0.15, 0.1))
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * w2, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, A)) * 0.2, rng.normal(size=(A, 64)) * w3, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    decades = {'rising': np.linspace(-12, 6, n), 'falling': np.linspace(6, -12, n),
+               'mixed': rng.uniform(-12, 6, n)}.get(case, np.zeros(n))
+    size = np.zeros(n) if case == 'zero' else 10.0 ** decades
+    adv = (rng.standard_normal(n) * size).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.05).astype(np.float32)
+    mean, std = np.zeros(O, np.float32), np.ones(O, np.float32)
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    values = port.critic_forward(cparams, mean, std, obs)[3]
+    returns = (values + rng.standard_normal(n) * size * 100.0).astype(np.float32)
+    stats = np.array([0, 1, 0, 0], np.float32)
+
+    def blocks(P, actor):
+        edges = [0, 64 * O, 64 * O + 64, 64 * O + 64 + 4096, 64 * O + 128 + 4096]
+        return list(zip(edges, edges[1:] + [P]))
+
+    for what, run in (('actor', lambda v: actor_grad(lib, params, obs, actions, adv, stats, old_lp, v)),
+                      ('critic', lambda v: critic_grad(lib, cparams, mean, std, obs, returns, v))):
+        want, P = run(1)
+        got, _ = run(4)
+        assert np.isfinite(got).all(), (case, what)
+        if case == 'zero' and what == 'critic':
+            continue          # errors of 1e-7: the two variants' own value rounding, nothing to compare
+        np.testing.assert_allclose(got[P:], want[P:], rtol=1e-4, atol=1e-4 * np.abs(want[P:]).max(),
+                                   err_msg=f'{case} {what}: statistic sums')
+        for lo, hi in blocks(P, what == 'actor'):
+            top = np.abs(want[lo:hi]).max()
+            err = np.abs(got[lo:hi].astype(np.float64) - want[lo:hi]).max()
+            assert err <= (4e-5 if 'weights' in case else 4e-6) * top, (case, what, (lo, hi), err, top)
+        if case == 'zero' and what == 'actor':
+            assert not got[:P].any()
 
 
 def test_config5_size_properties(lib):

@@ -762,8 +762,9 @@ std::atomic<int> g_grad_waves{4};
 // 0 = 32x32x2 tiles, one wave per SIMD (mlp64_grad_kernel); 1 = 16x16x4 tiles, two waves per
 // SIMD (mlp64x16.hip); 2 = 1 with the two 64x64 hidden-layer products of a tile on bf16x3 terms
 // (six v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulation; Lds16<.., CH = 1>); 3 = 2 with
-// dW2 on bf16x3 terms as well (2 x 2 tiles of v_mfma_f32_32x32x16_bf16; CH = 2).
-constexpr int kDefaultGradVariant = 3;
+// dW2 on bf16x3 terms as well (2 x 2 tiles of v_mfma_f32_32x32x16_bf16; CH = 2); 4 = the three products on
+// fp16x2 terms instead (three fp16 MFMAs per fp32 product, operands scaled into binary16's range; CH = 3).
+constexpr int kDefaultGradVariant = 4;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
@@ -858,8 +859,8 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     return TONIC_OK;
   }
   if (strcmp(key, "grad_variant") == 0) {
-    TONIC_REQUIRE(value >= -1 && value <= 3, TONIC_ERR_INVALID_ARGUMENT,
-                  "grad_variant must be 0 .. 3 or -1 (default), got %d", value);
+    TONIC_REQUIRE(value >= -1 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_variant must be 0 .. 4 or -1 (default), got %d", value);
     g_grad_variant = value < 0 ? kDefaultGradVariant : value;
     return TONIC_OK;
   }

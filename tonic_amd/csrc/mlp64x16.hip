@@ -47,10 +47,20 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //      precision (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped terms are below 2^-24 of
 //      |a||b|), accumulated in fp32: 48 v_mfma_f32_16x16x32_bf16 of ~18 cycles per product plus
 //      5.5 VALU instructions per activation for the split.  Weights are split once, at staging.
+//   3  fp16x2: every fp32 operand, scaled by a power of two into the top of binary16's range, is split
+//      into two fp16 terms (hi + lo, 11 + 11 bits and a sign: the residual of the split is below
+//      2^-24 of the operand, fp32's own rounding) and the product is the sum of THREE fp16 MFMAs
+//      (lo.hi, hi.lo, hi.hi; the dropped lo.lo is below 2^-24 |a||b|), fp32 accumulation: 24
+//      v_mfma_f32_16x16x32_f16 per product and 2 VALU instructions per activation for the split
+//      (v_cvt_pk_f16_f32 + v_fma_mix_f32).  dW2 runs the same way on 32x32x16 tiles.  Scales: the
+//      weight images by the power of two that puts max |W2| below 2^14 (found at staging), h1 by 2^14
+//      (|tanh| <= 1), the backward pass by ONE power of two per wave that only ever shrinks — a tile
+//      whose gradients would leave the range first rescales the wave's accumulators (exact: powers
+//      of two) — so nothing can overflow binary16 and everything that is summed shares a unit.
 template <int KS1, int AP, int CH>
 struct Lds16 {
   static constexpr int TS = CH ? 20 : 24;                // row stride of the transpose tiles
-  static constexpr int kW2 = CH ? 6144 : 4096;           // floats per W2 image
+  static constexpr int kW2 = (CH == 1 || CH == 2) ? 6144 : 4096;   // floats per W2 image
   static constexpr int W1I = 0;                          // [4][KS1][64]       (b32 per step)
   static constexpr int W2S = W1I + 4 * KS1 * 64;         // CH 0: [4][4][64][4] (b128 per 4 steps)
   static constexpr int W2B = W2S + kW2;                  // CH 1: [2][4][3 terms][64][8 bf16]
@@ -59,12 +69,24 @@ struct Lds16 {
   static constexpr int W3P = B2P + 64;                   // [AP][4 groups][16]
   static constexpr int HC = W3P + AP * 64;               // [8][8] head constants
   static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
-  static constexpr int WAVE0 = (NORM + 8 * KS1 + 3) / 4 * 4;
+  static constexpr int SC = NORM + 8 * KS1;              // CH 3: {max |W2| bits, 1 / forward scale,
+                                                         //        1 / backward weight scale, max |W3|}
+  // CH 3, policies with more than one action: the head's two products on fp32 MFMA tiles.  Row
+  // 4 g + r of the forward image is action g + 4 r, so lane group g of a tile ends up with the
+  // outputs of actions g and g + 4 — the k index those actions have in the backward product — and
+  // every group does the loss arithmetic of ITS actions only.
+  static constexpr int HSLOTS = (AP + 3) / 4;            // actions per lane group
+  static constexpr bool HM = CH == 3 && AP > 1;
+  static constexpr int W3F = SC + 8;                     // [4 c][64 lanes][4 e]: W3[action(row)][feat16(4c+e, g)]
+  static constexpr int W3B = W3F + (HM ? 1024 : 0);      // [HSLOTS c][64 lanes][4 T]: W3[g + 4c][16 T + i]
+  static constexpr int WAVE0 = (W3B + (HM ? HSLOTS * 256 : 0) + 3) / 4 * 4;
   static constexpr int T_FLOATS = 64 * TS;
   static constexpr int DO_FLOATS = 16 * 16;
   static constexpr int WAVE_FLOATS = 2 * T_FLOATS + DO_FLOATS;
   static constexpr int TOTAL = WAVE0 + kWaves16 * WAVE_FLOATS;
-  static constexpr int BYTES = TOTAL * 4;
+  // the epilogue overlays five gradient images (the bucket's largest: O = 4 KS1, A = AP) on all of this
+  static constexpr int FOLD = 5 * ((64 * 4 * KS1 + 64 + 4096 + 64 + 66 * AP + kStatSlots + 63) / 64 * 64);
+  static constexpr int BYTES = (TOTAL > FOLD ? TOTAL : FOLD) * 4;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -90,6 +112,42 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
   lo = pack_bf16(a, b);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int kF16Top = 14;          // scaled operands stay below 2^14 (binary16: 65504)
+
+// (fp16(a), fp16(b)) packed, round to nearest even: v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
+// a = hi + lo + r, |r| <= 2^-24 |a| for |a| in [2^-2, 2^16) (below that the binary16 subnormal grid
+// 2^-24 bounds r absolutely); the residual a - hi is exact in fp32 and comes out of ONE
+// v_fma_mix_f32 (fp16 half of `hi` x -1 + a) — the compiler itself emits a conversion and a subtract.
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_f16(a, b);
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(a) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(b) : "v"(hi), "v"(b));
+  lo = pack_f16(a, b);
+}
+
+// 2^k as a float (k in [-126, 127])
+__device__ __forceinline__ float pow2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+
+// max over the 16 lanes of a DPP row, in every lane of the row (four v_max_f32 with DPP operands)
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, dpp_lane<0xB1>(v));     // quad_perm [1, 0, 3, 2]
+  v = fmaxf(v, dpp_lane<0x4E>(v));     // quad_perm [2, 3, 0, 1]
+  v = fmaxf(v, dpp_lane<0x141>(v));    // row_half_mirror
+  v = fmaxf(v, dpp_lane<0x140>(v));    // row_mirror
+  return v;
+}
+
 template <int KS1, int AP, bool ACTOR, int CH>
 __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   using L = Lds16<KS1, AP, CH>;
@@ -103,12 +161,14 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   const float* W3 = ACTOR ? tail + A : tail;
   const float* b3 = W3 + (ACTOR ? A * 64 : 64);
   for (int idx = tid; idx < 4 * KS1 * 64; idx += nth) lds[L::W1I + idx] = 0.f;
+  if (CH == 3 && tid == 0) lds[L::SC] = 0.f;
   __syncthreads();
   for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
     const int row = gi / O, k = gi - row * O;
     const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
     lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi] * kTanhScale;
   }
+  int w_exp = 0;   // CH 3: the exponent that bounds every |W2| (|w| < 2^w_exp), the same in every workgroup
   {
     // all eight W2 values of this thread are requested before the first LDS scatter (a load in a
     // plain copy loop is waited for before the next one is issued)
@@ -116,11 +176,49 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
     float w2v[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) w2v[u] = W2[tid + u * nth];
+    if constexpr (CH == 3) {
+      float m = 0.f;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) m = fmaxf(m, fabsf(w2v[u]));
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(lds + L::SC), __float_as_uint(m));
+      __syncthreads();
+      w_exp = __builtin_amdgcn_frexp_expf(lds[L::SC]);
+      w_exp = w_exp < -60 ? -60 : (w_exp > 60 ? 60 : w_exp);
+      if (tid == 0) {
+        lds[L::SC + 1] = pow2i(w_exp - 2 * kF16Top + 2);    // 1 / (forward image scale x 2^14 of h1)
+        lds[L::SC + 2] = pow2i(w_exp - kF16Top);            // 1 / backward image scale
+      }
+    }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int gi = tid + u * nth, row = gi >> 6, col = gi & 63;
       const float w = w2v[u];
-      if (CH == 0) {
+      if constexpr (CH == 3) {
+        // fp16x2 images, the bf16x3 layout with two terms: [2 m][4 T][2 terms][64 lanes][8 fp16].
+        // |w kTanhScale| < 2^(w_exp + 2): the forward image is scaled by 2^(12 - w_exp), the
+        // backward one by 2^(14 - w_exp).
+        unsigned short* fwd = reinterpret_cast<unsigned short*>(lds + L::W2S);
+        unsigned short* bwd = reinterpret_cast<unsigned short*>(lds + L::W2B);
+        unsigned hi, lo;
+        {
+          const int T = row >> 4, i = row & 15;
+          const int q = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
+          const int at = ((((q >> 3) * 4 + T) * 2) * 64 + gg * 16 + i) * 8 + (q & 7);
+          split2_pair(w * kTanhScale * pow2i(kF16Top - 2 - w_exp), 0.f, hi, lo);
+          fwd[at] = (unsigned short)hi;
+          fwd[at + 512] = (unsigned short)lo;
+        }
+        {
+          const int T = col >> 4, i = col & 15;
+          const int q = ((row >> 4) << 2) | (row & 3), gg = (row >> 2) & 3;
+          const int at = ((((q >> 3) * 4 + T) * 2) * 64 + gg * 16 + i) * 8 + (q & 7);
+          split2_pair(w * pow2i(kF16Top - w_exp), 0.f, hi, lo);
+          bwd[at] = (unsigned short)hi;
+          bwd[at + 512] = (unsigned short)lo;
+        }
+      } else if (CH == 0) {
         {  // forward image: A row = output feature `row`, k = input feature `col`
           const int T = row >> 4, i = row & 15;
           const int st = ((col >> 4) << 2) | (col & 3), gg = (col >> 2) & 3;
@@ -161,7 +259,29 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   for (int idx = tid; idx < 64; idx += nth) {
     const int g = idx >> 4, q = idx & 15;
     lds[L::B1P + idx] = b1[feat16(q, g)] * kTanhScale;
-    lds[L::B2P + idx] = b2[feat16(q, g)] * kTanhScale;
+    // CH 3: the layer-2 chain starts from the bias in the unit of its products
+    lds[L::B2P + idx] = b2[feat16(q, g)] * kTanhScale * (CH == 3 ? pow2i(2 * kF16Top - 2 - w_exp) : 1.f);
+  }
+  if constexpr (L::HM) {
+    const int nout = ACTOR ? A : 1;
+    for (int idx = tid; idx < 1024; idx += nth) {
+      const int e = idx & 3, l = (idx >> 2) & 63, c = idx >> 8, i = l & 15, gg = l >> 4;
+      const int aa = (i >> 2) + 4 * (i & 3);
+      lds[L::W3F + idx] = ((i & 3) < L::HSLOTS && aa < nout) ? W3[aa * 64 + feat16(4 * c + e, gg)] : 0.f;
+    }
+    for (int idx = tid; idx < L::HSLOTS * 256; idx += nth) {
+      const int T = idx & 3, l = (idx >> 2) & 63, c = idx >> 8, i = l & 15, gg = l >> 4;
+      const int aa = gg + 4 * c;
+      lds[L::W3B + idx] = aa < nout ? W3[aa * 64 + 16 * T + i] : 0.f;
+    }
+  }
+  if (CH == 3 && tid < 64) {               // max |W3| over the live heads: bounds dz2 from the head gradients
+    const int nout = ACTOR ? A : 1;
+    float m = 0.f;
+    for (int aa = 0; aa < nout; ++aa) m = fmaxf(m, fabsf(W3[aa * 64 + tid]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (tid == 0) lds[L::SC + 3] = m;
   }
   for (int idx = tid; idx < AP * 64; idx += nth) {
     const int aa = idx >> 6, g = (idx >> 4) & 3, q = idx & 15;
@@ -209,17 +329,22 @@ __device__ __forceinline__ float sum_groups(float v) {
   return __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
 }
 
-__device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16]) {
+// OUT_EXP: the result comes out times 2^OUT_EXP (exactly the scaled bits of the unscaled result);
+// `in_scale` multiplies the argument first (CH 3: the chain's unit back to 1).
+template <int OUT_EXP = 0, bool SCALED_IN = false>
+__device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16], float in_scale = 1.f) {
   // acc = 2 log2(e) x (kTanhScale); tanh(x) = 1 - 2 / (1 + e^{2x}): four instructions per element
   // (exp, add, rcp, fma) against seven for the odd-symmetric form; absolute error <= 2e-7 over the
   // whole range (e^{2x} = inf gives exactly 1, e^{2x} = 0 exactly -1).
   float t[16], d[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t[q] = __builtin_amdgcn_exp2f(acc[q >> 2][q & 3]);
+  for (int q = 0; q < 16; ++q)
+    t[q] = __builtin_amdgcn_exp2f(SCALED_IN ? acc[q >> 2][q & 3] * in_scale : acc[q >> 2][q & 3]);
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = __builtin_amdgcn_rcpf(1.f + t[q]);
+  constexpr float one = (float)(1 << OUT_EXP);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) out[q] = fmaf(-2.f, d[q], 1.f);
+  for (int q = 0; q < 16; ++q) out[q] = fmaf(-2.f * one, d[q], one);
 }
 
 // acc[T] (+)= sum over 16 steps of W-image chunk x in[]: 64 in-features, 64 out-features.
@@ -290,6 +415,52 @@ __device__ __forceinline__ void chain64_b3(const float* wimg, const float (&in)[
   }
 }
 
+// The same product on fp16x2 terms (Lds16 CH = 3); `in` is already in binary16's range.
+__device__ __forceinline__ f32x4 mfma_h16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma_h32(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// eight fp32 values (two ds_read_b128) -> their two fp16 terms, element order preserved
+__device__ __forceinline__ void split2_x8(const f32x4& a, const f32x4& b, u32x4 (&t)[2]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned h, l;
+    split2_pair(a[2 * p], a[2 * p + 1], h, l);
+    t[0][p] = h; t[1][p] = l;
+    split2_pair(b[2 * p], b[2 * p + 1], h, l);
+    t[0][2 + p] = h; t[1][2 + p] = l;
+  }
+}
+
+__device__ __forceinline__ void chain64_f2(const float* wimg, const float (&in)[16], int lane,
+                                           f32x4 (&acc)[4]) {
+  const u32x4* w4 = reinterpret_cast<const u32x4*>(wimg);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    u32x4 bh, bl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned h, l;
+      split2_pair(in[8 * m + 2 * p], in[8 * m + 2 * p + 1], h, l);
+      bh[p] = h; bl[p] = l;
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      const u32x4 wh = w4[((m * 4 + T) * 2 + 0) * 64 + lane];
+      const u32x4 wl = w4[((m * 4 + T) * 2 + 1) * 64 + lane];
+      acc[T] = mfma_h16(wl, bh, acc[T]);
+      acc[T] = mfma_h16(wh, bl, acc[T]);
+      acc[T] = mfma_h16(wh, bh, acc[T]);
+    }
+  }
+}
+
 __device__ __forceinline__ void load_bias16(const float* bimg, int g, f32x4 (&acc)[4]) {
   const f32x4* p = reinterpret_cast<const f32x4*>(bimg + g * 16);
 #pragma unroll
@@ -337,7 +508,13 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // CH 2: dW2 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 on bf16x3 terms — the 16 samples of a tile
   // are exactly one K block; 24 MFMAs of 32 cycles instead of 64 fp32 MFMAs of 32 cycles.  Lane
   // (feature l & 31 of a 32-feature tile, half l >> 5) contributes samples 8 half .. 8 half + 7.
-  constexpr bool W2B3 = CH == 2;
+  constexpr bool W2B3 = CH >= 2;
+  // CH 3: the three 64x64 products on fp16x2 terms (see Lds16); everything behind the loss gradient
+  // runs in the wave's unit 2^(kF16Top - e_run) and is brought back when the accumulators are stored.
+  constexpr bool F16 = CH == 3;
+  // heads on MFMA (Lds16::HM): NS action slots per lane, slot r of lane group g = action g + 4 r
+  constexpr bool HM = L::HM && ACTOR;
+  constexpr int NS = HM ? L::HSLOTS : AP;
   // LDS reads of head weights kept in flight (4 registers each); the widest bucket has none to spare
   constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -390,6 +567,45 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   f32x4 gHead = {0.f, 0.f, 0.f, 0.f};
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
+  // CH 3: every gradient accumulator above holds (true sum) x 2^(kF16Top - e_run) [x a constant of
+  // its class]; e_run only grows.  A tile announces the exponent that bounds its head gradients
+  // (x max |W3|: a bound on its dz2) BEFORE anything of it is scaled, so no operand of an fp16
+  // product exceeds 2^kF16Top; two binades of headroom keep the rescales to a handful per launch.
+  int e_run = -100;
+  float s_run = pow2i(kF16Top + 100);
+  auto enter_unit = [&](float bound) {
+    const int e = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(bound));
+    if (e > e_run) {
+      const int e_new = e + 2 > 110 ? 110 : e + 2;
+      const float f = __builtin_ldexpf(1.f, e_run - e_new);
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        gb2w[x] *= f;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gW2w[x][y][r] *= f;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        gb1[x] *= f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gW3[x][r] *= f;
+#pragma unroll
+          for (int y = 0; y < XT; ++y) gW1[x][y][r] *= f;
+        }
+#pragma unroll
+        for (int y = 0; y < (XR > 0 ? XR : 1); ++y) gW1r[x][y] *= f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gHead[r] *= f;
+      e_run = e_new;
+      s_run = pow2i(kF16Top - e_new);
+    }
+  };
+
   // Experiment knob (tonic_set_tuning "grad_skew", default 0): delays the second-dispatched half of
   // the workgroup.  It was meant to put the two waves of a SIMD into opposite MFMA / VALU phases;
   // micro-benchmarks (scripts/ubench) then showed that fp32 MFMA and VALU instructions never
@@ -403,7 +619,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // with its own s_waitcnt vmcnt(0): eight serialised HBM round trips per tile.)
   struct TileIn {
     float x[KS1];
-    float act[AP];
+    float act[NS];
     float adv, lp, ret;
   };
   auto load_tile = [&](int64_t t, TileIn& in) {
@@ -418,10 +634,13 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     }
     in.adv = 0.f; in.lp = 0.f; in.ret = 0.f;
 #pragma unroll
-    for (int aa = 0; aa < AP; ++aa) in.act[aa] = 0.f;
+    for (int aa = 0; aa < NS; ++aa) in.act[aa] = 0.f;
     if (ACTOR) {
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) in.act[aa] = a.actions[nc * A + (aa < A ? aa : A - 1)];
+      for (int r = 0; r < NS; ++r) {
+        const int aa = HM ? g + 4 * r : r;
+        in.act[r] = a.actions[nc * A + (aa < A ? aa : A - 1)];
+      }
       in.adv = a.adv[nc];
       in.lp = a.old_logp[nc];
     } else if (!FWD) {
@@ -440,6 +659,13 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   if (!ACTOR && tile < ntiles) load_tile(tile, cur);
   stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
   __syncthreads();
+  float fwd_unit = 1.f, bwd_unit = 1.f, w3_bound = 0.f;
+  if constexpr (F16) {
+    fwd_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 1])));
+    bwd_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 2])));
+    // |dz2| <= sum_a |dzl[a]| max |W3|, and dzl = 2 (...) in both losses
+    w3_bound = 2.f * __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 3])));
+  }
   if (ACTOR && tile < ntiles) load_tile(tile, cur);
   for (; tile < ntiles; tile += tile_stride) {
     PHASE(11);                                       // loop overhead / previous tail
@@ -460,14 +686,14 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
                                     -a.norm_clip, a.norm_clip);
       x[st] = v * ((valid && k < O) ? 1.f : 0.f);
     }
-    float (&in_act)[AP] = cur.act;
+    float (&in_act)[NS] = cur.act;
     const float in_adv = cur.adv, in_lp = cur.lp, in_ret = cur.ret;
     // next tile's inputs are requested now and consumed one iteration later: ~6k cycles of HBM
     // latency per tile (measured with the phase probes) disappear behind this tile's work
     if (tile + tile_stride < ntiles) load_tile(tile + tile_stride, nxt);
 
     // ---- forward
-    float h1[16], h2[16], z[AP], dzl[AP];
+    float h1[16], h2[16], z[NS], dzl[NS];
     {
       f32x4 acc[4];
       load_bias16(lds + L::B1P, g, acc);
@@ -478,16 +704,31 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
           acc[T] = mfma16(lds[L::W1I + (T * KS1 + st) * 64 + lane], x[st], acc[T]);
       }
       PHASE(0);                                      // input loads + layer-1 chain issued
-      tanh16(acc, h1);
+      if constexpr (F16) tanh16<kF16Top>(acc, h1);          // h1 x 2^14 from here on
+      else tanh16(acc, h1);
       PHASE(1);
       load_bias16(lds + L::B2P, g, acc);
       if constexpr (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
+      else if constexpr (F16) chain64_f2(lds + L::W2S, h1, lane, acc);
       else chain64_b3(lds + L::W2S, h1, lane, acc);
       PHASE(2);
-      tanh16(acc, h2);
+      if constexpr (F16) tanh16<0, true>(acc, h2, fwd_unit);
+      else tanh16(acc, h2);
       PHASE(3);
     }
-    {
+    if constexpr (HM) {
+      // z^T[row][sample] = W3 . h2 on 16 MFMAs: lane (s, g) receives the rows 4 g + r = actions g + 4 r
+      f32x4 zacc = zero4;
+      const f32x4* w3f = reinterpret_cast<const f32x4*>(lds + L::W3F);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 w = w3f[c * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zacc = mfma16(w[e], h2[4 * c + e], zacc);
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) z[r] = zacc[r];          // + bias: with the head constants below
+    } else {
       // W3 operands through a rolling window of kW3Window LDS reads in flight: the plain loop
       // (read 16 bytes, wait, four FMAs, next) exposed 24 LDS round trips per tile
       const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P) + g * 4;
@@ -517,15 +758,21 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     }
     const float cw = counted ? 1.f : 0.f;            // arithmetic mask: no lane branches below
     if (ACTOR) {
-      float logp = 0.f, loc[AP], dif[AP], dsg[AP];
+      float logp = 0.f, loc[NS], dif[NS], dsg[NS], bsum = 0.f;
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
+      for (int r = 0; r < NS; ++r) {
+        const int aa = HM ? g + 4 * r : r;                 // HM: this lane group's actions only
         const f32x4 hc = *reinterpret_cast<const f32x4*>(lds + L::HC + aa * 8);
-        loc[aa] = tanh_fast(z[aa]);
-        const float act = valid ? in_act[aa] : loc[aa];
-        dif[aa] = act - loc[aa];
-        const float term = -(dif[aa] * dif[aa]) * hc[2] - hc[3];
-        logp += (EXACT || aa < A) ? term : 0.f;
+        loc[r] = tanh_fast(HM ? z[r] + hc[0] : z[r]);
+        const float act = valid ? in_act[r] : loc[r];
+        dif[r] = act - loc[r];
+        const float term = -(dif[r] * dif[r]) * hc[2] - hc[3];
+        logp += ((EXACT && !HM) || aa < A) ? term : 0.f;
+        if constexpr (F16) bsum = fmaf(fabsf(dif[r]), hc[2], bsum);      // |dzl| <= |gl| |dif| / var
+      }
+      if constexpr (HM) {                                  // the other groups' actions
+        logp = sum_groups(logp);
+        bsum = sum_groups(bsum);
       }
       const float old_lp = valid ? in_lp : logp;
       float adv = valid ? in_adv : 0.f;
@@ -537,31 +784,47 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
       // (a.plain: StochasticPolicyGradient, d(-adv * logp) / d logp = -adv, nothing is clipped)
       const bool plain = a.plain != 0;
-      const float gl = (valid && (plain || !dead)) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
+      float gl = (valid && (plain || !dead)) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
+      if constexpr (F16) {
+        enter_unit(row_max16(fabsf(gl) * bsum * w3_bound));
+        gl *= s_run;
+      }
       st0 += cw * (plain ? -(adv * logp) : -fminf(surr1, surr2));
       st1 += cw * (old_lp - logp);
       st2 += (counted && outside && !plain) ? 1.f : 0.f;
       st3 += cw;
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
+      for (int r = 0; r < NS; ++r) {
+        const int aa = HM ? g + 4 * r : r;
         const f32x2 hs = *reinterpret_cast<const f32x2*>(lds + L::HC + aa * 8 + 4);   // 1/sigma, 1/var
-        const float dloc = gl * dif[aa] * hs[1];
-        const float live = (EXACT || aa < A) ? 1.f : 0.f;
-        dzl[aa] = live * dloc * (1.f - loc[aa] * loc[aa]);
-        dsg[aa] = live * gl * (dif[aa] * dif[aa] * hs[1] * hs[0] - hs[0]);
-      }
-      if (g == 0) {
-        f32x4 lo = zero4, hi = zero4;
-#pragma unroll
-        for (int aa = 0; aa < AP; ++aa) {
-          if (aa < 4) lo[aa] = dsg[aa]; else hi[aa - 4] = dsg[aa];
+        const float dloc = gl * dif[r] * hs[1];
+        const float live = ((EXACT && !HM) || aa < A) ? 1.f : 0.f;
+        dzl[r] = live * dloc * (1.f - loc[r] * loc[r]);
+        dsg[r] = live * gl * (dif[r] * dif[r] * hs[1] * hs[0] - hs[0]);
+        if constexpr (HM) {                                // row s of dO: [dz of 8 actions | dsigma of 8]
+          DO[s * 16 + aa] = dzl[r];
+          DO[s * 16 + 8 + aa] = dsg[r];
         }
-        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = lo;
-        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = hi;
+      }
+      if constexpr (!HM) {
+        if (g == 0) {
+          f32x4 lo = zero4, hi = zero4;
+#pragma unroll
+          for (int aa = 0; aa < AP; ++aa) {
+            if (aa < 4) lo[aa] = dsg[aa]; else hi[aa - 4] = dsg[aa];
+          }
+          reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = lo;
+          reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = hi;
+        }
       }
     } else {
       const float err = valid ? z[0] - in_ret : 0.f;
-      dzl[0] = 2.f * err;
+      if constexpr (F16) {
+        enter_unit(row_max16(fabsf(err) * w3_bound));
+        dzl[0] = 2.f * (err * s_run);
+      } else {
+        dzl[0] = 2.f * err;
+      }
       st0 += cw * err * err;
       st1 += cw * z[0];
       st3 += cw;
@@ -574,16 +837,33 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     PHASE(4);                                        // head + loss
     // ---- backward
     scatter_S16<TS16>(TA, h2, s, g);                       // h2^T for dW3
-    if (g == 0) {
-      f32x4 lo = zero4, hi = zero4;
+    if constexpr (!HM) {
+      if (g == 0) {
+        f32x4 lo = zero4, hi = zero4;
 #pragma unroll
-      for (int aa = 0; aa < AP; ++aa) {
-        if (aa < 4) lo[aa] = dzl[aa]; else hi[aa - 4] = dzl[aa];
+        for (int aa = 0; aa < AP; ++aa) {
+          if (aa < 4) lo[aa] = dzl[aa]; else hi[aa - 4] = dzl[aa];
+        }
+        reinterpret_cast<f32x4*>(DO + s * 16)[0] = lo;
+        reinterpret_cast<f32x4*>(DO + s * 16)[1] = hi;
       }
-      reinterpret_cast<f32x4*>(DO + s * 16)[0] = lo;
-      reinterpret_cast<f32x4*>(DO + s * 16)[1] = hi;
     }
-    {
+    if constexpr (HM) {
+      // (dz . W3)^T[feature][sample] on 4 NS MFMAs: k = lane group = the slot's action
+      f32x4 hacc[4] = {zero4, zero4, zero4, zero4};
+      const f32x4* w3b = reinterpret_cast<const f32x4*>(lds + L::W3B);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        const f32x4 w = w3b[c * 64 + lane];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hacc[T] = mfma16(w[T], dzl[c], hacc[T]);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float y = h2[q];
+        h2[q] = hacc[q >> 2][q & 3] * fmaf(-y, y, 1.f);
+      }
+    } else {
       const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P) + g * 4;
       constexpr int kReads = AP * 4;                 // t -> (j = t / AP, aa = t % AP)
       f32x4 win[kW3Window];
@@ -614,6 +894,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 
     f32x4 dacc[4] = {zero4, zero4, zero4, zero4};
     if constexpr (CH == 0) chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
+    else if constexpr (F16) chain64_f2(lds + L::W2B, dz2, lane, dacc);
     else chain64_b3(lds + L::W2B, dz2, lane, dacc);
     PHASE(6);
 
@@ -646,13 +927,23 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
                                                           8 * (lane >> 5));
         const f32x4 v0 = row[0], v1 = row[1];
         gb2w[Ti] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-        split3_x8(v0, v1, aT[Ti]);
+        if constexpr (F16) {
+          u32x4 t2[2];
+          split2_x8(v0, v1, t2);
+          aT[Ti][0] = t2[0]; aT[Ti][1] = t2[1];
+        } else {
+          split3_x8(v0, v1, aT[Ti]);
+        }
       }
     }
     PHASE(7);                                        // dW3 + dz2^T gathers
     float dz1[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dz1[q] = dacc[q >> 2][q & 3] * fmaf(-h1[q], h1[q], 1.f);
+    for (int q = 0; q < 16; ++q) {
+      // CH 3: h1 carries 2^14; (h1 x -2^-28) h1 + 1 rounds once, like the plain form
+      const float nh = F16 ? h1[q] * -0x1p-28f : -h1[q];
+      dz1[q] = dacc[q >> 2][q & 3] * fmaf(nh, h1[q], 1.f);
+    }
     wave_lds_sync();
     scatter_S16<TS16>(TA, h1, s, g);
     scatter_S16<TS16>(TB, dz1, s, g);
@@ -675,18 +966,31 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       for (int Tj = 0; Tj < 2; ++Tj) {
         const f32x4* row = reinterpret_cast<const f32x4*>(TA + (32 * Tj + (lane & 31)) * TS16 +
                                                           8 * (lane >> 5));
-        u32x4 bT[3];
-        split3_x8(row[0], row[1], bT);
+        if constexpr (F16) {
+          u32x4 bT[2];
+          split2_x8(row[0], row[1], bT);
 #pragma unroll
-        for (int Ti = 0; Ti < 2; ++Ti) {
-          f32x16 acc = gW2w[Ti][Tj];
-          acc = mfma_b32(aT[Ti][2], bT[0], acc);
-          acc = mfma_b32(aT[Ti][0], bT[2], acc);
-          acc = mfma_b32(aT[Ti][1], bT[1], acc);
-          acc = mfma_b32(aT[Ti][1], bT[0], acc);
-          acc = mfma_b32(aT[Ti][0], bT[1], acc);
-          acc = mfma_b32(aT[Ti][0], bT[0], acc);
-          gW2w[Ti][Tj] = acc;
+          for (int Ti = 0; Ti < 2; ++Ti) {
+            f32x16 acc = gW2w[Ti][Tj];
+            acc = mfma_h32(aT[Ti][1], bT[0], acc);
+            acc = mfma_h32(aT[Ti][0], bT[1], acc);
+            acc = mfma_h32(aT[Ti][0], bT[0], acc);
+            gW2w[Ti][Tj] = acc;
+          }
+        } else {
+          u32x4 bT[3];
+          split3_x8(row[0], row[1], bT);
+#pragma unroll
+          for (int Ti = 0; Ti < 2; ++Ti) {
+            f32x16 acc = gW2w[Ti][Tj];
+            acc = mfma_b32(aT[Ti][2], bT[0], acc);
+            acc = mfma_b32(aT[Ti][0], bT[2], acc);
+            acc = mfma_b32(aT[Ti][1], bT[1], acc);
+            acc = mfma_b32(aT[Ti][1], bT[0], acc);
+            acc = mfma_b32(aT[Ti][0], bT[1], acc);
+            acc = mfma_b32(aT[Ti][0], bT[0], acc);
+            gW2w[Ti][Tj] = acc;
+          }
         }
       }
     }
@@ -730,6 +1034,35 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     for (int k = 0; k < 12; ++k) dst[k] = ph[k];
   }
   if constexpr (FWD) return;
+
+  if constexpr (F16) {
+    // back from the wave's unit (powers of two: exact); factor by factor, so that no product of
+    // factors leaves the normal range on its own
+    const float inv_s = pow2i(e_run - kF16Top);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      gb2w[x] *= inv_s;
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gW2w[x][y][r] = gW2w[x][y][r] * inv_s * 0x1p-14f;   // h1's 2^14
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      gb1[x] = gb1[x] * inv_s * bwd_unit;                                    // the W2 image's scale
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gW3[x][r] *= inv_s;
+#pragma unroll
+        for (int y = 0; y < XT; ++y) gW1[x][y][r] = gW1[x][y][r] * inv_s * bwd_unit;
+      }
+#pragma unroll
+      for (int y = 0; y < (XR > 0 ? XR : 1); ++y) gW1r[x][y] = gW1r[x][y] * inv_s * bwd_unit;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gHead[r] *= inv_s;
+  }
 
   // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
   // `G[i] += v` per wave in turn would be a dependent LDS read-modify-write per element (the
@@ -1734,8 +2067,8 @@ int by_inputs(bool actor, int blocks, hipStream_t stream, const MlpArgs& args) {
 }  // namespace
 
 int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
-  auto kernel = mlp64_grad16_kernel<5, 1, 1, 6, true, true, 0, true>;
-  constexpr int lds_bytes = Lds16<5, 6, 0>::BYTES;
+  auto kernel = mlp64_grad16_kernel<5, 1, 1, 6, true, true, 3, true>;     // the shipped arithmetic
+  constexpr int lds_bytes = Lds16<5, 6, 3>::BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) { set_error("probe: %s", hipGetErrorString(e)); return TONIC_ERR_LAUNCH; }
@@ -1746,12 +2079,14 @@ int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
 
 // The critic's forward over a whole batch: values -> args.out1 (chain as launch_grad16)
 int launch_values16(int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
+  if (chain == 3) return values_by_inputs<3>(blocks, stream, args);
   if (chain == 2) return values_by_inputs<2>(blocks, stream, args);
   return chain == 1 ? values_by_inputs<1>(blocks, stream, args)
                     : values_by_inputs<0>(blocks, stream, args);
 }
 
 int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
+  if (chain == 3) return by_inputs<3>(actor, blocks, stream, args);
   if (chain == 2) return by_inputs<2>(actor, blocks, stream, args);
   return chain == 1 ? by_inputs<1>(actor, blocks, stream, args)
                     : by_inputs<0>(actor, blocks, stream, args);
