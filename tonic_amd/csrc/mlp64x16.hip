@@ -70,14 +70,15 @@ struct Lds16 {
   static constexpr int HC = W3P + AP * 64;               // [8][8] head constants
   static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
   static constexpr int SC = NORM + 8 * KS1;              // CH 3: {max |W2| bits, 1 / forward scale,
-                                                         //        1 / backward weight scale, max |W3|}
+                                                         //        1 / backward weight scale, max |W3|,
+                                                         //        1 / (head image scale x 2^14 of h2)}
   // CH 3, policies with more than one action: the head's two products on fp32 MFMA tiles.  Row
   // 4 g + r of the forward image is action g + 4 r, so lane group g of a tile ends up with the
   // outputs of actions g and g + 4 — the k index those actions have in the backward product — and
   // every group does the loss arithmetic of ITS actions only.
   static constexpr int HSLOTS = (AP + 3) / 4;            // actions per lane group
   static constexpr bool HM = CH == 3 && AP > 1;
-  static constexpr int W3F = SC + 8;                     // [4 c][64 lanes][4 e]: W3[action(row)][feat16(4c+e, g)]
+  static constexpr int W3F = SC + 8;                     // [2 m][2 terms][64 lanes][8 fp16]: W3[action(row)][feat16(8m+e, g)] x 2^(14 - w3_exp)
   static constexpr int W3B = W3F + (HM ? 1024 : 0);      // [HSLOTS c][64 lanes][4 T]: W3[g + 4c][16 T + i]
   static constexpr int WAVE0 = (W3B + (HM ? HSLOTS * 256 : 0) + 3) / 4 * 4;
   static constexpr int T_FLOATS = 64 * TS;
@@ -177,6 +178,14 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
 #pragma unroll
     for (int u = 0; u < kPer; ++u) w2v[u] = W2[tid + u * nth];
     if constexpr (CH == 3) {
+      if (tid < 64) {           // max |W3| over the live heads: bounds dz2 from the head gradients
+        const int nout = ACTOR ? A : 1;
+        float m3 = 0.f;
+        for (int aa = 0; aa < nout; ++aa) m3 = fmaxf(m3, fabsf(W3[aa * 64 + tid]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        if (tid == 0) lds[L::SC + 3] = m3;
+      }
       float m = 0.f;
 #pragma unroll
       for (int u = 0; u < kPer; ++u) m = fmaxf(m, fabsf(w2v[u]));
@@ -263,25 +272,26 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
     lds[L::B2P + idx] = b2[feat16(q, g)] * kTanhScale * (CH == 3 ? pow2i(2 * kF16Top - 2 - w_exp) : 1.f);
   }
   if constexpr (L::HM) {
+    // head images (behind the barrier of the W2 block: SC + 3 holds max |W3|)
     const int nout = ACTOR ? A : 1;
+    int w3_exp = __builtin_amdgcn_frexp_expf(lds[L::SC + 3]);
+    w3_exp = w3_exp < -60 ? -60 : (w3_exp > 60 ? 60 : w3_exp);
+    if (tid == 0) lds[L::SC + 4] = pow2i(w3_exp - 2 * kF16Top);
+    unsigned short* img = reinterpret_cast<unsigned short*>(lds + L::W3F);
     for (int idx = tid; idx < 1024; idx += nth) {
-      const int e = idx & 3, l = (idx >> 2) & 63, c = idx >> 8, i = l & 15, gg = l >> 4;
+      const int e = idx & 7, l = (idx >> 3) & 63, m = idx >> 9, i = l & 15, gg = l >> 4;
       const int aa = (i >> 2) + 4 * (i & 3);
-      lds[L::W3F + idx] = ((i & 3) < L::HSLOTS && aa < nout) ? W3[aa * 64 + feat16(4 * c + e, gg)] : 0.f;
+      const float w = ((i & 3) < L::HSLOTS && aa < nout) ? W3[aa * 64 + feat16(8 * m + e, gg)] : 0.f;
+      unsigned hi, lo;
+      split2_pair(w * pow2i(kF16Top - w3_exp), 0.f, hi, lo);
+      img[((m * 2 + 0) * 64 + l) * 8 + e] = (unsigned short)hi;
+      img[((m * 2 + 1) * 64 + l) * 8 + e] = (unsigned short)lo;
     }
     for (int idx = tid; idx < L::HSLOTS * 256; idx += nth) {
       const int T = idx & 3, l = (idx >> 2) & 63, c = idx >> 8, i = l & 15, gg = l >> 4;
       const int aa = gg + 4 * c;
       lds[L::W3B + idx] = aa < nout ? W3[aa * 64 + 16 * T + i] : 0.f;
     }
-  }
-  if (CH == 3 && tid < 64) {               // max |W3| over the live heads: bounds dz2 from the head gradients
-    const int nout = ACTOR ? A : 1;
-    float m = 0.f;
-    for (int aa = 0; aa < nout; ++aa) m = fmaxf(m, fabsf(W3[aa * 64 + tid]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (tid == 0) lds[L::SC + 3] = m;
   }
   for (int idx = tid; idx < AP * 64; idx += nth) {
     const int aa = idx >> 6, g = (idx >> 4) & 3, q = idx & 15;
@@ -659,7 +669,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   if (!ACTOR && tile < ntiles) load_tile(tile, cur);
   stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
   __syncthreads();
-  float fwd_unit = 1.f, bwd_unit = 1.f, w3_bound = 0.f;
+  float fwd_unit = 1.f, bwd_unit = 1.f, w3_bound = 0.f, head_unit = 1.f;
+  if constexpr (HM)
+    head_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 4])));
   if constexpr (F16) {
     fwd_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 1])));
     bwd_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 2])));
@@ -712,22 +724,32 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       else if constexpr (F16) chain64_f2(lds + L::W2S, h1, lane, acc);
       else chain64_b3(lds + L::W2S, h1, lane, acc);
       PHASE(2);
-      if constexpr (F16) tanh16<0, true>(acc, h2, fwd_unit);
+      if constexpr (HM) tanh16<kF16Top, true>(acc, h2, fwd_unit);     // h2 x 2^14 as well: the head's operand
+      else if constexpr (F16) tanh16<0, true>(acc, h2, fwd_unit);
       else tanh16(acc, h2);
       PHASE(3);
     }
     if constexpr (HM) {
-      // z^T[row][sample] = W3 . h2 on 16 MFMAs: lane (s, g) receives the rows 4 g + r = actions g + 4 r
+      // z^T[row][sample] = W3 . h2 on fp16x2 terms, six MFMAs: lane (s, g) receives the rows 4 g + r =
+      // actions g + 4 r, in the unit 1 / head_unit
       f32x4 zacc = zero4;
-      const f32x4* w3f = reinterpret_cast<const f32x4*>(lds + L::W3F);
+      const u32x4* w3f = reinterpret_cast<const u32x4*>(lds + L::W3F);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 w = w3f[c * 64 + lane];
+      for (int m = 0; m < 2; ++m) {
+        u32x4 bh, bl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) zacc = mfma16(w[e], h2[4 * c + e], zacc);
+        for (int p = 0; p < 4; ++p) {
+          unsigned h, l;
+          split2_pair(h2[8 * m + 2 * p], h2[8 * m + 2 * p + 1], h, l);
+          bh[p] = h; bl[p] = l;
+        }
+        const u32x4 wh = w3f[(m * 2 + 0) * 64 + lane], wl = w3f[(m * 2 + 1) * 64 + lane];
+        zacc = mfma_h16(wl, bh, zacc);
+        zacc = mfma_h16(wh, bl, zacc);
+        zacc = mfma_h16(wh, bh, zacc);
       }
 #pragma unroll
-      for (int r = 0; r < NS; ++r) z[r] = zacc[r];          // + bias: with the head constants below
+      for (int r = 0; r < NS; ++r) z[r] = zacc[r];          // x head_unit + bias: with the head constants below
     } else {
       // W3 operands through a rolling window of kW3Window LDS reads in flight: the plain loop
       // (read 16 bytes, wait, four FMAs, next) exposed 24 LDS round trips per tile
@@ -763,7 +785,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       for (int r = 0; r < NS; ++r) {
         const int aa = HM ? g + 4 * r : r;                 // HM: this lane group's actions only
         const f32x4 hc = *reinterpret_cast<const f32x4*>(lds + L::HC + aa * 8);
-        loc[r] = tanh_fast(HM ? z[r] + hc[0] : z[r]);
+        loc[r] = tanh_fast(HM ? fmaf(z[r], head_unit, hc[0]) : z[r]);
         const float act = valid ? in_act[r] : loc[r];
         dif[r] = act - loc[r];
         const float term = -(dif[r] * dif[r]) * hc[2] - hc[3];
@@ -860,8 +882,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float y = h2[q];
-        h2[q] = hacc[q >> 2][q & 3] * fmaf(-y, y, 1.f);
+        const float y = h2[q];                             // x 2^14
+        h2[q] = hacc[q >> 2][q & 3] * fmaf(y * -0x1p-28f, y, 1.f);
       }
     } else {
       const f32x4* w3p = reinterpret_cast<const f32x4*>(lds + L::W3P) + g * 4;
@@ -1053,7 +1075,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       gb1[x] = gb1[x] * inv_s * bwd_unit;                                    // the W2 image's scale
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        gW3[x][r] *= inv_s;
+        gW3[x][r] = HM ? gW3[x][r] * inv_s * 0x1p-14f : gW3[x][r] * inv_s;         // HM: h2's 2^14
 #pragma unroll
         for (int y = 0; y < XT; ++y) gW1[x][y][r] = gW1[x][y][r] * inv_s * bwd_unit;
       }
