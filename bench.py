@@ -164,12 +164,14 @@ def kernel_rooflines(agent):
     # quoted such a loop (286 us) where rocprofv3 averaged 307 us over the job's launches.
     ws, wsc = actor._workspace_for(n), critic._workspace_for(n)
 
-    def as_in_the_job(fn, launches=ITERATIONS, rounds=2, idle_s=0.042):
+    def as_in_the_job(fn, launches=ITERATIONS, rounds=2, idle_s=0.042, before=None):
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         total = 0.0
         for _ in range(rounds):
             torch.cuda.synchronize()
             time.sleep(idle_s)
+            for _ in range(launches if before is not None else 0):
+                before()
             start.record()
             for _ in range(launches):
                 fn()
@@ -178,7 +180,11 @@ def kernel_rooflines(agent):
             total += start.elapsed_time(end)
         return total / (rounds * launches)
     steady_a, steady_c = time_events(actor_grad, 120), time_events(critic_grad, 120)
-    ms_a, ms_c = as_in_the_job(actor_grad), as_in_the_job(critic_grad)
+    # (the PPO agent holds the critic's chain back to the END of the rollout — tonic_stream_gate — so the
+    #  actor's launches follow 80 critic launches, and the critic's follow the lightly loaded phase)
+    gated = os.environ.get('TONIC_AMD_CRITIC_GATE', '1') != '0'
+    ms_a = as_in_the_job(actor_grad, idle_s=0.022, before=critic_grad) if gated else as_in_the_job(actor_grad)
+    ms_c = as_in_the_job(critic_grad, idle_s=0.022 if gated else 0.042)
     out[shipped] = (steady_a, steady_c)
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
@@ -199,8 +205,10 @@ def kernel_rooflines(agent):
                 mixed_ceiling_tflops=round(mixed_ceiling_tflops(share, rate), 1),
                 rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
                 ms_per_launch=round(ms_a, 4), launches_timed=2 * ITERATIONS,
-                timed_as='80 launches behind a 42 ms lightly loaded phase, twice (the job\'s pattern: the '
-                         'clock ramps during them)',
+                timed_as=('80 launches behind a 22 ms lightly loaded phase and the critic\'s 80 launches, twice '
+                          '(the job\'s pattern with the critic chain gated to the end of the rollout)' if gated
+                          else '80 launches behind a 42 ms lightly loaded phase, twice (the job\'s pattern: the '
+                               'clock ramps during them)'),
                 steady_state=dict(ms_per_launch=round(steady_a, 4), launches_timed=120,
                                   achieved=round(ACTOR_FLOP_PER_SAMPLE * n / (steady_a * 1e-3) / 1e12, 2),
                                   frac=round(ACTOR_FLOP_PER_SAMPLE * n / (steady_a * 1e-3) / 1e12
@@ -634,11 +642,15 @@ def cfg1_plumbing(steps=3):
         O, A, W = saved
 
 
-def timed_steps(run_one, steps, warmup, world):
-    """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time."""
+def timed_steps(run_one, steps, warmup, world, finish=None):
+    """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time.  `finish`
+    (agent.settle): whatever the last step left running is waited for INSIDE the timed region — PPO's
+    critic iterations, which a running job finishes under its next rollout, are finished here."""
     import torch
 
     def barrier():
+        if finish is not None:
+            finish()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -663,7 +675,7 @@ def measure_job(workers, rank, world, steps, warmup, capture, device_too=True):
     from tonic_amd.rollout import DeviceRollout
     agent = build_agent(seed=0)                      # same seed: replicated parameters
     loop = HostLoop(agent, workers, seed=1 + rank)
-    elapsed = timed_steps(lambda: loop.run(T), steps, warmup, world)
+    elapsed = timed_steps(lambda: loop.run(T), steps, warmup, world, finish=agent.settle)
     out = dict(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3,
                value=world * T * workers * steps / elapsed,
                actor_iterations=int((agent.last_infos[0][:, 6] > 0).sum()))
@@ -993,6 +1005,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         loop.run(1)                                       # the T-th update() runs the learner
+        agent.settle()                                    # (incl. the critic's iterations it left running)
         torch.cuda.synchronize()
         result['collect_ms'] = round((t1 - t0) * 1e3 * T / (T - 1), 3)
         result['update_ms'] = round((time.perf_counter() - t1) * 1e3, 3)
@@ -1002,6 +1015,10 @@ def main():
         # device time of the critic's 80 iterations of that update, which ran under the rollout's
         # remaining steps on the second stream (0 when the overlap is off)
         result['critic_chain_ms'] = round(getattr(agent, 'critic_chain_ms', 0.0), 3)
+        # ... and of the actor's 80 iterations (grad + fold + Adam each) of the last update, by events
+        result['actor_chain_ms'] = round(getattr(agent, 'actor_chain_ms', 0.0), 3)
+        result['config']['critic_chain_gated'] = bool(
+            getattr(agent, '_gate_ticket', 0)) and os.environ.get('TONIC_AMD_CRITIC_GATE', '1') != '0'
     if rank == 0 and not args.no_extras and not args.quick_extras and world == 1:
         roof, roof_c, roof_g = kernel_rooflines(agent)
         result['roofline'] = roof

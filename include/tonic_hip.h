@@ -51,7 +51,7 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -423,6 +423,18 @@ int tonic_collector_arm(tonic_collector_t* collector, int64_t row, int32_t eps_s
 int tonic_collector_claim(tonic_collector_t* collector);
 int tonic_collector_end_rollout(tonic_collector_t* collector, int64_t last_row,
                                 void* learner_stream);
+
+/* ---- a gate in a stream ---------------------------------------------------------------------------
+ * replaces: nothing in the reference (ppo.py:33-46 runs the critic's iterations between the actor's;
+ *   tonic_amd runs them on a second stream under the NEXT rollout, agents.PPO._update).  Work enqueued
+ *   on `stream` behind the gate starts when the caller stores a value >= `value` into `host_word`
+ *   (page-locked host memory: a plain CPU store opens it, no launch) or after `timeout_seconds`,
+ *   whichever comes first: one wave polls the word at system scope.  PPO enqueues the critic's 160
+ *   launches while the host has nothing else to do and opens the gate at the Segment row from which
+ *   they just finish before the rollout does — the next update's first launches then find the device at
+ *   its working point (profiles/r04_clock_ramp.md).  Timing only: what the gated work computes does not
+ *   depend on when the gate opens. */
+int tonic_stream_gate(const uint32_t* host_word, uint32_t value, double timeout_seconds, void* stream);
 
 /* ---- one-shot all-reduce between the GPUs of a node -----------------------
  * replaces: nothing in the reference (single process); it is the exchange step of the sharded

@@ -520,8 +520,8 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
     256 workgroups at 256 workers), so the comparison with the interleaved launches
     (TONIC_AMD_CRITIC_OVERLAP=0) is BIT FOR BIT — every logged row of the first and the last update
     (80 actor rows, 80 critic rows each), every parameter and the normaliser after three rollouts +
-    updates.  (From the second update on the chain goes out LATE in the rollout, so that it ends a
-    margin before the rollout does: PPO._critic_start_row.)  A race
+    updates.  (From the second update on a gate holds the chain back so that it ends a margin before
+    the rollout does: PPO._arm_gate.)  A race
     on the spare observation buffer, the normaliser snapshot or the Segment cannot hide behind a
     tolerance here."""
     if _in_a_process_of_its_own(request):
@@ -587,6 +587,39 @@ def test_critic_chain_under_a_running_rollout_is_bit_identical_at_size(lib, monk
             break
     print('sampled steps that found the critic chain running:', seen)
     assert max(seen) >= 1, 'the chain must actually have run under a rollout'
+
+
+def test_stream_gate_holds_a_stream_until_the_host_stores(lib):
+    """tonic_stream_gate: work behind the gate starts when the host stores the ticket into the pinned
+    word — a plain CPU store — or when the gate's own time is up, and not before."""
+    import time
+    from tonic_amd import _lib
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    view = word.numpy()
+    side = torch.cuda.Stream()
+    target = torch.zeros(1024, device='cuda')
+    torch.cuda.synchronize()
+    for ticket, opened_by_host in ((1, True), (2, False), (3, True)):
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            _lib.check(lib.tonic_stream_gate(word.data_ptr(), ticket, 0.25, side.cuda_stream), 'gate')
+            target.add_(1.0)
+            done.record(side)
+        time.sleep(0.05)
+        assert not done.query(), 'the gate must hold the stream'
+        t0 = time.perf_counter()
+        if opened_by_host:
+            view[0] = ticket
+        done.synchronize()
+        waited = time.perf_counter() - t0
+        assert (waited < 0.05) if opened_by_host else (0.1 < waited < 0.4), (ticket, waited)
+    assert float(target[0]) == 3.0
+    # a ticket that is already there does not hold anything
+    with torch.cuda.stream(side):
+        _lib.check(lib.tonic_stream_gate(word.data_ptr(), 3, 5.0, side.cuda_stream), 'gate')
+    t0 = time.perf_counter()
+    side.synchronize()
+    assert time.perf_counter() - t0 < 0.05
 
 
 def test_completion_words_order_the_actions(lib):

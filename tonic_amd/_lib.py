@@ -141,6 +141,7 @@ SIGNATURES = {
     'tonic_comm_status': (ctypes.c_int, [c_vp]),
     'tonic_comm_set_timeout': (ctypes.c_int, [c_vp, c_f64]),
     'tonic_comm_can_access_peer': (ctypes.c_int, [c_i32, c_i32]),
+    'tonic_stream_gate': (ctypes.c_int, [c_vp, ctypes.c_uint32, c_f64, c_vp]),
     'tonic_comm_destroy': (ctypes.c_int, [c_vp]),
     'tonic_debug_grad16_phases': (ctypes.c_int, [c_vp] * 6 + [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'tonic_debug_forward_stamps': (ctypes.c_int, [c_vp]),
@@ -149,7 +150,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 6        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 7        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

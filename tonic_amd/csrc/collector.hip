@@ -812,6 +812,31 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
   return TONIC_OK;
 }
 
+// ---- tonic_stream_gate: one wave holds a stream until the host stores to a pinned word
+namespace {
+__global__ __launch_bounds__(64) void stream_gate_kernel(const unsigned* word, unsigned value,
+                                                         unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value &&
+         wall_clock64() - t0 < ticks)
+    for (int k = 0; k < 3; ++k) __builtin_amdgcn_s_sleep(127);   // ~5 us between polls of the host's cache line
+}
+}  // namespace
+
+extern "C" int tonic_stream_gate(const uint32_t* host_word, uint32_t value, double timeout_seconds,
+                                 void* stream) {
+  TONIC_REQUIRE(host_word != nullptr && timeout_seconds > 0.0 && timeout_seconds <= 3600.0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_stream_gate: bad argument");
+  void* device_word = nullptr;
+  TONIC_HIP(hipHostGetDevicePointer(&device_word, const_cast<uint32_t*>(host_word), 0),
+            "tonic_stream_gate: the word is not page-locked host memory");
+  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                     static_cast<const unsigned*>(device_word), value,
+                     (unsigned long long)(timeout_seconds * 1e8));
+  TONIC_CHECK_LAUNCH("tonic_stream_gate");
+  return TONIC_OK;
+}
+
 // ---- test tool (include/tonic_hip_dev.h)
 namespace {
 __global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks) {

@@ -21,6 +21,7 @@ generator, a2c.py:87-90) first rewinds the generator to where the reference woul
 import ctypes
 import os
 import random
+import time
 import weakref
 
 import numpy as np
@@ -604,6 +605,7 @@ class A2C(Agent):
             self._rollout_behind = None
 
     def test_step(self, observations, steps):
+        self._open_gate()       # (the current stream waits for the critic's iterations: let them start)
         noise = getattr(self, '_noise', None)
         if noise is not None:
             self._settle()          # (a step issued ahead reads the slot: let it finish first)
@@ -639,6 +641,9 @@ class A2C(Agent):
                 self._collector.ppo_step(index + 1, self._slot, True)
             self._speculated = True
             replay.index = index + 1
+            gate = self._gate_row
+            if gate is not None and index >= gate:
+                self._open_gate()
             normalizer = self.model.observation_normalizer
             if normalizer:
                 normalizer.new_count += block.workers             # (note_device_rows)
@@ -676,10 +681,15 @@ class A2C(Agent):
             raise NotImplementedError('return normalisers are not supported (never enabled by '
                                       'the reference defaults)')
         replay.index += 1
+        if self._gate_row is not None and replay.index > self._gate_row:
+            self._open_gate()
         if self.model.observation_normalizer:
             self.model.observation_normalizer.note_device_rows(block.workers)
         self._pending = not self._speculated
         if replay.ready():
+            started = getattr(self, '_rollout_started', None)
+            if started is not None:          # host time per environment step of the rollout that ends here
+                self._rollout_step_us = (time.perf_counter() - started) * 1e6 / replay.max_size
             self._collector.end_rollout(replay.index - 1)
             self._pending, self._rollout_open = False, False
             # (this rollout came through the collector, which binds the Segment's buffers anew at
@@ -689,6 +699,12 @@ class A2C(Agent):
                 self._update()
             finally:
                 self._host_rollout = False
+
+    # (PPO: the row of the running rollout at which the gate in front of the critic's iterations opens)
+    _gate_row = None
+
+    def _open_gate(self):
+        self._gate_row = None
 
     def _evaluate(self):
         """a2c.py:92-99 on the HBM-resident segment: fills values / next_values in place."""
@@ -919,6 +935,7 @@ class PPO(A2C):
         pending = getattr(self, '_critic_pending', None)
         if pending is None:
             return
+        self._open_gate()
         self._critic_pending = None
         torch.cuda.current_stream().wait_event(pending['done'])   # whoever reads the critic next is behind it
         rows = pending['infos'][1].cpu().numpy()
@@ -963,9 +980,12 @@ class PPO(A2C):
             replays.flatten_batch(buffers[k]) for k in replays.segments.LEARNER_KEYS)
         replay.index = 0
         n = obs.shape[0]
+        first, last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        first.record()
         for it in range(updates):
             actor.enqueue_grad(obs, act, raw_adv, replay.adv_stats, log_probs)
             actor.enqueue_step(n, replay.adv_stats, infos[0, it])
+        last.record()
         # the critic's iterations: same inputs, the normaliser as it is NOW, their own stream
         snapshot = tuple(t.clone() for t in critic.norm_tensors())
         ready = torch.cuda.Event()
@@ -978,6 +998,7 @@ class PPO(A2C):
         side.wait_event(ready)
         clock, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(side):
+            self._arm_gate(side)
             clock.record(side)
             for it in range(updates):
                 critic.enqueue_grad(obs, returns, norm=snapshot)
@@ -990,6 +1011,7 @@ class PPO(A2C):
         #  host-bound collect loop's critical path, 82.3 against 80.9 ms per step.)
         self._critic_pending = dict(done=done, clock=clock, infos=infos, keep=(obs, returns, snapshot))
         rows = infos[0].cpu().numpy()                    # waits for the actor's iterations only
+        self.actor_chain_ms = first.elapsed_time(last)   # (bench.py reports it)
         parallel.check_one_shot()
         logger.store('actor/iterations', log_ppo_actor_rows(rows))
         self._last_infos = np.stack([rows, np.zeros_like(rows)])
@@ -1009,6 +1031,48 @@ class PPO(A2C):
         self._rollout_marker.wait_event(ordered)
         self._rollout_behind = self._rollout_marker
         torch.cuda.current_stream().wait_event(done)
+        self._rollout_started = time.perf_counter()
+
+    # The critic's launches are enqueued above, while the host has nothing else to do, but they need not
+    # START there: behind a phase in which the device is lightly loaded (a rollout keeps a few compute
+    # units polling) the next update's first launches run 10 - 25 % slower until the device's power
+    # management has followed the load (~25 ms: the whole actor chain, profiles/r04_clock_ramp.md).  A gate
+    # (tonic_stream_gate: one polling wave) holds the chain back until the row of the NEXT rollout from
+    # which it just finishes before that rollout does — the host opens it with a plain store from
+    # agent.update — so the update that follows starts on a device at its working point.  Timing only;
+    # whoever needs the critic (settle), the current stream (test_step) or a rollout slower than the
+    # last one (the gate's own limit) opens it as well.  TONIC_AMD_CRITIC_GATE=0: the chain starts at once.
+    GATE_MARGIN_MS = 1.0
+    GATE_ROLLOUT_US = 100e3
+
+    def _arm_gate(self, side):
+        self._gate_row = None
+        chain_ms, step_us = getattr(self, 'critic_chain_ms', None), getattr(self, '_rollout_step_us', None)
+        if os.environ.get('TONIC_AMD_CRITIC_GATE', '1') == '0' or not chain_ms or not step_us:
+            return
+        rows = self.replay.max_size
+        row = rows - int(np.ceil((1.1 * chain_ms + self.GATE_MARGIN_MS) * 1e3 / step_us))
+        if row <= 0 or rows * step_us > self.GATE_ROLLOUT_US:
+            # the chain needs the whole rollout / a rollout much longer than the device's ramp: nothing to
+            # gain, and a polling wave must not sit in a hardware queue for long (HIP streams share a
+            # handful of them: whatever another stream launches into that queue waits behind the gate)
+            return
+        if getattr(self, '_gate_word', None) is None:
+            self._gate_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._gate_view = self._gate_word.numpy()
+            self._gate_ticket = 0
+        self._gate_ticket += 1
+        # (its own limit: twice the time the host needs to that row — nobody who synchronises the device
+        #  without asking the agent first waits longer than that)
+        limit = max(0.01, 2.0 * row * step_us * 1e-6 + 0.005)
+        _lib.check(_lib.load().tonic_stream_gate(self._gate_word.data_ptr(), self._gate_ticket, limit,
+                                                 side.cuda_stream), 'stream gate')
+        self._gate_row = row
+
+    def _open_gate(self):
+        if self._gate_row is not None:
+            self._gate_view[0] = self._gate_ticket
+            self._gate_row = None
 
     def _guard_critic_readers(self):
         """Whoever reads the critic through torch — a forward pass of the module, state_dict() —
