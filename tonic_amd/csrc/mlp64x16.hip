@@ -575,6 +575,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // Column sums of the per-sample head gradients (db3 = sum dz, d loss/d sigma) ride on the dW3
   // MFMAs: one more chain against a B operand of ones (rows 0..7 -> db3[a], rows 8..15 -> dsigma[a]).
   f32x4 gHead = {0.f, 0.f, 0.f, 0.f};
+  // HM: those sums per lane instead (slot r of lane group g = action g + 4 r; folded over the 16 sample
+  // lanes once, at the end): four adds per tile for four fp32 MFMAs, which no VALU work can hide behind
+  float hb[2] = {0.f, 0.f}, hsg[2] = {0.f, 0.f};
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
   // CH 3: every gradient accumulator above holds (true sum) x 2^(kF16Top - e_run) [x a constant of
@@ -611,6 +614,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) gHead[r] *= f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { hb[r] *= f; hsg[r] *= f; }
       e_run = e_new;
       s_run = pow2i(kF16Top - e_new);
     }
@@ -679,6 +684,11 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     w3_bound = 2.f * __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 3])));
   }
   if (ACTOR && tile < ntiles) load_tile(tile, cur);
+  if constexpr (HM) {
+    DO[128 + lane] = 0.f;              // rows 8 .. 15 of dO^T: never written again
+    DO[192 + lane] = 0.f;
+    wave_lds_sync();
+  }
   for (; tile < ntiles; tile += tile_stride) {
     PHASE(11);                                       // loop overhead / previous tail
     const int64_t ns = tile * 16 + s;
@@ -823,9 +833,10 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
         const float live = ((EXACT && !HM) || aa < A) ? 1.f : 0.f;
         dzl[r] = live * dloc * (1.f - loc[r] * loc[r]);
         dsg[r] = live * gl * (dif[r] * dif[r] * hs[1] * hs[0] - hs[0]);
-        if constexpr (HM) {                                // row s of dO: [dz of 8 actions | dsigma of 8]
-          DO[s * 16 + aa] = dzl[r];
-          DO[s * 16 + 8 + aa] = dsg[r];
+        if constexpr (HM) {                                // dO^T: row = action, 16 samples
+          DO[aa * 16 + s] = dzl[r];
+          hb[r] += dzl[r];
+          hsg[r] += dsg[r];
         }
       }
       if constexpr (!HM) {
@@ -923,10 +934,17 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     // dW3[a][f] += dO^T . h2  (MFMA: rows = action index, padded to 16)
     {
       float aop[4];
+      if constexpr (HM) {
+        // rows 8 .. 15 of dO^T were zeroed once: those rows of gW3 are not used
+        const f32x4 row = *reinterpret_cast<const f32x4*>(DO + i * 16 + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) aop[e] = DO[(4 * g + e) * 16 + i];
+        for (int e = 0; e < 4; ++e) aop[e] = row[e];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gHead = mfma16(aop[e], 1.f, gHead);
+        for (int e = 0; e < 4; ++e) aop[e] = DO[(4 * g + e) * 16 + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gHead = mfma16(aop[e], 1.f, gHead);
+      }
 #pragma unroll
       for (int T = 0; T < 4; ++T) {
         const f32x4 hF = gather_F16<TS16>(TA, T, i, g);
@@ -1084,6 +1102,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) gHead[r] *= inv_s;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { hb[r] *= inv_s; hsg[r] *= inv_s; }
   }
 
   // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
@@ -1152,8 +1172,21 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
           if (lane < 32) IMG[ob2 + 32 * Ti + lane] = v2;
         }
       }
-      // gHead rows: lane (j, g), reg r -> row 4g + r (every column j holds the same sum)
-      if (s == 0) {
+      if constexpr (HM) {
+        // per-lane head sums -> over the 16 samples of the lane's row, then lane s = 0 of group g
+        // stores the sums of its actions g + 4 r
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          float vb = hb[r], vs = hsg[r];
+          vb += dpp_lane<0xB1>(vb); vs += dpp_lane<0xB1>(vs);        // quad_perm [1, 0, 3, 2]
+          vb += dpp_lane<0x4E>(vb); vs += dpp_lane<0x4E>(vs);        // quad_perm [2, 3, 0, 1]
+          vb += dpp_lane<0x141>(vb); vs += dpp_lane<0x141>(vs);      // row_half_mirror
+          vb += dpp_lane<0x140>(vb); vs += dpp_lane<0x140>(vs);      // row_mirror
+          const int aa = g + 4 * r;
+          if (s == 0 && aa < nout) { IMG[ob3 + aa] = vb; IMG[oLs + aa] = vs; }
+        }
+      } else if (s == 0) {
+        // gHead rows: lane (j, g), reg r -> row 4g + r (every column j holds the same sum)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * g + r;
