@@ -525,6 +525,10 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // heads on MFMA (Lds16::HM): NS action slots per lane, slot r of lane group g = action g + 4 r
   constexpr bool HM = L::HM && ACTOR;
   constexpr int NS = HM ? L::HSLOTS : AP;
+  // one head output (the critic, one-action policies) in the fp16x2 kernels: dW3 = sum_s dz_s h2_s is a
+  // 64-vector — sixteen FMAs per lane and tile instead of sixteen fp32 MFMAs on a 16-row tile with
+  // one live row (+ 4 for the bias sum), no h2^T / dO tiles; folded over the sample lanes at the end
+  constexpr bool H1 = F16 && AP == 1;
   // LDS reads of head weights kept in flight (4 registers each); the widest bucket has none to spare
   constexpr int kW3Window = KS1 >= 8 ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -578,6 +582,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // HM: those sums per lane instead (slot r of lane group g = action g + 4 r; folded over the 16 sample
   // lanes once, at the end): four adds per tile for four fp32 MFMAs, which no VALU work can hide behind
   float hb[2] = {0.f, 0.f}, hsg[2] = {0.f, 0.f};
+  float gW3s[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) gW3s[q] = 0.f;
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
   // CH 3: every gradient accumulator above holds (true sum) x 2^(kF16Top - e_run) [x a constant of
@@ -616,6 +623,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       for (int r = 0; r < 4; ++r) gHead[r] *= f;
 #pragma unroll
       for (int r = 0; r < 2; ++r) { hb[r] *= f; hsg[r] *= f; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gW3s[q] *= f;
       e_run = e_new;
       s_run = pow2i(kF16Top - e_new);
     }
@@ -839,7 +848,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
           hsg[r] += dsg[r];
         }
       }
-      if constexpr (!HM) {
+      if constexpr (H1) {
+        hsg[0] += dsg[0];
+      } else if constexpr (!HM) {
         if (g == 0) {
           f32x4 lo = zero4, hi = zero4;
 #pragma unroll
@@ -861,16 +872,24 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       st0 += cw * err * err;
       st1 += cw * z[0];
       st3 += cw;
-      if (g == 0) {
-        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = zero4;
-        reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = zero4;
+      if constexpr (!H1) {
+        if (g == 0) {
+          reinterpret_cast<f32x4*>(DO + s * 16 + 8)[0] = zero4;
+          reinterpret_cast<f32x4*>(DO + s * 16 + 8)[1] = zero4;
+        }
       }
     }
 
     PHASE(4);                                        // head + loss
     // ---- backward
-    scatter_S16<TS16>(TA, h2, s, g);                       // h2^T for dW3
-    if constexpr (!HM) {
+    if constexpr (H1) {
+      hb[0] += dzl[0];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gW3s[q] = fmaf(dzl[0], h2[q], gW3s[q]);
+    } else {
+      scatter_S16<TS16>(TA, h2, s, g);                     // h2^T for dW3
+    }
+    if constexpr (!HM && !H1) {
       if (g == 0) {
         f32x4 lo = zero4, hi = zero4;
 #pragma unroll
@@ -932,7 +951,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     PHASE(6);
 
     // dW3[a][f] += dO^T . h2  (MFMA: rows = action index, padded to 16)
-    {
+    if constexpr (!H1) {
       float aop[4];
       if constexpr (HM) {
         // rows 8 .. 15 of dO^T were zeroed once: those rows of gW3 are not used
@@ -1104,6 +1123,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     for (int r = 0; r < 4; ++r) gHead[r] *= inv_s;
 #pragma unroll
     for (int r = 0; r < 2; ++r) { hb[r] *= inv_s; hsg[r] *= inv_s; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gW3s[q] *= inv_s;
   }
 
   // ---------------- fold into the flat gradient image (same layout as mlp64_grad_kernel)
@@ -1148,10 +1169,12 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
           const float vr = sum_groups(gW1r[Ti][c]);
           if (g == 0 && 16 * XT + c < O) IMG[oW1 + (16 * Ti + i) * O + 16 * XT + c] = vr;
         }
+        if constexpr (!H1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int aa = 4 * g + r;                    // gW3[T] rows are action indices
-          if (aa < nout) IMG[oW3 + aa * 64 + 16 * Ti + s] = gW3[Ti][r];
+          for (int r = 0; r < 4; ++r) {
+            const int aa = 4 * g + r;                    // gW3[T] rows are action indices
+            if (aa < nout) IMG[oW3 + aa * 64 + 16 * Ti + s] = gW3[Ti][r];
+          }
         }
       }
       if constexpr (W2B3) {
@@ -1172,7 +1195,26 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
           if (lane < 32) IMG[ob2 + 32 * Ti + lane] = v2;
         }
       }
-      if constexpr (HM) {
+      if constexpr (H1) {
+        // per-lane sums (feature feat16(q, g), this lane's samples) -> over the 16 sample lanes of the row
+        auto row_sum = [](float v) {
+          v += dpp_lane<0xB1>(v);
+          v += dpp_lane<0x4E>(v);
+          v += dpp_lane<0x141>(v);
+          v += dpp_lane<0x140>(v);
+          return v;
+        };
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float v = row_sum(gW3s[q]);
+          if (s == 0) IMG[oW3 + feat16(q, g)] = v;
+        }
+        const float vb = row_sum(hb[0]), vs = row_sum(hsg[0]);
+        if (lane == 0) {
+          IMG[ob3] = vb;
+          if (ACTOR) IMG[oLs] = vs;
+        }
+      } else if constexpr (HM) {
         // per-lane head sums -> over the 16 samples of the lane's row, then lane s = 0 of group g
         // stores the sums of its actions g + 4 r
 #pragma unroll
