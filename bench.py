@@ -68,7 +68,7 @@ def time_events(fn, repeats):
 # binary16's range) into two fp16 terms and sum the three fp16 MFMAs that matter at fp32 precision
 # ("fp16x2"; tests/test_gpu_parity.py holds that variant to the error of the fp32-MFMA variants against
 # float64, tonic_set_tuning selects them).
-DTYPE = 'f32 (64x64 products of the grad kernels fp16x2-emulated: hi+lo split below 2^-24, fp32 accumulate)'
+DTYPE = 'f32 (64x64 products of the grad kernels fp16x2-emulated: hi+lo fp16 split of the scaled fp32 operands, 23+ significant bits, fp32 accumulate)'
 
 
 def pmc_traffic(prefix):
@@ -192,7 +192,7 @@ def kernel_rooflines(agent):
                   'fp32-equivalent: layer 1, dW1, dW3 on fp32 MFMA; the 64x64 products (h1->z2, dz2->dh1'
                   + (', dW2: 77 %' if shipped >= 3 else ': 52 %') + ' of the flops) as '
                   + ('three fp16 MFMAs per product on hi+lo fp16 splits of the power-of-two-scaled fp32 '
-                     'operands (split residual and dropped term below 2^-24)' if shipped == 4 else
+                     'operands (the split keeps 23+ significant bits; against float64 the gradient sums are as close as with fp32 MFMAs)' if shipped == 4 else
                      'six bf16 MFMAs per product on exact hi+mid+lo bf16 splits of the fp32 operands')
                   + ', fp32 accumulation.  peak stays the fp32 MFMA peak: what the same arithmetic costs '
                   'without the split')

@@ -48,9 +48,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //      |a||b|), accumulated in fp32: 48 v_mfma_f32_16x16x32_bf16 of ~18 cycles per product plus
 //      5.5 VALU instructions per activation for the split.  Weights are split once, at staging.
 //   3  fp16x2: every fp32 operand, scaled by a power of two into the top of binary16's range, is split
-//      into two fp16 terms (hi + lo, 11 + 11 bits and a sign: the residual of the split is below
-//      2^-24 of the operand, fp32's own rounding) and the product is the sum of THREE fp16 MFMAs
-//      (lo.hi, hi.lo, hi.hi; the dropped lo.lo is below 2^-24 |a||b|), fp32 accumulation: 24
+//      into two fp16 terms (hi + lo, 11 + 11 bits and the sign of lo: the split leaves at most
+//      2^-23 of the operand — 23 significant bits in the worst case, one short of fp32) and the
+//      product is the sum of THREE fp16 MFMAs (lo.hi, hi.lo, hi.hi; the dropped lo.lo is at most
+//      2^-22 |a||b|, 2^-24 rms), fp32 accumulation — against float64 the gradient sums are as close as
+//      those of the fp32-MFMA build (tests/test_gpu_parity.py, tests/test_fp16x2_arithmetic.py): 24
 //      v_mfma_f32_16x16x32_f16 per product and 2 VALU instructions per activation for the split
 //      (v_cvt_pk_f16_f32 + v_fma_mix_f32).  dW2 runs the same way on 32x32x16 tiles.  Scales: the
 //      weight images by the power of two that puts max |W2| below 2^14 (found at staging), h1 by 2^14
@@ -123,8 +125,8 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-// a = hi + lo + r, |r| <= 2^-24 |a| for |a| in [2^-2, 2^16) (below that the binary16 subnormal grid
-// 2^-24 bounds r absolutely); the residual a - hi is exact in fp32 and comes out of ONE
+// a = hi + lo + r, |r| <= 2^-23 |a| for |a| in [2^-1, 2^16) (below that the binary16 subnormal grid
+// bounds r absolutely: 2^-25); the residual a - hi is exact in fp32 and comes out of ONE
 // v_fma_mix_f32 (fp16 half of `hi` x -1 + a) — the compiler itself emits a conversion and a subtract.
 __device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsigned& lo) {
   hi = pack_f16(a, b);
