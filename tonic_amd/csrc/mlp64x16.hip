@@ -64,7 +64,11 @@ struct Lds16 {
   static constexpr int TS = CH ? 20 : 24;                // row stride of the transpose tiles
   static constexpr int kW2 = (CH == 1 || CH == 2) ? 6144 : 4096;   // floats per W2 image
   static constexpr int W1I = 0;                          // [4][KS1][64]       (b32 per step)
-  static constexpr int W2S = W1I + 4 * KS1 * 64;         // CH 0: [4][4][64][4] (b128 per 4 steps)
+  // CH 3: [4 T][2 terms][64 lanes][8 fp16]: lane group g, slot e = input XE g + e (layer 1 on fp16x2
+  // terms as well: one K = 32 block holds every input of the fused shapes, O <= 32)
+  static constexpr int XE = KS1 == 1 ? 4 : 8;
+  static constexpr int kW1 = CH == 3 ? 2048 : 4 * KS1 * 64;
+  static constexpr int W2S = W1I + kW1;                  // CH 0: [4][4][64][4] (b128 per 4 steps)
   static constexpr int W2B = W2S + kW2;                  // CH 1: [2][4][3 terms][64][8 bf16]
   static constexpr int B1P = W2B + kW2;                  // [4 groups][16]
   static constexpr int B2P = B1P + 64;
@@ -73,7 +77,8 @@ struct Lds16 {
   static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
   static constexpr int SC = NORM + 8 * KS1;              // CH 3: {max |W2| bits, 1 / forward scale,
                                                          //        1 / backward weight scale, max |W3|,
-                                                         //        1 / (head image scale x 2^14 of h2)}
+                                                         //        1 / (head image scale x 2^14 of h2),
+                                                         //        max |W1| bits, 1 / W1 image scale}
   // CH 3, policies with more than one action: the head's two products on fp32 MFMA tiles.  Row
   // 4 g + r of the forward image is action g + 4 r, so lane group g of a tile ends up with the
   // outputs of actions g and g + 4 — the k index those actions have in the backward product — and
@@ -163,13 +168,21 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   const float* tail = b2 + 64;
   const float* W3 = ACTOR ? tail + A : tail;
   const float* b3 = W3 + (ACTOR ? A * 64 : 64);
-  for (int idx = tid; idx < 4 * KS1 * 64; idx += nth) lds[L::W1I + idx] = 0.f;
-  if (CH == 3 && tid == 0) lds[L::SC] = 0.f;
+  for (int idx = tid; idx < L::kW1; idx += nth) lds[L::W1I + idx] = 0.f;
+  if (CH == 3 && tid == 0) { lds[L::SC] = 0.f; lds[L::SC + 5] = 0.f; }
   __syncthreads();
-  for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
-    const int row = gi / O, k = gi - row * O;
-    const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
-    lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi] * kTanhScale;
+  if constexpr (CH == 3) {
+    float m1 = 0.f;                                      // max |W1|: the image's scale (built below)
+    for (int gi = tid; gi < 64 * O; gi += nth) m1 = fmaxf(m1, fabsf(W1[gi]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+    if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(lds + L::SC + 5), __float_as_uint(m1));
+  } else {
+    for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
+      const int row = gi / O, k = gi - row * O;
+      const int T = row >> 4, i = row & 15, st = k >> 2, gg = k & 3;
+      lds[L::W1I + (T * KS1 + st) * 64 + gg * 16 + i] = W1[gi] * kTanhScale;
+    }
   }
   int w_exp = 0;   // CH 3: the exponent that bounds every |W2| (|w| < 2^w_exp), the same in every workgroup
   {
@@ -200,6 +213,19 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
       if (tid == 0) {
         lds[L::SC + 1] = pow2i(w_exp - 2 * kF16Top + 2);    // 1 / (forward image scale x 2^14 of h1)
         lds[L::SC + 2] = pow2i(w_exp - kF16Top);            // 1 / backward image scale
+      }
+      // layer 1's image: |w kTanhScale| < 2^(w1_exp + 2), scaled by 2^(12 - w1_exp)
+      int w1_exp = __builtin_amdgcn_frexp_expf(lds[L::SC + 5]);
+      w1_exp = w1_exp < -60 ? -60 : (w1_exp > 60 ? 60 : w1_exp);
+      if (tid == 0) lds[L::SC + 6] = pow2i(w1_exp + 2 - kF16Top);
+      unsigned short* img1 = reinterpret_cast<unsigned short*>(lds + L::W1I);
+      for (int gi = tid; gi < 64 * O; gi += nth) {
+        const int row = gi / O, k = gi - row * O;
+        const int T = row >> 4, i = row & 15, gg = k / L::XE, e = k - gg * L::XE;
+        unsigned hi, lo;
+        split2_pair(W1[gi] * kTanhScale * pow2i(kF16Top - 2 - w1_exp), 0.f, hi, lo);
+        img1[((T * 2 + 0) * 64 + gg * 16 + i) * 8 + e] = (unsigned short)hi;
+        img1[((T * 2 + 1) * 64 + gg * 16 + i) * 8 + e] = (unsigned short)lo;
       }
     }
 #pragma unroll
@@ -326,7 +352,10 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   if (!ACTOR) {
     for (int idx = tid; idx < 4 * KS1; idx += nth) {
       lds[L::NORM + idx] = idx < O ? a.norm_mean[idx] : 0.f;
-      lds[L::NORM + 4 * KS1 + idx] = idx < O ? a.norm_std[idx] : 1.f;
+      // CH 3 stages 1 / std: eight normalisations per lane and tile as subtract + multiply (a true
+      // division is ~10 instructions; the quotient differs from it by at most an ulp)
+      const float sd = idx < O ? a.norm_std[idx] : 1.f;
+      lds[L::NORM + 4 * KS1 + idx] = CH == 3 ? 1.0f / sd : sd;
     }
   }
 }
@@ -341,17 +370,30 @@ __device__ __forceinline__ float sum_groups(float v) {
   return __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
 }
 
+// max(v, the same lane of the other three 16-lane groups)
+__device__ __forceinline__ float max_groups(float v) {
+  const unsigned bits = __float_as_uint(v);
+  auto p16 = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+  v = fmaxf(__uint_as_float(p16[0]), __uint_as_float(p16[1]));
+  const unsigned b2 = __float_as_uint(v);
+  auto p32 = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+  return fmaxf(__uint_as_float(p32[0]), __uint_as_float(p32[1]));
+}
+
 // OUT_EXP: the result comes out times 2^OUT_EXP (exactly the scaled bits of the unscaled result);
 // `in_scale` multiplies the argument first (CH 3: the chain's unit back to 1).
-template <int OUT_EXP = 0, bool SCALED_IN = false>
-__device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16], float in_scale = 1.f) {
+// BIAS: the argument is acc x in_scale + bias (CH 3, layer 1: the per-sample unit of x and the bias in one FMA).
+template <int OUT_EXP = 0, bool SCALED_IN = false, bool BIAS = false>
+__device__ __forceinline__ void tanh16(f32x4 (&acc)[4], float (&out)[16], float in_scale = 1.f,
+                                       const f32x4* bias = nullptr) {
   // acc = 2 log2(e) x (kTanhScale); tanh(x) = 1 - 2 / (1 + e^{2x}): four instructions per element
   // (exp, add, rcp, fma) against seven for the odd-symmetric form; absolute error <= 2e-7 over the
   // whole range (e^{2x} = inf gives exactly 1, e^{2x} = 0 exactly -1).
   float t[16], d[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q)
-    t[q] = __builtin_amdgcn_exp2f(SCALED_IN ? acc[q >> 2][q & 3] * in_scale : acc[q >> 2][q & 3]);
+    t[q] = __builtin_amdgcn_exp2f(BIAS ? fmaf(acc[q >> 2][q & 3], in_scale, bias[q >> 2][q & 3])
+                                  : SCALED_IN ? acc[q >> 2][q & 3] * in_scale : acc[q >> 2][q & 3]);
 #pragma unroll
   for (int q = 0; q < 16; ++q) d[q] = __builtin_amdgcn_rcpf(1.f + t[q]);
   constexpr float one = (float)(1 << OUT_EXP);
@@ -643,8 +685,10 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // Per-sample inputs, branch-free: out-of-range lanes read a clamped (valid) address and the
   // value is discarded by a select.  (A load under `if (valid)` becomes an exec-masked branch
   // with its own s_waitcnt vmcnt(0): eight serialised HBM round trips per tile.)
+  // CH 3: lane group g holds the inputs XE g + e (the B operand of a 16x16x32 MFMA); else 4 st + g
+  constexpr int NX = F16 ? L::XE : KS1;
   struct TileIn {
-    float x[KS1];
+    float x[NX];
     float act[NS];
     float adv, lp, ret;
   };
@@ -653,8 +697,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     const bool ok = nsl < a.n;
     const int64_t nc = ok ? nsl : a.n - 1;
 #pragma unroll
-    for (int st = 0; st < KS1; ++st) {
-      const int k = 4 * st + g;
+    for (int st = 0; st < NX; ++st) {
+      const int k = F16 ? L::XE * g + st : 4 * st + g;
       const int kc = k < O ? k : O - 1;
       in.x[st] = a.obs[nc * O + kc];      // RAW: any arithmetic here would wait for the load now
     }
@@ -685,7 +729,9 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   if (!ACTOR && tile < ntiles) load_tile(tile, cur);
   stage_weights16<KS1, AP, ACTOR, CH>(lds, a);
   __syncthreads();
-  float fwd_unit = 1.f, bwd_unit = 1.f, w3_bound = 0.f, head_unit = 1.f;
+  float fwd_unit = 1.f, bwd_unit = 1.f, w3_bound = 0.f, head_unit = 1.f, w1_unit = 1.f;
+  if constexpr (F16)
+    w1_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 6])));
   if constexpr (HM)
     head_unit = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lds[L::SC + 4])));
   if constexpr (F16) {
@@ -708,15 +754,16 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 
     // consume the prefetched raw inputs: normalise (critic) and zero the padding with a 0/1
     // multiply (a select would let the compiler sink the load into an exec-masked branch)
-    float x[KS1];
+    float x[NX];
 #pragma unroll
-    for (int st = 0; st < KS1; ++st) {
-      const int k = 4 * st + g;
+    for (int st = 0; st < NX; ++st) {
+      const int k = F16 ? L::XE * g + st : 4 * st + g;
       const int kc = k < O ? k : O - 1;
       float v = cur.x[st];
-      if (!ACTOR)                                       // mean_stds.py:36-38 (clip: +inf = none)
-        v = __builtin_amdgcn_fmed3f((v - lds[L::NORM + kc]) / lds[L::NORM + 4 * KS1 + kc],
-                                    -a.norm_clip, a.norm_clip);
+      if (!ACTOR) {                                     // mean_stds.py:36-38 (clip: +inf = none)
+        const float centred = v - lds[L::NORM + kc], sd = lds[L::NORM + 4 * KS1 + kc];
+        v = __builtin_amdgcn_fmed3f(F16 ? centred * sd : centred / sd, -a.norm_clip, a.norm_clip);
+      }
       x[st] = v * ((valid && k < O) ? 1.f : 0.f);
     }
     float (&in_act)[NS] = cur.act;
@@ -729,16 +776,45 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     float h1[16], h2[16], z[NS], dzl[NS];
     {
       f32x4 acc[4];
-      load_bias16(lds + L::B1P, g, acc);
+      if constexpr (F16) {
+        // layer 1 on fp16x2 terms: the sample's inputs in its own unit 2^(14 - ex) (observations
+        // have no bound: the exponent of the largest |x| of the sample, over the four lane groups)
+        float amax = 0.f;
 #pragma unroll
-      for (int st = 0; st < KS1; ++st) {
+        for (int e = 0; e < NX; ++e) amax = fmaxf(amax, fabsf(x[e]));
+        int ex = __builtin_amdgcn_frexp_expf(max_groups(amax));
+        ex = ex < -38 ? -38 : (ex > 60 ? 60 : ex);
+        const float sx = pow2i(kF16Top - ex);
+        u32x4 bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-          acc[T] = mfma16(lds[L::W1I + (T * KS1 + st) * 64 + lane], x[st], acc[T]);
+        for (int p = 0; p < NX / 2; ++p) {
+          unsigned h, l;
+          split2_pair(x[2 * p] * sx, x[2 * p + 1] * sx, h, l);
+          bh[p] = h; bl[p] = l;
+        }
+        const u32x4* w1 = reinterpret_cast<const u32x4*>(lds + L::W1I);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+          const u32x4 wh = w1[(T * 2 + 0) * 64 + lane], wl = w1[(T * 2 + 1) * 64 + lane];
+          acc[T] = mfma_h16(wl, bh, zero4);
+          acc[T] = mfma_h16(wh, bl, acc[T]);
+          acc[T] = mfma_h16(wh, bh, acc[T]);
+        }
+        f32x4 b1v[4];
+        load_bias16(lds + L::B1P, g, b1v);
+        PHASE(0);                                    // input loads + layer-1 chain issued
+        tanh16<kF16Top, true, true>(acc, h1, w1_unit * pow2i(ex - kF16Top), b1v);   // h1 x 2^14 from here on
+      } else {
+        load_bias16(lds + L::B1P, g, acc);
+#pragma unroll
+        for (int st = 0; st < KS1; ++st) {
+#pragma unroll
+          for (int T = 0; T < 4; ++T)
+            acc[T] = mfma16(lds[L::W1I + (T * KS1 + st) * 64 + lane], x[st], acc[T]);
+        }
+        PHASE(0);                                    // input loads + layer-1 chain issued
+        tanh16(acc, h1);
       }
-      PHASE(0);                                      // input loads + layer-1 chain issued
-      if constexpr (F16) tanh16<kF16Top>(acc, h1);          // h1 x 2^14 from here on
-      else tanh16(acc, h1);
       PHASE(1);
       load_bias16(lds + L::B2P, g, acc);
       if constexpr (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
@@ -1065,7 +1141,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     }
     wave_lds_sync();
 #pragma unroll
-    for (int st = 0; st < KS1; ++st) TA[(4 * st + g) * TS16 + s] = x[st];
+    for (int st = 0; st < NX; ++st) TA[((F16 ? L::XE * g + st : 4 * st + g)) * TS16 + s] = x[st];
     wave_lds_sync();
 #pragma unroll
     for (int Tj = 0; Tj < XT; ++Tj) {
