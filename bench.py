@@ -207,6 +207,9 @@ def kernel_rooflines(agent):
     roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
                 achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
+                peak_note='the fp32-MFMA peak: what the kernel\'s fp32-equivalent arithmetic costs un-split; with '
+                          '88 % of the flops on three fp16 MFMAs per product the fraction is a speed-up figure and '
+                          'can exceed 1 — frac_vs_mixed_ceiling is the ceiling of the kernel\'s own instruction mix',
                 frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share, rate), 4),
                 mixed_ceiling_tflops=round(mixed_ceiling_tflops(share, rate), 1),
                 rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
