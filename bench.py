@@ -687,7 +687,11 @@ def measure_job(workers, rank, world, steps, warmup, capture, device_too=True):
     elapsed = timed_steps(lambda: loop.run(T), steps, warmup, world, finish=agent.settle)
     out = dict(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3,
                value=world * T * workers * steps / elapsed,
-               actor_iterations=int((agent.last_infos[0][:, 6] > 0).sum()))
+               actor_iterations=int((agent.last_infos[0][:, 6] > 0).sum()),
+               # device time of the LAST timed update's two chains (80 x [grad + fold + Adam] each; the critic's
+               # ran under the rollout that followed, or inside `finish`), by events
+               actor_chain_ms=round(getattr(agent, 'actor_chain_ms', None) or 0.0, 3),
+               critic_chain_ms=round(getattr(agent, 'critic_chain_ms', None) or 0.0, 3))
     rollout = None
     if device_too:
         rollout = DeviceRollout(agent, workers, T, seed=1 + rank)
@@ -1021,11 +1025,8 @@ def main():
         result['host_loop'] = loop.breakdown()
         loop.run(T - loop.agent.replay.index)             # finish the segment
         agent.settle()
-        # device time of the critic's 80 iterations of that update, which ran under the rollout's
-        # remaining steps on the second stream (0 when the overlap is off)
-        result['critic_chain_ms'] = round(getattr(agent, 'critic_chain_ms', 0.0), 3)
-        # ... and of the actor's 80 iterations (grad + fold + Adam each) of the last update, by events
-        result['actor_chain_ms'] = round(getattr(agent, 'actor_chain_ms', 0.0), 3)
+        result['critic_chain_ms'] = main_run['critic_chain_ms']
+        result['actor_chain_ms'] = main_run['actor_chain_ms']
         result['config']['critic_chain_gated'] = bool(
             getattr(agent, '_gate_ticket', 0)) and os.environ.get('TONIC_AMD_CRITIC_GATE', '1') != '0'
     if rank == 0 and not args.no_extras and not args.quick_extras and world == 1:
