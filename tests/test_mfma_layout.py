@@ -5,6 +5,7 @@ import pytest
 
 import mfma_emulator as emu
 import mfma_emulator16 as emu16
+import mfma_emulator16f as emu16f
 import numpy_port as port
 
 
@@ -15,11 +16,12 @@ def _random_actor(rng, O, A):
             rng.normal(size=A) * 0.1]
 
 
-EMULATORS = {'32x32x2': emu.emulate_grad, '16x16x4': emu16.emulate_grad16}
+EMULATORS = {'32x32x2': emu.emulate_grad, '16x16x4': emu16.emulate_grad16,
+             'fp16x2, head on MFMA (shipped)': emu16f.emulate_grad16f}
 
 
 @pytest.mark.parametrize('variant', list(EMULATORS))
-@pytest.mark.parametrize('O,A,n', [(17, 6, 70), (3, 1, 33), (28, 8, 64)])
+@pytest.mark.parametrize('O,A,n', [(17, 6, 70), (3, 1, 33), (28, 8, 64), (20, 3, 40), (12, 8, 21)])
 def test_actor_grad_layout(O, A, n, variant):
     rng = np.random.RandomState(O)
     params = [p.astype(np.float32) for p in _random_actor(rng, O, A)]
@@ -47,7 +49,7 @@ def test_actor_grad_layout(O, A, n, variant):
 
 
 @pytest.mark.parametrize('variant', list(EMULATORS))
-@pytest.mark.parametrize('O,n', [(17, 70), (3, 5), (28, 96)])
+@pytest.mark.parametrize('O,n', [(17, 70), (3, 5), (28, 96), (19, 37), (16, 16)])
 def test_critic_grad_layout(O, n, variant):
     rng = np.random.RandomState(100 + O)
     params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
