@@ -1,5 +1,10 @@
-// Fused forward + loss + backward of the 2x64-tanh PPO networks on 16x16x4 fp32 MFMA tiles,
-// TWO waves per SIMD (8 waves / workgroup, <= 256 registers per wave).
+// Fused forward + loss + backward of the 2x64-tanh PPO networks on 16-sample MFMA tiles,
+// TWO waves per SIMD (8 waves / workgroup, <= 256 registers per wave).  The shipped form (CH = 3
+// below) runs layer 1, the 64x64 products and the policy head's forward product as fp16x2 terms on
+// v_mfma_f32_16x16x32_f16 / 32x32x16_f16, the remaining products on v_mfma_f32_16x16x4_f32; the
+// all-fp32 form (CH = 0) and the bf16x3 forms (CH = 1, 2) are kept as references the tests compare
+// with (tonic_set_tuning "grad_variant").  tests/mfma_emulator16f.py mirrors the shipped form's
+// index design lane by lane in NumPy.
 //
 // Same mathematics and the same flat gradient image as mlp64.hip's mlp64_grad_kernel (see the
 // reference citations there); what changes is the tiling.  PMC on the 32x32x2 version
@@ -47,6 +52,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //      precision (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped terms are below 2^-24 of
 //      |a||b|), accumulated in fp32: 48 v_mfma_f32_16x16x32_bf16 of ~18 cycles per product plus
 //      5.5 VALU instructions per activation for the split.  Weights are split once, at staging.
+//   2  = 1 with dW2 on bf16x3 terms as well (2 x 2 tiles of v_mfma_f32_32x32x16_bf16);
 //   3  fp16x2: every fp32 operand, scaled by a power of two into the top of binary16's range, is split
 //      into two fp16 terms (hi + lo, 11 + 11 bits and the sign of lo: the split leaves at most
 //      2^-23 of the operand — 23 significant bits in the worst case, one short of fp32) and the
@@ -59,6 +65,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //      (|tanh| <= 1), the backward pass by ONE power of two per wave that only ever shrinks — a tile
 //      whose gradients would leave the range first rescales the wave's accumulators (exact: powers
 //      of two) — so nothing can overflow binary16 and everything that is summed shares a unit.
+//      Layer 1 runs the same way, each SAMPLE's inputs in the unit of its own largest |x|, and so does
+//      the forward product of a policy head with more than one action (Lds16::HM); heads with one
+//      output (the critic) keep their products as per-lane FMAs.
 template <int KS1, int AP, int CH>
 struct Lds16 {
   static constexpr int TS = CH ? 20 : 24;                // row stride of the transpose tiles
