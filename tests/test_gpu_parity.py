@@ -230,6 +230,41 @@ def test_actor_and_critic_grads_golden_batch(lib, golden, name, variant):
     np.testing.assert_allclose(got_c[Pc + 1] / n, info_c['v'].mean(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('variant', [1, 3, 4])
+@pytest.mark.parametrize('O,A', [(11, 3), (17, 2), (24, 7), (8, 5), (4, 4), (32, 1)])
+def test_grads_in_every_padded_bucket_vs_oracle(lib, O, A, variant):
+    """Action counts that are not a kernel bucket of their own (2 .. 5 ride in the six-action build, 7 in the
+    eight-action one: padded heads, `EXACT` off) and observation widths of every input bucket, a ragged batch,
+    against the oracle's explicit back-propagation — in the shipped build the padded slots are lane groups'
+    action slots that must stay dead (csrc/mlp64x16.hip, Lds16::HM)."""
+    rng = np.random.RandomState(100 * O + A)
+    n = 16 * 8 * 5 + 11
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1,
+              rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, A)) * 0.3, rng.normal(size=(A, 64)) * 0.2, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    obs = rng.normal(size=(n, O)).astype(np.float32)
+    actions = np.clip(rng.normal(size=(n, A)), -1, 1).astype(np.float32)
+    adv = rng.normal(size=n).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.3).astype(np.float32)
+    want, info = port.clipped_ratio_grads(params, obs, actions, adv, old_lp)
+    got, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32), old_lp, variant)
+    assert_grads_close(got[:P], want, n, f'O={O} A={A} actor grads')
+    np.testing.assert_allclose(got[P + 0] / n, info['loss'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[P + 1] / n, info['kl'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[P + 2] / n, info['clip_fraction'], atol=1e-7)
+    assert got[P + 5] == n
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    mean = rng.normal(size=O).astype(np.float32)
+    std = (np.abs(rng.normal(size=O)) + 0.5).astype(np.float32)
+    returns = rng.normal(size=n).astype(np.float32)
+    want_c, info_c = port.value_regression_grads(cparams, mean, std, obs, returns)
+    got_c, Pc = critic_grad(lib, cparams, mean, std, obs, returns, variant)
+    assert_grads_close(got_c[:Pc], want_c, n, f'O={O} critic grads')
+    np.testing.assert_allclose(got_c[Pc + 0] / n, info_c['loss'], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 def test_grads_ratio_clipping_branches(lib, variant):
     """Forces both clipped branches (ratio > 1.2 with adv > 0, ratio < 0.8 with adv < 0) and
