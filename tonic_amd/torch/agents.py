@@ -932,10 +932,10 @@ class PPO(A2C):
 
     def settle(self):
         """Waits for the critic iterations a previous update left running and logs their rows."""
+        self._open_gate()
         pending = getattr(self, '_critic_pending', None)
         if pending is None:
             return
-        self._open_gate()
         self._critic_pending = None
         torch.cuda.current_stream().wait_event(pending['done'])   # whoever reads the critic next is behind it
         rows = pending['infos'][1].cpu().numpy()
