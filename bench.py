@@ -77,7 +77,7 @@ def pmc_traffic(prefix):
     collected from inside the timed run, so the summary of the same kernels is quoted (the newest
     round's file that has the kernel)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
+    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 table = json.load(f)['kernels']
@@ -94,7 +94,7 @@ def rocprof_us(prefix):
     `python bench.py` (profiles/rNN_kernel_us.json, written by scripts/kernel_us.py from the
     stats csv of the same round; the newest round's), next to the HIP-event figure measured live."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r04_kernel_us.json', 'r03_kernel_us.json'):
+    for name in ('r05_kernel_us.json', 'r04_kernel_us.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 table = json.load(f)['kernels']
@@ -140,22 +140,11 @@ def kernel_rooflines(agent):
             p(critic.flat.flat), p(mean), p(std), 0.0, p(obs), p(ret), p(critic.grad_sums), n, O, 0,
             p(wsc), wsc.numel(), stream), 'critic')
 
-    # grad_variant: 0 = 32x32x2 fp32 tiles, 1 wave per SIMD; 1 = 16x16x4 fp32 tiles, 2 waves; 2 = 1 with
-    # the two 64x64 hidden-layer products on bf16x3 terms; 3 = 2 with dW2 on bf16x3 terms; 4 = the three
-    # products on fp16x2 terms.  The roofline
-    # entry is the variant the library ships as its default (the one the timed job above ran); the
-    # others are listed beside it.
+    # The product library holds one form of the grad kernels (grad_variant 4: layer 1, the 64x64 products and
+    # the head's forward product on fp16x2 terms; the fp32-MFMA / bf16x3 references live in the tests' dev build).
     shipped = ctypes.c_int32(-1)
     _lib.check(lib.tonic_get_tuning(b'grad_variant', ctypes.byref(shipped)), 'tuning')
     shipped = shipped.value
-    out = {}
-    for variant in (0, 1, 2, 3, 4):
-        _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
-        ws = actor._workspace_for(n)
-        wsc = critic._workspace_for(n)
-        ms_a, ms_c = time_events(actor_grad, 10), time_events(critic_grad, 10)
-        out[variant] = (ms_a, ms_c)
-    _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
     # The shipped variant the way the JOB runs it: 80 launches behind a phase in which the chip is
     # lightly loaded for as long as a rollout takes (42 ms), twice = 160 launches.  The device's
     # clock follows its load with a lag of ~25 ms (profiles/r04_clock_ramp.md: the first launches
@@ -185,54 +174,46 @@ def kernel_rooflines(agent):
     gated = os.environ.get('TONIC_AMD_CRITIC_GATE', '1') != '0'
     ms_a = as_in_the_job(actor_grad, idle_s=0.022, before=critic_grad) if gated else as_in_the_job(actor_grad)
     ms_c = as_in_the_job(critic_grad, idle_s=0.022 if gated else 0.042)
-    out[shipped] = (steady_a, steady_c)
     tf_a = ACTOR_FLOP_PER_SAMPLE * n / (ms_a * 1e-3) / 1e12
     tf_c = CRITIC_FLOP_PER_SAMPLE * n / (ms_c * 1e-3) / 1e12
-    if shipped == 4:
-        arithmetic = ('fp32-equivalent: dW1, dW3 and the head\'s backward product on fp32 MFMA; layer 1, the '
-                      '64x64 products (h1->z2, dz2->dh1, dW2) and the head\'s forward product — 88 % of the flops '
-                      '— as three fp16 MFMAs per product on hi+lo fp16 splits of the power-of-two-scaled fp32 '
-                      'operands (the split keeps 23+ significant bits; against float64 the gradient sums are as '
-                      'close as with fp32 MFMAs), fp32 accumulation.  peak stays the fp32 MFMA peak: what the '
-                      'same arithmetic costs without the split — a speed-up figure, frac_vs_mixed_ceiling is '
-                      'the ceiling of the kernel\'s own instruction mix')
-    else:
-        arithmetic = ('fp32 MFMA throughout' if shipped < 2 else
-                      'fp32-equivalent: layer 1, dW1, dW3 on fp32 MFMA; the 64x64 products (h1->z2, dz2->dh1'
-                      + (', dW2: 77 %' if shipped >= 3 else ': 52 %') + ' of the flops) as six bf16 MFMAs per '
-                      'product on exact hi+mid+lo bf16 splits of the fp32 operands, fp32 accumulation.  peak '
-                      'stays the fp32 MFMA peak: what the same arithmetic costs without the split')
-    share = {0: 0.0, 1: 0.0, 2: 0.52, 3: 0.77, 4: 0.88}[shipped]
-    rate = 16.0 / 3.0 if shipped == 4 else 8.0 / 3.0
-    roof = dict(bound='mfma', kernel='mlp64_grad16_kernel<actor> (+reduce_partials)',
-                achieved=round(tf_a, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                frac=round(tf_a / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic('mlp64_grad16_kernel<actor>'),
-                peak_note='the fp32-MFMA peak: what the kernel\'s fp32-equivalent arithmetic costs un-split; with '
-                          '88 % of the flops on three fp16 MFMAs per product the fraction is a speed-up figure and '
-                          'can exceed 1 — frac_vs_mixed_ceiling is the ceiling of the kernel\'s own instruction mix',
-                frac_vs_mixed_ceiling=round(tf_a / mixed_ceiling_tflops(share, rate), 4),
-                mixed_ceiling_tflops=round(mixed_ceiling_tflops(share, rate), 1),
-                rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
-                ms_per_launch=round(ms_a, 4), launches_timed=2 * ITERATIONS,
+    # The ceiling is the kernel's OWN instruction mix: 88 % of the fp32-equivalent flops run as three fp16
+    # MFMAs per product (16 / 3 x the fp32 MFMA rate), 12 % (dW1, dW3, the head's backward product) as fp32
+    # MFMAs.  `frac` is measured against that; what the same arithmetic would cost un-split — the fp32 MFMA
+    # peak, against which a split kernel can read above 1 — is kept beside it as a speed-up figure only.
+    rate = 16.0 / 3.0
+    arithmetic = ('fp32 in / out / accumulate; 88 % (critic: 91 %) of the flops (layer 1, h1->z2, dz2->dh1, dW2, the head\'s '
+                  'forward product) as three fp16 MFMAs per product on hi+lo fp16 splits of power-of-two-scaled '
+                  'fp32 operands (23+ significant bits), 12 % (dW1, dW3, the head\'s backward product) on fp32 MFMA')
+
+    def entry(kernel, tf, ms, steady_ms, flop, split_flop):
+        # split_flop: the flops per sample that run on fp16x2 terms (layer 1 2 O 64, three 64x64 products,
+        # the actor's head forward 2 A 64)
+        share = split_flop / flop
+        ceiling = mixed_ceiling_tflops(share, rate)
+        steady_tf = flop * n / (steady_ms * 1e-3) / 1e12
+        return dict(bound='mfma', kernel=kernel, achieved=round(tf, 2), peak=round(ceiling, 1), unit='TFLOP/s',
+                    frac=round(tf / ceiling, 4),
+                    peak_is=f'the ceiling of the kernel\'s own instruction mix: {100 * (1 - share):.0f} % of the '
+                            f'fp32-equivalent flops at the fp32 MFMA peak (157.3), {100 * share:.0f} % as 3 fp16 MFMAs '
+                            f'per product at the fp16 peak (2 516.6)',
+                    fp32_equivalent=dict(peak=FP32_MFMA_PEAK_TFLOPS, frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                         note='speed-up over the un-split arithmetic, not a roofline fraction'),
+                    ms_per_launch=round(ms, 4), launches_timed=2 * ITERATIONS,
+                    steady_state=dict(ms_per_launch=round(steady_ms, 4), launches_timed=120,
+                                      achieved=round(steady_tf, 2), frac=round(steady_tf / ceiling, 4)),
+                    samples_per_launch=n, flop_per_sample=flop)
+    split = 2 * O * 64 + 3 * 2 * 64 * 64
+    roof = entry('mlp64_grad16_kernel<actor> (+reduce_partials)', tf_a, ms_a, steady_a, ACTOR_FLOP_PER_SAMPLE,
+                 split + 2 * A * 64)
+    roof.update(pmc_traffic('mlp64_grad16_kernel<actor>'), rocprof_us=rocprof_us('mlp64_grad16_kernel<actor>'),
+                grad_variant=shipped, arithmetic=arithmetic,
                 timed_as=('80 launches behind a 22 ms lightly loaded phase and the critic\'s 80 launches, twice '
                           '(the job\'s pattern with the critic chain gated to the end of the rollout)' if gated
                           else '80 launches behind a 42 ms lightly loaded phase, twice (the job\'s pattern: the '
-                               'clock ramps during them)'),
-                steady_state=dict(ms_per_launch=round(steady_a, 4), launches_timed=120,
-                                  achieved=round(ACTOR_FLOP_PER_SAMPLE * n / (steady_a * 1e-3) / 1e12, 2),
-                                  frac=round(ACTOR_FLOP_PER_SAMPLE * n / (steady_a * 1e-3) / 1e12
-                                             / FP32_MFMA_PEAK_TFLOPS, 4)),
-                samples_per_launch=n,
-                flop_per_sample=ACTOR_FLOP_PER_SAMPLE, grad_variant=shipped, arithmetic=arithmetic,
-                variants_ms={str(k): [round(v[0], 4), round(v[1], 4)] for k, v in out.items()})
-    roof_critic = dict(bound='mfma', kernel='mlp64_grad16_kernel<critic> (+reduce_partials)',
-                       achieved=round(tf_c, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                       frac=round(tf_c / FP32_MFMA_PEAK_TFLOPS, 4),
-                       ms_per_launch=round(ms_c, 4), launches_timed=2 * ITERATIONS,
-                       steady_state=dict(ms_per_launch=round(steady_c, 4), launches_timed=120,
-                                         frac=round(CRITIC_FLOP_PER_SAMPLE * n / (steady_c * 1e-3) / 1e12
-                                                    / FP32_MFMA_PEAK_TFLOPS, 4)),
-                       rocprof_us=rocprof_us('mlp64_grad16_kernel<critic>'))
+                               'clock ramps during them)'))
+    roof_critic = entry('mlp64_grad16_kernel<critic> (+reduce_partials)', tf_c, ms_c, steady_c,
+                        CRITIC_FLOP_PER_SAMPLE, split)
+    roof_critic.update(rocprof_us=rocprof_us('mlp64_grad16_kernel<critic>'))
 
     # GAE scan: 28 algorithmic B / transition (read nv, r, reset, term, values; write ret, adv)
     def gae_entry(t_steps, workers, chunks):
@@ -1029,6 +1010,17 @@ def main():
         result['actor_chain_ms'] = main_run['actor_chain_ms']
         result['config']['critic_chain_gated'] = bool(
             getattr(agent, '_gate_ticket', 0)) and os.environ.get('TONIC_AMD_CRITIC_GATE', '1') != '0'
+        if result['config']['critic_chain_gated']:
+            # the same job with the critic's chain started at once instead of held back to the end of the
+            # rollout (tonic_stream_gate only arms behind rollouts of < 100 ms, i.e. zero-cost simulators):
+            # the headline beside its un-tuned twin, same agent, same harness
+            os.environ['TONIC_AMD_CRITIC_GATE'] = '0'
+            try:
+                off = timed_steps(lambda: loop.run(T), args.steps, 1, world, finish=agent.settle)
+            finally:
+                os.environ['TONIC_AMD_CRITIC_GATE'] = '1'
+            result['critic_gate_off'] = dict(env_steps_per_sec=round(world * T * workers * args.steps / off, 1),
+                                             ms_per_step=round(off / args.steps * 1e3, 3), steps=args.steps)
     if rank == 0 and not args.no_extras and not args.quick_extras and world == 1:
         roof, roof_c, roof_g = kernel_rooflines(agent)
         result['roofline'] = roof

@@ -33,7 +33,8 @@ def run(out_path):
     # what parallel.one_shot runs before the learner may rely on the windows
     passed, why = comm.self_test(calls=6)
     # ... and what the learner's exchange would pick on this box, with the reason
-    #     (TONIC_AMD_ALLREDUCE unset = auto: the ranks decide together)
+    #     (TONIC_AMD_ALLREDUCE=auto: the ranks decide together)
+    os.environ.setdefault('TONIC_AMD_ALLREDUCE', 'auto')
     picked = parallel.one_shot(11101)
     choice = parallel.allreduce_choice() or {}
     np.savez(out_path + f'.rank{rank}.npz', chain=chain.cpu().numpy(),

@@ -99,3 +99,68 @@ def test_the_running_unit_never_lets_an_operand_leave_binary16():
         total = sum(t.astype(np.float64).sum() for t in tiles)
         assert abs(accumulator * 2.0 ** (e_run - 14) - total) <= 1e-12 * sum(np.abs(t).sum() for t in tiles)
         assert rescales <= (40 if order == 'rising' else 12), (order, rescales)
+
+
+def layer_one(weights, x, equilibrate):
+    """Layer 1 of the shipped grad kernels on fp16x2 terms (csrc/mlp64x16.hip, stage_weights16 / the tile loop):
+    z1 = W1 x, each SAMPLE's inputs in the unit of its own largest entry.  equilibrate: column k of the image is
+    W1[:, k] 2^(12 - e_k), e_k the exponent of max |W1[:, k]|, and input k enters times 2^(e_k) (Lds16::CX)."""
+    cols = weights.shape[1]
+    wp, xp = np.zeros((64, 32), np.float32), np.zeros((32, x.shape[0]), np.float32)
+    wp[:, :cols], xp[:cols] = weights, x.T
+    if equilibrate:
+        top = np.abs(wp).max(0)
+        e_k = np.clip(np.where(top > 0, np.frexp(top)[1], 0), -40, 40)
+        image, inputs, unit = wp * np.float32(2.0) ** (12 - e_k)[None, :], xp * (np.float32(2.0) ** e_k)[:, None], 2.0 ** -12
+    else:
+        e = int(np.frexp(np.abs(wp).max())[1])
+        image, inputs, unit = wp * np.float32(2.0 ** (12 - e)), xp, 2.0 ** (e - 12)
+    ex = np.clip(np.frexp(np.abs(inputs).max(0))[1], -38, 100)
+    sx = np.float32(2.0) ** (14 - ex)
+    x_hi, x_lo = split2(inputs * sx[None, :])
+    w_hi, w_lo = split2(image)
+    assert np.isfinite(x_hi.astype(np.float32)).all() and np.isfinite(w_hi.astype(np.float32)).all()
+    return mfma_terms([(w_lo, x_hi), (w_hi, x_lo), (w_hi, x_hi)], 32).astype(np.float64) * unit / sx[None, :].astype(np.float64)
+
+
+@pytest.mark.parametrize('outlier', [False, True])
+def test_layer_one_is_fp32_class_for_features_seven_decades_apart(outlier):
+    """The reference's actor sees raw observations (models/actors.py:128-129): columns 1e-3 ... 1e4 with weights
+    that undo the scales (every term of z1 is O(1)), with and without a single 1e6 entry.  In the unit of the
+    sample's largest |x| alone, a feature 2^-17 below it loses its low term to binary16's subnormal grid: the
+    error is 1e-4 of sum |w||x|; with the columns equilibrated it is the fp32 MFMA's, x 2 at most."""
+    rng = np.random.RandomState(3)
+    cols, n = 17, 2048
+    scales = 10.0 ** np.linspace(-3, 4, cols)
+    rng.shuffle(scales)
+    x = (rng.standard_normal((n, cols)) * scales).astype(np.float32)
+    if outlier:
+        x[7, 3] = 1e6
+    weights = (rng.normal(size=(64, cols)) * 0.3 / scales).astype(np.float32)
+    exact = weights.astype(np.float64) @ x.T.astype(np.float64)
+    size = np.abs(weights).astype(np.float64) @ np.abs(x.T).astype(np.float64)
+    wp, xp = np.zeros((64, 32), np.float32), np.zeros((32, n), np.float32)
+    wp[:, :cols], xp[:cols] = weights, x.T
+    fp32 = (np.abs(mfma_terms([(wp, xp)], 4) - exact) / size).max()
+    unit_only = (np.abs(layer_one(weights, x, False) - exact) / size).max()
+    shipped = (np.abs(layer_one(weights, x, True) - exact) / size).max()
+    assert fp32 < 3e-7
+    assert unit_only > 1e-5, 'the case no longer shows what the equilibration is for'
+    assert shipped <= 2.0 * fp32, (fp32, shipped)
+
+
+def test_quotient_by_reciprocal_and_one_newton_step_is_the_division():
+    """`quotient_by` (csrc/mlp64x16.hip): (x - mean) / std of mean_stds.py:36 as q0 = c r, q = fma(fma(-q0, sd, c), r, q0)
+    with r = fl(1 / sd).  Over 4 M operand pairs around the std floor the result is the IEEE quotient (the plain
+    product c r differs from it in ~25 % of the cases)."""
+    rng = np.random.RandomState(9)
+    c = (rng.standard_normal(1 << 22) * 10.0 ** rng.uniform(-3, 3, 1 << 22)).astype(np.float32)
+    sd = np.maximum(10.0 ** rng.uniform(-2, 2, 1 << 22), 1e-2).astype(np.float32)
+    r = (np.float32(1) / sd).astype(np.float32)
+    q0 = (c * r).astype(np.float32)
+    L = np.longdouble
+    rem = (c.astype(L) - q0.astype(L) * sd.astype(L)).astype(np.float32)          # exact in the FMA, then rounded
+    q = (q0.astype(L) + rem.astype(L) * r.astype(L)).astype(np.float32)
+    want = (c / sd).astype(np.float32)
+    assert (q0 != want).mean() > 0.05
+    assert np.array_equal(q, want)

@@ -186,7 +186,7 @@ def test_one_shot_allreduce_between_peer_devices(tmp_path):
     for r in range(1, world):
         assert np.array_equal(ranks[r]['chain'], ranks[0]['chain'])
     # with a device per rank and peer access between every pair the learner's exchange selects the
-    # one-shot all-reduce by itself (TONIC_AMD_ALLREDUCE unset); anything else must come with a reason
+    # one-shot all-reduce by itself (TONIC_AMD_ALLREDUCE=auto, set by the worker); anything else must come with a reason
     for r in range(world):
         assert int(ranks[r]['self_test'][0]) == 1, str(ranks[r]['self_test_reason'])
         assert str(ranks[r]['choice']) in ('oneshot', 'rccl')

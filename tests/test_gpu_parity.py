@@ -10,6 +10,7 @@ import pytest
 
 import numpy_port as port
 from test_oracle_golden import PPO_CASES, _params
+from conftest import variant_library
 
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
@@ -153,6 +154,7 @@ def test_value_forward_vs_oracle(lib, O, n):
 
 def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
     from tonic_amd import _lib
+    lib = variant_library(lib, variant)
     if variant is not None:
         _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
     n, O = obs.shape
@@ -171,6 +173,7 @@ def actor_grad(lib, params, obs, actions, adv, stats, old_lp, variant=None):
 
 def critic_grad(lib, params, mean, std, obs, returns, variant=None, clip=0.0):
     from tonic_amd import _lib
+    lib = variant_library(lib, variant)
     if variant is not None:
         _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
     n, O = obs.shape
@@ -333,6 +336,7 @@ def test_critic_grad_is_bit_reproducible_at_baseline_size(lib, variant):
               rng.normal(size=(1, 64)) * 0.3, rng.normal(size=1)]
     params = [p.astype(np.float32) for p in params]
     from tonic_amd import _lib
+    lib = variant_library(lib, variant)
     P = lib.tonic_v_critic_param_count(O)
     ws = torch.empty(lib.tonic_ppo_workspace_bytes(n, O, 1, 0), dtype=torch.uint8, device='cuda')
     keep = [dev(flat(params)), dev((rng.standard_normal(O) * 0.1).astype(np.float32)),
@@ -514,6 +518,93 @@ def test_fp16x2_products_keep_their_unit_over_extreme_ranges(lib, case):
             assert err <= 4e-6 * top, (case, what, (lo, hi), err, top)
         if case == 'zero' and what == 'actor':
             assert not got[:P].any()
+
+
+@pytest.mark.parametrize('weights', ['as_initialised', 'conditioned'])
+@pytest.mark.parametrize('features', ['seven_decades', 'one_outlier'])
+def test_fp16x2_layer_one_with_observations_of_mixed_magnitude(lib, features, weights):
+    """The reference's actor sees RAW observations (models/actors.py:128-129, quirk Q1) and the critic sees them
+    through (x - mean) / std with whatever statistics it has (normalizers/mean_stds.py:34-39): feature columns
+    seven decades apart — 1e-3 ... 1e4 — and a sample with a single 1e6 entry, (i) with first-layer weights as
+    initialised (the large columns saturate tanh) and (ii) with weights that undo the column scales (every term
+    of z1 is O(1): what a trained network looks like).  Layer 1 of the shipped kernels (grad_variant 4) runs on
+    fp16x2 terms in a per-sample unit; W1 is equilibrated by column (Lds16::CX) so that the unit is taken over
+    terms of equal weight.  Without that, case (ii) is off by 1e-4 in z1 (tests/test_fp16x2_arithmetic.py).
+    Gradient sums of actor AND critic against float64 autograd, held to the fp32-MFMA variant's error x 2."""
+    rng = np.random.RandomState(41)
+    O, A, n = 17, 6, 65536
+    scales = 10.0 ** np.linspace(-3, 4, O)
+    rng.shuffle(scales)
+    obs = rng.standard_normal((n, O)) * scales
+    if features == 'one_outlier':
+        obs = rng.standard_normal((n, O))
+        obs[np.arange(0, n, 977), rng.randint(0, O, len(range(0, n, 977)))] = 1e6
+        scales = np.ones(O)
+    obs = obs.astype(np.float32)
+    w1 = rng.normal(size=(64, O)) * 0.3
+    if weights == 'conditioned':
+        w1 = w1 / scales
+    params = [w1, rng.normal(size=64) * 0.1, rng.normal(size=(64, 64)) * 0.15, rng.normal(size=64) * 0.1,
+              rng.normal(size=(1, A)) * 0.2, rng.normal(size=(A, 64)) * 0.1, rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.1).astype(np.float32)
+    returns = rng.standard_normal(n).astype(np.float32)
+    mean, std = np.zeros(O, np.float32), np.ones(O, np.float32)
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    want_a, want_c = float64_gradient_sums(params, cparams, obs, actions, adv, old_lp, returns)
+    errors = {}
+    for variant in (1, 4):
+        got_a, P = actor_grad(lib, params, obs, actions, adv, np.array([0, 1, 0, 0], np.float32), old_lp, variant)
+        got_c, Pc = critic_grad(lib, cparams, mean, std, obs, returns, variant)
+        assert np.isfinite(got_a).all() and np.isfinite(got_c).all(), (features, weights, variant)
+        errors[variant] = (np.abs(got_a[:P] - want_a).max() / np.abs(want_a).max(),
+                           np.abs(got_c[:Pc] - want_c).max() / np.abs(want_c).max())
+    print(features, weights, 'max relative error vs float64 (actor, critic) per grad_variant:', errors)
+    for k in (0, 1):
+        assert errors[1][k] < 5e-6, errors
+        assert errors[4][k] <= 2.0 * errors[1][k] + 1e-8, errors
+
+
+@pytest.mark.parametrize('variant', [1, 4])
+def test_critic_normalisation_at_the_std_floor(lib, variant):
+    """MeanStd floors std at 1e-2 (normalizers/mean_stds.py:62-66) and divides (:36): with |x - mean| up to 1e3
+    the critic's inputs reach 1e5.  The shipped kernels form the quotient as multiply by the staged reciprocal
+    + one Newton step on the exact remainder (quotient_by: the division's rounding); values and gradient sums
+    against numpy_port.critic_forward / value_regression_grads at 1e-5, most features of ordinary size so that
+    the network is not saturated everywhere."""
+    from tonic_amd import _lib
+    rng = np.random.RandomState(43)
+    O, n = 17, 32768
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1, rng.normal(size=(64, 64)) * 0.15,
+              rng.normal(size=64) * 0.1, rng.normal(size=(1, 64)) * 0.3, rng.normal(size=1)]
+    params[0][:, :4] *= 1e-4                       # the weights of the columns whose inputs reach 1e5
+    params = [p.astype(np.float32) for p in params]
+    mean = rng.normal(size=O).astype(np.float32)
+    std = np.full(O, 1e-2, np.float32)
+    obs = mean + rng.standard_normal((n, O)) * 1e-2
+    obs[:, :4] = mean[:4] + rng.uniform(-1e3, 1e3, (n, 4))
+    obs[::50, 7] = mean[7] + 1e3                   # and isolated saturating entries
+    obs = obs.astype(np.float32)
+    returns = rng.standard_normal(n).astype(np.float32)
+    want_v = port.critic_forward(params, mean, std, obs)[3]
+    out = torch.empty(n).cuda()
+    keep = [dev(flat(params)), dev(mean), dev(std), dev(obs)]
+    vlib, lib = lib, variant_library(lib, variant)
+    _lib.check(lib.tonic_set_tuning(b'grad_variant', variant), 'tuning')
+    try:
+        _lib.check(lib.tonic_value_forward(*[t.data_ptr() for t in keep[:3]], 0.0, keep[3].data_ptr(),
+                                           out.data_ptr(), n, O, None), 'value')
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.tonic_set_tuning(b'grad_variant', -1), 'tuning')
+    np.testing.assert_allclose(out.cpu().numpy(), want_v, rtol=1e-5, atol=1e-5)
+    want = flat(port.value_regression_grads(params, mean, std, obs, returns)[0]).astype(np.float64)
+    got, P = critic_grad(vlib, params, mean, std, obs, returns, variant)
+    err = np.abs(got[:P].astype(np.float64) / n - want).max()
+    assert err <= 1e-5 * np.abs(want).max() + 1e-7, (variant, err, np.abs(want).max())
 
 
 def test_config5_size_properties(lib):

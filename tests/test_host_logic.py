@@ -451,7 +451,7 @@ assert not ok and why == 'rank 1: no window on this rank', (ok, why)
 # process group.  The decision is taken once.
 assert parallel.one_shot(1000) is None
 choice = parallel.allreduce_choice()
-assert choice['kind'] == 'rccl' and 'no GPU' in choice['reason'], choice
+assert choice['kind'] == 'rccl' and 'without a GPU' in choice['reason'], choice
 assert parallel.one_shot(5000) is None and parallel.allreduce_choice() is choice
 dist.barrier()
 print('rank', rank, 'ok')
@@ -467,7 +467,7 @@ def test_exchange_choice_is_unanimous_and_recorded_gloo(tmp_path):
     script.write_text(CHOICE_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29613', WORLD_SIZE='2',
                OMP_NUM_THREADS='1')
-    env.pop('TONIC_AMD_ALLREDUCE', None)
+    env['TONIC_AMD_ALLREDUCE'] = 'auto'            # (the default is the process group: see parallel.one_shot)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

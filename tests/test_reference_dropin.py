@@ -150,9 +150,10 @@ def test_categorical_with_support_equals_the_reference():
     assert torch.equal(a.project(returns), b.project(returns))
 
 
-def test_explorations_follow_the_reference_streams():
-    """tonic/explorations/noisy.py (host logic either side of the policy forward; the scripted debug
-    agents of tonic/agents/basic.py are out of scope — SURVEY.md §2 — and not provided): same constructor arguments, same NumPy RandomState stream, same per-worker reset
+def test_explorations_and_scripted_agents_follow_the_reference_streams():
+    """tonic/explorations/noisy.py and tonic/agents/basic.py (host logic either side of the policy
+    forward; `--agent 'tonic.agents.UniformRandom()'` is part of the reference's command line): same
+    constructor arguments, same NumPy RandomState stream, same per-worker reset
     handling — bit-identical action sequences over warm-up, policy steps and resets."""
     tonic = reference_loader.load_reference()
     import tonic_amd
@@ -174,6 +175,21 @@ def test_explorations_follow_the_reference_streams():
             resets = rng.rand(4) < 0.3
             theirs.update(resets)
             ours.update(resets)
+    for name, kwargs in (('NormalRandom', dict(loc=0.1, scale=0.5)), ('UniformRandom', {}),
+                         ('OrnsteinUhlenbeck', dict(scale=0.3)), ('Constant', dict(constant=0.25))):
+        theirs = getattr(tonic.agents, name)(**kwargs)
+        ours = getattr(tonic_amd.agents, name)(**kwargs)
+        theirs.initialize(None, action_space, seed=3)
+        ours.initialize(None, action_space, seed=3)
+        for steps in range(8):
+            observations = np.zeros((4, 5), np.float32)
+            assert np.array_equal(theirs.step(observations, steps), ours.step(observations, steps))
+            assert np.array_equal(theirs.test_step(observations, steps),
+                                  ours.test_step(observations, steps))
+            resets = rng.rand(4) < 0.3
+            outcome = (observations, np.zeros(4), resets, resets, steps)
+            theirs.update(*outcome), ours.update(*outcome)
+            theirs.test_update(*outcome), ours.test_update(*outcome)
 
 
 def test_learning_curve_fixture_is_what_the_reference_does(tmp_path):

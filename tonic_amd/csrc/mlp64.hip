@@ -820,12 +820,14 @@ int launch_value(int blocks, hipStream_t st, const MlpArgs& a) {
   return launch(value_forward_kernel<KS1, kFwdWaves>, blocks, kFwdWaves * 64,
                 Lds<KS1, 1, false, kFwdWaves>::BYTES, st, a, "tonic_value_forward");
 }
+#ifdef TONIC_DEV
 template <int KS1, int AP, bool ACTOR>
 int launch_grad(int blocks, hipStream_t st, const MlpArgs& a) {
   const char* what = ACTOR ? "tonic_ppo_actor_grad" : "tonic_value_regression_grad";
   return launch(mlp64_grad_kernel<KS1, AP, ACTOR, 4>, blocks, 256,
                 Lds<KS1, AP, true, 4>::BYTES, st, a, what);
 }
+#endif
 
 template <typename F>
 int dispatch_ks1(int ks1, F&& f) {
@@ -861,6 +863,13 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
   if (strcmp(key, "grad_variant") == 0) {
     TONIC_REQUIRE(value >= -1 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_variant must be 0 .. 4 or -1 (default), got %d", value);
+#ifndef TONIC_DEV
+    // the product library holds ONE form of the grad kernels; the fp32-MFMA / bf16x3 references the
+    // parity tests compare it with live in libtonic_hip_dev.so (make dev)
+    TONIC_REQUIRE(value < 0 || value == kDefaultGradVariant, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_variant %d is a developer reference (libtonic_hip_dev.so); this library holds %d",
+                  value, kDefaultGradVariant);
+#endif
     g_grad_variant = value < 0 ? kDefaultGradVariant : value;
     return TONIC_OK;
   }
@@ -1121,6 +1130,7 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
   a.skew = g_grad_skew;
   const int ap = ACTOR ? ap_bucket(a.A) : 1;
   hipStream_t st = as_stream(stream);
+#ifdef TONIC_DEV
   const int rc = use16 ? launch_grad16(ACTOR, blocks, st, a, variant - 1) : dispatch_ks1(ks1_bucket(a.O), [&](auto ks) {
     constexpr int KS1 = decltype(ks)::value;
     if constexpr (!ACTOR) {
@@ -1131,6 +1141,11 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
       return launch_grad<KS1, 8, true>(blocks, st, a);
     }
   });
+#else
+  (void)ap;
+  TONIC_REQUIRE(use16, TONIC_ERR_UNSUPPORTED_SHAPE, "fused grad kernel: O = %d, A = %d not served", a.O, a.A);
+  const int rc = launch_grad16(ACTOR, blocks, st, a, variant - 1);
+#endif
   if (rc != TONIC_OK) return rc;
   return launch_reduce_partials(ACTOR, static_cast<const float*>(d_workspace), blocks,
                                 (int)pstride, (int)P, a.params, d_grad_sums, a.O, a.A,

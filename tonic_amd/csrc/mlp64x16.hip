@@ -83,18 +83,26 @@ struct Lds16 {
   static constexpr int B2P = B1P + 64;
   static constexpr int W3P = B2P + 64;                   // [AP][4 groups][16]
   static constexpr int HC = W3P + AP * 64;               // [8][8] head constants
-  static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1]
-  static constexpr int SC = NORM + 8 * KS1;              // CH 3: {max |W2| bits, 1 / forward scale,
+  static constexpr int NORM = HC + 64;                   // mean[4*KS1], std[4*KS1], CH 3: + 1 / std[4*KS1]
+  static constexpr int SC = NORM + 12 * KS1;             // CH 3: {max |W2| bits, 1 / forward scale,
                                                          //        1 / backward weight scale, max |W3|,
                                                          //        1 / (head image scale x 2^14 of h2),
-                                                         //        max |W1| bits, 1 / W1 image scale}
+                                                         //        -, 1 / W1 image scale}
   // CH 3, policies with more than one action: the head's two products on fp32 MFMA tiles.  Row
   // 4 g + r of the forward image is action g + 4 r, so lane group g of a tile ends up with the
   // outputs of actions g and g + 4 — the k index those actions have in the backward product — and
   // every group does the loss arithmetic of ITS actions only.
   static constexpr int HSLOTS = (AP + 3) / 4;            // actions per lane group
   static constexpr bool HM = CH == 3 && AP > 1;
-  static constexpr int W3F = SC + 8;                     // [2 m][2 terms][64 lanes][8 fp16]: W3[action(row)][feat16(8m+e, g)] x 2^(14 - w3_exp)
+  // CH 3, layer 1: W1 is equilibrated by COLUMN with powers of two — column k of the image is
+  // W1[:, k] 2^(12 - e_k) (e_k: the exponent of max |W1[:, k]|) and input k enters as x_k 2^(e_k), both
+  // exact — so that the per-sample unit below is taken over terms of comparable weight: the reference's
+  // actor sees RAW observations (models/actors.py:128-129), features seven decades apart with weights
+  // to match are the normal case, and a feature 2^-17 below the sample's largest |x| would otherwise
+  // lose its low term to binary16's subnormal grid (1e-4 in z1 instead of 2e-7, tests/test_fp16x2_arithmetic.py).
+  static constexpr int CXM = SC + 8;                     // [32] max |W1[:, k]| bits
+  static constexpr int CX = CXM + 32;                    // [32] 2^(e_k)
+  static constexpr int W3F = CX + 32;                    // [2 m][2 terms][64 lanes][8 fp16]: W3[action(row)][feat16(8m+e, g)] x 2^(14 - w3_exp)
   static constexpr int W3B = W3F + (HM ? 1024 : 0);      // [HSLOTS c][64 lanes][4 T]: W3[g + 4c][16 T + i]
   static constexpr int WAVE0 = (W3B + (HM ? HSLOTS * 256 : 0) + 3) / 4 * 4;
   static constexpr int T_FLOATS = 64 * TS;
@@ -149,6 +157,14 @@ __device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsi
   lo = pack_f16(a, b);
 }
 
+// c / sd with the division's rounding, given r = fl(1 / sd): q0 = fl(c r) is within 1.5 ulp of the
+// quotient, its remainder c - q0 sd comes exactly out of one FMA and the correction lands on the
+// correctly rounded quotient (Markstein's final step; sd >= 1e-2 here, nothing under- or overflows).
+__device__ __forceinline__ float quotient_by(float c, float sd, float r) {
+  const float q0 = c * r;
+  return fmaf(fmaf(-q0, sd, c), r, q0);
+}
+
 // 2^k as a float (k in [-126, 127])
 __device__ __forceinline__ float pow2i(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
@@ -178,14 +194,13 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   const float* W3 = ACTOR ? tail + A : tail;
   const float* b3 = W3 + (ACTOR ? A * 64 : 64);
   for (int idx = tid; idx < L::kW1; idx += nth) lds[L::W1I + idx] = 0.f;
-  if (CH == 3 && tid == 0) { lds[L::SC] = 0.f; lds[L::SC + 5] = 0.f; }
+  if (CH == 3 && tid == 0) lds[L::SC] = 0.f;
+  if (CH == 3 && tid < 32) lds[L::CXM + tid] = 0.f;
   __syncthreads();
   if constexpr (CH == 3) {
-    float m1 = 0.f;                                      // max |W1|: the image's scale (built below)
-    for (int gi = tid; gi < 64 * O; gi += nth) m1 = fmaxf(m1, fabsf(W1[gi]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
-    if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(lds + L::SC + 5), __float_as_uint(m1));
+    // max |W1[:, k]| per input column: the column's scale in the image (built below)
+    for (int gi = tid; gi < 64 * O; gi += nth)
+      atomicMax(reinterpret_cast<unsigned*>(lds + L::CXM) + gi % O, __float_as_uint(fabsf(W1[gi])));
   } else {
     for (int gi = tid; gi < 64 * O; gi += nth) {          // coalesced reads, LDS scatter
       const int row = gi / O, k = gi - row * O;
@@ -223,16 +238,20 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
         lds[L::SC + 1] = pow2i(w_exp - 2 * kF16Top + 2);    // 1 / (forward image scale x 2^14 of h1)
         lds[L::SC + 2] = pow2i(w_exp - kF16Top);            // 1 / backward image scale
       }
-      // layer 1's image: |w kTanhScale| < 2^(w1_exp + 2), scaled by 2^(12 - w1_exp)
-      int w1_exp = __builtin_amdgcn_frexp_expf(lds[L::SC + 5]);
-      w1_exp = w1_exp < -60 ? -60 : (w1_exp > 60 ? 60 : w1_exp);
-      if (tid == 0) lds[L::SC + 6] = pow2i(w1_exp + 2 - kF16Top);
+      // layer 1's image, column k: |w kTanhScale| < 2^(e_k + 2), scaled by 2^(12 - e_k); the
+      // inputs come times 2^(e_k) (Lds16::CX), the products in the unit 2^(2 - 14)
+      auto column_exp = [&](int k) {
+        const int e = __builtin_amdgcn_frexp_expf(lds[L::CXM + k]);
+        return e < -40 ? -40 : (e > 40 ? 40 : e);
+      };
+      if (tid == 0) lds[L::SC + 6] = pow2i(2 - kF16Top);
+      if (tid < 32) lds[L::CX + tid] = pow2i(column_exp(tid));
       unsigned short* img1 = reinterpret_cast<unsigned short*>(lds + L::W1I);
       for (int gi = tid; gi < 64 * O; gi += nth) {
         const int row = gi / O, k = gi - row * O;
         const int T = row >> 4, i = row & 15, gg = k / L::XE, e = k - gg * L::XE;
         unsigned hi, lo;
-        split2_pair(W1[gi] * kTanhScale * pow2i(kF16Top - 2 - w1_exp), 0.f, hi, lo);
+        split2_pair(W1[gi] * kTanhScale * pow2i(kF16Top - 2 - column_exp(k)), 0.f, hi, lo);
         img1[((T * 2 + 0) * 64 + gg * 16 + i) * 8 + e] = (unsigned short)hi;
         img1[((T * 2 + 1) * 64 + gg * 16 + i) * 8 + e] = (unsigned short)lo;
       }
@@ -361,10 +380,12 @@ __device__ __forceinline__ void stage_weights16(float* lds, const MlpArgs& a) {
   if (!ACTOR) {
     for (int idx = tid; idx < 4 * KS1; idx += nth) {
       lds[L::NORM + idx] = idx < O ? a.norm_mean[idx] : 0.f;
-      // CH 3 stages 1 / std: eight normalisations per lane and tile as subtract + multiply (a true
-      // division is ~10 instructions; the quotient differs from it by at most an ulp)
+      // CH 3 also stages 1 / std: the normalisations of a tile (eight per lane) run as multiply +
+      // one Newton step on the remainder (quotient_by), which gives the DIVISION's rounding of
+      // mean_stds.py:36 in 3 instructions instead of the ~10 of an IEEE division
       const float sd = idx < O ? a.norm_std[idx] : 1.f;
-      lds[L::NORM + 4 * KS1 + idx] = CH == 3 ? 1.0f / sd : sd;
+      lds[L::NORM + 4 * KS1 + idx] = sd;
+      if (CH == 3) lds[L::NORM + 8 * KS1 + idx] = 1.0f / sd;
     }
   }
 }
@@ -771,7 +792,8 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       float v = cur.x[st];
       if (!ACTOR) {                                     // mean_stds.py:36-38 (clip: +inf = none)
         const float centred = v - lds[L::NORM + kc], sd = lds[L::NORM + 4 * KS1 + kc];
-        v = __builtin_amdgcn_fmed3f(F16 ? centred * sd : centred / sd, -a.norm_clip, a.norm_clip);
+        const float hat = F16 ? quotient_by(centred, sd, lds[L::NORM + 8 * KS1 + kc]) : centred / sd;
+        v = __builtin_amdgcn_fmed3f(hat, -a.norm_clip, a.norm_clip);
       }
       x[st] = v * ((valid && k < O) ? 1.f : 0.f);
     }
@@ -788,17 +810,21 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       if constexpr (F16) {
         // layer 1 on fp16x2 terms: the sample's inputs in its own unit 2^(14 - ex) (observations
         // have no bound: the exponent of the largest |x| of the sample, over the four lane groups)
-        float amax = 0.f;
+        // (every input first times its column's power of two, Lds16::CX: exact)
+        float xc[NX], amax = 0.f;
 #pragma unroll
-        for (int e = 0; e < NX; ++e) amax = fmaxf(amax, fabsf(x[e]));
+        for (int e = 0; e < NX; ++e) {
+          xc[e] = x[e] * lds[L::CX + L::XE * g + e];
+          amax = fmaxf(amax, fabsf(xc[e]));
+        }
         int ex = __builtin_amdgcn_frexp_expf(max_groups(amax));
-        ex = ex < -38 ? -38 : (ex > 60 ? 60 : ex);
+        ex = ex < -38 ? -38 : (ex > 100 ? 100 : ex);
         const float sx = pow2i(kF16Top - ex);
         u32x4 bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int p = 0; p < NX / 2; ++p) {
           unsigned h, l;
-          split2_pair(x[2 * p] * sx, x[2 * p + 1] * sx, h, l);
+          split2_pair(xc[2 * p] * sx, xc[2 * p + 1] * sx, h, l);
           bh[p] = h; bl[p] = l;
         }
         const u32x4* w1 = reinterpret_cast<const u32x4*>(lds + L::W1I);
@@ -2262,18 +2288,30 @@ int launch_grad16_probe(int blocks, hipStream_t stream, const MlpArgs& args) {
 }
 
 // The critic's forward over a whole batch: values -> args.out1 (chain as launch_grad16)
+// chain 3 (fp16x2 terms) is the ONE form the product library holds; 0 - 2 (fp32 MFMA, bf16x3) are the
+// references the parity tests compare it with, built only with TONIC_DEV (libtonic_hip_dev.so).
 int launch_values16(int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
   if (chain == 3) return values_by_inputs<3>(blocks, stream, args);
+#ifdef TONIC_DEV
   if (chain == 2) return values_by_inputs<2>(blocks, stream, args);
   return chain == 1 ? values_by_inputs<1>(blocks, stream, args)
                     : values_by_inputs<0>(blocks, stream, args);
+#else
+  set_error("grad chain %d is a developer reference: build with TONIC_DEV=1", chain);
+  return TONIC_ERR_INVALID_ARGUMENT;
+#endif
 }
 
 int launch_grad16(bool actor, int blocks, hipStream_t stream, const MlpArgs& args, int chain) {
   if (chain == 3) return by_inputs<3>(actor, blocks, stream, args);
+#ifdef TONIC_DEV
   if (chain == 2) return by_inputs<2>(actor, blocks, stream, args);
   return chain == 1 ? by_inputs<1>(actor, blocks, stream, args)
                     : by_inputs<0>(actor, blocks, stream, args);
+#else
+  set_error("grad chain %d is a developer reference: build with TONIC_DEV=1", chain);
+  return TONIC_ERR_INVALID_ARGUMENT;
+#endif
 }
 
 }  // namespace tonic

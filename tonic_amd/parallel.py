@@ -135,46 +135,58 @@ def _agree(ok, reason=''):
 
 def _peers_reachable():
     """tonic_allreduce_f32 writes into windows of the peers' device memory: every rank on a device of
-    its own, all in one process namespace (one node), and hipDeviceCanAccessPeer for every pair."""
+    its own, all in one process namespace (one node), and hipDeviceCanAccessPeer for every pair.
+    Every rank runs the SAME collectives here whatever it finds locally — one gather of (host, device,
+    has a GPU), a verdict formed from the gathered list, one _agree — so a job whose ranks differ (one
+    without a GPU, one on another host) cannot end up with mismatched collectives."""
     import socket
 
     from tonic_amd import _lib
-    if not torch.cuda.is_available():
-        return _agree(False, 'no GPU')
-    lib = _lib.load()
-    me = (socket.gethostname(), torch.cuda.current_device())
+    has_gpu = torch.cuda.is_available()
+    me = (socket.gethostname(), torch.cuda.current_device() if has_gpu else -1, has_gpu)
     everyone = [None] * world_size()
     dist.all_gather_object(everyone, me)
-    if len({host for host, _ in everyone}) > 1:
-        return _agree(False, 'ranks on several hosts')
-    devices = [device for _, device in everyone]
-    if len(set(devices)) < len(devices):
-        return _agree(False, f'ranks share devices {devices}')
-    for peer in devices:
-        can = lib.tonic_comm_can_access_peer(me[1], peer)
-        if can != 1:
-            why = lib.tonic_last_error().decode() if can < 0 else 'hipDeviceCanAccessPeer = 0'
-            return _agree(False, f'device {me[1]} -> device {peer}: {why}')
-    return _agree(True)
+    devices = [device for _, device, _ in everyone]
+    ok, why = True, ''
+    if not all(gpu for _, _, gpu in everyone):
+        ok, why = False, 'a rank without a GPU'
+    elif len({host for host, _, _ in everyone}) > 1:
+        ok, why = False, 'ranks on several hosts'
+    elif len(set(devices)) < len(devices):
+        ok, why = False, f'ranks share devices {devices}'
+    else:
+        try:
+            lib = _lib.load()
+            for peer in devices:
+                can = lib.tonic_comm_can_access_peer(me[1], peer)
+                if can != 1:
+                    reason = lib.tonic_last_error().decode() if can < 0 else 'hipDeviceCanAccessPeer = 0'
+                    ok, why = False, f'device {me[1]} -> device {peer}: {reason}'
+                    break
+        except Exception as error:      # (a local failure is a verdict, not a missing collective)
+            ok, why = False, str(error)
+    return _agree(ok, why)
 
 
 def one_shot(max_floats):
     """The process-wide OneShotAllReduce (tonic_allreduce_f32) when the gradient exchange should use
     it, else None: callers then use torch.distributed (RCCL).  TONIC_AMD_ALLREDUCE:
-      auto (default)  the ranks decide TOGETHER, once: every rank on a device of its own on one
+      rccl (default)  torch.distributed's process group (RCCL on a GPU node).  The one-shot exchange
+                      has only ever run between processes that share ONE device (tests) — no multi-GPU
+                      node was available to any round — so it is opt-in until a run on xGMI is recorded;
+      auto            the ranks decide TOGETHER, once: every rank on a device of its own on one
                       host, peer access between every pair (hipDeviceCanAccessPeer), the windows
                       open (hipIpc*), and a self-test of exact sums over several sizes and both slot
                       parities passes on every rank — else RCCL, with the reason kept
                       (`allreduce_choice()`);
-      oneshot         always (tests: also between processes that share one device);
-      rccl            never.
+      oneshot         always (tests: also between processes that share one device).
     The windows grow on demand before first use only."""
     global _one_shot, _choice
     if world_size() == 1:
         return None
     if _one_shot is not None and _one_shot.max_floats >= max_floats:
         return _one_shot
-    mode = os.environ.get('TONIC_AMD_ALLREDUCE', 'auto')
+    mode = os.environ.get('TONIC_AMD_ALLREDUCE', 'rccl')
     if mode == 'rccl' or (_choice is not None and _choice['kind'] == 'rccl'):
         if _choice is None:
             _choice = dict(kind='rccl', reason='TONIC_AMD_ALLREDUCE=rccl')
@@ -192,15 +204,24 @@ def one_shot(max_floats):
         return _one_shot
     ok, why = _peers_reachable()
     candidate = None
-    if ok:
-        from tonic_amd import _lib
+    # From here every rank walks the same three _agree steps whatever happens locally: a rank that fails
+    # (an exception included) carries its objection INTO the next _agree instead of skipping it, so no
+    # rank is ever left alone in a collective.
+    local, local_why = ok, why
+    if local:
         try:
             candidate = OneShotAllReduce(max(max_floats, 1 << 18), tolerant=True)
-            ok, why = _agree(candidate.handle is not None, candidate.error)
-            if ok:
-                ok, why = _agree(*candidate.self_test())
-        except _lib.TonicHipError as error:      # (a failure outside the agreed steps)
-            ok, why = False, str(error)
+            local, local_why = candidate.handle is not None, candidate.error
+        except Exception as error:
+            local, local_why = False, str(error)
+    if ok:
+        ok, why = _agree(local, local_why)
+    if ok:
+        try:
+            local, local_why = candidate.self_test()
+        except Exception as error:
+            local, local_why = False, str(error)
+        ok, why = _agree(local, local_why)
     if not ok:
         if candidate is not None:
             candidate.close()

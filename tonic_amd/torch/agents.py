@@ -47,6 +47,7 @@ def default_model():
 
 
 _SIDE_STREAMS = {}
+_ARMED_GATES = weakref.WeakSet()      # agents whose critic chain waits behind a tonic_stream_gate
 
 
 def _side_stream(name):
@@ -885,6 +886,7 @@ class PPO(A2C):
     # (swapped in when it starts), the normaliser's mean / std (updated in place after the update,
     # a2c.py:126-127) are snapshot.  TONIC_AMD_CRITIC_OVERLAP=0: the interleaved launches of enqueue_update.
     OVERLAP_BLOCKS = None       # (developer override of the critic's workgroups per launch)
+    MIN_OVERLAP_BLOCKS = 128    # below this width the critic's chain does not go under a rollout
 
     def _critic_blocks(self):
         """Workgroups of the critic's launches while a rollout is collected: what the resident
@@ -915,6 +917,11 @@ class PPO(A2C):
         return (self.replay.batch_size is None
                 and not self.actor_updater.stock and not self.critic_updater.stock
                 and self.observation_size <= 32 and self.action_size <= 8
+                # the collect kernel must leave the critic at least half of the chip: with thousands of
+                # workers per GPU (cfg 5 on one GPU: 645 collect workgroups) a chain squeezed into the
+                # few units left over would run many times longer than the rollout it hides under —
+                # such configurations keep the full-width interleaved launches
+                and self._critic_blocks() >= self.MIN_OVERLAP_BLOCKS
                 and getattr(self, '_collector', None) is not None
                 # only behind a rollout that came through the collector (it binds the Segment's
                 # buffers anew every rollout; anybody else — rollout.DeviceRollout's captured graph —
@@ -988,6 +995,15 @@ class PPO(A2C):
         last.record()
         # the critic's iterations: same inputs, the normaliser as it is NOW, their own stream
         snapshot = tuple(t.clone() for t in critic.norm_tensors())
+        normaliser_done = False
+        if parallel.exchanging() and self.model.observation_normalizer:
+            # Several ranks: the normaliser's update is a collective + a read-back on THIS stream; issued
+            # after the critic's chain it would queue behind the chain's 80 all-reduces on the
+            # communicator (one rank's host blocked for the whole chain).  It depends on neither
+            # network (a2c.py:126-127 merges the rollout's recorded sums), the chain reads the snapshot:
+            # it goes first.
+            self.model.observation_normalizer.update()
+            normaliser_done = True
         ready = torch.cuda.Event()
         ready.record()
         if getattr(self, '_critic_stream', None) is None:
@@ -1015,7 +1031,7 @@ class PPO(A2C):
         parallel.check_one_shot()
         logger.store('actor/iterations', log_ppo_actor_rows(rows))
         self._last_infos = np.stack([rows, np.zeros_like(rows)])
-        if self.model.observation_normalizer:
+        if self.model.observation_normalizer and not normaliser_done:
             self.model.observation_normalizer.update()
         # What the next rollout depends on — the actor, the normaliser — is on the current stream up
         # to here: a stream of its own carries that point to the collector (step() -> begin_rollout),
@@ -1030,7 +1046,12 @@ class PPO(A2C):
         ordered.record()
         self._rollout_marker.wait_event(ordered)
         self._rollout_behind = self._rollout_marker
-        torch.cuda.current_stream().wait_event(done)
+        if self._gate_row is None:
+            torch.cuda.current_stream().wait_event(done)
+        # (A chain parked behind a gate is NOT put in front of the current stream: the gate opens late in
+        #  the next rollout, and user work on this stream — a `current_stream().synchronize()` after
+        #  agent.update — would stall for most of a rollout.  Whoever reads the critic is ordered behind
+        #  the chain by settle(): the package's own readers, a forward pass of the module, state_dict().)
         self._rollout_started = time.perf_counter()
 
     # The critic's launches are enqueued above, while the host has nothing else to do, but they need not
@@ -1050,6 +1071,12 @@ class PPO(A2C):
         chain_ms, step_us = getattr(self, 'critic_chain_ms', None), getattr(self, '_rollout_step_us', None)
         if os.environ.get('TONIC_AMD_CRITIC_GATE', '1') == '0' or not chain_ms or not step_us:
             return
+        if parallel.exchanging():
+            # The chain's iterations all-reduce their gradient sums: a collective issued on the main
+            # stream meanwhile (the normaliser's statistics) queues BEHIND them on the communicator,
+            # and with a host-synchronous backend the first of them blocks the host — the only party
+            # that can open a gate.  Ranks that exchange never hold the chain back.
+            return
         rows = self.replay.max_size
         row = rows - int(np.ceil((1.1 * chain_ms + self.GATE_MARGIN_MS) * 1e3 / step_us))
         if row <= 0 or rows * step_us > self.GATE_ROLLOUT_US:
@@ -1068,11 +1095,16 @@ class PPO(A2C):
         _lib.check(_lib.load().tonic_stream_gate(self._gate_word.data_ptr(), self._gate_ticket, limit,
                                                  side.cuda_stream), 'stream gate')
         self._gate_row = row
+        _ARMED_GATES.add(self)
 
     def _open_gate(self):
-        if self._gate_row is not None:
-            self._gate_view[0] = self._gate_ticket
-            self._gate_row = None
+        # The critic stream is shared by the agents of a process (_side_stream): whatever another
+        # agent has parked there holds THIS agent's chain too, so every armed gate is opened.
+        for agent in list(_ARMED_GATES):
+            if agent._gate_row is not None:
+                agent._gate_view[0] = agent._gate_ticket
+                agent._gate_row = None
+        _ARMED_GATES.clear()
 
     def _guard_critic_readers(self):
         """Whoever reads the critic through torch — a forward pass of the module, state_dict() —
