@@ -29,6 +29,7 @@ struct MlpArgs {
   int plain;                // 1: plain policy gradient, loss = -mean(adv * logp) (actors.py:20-51)
   int pstride;
   int skew;                 // initial phase offset (x ~8k cycles) of the second wave per SIMD
+  int prio;                 // wave priorities of the 16-sample grad kernels (tuning key "grad_prio")
 };
 
 // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2|x|): one v_exp_f32 + one v_rcp_f32, no

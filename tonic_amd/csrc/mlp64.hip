@@ -766,6 +766,7 @@ std::atomic<int> g_grad_waves{4};
 // fp16x2 terms instead (three fp16 MFMAs per fp32 product, operands scaled into binary16's range; CH = 3).
 constexpr int kDefaultGradVariant = 4;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
+std::atomic<int> g_grad_prio{0};       // mlp64x16: wave priorities, see the kernel (0 off, 1 late half high, 2 alternate per tile)
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
@@ -860,6 +861,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_grad_skew = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "grad_prio") == 0) {
+    TONIC_REQUIRE(value >= 0 && value <= 2, TONIC_ERR_INVALID_ARGUMENT,
+                  "grad_prio must be 0, 1 or 2, got %d", value);
+    g_grad_prio = value;
+    return TONIC_OK;
+  }
   if (strcmp(key, "grad_variant") == 0) {
     TONIC_REQUIRE(value >= -1 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
                   "grad_variant must be 0 .. 4 or -1 (default), got %d", value);
@@ -906,6 +913,7 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
                 "tonic_get_tuning: null argument");
   if (strcmp(key, "grad_waves") == 0) { *value = g_grad_waves; return TONIC_OK; }
   if (strcmp(key, "grad_skew") == 0) { *value = g_grad_skew; return TONIC_OK; }
+  if (strcmp(key, "grad_prio") == 0) { *value = g_grad_prio; return TONIC_OK; }
   if (strcmp(key, "grad_variant") == 0) { *value = g_grad_variant; return TONIC_OK; }
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
   if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
@@ -1128,6 +1136,7 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
   a.out0 = static_cast<float*>(d_workspace);
   a.pstride = (int)pstride;
   a.skew = g_grad_skew;
+  a.prio = g_grad_prio;
   const int ap = ACTOR ? ap_bucket(a.A) : 1;
   hipStream_t st = as_stream(stream);
 #ifdef TONIC_DEV

@@ -711,6 +711,13 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   if (__builtin_amdgcn_readfirstlane(wave) >= kWaves16 / 2) {
     for (int k = 0; k < a.skew; ++k) __builtin_amdgcn_s_sleep(127);
   }
+  // Wave priorities (tonic_set_tuning "grad_prio"): the issue arbiter prefers the OLDER of the two waves
+  // of a SIMD, the second-dispatched half of a workgroup takes 14.4 k cycles per tile against 11.8 k
+  // (profiles/r04_grad_phases.txt) and the launch ends with the slow half.  1: waves 4 - 7 run at
+  // priority 1 throughout; 2: the two waves of a SIMD swap priorities every tile.  Timing only.
+  const bool late_half = __builtin_amdgcn_readfirstlane(wave) >= kWaves16 / 2;
+  if (a.prio == 1 && late_half) __builtin_amdgcn_s_setprio(1);
+  int prio_turn = late_half ? 1 : 0;
 
   // Per-sample inputs, branch-free: out-of-range lanes read a clamped (valid) address and the
   // value is discarded by a select.  (A load under `if (valid)` becomes an exec-masked branch
@@ -777,6 +784,11 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     wave_lds_sync();
   }
   for (; tile < ntiles; tile += tile_stride) {
+    if (a.prio == 2) {
+      if (prio_turn & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      ++prio_turn;
+    }
     PHASE(11);                                       // loop overhead / previous tail
     const int64_t ns = tile * 16 + s;
     const bool valid = ns < a.n;
