@@ -810,7 +810,14 @@ def cfg4_main(args, rank, world):
                    'parallelism': f'dp{world} (worker-axis shard of the Buffer, all-reduce of flat '
                                   'gradient sums)'},
         'us_per_iteration': round(seconds * 1e6, 1),
+        # the exchange of one iteration: the critics' sums every iteration, the actor's every second one
+        # (TD3's delay) — 1.5 all-reduces of 4 x these floats; one rank: none
         'allreduce_bytes_per_iteration': 4 * critic_floats + 2 * actor_floats,
+        'allreduces_per_iteration': 1.5 if world > 1 else 0,
+        # one rank: the whole update call (50 x 5 / 3 chained launches) replays from one hipGraph; several
+        # ranks: eager launches of the split entry points, the exchange between gradients and step
+        'hip_graph': bool(getattr(agent, '_graph', None) is not None),
+        'launches_per_iteration': 5 if world == 1 else 11,
         'allreduce_floats': dict(critics_every_iteration=critic_floats,
                                  actor_every_second=actor_floats),
         'roofline': dict(bound='mfma (latency-bound at B=100: 7 row tiles)', flop_per_iteration=int(flop),

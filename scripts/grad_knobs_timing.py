@@ -65,5 +65,5 @@ for prio, skew in ((0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 4), (0, 8), (2, 1
     ref = ref or bits
     print(f'grad_prio {prio} grad_skew {skew:2d}: actor {timed(actor):7.1f} us  critic {timed(critic):7.1f} us  '
           f'same bits: {bits == ref}', flush=True)
-_lib.check(lib.tonic_set_tuning(b'grad_prio', 0), 'tuning')
+_lib.check(lib.tonic_set_tuning(b'grad_prio', 2), 'tuning')
 _lib.check(lib.tonic_set_tuning(b'grad_skew', 0), 'tuning')

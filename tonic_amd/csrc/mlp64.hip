@@ -766,7 +766,10 @@ std::atomic<int> g_grad_waves{4};
 // fp16x2 terms instead (three fp16 MFMAs per fp32 product, operands scaled into binary16's range; CH = 3).
 constexpr int kDefaultGradVariant = 4;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
-std::atomic<int> g_grad_prio{0};       // mlp64x16: wave priorities, see the kernel (0 off, 1 late half high, 2 alternate per tile)
+// mlp64x16: wave priorities, see the kernel (0 off, 1 late half high, 2 the two waves of a SIMD swap priorities
+// every tile).  Measured (profiles/r05_grad_knobs.txt, N = 1 048 576): 2 takes the launch from 207.0 to 199.0 us
+// (actor) and 163.6 to 156.2 us (critic), same bits; 1 and every start skew change nothing or lose.
+std::atomic<int> g_grad_prio{2};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break
 
@@ -863,7 +866,7 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
   }
   if (strcmp(key, "grad_prio") == 0) {
     TONIC_REQUIRE(value >= 0 && value <= 2, TONIC_ERR_INVALID_ARGUMENT,
-                  "grad_prio must be 0, 1 or 2, got %d", value);
+                  "grad_prio must be 0, 1 or 2 (default), got %d", value);
     g_grad_prio = value;
     return TONIC_OK;
   }
