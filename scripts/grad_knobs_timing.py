@@ -57,7 +57,7 @@ for _ in range(40):           # the device's clock follows its load: warm it
     actor(); critic()
 torch.cuda.synchronize()
 ref = None
-for prio, skew in ((0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 4), (0, 8), (2, 1), (2, 4), (1, 4), (0, 0)):
+for prio, skew in [(int(a), int(b)) for a, b in (c.split(':') for c in (sys.argv[2] if len(sys.argv) > 2 else '0:0,1:0,2:0,0:1,0:4,2:1,0:0').split(','))]:
     _lib.check(lib.tonic_set_tuning(b'grad_prio', prio), 'tuning')
     _lib.check(lib.tonic_set_tuning(b'grad_skew', skew), 'tuning')
     actor(); critic(); torch.cuda.synchronize()
