@@ -478,6 +478,74 @@ def test_exchange_choice_is_unanimous_and_recorded_gloo(tmp_path):
         assert f'rank {r} ok' in out
 
 
+CFG4_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import tonic_amd
+from tonic_amd import parallel
+from tonic_amd.torch.agents import shard_noise
+rank, world = parallel.init_from_env(backend='gloo')
+# BASELINE config 4 (SURVEY 8 cfg table): Buffer() -> max_size = 1e6 // 512 = 1953 rows of 512 workers, the
+# reference's default batch of 100, 50 iterations per update, humanoid-walk actions (A = 21)
+W_global, B, iterations, A = 512, 100, 50, 21
+buf = tonic_amd.replays.Buffer(size=int(1e6), batch_size=B, batch_iterations=iterations)
+rows = int(1e6) // W_global
+assert rows == 1953
+lo, hi = parallel.shard_bounds(W_global)
+buf.num_workers, buf.global_workers, buf.rank, buf.world = hi - lo, W_global, rank, world
+buf.max_size, buf.size = rows, rows
+# the reference's global index stream (buffers.py:86) and the learner's noise, the same on every rank
+stream = np.random.RandomState(0)
+indices = np.stack([stream.randint(rows * W_global, size=B) for _ in range(iterations)])
+eps = np.random.RandomState(1).standard_normal((iterations, 1, B, A)).astype(np.float32)
+local, positions, counts = buf.shard_indices(indices)
+mine = shard_noise(eps, positions, counts, B)
+# (1) the per-rank parts partition every batch
+owned = torch.zeros(iterations, B, dtype=torch.int64)
+for it in range(iterations):
+    owned[it, positions[it, :counts[it]]] = 1
+dist.all_reduce(owned)
+assert bool((owned == 1).all()), 'every sample of a global batch belongs to exactly one rank'
+totals = torch.tensor(counts)
+dist.all_reduce(totals)
+assert bool((totals == B).all())
+# (2) a local index addresses the same transition in the [1953, 256] shard: transition ids as payload
+ids = np.arange(rows * W_global, dtype=np.int64).reshape(rows, W_global)[:, lo:hi].reshape(-1)
+for it in range(iterations):
+    c = counts[it]
+    assert np.array_equal(ids[local[it, :c]], indices[it, positions[it, :c]])
+    assert np.array_equal(mine[it, 0, :c], eps[it, 0, positions[it, :c]])
+# (3) the exchange of one optimizer step at this configuration's sizes: the critics' 177 666 + 8 gradient
+#     sums and the actor's 88 597 + 8 (SURVEY 8e), summed over the ranks in one all-reduce each
+for floats in (177666 + 8, 88597 + 8):
+    sums = torch.arange(floats, dtype=torch.float32) % 1009.0 * (rank + 1)
+    parallel.allreduce_sums(sums)
+    want = torch.arange(floats, dtype=torch.float32) % 1009.0 * (world * (world + 1) // 2)
+    assert torch.equal(sums, want)
+print('rank', rank, 'ok', int(counts.min()), int(counts.max()))
+'''
+
+
+def test_cfg4_shard_path_at_baseline_shapes_gloo(tmp_path):
+    """BASELINE config 4's sharded learner on two CPU ranks at its REAL shapes — the global [1953, 512] Buffer
+    split into [1953, 256] shards, the reference's default batch of 100, 50 iterations: the global index stream
+    splits into per-rank parts that partition every batch and address the right transitions, the noise rows
+    follow their samples, and the per-step exchange (177 674 / 88 605 floats) sums over the ranks."""
+    script = tmp_path / 'cfg4.py'
+    script.write_text(CFG4_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', WORLD_SIZE='2',
+               OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f'rank {r} ok' in out
+
+
 def test_buffer_shard_indices_partition_the_global_batch():
     """SURVEY §8e, off-policy: every rank draws the same GLOBAL index stream and keeps the samples
     whose worker column it owns.  The per-rank parts must partition the batch, and the local
