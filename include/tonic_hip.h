@@ -38,7 +38,7 @@ extern "C" {
 typedef enum tonic_status {
   TONIC_OK = 0,
   TONIC_ERR_INVALID_ARGUMENT = -1,   /* bad shape / NULL pointer / unsupported size   */
-  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* PPO path: O > 384, A > 32 or hidden != 64; the    */
+  TONIC_ERR_UNSUPPORTED_SHAPE = -2,  /* PPO path: O > 384, A > 32, a torso outside 1..4 layers of 4..384; the */
                                      /* workspace-less forwards: O > 32 or A > 8          */
   TONIC_ERR_LAUNCH = -3,             /* a HIP runtime call / kernel launch failed       */
   TONIC_ERR_WORKSPACE = -4,          /* workspace too small                             */
@@ -51,7 +51,7 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad, 7 = tonic_stream_gate)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -168,6 +168,46 @@ int tonic_value_regression_grad(const float* d_critic_params, const float* d_nor
                                 const float* d_returns, float* d_grad_sums, int64_t n,
                                 int32_t O, int32_t max_workgroups, void* d_workspace,
                                 int64_t workspace_bytes, void* stream);
+
+/* ---- PPO / A2C networks with ANY torso --------------------------------------------------------
+ * replaces: the same reference code as the five entries above for actor / critic networks built with
+ *   tonic.torch.models.MLP(sizes, activation) other than the default (tonic/torch/models/utils.py:4-23;
+ *   the default MLP((64, 64), Tanh) of a2c.py:7-17 is served by the entries above): `layers` hidden
+ *   layers (1 .. 4) of `sizes[l]` units (4 .. 384, multiples of 4), activation 1 = torch.nn.Tanh,
+ *   2 = torch.nn.ReLU; heads as above (DetachedScaleGaussianPolicyHead / ValueHead).  Layer by layer on
+ *   fp32 MFMA tiles with the activations in the workspace (csrc/mlpwide.hip); O <= 384, A <= 32.
+ * Parameter blocks: dense, parameters() order — per layer W [size, fan_in] then b [size]; actor: then
+ *   log_scale [A], W_loc [A, last], b_loc [A]; critic: w_v [last], b_v [1].  tonic_ppo_torso_param_count
+ *   returns the float count (-1: unsupported torso / shape), tonic_ppo_torso_workspace_bytes the scratch.
+ * Same argument meaning, outputs (gradient SUMS + 8 statistic sums) and error behaviour as the
+ *   entries they mirror.
+ */
+int64_t tonic_ppo_torso_param_count(int32_t O, int32_t A, int32_t actor, int32_t layers,
+                                    const int32_t* sizes);
+int64_t tonic_ppo_torso_workspace_bytes(int64_t n, int32_t O, int32_t A, int32_t actor, int32_t layers,
+                                        const int32_t* sizes);
+int tonic_ppo_act_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                        const float* d_actor_params, const float* d_observations, const float* d_eps,
+                        float* d_actions, float* d_log_probs, int64_t n, int32_t O, int32_t A,
+                        void* d_workspace, int64_t workspace_bytes, void* stream);
+int tonic_value_forward_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                              const float* d_critic_params, const float* d_norm_mean,
+                              const float* d_norm_std, double norm_clip, const float* d_observations,
+                              float* d_values, int64_t n, int32_t O, void* d_workspace,
+                              int64_t workspace_bytes, void* stream);
+int tonic_ppo_actor_grad_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                               const float* d_actor_params, const float* d_observations,
+                               const float* d_actions, const float* d_advantages,
+                               const float* d_adv_stats, const float* d_old_log_probs,
+                               float* d_grad_sums, int64_t n, int32_t O, int32_t A,
+                               double ratio_clip, double entropy_coeff, const int32_t* d_skip_flag,
+                               void* d_workspace, int64_t workspace_bytes, void* stream);
+int tonic_value_regression_grad_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                                      const float* d_critic_params, const float* d_norm_mean,
+                                      const float* d_norm_std, double norm_clip,
+                                      const float* d_observations, const float* d_returns,
+                                      float* d_grad_sums, int64_t n, int32_t O, void* d_workspace,
+                                      int64_t workspace_bytes, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------
  * replaces: torch.optim.Adam single-tensor path (torch/optim/adam.py:395-547) as

@@ -1471,17 +1471,23 @@ def _generic_ppo_agent(g, steps, iterations):
     return agent
 
 
+@pytest.mark.parametrize('path', ['hip', 'stock'])
 @pytest.mark.parametrize('name', ['ppo_relu256_small', 'ppo_tanh3_small'])
-def test_ppo_with_any_torso_matches_reference(golden, lib, name):
+def test_ppo_with_any_torso_matches_reference(golden, lib, name, path, monkeypatch):
     """models/utils.py:4-23 accepts any MLP(sizes, activation): PPO with MLP((256, 256), ReLU) and
-    with three tanh layers (96, 48, 32) — shapes the hand-written kernels do not serve, run as
-    stock torch operators on the device — replays the reference agent's run: identical
-    initialisation from the seed, the acting trajectory (actions, log-probabilities), and one whole
-    learner update (returns, per-iteration statistics, KL stop, parameter deltas)."""
+    with three tanh layers (96, 48, 32) — torsos the fused kernels do not hold — replays the reference
+    agent's run: identical initialisation from the seed, the acting trajectory (actions,
+    log-probabilities), and one whole learner update (returns, per-iteration statistics, KL stop,
+    parameter deltas).  `hip`: the layer-by-layer HIP path (the tonic_*_torso entries, csrc/mlpwide.hip:
+    1 .. 4 layers of 4 .. 384 units, Tanh / ReLU); `stock`: what every torso outside that serves runs on —
+    stock torch operators on the device (TONIC_AMD_TORSO_STOCK=1 forces it here)."""
+    if path == 'stock':
+        monkeypatch.setenv('TONIC_AMD_TORSO_STOCK', '1')
     g = golden(name)
     W, steps, iterations = int(g['cfg'][2]), int(g['cfg'][3]), int(g['cfg'][5])
     agent = _generic_ppo_agent(g, steps, iterations)
-    assert agent.actor_updater.stock and agent.critic_updater.stock
+    for updater in (agent.actor_updater, agent.critic_updater):
+        assert updater.stock == (path == 'stock') and (updater.torso is not None) == (path == 'hip')
     state = agent.model.state_dict()
     for key in state:       # identical initialisation from the same seed (CPU init parity)
         np.testing.assert_array_equal(state[key].cpu().numpy(), g['init/' + key], err_msg=key)
@@ -1519,3 +1525,94 @@ def test_ppo_with_any_torso_matches_reference(golden, lib, name):
         # (float32 summation order differs between torch-CPU and the device: a few Adam steps turn
         #  a gradient element at rounding level into a step of its own — DESIGN.md §2)
         assert (diff <= 2e-5).mean() >= 0.999 and diff.max() <= 2e-4, (key, diff.max())
+
+
+@pytest.mark.parametrize('sizes,activation,O,A,n', [
+    ((256, 256), 'ReLU', 17, 6, 20011), ((96, 48, 32), 'Tanh', 11, 3, 4099), ((128,), 'Tanh', 28, 8, 5000),
+    ((64, 64, 64, 64), 'ReLU', 5, 2, 3000), ((384, 8), 'Tanh', 111, 8, 2500), ((400 - 16, 300), 'ReLU', 40, 21, 1037)])
+def test_torso_grads_vs_float64_autograd(lib, sizes, activation, O, A, n):
+    """The tonic_*_torso entries (any MLP(sizes, activation) of models/utils.py:4-23 on the layer-by-layer HIP
+    path): gradient SUMS of the PPO actor loss and of the critic's squared error, the value forward and the
+    acting forward against float64 torch autograd of the same networks — one to four layers, 4 .. 384 units,
+    Tanh / ReLU, layers wider than one 64-output slice, ragged batches."""
+    import ctypes
+    from tonic_amd import _lib
+    rng = np.random.RandomState(len(sizes) * 1000 + O)
+    act = dict(Tanh=1, ReLU=2)[activation]
+    fn = torch.tanh if act == 1 else torch.relu
+    arr = (ctypes.c_int32 * len(sizes))(*sizes)
+    dims = (O,) + tuple(sizes)
+    torso = []
+    for fan_in, fan_out in zip(dims[:-1], dims[1:]):
+        torso += [rng.normal(size=(fan_out, fan_in)) / np.sqrt(fan_in), rng.normal(size=fan_out) * 0.1]
+    last = sizes[-1]
+    actor = torso + [rng.normal(size=(1, A)) * 0.2, rng.normal(size=(A, last)) / np.sqrt(last),
+                     rng.normal(size=A) * 0.1]
+    critic = torso + [rng.normal(size=(1, last)) / np.sqrt(last), rng.normal(size=1)]
+    actor, critic = [p.astype(np.float32) for p in actor], [p.astype(np.float32) for p in critic]
+    assert lib.tonic_ppo_torso_param_count(O, A, 1, len(sizes), arr) == flat(actor).size
+    assert lib.tonic_ppo_torso_param_count(O, 1, 0, len(sizes), arr) == flat(critic).size
+    obs = rng.standard_normal((n, O)).astype(np.float32)
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    returns = rng.standard_normal(n).astype(np.float32)
+    mean = (rng.standard_normal(O) * 0.1).astype(np.float32)
+    std = (1 + 0.3 * rng.uniform(size=O)).astype(np.float32)
+
+    def f64(arrays):
+        return [torch.tensor(np.asarray(a, np.float64), device='cuda', requires_grad=True) for a in arrays]
+
+    def body(x, params):
+        for W, b in zip(params[0::2], params[1::2]):
+            x = fn(x @ W.T + b)
+        return x
+    x = torch.tensor(obs.astype(np.float64), device='cuda')
+    pa = f64(actor)
+    loc = torch.tanh(body(x, pa[:-3]) @ pa[-2].T + pa[-1])
+    dist = torch.distributions.Normal(loc, (torch.nn.functional.softplus(pa[-3]) + 1e-8).clamp(1e-4, 1.0))
+    a_t = torch.tensor(actions.astype(np.float64), device='cuda')
+    old_lp = (dist.log_prob(a_t).sum(-1).detach().cpu().numpy() + rng.normal(size=n) * 0.1).astype(np.float32)
+    ratio = torch.exp(dist.log_prob(a_t).sum(-1) - torch.tensor(old_lp.astype(np.float64), device='cuda'))
+    adv_t = torch.tensor(adv.astype(np.float64), device='cuda')
+    loss = -torch.min(adv_t * ratio, adv_t * ratio.clamp(0.8, 1.2)).sum()
+    want_a = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, pa)]).cpu().numpy()
+    pc = f64(critic)
+    xn = (x - torch.tensor(mean.astype(np.float64), device='cuda')) / torch.tensor(std.astype(np.float64), device='cuda')
+    v = (body(xn, pc[:-2]) @ pc[-2].T + pc[-1])[:, 0]
+    want_c = torch.cat([g.reshape(-1) for g in torch.autograd.grad(
+        ((v - torch.tensor(returns.astype(np.float64), device='cuda')) ** 2).sum(), pc)]).cpu().numpy()
+
+    P, Pc = flat(actor).size, flat(critic).size
+    ws = torch.empty(max(lib.tonic_ppo_torso_workspace_bytes(n, O, A, 1, len(sizes), arr),
+                         lib.tonic_ppo_torso_workspace_bytes(n, O, 1, 0, len(sizes), arr)),
+                     dtype=torch.uint8, device='cuda')
+    keep = [dev(flat(actor)), dev(obs), dev(actions), dev(adv), dev(np.array([0, 1, 0, 0], np.float32)),
+            dev(old_lp)]
+    out = torch.zeros(P + 8, device='cuda')
+    _lib.check(lib.tonic_ppo_actor_grad_torso(len(sizes), arr, act, *[t.data_ptr() for t in keep], out.data_ptr(),
+                                              n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor')
+    got_a = out.cpu().numpy()
+    assert np.abs(got_a[:P] - want_a).max() <= 2e-5 * np.abs(want_a).max(), np.abs(got_a[:P] - want_a).max()
+    np.testing.assert_allclose(got_a[P] / n, float(loss) / n, rtol=2e-5, atol=2e-6)
+    keepc = [dev(flat(critic)), dev(mean), dev(std), dev(obs), dev(returns)]
+    outc = torch.zeros(Pc + 8, device='cuda')
+    _lib.check(lib.tonic_value_regression_grad_torso(
+        len(sizes), arr, act, *[t.data_ptr() for t in keepc[:3]], 0.0, *[t.data_ptr() for t in keepc[3:]],
+        outc.data_ptr(), n, O, ws.data_ptr(), ws.numel(), None), 'critic')
+    got_c = outc.cpu().numpy()
+    assert np.abs(got_c[:Pc] - want_c).max() <= 2e-5 * np.abs(want_c).max(), np.abs(got_c[:Pc] - want_c).max()
+    values = torch.empty(n, device='cuda')
+    _lib.check(lib.tonic_value_forward_torso(len(sizes), arr, act, *[t.data_ptr() for t in keepc[:3]], 0.0,
+                                             keepc[3].data_ptr(), values.data_ptr(), n, O, ws.data_ptr(),
+                                             ws.numel(), None), 'values')
+    np.testing.assert_allclose(values.cpu().numpy(), v.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    eps = rng.standard_normal((n, A)).astype(np.float32)
+    acts, lps = torch.empty(n, A, device='cuda'), torch.empty(n, device='cuda')
+    keepe = dev(eps)
+    _lib.check(lib.tonic_ppo_act_torso(len(sizes), arr, act, keep[0].data_ptr(), keep[1].data_ptr(),
+                                       keepe.data_ptr(), acts.data_ptr(), lps.data_ptr(), n, O, A,
+                                       ws.data_ptr(), ws.numel(), None), 'act')
+    want_act = dist.loc.detach() + dist.scale.detach() * torch.tensor(eps.astype(np.float64), device='cuda')
+    np.testing.assert_allclose(acts.cpu().numpy(), want_act.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lps.cpu().numpy(), dist.log_prob(want_act).sum(-1).detach().cpu().numpy(),
+                               rtol=1e-5, atol=2e-5)

@@ -61,6 +61,16 @@ SIGNATURES = {
                                                           c_vp, c_i32, c_vp, c_i64, c_vp]),
     'tonic_value_regression_grad': (ctypes.c_int, [c_vp] * 3 + [c_f64] + [c_vp] * 3 +
                                     [c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    'tonic_ppo_torso_param_count': (c_i64, [c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'tonic_ppo_torso_workspace_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'tonic_ppo_act_torso': (ctypes.c_int, [c_i32, c_vp, c_i32] + [c_vp] * 5 + [c_i64, c_i32, c_i32, c_vp,
+                                                                           c_i64, c_vp]),
+    'tonic_value_forward_torso': (ctypes.c_int, [c_i32, c_vp, c_i32] + [c_vp] * 3 + [c_f64] + [c_vp] * 2 +
+                                  [c_i64, c_i32, c_vp, c_i64, c_vp]),
+    'tonic_ppo_actor_grad_torso': (ctypes.c_int, [c_i32, c_vp, c_i32] + [c_vp] * 7 +
+                                   [c_i64, c_i32, c_i32, c_f64, c_f64, c_vp, c_vp, c_i64, c_vp]),
+    'tonic_value_regression_grad_torso': (ctypes.c_int, [c_i32, c_vp, c_i32] + [c_vp] * 3 + [c_f64] +
+                                          [c_vp] * 3 + [c_i64, c_i32, c_vp, c_i64, c_vp]),
     'tonic_adam_step': (ctypes.c_int, [c_vp] * 5 + [c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                                      c_i32, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'tonic_clip_workspace_bytes': (c_i64, [c_i64]),
@@ -150,7 +160,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 7        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 8        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

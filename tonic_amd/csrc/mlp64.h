@@ -43,21 +43,35 @@ __device__ __forceinline__ float tanh_fast(float x) {
 
 // mlp64.hip: fixed-order fold of the per-workgroup partial images into d_grad_sums (+ the
 // log_scale / entropy / sigma post-processing of the actor)
+// (log_scale_offset: where the actor's log_scale sits in the block; < 0: the default torso's place)
 int launch_reduce_partials(bool actor, const float* partials, int blocks, int pstride, int P,
                            const float* params, float* d_grad_sums, int O, int A,
                            float entropy_coeff, double rows, const int32_t* skip,
-                           hipStream_t stream);
+                           hipStream_t stream, int log_scale_offset = -1);
 
-// mlpwide.hip: the layer-by-layer path for shapes outside the fused kernels (O > 32 or A > 8)
+// mlpwide.hip: the layer-by-layer path — shapes outside the fused kernels (O > 32 or A > 8) and ANY torso
+// MLP(sizes, activation) of tonic/torch/models/utils.py:4-23 (1 .. 4 hidden layers of 4 .. 384 units,
+// multiples of 4, Tanh or ReLU); the default argument is the reference's default torso (a2c.py:7-17).
+constexpr int kMaxTorsoLayers = 4;
+struct Torso {
+  int layers;
+  int size[kMaxTorsoLayers];
+  int act;                                   // 1 Tanh, 2 ReLU
+  static Torso standard() { return Torso{2, {64, 64, 0, 0}, 1}; }
+};
+bool torso_supported(const Torso& t);
+int64_t torso_param_count(int O, int A, bool actor, const Torso& t);
 bool wide_shape(int O, int A, bool actor);
 bool wide_supported(int O, int A, bool actor);
-int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor);
+int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor, const Torso& t = Torso::standard());
 int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, void* d_workspace,
-                    int64_t workspace_bytes, hipStream_t stream);
+                    int64_t workspace_bytes, hipStream_t stream, const Torso& t = Torso::standard());
 int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
-                     int64_t workspace_bytes, hipStream_t stream);
-int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream);
-int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream);
+                     int64_t workspace_bytes, hipStream_t stream, const Torso& t = Torso::standard());
+int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream,
+             const Torso& t = Torso::standard());
+int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t stream,
+               const Torso& t = Torso::standard());
 
 // mlp64x16.hip
 bool grad16_supported(int O, int A, bool actor);

@@ -690,7 +690,7 @@ constexpr int kReduceWaves = 16;
 template <bool ACTOR>
 __global__ __launch_bounds__(kReduceWaves * 64) void reduce_partials_kernel(
     const float* partials, int nblocks, int pstride, int P, const float* params,
-    float* grad_sums, int O, int A, float entropy_coeff, double nloc, const int32_t* skip) {
+    float* grad_sums, int oLs, int A, float entropy_coeff, double nloc, const int32_t* skip) {
   __shared__ double slices[kReduceWaves][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
@@ -722,7 +722,6 @@ __global__ __launch_bounds__(kReduceWaves * 64) void reduce_partials_kernel(
   for (int w = 0; w < kReduceWaves; ++w) acc += slices[w][lane];
   float out = (float)acc;
   if (ACTOR) {
-    const int oLs = 64 * O + 64 + 4096 + 64;
     if (p >= oLs && p < oLs + A) {
       const float ls = params[p];
       const float sp = ls > 20.f ? ls : log1pf(expf(ls));
@@ -1165,15 +1164,16 @@ static int run_grad(MlpArgs a, int64_t P, float* d_grad_sums, float entropy_coef
 int tonic::launch_reduce_partials(bool actor, const float* partials, int blocks, int pstride, int P,
                                   const float* params, float* d_grad_sums, int O, int A,
                                   float entropy_coeff, double rows, const int32_t* skip,
-                                  hipStream_t st) {
+                                  hipStream_t st, int log_scale_offset) {
   const int total = P + kStatSlots;
+  const int oLs = log_scale_offset >= 0 ? log_scale_offset : 64 * O + 64 + 4096 + 64;
   const dim3 grid((total + 63) / 64), block(kReduceWaves * 64);
   if (actor)
     hipLaunchKernelGGL(reduce_partials_kernel<true>, grid, block, 0, st, partials, blocks, pstride,
-                       P, params, d_grad_sums, O, A, entropy_coeff, rows, skip);
+                       P, params, d_grad_sums, oLs, A, entropy_coeff, rows, skip);
   else
     hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, block, 0, st, partials, blocks, pstride,
-                       P, params, d_grad_sums, O, A, entropy_coeff, rows, skip);
+                       P, params, d_grad_sums, oLs, A, entropy_coeff, rows, skip);
   TONIC_CHECK_LAUNCH("reduce_partials_kernel");
   return TONIC_OK;
 }
@@ -1203,6 +1203,114 @@ extern "C" int tonic_ppo_actor_grad(const float* d_actor_params, const float* d_
   return run_grad<true>(a, tonic_ppo_actor_param_count(O, A), d_grad_sums,
                         (float)entropy_coeff, max_workgroups,
                         d_workspace, workspace_bytes, stream);
+}
+
+// ---- any MLP(sizes, activation) torso: the layer-by-layer path (mlpwide.hip)
+static int torso_from(int32_t layers, const int32_t* sizes, int32_t activation, Torso& t) {
+  TONIC_REQUIRE(sizes != nullptr && layers >= 1 && layers <= kMaxTorsoLayers, TONIC_ERR_UNSUPPORTED_SHAPE,
+                "torso: %d hidden layers (1 .. %d are served)", layers, kMaxTorsoLayers);
+  t = Torso{layers, {0, 0, 0, 0}, activation};
+  for (int l = 0; l < layers; ++l) t.size[l] = sizes[l];
+  TONIC_REQUIRE(torso_supported(t), TONIC_ERR_UNSUPPORTED_SHAPE,
+                "torso: layers of 4 .. 384 units (multiples of 4), activation 1 (Tanh) or 2 (ReLU)");
+  return TONIC_OK;
+}
+
+extern "C" int64_t tonic_ppo_torso_param_count(int32_t O, int32_t A, int32_t actor, int32_t layers,
+                                               const int32_t* sizes) {
+  Torso t;
+  if (torso_from(layers, sizes, 1, t) != TONIC_OK || !wide_supported(O, actor ? A : 1, actor != 0)) return -1;
+  return torso_param_count(O, actor ? A : 1, actor != 0, t);
+}
+
+extern "C" int64_t tonic_ppo_torso_workspace_bytes(int64_t n, int32_t O, int32_t A, int32_t actor,
+                                                   int32_t layers, const int32_t* sizes) {
+  Torso t;
+  if (n <= 0 || torso_from(layers, sizes, 1, t) != TONIC_OK ||
+      !wide_supported(O, actor ? A : 1, actor != 0))
+    return -1;
+  return wide_workspace_bytes(n, O, actor ? A : 1, actor != 0, t);
+}
+
+extern "C" int tonic_ppo_act_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                                   const float* d_actor_params, const float* d_observations,
+                                   const float* d_eps, float* d_actions, float* d_log_probs, int64_t n,
+                                   int32_t O, int32_t A, void* d_workspace, int64_t workspace_bytes,
+                                   void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && n >= 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_ppo_act_torso: null argument");
+  Torso t;
+  if (int rc = torso_from(layers, sizes, activation, t)) return rc;
+  if (int rc = check_wide(O, A, true)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.eps = d_eps;
+  a.out0 = d_actions; a.out1 = d_log_probs; a.n = n; a.O = O; a.A = A;
+  return wide_act(a, d_workspace, workspace_bytes, as_stream(stream), t);
+}
+
+extern "C" int tonic_value_forward_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                                         const float* d_critic_params, const float* d_norm_mean,
+                                         const float* d_norm_std, double norm_clip,
+                                         const float* d_observations, float* d_values, int64_t n,
+                                         int32_t O, void* d_workspace, int64_t workspace_bytes,
+                                         void* stream) {
+  TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_values && n >= 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_value_forward_torso: null argument");
+  Torso t;
+  if (int rc = torso_from(layers, sizes, activation, t)) return rc;
+  if (int rc = check_wide(O, 1, false)) return rc;
+  if (n == 0) return TONIC_OK;
+  MlpArgs a{};
+  a.params = d_critic_params; a.obs = d_observations; a.norm_mean = d_norm_mean;
+  a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
+  a.out0 = d_values; a.n = n; a.O = O; a.A = 1;
+  return wide_value(a, d_workspace, workspace_bytes, as_stream(stream), t);
+}
+
+extern "C" int tonic_ppo_actor_grad_torso(int32_t layers, const int32_t* sizes, int32_t activation,
+                                          const float* d_actor_params, const float* d_observations,
+                                          const float* d_actions, const float* d_advantages,
+                                          const float* d_adv_stats, const float* d_old_log_probs,
+                                          float* d_grad_sums, int64_t n, int32_t O, int32_t A,
+                                          double ratio_clip, double entropy_coeff,
+                                          const int32_t* d_skip_flag, void* d_workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(d_actor_params && d_observations && d_actions && d_advantages && d_adv_stats &&
+                    d_old_log_probs && d_grad_sums && n > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_ppo_actor_grad_torso: bad argument");
+  Torso t;
+  if (int rc = torso_from(layers, sizes, activation, t)) return rc;
+  if (int rc = check_wide(O, A, true)) return rc;
+  MlpArgs a{};
+  a.params = d_actor_params; a.obs = d_observations; a.actions = d_actions;
+  a.adv = d_advantages; a.adv_stats = d_adv_stats; a.old_logp = d_old_log_probs;
+  a.skip = d_skip_flag; a.n = n; a.O = O; a.A = A;
+  a.clip_lo = (float)(1.0 - ratio_clip);
+  a.clip_hi = (float)(1.0 + ratio_clip);
+  a.plain = ratio_clip < 0 ? 1 : 0;
+  return wide_actor_grad(a, d_grad_sums, (float)entropy_coeff, d_workspace, workspace_bytes,
+                         as_stream(stream), t);
+}
+
+extern "C" int tonic_value_regression_grad_torso(int32_t layers, const int32_t* sizes,
+                                                 int32_t activation, const float* d_critic_params,
+                                                 const float* d_norm_mean, const float* d_norm_std,
+                                                 double norm_clip, const float* d_observations,
+                                                 const float* d_returns, float* d_grad_sums, int64_t n,
+                                                 int32_t O, void* d_workspace, int64_t workspace_bytes,
+                                                 void* stream) {
+  TONIC_REQUIRE(d_critic_params && d_norm_mean && d_norm_std && d_observations && d_returns &&
+                    d_grad_sums && n > 0,
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_value_regression_grad_torso: bad argument");
+  Torso t;
+  if (int rc = torso_from(layers, sizes, activation, t)) return rc;
+  if (int rc = check_wide(O, 1, false)) return rc;
+  MlpArgs a{};
+  a.params = d_critic_params; a.obs = d_observations; a.returns = d_returns;
+  a.norm_mean = d_norm_mean; a.norm_std = d_norm_std; a.norm_clip = clip_bound(norm_clip);
+  a.n = n; a.O = O; a.A = 1;
+  return wide_critic_grad(a, d_grad_sums, d_workspace, workspace_bytes, as_stream(stream), t);
 }
 
 // Developer tool: per-phase s_memtime totals of the 8 waves of workgroup 0 of the 16x16x4 actor

@@ -40,12 +40,20 @@ struct DenseArgs {
   const float* W; int ldw; int transposed; // weight(j, k) = transposed ? W[k * ldw + j] : W[j * ldw + k]
   const float* bias;                       // [NOUT] or null
   const float* norm_mean; const float* norm_std; float norm_clip;   // null: input not normalised
-  const float* D;                          // [N, ldy] or null: multiply the result by (1 - D^2)
+  const float* D;                          // [N, ldy] or null: multiply the result by act'(z) given D = act(z):
+  int dkind;                               //   1 tanh: 1 - D^2;  2 ReLU: D > 0
   float* Y; int ldy;
   int64_t N;
-  int K, NOUT, act;                        // act: 0 none, 1 tanh
+  int K, NOUT, act;                        // act: 0 none, 1 tanh, 2 ReLU
   const int32_t* skip;
 };
+
+__device__ __forceinline__ float wide_activation(float z, int act) {
+  return act == 1 ? tanh_fast(z) : act == 2 ? fmaxf(z, 0.f) : z;
+}
+__device__ __forceinline__ float wide_derivative(float v, float d, int dkind) {
+  return dkind == 2 ? (d > 0.f ? v : 0.f) : v * (1.f - d * d);
+}
 
 // TN = feature tiles of 16 outputs (NOUT <= 16 * TN).
 template <int TN>
@@ -166,14 +174,14 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += a.bias[j + r];
             }
-            if (a.act == 1) {
+            if (a.act != 0) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = tanh_fast(v[r]);
+              for (int r = 0; r < 4; ++r) v[r] = wide_activation(v[r], a.act);
             }
             if (a.D != nullptr) {
               const f32x4 d = *reinterpret_cast<const f32x4*>(a.D + row * a.ldy + j);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = v[r] * (1.f - d[r] * d[r]);
+              for (int r = 0; r < 4; ++r) v[r] = wide_derivative(v[r], d[r], a.dkind);
             }
             *reinterpret_cast<f32x4*>(a.Y + row * a.ldy + j) = v;
           }
@@ -186,11 +194,8 @@ __global__ __launch_bounds__(kWideThreads) void dense_kernel(DenseArgs a) {
             const int j = 16 * T + 4 * g + r;              // D[row = feature][col = sample]
             if (j < a.NOUT) {
               float v = acc[T][r] + (a.bias != nullptr ? a.bias[j] : 0.f);
-              if (a.act == 1) v = tanh_fast(v);
-              if (a.D != nullptr) {
-                const float d = a.D[row * a.ldy + j];
-                v = v * (1.f - d * d);
-              }
+              v = wide_activation(v, a.act);
+              if (a.D != nullptr) v = wide_derivative(v, a.D[row * a.ldy + j], a.dkind);
               a.Y[row * a.ldy + j] = v;
             }
           }
@@ -597,9 +602,30 @@ __global__ void gather_column_kernel(const float* src, int ld, float* dst, int64
 
 // ---------------------------------------------------------------------------------- host side
 
+int launch_dense_slice(const DenseArgs& a, hipStream_t st);
+
+// One layer: the kernel holds the weight image of at most 64 outputs in LDS — wider layers go out as
+// slices of 64 outputs (rows of W, or columns of W^T; bias, mask and result columns move along).
 int launch_dense(const DenseArgs& a, hipStream_t st) {
+  if (a.NOUT <= 64) return launch_dense_slice(a, st);
+  for (int j0 = 0; j0 < a.NOUT; j0 += 64) {
+    DenseArgs d = a;
+    d.NOUT = a.NOUT - j0 < 64 ? a.NOUT - j0 : 64;
+    d.W = a.transposed ? a.W + j0 : a.W + (int64_t)j0 * a.ldw;
+    if (a.bias != nullptr) d.bias = a.bias + j0;
+    if (a.D != nullptr) d.D = a.D + j0;
+    d.Y = a.Y + j0;
+    if (int rc = launch_dense_slice(d, st)) return rc;
+  }
+  return TONIC_OK;
+}
+
+int launch_dense_slice(const DenseArgs& a, hipStream_t st) {
   const bool vec = (a.K & 3) == 0 && (a.ldx & 3) == 0;           // (as in the kernel)
-  const int tn = (a.NOUT + 15) / 16, ks = vec ? 4 * ((a.K + 15) / 16) : (a.K + 3) / 4;
+  const int tiles_out = (a.NOUT + 15) / 16, ks = vec ? 4 * ((a.K + 15) / 16) : (a.K + 3) / 4;
+  // (the kernel is instantiated for 1, 2 or 4 feature tiles and lays its LDS out for THAT many: three tiles
+  //  — a 33 .. 48-output slice of a torso layer — run the four-tile instance)
+  const int tn = tiles_out <= 1 ? 1 : tiles_out == 2 ? 2 : 4;
   const int lds_bytes = tn * ks * 64 * 4 + (vec ? 0 : 4 * 16 * 68 * 4);   // + the waves' transpose tiles
   const int64_t tiles = (a.N + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;
@@ -647,7 +673,23 @@ int launch_wgrad_rows(const WgradArgs& a, int blocks, hipStream_t st) {
   return TONIC_OK;
 }
 
+int launch_wgrad_slice(const WgradArgs& a, int blocks, hipStream_t st);
+
+// dW of one layer in slices of 64 output rows (the kernels hold at most four 16-row tiles per wave)
 int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
+  if (a.NOUT <= 64) return launch_wgrad_slice(a, blocks, st);
+  for (int j0 = 0; j0 < a.NOUT; j0 += 64) {
+    WgradArgs w = a;
+    w.NOUT = a.NOUT - j0 < 64 ? a.NOUT - j0 : 64;
+    w.dY = a.dY + j0;
+    w.w_offset = a.w_offset + j0 * a.K;
+    w.b_offset = a.b_offset + j0;
+    if (int rc = launch_wgrad_slice(w, blocks, st)) return rc;
+  }
+  return TONIC_OK;
+}
+
+int launch_wgrad_slice(const WgradArgs& a, int blocks, hipStream_t st) {
   const int tj = (a.NOUT + 15) / 16, tk = (a.K + 15) / 16;
   if (tk <= 4) {                                         // hidden-layer inputs: row split
     if (tj <= 1) return launch_wgrad_rows<1, 4>(a, blocks, st);
@@ -663,73 +705,83 @@ int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
 }
 
 struct WideLayout {        // offsets (floats) inside the flat parameter block, and the scratch
-  int W1, b1, W2, b2, ls, W3, b3, P;
+  Torso t;
+  int W[kMaxTorsoLayers], b[kMaxTorsoLayers], ls, Wh, bh, P;     // parameters() order (models/utils.py:12-23)
   int blocks; int64_t slab, pstride;
-  int64_t off_h1, off_h2, off_out, off_dz3, off_dz2, off_dz1, off_image, bytes;
-  WideLayout(int64_t n, int O, int A, bool actor) {
-    W1 = 0; b1 = 64 * O; W2 = b1 + 64; b2 = W2 + 4096;
-    if (actor) { ls = b2 + 64; W3 = ls + A; b3 = W3 + 64 * A; P = b3 + A; }
-    else { ls = -1; W3 = b2 + 64; b3 = W3 + 64; P = b3 + 1; }
+  int64_t off_h[kMaxTorsoLayers], off_dz[kMaxTorsoLayers], off_out, off_dzh, off_image, bytes;
+  WideLayout(int64_t n, int O, int A, bool actor, const Torso& torso) : t(torso) {
+    int at = 0, in = O;
+    for (int l = 0; l < t.layers; ++l) {
+      W[l] = at; at += t.size[l] * in; b[l] = at; at += t.size[l]; in = t.size[l];
+    }
+    if (actor) { ls = at; Wh = ls + A; bh = Wh + in * A; P = bh + A; }       // actors.py:52-53: log_scale first
+    else { ls = -1; Wh = at; bh = Wh + in; P = bh + 1; }
     blocks = (int)((n + 63) / 64 < kWideBlocks ? (n + 63) / 64 : kWideBlocks);
     if (blocks < 1) blocks = 1;
     slab = round_up((n + blocks - 1) / blocks, 4);
     pstride = round_up(P + kStatSlots, 64);
-    const int64_t hidden = round_up(n * 64 * 4, 256), head = round_up(n * kWideLd * 4, 256);
-    off_h1 = 0; off_h2 = hidden; off_out = 2 * hidden; off_dz3 = off_out + head;
-    off_dz2 = off_dz3 + head; off_dz1 = off_dz2 + hidden;
-    off_image = off_dz1 + hidden;
+    int64_t off = 0;
+    for (int l = 0; l < t.layers; ++l) { off_h[l] = off; off += round_up(n * t.size[l] * 4, 256); }
+    const int64_t head = round_up(n * kWideLd * 4, 256);
+    off_out = off; off += head; off_dzh = off; off += head;
+    for (int l = 0; l < t.layers; ++l) { off_dz[l] = off; off += round_up(n * t.size[l] * 4, 256); }
+    off_image = off;
     bytes = off_image + round_up((int64_t)blocks * pstride * 4, 256);
   }
+  int last() const { return t.size[t.layers - 1]; }
 };
 
-// forward pass into the scratch: h1, h2, head outputs (tanh'ed locations / the value column)
+// forward pass into the scratch: hidden activations, head outputs (tanh'ed locations / the value column)
 int wide_forward(const float* params, const WideLayout& L, const float* obs, int64_t n, int O,
                  int A, bool actor, const float* mean, const float* std, float clip, char* ws,
                  const int32_t* skip, hipStream_t st) {
-  float* h1 = reinterpret_cast<float*>(ws + L.off_h1);
-  float* h2 = reinterpret_cast<float*>(ws + L.off_h2);
-  float* out = reinterpret_cast<float*>(ws + L.off_out);
   DenseArgs d{};
-  d.N = n; d.skip = skip; d.act = 1;
-  d.X = obs; d.ldx = O; d.W = params + L.W1; d.ldw = O; d.bias = params + L.b1; d.K = O;
-  d.NOUT = 64; d.Y = h1; d.ldy = 64;
+  d.N = n; d.skip = skip; d.act = L.t.act;
+  d.X = obs; d.ldx = O; d.K = O;
   d.norm_mean = mean; d.norm_std = std; d.norm_clip = clip;
-  if (int rc = launch_dense(d, st)) return rc;
-  d.norm_mean = nullptr; d.norm_std = nullptr;
-  d.X = h1; d.ldx = 64; d.W = params + L.W2; d.ldw = 64; d.bias = params + L.b2; d.K = 64;
-  d.Y = h2;
-  if (int rc = launch_dense(d, st)) return rc;
-  d.X = h2; d.W = params + L.W3; d.bias = params + L.b3; d.NOUT = actor ? A : 1; d.Y = out;
-  d.ldy = kWideLd; d.act = actor ? 1 : 0;
+  for (int l = 0; l < L.t.layers; ++l) {
+    float* h = reinterpret_cast<float*>(ws + L.off_h[l]);
+    d.W = params + L.W[l]; d.ldw = d.K; d.bias = params + L.b[l];
+    d.NOUT = L.t.size[l]; d.Y = h; d.ldy = L.t.size[l];
+    if (int rc = launch_dense(d, st)) return rc;
+    d.norm_mean = nullptr; d.norm_std = nullptr;
+    d.X = h; d.ldx = L.t.size[l]; d.K = L.t.size[l];
+  }
+  d.W = params + L.Wh; d.ldw = d.K; d.bias = params + L.bh; d.NOUT = actor ? A : 1;
+  d.Y = reinterpret_cast<float*>(ws + L.off_out); d.ldy = kWideLd;
+  d.act = actor ? 1 : 0;                         // loc_activation Tanh (actors.py:44-48) / none (critics.py:11)
   return launch_dense(d, st);
 }
 
-// backward pass from dz3 (in the scratch) to the per-slab partial images
+// backward pass from the head gradient (in the scratch) to the per-slab partial images
 int wide_backward(const float* params, const WideLayout& L, const float* obs, int64_t n, int O,
                   int A, bool actor, const float* mean, const float* std, float clip, char* ws,
                   const int32_t* skip, hipStream_t st) {
-  float* h1 = reinterpret_cast<float*>(ws + L.off_h1);
-  float* h2 = reinterpret_cast<float*>(ws + L.off_h2);
-  float* dz3 = reinterpret_cast<float*>(ws + L.off_dz3);
-  float* dz2 = reinterpret_cast<float*>(ws + L.off_dz2);
-  float* dz1 = reinterpret_cast<float*>(ws + L.off_dz1);
   float* image = reinterpret_cast<float*>(ws + L.off_image);
   const int nout = actor ? A : 1;
   WgradArgs w{};
   w.image = image; w.pstride = (int)L.pstride; w.N = n; w.slab = L.slab; w.skip = skip;
-  w.dY = dz3; w.ldy = kWideLd; w.NOUT = nout; w.X = h2; w.ldx = 64; w.K = 64;
-  w.w_offset = L.W3; w.b_offset = L.b3;
-  if (int rc = launch_wgrad(w, L.blocks, st)) return rc;
   DenseArgs d{};
-  d.N = n; d.skip = skip; d.act = 0; d.transposed = 1;
-  d.X = dz3; d.ldx = kWideLd; d.K = nout; d.W = params + L.W3; d.ldw = 64; d.NOUT = 64;
-  d.D = h2; d.Y = dz2; d.ldy = 64;
-  if (int rc = launch_dense(d, st)) return rc;
-  w.dY = dz2; w.ldy = 64; w.NOUT = 64; w.X = h1; w.w_offset = L.W2; w.b_offset = L.b2;
-  if (int rc = launch_wgrad(w, L.blocks, st)) return rc;
-  d.X = dz2; d.ldx = 64; d.K = 64; d.W = params + L.W2; d.D = h1; d.Y = dz1;
-  if (int rc = launch_dense(d, st)) return rc;
-  w.dY = dz1; w.X = obs; w.ldx = O; w.K = O; w.w_offset = L.W1; w.b_offset = L.b1;
+  d.N = n; d.skip = skip; d.act = 0; d.transposed = 1; d.dkind = L.t.act;
+  // the layer above layer l: its gradient dY [n, ldy] of `outs` columns, its weights at `w_up`
+  const float* dY = reinterpret_cast<const float*>(ws + L.off_dzh);
+  int ldy = kWideLd, outs = nout, w_up = L.Wh, b_up = L.bh;
+  for (int l = L.t.layers - 1; l >= 0; --l) {
+    const int H = L.t.size[l];
+    const float* h = reinterpret_cast<const float*>(ws + L.off_h[l]);
+    float* dz = reinterpret_cast<float*>(ws + L.off_dz[l]);
+    // weight gradient of the layer above: dW = dY^T . h
+    w.dY = dY; w.ldy = ldy; w.NOUT = outs; w.X = h; w.ldx = H; w.K = H;
+    w.w_offset = w_up; w.b_offset = b_up;
+    if (int rc = launch_wgrad(w, L.blocks, st)) return rc;
+    // dz_l = (dY . W_up) * act'(h_l)
+    d.X = dY; d.ldx = ldy; d.K = outs; d.W = params + w_up; d.ldw = H; d.NOUT = H;
+    d.D = h; d.Y = dz; d.ldy = H;
+    if (int rc = launch_dense(d, st)) return rc;
+    dY = dz; ldy = H; outs = H; w_up = L.W[l]; b_up = L.b[l];
+  }
+  w.dY = dY; w.ldy = ldy; w.NOUT = outs; w.X = obs; w.ldx = O; w.K = O;
+  w.w_offset = L.W[0]; w.b_offset = L.b[0];
   w.norm_mean = mean; w.norm_std = std; w.norm_clip = clip;
   return launch_wgrad(w, L.blocks, st);
 }
@@ -742,13 +794,24 @@ bool wide_supported(int O, int A, bool actor) {
   return O >= 1 && O <= 384 && (!actor || (A >= 1 && A <= kWideLd));
 }
 
-int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor) {
-  return WideLayout(n, O, A, actor).bytes;
+bool torso_supported(const Torso& t) {
+  if (t.layers < 1 || t.layers > kMaxTorsoLayers || (t.act != 1 && t.act != 2)) return false;
+  for (int l = 0; l < t.layers; ++l)
+    if (t.size[l] < 4 || t.size[l] > 384 || t.size[l] % 4 != 0) return false;
+  return true;
+}
+
+int64_t torso_param_count(int O, int A, bool actor, const Torso& t) {
+  return WideLayout(1, O, A, actor, t).P;
+}
+
+int64_t wide_workspace_bytes(int64_t n, int O, int A, bool actor, const Torso& t) {
+  return WideLayout(n, O, A, actor, t).bytes;
 }
 
 int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, void* d_workspace,
-                    int64_t workspace_bytes, hipStream_t st) {
-  const WideLayout L(a.n, a.O, a.A, true);
+                    int64_t workspace_bytes, hipStream_t st, const Torso& t) {
+  const WideLayout L(a.n, a.O, a.A, true, t);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
                 "wide actor grad: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
                 (long long)L.bytes);
@@ -758,7 +821,7 @@ int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, v
     return rc;
   PpoLossArgs l{};
   l.loc = reinterpret_cast<float*>(ws + L.off_out);
-  l.dz3 = reinterpret_cast<float*>(ws + L.off_dz3);
+  l.dz3 = reinterpret_cast<float*>(ws + L.off_dzh);
   l.ld = kWideLd; l.actions = a.actions; l.adv = a.adv; l.adv_stats = a.adv_stats;
   l.old_logp = a.old_logp; l.log_scale = a.params + L.ls;
   l.image = reinterpret_cast<float*>(ws + L.off_image); l.pstride = (int)L.pstride;
@@ -770,12 +833,12 @@ int wide_actor_grad(const MlpArgs& a, float* d_grad_sums, float entropy_coeff, v
                              a.skip, st))
     return rc;
   return launch_reduce_partials(true, l.image, L.blocks, (int)L.pstride, L.P, a.params,
-                                d_grad_sums, a.O, a.A, entropy_coeff, (double)a.n, a.skip, st);
+                                d_grad_sums, a.O, a.A, entropy_coeff, (double)a.n, a.skip, st, L.ls);
 }
 
 int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
-                     int64_t workspace_bytes, hipStream_t st) {
-  const WideLayout L(a.n, a.O, 1, false);
+                     int64_t workspace_bytes, hipStream_t st, const Torso& t) {
+  const WideLayout L(a.n, a.O, 1, false, t);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
                 "wide critic grad: workspace of %lld bytes, %lld needed",
                 (long long)workspace_bytes, (long long)L.bytes);
@@ -785,7 +848,7 @@ int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
     return rc;
   ValueLossArgs l{};
   l.values = reinterpret_cast<float*>(ws + L.off_out);
-  l.dv = reinterpret_cast<float*>(ws + L.off_dz3);
+  l.dv = reinterpret_cast<float*>(ws + L.off_dzh);
   l.ld = kWideLd; l.returns = a.returns;
   l.image = reinterpret_cast<float*>(ws + L.off_image); l.pstride = (int)L.pstride; l.P = L.P;
   l.N = a.n; l.slab = L.slab; l.skip = a.skip;
@@ -798,8 +861,9 @@ int wide_critic_grad(const MlpArgs& a, float* d_grad_sums, void* d_workspace,
                                 d_grad_sums, a.O, 1, 0.f, (double)a.n, a.skip, st);
 }
 
-int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st) {
-  const WideLayout L(a.n, a.O, a.A, true);
+int wide_act(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st,
+             const Torso& t) {
+  const WideLayout L(a.n, a.O, a.A, true, t);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
                 "wide act: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
                 (long long)L.bytes);
@@ -935,12 +999,13 @@ __global__ __launch_bounds__(kWideThreads) void wide_sample_store_kernel(
 int wide_collect_words(int64_t W) { return (int)((W + kWideThreads - 1) / kWideThreads); }
 
 int64_t wide_collect_workspace_bytes(int64_t W, int O, int A) {
-  return WideLayout(W, O, A, true).bytes + round_up(W * O * 4, 256) + round_up(W * A * 4, 256);
+  return WideLayout(W, O, A, true, Torso::standard()).bytes + round_up(W * O * 4, 256) +
+         round_up(W * A * 4, 256);
 }
 
 int wide_collect_step(const WideCollect& c, void* d_workspace, int64_t workspace_bytes,
                       hipStream_t st) {
-  const WideLayout L(c.W, c.O, c.A, true);
+  const WideLayout L(c.W, c.O, c.A, true, Torso::standard());
   TONIC_REQUIRE(d_workspace && workspace_bytes >= wide_collect_workspace_bytes(c.W, c.O, c.A),
                 TONIC_ERR_WORKSPACE, "wide collect step: workspace too small");
   char* ws = static_cast<char*>(d_workspace);
@@ -958,8 +1023,9 @@ int wide_collect_step(const WideCollect& c, void* d_workspace, int64_t workspace
   return TONIC_OK;
 }
 
-int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st) {
-  const WideLayout L(a.n, a.O, 1, false);
+int wide_value(const MlpArgs& a, void* d_workspace, int64_t workspace_bytes, hipStream_t st,
+               const Torso& t) {
+  const WideLayout L(a.n, a.O, 1, false, t);
   TONIC_REQUIRE(d_workspace && workspace_bytes >= L.bytes, TONIC_ERR_WORKSPACE,
                 "wide value forward: workspace of %lld bytes, %lld needed",
                 (long long)workspace_bytes, (long long)L.bytes);

@@ -395,15 +395,27 @@ class A2C(Agent):
             stage_out.wait()
             return stage_out.host_view('actions').copy()
         p = _lib.ptr
-        need = self.lib.tonic_ppo_workspace_bytes(W, self.observation_size, A, 1)
+        torso = getattr(self.actor_updater, 'torso', None)
+        if torso is not None:
+            need = self.lib.tonic_ppo_torso_workspace_bytes(W, self.observation_size, A, 1, torso[0], torso[1])
+        else:
+            need = self.lib.tonic_ppo_workspace_bytes(W, self.observation_size, A, 1)
         if getattr(self, '_act_workspace', None) is None or self._act_workspace.numel() < need:
             self._act_workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.tonic_ppo_act_wide(
-            p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
-            p(stage_in.device_view('eps')), p(stage_out.device_view('actions')),
-            p(stage_out.device_view('log_probs')) if want_log_probs else None,
-            W, self.observation_size, A, p(self._act_workspace), self._act_workspace.numel(),
-            _lib.current_stream()), 'tonic_ppo_act_wide')
+        if torso is not None:
+            _lib.check(self.lib.tonic_ppo_act_torso(
+                *torso, p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
+                p(stage_in.device_view('eps')), p(stage_out.device_view('actions')),
+                p(stage_out.device_view('log_probs')) if want_log_probs else None,
+                W, self.observation_size, A, p(self._act_workspace), self._act_workspace.numel(),
+                _lib.current_stream()), 'tonic_ppo_act_torso')
+        else:
+            _lib.check(self.lib.tonic_ppo_act_wide(
+                p(self.model.flat_actor.flat), p(stage_in.device_view('observations')),
+                p(stage_in.device_view('eps')), p(stage_out.device_view('actions')),
+                p(stage_out.device_view('log_probs')) if want_log_probs else None,
+                W, self.observation_size, A, p(self._act_workspace), self._act_workspace.numel(),
+                _lib.current_stream()), 'tonic_ppo_act_wide')
         stage_out.download()
         stage_out.mark()
         stage_in.done = stage_out.done
@@ -444,9 +456,12 @@ class A2C(Agent):
         launches per step on the mapped block, csrc/mlpwide.hip wide_collect_step);
         TONIC_AMD_WIDE_STAGED=1 keeps the older path of staged copies and separate launches."""
         # (torsos outside the kernels' shapes act through stock torch operators, staged as well)
-        return getattr(self.actor_updater, 'stock', False) or (
-            (self.observation_size > 32 or self.action_size > 8)
-            and os.environ.get('TONIC_AMD_WIDE_STAGED', '0') == '1')
+        # (... and torsos on the layer-by-layer HIP path, tonic_ppo_act_torso, staged too: the collector's
+        #  per-step kernels hold the default torso)
+        return getattr(self.actor_updater, 'stock', False) or \
+            getattr(self.actor_updater, 'torso', None) is not None or (
+                (self.observation_size > 32 or self.action_size > 8)
+                and os.environ.get('TONIC_AMD_WIDE_STAGED', '0') == '1')
 
     def _step_staged(self, observations):
         observations = np.asarray(observations, np.float32)

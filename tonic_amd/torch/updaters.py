@@ -12,6 +12,8 @@ stream, with no host synchronisation:
 The PPO agent drives them through ``enqueue`` for all 80 iterations and reads the
 statistics back once; ``__call__`` (enqueue + read back) exists for drop-in compatibility.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -36,10 +38,30 @@ def adam_hyperparameters(factory, default_lr):
 
 
 def fused_ppo_torso(torso):
-    """The hand-written PPO kernels (csrc/mlp64x16.hip, mlpwide.hip) serve the reference's default
-    torso, MLP((64, 64), Tanh); every other ``MLP(sizes, activation)`` runs the same arithmetic as
-    stock PyTorch-ROCm operators on the HBM-resident data (see `_StockTorch`)."""
+    """The fused PPO kernels (csrc/mlp64x16.hip; layer by layer for wide observations / actions) serve the
+    reference's default torso, MLP((64, 64), Tanh)."""
     return tuple(torso.sizes) == (64, 64) and torso.activation is torch.nn.Tanh
+
+
+_TORSO_ACTIVATIONS = {torch.nn.Tanh: 1, torch.nn.ReLU: 2}
+
+
+def hip_ppo_torso(torso):
+    """(layers, sizes as a ctypes int32 array, activation code) when the layer-by-layer HIP path
+    (csrc/mlpwide.hip, the tonic_*_torso entries) serves this ``MLP(sizes, activation)``: 1 .. 4 hidden
+    layers of 4 .. 384 units (multiples of 4), Tanh or ReLU, no custom initialiser — None otherwise (and for
+    the default torso, which the fused kernels serve).  Every other torso runs the same arithmetic as stock
+    PyTorch-ROCm operators on the HBM-resident data (see `_StockTorch`)."""
+    import ctypes
+    sizes = tuple(int(v) for v in torso.sizes)
+    code = _TORSO_ACTIVATIONS.get(torso.activation)
+    if fused_ppo_torso(torso) or code is None or not 1 <= len(sizes) <= 4:
+        return None
+    if any(v < 4 or v > 384 or v % 4 for v in sizes):
+        return None
+    if os.environ.get('TONIC_AMD_TORSO_STOCK', '0') == '1':      # (developer switch: A/B against stock torch)
+        return None
+    return len(sizes), (ctypes.c_int32 * len(sizes))(*sizes), code
 
 
 class _StockTorch:
@@ -84,6 +106,7 @@ class _StockTorch:
 
 class _FlatUpdater(_StockTorch):
     stats_kind = 0
+    torso = None            # (layers, sizes, activation): the tonic_*_torso entries serve this network
 
     def _setup(self, flat, hyper):
         self.lib = _lib.load()
@@ -116,8 +139,13 @@ class _FlatUpdater(_StockTorch):
         shapes beyond them (O > 32, A > 8: csrc/mlpwide.hip) also the activations of the
         layer-by-layer passes."""
         actor = self.stats_kind == 1
-        need = self.lib.tonic_ppo_workspace_bytes(
-            n, self.observation_size, self.action_size if actor else 1, 1 if actor else 0)
+        if self.torso is not None:
+            need = self.lib.tonic_ppo_torso_workspace_bytes(
+                n, self.observation_size, self.action_size if actor else 1, 1 if actor else 0,
+                self.torso[0], self.torso[1])
+        else:
+            need = self.lib.tonic_ppo_workspace_bytes(
+                n, self.observation_size, self.action_size if actor else 1, 1 if actor else 0)
         if need < 0:
             raise NotImplementedError(
                 f'PPO networks with {self.observation_size} observations / '
@@ -225,7 +253,11 @@ class ClippedRatio(_FlatUpdater):
         self.observation_size = model.actor.torso.model[0].in_features
         self.action_size = model.actor.head.log_scale.shape[1]
         if not fused_ppo_torso(model.actor.torso):
-            self._stock_setup(self.optimizer, 3e-4)
+            self.torso = hip_ppo_torso(model.actor.torso)
+            if self.torso is None or self.lib.tonic_ppo_torso_param_count(
+                    self.observation_size, self.action_size, 1, self.torso[0], self.torso[1]) != self.count:
+                self.torso = None
+                self._stock_setup(self.optimizer, 3e-4)
 
     def _stock_grad(self, observations, actions, advantages, adv_stats, log_probs):
         """actors.py:70-112 up to the optimizer step (ClippedRatio; ratio_clip < 0: the plain
@@ -293,6 +325,13 @@ class ClippedRatio(_FlatUpdater):
         n = observations.shape[0]
         ws = self._workspace_for(n)
         p = _lib.ptr
+        if self.torso is not None:
+            _lib.check(self.lib.tonic_ppo_actor_grad_torso(
+                *self.torso, p(self.flat.flat), p(observations), p(actions), p(advantages), p(adv_stats),
+                p(log_probs), p(self.grad_sums), n, self.observation_size, self.action_size,
+                float(self.ratio_clip), float(self.entropy_coeff), self.stop_flag_ptr(),
+                p(ws), ws.numel(), _lib.current_stream()), 'tonic_ppo_actor_grad_torso')
+            return
         _lib.check(self.lib.tonic_ppo_actor_grad(
             p(self.flat.flat), p(observations), p(actions), p(advantages), p(adv_stats),
             p(log_probs), p(self.grad_sums), n, self.observation_size, self.action_size,
@@ -498,7 +537,11 @@ class VRegression(_FlatUpdater):
         self.observation_size = model.critic.torso.model[0].in_features
         self.normalizer = model.observation_normalizer
         if not fused_ppo_torso(model.critic.torso):
-            self._stock_setup(self.optimizer, 1e-3)
+            self.torso = hip_ppo_torso(model.critic.torso)
+            if self.torso is None or self.lib.tonic_ppo_torso_param_count(
+                    self.observation_size, 1, 0, self.torso[0], self.torso[1]) != self.count:
+                self.torso = None
+                self._stock_setup(self.optimizer, 1e-3)
         if self.normalizer is None:
             device = self.grad_sums.device
             self._unit_mean = torch.zeros(self.observation_size, device=device)
@@ -521,6 +564,12 @@ class VRegression(_FlatUpdater):
         mean, std = self.norm_tensors()
         p = _lib.ptr
         ws = self._workspace_for(observations.shape[0])
+        if self.torso is not None:
+            _lib.check(self.lib.tonic_value_forward_torso(
+                *self.torso, p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(out),
+                observations.shape[0], self.observation_size, p(ws), ws.numel(),
+                _lib.current_stream()), 'tonic_value_forward_torso')
+            return out
         _lib.check(self.lib.tonic_value_forward_wide(
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(out),
             observations.shape[0], self.observation_size, p(ws), ws.numel(),
@@ -541,6 +590,12 @@ class VRegression(_FlatUpdater):
         ws = self._workspace_for(n)
         mean, std = norm if norm is not None else self.norm_tensors()
         p = _lib.ptr
+        if self.torso is not None:
+            _lib.check(self.lib.tonic_value_regression_grad_torso(
+                *self.torso, p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations),
+                p(returns), p(self.grad_sums), n, self.observation_size, p(ws), ws.numel(),
+                _lib.current_stream()), 'tonic_value_regression_grad_torso')
+            return
         _lib.check(self.lib.tonic_value_regression_grad(
             p(self.flat.flat), p(mean), p(std), self.norm_clip(), p(observations), p(returns),
             p(self.grad_sums), n, self.observation_size, self.max_workgroups, p(ws), ws.numel(),
