@@ -51,7 +51,7 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -541,9 +541,16 @@ int tonic_adam_polyak_step(float* d_online, const float* d_grad_sums, float* d_e
  *   tonic_adam_step (zero gradient) and tonic_polyak_update.  The *_param_count queries return the
  *   padded block length; gradient / Adam-moment buffers use the same layout and length.
  * All scratch comes from ONE caller-provided workspace (tonic_offpolicy_workspace_bytes).
+ * Torsos other than the reference's (tonic/torch/models/utils.py:4-23 accepts any MLP(sizes, activation)): for
+ *   the SAC / TD3 / DDPG entries — tonic_policy_forward, tonic_twin_q_grad, tonic_actor_q_grad, the three size
+ *   queries below — `H` may be tonic_mlp_hidden(H1, H2, activation): two hidden layers of H1 and H2 units
+ *   (1 .. 1023: the (400, 300) class), activation 1 = torch.nn.ReLU, 2 = Tanh, 3 = ELU; W2 is then [H2, H1],
+ *   heads / w3 are H2 wide, same padding rules.  Such torsos run layer by layer (csrc/gemm16.hip) instead of in
+ *   the fused kernels; tonic_q_iteration and the D4PG / MPO entries take plain widths only.
  */
 int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);
 int32_t tonic_mlp_weight_stride(int32_t cols);
+int32_t tonic_mlp_hidden(int32_t H1, int32_t H2, int32_t activation);
 int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads);
 int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H);
 

@@ -192,18 +192,30 @@ def _agent_from_golden(g, kind):
     return agent
 
 
-# (the last two: torsos outside the hand-written kernels' shapes — unequal widths, ELU — which run
-#  as stock torch operators on the device, updaters._StockTorch)
+# (the last two: torsos outside the fused kernels' shape — unequal widths (100, 60), ELU (48, 40) — which run
+#  layer by layer on gemm16 launches: `H` = tonic_mlp_hidden(H1, H2, activation))
+GENERIC_TORSOS = ('sac_uneven_small', 'td3_elu_small')
 OFFPOLICY_CASES = [('sac_small', 'sac'), ('td3_small', 'td3'), ('ddpg_small', 'ddpg'),
                    ('d4pg_small', 'd4pg'), ('mpo_small', 'mpo'), ('sac_uneven_small', 'sac'),
                    ('td3_elu_small', 'td3')]
 
 
+@pytest.mark.parametrize('name,kind', [('sac_uneven_small', 'sac'), ('td3_elu_small', 'td3')])
+def test_offpolicy_generic_torsos_as_stock_torch_operators(lib, golden, name, kind, monkeypatch):
+    """What every torso outside the HIP paths runs on (three layers, other activations, ...): stock torch
+    operators on the device — forced here for the two generic goldens with TONIC_AMD_TORSO_STOCK=1."""
+    monkeypatch.setenv('TONIC_AMD_TORSO_STOCK', '1')
+    test_offpolicy_update_matches_reference(lib, golden, name, kind, stock=True)
+
+
 @pytest.mark.parametrize('name,kind', OFFPOLICY_CASES)
-def test_offpolicy_update_matches_reference(lib, golden, name, kind):
+def test_offpolicy_update_matches_reference(lib, golden, name, kind, stock=False):
     g = golden(name)
     import tonic_amd.torch as tt
     agent = _agent_from_golden(g, kind)
+    if name in GENERIC_TORSOS:
+        for updater in (agent.critic_updater, agent.actor_updater):
+            assert updater.stock == stock and (stock or updater.hidden >= 1024), (updater.stock, updater.hidden)
     state = agent.model.state_dict()
     for key in state:       # identical initialisation from the same seed (CPU init parity)
         np.testing.assert_array_equal(state[key].cpu().numpy(), g['init/' + key], err_msg=key)

@@ -97,6 +97,7 @@ SIGNATURES = {
                                                                       c_vp]),
     'tonic_offpolicy_workspace_bytes': (c_i64, [c_i32] * 4),
     'tonic_mlp_weight_stride': (c_i32, [c_i32]),
+    'tonic_mlp_hidden': (c_i32, [c_i32, c_i32, c_i32]),
     'tonic_mlp_actor_param_count': (c_i64, [c_i32] * 4),
     'tonic_q_critic_param_count': (c_i64, [c_i32] * 3),
     'tonic_buffer_store': (ctypes.c_int, [c_vp] * 14 + [c_i64, c_i64, c_i32, c_i32, c_f64, c_vp]),

@@ -26,19 +26,21 @@
 
 namespace tonic {
 
-enum GemmAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum GemmAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_ELU = 3 };
 
 struct GemmArgs {
   const float* A;
   const float* B;
   float* C;
   const float* bias;     // [N] added to every row (may be null)
-  const float* mask;     // [M, ldmask]: C *= (mask > 0)  (ReLU derivative; may be null)
+  const float* mask;     // [M, ldmask]: C *= act'(z) given mask = act(z), by mask_act (may be null):
+                         //   ACT_NONE / ACT_RELU: mask > 0;  ACT_TANH: 1 - mask^2;  ACT_ELU: mask > 0 ? 1 : mask + 1
   float* colsum;         // TN only: colsum[m] (+)= sum_k A[k][m]  (bias gradient; may be null)
   int M, N, K;
   int lda, ldb, ldc, ldmask;
   int64_t strideA, strideB, strideC, strideBias, strideMask, strideColsum;   // batch (blockIdx.z)
   int act;               // GemmAct applied after bias
+  int mask_act;          // the activation whose derivative the mask stands for (see mask)
   int accumulate;        // C += result instead of C = result
   float alpha;           // result scale (applied before bias)
 };

@@ -124,7 +124,13 @@ __device__ __forceinline__ void gemm16_tiles(const GemmArgs& g, int block_index,
       float v = (half == 0 ? acc0[r] : acc1[r]) * g.alpha + bn;
       if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (g.act == ACT_TANH) v = tanhf(v);
-      if (mask != nullptr && !(mask[(int64_t)m * g.ldmask + n] > 0.f)) v = 0.f;
+      else if (g.act == ACT_ELU) v = v > 0.f ? v : expm1f(v);       // torch.nn.ELU, alpha = 1
+      if (mask != nullptr) {
+        const float a = mask[(int64_t)m * g.ldmask + n];
+        if (g.mask_act == ACT_TANH) v = v * (1.f - a * a);
+        else if (g.mask_act == ACT_ELU) v = a > 0.f ? v : v * (a + 1.f);
+        else if (!(a > 0.f)) v = 0.f;
+      }
       float* dst = C + (int64_t)m * g.ldc + n;
       *dst = g.accumulate ? *dst + v : v;
     }

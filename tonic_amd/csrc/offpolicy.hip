@@ -21,19 +21,59 @@
 
 namespace tonic {
 
-struct ActorShape { int O, H, A, heads; };      // heads: 1 = deterministic (TD3), 2 = loc+scale (SAC)
-struct CriticShape { int O, A, H; };
+// Torso: MLP((H, H2), activation) of tonic/torch/models/utils.py:4-23.  The fused kernels (mlpfwd.hip) hold the
+// reference's shape — two ReLU layers of one width (H2 = 0 = "as H", act = ACT_RELU); every other two-layer torso
+// (unequal widths: the (400, 300) class; Tanh; ELU) runs layer by layer on gemm16 launches — `plain()` tells.
+struct ActorShape {                              // heads: 1 = deterministic (TD3), 2 = loc+scale (SAC)
+  int O, H, A, heads; int H2 = 0; int act = ACT_RELU;
+  __host__ __device__ int h2() const { return H2 > 0 ? H2 : H; }
+  __host__ __device__ int hp() const { return weight_ld(H > h2() ? H : h2()); }   // pitch of every hidden array
+  bool plain() const { return h2() == H && act == ACT_RELU; }
+};
+struct CriticShape {
+  int O, A, H; int H2 = 0; int act = ACT_RELU;
+  __host__ __device__ int h2() const { return H2 > 0 ? H2 : H; }
+  __host__ __device__ int hp() const { return weight_ld(H > h2() ? H : h2()); }
+  bool plain() const { return h2() == H && act == ACT_RELU; }
+};
+
+// The C ABI passes ONE int32 `H`: the width of a plain torso, or tonic_mlp_hidden(H1, H2, activation) =
+// H1 | H2 << 10 | activation << 20 (widths below 1024; activation: GemmAct).
+struct Hidden { int H1, H2, act; };
+inline Hidden unpack_hidden(int32_t code) {
+  Hidden h{code & 1023, (code >> 10) & 1023, (code >> 20) & 7};
+  if (code < 1024) h = Hidden{code, code, ACT_RELU};
+  if (h.H2 == 0) h.H2 = h.H1;
+  if (h.act == 0) h.act = ACT_RELU;
+  return h;
+}
+inline ActorShape actor_shape(int O, int32_t code, int A, int heads) {
+  const Hidden h = unpack_hidden(code);
+  return ActorShape{O, h.H1, A, heads, h.H2 == h.H1 ? 0 : h.H2, h.act};
+}
+inline CriticShape critic_shape(int O, int A, int32_t code) {
+  const Hidden h = unpack_hidden(code);
+  return CriticShape{O, A, h.H1, h.H2 == h.H1 ? 0 : h.H2, h.act};
+}
+inline int hidden_pitch(int32_t code) {
+  const Hidden h = unpack_hidden(code);
+  return weight_ld(h.H1 > h.H2 ? h.H1 : h.H2);
+}
+inline bool hidden_plain(int32_t code) {
+  const Hidden h = unpack_hidden(code);
+  return h.H1 == h.H2 && h.act == ACT_RELU;
+}
 
 // Floats of one network in the padded layout (mlpfwd.h: weight_ld / slot4):
-//   actor : W1 [H, O] b1 [H] W2 [H, H] b2 [H] then per head Wh [A, H] bh [A]
-//   critic: W1 [H, O + A] b1 [H] W2 [H, H] b2 [H] w3 [1, H] b3 [1]
+//   actor : W1 [H, O] b1 [H] W2 [H2, H] b2 [H2] then per head Wh [A, H2] bh [A]
+//   critic: W1 [H, O + A] b1 [H] W2 [H2, H] b2 [H2] w3 [1, H2] b3 [1]
 __host__ __device__ inline int64_t actor_count(ActorShape s) {
-  return (int64_t)s.H * weight_ld(s.O) + slot4(s.H) + (int64_t)s.H * weight_ld(s.H) + slot4(s.H) +
-         (int64_t)s.heads * ((int64_t)s.A * weight_ld(s.H) + slot4(s.A));
+  return (int64_t)s.H * weight_ld(s.O) + slot4(s.H) + (int64_t)s.h2() * weight_ld(s.H) + slot4(s.h2()) +
+         (int64_t)s.heads * ((int64_t)s.A * weight_ld(s.h2()) + slot4(s.A));
 }
 __host__ __device__ inline int64_t critic_count(CriticShape s) {
-  return (int64_t)s.H * weight_ld(s.O + s.A) + slot4(s.H) + (int64_t)s.H * weight_ld(s.H) +
-         slot4(s.H) + weight_ld(s.H) + slot4(1);
+  return (int64_t)s.H * weight_ld(s.O + s.A) + slot4(s.H) + (int64_t)s.h2() * weight_ld(s.H) +
+         slot4(s.h2()) + weight_ld(s.h2()) + slot4(1);
 }
 
 // ------------------------------------------------------------------ element-wise kernels
@@ -599,22 +639,23 @@ struct ActorBlock {
   ActorShape s;
   int ld1, ldH;
   int64_t head_stride;
-  ActorBlock(T* p, ActorShape sh) : s(sh), ld1(weight_ld(sh.O)), ldH(weight_ld(sh.H)) {
-    W1 = p; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.H * ldH;
-    Wh = b2 + slot4(s.H);
-    head_stride = (int64_t)s.A * ldH + slot4(s.A);
+  int ldO;                                       // row pitch of the heads (their inputs: the second layer)
+  ActorBlock(T* p, ActorShape sh) : s(sh), ld1(weight_ld(sh.O)), ldH(weight_ld(sh.H)), ldO(weight_ld(sh.h2())) {
+    W1 = p; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.h2() * ldH;
+    Wh = b2 + slot4(s.h2());
+    head_stride = (int64_t)s.A * ldO + slot4(s.A);
   }
   T* head_w(int h) const { return Wh + h * head_stride; }
-  T* head_b(int h) const { return head_w(h) + (int64_t)s.A * ldH; }
+  T* head_b(int h) const { return head_w(h) + (int64_t)s.A * ldO; }
 };
 using ActorParams = ActorBlock<const float>;
 
 struct CriticOffsets {
   int64_t W1, b1, W2, b2, w3, b3, count;
-  int ld1, ldH;
-  explicit CriticOffsets(CriticShape s) : ld1(weight_ld(s.O + s.A)), ldH(weight_ld(s.H)) {
-    W1 = 0; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.H * ldH;
-    w3 = b2 + slot4(s.H); b3 = w3 + ldH; count = b3 + slot4(1);
+  int ld1, ldH, ldO;                             // ldO: pitch of the value head's row (second layer wide)
+  explicit CriticOffsets(CriticShape s) : ld1(weight_ld(s.O + s.A)), ldH(weight_ld(s.H)), ldO(weight_ld(s.h2())) {
+    W1 = 0; b1 = W1 + (int64_t)s.H * ld1; W2 = b1 + slot4(s.H); b2 = W2 + (int64_t)s.h2() * ldH;
+    w3 = b2 + slot4(s.h2()); b3 = w3 + ldO; count = b3 + slot4(1);
   }
 };
 
@@ -656,8 +697,8 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
   ActorParams p(params, s);
   if (ldx <= 0) ldx = s.O;                      // dense observation rows unless told otherwise
   if (tail_done != nullptr) *tail_done = false;
-  const int HP = weight_ld(s.H);
-  if (mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
+  const int HP = s.hp(), H2 = s.h2();
+  if (s.plain() && mlp_forward_supported(s.H, s.A, s.heads)) {      // one launch for torso + heads
     MlpFwdArgs f{};
     f.X = obs; f.ldx = ldx; f.K1 = s.O;
     f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2; f.ldw1 = p.ld1; f.ldw2 = p.ldH;
@@ -680,16 +721,16 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     return launch_mlp_forward(f, 1, st);
   }
   GemmArgs g = gemm(obs, ldx, p.W1, p.ld1, h1, HP, B, s.H, s.O);
-  g.bias = p.b1; g.act = ACT_RELU;
+  g.bias = p.b1; g.act = s.act;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h1, HP, p.W2, p.ldH, h2, HP, B, s.H, s.H);
-  g.bias = p.b2; g.act = ACT_RELU;
+  g = gemm(h1, HP, p.W2, p.ldH, h2, HP, B, H2, s.H);
+  g.bias = p.b2; g.act = s.act;
   TRY(launch_gemm('c', 'c', g, 1, st));
-  g = gemm(h2, HP, p.head_w(0), p.ldH, head0, ldh, B, s.A, s.H);
+  g = gemm(h2, HP, p.head_w(0), p.ldO, head0, ldh, B, s.A, H2);
   g.bias = p.head_b(0); g.act = tanh_head ? ACT_TANH : ACT_NONE;
   TRY(launch_gemm('c', 'c', g, 1, st));
   if (s.heads == 2) {
-    g = gemm(h2, HP, p.head_w(1), p.ldH, head1, ldh, B, s.A, s.H);
+    g = gemm(h2, HP, p.head_w(1), p.ldO, head1, ldh, B, s.A, H2);
     g.bias = p.head_b(1);
     TRY(launch_gemm('c', 'c', g, 1, st));
   }
@@ -730,9 +771,9 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
                     const float* params2 = nullptr, const float* X2 = nullptr) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
-  const int HP = weight_ld(s.H);
+  const int HP = s.hp(), H2 = s.h2();
   const int64_t hs = (int64_t)Bp * HP;
-  if (mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
+  if (s.plain() && mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
     int launch_nets = 0;
     const MlpFwdArgs f = critics_forward_args(params, s, nets, X, ldx, B, Bp, h1, h2, q, params2,
                                               X2, &launch_nets);
@@ -744,14 +785,14 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
                            q + (int64_t)nets * Bp, st);
   }
   GemmArgs g = gemm(X, ldx, params + o.W1, o.ld1, h1, HP, B, s.H, in);
-  g.bias = params + o.b1; g.act = ACT_RELU;
+  g.bias = params + o.b1; g.act = s.act;
   g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h1, HP, params + o.W2, o.ldH, h2, HP, B, s.H, s.H);
-  g.bias = params + o.b2; g.act = ACT_RELU;
+  g = gemm(h1, HP, params + o.W2, o.ldH, h2, HP, B, H2, s.H);
+  g.bias = params + o.b2; g.act = s.act;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = hs;
   TRY(launch_gemm('c', 'c', g, nets, st));
-  g = gemm(h2, HP, params + o.w3, o.ldH, q, 1, B, 1, s.H);
+  g = gemm(h2, HP, params + o.w3, o.ldO, q, 1, B, 1, H2);
   g.bias = params + o.b3;
   g.strideA = hs; g.strideB = o.count; g.strideBias = o.count; g.strideC = Bp;
   TRY(launch_gemm('c', 'c', g, nets, st));
@@ -802,13 +843,13 @@ int critics_weight_gradients(CriticShape s, int nets, const float* X, int ldx, i
                              const float* dh1, float* grads, hipStream_t st, const AdamFold* fold) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
-  const int HP = weight_ld(s.H);
+  const int HP = s.hp(), H2 = s.h2();
   const int64_t hs = (int64_t)Bp * HP;
   GemmArgs w[3];
-  w[0] = gemm(dq, 1, h2, HP, grads + o.w3, o.ldH, 1, s.H, B);
+  w[0] = gemm(dq, 1, h2, HP, grads + o.w3, o.ldO, 1, H2, B);
   w[0].colsum = grads + o.b3; w[0].strideColsum = o.count;
   w[0].strideA = Bp; w[0].strideB = hs; w[0].strideC = o.count;
-  w[1] = gemm(dh2, HP, h1, HP, grads + o.W2, o.ldH, s.H, s.H, B);
+  w[1] = gemm(dh2, HP, h1, HP, grads + o.W2, o.ldH, H2, s.H, B);
   w[1].colsum = grads + o.b2; w[1].strideColsum = o.count;
   w[1].strideA = hs; w[1].strideB = hs; w[1].strideC = o.count;
   w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
@@ -822,7 +863,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
                      float* dh1, float* grads, float* dxa, hipStream_t st,
                      const StepLoss* loss = nullptr, const AdamFold* fold = nullptr) {
   const CriticOffsets o(s);
-  const bool one_launch = mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0);
+  const bool one_launch = s.plain() && mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0);
   if (loss && !one_launch) {
     if (loss->kind == LOSS_TD) {
       hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, st, loss->rewards,
@@ -833,7 +874,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
                          loss->alpha, nets == 2 ? 1 : 0, dq, loss->stats, B, Bp);
     }
   }
-  const int HP = weight_ld(s.H);
+  const int HP = s.hp(), H2 = s.h2();
   const int64_t hs = (int64_t)Bp * HP;
   const int ldxa = pad16(s.A);
   GemmArgs g;
@@ -843,13 +884,13 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
-    g = gemm(dq, 1, params + o.w3, o.ldH, dh2, HP, B, s.H, 1);
-    g.mask = h2; g.ldmask = HP;
+    g = gemm(dq, 1, params + o.w3, o.ldO, dh2, HP, B, H2, 1);
+    g.mask = h2; g.ldmask = HP; g.mask_act = s.act;
     g.strideA = Bp; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
-    // dz1 = (dz2 W2) * relu'(h1)
-    g = gemm(dh2, HP, params + o.W2, o.ldH, dh1, HP, B, s.H, s.H);
-    g.mask = h1; g.ldmask = HP;
+    // dz1 = (dz2 W2) * act'(h1)
+    g = gemm(dh2, HP, params + o.W2, o.ldH, dh1, HP, B, s.H, H2);
+    g.mask = h1; g.ldmask = HP; g.mask_act = s.act;
     g.strideA = hs; g.strideB = o.count; g.strideC = hs; g.strideMask = hs;
     TRY(launch_gemm('c', 's', g, nets, st));
     if (dxa) {     // dxa = dz1 W1[:, O : O + A]
@@ -874,7 +915,7 @@ struct Workspace {
 };
 
 int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
-  const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
+  const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = hidden_pitch(H);
   // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
   return 2 * Bp * HP + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * HP + 2 * Bp) +
          Bp * ldx + 2 * Bp * ldh + 2 * Bp * HP + 2 * Bp * ldh + 64 * 16 +
@@ -893,10 +934,18 @@ extern "C" int64_t tonic_offpolicy_workspace_bytes(int32_t B, int32_t O, int32_t
 extern "C" int32_t tonic_mlp_weight_stride(int32_t cols) { return weight_ld(cols); }
 
 extern "C" int64_t tonic_mlp_actor_param_count(int32_t O, int32_t H, int32_t A, int32_t heads) {
-  return actor_count(ActorShape{O, H, A, heads});
+  return actor_count(actor_shape(O, H, A, heads));
 }
 extern "C" int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H) {
-  return critic_count(CriticShape{O, A, H});
+  return critic_count(critic_shape(O, A, H));
+}
+
+// The `H` argument of the off-policy entries for a torso other than two ReLU layers of one width:
+// MLP((H1, H2), activation) with activation 1 = ReLU, 2 = Tanh, 3 = ELU (GemmAct).  -1: not representable.
+extern "C" int32_t tonic_mlp_hidden(int32_t H1, int32_t H2, int32_t activation) {
+  if (H1 < 1 || H1 > 1023 || H2 < 1 || H2 > 1023 || activation < ACT_RELU || activation > ACT_ELU) return -1;
+  if (H1 == H2 && activation == ACT_RELU) return H1;
+  return H1 | (H2 << 10) | (activation << 20);
 }
 
 // Policy forward for acting / evaluation.  kind: 0 = deterministic tanh head (TD3,
@@ -911,11 +960,11 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_policy_forward: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldh = pad16(A), HP = weight_ld(H);
+  const int Bp = pad16(B), ldh = pad16(A), HP = hidden_pitch(H);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
   float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
   float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
-  const ActorShape s{O, H, A, kind == 0 ? 1 : 2};
+  const ActorShape s = actor_shape(O, H, A, kind == 0 ? 1 : 2);
   const int threads = 256;
   if (kind == 2) {       // Gaussian head with a tanh loc (MPO, mpo.py:77-85): a = loc + sigma * eps
     TRY(actor_forward(d_actor_params, s, d_observations, B, h1, h2, head0, head1, ldh, true, st));
@@ -966,8 +1015,8 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_twin_q_grad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = weight_ld(H);
-  const CriticShape cs{O, A, H};
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = hidden_pitch(H);
+  const CriticShape cs = critic_shape(O, A, H);
   const int64_t Pc = critic_count(cs);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
   float* a_h1 = ws.take((int64_t)Bp * HP); float* a_h2 = ws.take((int64_t)Bp * HP);
@@ -986,7 +1035,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   float* dh2 = ws.take(2 * hs); float* dh1 = ws.take(2 * hs);
 
   // ---- targets (no grad)
-  const ActorShape as{O, H, A, kind == 1 ? 2 : 1};
+  const ActorShape as = actor_shape(O, H, A, kind == 1 ? 2 : 1);
   // the policy's tail also encodes both critic inputs: (s', a') from its own actions -> X, the
   // stored (s, a) -> X2
   PolicyTail tail{};
@@ -1040,7 +1089,7 @@ MlpBwdArgs actor_chain_args(const float* params, ActorShape as, int B, const flo
                             const float* a_h2, const float* dloc, const float* dspre, int ldh,
                             float* da_h2, float* da_h1, float* dxa, int xa_first, int xa_count,
                             const MlpBwdArgs* head_fold) {
-  const int H = as.H, A = as.A, HP = weight_ld(H);
+  const int H = as.H, A = as.A, HP = as.hp();
   ActorParams p(params, as);
   MlpBwdArgs b{};
   b.heads = as.heads; b.NH = A; b.ldh = ldh;
@@ -1065,16 +1114,16 @@ int actor_weight_gradients(ActorShape as, const float* X, int ldx, int B, const 
                            const float* a_h2, const float* dloc, const float* dspre, int ldh,
                            const float* da_h2, const float* da_h1, float* grads, hipStream_t st,
                            const AdamFold* fold) {
-  const int H = as.H, A = as.A, HP = weight_ld(H);
+  const int H = as.H, A = as.A, HP = as.hp(), H2 = as.h2();
   const ActorBlock<float> gp(grads, as);               // the gradient sums share the layout
   GemmArgs w[4];
   int count = 0;
   for (int h = 0; h < as.heads; ++h) {
     const float* dhead = h == 0 ? dloc : dspre;
-    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldH, A, H, B);
+    w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldO, A, H2, B);
     w[count++].colsum = gp.head_b(h);
   }
-  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H, H, B);
+  w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H2, H, B);
   w[count++].colsum = gp.b2;
   w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
   w[count++].colsum = gp.b1;
@@ -1086,23 +1135,23 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
                           const float* dspre, int ldh, float* da_h2, float* da_h1, float* grads,
                           float* dxa, int xa_first, int xa_count, hipStream_t st,
                           const MlpBwdArgs* head_fold = nullptr, const AdamFold* fold = nullptr) {
-  const int H = as.H, A = as.A, HP = weight_ld(H);
+  const int H = as.H, A = as.A, HP = as.hp(), H2 = as.h2();
   ActorParams p(params, as);
   GemmArgs g;
-  // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * relu'(h2) ; dz1
-  if (mlp_backward_supported(H, A, as.heads, xa_count)) {
+  // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * act'(h2) ; dz1
+  if (as.plain() && mlp_backward_supported(H, A, as.heads, xa_count)) {
     const MlpBwdArgs b = actor_chain_args(params, as, B, a_h1, a_h2, dloc, dspre, ldh, da_h2, da_h1,
                                           dxa, xa_first, xa_count, head_fold);
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
       const float* dhead = h == 0 ? dloc : dspre;
-      g = gemm(dhead, ldh, p.head_w(h), p.ldH, da_h2, HP, B, H, A);
-      g.mask = a_h2; g.ldmask = HP; g.accumulate = h > 0;
+      g = gemm(dhead, ldh, p.head_w(h), p.ldO, da_h2, HP, B, H2, A);
+      g.mask = a_h2; g.ldmask = HP; g.accumulate = h > 0; g.mask_act = as.act;
       TRY(launch_gemm('c', 's', g, 1, st));
     }
-    g = gemm(da_h2, HP, p.W2, p.ldH, da_h1, HP, B, H, H);
-    g.mask = a_h1; g.ldmask = HP;
+    g = gemm(da_h2, HP, p.W2, p.ldH, da_h1, HP, B, H, H2);
+    g.mask = a_h1; g.ldmask = HP; g.mask_act = as.act;
     TRY(launch_gemm('c', 's', g, 1, st));
     if (dxa) {
       g = gemm(da_h1, HP, p.W1 + xa_first, p.ld1, dxa, pad16(xa_count), B, xa_count, H);
@@ -1163,7 +1212,7 @@ extern "C" int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32
 }
 
 extern "C" int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads) {
-  return mlp_forward_supported(H, A, heads) && mlp_policy_tail_supported(H, A) &&
+  return hidden_plain(H) && mlp_forward_supported(H, A, heads) && mlp_policy_tail_supported(H, A) &&
          mlp_forward_supported(H, 1, 1) && mlp_backward_supported(H, 1, 0, A) &&
          mlp_backward_supported(H, A, heads, 0) && O > 0 ? 1 : 0;
 }
@@ -1661,10 +1710,10 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes(B, O, A, H),
                 TONIC_ERR_WORKSPACE, "tonic_actor_q_grad: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = weight_ld(H);
+  const int Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), threads = 256, HP = hidden_pitch(H);
   const int nets = kind == 0 ? 1 : 2;
-  const CriticShape cs{O, A, H};
-  const ActorShape as{O, H, A, kind == 0 ? 1 : 2};
+  const CriticShape cs = critic_shape(O, A, H);
+  const ActorShape as = actor_shape(O, H, A, kind == 0 ? 1 : 2);
   const int64_t Pa = actor_count(as);
   Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
   float* a_h1 = ws.take((int64_t)Bp * HP); float* a_h2 = ws.take((int64_t)Bp * HP);

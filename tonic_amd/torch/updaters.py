@@ -626,12 +626,27 @@ class VRegression(_FlatUpdater):
 
 # ----------------------------------------------------------------- off-policy (SAC / TD3)
 
-def _torso_width(torso):
-    sizes = tuple(torso.sizes)
-    if len(sizes) != 2 or sizes[0] != sizes[1] or torso.activation is not torch.nn.ReLU:
-        raise NotImplementedError('the fused off-policy kernels need a two-layer ReLU torso of '
-                                  f'equal widths, got {sizes} / {torso.activation}')
-    return sizes[0]
+_Q_ACTIVATIONS = {torch.nn.ReLU: 1, torch.nn.Tanh: 2, torch.nn.ELU: 3}       # GemmAct of csrc/gemm16.h
+
+
+def _torso_width(torso, generic=False):
+    """The `H` argument of the off-policy entries: the width of the reference's torso — two ReLU layers of one
+    width, which the fused kernels hold (csrc/mlpfwd.hip) — or, `generic`, tonic_mlp_hidden(H1, H2, activation)
+    for any other two-layer torso with ReLU / Tanh / ELU (unequal widths: the (400, 300) class), which the SAC /
+    TD3 / DDPG entries run layer by layer on gemm16 launches.  Anything else raises (callers with a stock-torch
+    form catch it)."""
+    sizes = tuple(int(v) for v in torso.sizes)
+    plain = len(sizes) == 2 and sizes[0] == sizes[1] and torso.activation is torch.nn.ReLU
+    if plain:
+        return sizes[0]
+    code = _Q_ACTIVATIONS.get(torso.activation)
+    if (generic and len(sizes) == 2 and code is not None
+            and os.environ.get('TONIC_AMD_TORSO_STOCK', '0') != '1'):
+        packed = _lib.load().tonic_mlp_hidden(sizes[0], sizes[1], code)
+        if packed > 0:
+            return packed
+    raise NotImplementedError('the off-policy kernels serve two-layer torsos (ReLU / Tanh / ELU for SAC, TD3 '
+                              f'and DDPG; equal-width ReLU for D4PG and MPO), got {sizes} / {torso.activation}')
 
 
 class _QUpdater(_FlatUpdater):
@@ -646,9 +661,9 @@ class _QUpdater(_FlatUpdater):
         self.observation_size = model.actor.torso.model[0].in_features
         critic = model.critic_1 if hasattr(model, 'critic_1') else model.critic
         try:
-            self.hidden = _torso_width(model.actor.torso)
-            if _torso_width(critic.torso) != self.hidden:
-                raise NotImplementedError('actor and critic torsos must have the same width')
+            self.hidden = _torso_width(model.actor.torso, self.stock_capable)
+            if _torso_width(critic.torso, self.stock_capable) != self.hidden:
+                raise NotImplementedError('actor and critic torsos must have the same shape')
         except NotImplementedError:
             if not self.stock_capable:
                 raise
