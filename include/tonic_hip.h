@@ -51,7 +51,7 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -724,8 +724,10 @@ int tonic_distributional_actor_grad(const float* d_actor_params, const float* d_
  *   up to the optimizer steps, per-dimension KL constraints: E-step weights softmax_s(Q / temperature)
  *   (+ the action-bound penalty weights), decomposed fixed-std / fixed-mean policy losses, the
  *   alpha-weighted KL terms and the dual losses.  d_duals [2 A + 2] = {log_temperature,
- *   log_alpha_mean[A], log_alpha_std[A], log_penalty_temperature} (already floored at min_log_dual by
- *   the caller).  Outputs: d_grad_sums = gradient SUMS of the actor + {B * (policy + KL losses), 0, 0,
+ *   log_alpha_mean[A], log_alpha_std[A], log_penalty_temperature}: floored IN PLACE at min_log_dual by
+ *   this call, as the reference clamps them at the head of its own (actors.py:347-356) — every read goes
+ *   through the floor, the last kernel ahead of the duals' optimizer step writes the floored values back
+ *   (the penalty temperature only with action_penalization).  Outputs: d_grad_sums = gradient SUMS of the actor + {B * (policy + KL losses), 0, 0,
  *   0, 0, B, 0, 0}; d_dual_grads [2 A + 2 + 8] = d loss / d log-duals + {0, 0, 0, 0, 0, 1, 0, 0};
  *   d_stats [9 + 2 A] = {policy_mean_loss, policy_std_loss, kl_mean_loss, kl_std_loss, alpha_mean_loss,
  *   alpha_std_loss, temperature_loss, temperature, alpha_mean[A], alpha_std[A], penalty_temperature}. */
@@ -739,7 +741,7 @@ int tonic_expected_sarsa_grad(const float* d_target_actor, const float* d_target
                               int32_t B, int32_t O, int32_t H, int32_t A, int32_t S,
                               void* d_workspace, int64_t workspace_bytes, void* stream);
 int tonic_mpo_actor_grad(const float* d_actor_params, const float* d_target_actor,
-                         const float* d_target_critic, const float* d_duals,
+                         const float* d_target_critic, float* d_duals, double min_log_dual,
                          const float* d_norm_mean, const float* d_norm_std, double norm_clip,
                          const float* d_observations, const float* d_eps, float* d_grad_sums,
                          float* d_dual_grads, float* d_stats, int32_t B, int32_t O, int32_t H,
@@ -756,13 +758,14 @@ int tonic_mpo_actor_grad(const float* d_actor_params, const float* d_target_acto
  *   (d_actor_stats = d_grad_sums + actor parameter count: {B * losses, 0, 0, 0, 0, B, 0, 0} with this
  *   rank's B, possibly 0) from the all-reduced sums and the global batch size. */
 int tonic_mpo_actor_grad_shard(const float* d_actor_params, const float* d_target_actor,
-                               const float* d_target_critic, const float* d_duals,
+                               const float* d_target_critic, float* d_duals, double min_log_dual,
                                const float* d_norm_mean, const float* d_norm_std, double norm_clip,
                                const float* d_observations, const float* d_eps, float* d_grad_sums,
                                double* d_column_sums, int32_t B, int32_t O, int32_t H, int32_t A,
                                int32_t S, int32_t action_penalization, void* d_workspace,
                                int64_t workspace_bytes, void* stream);
-int tonic_mpo_dual_step(const double* d_column_sums, const float* d_duals, float* d_dual_grads,
+int tonic_mpo_dual_step(const double* d_column_sums, float* d_duals, double min_log_dual,
+                        float* d_dual_grads,
                         float* d_stats, float* d_actor_stats, int32_t B, int32_t B_global,
                         int32_t A, int32_t S, double epsilon, double epsilon_penalty,
                         double epsilon_mean, double epsilon_std, int32_t action_penalization,

@@ -117,11 +117,12 @@ SIGNATURES = {
     'tonic_mpo_workspace_bytes': (c_i64, [c_i32] * 5),
     'tonic_expected_sarsa_grad': (ctypes.c_int, [c_vp] * 5 + [c_f64] + [c_vp] * 7 + [c_i32] * 5 +
                                   [c_vp, c_i64, c_vp]),
-    'tonic_mpo_actor_grad': (ctypes.c_int, [c_vp] * 6 + [c_f64] + [c_vp] * 5 + [c_i32] * 5 +
-                             [c_f64] * 4 + [c_i32] + [c_vp, c_i64, c_vp]),
-    'tonic_mpo_actor_grad_shard': (ctypes.c_int, [c_vp] * 6 + [c_f64] + [c_vp] * 4 + [c_i32] * 6 +
-                                   [c_vp, c_i64, c_vp]),
-    'tonic_mpo_dual_step': (ctypes.c_int, [c_vp] * 5 + [c_i32] * 4 + [c_f64] * 4 + [c_i32, c_vp]),
+    'tonic_mpo_actor_grad': (ctypes.c_int, [c_vp] * 4 + [c_f64] + [c_vp] * 2 + [c_f64] + [c_vp] * 5 +
+                             [c_i32] * 5 + [c_f64] * 4 + [c_i32] + [c_vp, c_i64, c_vp]),
+    'tonic_mpo_actor_grad_shard': (ctypes.c_int, [c_vp] * 4 + [c_f64] + [c_vp] * 2 + [c_f64] + [c_vp] * 4 +
+                                   [c_i32] * 6 + [c_vp, c_i64, c_vp]),
+    'tonic_mpo_dual_step': (ctypes.c_int, [c_vp] * 2 + [c_f64] + [c_vp] * 3 + [c_i32] * 4 + [c_f64] * 4 +
+                            [c_i32, c_vp]),
     'tonic_collector_block_bytes': (c_i64, [c_i64, c_i32, c_i32]),
     'tonic_collector_block_init': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32]),
     'tonic_collector_block_offset': (c_i64, [c_vp, c_i32]),

@@ -331,12 +331,15 @@ __device__ __forceinline__ float dual_value(float log_dual) { return softplus_f(
 // LSE, sum_s w q / T, LSE_penalty, sum_s w_p cost / T_p}; klm / kls [m][a] = the per-dimension KLs.
 __global__ __launch_bounds__(256) void mpo_state_kernel(
     const float* q, const float* act, const float* loc_t, const float* spre_t, const float* loc,
-    const float* spre, int ldh, const float* duals, int penalize, float* dloc, float* dspre,
+    const float* spre, int ldh, const float* duals, float floor, int penalize, float* dloc, float* dspre,
     float* part, float* klm, float* kls, int B, int A, int S) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (m >= B) return;
-  const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
+  // (every log-dual is read through the floor the reference clamps it to, in place, at the head of its call —
+  //  actors.py:347-356; mpo_dual_kernel, the last reader ahead of the duals' optimizer step, writes the
+  //  clamped values back)
+  const float T = dual_value(fmaxf(duals[0], floor)), Tp = dual_value(fmaxf(duals[2 * A + 1], floor));
   // weights_and_temperature_loss (actors.py:325-338): softmax over the samples of q / T
   const bool sample = lane < S;
   const float tempered = sample ? q[(int64_t)lane * B + m] / T : -INFINITY;
@@ -389,7 +392,8 @@ __global__ __launch_bounds__(256) void mpo_state_kernel(
     const float ratio = st / sg;
     klm[(int64_t)m * A + a] = 0.5f * ((lt - lo) / st) * ((lt - lo) / st);
     kls[(int64_t)m * A + a] = 0.5f * (ratio * ratio - 1.f - logf(ratio * ratio));
-    const float alpha_mean = dual_value(duals[1 + a]), alpha_std = dual_value(duals[1 + A + a]);
+    const float alpha_mean = dual_value(fmaxf(duals[1 + a], floor)),
+                alpha_std = dual_value(fmaxf(duals[1 + A + a], floor));
     g_loc += alpha_mean * (lo - lt) / (st * st);
     g_sigma += alpha_std * (1.f / sg - st * st / (sg * sg * sg));
     const float raw = softplus_f(pre);
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void mpo_state_kernel(
 // out_sums != null: only the local column sums [6 + 2 A] (float64) are written; in_sums != null: the
 // columns are taken from there (the all-reduced sums) instead of the per-state arrays.
 __global__ void mpo_dual_kernel(const float* part, const float* klm, const float* kls,
-                                const float* duals, int penalize, float epsilon,
+                                float* duals, float floor, int penalize, float epsilon,
                                 float epsilon_penalty, float epsilon_mean, float epsilon_std,
                                 float* dual_grads, float* stats, float* actor_stats, int B, int A,
                                 int S, const double* in_sums, double* out_sums, int B_norm) {
@@ -440,19 +444,22 @@ __global__ void mpo_dual_kernel(const float* part, const float* klm, const float
   if (out_sums != nullptr) return;                    // (uniform)
   __syncthreads();
   if (tid >= 64) return;                              // wave 0: lane = action dimension
-  const float T = dual_value(duals[0]), Tp = dual_value(duals[2 * A + 1]);
+  const float log_T = fmaxf(duals[0], floor), log_Tp = fmaxf(duals[2 * A + 1], floor);
+  const float T = dual_value(log_T), Tp = dual_value(log_Tp);
   const float log_S = logf((float)S);
   auto sigmoid = [](float x) { return 1.f / (1.f + expf(-x)); };
   float kl_mean_loss = 0.f, kl_std_loss = 0.f, alpha_mean_loss = 0.f, alpha_std_loss = 0.f;
   if (tid < A) {
     const int a = tid;
-    const float am = dual_value(duals[1 + a]), as = dual_value(duals[1 + A + a]);
+    const float log_am = fmaxf(duals[1 + a], floor), log_as = fmaxf(duals[1 + A + a], floor);
+    const float am = dual_value(log_am), as = dual_value(log_as);
     const float km = (float)col[6 + a], ks = (float)col[6 + A + a];
     kl_mean_loss = am * km; kl_std_loss = as * ks;                        // actors.py:319-323
     alpha_mean_loss = am * (epsilon_mean - km);
     alpha_std_loss = as * (epsilon_std - ks);
-    dual_grads[1 + a] = (epsilon_mean - km) * sigmoid(duals[1 + a]);
-    dual_grads[1 + A + a] = (epsilon_std - ks) * sigmoid(duals[1 + A + a]);
+    dual_grads[1 + a] = (epsilon_mean - km) * sigmoid(log_am);
+    dual_grads[1 + A + a] = (epsilon_std - ks) * sigmoid(log_as);
+    duals[1 + a] = log_am; duals[1 + A + a] = log_as;      // the reference's in-place clamp (actors.py:347-356)
     stats[8 + a] = am; stats[8 + A + a] = as;
   }
   kl_mean_loss = wave_sum(kl_mean_loss); kl_std_loss = wave_sum(kl_std_loss);
@@ -460,12 +467,14 @@ __global__ void mpo_dual_kernel(const float* part, const float* klm, const float
   if (tid != 0) return;
   // temperature * (epsilon + mean(logsumexp) - log S): d / dT = epsilon + mean(LSE) - log S - mean(sum_s w q / T)
   float temperature_loss = T * (epsilon + (float)col[2] - log_S);
-  dual_grads[0] = (epsilon + (float)col[2] - log_S - (float)col[3]) * sigmoid(duals[0]);
+  dual_grads[0] = (epsilon + (float)col[2] - log_S - (float)col[3]) * sigmoid(log_T);
+  duals[0] = log_T;
+  if (penalize) duals[2 * A + 1] = log_Tp;
   dual_grads[2 * A + 1] = 0.f;
   if (penalize) {
     temperature_loss += Tp * (epsilon_penalty + (float)col[4] - log_S);
     dual_grads[2 * A + 1] =
-        (epsilon_penalty + (float)col[4] - log_S - (float)col[5]) * sigmoid(duals[2 * A + 1]);
+        (epsilon_penalty + (float)col[4] - log_S - (float)col[5]) * sigmoid(log_Tp);
   }
   for (int i = 0; i < 8; ++i) dual_grads[2 * A + 2 + i] = i == 5 ? 1.f : 0.f;
   stats[0] = -(float)col[0]; stats[1] = -(float)col[1]; stats[2] = kl_mean_loss; stats[3] = kl_std_loss;
@@ -1617,7 +1626,7 @@ extern "C" int tonic_expected_sarsa_grad(
 namespace {
 int mpo_actor_grad(
     const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
-    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    float* d_duals, double min_log_dual, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
     const float* d_observations, const float* d_eps, float* d_grad_sums, float* d_dual_grads,
     float* d_stats, int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, double epsilon,
     double epsilon_penalty, double epsilon_mean, double epsilon_std, int32_t action_penalization,
@@ -1638,10 +1647,10 @@ int mpo_actor_grad(
   TRY(actor_forward(d_actor_params, as, d_observations, B, w.o_h1, w.o_h2, w.loc, w.spre, ldh, true,
                     st));
   hipLaunchKernelGGL(mpo_state_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.tq,
-                     w.act, w.loc_t, w.spre_t, w.loc, w.spre, ldh, d_duals, action_penalization,
-                     w.dloc, w.dspre, w.part, w.klm, w.kls, B, A, S);
+                     w.act, w.loc_t, w.spre_t, w.loc, w.spre, ldh, d_duals, (float)min_log_dual,
+                     action_penalization, w.dloc, w.dspre, w.part, w.klm, w.kls, B, A, S);
   hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(1024), 0, st, w.part, w.klm, w.kls, d_duals,
-                     action_penalization, (float)epsilon, (float)epsilon_penalty,
+                     (float)min_log_dual, action_penalization, (float)epsilon, (float)epsilon_penalty,
                      (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats,
                      d_grad_sums + actor_count(as), B, A, S, (const double*)nullptr, d_column_sums,
                      B);
@@ -1654,12 +1663,12 @@ int mpo_actor_grad(
 
 extern "C" int tonic_mpo_actor_grad(
     const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
-    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    float* d_duals, double min_log_dual, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
     const float* d_observations, const float* d_eps, float* d_grad_sums, float* d_dual_grads,
     float* d_stats, int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, double epsilon,
     double epsilon_penalty, double epsilon_mean, double epsilon_std, int32_t action_penalization,
     void* d_workspace, int64_t workspace_bytes, void* stream) {
-  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, d_norm_mean,
+  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, min_log_dual, d_norm_mean,
                         d_norm_std, norm_clip, d_observations, d_eps, d_grad_sums, d_dual_grads,
                         d_stats, B, O, H, A, S, epsilon, epsilon_penalty, epsilon_mean, epsilon_std,
                         action_penalization, d_workspace, workspace_bytes, stream, nullptr);
@@ -1667,19 +1676,19 @@ extern "C" int tonic_mpo_actor_grad(
 
 extern "C" int tonic_mpo_actor_grad_shard(
     const float* d_actor_params, const float* d_target_actor, const float* d_target_critic,
-    const float* d_duals, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
+    float* d_duals, double min_log_dual, const float* d_norm_mean, const float* d_norm_std, double norm_clip,
     const float* d_observations, const float* d_eps, float* d_grad_sums, double* d_column_sums,
     int32_t B, int32_t O, int32_t H, int32_t A, int32_t S, int32_t action_penalization,
     void* d_workspace, int64_t workspace_bytes, void* stream) {
   TONIC_REQUIRE(d_column_sums != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_mpo_actor_grad_shard: null column sums");
-  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, d_norm_mean,
+  return mpo_actor_grad(d_actor_params, d_target_actor, d_target_critic, d_duals, min_log_dual, d_norm_mean,
                         d_norm_std, norm_clip, d_observations, d_eps, d_grad_sums, nullptr, nullptr,
                         B, O, H, A, S, 0.0, 0.0, 0.0, 0.0, action_penalization, d_workspace,
                         workspace_bytes, stream, d_column_sums);
 }
 
-extern "C" int tonic_mpo_dual_step(const double* d_column_sums, const float* d_duals,
+extern "C" int tonic_mpo_dual_step(const double* d_column_sums, float* d_duals, double min_log_dual,
                                    float* d_dual_grads, float* d_stats, float* d_actor_stats,
                                    int32_t B, int32_t B_global, int32_t A, int32_t S,
                                    double epsilon, double epsilon_penalty, double epsilon_mean,
@@ -1689,7 +1698,7 @@ extern "C" int tonic_mpo_dual_step(const double* d_column_sums, const float* d_d
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_mpo_dual_step: bad argument");
   hipLaunchKernelGGL(mpo_dual_kernel, dim3(1), dim3(1024), 0, as_stream(stream),
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, d_duals,
-                     action_penalization, (float)epsilon, (float)epsilon_penalty,
+                     (float)min_log_dual, action_penalization, (float)epsilon, (float)epsilon_penalty,
                      (float)epsilon_mean, (float)epsilon_std, d_dual_grads, d_stats, d_actor_stats,
                      B, A, S, d_column_sums, (double*)nullptr, B_global);
   TONIC_CHECK_LAUNCH("tonic_mpo_dual_step");

@@ -1139,7 +1139,9 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
     def enqueue(self, observations, eps, info_row, n_global=None, targets=None, stats_row=None):
         from tonic_amd import parallel
         p = _lib.ptr
-        self.duals.clamp_(min=self.min_log_dual)                           # actors.py:347-356
+        # (actors.py:347-356 floors the log-duals in place at the head of the call: the kernels read them
+        #  through the floor and write the floored values back ahead of the duals' optimizer step)
+        floor = float(self.min_log_dual)
         stats = stats_row if stats_row is not None else self.mpo_stats
         B = 0 if observations is None else observations.shape[0]
         if parallel.exchanging():
@@ -1150,7 +1152,7 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
                 mean, std = self.norm_tensors()
                 _lib.check(self.lib.tonic_mpo_actor_grad_shard(
                     p(self.flat.flat), p(self.model.flat_target_actor.flat),
-                    p(self.model.flat_target_critics.flat), p(self.duals), p(mean), p(std),
+                    p(self.model.flat_target_critics.flat), p(self.duals), floor, p(mean), p(std),
                     self.norm_clip(), p(observations), p(eps), p(self.grad_sums),
                     p(self.column_sums), B, self.observation_size, self.hidden, self.action_size,
                     self.num_samples, int(bool(self.action_penalization)), p(ws), ws.numel(),
@@ -1160,7 +1162,7 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
                 self.column_sums.zero_()
             torch.distributed.all_reduce(self.column_sums)
             _lib.check(self.lib.tonic_mpo_dual_step(
-                p(self.column_sums), p(self.duals), p(self.dual_grads), p(stats),
+                p(self.column_sums), p(self.duals), floor, p(self.dual_grads), p(stats),
                 p(self.grad_sums[self.count:]), B, n_global, self.action_size, self.num_samples,
                 float(self.epsilon), float(self.epsilon_penalty), float(self.epsilon_mean),
                 float(self.epsilon_std), int(bool(self.action_penalization)),
@@ -1170,7 +1172,7 @@ class MaximumAPosterioriPolicyOptimization(_ActorQGradient):
             mean, std = self.norm_tensors()
             _lib.check(self.lib.tonic_mpo_actor_grad(
                 p(self.flat.flat), p(self.model.flat_target_actor.flat),
-                p(self.model.flat_target_critics.flat), p(self.duals), p(mean), p(std),
+                p(self.model.flat_target_critics.flat), p(self.duals), floor, p(mean), p(std),
                 self.norm_clip(), p(observations), p(eps), p(self.grad_sums), p(self.dual_grads),
                 p(stats), B, self.observation_size, self.hidden, self.action_size,
                 self.num_samples, float(self.epsilon), float(self.epsilon_penalty),
