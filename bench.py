@@ -815,9 +815,11 @@ def cfg4_main(args, rank, world):
         'allreduce_bytes_per_iteration': 4 * critic_floats + 2 * actor_floats,
         'allreduces_per_iteration': 1.5 if world > 1 else 0,
         # one rank: the whole update call (50 x 5 / 3 chained launches) replays from one hipGraph; several
-        # ranks: eager launches of the split entry points, the exchange between gradients and step
+        # ranks: the same chained launches in two halves around the exchange (tonic_q_iteration_t.phase) + the
+        # two optimizer launches, eager (the exchange is a host call; per-rank batch sizes vary by iteration)
         'hip_graph': bool(getattr(agent, '_graph', None) is not None),
-        'launches_per_iteration': 5 if world == 1 else 11,
+        'launches_per_iteration': 5 if world == 1 else 7,
+        'fused_in_phases': bool(getattr(agent, '_phased_update', False)),
         'allreduce_floats': dict(critics_every_iteration=critic_floats,
                                  actor_every_second=actor_floats),
         'roofline': dict(bound='mfma (latency-bound at B=100: 7 row tiles)', flop_per_iteration=int(flop),

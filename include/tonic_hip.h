@@ -51,7 +51,7 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries, tonic_q_iteration_t.phase)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -670,6 +670,17 @@ typedef struct tonic_q_iteration_t {
                                   workspace: written once per iteration with agent-scope stores, read
                                   with agent-scope loads until they are no longer the "empty" pattern
                                   the iteration's first launch fills the area with                  */
+  int32_t phase;               /* 0: the whole iteration, optimizer steps in the weight-gradient launches'
+                                  epilogues (one rank, no gradient clipping).  Several ranks / clipping
+                                  need the COMPLETE gradient sums between gradients and step — the same
+                                  chained launches in two halves, gradient SUMS + statistic slots only:
+                                  1: policy passes + critic step + the critics' weight gradients
+                                  -> critic.d_grad_sums; the caller exchanges / clips them and steps the
+                                  critics (tonic_adam_step), then (actor_due) 2: the actor step on the
+                                  UPDATED critics + the actor's weight gradients -> actor.d_grad_sums, the
+                                  caller steps the actor and the targets (tonic_adam_polyak_step).  In
+                                  these phases the failure word is only ever SET (the caller clears it
+                                  ahead of an update and looks at it after it)                         */
 } tonic_q_iteration_t;
 
 int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);

@@ -70,6 +70,22 @@ def test_offpolicy_two_ranks_equal_single_process(tmp_path, kind, port):
             assert diff.max() < 3e-3 and np.mean(diff > 2e-5) < 1e-3, (key, diff.max())
 
 
+@pytest.mark.parametrize('kind,port', [('td3', 29881), ('sac', 29891)])
+def test_offpolicy_ranks_run_the_chained_launches_around_the_exchange(tmp_path, kind, port):
+    """BASELINE config 4's path (TD3 sharded over the ranks; SAC alike): with several ranks the fused iteration
+    runs in two halves around the gradient exchange (tonic_q_iteration_t.phase) instead of falling back to the
+    split entry points — bit for bit their result at 2 and 4 ranks (TONIC_AMD_FUSED_PHASES=0 selects them)."""
+    for world in (2, 4):
+        outs = {}
+        for phases in ('0', '1'):
+            outs[phases] = str(tmp_path / f'{kind}{world}_{phases}.npz')
+            launch(world, outs[phases], port + 2 * world + int(phases), command=(OFFPOLICY_WORKER, kind),
+                   extra_env={'TONIC_AMD_FUSED_PHASES': phases})
+        a, b = np.load(outs['0']), np.load(outs['1'])
+        for key in a.files:
+            assert np.array_equal(a[key], b[key]), (world, key, np.abs(a[key] - b[key]).max())
+
+
 def test_buffer_get_yields_each_ranks_part_of_the_global_batch(tmp_path):
     """Buffer.get with 1 / 2 / 4 ranks: every rank yields exactly its rows of each globally drawn
     batch (possibly none, never an uninitialised tail); the union over ranks is the batch one

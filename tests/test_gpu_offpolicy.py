@@ -434,6 +434,51 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                                       got[first] if first else None, want[first] if first else None))
 
 
+@pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100), ('ddpg', 17, 6, 4, 100)])
+def test_fused_iteration_in_phases_equals_the_split_entry_points(lib, monkeypatch, kind, O, A, W, B):
+    """Whenever something must see the complete gradient sums between gradients and step — here a gradient-norm
+    clip on both updaters; the exchange between ranks in tests/test_gpu_multirank.py — the fused iteration runs in
+    two halves (tonic_q_iteration_t.phase 1 / 2: the same chained launches, sums only) around the updaters' own
+    clip + Adam [+ polyak] launches.  Bit for bit the split entry points' result (TONIC_AMD_FUSED_PHASES=0),
+    eager and replayed from a hipGraph."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    rng = np.random.RandomState(12)
+    rows, iterations = 48, 6
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    eps = rng.normal(size=(iterations, 2 if kind == 'sac' else 1, B, A)).astype(np.float32)
+    indices = rng.randint(rows * W, size=(iterations, B))
+    results = {}
+    for mode, env, graph in (('split', '0', False), ('phases', '1', False), ('phases-graph', '1', True)):
+        monkeypatch.setenv('TONIC_AMD_FUSED_PHASES', env)
+        updaters = dict(
+            sac=(tt.updaters.TwinCriticSoftDeterministicPolicyGradient, tt.updaters.TwinCriticSoftQLearning),
+            td3=(tt.updaters.DeterministicPolicyGradient, tt.updaters.TwinCriticDeterministicQLearning),
+            ddpg=(tt.updaters.DeterministicPolicyGradient, tt.updaters.DeterministicQLearning))[kind]
+        agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3, ddpg=tt.agents.DDPG)[kind](
+            replay=tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B),
+            actor_updater=updaters[0](gradient_clip=0.7), critic_updater=updaters[1](gradient_clip=1.3))
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+        assert (agent._fused_kind() is not None) == (mode != 'split')
+        assert mode == 'split' or agent._fused_in_phases()
+        for t in range(rows):
+            agent.replay.store(**{k: dev(v[t]) for k, v in host.items()})
+        infos = [agent.enqueue_update(indices, eps, graph=graph).cpu().numpy().copy() for _ in range(2)]
+        results[mode] = dict(
+            infos0=infos[0], infos1=infos[1], online=agent.model.flat_online.cpu().numpy(),
+            target=agent.model.flat_target.cpu().numpy(),
+            critic_m=agent.critic_updater.exp_avg.cpu().numpy(), actor_v=agent.actor_updater.exp_avg_sq.cpu().numpy(),
+            steps=np.array([int(agent.critic_updater.state[0]), int(agent.actor_updater.state[0])]))
+    assert np.abs(results['split']['online']).max() > 0 and np.isfinite(results['split']['online']).all()
+    for mode in ('phases', 'phases-graph'):
+        for key, want in results['split'].items():
+            assert np.array_equal(results[mode][key], want), (mode, key)
+
+
 def test_a_lost_workgroup_of_a_chained_launch_skips_the_step_and_raises(lib):
     """The workgroups of the chained launches wait for each other's values (exchange_read,
     csrc/mlpfwd.h).  A value that never comes — here: the first target workgroup of ONE critic

@@ -1231,6 +1231,9 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const tonic_q_iteration_t& a = *it;
   const int kind = a.kind, B = a.B, O = a.O, H = a.H, A = a.A;
   const bool due = a.actor_due != 0;
+  const int phase = a.phase;                 // 0 whole iteration | 1 critic half | 2 actor half (sums only)
+  TONIC_REQUIRE(phase >= 0 && phase <= 2 && (phase != 2 || due), TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_q_iteration: phase %d (actor_due %d)", phase, (int)due);
   TONIC_REQUIRE(kind >= 0 && kind <= 2 && B > 0 && a.d_actor && a.d_critics && a.d_target_actor &&
                     a.d_target_critics && a.d_norm_mean && a.d_norm_std && a.d_observations &&
                     a.d_actions && a.d_next_observations && a.d_rewards && a.d_discounts &&
@@ -1276,7 +1279,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   float* da_h2 = ws.take(hs); float* da_h1 = ws.take(hs);
 
   // ---- 1: the policy passes
-  {
+  if (phase != 2) {
     const float* policy = kind == 1 ? a.d_actor : a.d_target_actor;
     ActorParams p(policy, as);
     MlpFwdArgs f{};
@@ -1297,7 +1300,8 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     f.enc_obs = a.d_next_observations; f.enc_obs2 = a.d_observations; f.enc_act2 = a.d_actions;
     f.enc_mean = a.d_norm_mean; f.enc_std = a.d_norm_std; f.enc_clip = clip_bound(a.norm_clip);
     f.enc_out = X; f.enc_out2 = X2; f.enc_O = O; f.enc_ld = ldx;
-    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; f.reset_failed = failed; }
+    // (phases: the failure word is the caller's to clear — it stands for the whole update)
+    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; f.reset_failed = phase == 0 ? failed : nullptr; }
     if (due) {
       f.split = 1;
       f.second_params = a.d_actor - policy;            // (0 for SAC: the same network on s)
@@ -1327,7 +1331,10 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const StepLoss td{LOSS_TD, a.d_rewards, a.d_discounts, tq,
                     kind == 1 ? logp_next : (const float*)nullptr, (float)a.critic_entropy_coeff, q,
                     a.critic.d_grad_sums + nets * Pc};
-  if (chain) {
+  const AdamFold* critic_fold = phase == 0 ? &cf : nullptr;       // phases: gradient sums only
+  if (phase == 2) {
+    // (the critic half ran in an earlier call)
+  } else if (chain) {
     // 2 + 3 as ONE launch: the online critics' workgroups go on to the TD loss and their chain as
     // soon as the targets of their 16 rows have arrived (q_critic_step_kernel)
     QCriticStep step{};
@@ -1342,14 +1349,14 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     step.nets = nets;
     TRY(launch_q_critic_step(step, st));
     TRY(critics_weight_gradients(cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
-                                 a.critic.d_grad_sums, st, &cf));
+                                 a.critic.d_grad_sums, st, critic_fold));
   } else {
     TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                         a.d_critics, X2));
     TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
-                         a.critic.d_grad_sums, nullptr, st, &td, &cf));
+                         a.critic.d_grad_sums, nullptr, st, &td, critic_fold));
   }
-  if (!due) {
+  if (!due || phase == 1) {
     TONIC_CHECK_LAUNCH("tonic_q_iteration");
     return TONIC_OK;
   }
@@ -1372,6 +1379,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   af.skip = chain ? failed : nullptr;
   af.target = a.d_target_actor;
   af.polyak_keep = (float)(1.0 - a.target_coeff); af.polyak_mix = (float)a.target_coeff;
+  const AdamFold* actor_fold = phase == 0 ? &af : nullptr;
   if (chain) {
     // 5 + 6 + 7 as ONE launch (q_actor_step_kernel): critics forward -> objective (the twins
     // exchange q) -> their chain to the action columns -> head backward + the actor's chain
@@ -1391,14 +1399,14 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     TRY(launch_q_actor_step(step, st));
     TRY(actor_weight_gradients(as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
                                kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
-                               st, &af));
+                               st, actor_fold));
   } else {
     TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st));
     TRY(critics_backward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr,
                          dxa, st, &objective));
     TRY(actor_shaped_backward(a.d_actor, as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
                               kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
-                              nullptr, 0, 0, st, &hb, &af));
+                              nullptr, 0, 0, st, &hb, actor_fold));
   }
   TONIC_CHECK_LAUNCH("tonic_q_iteration");
   return TONIC_OK;

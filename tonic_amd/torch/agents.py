@@ -1366,7 +1366,14 @@ class DDPG(Agent):
             graph = os.environ.get('TONIC_AMD_NO_GRAPH', '0') != '1'
 
         fused = self._fused_kind()
-        if fused is not None:
+        # Several ranks / gradient clipping need the complete gradient sums between gradients and step: the
+        # same chained launches in two halves around the exchange (tonic_q_iteration_t.phase), the steps
+        # through the updaters' own `_step` (all-reduce, clip, Adam [+ polyak]) like the split entry points
+        phased = fused is not None and self._fused_in_phases()
+        self._phased_update = phased
+        if phased:
+            self._fused_workspace_for(max(indices.shape[1], 1))[:4].zero_()   # the update's failure word
+        if fused is not None and not phased:
             # the optimizer steps' float64 constants, formed here like the reference's Python
             # floats: [iteration, {critic, actor}, {step_size, bias_correction2_sqrt}]
             table = np.zeros((iterations, 2, 2), np.float32)
@@ -1402,6 +1409,9 @@ class DDPG(Agent):
                 n_global = None if counts is None else global_batch
                 if c > 0:
                     batch = {k: v[it, :c] for k, v in batches.items()}
+                if phased:
+                    self._enqueue_phased(fused, batch if c > 0 else None, it, self._actor_due(it), n_global)
+                    continue
                 if fused is not None:
                     self._enqueue_fused(fused, batch, it, self._actor_due(it))
                     continue
@@ -1423,7 +1433,7 @@ class DDPG(Agent):
         stock = self.critic_updater.stock or self.actor_updater.stock    # (autograd: no capture)
         if not graph or stock or parallel.exchanging():      # collectives sit between the kernels
             enqueue()
-            self._step_mirror_valid = fused is not None
+            self._step_mirror_valid = fused is not None and not phased
             return self._infos
         if self._graph is None:
             batch_size = indices.shape[1]
@@ -1437,7 +1447,7 @@ class DDPG(Agent):
             with torch.cuda.graph(self._graph):
                 enqueue()
         self._graph.replay()
-        self._step_mirror_valid = fused is not None
+        self._step_mirror_valid = fused is not None and not phased
         return self._infos
 
     def _enqueue_actor(self, observations, eps, iteration, n_global, targets):
@@ -1460,14 +1470,25 @@ class DDPG(Agent):
         kind, actor_class = self._FUSED.get(type(critic), (None, None))
         if kind is None or type(actor) is not actor_class or critic.stock or actor.stock:
             return None
-        if os.environ.get('TONIC_AMD_FUSED_ITERATION', '1') == '0' or parallel.exchanging():
-            return None
-        if critic.gradient_clip > 0 or actor.gradient_clip > 0 or critic.world_size > 1:
+        if os.environ.get('TONIC_AMD_FUSED_ITERATION', '1') == '0':
             return None
         if not self.lib.tonic_q_iteration_supported(self.observation_size, self.hidden,
                                                     self.action_size, 2 if kind == 1 else 1):
             return None
+        needs_phases = parallel.exchanging() or critic.world_size > 1 or critic.gradient_clip > 0 \
+            or actor.gradient_clip > 0
+        if needs_phases and os.environ.get('TONIC_AMD_FUSED_PHASES', '1') == '0':
+            return None
         return kind
+
+    def _fused_in_phases(self):
+        """The fused iteration in two halves, gradient sums only (tonic_q_iteration_t.phase 1 / 2): whenever
+        something has to see the complete sums before the step — the exchange between ranks, a gradient-norm
+        clip.  TONIC_AMD_FUSED_PHASES=0: the split entry points there, as before round 5."""
+        critic, actor = self.critic_updater, self.actor_updater
+        needed = parallel.exchanging() or critic.world_size > 1 or critic.gradient_clip > 0 \
+            or actor.gradient_clip > 0
+        return needed and os.environ.get('TONIC_AMD_FUSED_PHASES', '1') != '0'
 
     def _fused_workspace_for(self, batch_size):
         need = self.lib.tonic_q_iteration_workspace_bytes(batch_size, self.observation_size,
@@ -1478,7 +1499,26 @@ class DDPG(Agent):
             self._fused_workspace = ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return ws
 
-    def _enqueue_fused(self, kind, batch, iteration, actor_due):
+    def _enqueue_phased(self, kind, batch, iteration, actor_due, n_global):
+        """One iteration as [policy passes + critic step + critics' weight gradients] -> exchange / clip + Adam
+        -> [actor step + actor's weight gradients] -> exchange / clip + Adam + polyak: 3 + 1 + 2 + 1 launches
+        around the two exchanges instead of the split entry points' 4 + 1 + 5 + 1."""
+        critic, actor, model = self.critic_updater, self.actor_updater, self.model
+        targets = (model.flat_target, model.flat_online, 0, model.target_coeff)
+        if batch is None:                           # this rank drew none of the global batch
+            critic.enqueue_empty(self._infos[0, iteration], n_global)
+            if actor_due:
+                self._enqueue_actor(None, None, iteration, n_global, targets)
+            return
+        B = batch['observations'].shape[0]
+        n = n_global or B * critic.world_size
+        self._enqueue_fused(kind, batch, iteration, actor_due, phase=1)
+        critic._step(n, self._infos[0, iteration])
+        if actor_due:
+            self._enqueue_fused(kind, batch, iteration, actor_due, phase=2)
+            actor._step(n, self._infos[1, iteration], targets=targets)
+
+    def _enqueue_fused(self, kind, batch, iteration, actor_due, phase=0):
         critic, actor, model, p = self.critic_updater, self.actor_updater, self.model, _lib.ptr
         B = batch['observations'].shape[0]
         ws = self._fused_workspace_for(B)
@@ -1508,9 +1548,11 @@ class DDPG(Agent):
             noise_scale=float(noise.scale if noise else 0.0),
             noise_clip=float(noise.clip if noise else 0.0),
             target_coeff=float(model.target_coeff),
-            critic=optimizer(critic, self._infos[0, iteration], self._static_adam[iteration, 0]),
-            actor=optimizer(actor, self._infos[1, iteration], self._static_adam[iteration, 1]),
-            d_workspace=p(ws), workspace_bytes=ws.numel())
+            critic=optimizer(critic, self._infos[0, iteration],
+                             self._static_adam[iteration, 0] if phase == 0 else None),
+            actor=optimizer(actor, self._infos[1, iteration],
+                            self._static_adam[iteration, 1] if phase == 0 else None),
+            d_workspace=p(ws), workspace_bytes=ws.numel(), phase=phase)
         _lib.check(self.lib.tonic_q_iteration(ctypes.byref(args), _lib.current_stream()),
                    'tonic_q_iteration')
 
@@ -1537,6 +1579,12 @@ class DDPG(Agent):
         eps = self._draw_noise(indices.shape[0])
         infos = self.enqueue_update(indices, eps).cpu().numpy()
         parallel.check_one_shot()
+        if getattr(self, '_phased_update', False) and int(self._fused_workspace[:4].view(torch.int32)[0]):
+            # (in phases the steps are the updaters' own launches: nothing held them back)
+            raise _lib.TonicHipError(
+                'a chained launch of this update gave up waiting for a peer workgroup (250 ms): its gradient '
+                'sums were incomplete and have been stepped on — the parameters are no longer valid '
+                '(TONIC_AMD_TUNING=q_chain=0 runs one launch per pass)')
         try:
             _check_chain(infos)
         except _lib.TonicHipError:
