@@ -1593,7 +1593,7 @@ def test_torso_grads_vs_float64_autograd(lib, sizes, activation, O, A, n):
                                               n, O, A, 0.2, 0.0, None, ws.data_ptr(), ws.numel(), None), 'actor')
     got_a = out.cpu().numpy()
     assert np.abs(got_a[:P] - want_a).max() <= 2e-5 * np.abs(want_a).max(), np.abs(got_a[:P] - want_a).max()
-    np.testing.assert_allclose(got_a[P] / n, float(loss) / n, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got_a[P] / n, float(loss.detach()) / n, rtol=2e-5, atol=2e-6)
     keepc = [dev(flat(critic)), dev(mean), dev(std), dev(obs), dev(returns)]
     outc = torch.zeros(Pc + 8, device='cuda')
     _lib.check(lib.tonic_value_regression_grad_torso(

@@ -765,7 +765,7 @@ std::atomic<int> g_grad_waves{4};
 // fp16x2 terms instead (three fp16 MFMAs per fp32 product, operands scaled into binary16's range; CH = 3).
 constexpr int kDefaultGradVariant = 4;
 std::atomic<int> g_grad_variant{kDefaultGradVariant};
-// mlp64x16: wave priorities (0 off, 1 late half high, 2 swap per tile + the actor's fp16 chains raised: see the kernel)
+// mlp64x16: wave priorities (0 off, 1 late half high, 2 the two waves of a SIMD swap priorities every tile: see the kernel)
 std::atomic<int> g_grad_prio{2};
 std::atomic<int> g_grad_skew{0};       // mlp64x16: optional start skew of waves 4-7, units of s_sleep(127); off:
                            // fp32 MFMA and VALU never overlap on gfx950, so there is no convoy to break

@@ -714,24 +714,14 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
   // Wave priorities (tonic_set_tuning "grad_prio", timing only — same bits).  The issue arbiter prefers the
   // OLDER of the two waves of a SIMD: the second-dispatched half of a workgroup took 14.4 k cycles per tile
   // against 11.8 k (profiles/r04_grad_phases.txt) and a launch ends with its slow half.  2 (default): the
-  // two waves of a SIMD swap priorities 0 / 1 every tile, and in the actor kernel the fp16 MFMA chains of a
-  // tile (layer 2, the backward chain, dW2) run two levels above the tile's base, so that the matrix pipe is
-  // re-issued the moment it frees up while the SIMD's other wave fills the gaps with VALU work
-  // (profiles/r05_grad_knobs.txt: actor 206.4 -> 198.7 with the swap -> 195.0 us with the chains, critic
-  // 163.5 -> 156.2 with the swap, 157.6 with the chains as well: off there).  1: the late half at priority
-  // 1 throughout (no effect); a start skew of the late half (grad_skew) loses.
-  constexpr bool kChainPrio = ACTOR && CH == 3;
+  // two waves of a SIMD swap priorities 0 / 1 every tile (profiles/r05_grad_knobs.txt: actor 206.4 -> 198.7
+  // us, critic 163.5 -> 156.2 us per launch).  Raising the fp16 MFMA chains of a tile two more levels bought
+  // the actor another 1.8 % — and 104 bytes of scratch per lane (the branches that pick the level split the
+  // loop's most register-hungry blocks: HBM traffic 1.05 -> 1.24 x algorithmic, profiles/r05_traffic_chain_prio.json):
+  // not kept.  1: the late half at priority 1 throughout (no effect); a start skew of the late half loses.
   const bool late_half = __builtin_amdgcn_readfirstlane(wave) >= kWaves16 / 2;
   if (a.prio == 1 && late_half) __builtin_amdgcn_s_setprio(1);
   int prio_turn = late_half ? 1 : 0;
-  bool prio_base = false;             // this tile's base level is 1
-  auto chain_prio = [&](bool on) {
-    if constexpr (kChainPrio) {
-      if (a.prio != 2) return;
-      if (on) { if (prio_base) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
-      else { if (prio_base) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    }
-  };
 
   // Per-sample inputs, branch-free: out-of-range lanes read a clamped (valid) address and the
   // value is discarded by a select.  (A load under `if (valid)` becomes an exec-masked branch
@@ -801,7 +791,6 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
     if (a.prio == 2) {
       if (prio_turn & 1) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
-      prio_base = (prio_turn & 1) != 0;
       ++prio_turn;
     }
     PHASE(11);                                       // loop overhead / previous tail
@@ -880,7 +869,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
       PHASE(1);
       load_bias16(lds + L::B2P, g, acc);
       if constexpr (CH == 0) chain64(lds + L::W2S, h1, lane, acc);
-      else if constexpr (F16) { chain_prio(true); chain64_f2(lds + L::W2S, h1, lane, acc); chain_prio(false); }
+      else if constexpr (F16) chain64_f2(lds + L::W2S, h1, lane, acc);
       else chain64_b3(lds + L::W2S, h1, lane, acc);
       PHASE(2);
       if constexpr (HM) tanh16<kF16Top, true>(acc, h2, fwd_unit);     // h2 x 2^14 as well: the head's operand
@@ -1086,7 +1075,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
 
     f32x4 dacc[4] = {zero4, zero4, zero4, zero4};
     if constexpr (CH == 0) chain64(lds + L::W2B, dz2, lane, dacc);          // dh1 = dz2 . W2 (S layout)
-    else if constexpr (F16) { chain_prio(true); chain64_f2(lds + L::W2B, dz2, lane, dacc); chain_prio(false); }
+    else if constexpr (F16) chain64_f2(lds + L::W2B, dz2, lane, dacc);
     else chain64_b3(lds + L::W2B, dz2, lane, dacc);
     PHASE(6);
 
@@ -1168,7 +1157,6 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
         if constexpr (F16) {
           u32x4 bT[2];
           split2_x8(row[0], row[1], bT);
-          if (Tj == 0) chain_prio(true);
 #pragma unroll
           for (int Ti = 0; Ti < 2; ++Ti) {
             f32x16 acc = gW2w[Ti][Tj];
@@ -1177,7 +1165,6 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
             acc = mfma_h32(aT[Ti][0], bT[0], acc);
             gW2w[Ti][Tj] = acc;
           }
-          if (Tj == 1) chain_prio(false);
         } else {
           u32x4 bT[3];
           split3_x8(row[0], row[1], bT);
