@@ -15,7 +15,8 @@ Python loop included.  `device_resident` repeats the measurement with the rollou
 pre-generated in HBM and no host in the loop (round 1's `value`).
 
 Extra keys on the same JSON line: `roofline` (dominant kernel = fused actor forward+backward,
-fp32 MFMA bound), `roofline_gae` (HBM-bound scan, at the config size and at a bandwidth-bound
+MFMA bound: `frac` against the ceiling of the kernel's own fp32 / fp16 instruction mix, the fp32-MFMA
+figure beside it as `fp32_equivalent`), `roofline_gae` (HBM-bound scan, at the config size and at a bandwidth-bound
 sweep), `cpu_baseline` (oracle/torch_port.py = the reference's torch-CPU path timed on this
 box's cores on a bounded sample), `learner_updates_per_sec`, `host_loop` (where an environment
 step goes), `strong_scaling` (N > 1: the metric's 256 workers split over the ranks).
@@ -1042,7 +1043,7 @@ def main():
         # BASELINE config 5's per-GPU share (AntBullet shapes, 1 280 workers): 2 steps, same harness —
         # BEFORE the off-policy legs: every agent built in this process creates HIP streams, the
         # streams of a process share a handful of hardware queues, and a collector that lands on the
-        # queue of the critic's stream loses the overlap this leg is about (DESIGN §4.2b)
+        # queue of the critic's stream loses the overlap this leg is about (DESIGN §4.2)
         agent.close()
         del agent, loop, rollout
         import gc
