@@ -26,6 +26,10 @@ class DeviceRollout:
         self.lib = _lib.load()
         device = agent.device
         O, A = agent.observation_size, agent.action_size
+        updater = agent.actor_updater
+        if getattr(updater, 'stock', False) or getattr(updater, 'torso', None) is not None or O > 32 or A > 8:
+            raise NotImplementedError('DeviceRollout drives the fused per-step kernels: the default torso, '
+                                      'O <= 32, A <= 8 (other agents collect through agent.step)')
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
         self.W, self.T = workers, steps
