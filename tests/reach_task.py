@@ -37,10 +37,13 @@ CASES = {
     'SAC-wide': ('SAC', dict(shape=(40, 10))),
     'MPO-wide': ('MPO', dict(shape=(40, 10))),
     'PPO-humanoid-shapes': ('PPO', dict(shape=(376, 17))),
-    # torsos outside the hand-written kernels' shapes (any MLP(sizes, activation), run as stock
-    # torch operators on the device): PPO with a ReLU torso, SAC with the (400, 300) class
+    # torsos other than the reference's defaults (any MLP(sizes, activation)), on the layer-by-layer HIP paths
+    # (tonic_*_torso / tonic_mlp_hidden): PPO with a ReLU torso and with three tanh layers, SAC with the
+    # (400, 300) class, TD3 with unequal ELU layers
     'PPO-relu-torso': ('PPO', dict(torso=((128, 128), 'ReLU'))),
     'SAC-uneven-torso': ('SAC', dict(torso=((96, 64), 'ReLU'))),
+    'PPO-tanh3-torso': ('PPO', dict(torso=((96, 48, 32), 'Tanh'))),
+    'TD3-elu-torso': ('TD3', dict(torso=((48, 40), 'ELU'))),
     # the reference's own run is unstable here (its reward dips far below zero before it recovers):
     # held against the reference up to and including the dip (see tests/test_gpu_learning.py)
     'D4PG-wide': ('D4PG', dict(shape=(40, 10))),
@@ -138,6 +141,15 @@ def build_agent(tonic, torch_agents, case):
                 head=models.GaussianPolicyHead(
                     loc_activation=torch.nn.Identity,
                     distribution=models.SquashedMultivariateNormalDiag)),
+            critic=models.Critic(encoder=models.ObservationActionEncoder(),
+                                 torso=models.MLP(sizes, act), head=models.ValueHead()),
+            observation_normalizer=package.normalizers.MeanStd())
+    if 'torso' in options and name == 'TD3':
+        sizes, activation = options['torso']
+        act = getattr(torch.nn, activation)
+        model = models.ActorTwinCriticWithTargets(
+            actor=models.Actor(encoder=models.ObservationEncoder(), torso=models.MLP(sizes, act),
+                               head=models.DeterministicPolicyHead()),
             critic=models.Critic(encoder=models.ObservationActionEncoder(),
                                  torso=models.MLP(sizes, act), head=models.ValueHead()),
             observation_normalizer=package.normalizers.MeanStd())
