@@ -37,8 +37,8 @@ struct CriticShape {
   bool plain() const { return h2() == H && act == ACT_RELU; }
 };
 
-// The C ABI passes ONE int32 `H`: the width of a plain torso, or tonic_mlp_hidden(H1, H2, activation) =
-// H1 | H2 << 10 | activation << 20 (widths below 1024; activation: GemmAct).
+// The C ABI passes ONE int32 `H`: the width of a plain torso (below 1024), or tonic_mlp_hidden(H1, H2,
+// activation) = H1 | H2 << 10 | activation << 20 (widths below 1024; activation: GemmAct).
 struct Hidden { int H1, H2, act; };
 inline Hidden unpack_hidden(int32_t code) {
   Hidden h{code & 1023, (code >> 10) & 1023, (code >> 20) & 7};

@@ -637,7 +637,7 @@ def _torso_width(torso, generic=False):
     form catch it)."""
     sizes = tuple(int(v) for v in torso.sizes)
     plain = len(sizes) == 2 and sizes[0] == sizes[1] and torso.activation is torch.nn.ReLU
-    if plain:
+    if plain and sizes[0] < 1024:          # (the C ABI's `H` carries widths below 1 024: tonic_mlp_hidden)
         return sizes[0]
     code = _Q_ACTIVATIONS.get(torso.activation)
     if (generic and len(sizes) == 2 and code is not None
