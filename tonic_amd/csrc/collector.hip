@@ -17,6 +17,7 @@
 // spins on) straight back; transport 1 moves the same bytes with hipMemcpyAsync on the
 // collector's own stream around the kernel and waits on an event — no stream synchronisation
 // either way.
+#include <ctype.h>
 #include <errno.h>
 #include <limits.h>
 #include <linux/futex.h>
@@ -382,6 +383,46 @@ extern "C" void* tonic_host_device_pointer(void* pinned_host) {
   return device;
 }
 
+namespace {
+
+// The NUMA node the current HIP device hangs off (-1: unknown / one node), from sysfs.
+int device_numa_node() {
+  int device = 0;
+  char bus[32] = {0};
+  if (hipGetDevice(&device) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char* p = bus; *p; ++p) *p = (char)tolower(*p);
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE* f = fopen(path, "r");
+  if (f == nullptr) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
+// The shared block's pages next to the GPU that will poll and read them over PCIe every environment step.
+// They sit where the thread that first touched them ran (the trainer's, wherever the scheduler had put it):
+// on a two-socket host half of all processes got them on the far socket, and every one of the step's two or
+// three PCIe round trips then crosses the socket interconnect as well — 13.0 against 10.7 us per environment
+// step of 256 workers (profiles/r05_numa.md).  Best effort (mbind + MPOL_MF_MOVE on the mapping, before it
+// is page-locked); TONIC_AMD_NUMA_BIND=0 leaves the pages where they are.
+void move_block_near_device(void* block, size_t bytes) {
+  const char* off = getenv("TONIC_AMD_NUMA_BIND");
+  if (off != nullptr && off[0] == '0') return;
+  const int node = device_numa_node();
+  if (node < 0 || node >= 1024) return;
+  unsigned long mask[16] = {0};
+  mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+  constexpr int kMpolBind = 2, kMfMove = 2;           // <linux/mempolicy.h>: MPOL_BIND, MPOL_MF_MOVE
+  (void)syscall(SYS_mbind, block, bytes, kMpolBind, mask, 8 * sizeof(mask) + 1, kMfMove);
+}
+
+}  // namespace
+
 extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport) {
   TONIC_REQUIRE(out != nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_create: out is NULL");
   *out = nullptr;
@@ -407,6 +448,7 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
     tonic_collector_destroy(c);
     return TONIC_ERR_LAUNCH;
   };
+  move_block_near_device(block, (size_t)h->total_bytes);
   hipError_t e = hipHostRegister(block, (size_t)h->total_bytes, hipHostRegisterMapped);
   if (e == hipErrorHostMemoryAlreadyRegistered) {
     (void)hipGetLastError();          // a second collector on the same block: it stays locked

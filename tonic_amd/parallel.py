@@ -112,6 +112,48 @@ def combine_advantage_moments(total, total_sq, minimum, maximum, count):
     return mean, std, constant and minimum == 0.0
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if '-' in part:
+            first, last = part.split('-')
+            cpus.update(range(int(first), int(last) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
+_bound = {}
+
+
+def bind_near_gpu(device):
+    """Keeps this process on the CPUs of the NUMA node its GPU hangs off (sched_setaffinity; threads and worker
+    processes started afterwards inherit it).  The collect loop is a chain of PCIe round trips between this
+    process's memory and the GPU: started on the far socket of a two-socket host — where the scheduler puts every
+    second process — an environment step of 256 workers takes 13.0 us instead of 10.7 (profiles/r05_numa.md;
+    the collector also moves the shared block's pages: tonic_collector_create).  One process per GPU binds to its
+    own GPU's node, as launchers do with numactl.  No-op when the current affinity is already inside that node,
+    when the node is unknown, or with TONIC_AMD_NUMA_BIND=0.  Returns the CPUs bound to (None: nothing done)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index in _bound:
+        return _bound[index]
+    _bound[index] = None
+    if os.environ.get('TONIC_AMD_NUMA_BIND', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(index)
+        address = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id)
+        local = _parse_cpulist(open(f'/sys/bus/pci/devices/{address}/local_cpulist').read())
+        allowed = os.sched_getaffinity(0)
+        target = local & allowed
+        if target and not allowed <= local:
+            os.sched_setaffinity(0, target)
+            _bound[index] = target
+    except (OSError, ValueError, AttributeError):
+        pass                                   # (no sysfs entry, a container without the right: stay put)
+    return _bound[index]
+
+
 _one_shot = None
 _choice = None          # {'kind': 'oneshot' | 'rccl', 'reason': ...} once the ranks have decided
 

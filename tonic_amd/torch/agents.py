@@ -67,7 +67,9 @@ def _device():
             'tonic_amd agents need a ROCm GPU: the learner runs in hand-written HIP kernels '
             'and there is deliberately no CPU fallback')
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    return torch.device('cuda', local_rank if local_rank < torch.cuda.device_count() else 0)
+    device = torch.device('cuda', local_rank if local_rank < torch.cuda.device_count() else 0)
+    parallel.bind_near_gpu(device)             # (the collect loop is PCIe round trips: stay on the GPU's socket)
+    return device
 
 
 class Agent(agents.Agent):
