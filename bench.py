@@ -964,8 +964,8 @@ def main():
                    'critic_under_next_rollout': getattr(agent, '_critic_stream', None) is not None,
                    # the process (and the shared block's pages) on the NUMA node the GPU hangs off: a collect step
                    # is PCIe round trips with this process's memory (profiles/r05_numa.md; TONIC_AMD_NUMA_BIND=0: off)
-                   'process_bound_near_gpu': any(v is not None for v in parallel._bound.values())
-                   or os.environ.get('TONIC_AMD_NUMA_BIND', '1') != '0'},
+                   'numa_bind': os.environ.get('TONIC_AMD_NUMA_BIND', '1') != '0',
+                   'process_was_moved_to_the_gpus_node': any(v is not None for v in parallel._bound.values())},
         'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
         'actor_iterations_last_update': main_run['actor_iterations'],
     }
