@@ -562,7 +562,7 @@ class HostLoop:
         return dict(us_per_env_step=round(float(us.sum()), 2), agent_step_us=round(float(us[0]), 2),
                     env_step_us=round(float(us[1]), 2), agent_update_us=round(float(us[2]), 2),
                     env_steps_per_sec=round(W * 1e6 / float(us.sum()), 1),
-                    steps=environment_steps, transport=agent.transport)
+                    steps=environment_steps, transport=getattr(agent, 'transport_in_effect', agent.transport))
 
 
 def parallel_workers_loop(agent, groups=8, per_group=32, steps=512):
@@ -951,7 +951,7 @@ def main():
                    'global_workers': global_workers,
                    'parallelism': f'dp{world} (worker-axis shard, RCCL all-reduce of flat '
                                   'gradient sums)',
-                   'collector_transport': agent.transport,
+                   'collector_transport': getattr(agent, 'transport_in_effect', agent.transport),
                    # what `environment.step` is here: the vectorised synthetic simulator of this
                    # package, whose whole step (observations ~ N(0,1) from a pool, reward, episode
                    # lengths, resets) is ONE C entry point of the product library writing into the

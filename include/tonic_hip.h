@@ -51,7 +51,8 @@ const char* tonic_last_error(void);
  * 3 = pinned-host collector, gradient / normaliser clipping, 4 = distributional critic entries,
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
- * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries, tonic_q_iteration_t.phase)
+ * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries,  tonic_q_iteration_t.phase,
+ * 9 = collector transport 3 + tonic_collector_transport)
  * and the gfx target the kernels were built for. */
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
@@ -364,6 +365,16 @@ int tonic_ppo_collect_steps_packed(const float* d_packed_actor, const float* d_o
  * step, it waits for the host's next command word in pinned memory instead of being launched
  * again, and parks itself (the next step starts it again) after TONIC_AMD_COLLECTOR_PARK_US
  * (default 200) microseconds without a command, e.g. under a slow simulator or a test episode.
+ * transport 3: as 2, but the HOST pushes the step's command word, observation rows and noise rows into a
+ * window of fine-grained device memory (write-combined stores through the GPU's BAR, a store fence, then the
+ * command) — the kernel polls and reads its own HBM instead of pulling those bytes over PCIe: one PCIe read
+ * round trip and the poll's leave the step's critical path (6.2 -> 4.9 us for the bare exchange at W = 256,
+ * O = 28; scripts/ubench/pingpong.hip).  Outcome fields and actions travel as in transport 2.  Only the
+ * process that created the collector can store through the window: a forked worker group's ring leaves an
+ * armed command to the parent (tonic_collector_ring / _claim).  Falls back to transport 2 when the device
+ * memory is not CPU-visible (hipDeviceAttributeIsLargeBar), beyond 48 KB of observations per step (the
+ * kernel's pull is faster than the host's stores there), when another collector already pushes into the
+ * block, or with TONIC_AMD_COLLECTOR_PUSH=0; tonic_collector_transport tells.
  * Shapes beyond the fused act kernel (32 < O <= 384 or 8 < A <= 32) always run as transport 0 with
  * five launches per step (ingest, three dense layers, sample + store + completion words).
  * A step is idempotent — issuing the same row again overwrites the same rows and recomputes the same
@@ -439,6 +450,7 @@ int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transpo
 void* tonic_host_device_pointer(void* pinned_host);
 int tonic_collector_destroy(tonic_collector_t* collector);
 void* tonic_collector_stream(tonic_collector_t* collector);      /* the collector's hipStream_t */
+int32_t tonic_collector_transport(tonic_collector_t* collector); /* the transport in effect (see above) */
 int tonic_collector_bind_segment(tonic_collector_t* collector, float* d_seg_observations,
                                  float* d_seg_actions, float* d_seg_next_observations,
                                  float* d_seg_rewards, float* d_seg_resets,

@@ -60,7 +60,7 @@ WIDE_STEPS = [pytest.param(0, O, A, W, id=f'wide-{O}-{A}-{W}')
 
 
 @pytest.mark.parametrize('transport,O,A,W',
-                         [(t, O, A, W) for t in (0, 1, 2)
+                         [(t, O, A, W) for t in (0, 1, 2, 3)
                           for O, A, W in ((17, 6, 256), (28, 8, 1280), (3, 1, 5))] + WIDE_STEPS)
 def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     """T host-in-the-loop steps through the C entry points: actions and log-probs against
@@ -116,7 +116,7 @@ def test_collector_steps_match_the_oracle(lib, transport, O, A, W):
     collector.close()
 
 
-@pytest.mark.parametrize('transport,O,A,W', [(t, O, A, W) for t in (0, 2)
+@pytest.mark.parametrize('transport,O,A,W', [(t, O, A, W) for t in (0, 2, 3)
                                              for O, A, W in ((28, 8, 1280), (17, 6, 1024), (3, 2, 6000))])
 def test_carried_over_rows_cross_pcie_once(lib, transport, O, A, W):
     """Many workers + a block whose writer promised carry-over (tonic_collector_block_carry_over):
@@ -188,7 +188,7 @@ def test_collector_equals_device_resident_collect(lib):
         p(ref['actions']), p(ref['next_observations']), p(ref['rewards']), p(ref['resets']),
         p(ref['terminations']), p(ref['log_probs']), p(ref_sums), 0, T, W, O, A, None), 'collect')
     torch.cuda.synchronize()
-    for transport in (0, 1, 2):
+    for transport in (0, 1, 2, 3):
         block = Block(W, O, A)
         collector = Collector(block, transport)
         seg = _segment(T, W, O, A)
@@ -637,6 +637,9 @@ def test_completion_words_order_the_actions(lib):
     assert stress.main(W=256, steps=1024, transport=1) == 0
     assert stress.main(W=6, steps=6144, transport=2) == 0
     assert stress.main(W=256, steps=4096, transport=2) == 0
+    assert stress.main(W=6, steps=6144, transport=3) == 0
+    assert stress.main(W=256, steps=4096, transport=3) == 0
+    assert stress.main(W=256, O=28, A=8, steps=4096, transport=3) == 0
 
 
 def test_resident_kernel_parks_and_resumes(lib):
@@ -653,7 +656,7 @@ def test_resident_kernel_parks_and_resumes(lib):
     eps = rng.standard_normal((T, W, A)).astype(np.float32)
     rewards = rng.standard_normal((T, W)).astype(np.float32)
     results = {}
-    for transport, pauses in ((0, ()), (2, (2, 3, 6, 8))):
+    for transport, pauses in ((0, ()), (2, (2, 3, 6, 8)), (3, (2, 3, 6, 8))):
         block = Block(W, O, A)
         collector = Collector(block, transport)
         seg = _segment(T, W, O, A)
@@ -681,6 +684,7 @@ def test_resident_kernel_parks_and_resumes(lib):
         collector.close()
     for key, want in results[0].items():
         assert np.array_equal(results[2][key], want), key
+        assert np.array_equal(results[3][key], want), key
 
 
 @pytest.mark.parametrize('O,A,W,T,hog,hog_ms', [
@@ -877,3 +881,32 @@ def test_checkpoints_have_exactly_the_reference_state_dict(lib, golden, tmp_path
     for key, value in saved.items():
         assert tuple(value.shape) == reference[key].shape, key
         assert value.is_contiguous() and value.dtype == torch.float32
+
+
+def test_push_transport_is_in_effect_for_the_metrics_shapes(lib):
+    """transport 3 (command word, observation rows and noise rows pushed into a device window by the host)
+    is what a collector asked for it runs on an MI355X for cfg 1 / cfg 5's per-step shapes (W = 256), and
+    what a block beyond 48 KB of observations per step, a second collector on the same block and
+    TONIC_AMD_COLLECTOR_PUSH=0 fall back from — each to the resident pull transport."""
+    import os
+    from tonic_amd.collector import Block, Collector
+    block = Block(256, 28, 8)
+    first = Collector(block, 3)
+    assert first.transport == 3, 'this GPU has no CPU-visible device memory?'
+    second = Collector(block, 3)                  # the block's window belongs to the first
+    assert second.transport == 2
+    second.close()
+    first.close()
+    again = Collector(block, 3)                   # ... and is free again
+    assert again.transport == 3
+    again.close()
+    many = Collector(Block(1280, 28, 8), 3)       # 143 KB of observations per step: the pull is faster
+    assert many.transport == 2
+    many.close()
+    os.environ['TONIC_AMD_COLLECTOR_PUSH'] = '0'
+    try:
+        off = Collector(Block(256, 28, 8), 3)
+        assert off.transport == 2
+        off.close()
+    finally:
+        del os.environ['TONIC_AMD_COLLECTOR_PUSH']

@@ -140,6 +140,7 @@ SIGNATURES = {
     'tonic_host_device_pointer': (c_vp, [c_vp]),
     'tonic_collector_destroy': (ctypes.c_int, [c_vp]),
     'tonic_collector_stream': (c_vp, [c_vp]),
+    'tonic_collector_transport': (c_i32, [c_vp]),
     'tonic_collector_bind_segment': (ctypes.c_int, [c_vp] * 9 + [c_i64]),
     'tonic_collector_begin_rollout': (ctypes.c_int, [c_vp, c_vp, c_vp]),
     'tonic_collector_ppo_step': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
@@ -162,7 +163,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 8        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 9        # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

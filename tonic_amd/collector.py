@@ -152,7 +152,8 @@ class Collector:
                    'tonic_collector_create')
         self._cell = [handle.value]          # shared with the block, which outlives the handle
         block._handles.append(self._cell)
-        self.transport = transport
+        self.requested = transport
+        self.transport = lib.tonic_collector_transport(handle)      # (what is in effect: wide -> 0, no window -> 2)
         self._step = lib.tonic_collector_ppo_step          # bound once: the per-step hot calls
         self._wait = lib.tonic_collector_wait_actions
         self._arm = lib.tonic_collector_arm

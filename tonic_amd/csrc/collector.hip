@@ -16,9 +16,13 @@
 // outcome straight from the block over PCIe and write the actions (and a completion word the host
 // spins on) straight back; transport 1 moves the same bytes with hipMemcpyAsync on the
 // collector's own stream around the kernel and waits on an event — no stream synchronisation
-// either way.
+// either way.  transport 2 keeps that kernel resident for a rollout (a command word instead of a
+// launch); transport 3 is transport 2 with the step's command, observations and noise PUSHED into a
+// window of device memory by the host (write-combined stores through the GPU's BAR) instead of being
+// pulled over PCIe by the kernel: the poll and the actor tiles' input loads stay inside the GPU.
 #include <ctype.h>
 #include <errno.h>
+#include <immintrin.h>
 #include <limits.h>
 #include <linux/futex.h>
 #include <stdlib.h>
@@ -26,6 +30,8 @@
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
+
+#include <pthread.h>
 
 #include <new>
 
@@ -58,6 +64,10 @@ struct BlockHeader {
   // whoever completes the step record it acts on (tonic_collector_ring: the environment's step
   // call, or the last worker group in tonic_collector_worker_done); 0 = nothing armed
   alignas(64) uint64_t armed;
+  // transport 3: the device window of the collector that owns this block, as the HOST address the owning
+  // process stores through (0: none), and that process — forked workers share the header, not the mapping
+  alignas(64) uint64_t push_window;
+  int32_t push_pid;
 };
 static_assert(sizeof(BlockHeader) <= kHeaderBytes, "header does not fit its page");
 
@@ -116,14 +126,56 @@ bool wait_change(uint32_t* word, uint32_t seen, double timeout_s, int spin_itera
   }
 }
 
-// Issues the command the agent has armed, if any (host stores only: callable from a forked worker).
+// This process (cached; a forked child asks again).
+pid_t g_pid = 0;
+void forget_pid() { g_pid = 0; }
+pid_t my_pid() {
+  if (g_pid == 0) {
+    static bool hooked = false;
+    if (!hooked) { pthread_atfork(nullptr, nullptr, forget_pid); hooked = true; }
+    g_pid = getpid();
+  }
+  return g_pid;
+}
+
+// The window of a transport-3 collector if THIS process may store through it.
+char* push_window_of(const BlockHeader* h) {
+  const uint64_t window = __atomic_load_n(&h->push_window, __ATOMIC_ACQUIRE);
+  return window != 0 && h->push_pid == (int32_t)my_pid() ? reinterpret_cast<char*>(window) : nullptr;
+}
+
+// Block field -> the same field of the window: write-combined stores, nothing is ever read back.
+void push_field(const BlockHeader* h, char* window, int f, int64_t bytes) {
+  memcpy(window + h->offset[f], reinterpret_cast<const char*>(h) + h->offset[f], (size_t)bytes);
+}
+
+// The next command to the resident kernel.  Pull (transport 2): one release store to the block's header,
+// the kernel finds it by polling over PCIe.  Push (transport 3, in the owning process): the step's
+// observation rows go into the window first, a store fence keeps the write-combined stores in order, then
+// the command word follows them into the window.  (A stop command, bit 3, acts on nothing; rows_pushed: the
+// caller has put the observation rows into the window already.)
+void issue_command(BlockHeader* h, uint64_t word, bool rows_pushed = false) {
+  __atomic_store_n(&h->command, word, __ATOMIC_RELEASE);
+  char* window = push_window_of(h);
+  if (window == nullptr) return;
+  if ((word & 8u) == 0 && !rows_pushed)
+    push_field(h, window, TONIC_COLLECTOR_OBSERVATIONS, h->W * h->O * 4);
+  _mm_sfence();
+  *reinterpret_cast<volatile uint64_t*>(window + offsetof(BlockHeader, command)) = word;
+  _mm_sfence();
+}
+
+// Issues the command the agent has armed, if any (host stores only: callable from a forked worker —
+// which leaves the command of a PUSH collector where it is: the owning process issues it, from its own
+// ring or when the agent claims it back).
 // The exchange makes ring and claim / cancel mutually exclusive: exactly one side gets the word.
-int ring_armed(BlockHeader* h) {
+int ring_armed(BlockHeader* h, bool rows_pushed = false) {
   if (__atomic_load_n(&h->armed, __ATOMIC_RELAXED) == 0) return 0;
+  if (__atomic_load_n(&h->push_window, __ATOMIC_RELAXED) != 0 && push_window_of(h) == nullptr) return 0;
   const uint64_t word = __atomic_exchange_n(&h->armed, (uint64_t)0, __ATOMIC_ACQ_REL);
   if (word == 0) return 0;
   __atomic_store_n(&h->act_seq, (uint32_t)(word >> 32), __ATOMIC_RELEASE);
-  __atomic_store_n(&h->command, word, __ATOMIC_RELEASE);
+  issue_command(h, word, rows_pushed);
   return 1;
 }
 
@@ -180,7 +232,11 @@ extern "C" int tonic_collector_synthetic_step(void* block, const float* next_obs
   char* base = static_cast<char*>(block);
   const size_t bytes = (size_t)h->W * h->O * sizeof(float);
   memcpy(base + h->offset[TONIC_COLLECTOR_NEXT_OBSERVATIONS], next_observations, bytes);
-  memcpy(base + h->offset[TONIC_COLLECTOR_OBSERVATIONS], next_observations, bytes);
+  // A push collector's kernel reads the observation rows from its window: when this call issues the command
+  // they go THERE first, the command follows, and the block's own copy (what the trainer is handed) is made
+  // while the GPU is already at work.
+  char* window = ring && __atomic_load_n(&h->armed, __ATOMIC_RELAXED) != 0 ? push_window_of(h) : nullptr;
+  if (window == nullptr) memcpy(base + h->offset[TONIC_COLLECTOR_OBSERVATIONS], next_observations, bytes);
   const float* a = actions != nullptr ? actions
                                       : reinterpret_cast<const float*>(base + h->offset[TONIC_COLLECTOR_ACTIONS]);
   float* rewards = reinterpret_cast<float*>(base + h->offset[TONIC_COLLECTOR_REWARDS]);
@@ -192,7 +248,9 @@ extern "C" int tonic_collector_synthetic_step(void* block, const float* next_obs
   }
   // ring: the caller knows that the flags in the block are final too (nobody resets at this
   // step) -> the record is complete, the agent's armed command goes out from here
-  if (ring) ring_armed(h);
+  if (window != nullptr) memcpy(window + h->offset[TONIC_COLLECTOR_OBSERVATIONS], next_observations, bytes);
+  if (ring) ring_armed(h, window != nullptr);
+  if (window != nullptr) memcpy(base + h->offset[TONIC_COLLECTOR_OBSERVATIONS], next_observations, bytes);
   return TONIC_OK;
 }
 
@@ -280,9 +338,10 @@ struct tonic_collector {
   BlockHeader* host;            // the shared block (host address)
   char* mapped;                 // device-visible alias of the block (hipHostGetDevicePointer)
   char* staged;                 // transport 1: device copy of the block's fields
+  char* window;                 // transport 3: fine-grained device memory the host stores into (block layout)
   int64_t W;
   int O, A, transport;
-  bool registered;
+  bool counted;                 // among the users of its block (see BlockUse)
   hipStream_t stream;
   hipEvent_t learner_done, collect_done, actions_out;
   float* d_packed;
@@ -337,10 +396,22 @@ int claim_armed(tonic_collector* c) {
   return 1;
 }
 
-// Where the kernels read / write field `f`: the mapped block (transport 0) or its device copy.
+// Where the kernels read / write field `f`: the mapped block (transport 0 / 2), its device copy
+// (transport 1) or, for what the host pushes (transport 3: observations and noise), the window.
 float* field(tonic_collector* c, int f) {
   char* base = c->transport != 1 ? c->mapped : c->staged;
+  if (c->transport == 3 &&
+      (f == TONIC_COLLECTOR_OBSERVATIONS || f == TONIC_COLLECTOR_EPS0 || f == TONIC_COLLECTOR_EPS1))
+    base = c->window;
   return reinterpret_cast<float*>(base + c->host->offset[f]);
+}
+
+// transport 3: the noise rows of slot `eps_slot` follow the block into the window (off the step's
+// critical path when the command is armed ahead: the GPU is still busy with the step before)
+void push_noise(tonic_collector* c, int eps_slot) {
+  if (c->transport != 3 || eps_slot < 0) return;
+  push_field(c->host, c->window, eps_slot == 0 ? TONIC_COLLECTOR_EPS0 : TONIC_COLLECTOR_EPS1,
+             c->W * c->A * 4);
 }
 
 // The outcome of one environment step -> Segment row (the copy role of the collect kernel on its
@@ -385,6 +456,22 @@ extern "C" void* tonic_host_device_pointer(void* pinned_host) {
 
 namespace {
 
+// Collectors per block in this process (host code under the caller's serialisation, like the handles).  A
+// block is page-locked by its first collector and released by its last: ROCm accepts a second registration
+// of the same range, and the first hipHostUnregister would then take the mapping away from everybody.
+struct BlockUse { const void* block; int users; bool locked_here; };
+BlockUse g_blocks[256];
+BlockUse* block_use(const void* block, bool make) {
+  BlockUse* spare = nullptr;
+  for (BlockUse& b : g_blocks) {
+    if (b.users > 0 && b.block == block) return &b;
+    if (b.users == 0 && spare == nullptr) spare = &b;
+  }
+  if (!make || spare == nullptr) return nullptr;
+  spare->block = block; spare->locked_here = false;
+  return spare;
+}
+
 // The NUMA node the current HIP device hangs off (-1: unknown / one node), from sysfs.
 int device_numa_node() {
   int device = 0;
@@ -421,6 +508,28 @@ void move_block_near_device(void* block, size_t bytes) {
   (void)syscall(SYS_mbind, block, bytes, kMpolBind, mask, 8 * sizeof(mask) + 1, kMfMove);
 }
 
+// transport 3 needs the whole of device memory behind a CPU-visible BAR (every MI300 / MI350 server board;
+// hipDeviceAttributeIsLargeBar), a block nobody else pushes into, and a step whose rows the host writes
+// faster than the kernel pulls them: write-combined stores run at ~29 GB/s from one core, inside the
+// environment's step, against ~2 us + bytes / 50 GB/s for the pull (scripts/ubench/pingpong.hip: 6.2 -> 4.9
+// us per exchange at 28 KB with an otherwise idle host; the collect loop at W = 256, O = 28: 10.3 -> 9.7 us
+// per environment step) — up to 48 KB of observations per step.  (Pushing the command word alone and
+// pulling the rows is slower than the plain pull: 10.7 us, profiles/r05_push_transport.md.)
+// TONIC_AMD_COLLECTOR_PUSH=0: never.
+bool push_possible(const BlockHeader* h) {
+  const char* off = getenv("TONIC_AMD_COLLECTOR_PUSH");
+  if (off != nullptr && off[0] == '0') return false;
+  if (h->push_window != 0) return false;
+  if (h->W * h->O * 4 > 48 * 1024) return false;
+  int device = 0, large_bar = 0;
+  if (hipGetDevice(&device) != hipSuccess ||
+      hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return large_bar == 1;
+}
+
 }  // namespace
 
 extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport) {
@@ -429,9 +538,9 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   BlockHeader* h = header_of(block);
   TONIC_REQUIRE(h != nullptr, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_create: not an initialised collector block");
-  TONIC_REQUIRE(transport >= 0 && transport <= 2, TONIC_ERR_INVALID_ARGUMENT,
+  TONIC_REQUIRE(transport >= 0 && transport <= 3, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_create: transport must be 0 (mapped, one launch per step), "
-                "1 (hipMemcpyAsync) or 2 (mapped, resident kernel)");
+                "1 (hipMemcpyAsync), 2 (mapped, resident kernel) or 3 (resident kernel, inputs pushed)");
   TONIC_REQUIRE(h->O <= 384 && h->A <= 32, TONIC_ERR_UNSUPPORTED_SHAPE,
                 "tonic_collector_create: the act kernels serve O <= 384, A <= 32 (got %d, %d)",
                 h->O, h->A);
@@ -443,20 +552,24 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
   // block (mlpwide.hip wide_collect_step), i.e. transport 0 whatever was asked for
   c->wide = h->O > 32 || h->A > 8;
   if (c->wide) c->transport = 0;
+  if (c->transport == 3 && !push_possible(h)) c->transport = 2;
   auto fail = [&](const char* what, hipError_t e) {
     set_error("tonic_collector_create: %s: %s", what, hipGetErrorString(e));
     tonic_collector_destroy(c);
     return TONIC_ERR_LAUNCH;
   };
-  move_block_near_device(block, (size_t)h->total_bytes);
-  hipError_t e = hipHostRegister(block, (size_t)h->total_bytes, hipHostRegisterMapped);
-  if (e == hipErrorHostMemoryAlreadyRegistered) {
-    (void)hipGetLastError();          // a second collector on the same block: it stays locked
-  } else if (e != hipSuccess) {
-    return fail("hipHostRegister of the shared block", e);
-  } else {
-    c->registered = true;
+  hipError_t e = hipSuccess;
+  BlockUse* use = block_use(block, true);
+  if (use == nullptr) return fail("more than 256 live collector blocks", hipErrorOutOfMemory);
+  if (use->users == 0) {
+    move_block_near_device(block, (size_t)h->total_bytes);
+    e = hipHostRegister(block, (size_t)h->total_bytes, hipHostRegisterMapped);
+    if (e == hipErrorHostMemoryAlreadyRegistered) (void)hipGetLastError();     // (by the caller: theirs to release)
+    else if (e != hipSuccess) return fail("hipHostRegister of the shared block", e);
+    else use->locked_here = true;
   }
+  use->users += 1;
+  c->counted = true;
   void* mapped = nullptr;
   if ((e = hipHostGetDevicePointer(&mapped, block, 0)) != hipSuccess)
     return fail("hipHostGetDevicePointer", e);
@@ -484,6 +597,17 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
         (e = hipMemset(c->d_stamps, 0, 32 * 8)) != hipSuccess)
       return fail("hipMalloc of the stamp buffer", e);
   }
+  if (c->transport == 3) {
+    // the window: fine-grained device memory (the kernel's system-scope loads see the host's stores
+    // whatever an L2 holds), zero = no command yet
+    if ((e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->window), (size_t)h->total_bytes,
+                                   hipDeviceMallocFinegrained)) != hipSuccess ||
+        (e = hipMemset(c->window, 0, (size_t)h->total_bytes)) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess)
+      return fail("the device window of transport 3", e);
+    h->push_pid = (int32_t)my_pid();
+    __atomic_store_n(&h->push_window, (uint64_t)reinterpret_cast<uintptr_t>(c->window), __ATOMIC_RELEASE);
+  }
   const char* park = getenv("TONIC_AMD_COLLECTOR_PARK_US");
   c->park_us = park != nullptr ? atof(park) : 200.0;
   if ((e = hipMemset(c->staged, 0, (size_t)h->total_bytes)) != hipSuccess)
@@ -499,10 +623,15 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (claim_armed(c)) (void)tonic_collector_wait_actions(c, 1.0);   // (issued by the environment)
   if (c->live) {                     // a stop command (nothing to store) ends the resident kernel
     c->seq += 1;
-    __atomic_store_n(&c->host->command, ((uint64_t)c->seq << 32) | 8u, __ATOMIC_RELEASE);
+    issue_command(c->host, ((uint64_t)c->seq << 32) | 8u);
     c->live = false;
   }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->window != nullptr) {
+    if (c->host->push_window == (uint64_t)reinterpret_cast<uintptr_t>(c->window))
+      __atomic_store_n(&c->host->push_window, (uint64_t)0, __ATOMIC_RELEASE);
+    (void)hipFree(c->window);
+  }
   if (c->d_stamps) {
     unsigned long long t[32];
     if (hipMemcpy(t, c->d_stamps, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -530,13 +659,20 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (c->collect_done) (void)hipEventDestroy(c->collect_done);
   if (c->actions_out) (void)hipEventDestroy(c->actions_out);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->registered) (void)hipHostUnregister(c->host);
+  BlockUse* use = c->counted ? block_use(c->host, false) : nullptr;
+  if (use != nullptr && --use->users == 0 && use->locked_here) {
+    if (hipHostUnregister(c->host) != hipSuccess) (void)hipGetLastError();
+  }
   delete c;
   return TONIC_OK;
 }
 
 extern "C" void* tonic_collector_stream(tonic_collector_t* c) {
   return c != nullptr ? c->stream : nullptr;
+}
+
+extern "C" int32_t tonic_collector_transport(tonic_collector_t* c) {
+  return c != nullptr ? c->transport : -1;
 }
 
 extern "C" int tonic_collector_bind_segment(
@@ -611,7 +747,8 @@ Collect16Args step_arguments(tonic_collector* c) {
 int launch_resident(tonic_collector* c, unsigned first_seq) {
   TONIC_HIP(hipMemsetAsync(c->d_relay, 0, kRelayBytes, c->stream), "hipMemsetAsync");
   CollectResident r{};
-  r.command = reinterpret_cast<const unsigned long long*>(c->mapped + offsetof(BlockHeader, command));
+  r.command = reinterpret_cast<const unsigned long long*>(
+      (c->transport == 3 ? c->window : c->mapped) + offsetof(BlockHeader, command));
   r.relay = c->d_relay;
   r.claims = c->d_relay + 64;                     // (the park notice has a 256-byte line of its own)
   r.parked = reinterpret_cast<unsigned*>(c->mapped + offsetof(BlockHeader, parked));
@@ -636,8 +773,9 @@ extern "C" int tonic_collector_arm(tonic_collector_t* c, int64_t row, int32_t ep
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_arm: bad row %lld / slot %d",
                 (long long)row, eps_slot);
   // only a RESIDENT kernel can be commanded by somebody who cannot launch (a worker process)
-  if (c->transport != 2 || !c->live || c->wide || (c->norm_acc != nullptr && !c->hist_loaded))
+  if (c->transport < 2 || !c->live || c->wide || (c->norm_acc != nullptr && !c->hist_loaded))
     return 0;
+  push_noise(c, eps_slot);
   const uint64_t word = ((uint64_t)(c->seq + 1) << 32) | ((uint64_t)row << 8) |
                         (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
                         (eps_slot == 1 ? 1u : 0u);
@@ -679,7 +817,7 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
   c->last_row = row;
   c->seq += 1;
   __atomic_store_n(&c->host->act_seq, c->seq, __ATOMIC_RELEASE);
-  if (c->transport == 2) {
+  if (c->transport >= 2) {
     if (!c->live) {
       const int status = launch_resident(c, c->seq);
       if (status != TONIC_OK) return status;
@@ -687,7 +825,8 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
     const uint64_t word = ((uint64_t)c->seq << 32) | ((uint64_t)row << 8) |
                           (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
                           (eps_slot == 1 ? 1u : 0u);
-    __atomic_store_n(&c->host->command, word, __ATOMIC_RELEASE);
+    push_noise(c, eps_slot);
+    issue_command(c->host, word);
     c->waiting = true;
     return TONIC_OK;
   }
@@ -746,7 +885,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
       while (arrived < words && __atomic_load_n(flags + arrived, __ATOMIC_ACQUIRE) == c->seq)
         ++arrived;
       done = arrived == words;
-      const uint32_t parked = c->transport == 2 && !done
+      const uint32_t parked = c->transport >= 2 && !done
                                   ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u;
       // (a notice for another command while this one is incomplete: the kernel may be gone all the
       //  same — a slot of this command gave up on rows of workgroups that had left — look at the stream)
@@ -795,7 +934,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
         set_error("tonic_collector_wait_actions: no actions within %.1f s (command %u: %d of %d "
                   "completion words in order, others:%s; parked at %u, stream %s)", timeout_s, c->seq,
                   arrived, words, missing,
-                  c->transport == 2 ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u,
+                  c->transport >= 2 ? __atomic_load_n(&c->host->parked, __ATOMIC_ACQUIRE) : 0u,
                   hipStreamQuery(c->stream) == hipSuccess ? "idle" : "busy");
         return TONIC_ERR_TIMEOUT;
       }
@@ -817,7 +956,7 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
     c->seq += 1;
     const uint64_t word = ((uint64_t)c->seq << 32) | ((uint64_t)(last_row + 1) << 8) |
                           (last_row >= 0 ? 4u : 0u) | 8u;
-    __atomic_store_n(&c->host->command, word, __ATOMIC_RELEASE);
+    issue_command(c->host, word);
     c->waiting = true;
     const int status = tonic_collector_wait_actions(c, 60.0);
     if (status != TONIC_OK) return status;

@@ -193,6 +193,9 @@ class Parallel:
             self.block.actions[:] = actions
         self.block.submit_actions()
         self._wait()
+        # (a push collector's armed command is the parent's to issue: the workers cannot store through
+        #  the device window; with any other collector the last worker group has taken it already)
+        self.block.ring()
         return _outputs(self.block, self.copy_outputs)
 
     def close(self):

@@ -355,10 +355,13 @@ class A2C(Agent):
         self._speculated = self._eps_ahead = self._block_fed = self._armed = False
         self._critic_pending = self._rollout_behind = None       # (PPO: see _update)
         self._host_rollout = False
-        # 2 (default): the act kernel stays RESIDENT for a rollout and reads / writes the
-        # page-locked block in place; 0: the same kernel launched once per step; 1: hipMemcpyAsync
-        # around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per round trip)
-        self.transport = int(os.environ.get('TONIC_AMD_COLLECTOR_TRANSPORT', '2'))
+        # 3 (default): the act kernel stays RESIDENT for a rollout and the host pushes each step's
+        # command, observation and noise rows into a device window (the collector falls back to 2 where
+        # it cannot or should not: see tonic_collector_create); 2: resident, the kernel pulls everything
+        # from the page-locked block over PCIe; 0: the same kernel launched once per step;
+        # 1: hipMemcpyAsync around it (profiles/r02_collector_latency.md: 10.4 / 13.9 / 28.4 us per
+        # round trip for 2 / 0 / 1)
+        self.transport = int(os.environ.get('TONIC_AMD_COLLECTOR_TRANSPORT', '3'))
 
     # ------------------------------------------------------------------ acting
     def _io(self, workers):
@@ -432,6 +435,7 @@ class A2C(Agent):
         block = Block.owner_of(observations) or Block(W, O, A)
         self._block = block
         self._collector = Collector.for_block(block, self.transport)
+        self.transport_in_effect = self._collector.transport
         replay = self.replay
         if replay.buffers is None or replay.num_workers != W:
             replay._allocate(W, O, A)
@@ -617,7 +621,7 @@ class A2C(Agent):
                 noise.close()
                 self._noise = None
             self._collector.close()
-            self._block._collectors.pop(self._collector.transport, None)
+            self._block._collectors.pop(self._collector.requested, None)
             self._collector = self._block = None
             self._speculated = self._eps_ahead = self._block_fed = False
             self._rollout_behind = None
