@@ -32,6 +32,8 @@
 #include <unistd.h>
 
 #include <pthread.h>
+#include <setjmp.h>
+#include <signal.h>
 
 #include <new>
 
@@ -530,6 +532,34 @@ bool push_possible(const BlockHeader* h) {
   return large_bar == 1;
 }
 
+// Does a host store reach the window?  The attribute says the BAR covers device memory; whether THIS process may
+// store through it (containers, IOMMU set-ups) is tried once per window with the fault handlers held: a word
+// goes in through the mapping and comes back through hipMemcpy.
+sigjmp_buf g_probe_jump;
+void probe_fault(int) { siglongjmp(g_probe_jump, 1); }
+bool window_takes_host_stores(char* window) {
+  struct sigaction trap, old_segv, old_bus;
+  memset(&trap, 0, sizeof(trap));
+  trap.sa_handler = probe_fault;
+  sigemptyset(&trap.sa_mask);
+  if (sigaction(SIGSEGV, &trap, &old_segv) != 0) return false;
+  if (sigaction(SIGBUS, &trap, &old_bus) != 0) { sigaction(SIGSEGV, &old_segv, nullptr); return false; }
+  bool stored = false;
+  if (sigsetjmp(g_probe_jump, 1) == 0) {
+    *reinterpret_cast<volatile uint64_t*>(window + 64) = 0x746f6e6963707573ull;
+    _mm_sfence();
+    stored = true;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr);
+  sigaction(SIGBUS, &old_bus, nullptr);
+  uint64_t back = 0;
+  if (!stored || hipMemcpy(&back, window + 64, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return back == 0x746f6e6963707573ull;
+}
+
 }  // namespace
 
 extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int32_t transport) {
@@ -604,6 +634,15 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
                                    hipDeviceMallocFinegrained)) != hipSuccess ||
         (e = hipMemset(c->window, 0, (size_t)h->total_bytes)) != hipSuccess ||
         (e = hipDeviceSynchronize()) != hipSuccess)
+      return fail("the device window of transport 3", e);
+    if (!window_takes_host_stores(c->window)) {        // (the pull transport serves everybody)
+      (void)hipFree(c->window);
+      c->window = nullptr;
+      c->transport = 2;
+    }
+  }
+  if (c->transport == 3) {
+    if ((e = hipMemset(c->window, 0, 4096)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)
       return fail("the device window of transport 3", e);
     h->push_pid = (int32_t)my_pid();
     __atomic_store_n(&h->push_window, (uint64_t)reinterpret_cast<uintptr_t>(c->window), __ATOMIC_RELEASE);
