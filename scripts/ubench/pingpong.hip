@@ -173,5 +173,7 @@ int main(int argc, char** argv) {
   printf("push %d blocks %d in %d B out %d B poll_host %d: median %.2f us p10 %.2f p90 %.2f (out[1]=%g)\n",
          push, blocks, words_in * 4, words_out * 4, poll_host, lat[100 + (steps - 100) / 2] * 1e6,
          lat[100 + (steps - 100) / 10] * 1e6, lat[100 + 9 * (steps - 100) / 10] * 1e6, out[1]);
+  printf("  tail: p99 %.2f us p99.9 %.2f max %.2f\n", lat[100 + (size_t)(0.99 * (steps - 100))] * 1e6,
+         lat[100 + (size_t)(0.999 * (steps - 100))] * 1e6, lat[steps - 1] * 1e6);
   return 0;
 }
