@@ -632,8 +632,8 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
     // whatever an L2 holds), zero = no command yet
     if ((e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->window), (size_t)h->total_bytes,
                                    hipDeviceMallocFinegrained)) != hipSuccess ||
-        (e = hipMemset(c->window, 0, (size_t)h->total_bytes)) != hipSuccess ||
-        (e = hipDeviceSynchronize()) != hipSuccess)
+        (e = hipMemsetAsync(c->window, 0, (size_t)h->total_bytes, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)     // (this stream only: other agents' streams may be held)
       return fail("the device window of transport 3", e);
     if (!window_takes_host_stores(c->window)) {        // (the pull transport serves everybody)
       (void)hipFree(c->window);
@@ -642,7 +642,8 @@ extern "C" int tonic_collector_create(tonic_collector_t** out, void* block, int3
     }
   }
   if (c->transport == 3) {
-    if ((e = hipMemset(c->window, 0, 4096)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)
+    if ((e = hipMemsetAsync(c->window, 0, 4096, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
       return fail("the device window of transport 3", e);
     h->push_pid = (int32_t)my_pid();
     __atomic_store_n(&h->push_window, (uint64_t)reinterpret_cast<uintptr_t>(c->window), __ATOMIC_RELEASE);
