@@ -246,6 +246,38 @@ def test_environments_ring_the_block_when_their_step_record_is_complete():
             env.close()
 
 
+def test_vectorcall_shim_is_the_same_entry_points(monkeypatch):
+    """tonic_amd/_fastcall (csrc/fastcall.c) binds the per-step tonic_collector_* entries without ctypes:
+    same C functions, same arguments, same status codes and the same bytes in the block — and the package
+    falls back to the ctypes prototypes with TONIC_AMD_FASTCALL=0."""
+    from tonic_amd import _lib
+    from tonic_amd.collector import Block
+    lib = _lib.load()
+    fast = _lib.hot('tonic_collector_synthetic_step')
+    assert type(fast).__name__ == 'builtin_function_or_method', 'tonic_amd/_fastcall*.so is not built'
+    rng = np.random.RandomState(3)
+    rows, actions = rng.standard_normal((7, 5)).astype(np.float32), rng.standard_normal((7, 2)).astype(np.float32)
+    one, two = Block(7, 5, 2), Block(7, 5, 2)
+    for block, call in ((one, fast), (two, lib.tonic_collector_synthetic_step)):
+        block.actions[:] = actions
+        assert call(block.address, rows.ctypes.data, None, False) == 0
+    for field in ('observations', 'next_observations', 'rewards'):
+        assert np.array_equal(getattr(one, field), getattr(two, field)), field
+    assert np.array_equal(one.rewards, -(actions * actions).sum(1, dtype=np.float32))
+    # explicit actions, a true `ring` with nothing armed, the error path of a bad block
+    assert fast(one.address, rows.ctypes.data, actions.ctypes.data, True) == 0
+    assert fast(None, rows.ctypes.data, None, False) == lib.tonic_collector_synthetic_step(None, rows.ctypes.data, None, 0) != 0
+    for name, args in (('tonic_collector_wait_actions', (None, 0.01)), ('tonic_collector_arm', (None, 0, 0, True)),
+                       ('tonic_collector_ppo_step', (None, 0, 0, False)), ('tonic_collector_ring', (one.address,))):
+        assert _lib.hot(name)(*args) == getattr(lib, name)(*args), name
+    with pytest.raises(TypeError):
+        fast(one.address, rows.ctypes.data)
+    monkeypatch.setattr(_lib, '_fast', False)
+    monkeypatch.setenv('TONIC_AMD_FASTCALL', '0')
+    assert _lib.hot('tonic_collector_ring') is lib.tonic_collector_ring
+    monkeypatch.setattr(_lib, '_fast', False)
+
+
 def test_late_rows_reach_the_logger_before_it_reduces_an_epoch():
     """An agent that stores part of an update late (PPO: the critic's rows, whose iterations run
     under the next rollout) registers with `logger.before_dump`: its rows must be stored before the

@@ -198,6 +198,27 @@ def load():
     return lib
 
 
+_fast = False          # False: not looked for yet; None: absent or switched off
+
+
+def hot(name):
+    """The binding of a per-environment-step entry point: the vectorcall shim tonic_amd/_fastcall*.so
+    (csrc/fastcall.c: ~0.1 us per call) when it has been built, else the ctypes prototype (0.35 - 0.6 us).
+    Same C entry, same arguments, same status codes either way; TONIC_AMD_FASTCALL=0 forces ctypes."""
+    global _fast
+    lib = load()
+    if _fast is False:
+        _fast = None
+        if os.environ.get('TONIC_AMD_FASTCALL', '1') != '0':
+            try:
+                from tonic_amd import _fastcall
+                _fastcall.bind(LIBRARY_PATH)
+                _fast = _fastcall
+            except ImportError:
+                pass
+    return getattr(_fast, name) if _fast is not None else getattr(lib, name)
+
+
 def check(status, what):
     if status != 0:
         msg = load().tonic_last_error().decode()

@@ -80,6 +80,7 @@ class Block:
         # before the instance dictionary (and with it the mmap) is released.
         self._handles = []
         self._collectors = {}
+        self._ring = _lib.hot('tonic_collector_ring')
         weakref.finalize(self, Block._release, self._handles, lib, os.getpid())
         Block._live.add(self)
 
@@ -139,7 +140,7 @@ class Block:
     def ring(self):
         """The step record is complete: issues the command the agent armed for this moment (if
         any).  An environment calls this once its observations, outcome and flags are in place."""
-        return self.lib.tonic_collector_ring(self.address)
+        return self._ring(self.address)
 
 
 class Collector:
@@ -154,10 +155,10 @@ class Collector:
         block._handles.append(self._cell)
         self.requested = transport
         self.transport = lib.tonic_collector_transport(handle)      # (what is in effect: wide -> 0, no window -> 2)
-        self._step = lib.tonic_collector_ppo_step          # bound once: the per-step hot calls
-        self._wait = lib.tonic_collector_wait_actions
-        self._arm = lib.tonic_collector_arm
-        self._claim = lib.tonic_collector_claim
+        self._step = _lib.hot('tonic_collector_ppo_step')          # bound once: the per-step hot calls
+        self._wait = _lib.hot('tonic_collector_wait_actions')
+        self._arm = _lib.hot('tonic_collector_arm')
+        self._claim = _lib.hot('tonic_collector_claim')
 
     @property
     def handle(self):

@@ -74,6 +74,7 @@ class SyntheticBatch:
         return self.random.standard_normal(shape).astype(np.float32)
 
     def start(self):
+        from tonic_amd import _lib
         from tonic_amd.collector import Block
         self.block = Block(self.workers, self.observation_space.shape[0],
                            self.action_space.shape[0])
@@ -85,7 +86,7 @@ class SyntheticBatch:
         self._flags_set = False
         self.block.observations[:] = self._observe()
         if self.pool:
-            self._synthetic_step = self.block.lib.tonic_collector_synthetic_step
+            self._synthetic_step = _lib.hot('tonic_collector_synthetic_step')
             self._block_address = self.block.address
             self._pool_rows = [row.ctypes.data for row in self._pool]      # (bound once: hot path)
         return self.block.observations.copy() if self.copy_outputs else self.block.out_observations
