@@ -913,7 +913,7 @@ def main():
     if os.environ.get('NCCL_DEBUG', 'VERSION').upper() == 'VERSION':
         os.environ['NCCL_DEBUG'] = 'WARN'
     import torch
-    from tonic_amd import parallel
+    from tonic_amd import _lib, parallel
     rank, world = parallel.init_from_env()
     if world != max(args.gpus, 1):
         sys.exit(f'bench.py --gpus {args.gpus} runs as {world} rank(s): the line would claim '
@@ -965,7 +965,9 @@ def main():
                    # the process (and the shared block's pages) on the NUMA node the GPU hangs off: a collect step
                    # is PCIe round trips with this process's memory (profiles/r05_numa.md; TONIC_AMD_NUMA_BIND=0: off)
                    'numa_bind': os.environ.get('TONIC_AMD_NUMA_BIND', '1') != '0',
-                   'process_was_moved_to_the_gpus_node': any(v is not None for v in parallel._bound.values())},
+                   'process_was_moved_to_the_gpus_node': any(v is not None for v in parallel._bound.values()),
+                   # how the per-environment-step C entries are bound (tonic_amd/_fastcall: csrc/fastcall.c)
+                   'per_step_binding': 'vectorcall shim' if getattr(_lib.hot('tonic_collector_ring'), '__module__', '') == 'tonic_amd._fastcall' else 'ctypes'},
         'learner_updates_per_sec': round(ITERATIONS * args.steps / main_run['elapsed'], 2),
         'actor_iterations_last_update': main_run['actor_iterations'],
     }
