@@ -757,7 +757,9 @@ def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, request, O, A,
         return out, under
 
     want, _ = rollout(0, False)
-    rollout(2, False)       # (the resident kernel once without company: its first launch in a process
+    # (3: the resident kernel with its inputs pushed where a step's observations fit the window's rule —
+    #  the 256- and 5-worker cases — and pulled, transport 2, at 1 280 workers: both are covered)
+    rollout(3, False)       # (the resident kernel once without company: its first launch in a process
     #                          loads code, which the steps beside the foreign kernel must not wait for)
     for attempt in range(4):
         # EVERY run beside the foreign kernel must give the undisturbed run's bits.  Whether the
@@ -765,7 +767,7 @@ def test_resident_kernel_runs_the_slots_of_absent_workgroups(lib, request, O, A,
         # choice (workgroups are placed in order, round-robin over the XCDs: when the FIRST one finds
         # its XCD full, none gets in before the foreign kernel leaves — seen in about one run in
         # three): required in one of at most four runs, reported for all.
-        got, under = rollout(2, True)
+        got, under = rollout(3, True)
         seen.append(under)
         for key, value in want.items():
             assert np.array_equal(got[key], value), (attempt, key)
@@ -846,7 +848,7 @@ def test_resident_kernel_under_random_foreign_bursts(lib, request, O, A, W, T):
 
     want, _ = rollout(0, False)
     for attempt in range(2):
-        got, launched = rollout(2, True)
+        got, launched = rollout(3, True)
         print('foreign kernels launched during the rollout:', launched)
         assert launched >= 5
         for key, value in want.items():
