@@ -246,6 +246,72 @@ def test_environments_ring_the_block_when_their_step_record_is_complete():
             env.close()
 
 
+def test_push_protocol_of_the_block_header_on_ordinary_memory():
+    """Collector transport 3 without a GPU: the header's `push_window` / `push_pid` (csrc/collector.hip) name a
+    window the OWNING process stores the step's observation rows and the command word into.  Here the window is
+    ordinary host memory: a ring in the owning process must put the rows there BEFORE the command and make the
+    block's own copy as well; with another owner recorded (what a forked worker group sees) the armed command must
+    stay where it is — for all three environments, the workers of `Parallel` included."""
+    import os
+    from tonic_amd import _lib, environments
+    lib = _lib.load()
+    O, A, W = 5, 2, 6
+    for kind in ('batch', 'sequential', 'parallel'):
+        if kind == 'batch':
+            env = environments.SyntheticBatch(W, O, A, max_episode_steps=50, pool=3)
+        else:
+            env = environments.distribute(lambda: environments.Synthetic(O, A, max_episode_steps=50),
+                                          2 if kind == 'parallel' else 1, W // 2 if kind == 'parallel' else W)
+        env.initialize(seed=1)
+        env.start()
+        block = env.block
+        head = np.frombuffer(block.memory, np.uint64, 512, 0)
+        head32 = np.frombuffer(block.memory, np.int32, 1024, 0)
+        # the `armed` and `command` words, found as test_environments_ring_the_block... finds them
+        armed_at = command_at = None
+        for slot in range(16, 512, 8):
+            if head[slot] != 0:
+                continue
+            before = head.copy()
+            head[slot] = (7 << 32) | 0x106
+            if lib.tonic_collector_ring(block.address) == 1:
+                armed_at = slot
+                command_at = [i for i in range(512) if head[i] != before[i] and head[i] == (7 << 32) | 0x106][0]
+                break
+            head[slot] = 0
+        head[command_at] = 0
+        window_at, pid_at = armed_at + 8, 2 * (armed_at + 8) + 2       # the next 64-byte line: u64 window, i32 pid
+        window = np.zeros(block.nbytes, np.uint8)
+        window_words = window.view(np.uint64)
+        obs_offset = lib.tonic_collector_block_offset(block.address, 1)
+        rows = lambda memory: np.frombuffer(memory, np.float32, W * O, obs_offset).reshape(W, O)
+        actions = block.out_actions if kind == 'batch' else np.zeros((W, A), np.float32)
+        # (1) this process owns the window
+        head[window_at] = window.ctypes.data
+        head32[pid_at] = os.getpid()
+        for t in range(3):
+            word = ((8 + t) << 32) | 0x206
+            head[armed_at] = word
+            observations, _ = env.step(actions)
+            assert head[armed_at] == 0 and head[command_at] == word, (kind, t)
+            assert window_words[command_at] == word, (kind, t)
+            assert np.array_equal(rows(window), block.observations), (kind, t)
+            assert np.array_equal(np.asarray(observations), block.observations), (kind, t)
+            assert block.observations.any()
+        # (2) somebody else's window: nothing may be issued from here, nothing stored through the address
+        head32[pid_at] = os.getpid() + 1
+        window[:] = 0
+        head[command_at] = 0
+        head[armed_at] = (20 << 32) | 0x206
+        env.step(actions)
+        assert head[armed_at] == (20 << 32) | 0x206 and head[command_at] == 0, kind
+        assert lib.tonic_collector_ring(block.address) == 0 and not window.any(), kind
+        head[armed_at] = 0
+        head[window_at] = 0
+        if hasattr(env, 'close'):
+            env.close()
+
+
 def test_vectorcall_shim_is_the_same_entry_points(monkeypatch):
     """tonic_amd/_fastcall (csrc/fastcall.c) binds the per-step tonic_collector_* entries without ctypes:
     same C functions, same arguments, same status codes and the same bytes in the block — and the package
