@@ -236,26 +236,26 @@ def kernel_rooflines(agent):
         gbs = 28.0 * t_steps * workers / (ms * 1e-3) / 1e9
         return dict(T=t_steps, W=workers, chunks=chunks, ms=round(ms, 4),
                     achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    # chunks: 1 = the bit-exact single chain per column (the Segment's default), 0 = the library's
-    # choice = 128-row segments in one pass below W = 65 536; cfg-2 (256), cfg-5 per GPU (1280),
-    # cfg-5 global (10 240) and the bandwidth-bound size SURVEY §8d asks for (65 536)
-    sweep = [gae_entry(T, W, 1), gae_entry(T, W, 0), gae_entry(T, 1280, 1), gae_entry(T, 1280, 0),
+    # chunks: 0 = the library's choice (the Segment's default since round 6) = 128-row segments in one pass below
+    # W = 65 536; 1 = the bit-exact single chain per column (TONIC_AMD_GAE_EXACT=1); cfg-2 (256), cfg-5 per GPU
+    # (1280), cfg-5 global (10 240) and the bandwidth-bound size SURVEY §8d asks for (65 536)
+    sweep = [gae_entry(T, W, 0), gae_entry(T, W, 1), gae_entry(T, 1280, 1), gae_entry(T, 1280, 0),
              gae_entry(T, 4096, 0), gae_entry(T, 10240, 1), gae_entry(T, 10240, 0),
              gae_entry(T, 65536, 1), gae_entry(T, 65536, 2)]
     top = max(sweep, key=lambda e: e['achieved'])
-    own = sweep[0]          # the metric's own size with the Segment's default (the bit-exact single chain)
-    roof_gae = dict(bound='hbm', kernel='gae_stream16_kernel (W = 256, bit-exact chain); sweep: '
-                                        'gae_onepass_kernel / gae_scan_kernel (+gae_stats_kernel)',
+    own = sweep[0]          # the metric's own size with the Segment's default (one pass, returns within 1e-5)
+    roof_gae = dict(bound='hbm', kernel='gae_onepass_kernel (W = 256, the Segment\'s default); sweep: '
+                                        'gae_stream16_kernel (bit-exact chain) / gae_scan_kernel (+gae_stats_kernel)',
                     achieved=own['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=own['frac'],
                     bytes_per_transition=28, at=dict(T=own['T'], W=own['W'], chunks=own['chunks']),
-                    one_pass_at_this_size=dict(achieved=sweep[1]['achieved'], frac=sweep[1]['frac']),
+                    exact_chain_at_this_size=dict(achieved=sweep[1]['achieved'], frac=sweep[1]['frac'],
+                                                  ms=sweep[1]['ms']),
                     sweep_top=dict(achieved=top['achieved'], frac=top['frac'],
                                    at=dict(T=top['T'], W=top['W'], chunks=top['chunks'])),
                     sweep=sweep, **pmc_traffic('gae_scan_kernel'),
                     note='the headline figure is the metric\'s own size (T=4096, W=256: 29 MB, inside '
-                         'the Infinity Cache, bound by the length of one dependent float32 chain per '
-                         'column, not by bandwidth); the kernel reaches its HBM fraction on the sweep '
-                         '(sweep_top: W = 65 536, 1.9 GB)')
+                         'the Infinity Cache: launch- and latency-bound, not bandwidth-bound); the kernel '
+                         'reaches its HBM fraction on the sweep (sweep_top: W = 65 536, 1.9 GB)')
     return roof, roof_critic, roof_gae
 
 

@@ -53,7 +53,9 @@ const char* tonic_last_error(void);
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
  * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries,  tonic_q_iteration_t.phase,
  * 9 = collector transport 3 + tonic_collector_transport)
- * and the gfx target the kernels were built for. */
+ * and the gfx target the kernels were built for.  TONIC_ABI_VERSION is what a binding was compiled against:
+ * tonic_amd/_fastcall (csrc/fastcall.c) and tonic_amd/_lib.py compare it with the loaded library's answer. */
+#define TONIC_ABI_VERSION 9
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -556,7 +558,7 @@ int tonic_adam_polyak_step(float* d_online, const float* d_grad_sums, float* d_e
  * Torsos other than the reference's (tonic/torch/models/utils.py:4-23 accepts any MLP(sizes, activation)): for
  *   the SAC / TD3 / DDPG entries — tonic_policy_forward, tonic_twin_q_grad, tonic_actor_q_grad, the three size
  *   queries below — `H` may be tonic_mlp_hidden(H1, H2, activation): two hidden layers of H1 and H2 units
- *   (1 .. 1023: the (400, 300) class), activation 1 = torch.nn.ReLU, 2 = Tanh, 3 = ELU; W2 is then [H2, H1],
+ *   (1 .. 4095: the (400, 300) class; a plain width — two ReLU layers of H units — is passed as is, any width), activation 1 = torch.nn.ReLU, 2 = Tanh, 3 = ELU; W2 is then [H2, H1],
  *   heads / w3 are H2 wide, same padding rules.  Such torsos run layer by layer (csrc/gemm16.hip) instead of in
  *   the fused kernels; tonic_q_iteration and the D4PG / MPO entries take plain widths only.
  */

@@ -360,6 +360,54 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B, support)
         np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)
 
 
+@pytest.mark.parametrize('kind', ['sac', 'td3'])
+def test_plain_torsos_of_1024_units_stay_on_the_hip_entries(lib, kind):
+    """two ReLU layers of 1024 units are a PLAIN width of the C ABI's `H` argument (tonic_mlp_hidden
+    packs only unequal / non-ReLU torsos, bit 30 set) and run on the HIP entries layer by layer (csrc/gemm16.hip)
+    — not on stock torch operators: `updater.stock is False`, and two learner iterations agree with the torch-CPU
+    oracle from identical parameters, buffer, indices and noise."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    import torch_port
+    from tonic_amd.environments import Box
+    assert lib.tonic_mlp_hidden(1024, 1024, 1) == 1024 and lib.tonic_mlp_hidden(400, 300, 1) & (1 << 30)
+    O, A, W, B, rows, hidden = 17, 6, 2, 64, 48, 1024
+    rng = np.random.RandomState(17)
+    relu = torch.nn.ReLU
+    head = (tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
+                                         distribution=tt.models.SquashedMultivariateNormalDiag)
+            if kind == 'sac' else tt.models.DeterministicPolicyHead())
+    model = tt.models.ActorTwinCriticWithTargets(
+        actor=tt.models.Actor(encoder=tt.models.ObservationEncoder(),
+                              torso=tt.models.MLP((hidden, hidden), relu), head=head),
+        critic=tt.models.Critic(encoder=tt.models.ObservationActionEncoder(),
+                                torso=tt.models.MLP((hidden, hidden), relu), head=tt.models.ValueHead()),
+        observation_normalizer=tt.normalizers.MeanStd())
+    replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=2, batch_size=B)
+    agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3)[kind](model=model, replay=replay)
+    agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+    assert agent.critic_updater.stock is False and agent.actor_updater.stock is False
+    assert agent.hidden == hidden
+    state = {'pre/' + k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    for t in range(rows):
+        replay.store(**{k: dev(v[t]) for k, v in host.items()})
+    host['discounts'] = port.buffer_discounts(host['terminations'] != 0, 0.99)
+    indices = replay.sample_indices()
+    eps = rng.normal(size=(2, 2 if kind == 'sac' else 1, B, A)).astype(np.float32)
+    oracle = torch_port.OffPolicyPort(kind, state, 'pre/')
+    want = oracle.update(host, W, indices, eps)
+    infos = agent.enqueue_update(indices, eps).cpu().numpy()
+    np.testing.assert_allclose(infos[0][:, 0], [i['critic']['loss'] for i in want], rtol=1e-5, atol=1e-5)
+    after = agent.model.state_dict()
+    for key, value in oracle.state().items():
+        got = after[key].detach().cpu().numpy() - state['pre/' + key]
+        np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)
+
+
 @pytest.mark.parametrize('kind,O,A,W,B,hidden', [
     ('sac', 111, 8, 1, 1024, 256), ('td3', 67, 21, 64, 100, 256), ('ddpg', 17, 6, 4, 100, 256),
     ('sac', 11, 3, 4, 24, 32), ('td3', 9, 4, 3, 37, 48), ('sac', 40, 30, 2, 50, 256),

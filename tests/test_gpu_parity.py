@@ -189,12 +189,18 @@ def critic_grad(lib, params, mean, std, obs, returns, variant=None, clip=0.0):
     return out.cpu().numpy(), P
 
 
-def assert_grads_close(got_sums, want_grads, n, what):
+GRAD_TOL = float(__import__('os').environ.get('TONIC_TEST_GRAD_TOL', '1e-5'))
+
+
+def assert_grads_close(got_sums, want_grads, n, what, tol=None):
+    """Gradient means against the oracle's: max |diff| <= tol x max |gradient| (+ 1e-7), tol = 1e-5 — the north
+    star's figure — unless a call site names its own (and says why)."""
     want = flat(want_grads).astype(np.float64)
     got = got_sums.astype(np.float64) / n
     err = np.abs(got - want).max()
     scale = np.abs(want).max()
-    assert err <= 2e-5 * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e}'
+    tol = GRAD_TOL if tol is None else tol
+    assert err <= tol * scale + 1e-7, f'{what}: max |diff| {err:.3e} vs max |grad| {scale:.3e} (tol {tol:g})'
 
 
 @pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
@@ -569,6 +575,96 @@ def test_fp16x2_layer_one_with_observations_of_mixed_magnitude(lib, features, we
         if weights == 'conditioned':
             assert errors[1][k] < 5e-6, errors
         assert errors[4][k] <= 2.0 * errors[1][k] + 1e-8, errors
+
+
+def _ppo_act(lib, params, obs, eps):
+    from tonic_amd import _lib
+    W, O = obs.shape
+    A = eps.shape[1]
+    actions, logp = torch.empty(W, A).cuda(), torch.empty(W).cuda()
+    ws = torch.empty(max(lib.tonic_ppo_workspace_bytes(W, O, A, 1), 16), dtype=torch.uint8).cuda()
+    keep = [dev(flat(params)), dev(obs), dev(eps)]
+    _lib.check(lib.tonic_ppo_act_wide(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                      actions.data_ptr(), logp.data_ptr(), W, O, A, ws.data_ptr(), ws.numel(),
+                                      None), 'act')
+    torch.cuda.synchronize()
+    return actions.cpu().numpy(), logp.cpu().numpy()
+
+
+def test_fp16x2_kernels_with_non_finite_and_out_of_range_observations(lib):
+    """What the shipped fp16x2 kernels do OUTSIDE the envelope the other tests cover — NaN, +-inf, |x| = 1e30
+    observations, a denormal W1 column — held to the reference's behaviour: a NaN observation gives NaN actions
+    (the reference propagates it and trips `assert not np.isnan(actions.sum())`, utils/trainer.py:45); for inf and
+    1e30 (where the reference's float32 chain saturates tanh and stays finite) a row is either what the oracle
+    computes or NaN — loud, never a finite wrong answer; rows next to such a row are untouched; a W1 column of
+    denormals (column equilibration clamps its exponent, Lds16::CX) costs nothing.  Gradient sums: one NaN
+    observation poisons the loss sum like torch's mean does; with the 1e30 rows the sums are the oracle's or NaN."""
+    rng = np.random.RandomState(47)
+    O, A, W = 17, 6, 256
+    params = [rng.normal(size=(64, O)) * 0.3, rng.normal(size=64) * 0.1, rng.normal(size=(64, 64)) * 0.15,
+              rng.normal(size=64) * 0.1, rng.normal(size=(1, A)) * 0.2, rng.normal(size=(A, 64)) * 0.1,
+              rng.normal(size=A) * 0.1]
+    params = [p.astype(np.float32) for p in params]
+    params[0][:, 5] = (rng.normal(size=64) * 1e-41).astype(np.float32)       # a denormal column
+    assert 0 < np.abs(params[0][:, 5]).max() < 1.2e-38
+    obs = rng.standard_normal((W, O)).astype(np.float32)
+    eps = rng.standard_normal((W, A)).astype(np.float32)
+    odd = {3: np.nan, 40: np.inf, 41: -np.inf, 77: 1e30, 130: -1e30, 200: 3e38}
+    for row, value in odd.items():
+        obs[row, row % O if row % O != 5 else 6] = value
+    with np.errstate(all='ignore'):
+        _, _, loc, scale, _ = port.ppo_actor_forward(params, obs)
+        want_actions = loc + scale * eps
+        want_logp = port.normal_log_prob(want_actions, loc, scale)
+    got_actions, got_logp = _ppo_act(lib, params, obs, eps)
+    ordinary = np.array([r not in odd for r in range(W)])
+    np.testing.assert_allclose(got_actions[ordinary], want_actions[ordinary], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got_logp[ordinary], want_logp[ordinary], rtol=1e-5, atol=1e-5)
+    assert np.isnan(got_actions[3]).all(), 'a NaN observation must give NaN actions (trainer.py:45)'
+    outcome = {}
+    for row in odd:
+        if row == 3:
+            continue
+        finite = np.isfinite(got_actions[row]).all()
+        if finite and np.isfinite(want_actions[row]).all():
+            np.testing.assert_allclose(got_actions[row], want_actions[row], rtol=0, atol=5e-6,
+                                       err_msg=f'row {row} ({odd[row]}): finite but not the reference\'s answer')
+        else:
+            assert np.isnan(got_actions[row]).any() or not np.isfinite(want_actions[row]).all(), (row, got_actions[row])
+        outcome[odd[row]] = 'as the reference' if finite else 'NaN'
+    print('observations outside the envelope -> actions:', outcome)
+    # gradient sums and values: NaN poisons the sums (torch's mean does), 1e30 rows: the oracle's sums or NaN
+    n = 16 * 8 * 4
+    obs_n = rng.standard_normal((n, O)).astype(np.float32)
+    actions = np.clip(rng.standard_normal((n, A)), -1, 1).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    returns = rng.standard_normal(n).astype(np.float32)
+    _, _, loc, scale, _ = port.ppo_actor_forward(params, obs_n)
+    old_lp = (port.normal_log_prob(actions, loc, scale) + rng.normal(size=n) * 0.1).astype(np.float32)
+    mean, std = np.zeros(O, np.float32), np.ones(O, np.float32)
+    cparams = params[:4] + [params[5][:1].copy(), params[6][:1].copy()]
+    stats = np.array([0, 1, 0, 0], np.float32)
+    for value in (np.nan, 1e30):
+        bad = obs_n.copy()
+        bad[100, 2] = value
+        got_a, P = actor_grad(lib, params, bad, actions, adv, stats, old_lp)
+        got_c, Pc = critic_grad(lib, cparams, mean, std, bad, returns)
+        if np.isnan(value):
+            assert np.isnan(got_a[P + 0]) and np.isnan(got_c[Pc + 0]), 'a NaN observation must poison the loss'
+            continue
+        with np.errstate(all='ignore'):
+            want_a, _ = port.clipped_ratio_grads(params, bad, actions, adv, old_lp)
+            want_c, _ = port.value_regression_grads(cparams, mean, std, bad, returns)
+        for got, want, count, what in ((got_a, want_a, P, 'actor'), (got_c, want_c, Pc, 'critic')):
+            want = flat(want).astype(np.float64)
+            if np.isfinite(got[:count]).all() and np.isfinite(want).all():
+                err = np.abs(got[:count].astype(np.float64) / n - want).max()
+                assert err <= 2e-5 * np.abs(want).max() + 1e-7, (what, err)
+                print(f'1e30 observation, {what} gradient sums: as the reference ({err:.2e})')
+            else:
+                assert not np.isfinite(got[:count]).all() or not np.isfinite(want).all()
+                print(f'1e30 observation, {what} gradient sums: non-finite (loud); reference finite: '
+                      f'{bool(np.isfinite(want).all())}')
 
 
 @pytest.mark.parametrize('variant', [1, 4])

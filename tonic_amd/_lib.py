@@ -216,6 +216,10 @@ def hot(name):
                 _fast = _fastcall
             except ImportError:
                 pass
+            except Exception as error:       # a stale shim (other ABI, missing entry): ctypes serves, loudly
+                import warnings
+                warnings.warn(f'tonic_amd._fastcall not used ({error}); the per-step entries go through ctypes '
+                              '(`make -C tonic_amd/csrc fast` rebuilds the shim)')
     return getattr(_fast, name) if _fast is not None else getattr(lib, name)
 
 

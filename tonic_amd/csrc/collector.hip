@@ -32,8 +32,6 @@
 #include <unistd.h>
 
 #include <pthread.h>
-#include <setjmp.h>
-#include <signal.h>
 
 #include <new>
 
@@ -156,9 +154,12 @@ void push_field(const BlockHeader* h, char* window, int f, int64_t bytes) {
 // observation rows go into the window first, a store fence keeps the write-combined stores in order, then
 // the command word follows them into the window.  (A stop command, bit 3, acts on nothing; rows_pushed: the
 // caller has put the observation rows into the window already.)
-void issue_command(BlockHeader* h, uint64_t word, bool rows_pushed = false) {
+// `window`: where the pushed copy goes — the ISSUING collector's own window for the owner-side calls
+// (issue_command_of: null for a pull collector, whose resident kernel polls the header — a second collector
+// on a block whose first one pushes must not write its commands, or its stop word, into the first one's
+// window: ADVICE r5), the header's window for the block-level ring of the environment's step.
+void issue_command(BlockHeader* h, uint64_t word, bool rows_pushed, char* window) {
   __atomic_store_n(&h->command, word, __ATOMIC_RELEASE);
-  char* window = push_window_of(h);
   if (window == nullptr) return;
   if ((word & 8u) == 0 && !rows_pushed)
     push_field(h, window, TONIC_COLLECTOR_OBSERVATIONS, h->W * h->O * 4);
@@ -177,7 +178,7 @@ int ring_armed(BlockHeader* h, bool rows_pushed = false) {
   const uint64_t word = __atomic_exchange_n(&h->armed, (uint64_t)0, __ATOMIC_ACQ_REL);
   if (word == 0) return 0;
   __atomic_store_n(&h->act_seq, (uint32_t)(word >> 32), __ATOMIC_RELEASE);
-  issue_command(h, word, rows_pushed);
+  issue_command(h, word, rows_pushed, push_window_of(h));
   return 1;
 }
 
@@ -386,6 +387,14 @@ namespace {
     }                                                                               \
   } while (0)
 
+// A command of collector `c` itself (step, stop): into ITS window if it pushes, else the header alone.
+void issue_command_of(tonic_collector* c, uint64_t word) {
+  char* window = c->window != nullptr && c->host->push_pid == (int32_t)my_pid() &&
+                         c->host->push_window == (uint64_t)reinterpret_cast<uintptr_t>(c->window)
+                     ? c->window : nullptr;
+  issue_command(c->host, word, false, window);
+}
+
 // Takes the armed command back.  1: the environment has issued it meanwhile — the step is in
 // flight and the handle's bookkeeping catches up; 0: it was never issued (or nothing was armed).
 int claim_armed(tonic_collector* c) {
@@ -533,31 +542,25 @@ bool push_possible(const BlockHeader* h) {
 }
 
 // Does a host store reach the window?  The attribute says the BAR covers device memory; whether THIS process may
-// store through it (containers, IOMMU set-ups) is tried once per window with the fault handlers held: a word
-// goes in through the mapping and comes back through hipMemcpy.
-sigjmp_buf g_probe_jump;
-void probe_fault(int) { siglongjmp(g_probe_jump, 1); }
+// store through it (containers, IOMMU set-ups) is tried once per window WITHOUT touching it from user space: the
+// kernel does the store — read() from a pipe into the window returns EFAULT where a user store would fault (no
+// signal handlers swapped under a multi-threaded process, no longjmp across threads: ADVICE r5) — and the word
+// comes back through hipMemcpy.
 bool window_takes_host_stores(char* window) {
-  struct sigaction trap, old_segv, old_bus;
-  memset(&trap, 0, sizeof(trap));
-  trap.sa_handler = probe_fault;
-  sigemptyset(&trap.sa_mask);
-  if (sigaction(SIGSEGV, &trap, &old_segv) != 0) return false;
-  if (sigaction(SIGBUS, &trap, &old_bus) != 0) { sigaction(SIGSEGV, &old_segv, nullptr); return false; }
-  bool stored = false;
-  if (sigsetjmp(g_probe_jump, 1) == 0) {
-    *reinterpret_cast<volatile uint64_t*>(window + 64) = 0x746f6e6963707573ull;
-    _mm_sfence();
-    stored = true;
-  }
-  sigaction(SIGSEGV, &old_segv, nullptr);
-  sigaction(SIGBUS, &old_bus, nullptr);
+  const uint64_t word = 0x746f6e6963707573ull;
+  int fd[2];
+  if (pipe(fd) != 0) return false;
+  bool stored = write(fd[1], &word, sizeof(word)) == (ssize_t)sizeof(word) &&
+                read(fd[0], window + 64, sizeof(word)) == (ssize_t)sizeof(word);
+  close(fd[0]);
+  close(fd[1]);
+  _mm_sfence();
   uint64_t back = 0;
   if (!stored || hipMemcpy(&back, window + 64, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  return back == 0x746f6e6963707573ull;
+  return back == word;
 }
 
 }  // namespace
@@ -663,7 +666,7 @@ extern "C" int tonic_collector_destroy(tonic_collector_t* c) {
   if (claim_armed(c)) (void)tonic_collector_wait_actions(c, 1.0);   // (issued by the environment)
   if (c->live) {                     // a stop command (nothing to store) ends the resident kernel
     c->seq += 1;
-    issue_command(c->host, ((uint64_t)c->seq << 32) | 8u);
+    issue_command_of(c, ((uint64_t)c->seq << 32) | 8u);
     c->live = false;
   }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -815,6 +818,10 @@ extern "C" int tonic_collector_arm(tonic_collector_t* c, int64_t row, int32_t ep
   // only a RESIDENT kernel can be commanded by somebody who cannot launch (a worker process)
   if (c->transport < 2 || !c->live || c->wide || (c->norm_acc != nullptr && !c->hist_loaded))
     return 0;
+  // the block-level ring pushes an armed command into the header's window: only the collector that owns
+  // that window may arm (a second collector on the block steps through its own calls: ADVICE r5)
+  const uint64_t block_window = __atomic_load_n(&c->host->push_window, __ATOMIC_ACQUIRE);
+  if (block_window != 0 && block_window != (uint64_t)reinterpret_cast<uintptr_t>(c->window)) return 0;
   push_noise(c, eps_slot);
   const uint64_t word = ((uint64_t)(c->seq + 1) << 32) | ((uint64_t)row << 8) |
                         (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
@@ -866,7 +873,7 @@ extern "C" int tonic_collector_ppo_step(tonic_collector_t* c, int64_t row, int32
                           (store_previous ? 4u : 0u) | (eps_slot >= 0 ? 2u : 0u) |
                           (eps_slot == 1 ? 1u : 0u);
     push_noise(c, eps_slot);
-    issue_command(c->host, word);
+    issue_command_of(c, word);
     c->waiting = true;
     return TONIC_OK;
   }
@@ -996,7 +1003,7 @@ extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_ro
     c->seq += 1;
     const uint64_t word = ((uint64_t)c->seq << 32) | ((uint64_t)(last_row + 1) << 8) |
                           (last_row >= 0 ? 4u : 0u) | 8u;
-    issue_command(c->host, word);
+    issue_command_of(c, word);
     c->waiting = true;
     const int status = tonic_collector_wait_actions(c, 60.0);
     if (status != TONIC_OK) return status;

@@ -20,5 +20,5 @@ void set_error(const char* fmt, ...) {
 extern "C" const char* tonic_last_error(void) { return tonic::g_error; }
 // 2: off-policy parameter blocks use the padded layout (tonic_mlp_weight_stride)
 // 3: pinned-host collector (tonic_collector_*)
-extern "C" int32_t tonic_abi_version(void) { return 9; }
+extern "C" int32_t tonic_abi_version(void) { return TONIC_ABI_VERSION; }
 extern "C" const char* tonic_target_arch(void) { return "gfx950"; }

@@ -17,6 +17,8 @@
 #include <dlfcn.h>
 #include <stdint.h>
 
+#include "../../include/tonic_hip.h"      /* TONIC_ABI_VERSION: the signatures below are this version's */
+
 typedef int (*synthetic_step_fn)(void*, const float*, const float*, int32_t);
 typedef int (*wait_actions_fn)(void*, double);
 typedef int (*arm_fn)(void*, int64_t, int32_t, int32_t);
@@ -42,6 +44,13 @@ static PyObject* bind(PyObject* self, PyObject* arg) {
   void* lib = dlopen(path, RTLD_NOW | RTLD_NOLOAD);        /* the copy ctypes loaded: nothing is loaded here */
   if (lib == NULL) {
     PyErr_Format(PyExc_RuntimeError, "%s is not loaded: tonic_amd._lib.load() comes first", path);
+    return NULL;
+  }
+  /* a shim built against another ABI would call the entries with the wrong arguments after a successful dlsym */
+  int32_t (*abi)(void) = (int32_t (*)(void))dlsym(lib, "tonic_abi_version");
+  if (abi == NULL || abi() != TONIC_ABI_VERSION) {
+    PyErr_Format(PyExc_RuntimeError, "%s has ABI %d, tonic_amd._fastcall was built for %d: make -C tonic_amd/csrc fast",
+                 path, abi ? (int)abi() : -1, TONIC_ABI_VERSION);
     return NULL;
   }
   p_synthetic_step = (synthetic_step_fn)dlsym(lib, "tonic_collector_synthetic_step");

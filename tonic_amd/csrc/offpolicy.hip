@@ -37,12 +37,13 @@ struct CriticShape {
   bool plain() const { return h2() == H && act == ACT_RELU; }
 };
 
-// The C ABI passes ONE int32 `H`: the width of a plain torso (below 1024), or tonic_mlp_hidden(H1, H2,
-// activation) = H1 | H2 << 10 | activation << 20 (widths below 1024; activation: GemmAct).
+// The C ABI passes ONE int32 `H`: the width of a plain torso (any width: bit 30 clear), or tonic_mlp_hidden(H1,
+// H2, activation) = 1 << 30 | H1 | H2 << 12 | activation << 24 (widths below 4096; activation: GemmAct).
+constexpr int32_t kHiddenPacked = 1 << 30;
 struct Hidden { int H1, H2, act; };
 inline Hidden unpack_hidden(int32_t code) {
-  Hidden h{code & 1023, (code >> 10) & 1023, (code >> 20) & 7};
-  if (code < 1024) h = Hidden{code, code, ACT_RELU};
+  if ((code & kHiddenPacked) == 0) return Hidden{code, code, ACT_RELU};
+  Hidden h{code & 4095, (code >> 12) & 4095, (code >> 24) & 7};
   if (h.H2 == 0) h.H2 = h.H1;
   if (h.act == 0) h.act = ACT_RELU;
   return h;
@@ -952,9 +953,9 @@ extern "C" int64_t tonic_q_critic_param_count(int32_t O, int32_t A, int32_t H) {
 // The `H` argument of the off-policy entries for a torso other than two ReLU layers of one width:
 // MLP((H1, H2), activation) with activation 1 = ReLU, 2 = Tanh, 3 = ELU (GemmAct).  -1: not representable.
 extern "C" int32_t tonic_mlp_hidden(int32_t H1, int32_t H2, int32_t activation) {
-  if (H1 < 1 || H1 > 1023 || H2 < 1 || H2 > 1023 || activation < ACT_RELU || activation > ACT_ELU) return -1;
+  if (H1 < 1 || H1 > 4095 || H2 < 1 || H2 > 4095 || activation < ACT_RELU || activation > ACT_ELU) return -1;
   if (H1 == H2 && activation == ACT_RELU) return H1;
-  return H1 | (H2 << 10) | (activation << 20);
+  return kHiddenPacked | H1 | (H2 << 12) | (activation << 24);
 }
 
 // Policy forward for acting / evaluation.  kind: 0 = deterministic tanh head (TD3,

@@ -124,6 +124,37 @@ def _parse_cpulist(text):
 
 
 _bound = {}
+_original_affinity = None       # the mask the process had before the first bind (restore_affinity puts it back)
+
+
+_holders = 0
+
+
+def hold_affinity():
+    """An agent that asked for the binding and will say when it is done with it (release_affinity)."""
+    global _holders
+    _holders += 1
+
+
+def release_affinity():
+    global _holders
+    _holders = max(_holders - 1, 0)
+    if _holders == 0:
+        restore_affinity()
+
+
+def restore_affinity():
+    """Undoes bind_near_gpu: the process (this thread and those started from now on) gets back the CPU mask it
+    had before the first agent bound it — the agents' close() gets here when the last agent that holds the
+    binding closes.  Threads and worker processes started while bound keep what they inherited."""
+    global _original_affinity
+    if _original_affinity is not None and hasattr(os, 'sched_setaffinity'):
+        try:
+            os.sched_setaffinity(0, _original_affinity)
+        except OSError:
+            pass
+    _original_affinity = None
+    _bound.clear()
 
 
 def bind_near_gpu(device):
@@ -133,7 +164,10 @@ def bind_near_gpu(device):
     second process — an environment step of 256 workers takes 13.0 us instead of 10.7 (profiles/r05_numa.md;
     the collector also moves the shared block's pages: tonic_collector_create).  One process per GPU binds to its
     own GPU's node, as launchers do with numactl.  No-op when the current affinity is already inside that node,
-    when the node is unknown, or with TONIC_AMD_NUMA_BIND=0.  Returns the CPUs bound to (None: nothing done)."""
+    when the node is unknown, or with TONIC_AMD_NUMA_BIND=0.  Returns the CPUs bound to (None: nothing done).
+    A process-wide side effect of building an agent, so it is said once on the log, and `restore_affinity()`
+    (called by the agents' close()) puts the original mask back."""
+    global _original_affinity
     index = device.index if device.index is not None else torch.cuda.current_device()
     if index in _bound:
         return _bound[index]
@@ -147,8 +181,14 @@ def bind_near_gpu(device):
         allowed = os.sched_getaffinity(0)
         target = local & allowed
         if target and not allowed <= local:
+            if _original_affinity is None:
+                _original_affinity = set(allowed)
             os.sched_setaffinity(0, target)
             _bound[index] = target
+            from tonic_amd.utils import logger
+            logger.log(f'tonic_amd: process bound to the {len(target)} CPUs of GPU {index}\'s NUMA node (of '
+                       f'{len(allowed)} allowed; TONIC_AMD_NUMA_BIND=0 leaves the affinity alone, '
+                       'agent.close() restores it)')
     except (OSError, ValueError, AttributeError):
         pass                                   # (no sysfs entry, a container without the right: stay put)
     return _bound[index]

@@ -340,6 +340,9 @@ class A2C(Agent):
     def initialize(self, observation_space, action_space, seed=None):
         super().initialize(seed=seed)
         self.device = _device()
+        if not getattr(self, '_holds_affinity', False):
+            self._holds_affinity = True
+            parallel.hold_affinity()
         self.lib = _lib.load()
         self.model.initialize(observation_space, action_space)       # CPU init: seed parity
         self.model.pack(self.device)
@@ -625,6 +628,9 @@ class A2C(Agent):
             self._collector = self._block = None
             self._speculated = self._eps_ahead = self._block_fed = False
             self._rollout_behind = None
+        if getattr(self, '_holds_affinity', False):
+            self._holds_affinity = False
+            parallel.release_affinity()            # (bind_near_gpu: the last agent to close restores the CPU mask)
 
     def test_step(self, observations, steps):
         self._open_gate()       # (the current stream waits for the critic's iterations: let them start)
@@ -1220,6 +1226,9 @@ class DDPG(Agent):
     def initialize(self, observation_space, action_space, seed=None):
         super().initialize(seed=seed)
         self.device = _device()
+        if not getattr(self, '_holds_affinity', False):
+            self._holds_affinity = True
+            parallel.hold_affinity()
         self.lib = _lib.load()
         self.model.initialize(observation_space, action_space)      # CPU init: seed parity
         self.model.pack(self.device)
@@ -1237,6 +1246,12 @@ class DDPG(Agent):
         self._workers = None
         self._policy_io = {}
         self._graph, self._static_key = None, None       # a re-initialised agent re-captures
+
+    def close(self):
+        """Gives back what the agent holds beyond its tensors (the process's CPU binding: parallel.bind_near_gpu)."""
+        if getattr(self, '_holds_affinity', False):
+            self._holds_affinity = False
+            parallel.release_affinity()
 
     # ------------------------------------------------------------------ acting
     def _forward_policy(self, observations, kind, stochastic):

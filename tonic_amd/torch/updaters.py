@@ -49,15 +49,20 @@ _TORSO_ACTIVATIONS = {torch.nn.Tanh: 1, torch.nn.ReLU: 2}
 def hip_ppo_torso(torso):
     """(layers, sizes as a ctypes int32 array, activation code) when the layer-by-layer HIP path
     (csrc/mlpwide.hip, the tonic_*_torso entries) serves this ``MLP(sizes, activation)``: 1 .. 4 hidden
-    layers of 4 .. 384 units (multiples of 4), Tanh or ReLU, no custom initialiser — None otherwise (and for
+    layers of 4 .. 256 units (multiples of 4), Tanh or ReLU, no custom initialiser — None otherwise (and for
     the default torso, which the fused kernels serve).  Every other torso runs the same arithmetic as stock
-    PyTorch-ROCm operators on the HBM-resident data (see `_StockTorch`)."""
+    PyTorch-ROCm operators on the HBM-resident data (see `_StockTorch`).  The entries themselves take layers
+    up to 384 units (tested), but beyond 256 a layer is several 64-output slices each re-reading its input
+    rows and rocBLAS wins — (384, 300) ReLU at N = 1 M: 41.4 ms vs 32.3 ms per learner iteration,
+    profiles/r05_torso_timing.txt — so the agents hand such torsos to the stock operators
+    (TONIC_AMD_TORSO_WIDE_HIP=1 keeps them on the HIP entries)."""
     import ctypes
     sizes = tuple(int(v) for v in torso.sizes)
     code = _TORSO_ACTIVATIONS.get(torso.activation)
     if fused_ppo_torso(torso) or code is None or not 1 <= len(sizes) <= 4:
         return None
-    if any(v < 4 or v > 384 or v % 4 for v in sizes):
+    widest = 384 if os.environ.get('TONIC_AMD_TORSO_WIDE_HIP', '0') == '1' else 256
+    if any(v < 4 or v > widest or v % 4 for v in sizes):
         return None
     if os.environ.get('TONIC_AMD_TORSO_STOCK', '0') == '1':      # (developer switch: A/B against stock torch)
         return None
@@ -637,7 +642,7 @@ def _torso_width(torso, generic=False):
     form catch it)."""
     sizes = tuple(int(v) for v in torso.sizes)
     plain = len(sizes) == 2 and sizes[0] == sizes[1] and torso.activation is torch.nn.ReLU
-    if plain and sizes[0] < 1024:          # (the C ABI's `H` carries widths below 1 024: tonic_mlp_hidden)
+    if plain:                              # (a plain width goes through the C ABI's `H` as is)
         return sizes[0]
     code = _Q_ACTIVATIONS.get(torso.activation)
     if (generic and len(sizes) == 2 and code is not None
