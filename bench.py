@@ -519,6 +519,76 @@ def offpolicy_rates(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, cpu=T
     return out
 
 
+def offpolicy_loop(kind='sac', o_dim=111, a_dim=8, batch=1024, workers=1, loop_iterations=2000, rows=1000000):
+    """BASELINE configs 3 / 4 on their own metric: env steps/s AND learner updates/s of the REAL loop
+    (tonic/utils/trainer.py:42-56: agent.step -> environment.step -> agent.update; ddpg.py:45-72,
+    explorations/noisy.py:15-47, replays/buffers.py:28-56,81-91) over the vectorised synthetic simulator — the
+    policy acts on every step (warm-up behind us: steps start at 100 000), every transition is stored in the
+    HBM Buffer (pre-filled: 1 M transitions), and an update of 50 batch iterations fires whenever
+    `steps_between_batches = 50` environment steps have passed (W = 1: every 50th loop iteration; W = 64: every
+    loop iteration — the reference's schedule).  `host_loop`: where a loop iteration goes outside the learner."""
+    import torch
+    from tonic_amd.environments import SyntheticBatch
+    iterations = 50
+    agent, replay = build_offpolicy(kind, o_dim, a_dim, batch, workers, iterations, rows)
+    env = SyntheticBatch(workers, o_dim, a_dim, max_episode_steps=1000, pool=64)
+    env.initialize(seed=3)
+    observations = env.start()
+    first = 100000
+    replay.last_steps = first
+    clock = time.perf_counter
+    learner = {'calls': 0, 'seconds': 0.0}
+    inner = agent._update
+
+    def timed_update(steps):
+        t0 = clock()
+        inner(steps)
+        learner['calls'] += 1
+        learner['seconds'] += clock() - t0
+    agent._update = timed_update
+
+    def run(count, steps, observations, parts=None):
+        for _ in range(count):
+            t0 = clock()
+            actions = agent.step(observations, steps)
+            t1 = clock()
+            observations, infos = env.step(actions)
+            t2 = clock()
+            agent.update(**infos, steps=steps)
+            if parts is not None:
+                parts += (t1 - t0, t2 - t1, clock() - t2)
+            steps += workers
+        return steps, observations
+    warm = max(2 * (50 // workers + 1), 8)                   # at least two updates: capture + one replay
+    steps, observations = run(warm, first, observations)
+    torch.cuda.synchronize()
+    learner.update(calls=0, seconds=0.0)
+    parts = np.zeros(3)
+    t0 = clock()
+    steps, observations = run(loop_iterations, steps, observations, parts)
+    torch.cuda.synchronize()
+    dt = clock() - t0
+    agent._update = inner
+    outside = dt - learner['seconds']
+    out = dict(
+        workload=f'{kind.upper()} O={o_dim} A={a_dim} workers={workers} B={batch}: agent.step -> environment.step -> '
+                 f'agent.update over SyntheticBatch, {loop_iterations} loop iterations, an update of {iterations} '
+                 f'iterations every {max(50 // workers, 1)} loop iteration(s), {rows} transitions resident in HBM',
+        env_steps_per_sec=round(loop_iterations * workers / dt, 1),
+        learner_updates_per_sec=round(learner['calls'] * iterations / dt, 1),
+        update_calls=learner['calls'], ms_per_update_call=round(learner['seconds'] / max(learner['calls'], 1) * 1e3, 3),
+        learner_share=round(learner['seconds'] / dt, 3),
+        host_loop=dict(us_per_env_step=round(outside / loop_iterations * 1e6, 2),
+                       agent_step_us=round(parts[0] / loop_iterations * 1e6, 2),
+                       env_step_us=round(parts[1] / loop_iterations * 1e6, 2),
+                       agent_update_us_without_learner=round((parts[2] - learner['seconds']) / loop_iterations * 1e6, 2),
+                       workers=workers))
+    close = getattr(agent, 'close', None)
+    if close is not None:
+        close()
+    return out
+
+
 class HostLoop:
     """The trainer's loop body (tonic/utils/trainer.py:44-56) over the vectorised synthetic
     simulator: agent.step -> environment.step -> agent.update, NumPy in / NumPy out."""
@@ -1068,12 +1138,15 @@ def main():
         torch.cuda.empty_cache()
         result['cfg1_plumbing'] = cfg1_plumbing()
         result['offpolicy_sac'] = offpolicy_rates()
+        # configs 3 / 4 on their own metric (env steps/s + learner updates/s of the whole loop, acting included)
+        result['offpolicy_sac']['loop'] = offpolicy_loop('sac', 111, 8, 1024, workers=1, loop_iterations=2000)
         # cfg 4 per-GPU share: TD3, humanoid-walk shapes, 64 of the 512 workers, the
         # reference's default batch of 100 and the batch of cfg 3
         result['offpolicy_td3'] = {}
         for b in (100, 1024):
             rates = offpolicy_rates('td3', 67, 21, b, workers=64, cpu=False)
             result['offpolicy_td3'][f'B={b}'] = dict(rates['hip_graph'], roofline=rates['roofline'])
+        result['offpolicy_td3']['loop'] = offpolicy_loop('td3', 67, 21, 100, workers=64, loop_iterations=300)
         # D4PG (51 atoms) and MPO (20 sampled actions per state) on the same shapes, default B=100
         for other in ('d4pg', 'mpo'):
             rates = offpolicy_rates(other, 67, 21, 100, workers=64, cpu=False)

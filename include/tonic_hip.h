@@ -52,10 +52,12 @@ const char* tonic_last_error(void);
  * 5 = tonic_collector_arm / _ring / _claim / _block_carry_over, `ring` argument of
  * tonic_collector_synthetic_step, 6 = `max_workgroups` argument of tonic_ppo_actor_grad /
  * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries,  tonic_q_iteration_t.phase,
- * 9 = collector transport 3 + tonic_collector_transport)
+ * 9 = collector transport 3 + tonic_collector_transport, 10 = tonic_q_iteration_t.refresh_images (fp16x2 weight
+ * images of the off-policy passes in the workspaces: tonic_offpolicy_workspace_bytes / tonic_q_iteration_workspace_bytes
+ * grow), tonic_mlp_hidden packs with bit 30 set (plain widths of any size pass as they are))
  * and the gfx target the kernels were built for.  TONIC_ABI_VERSION is what a binding was compiled against:
  * tonic_amd/_fastcall (csrc/fastcall.c) and tonic_amd/_lib.py compare it with the loaded library's answer. */
-#define TONIC_ABI_VERSION 9
+#define TONIC_ABI_VERSION 10
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -695,6 +697,14 @@ typedef struct tonic_q_iteration_t {
                                   caller steps the actor and the targets (tonic_adam_polyak_step).  In
                                   these phases the failure word is only ever SET (the caller clears it
                                   ahead of an update and looks at it after it)                         */
+  int32_t refresh_images;      /* The fused passes read their weights from fp16x2 operand-order IMAGES kept in the
+                                  workspace (csrc/mlpimg.h: two binary16 terms per weight in MFMA operand order;
+                                  products = three fp16 MFMAs, fp32 accumulation — float32-class accuracy).  The
+                                  float32 parameter blocks stay the authority: 1 = rebuild every image from them
+                                  first — on the first iteration of an update call and whenever parameters were
+                                  written by anything but this entry's own optimizer epilogues since the workspace
+                                  last served (the phases always rebuild); 0 = the images the previous iteration's
+                                  epilogues left (they follow every Adam / polyak write).                          */
 } tonic_q_iteration_t;
 
 int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);

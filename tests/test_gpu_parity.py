@@ -650,7 +650,10 @@ def test_fp16x2_kernels_with_non_finite_and_out_of_range_observations(lib):
         got_a, P = actor_grad(lib, params, bad, actions, adv, stats, old_lp)
         got_c, Pc = critic_grad(lib, cparams, mean, std, bad, returns)
         if np.isnan(value):
-            assert np.isnan(got_a[P + 0]) and np.isnan(got_c[Pc + 0]), 'a NaN observation must poison the loss'
+            # torch: min / clamp propagate NaN, so loss, KL and every gradient the sample touches are NaN
+            assert np.isnan(got_a[P + 0]) and np.isnan(got_a[P + 1]) and np.isnan(got_c[Pc + 0]), \
+                ('a NaN observation must poison the logged loss', got_a[P:], got_c[Pc:])
+            assert np.isnan(got_a[:P]).any() and np.isnan(got_c[:Pc]).any(), 'and the gradient sums'
             continue
         with np.errstate(all='ignore'):
             want_a, _ = port.clipped_ratio_grads(params, bad, actions, adv, old_lp)

@@ -34,7 +34,8 @@ class QIteration(ctypes.Structure):
                 ('critic_entropy_coeff', c_f64), ('actor_entropy_coeff', c_f64),
                 ('noise_scale', c_f64), ('noise_clip', c_f64), ('target_coeff', c_f64),
                 ('critic', QOptimizer), ('actor', QOptimizer),
-                ('d_workspace', c_vp), ('workspace_bytes', c_i64), ('phase', c_i32)]
+                ('d_workspace', c_vp), ('workspace_bytes', c_i64), ('phase', c_i32),
+                ('refresh_images', c_i32)]
 
 
 # name -> (restype, argtypes); mirrors include/tonic_hip.h one to one.
@@ -163,7 +164,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 9        # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 10       # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):

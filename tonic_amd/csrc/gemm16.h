@@ -23,6 +23,7 @@
 #pragma once
 #include <atomic>
 #include "common.h"
+#include "mlpimg.h"
 
 namespace tonic {
 
@@ -43,6 +44,7 @@ struct GemmArgs {
   int mask_act;          // the activation whose derivative the mask stands for (see mask)
   int accumulate;        // C += result instead of C = result
   float alpha;           // result scale (applied before bias)
+  ImgTarget img;         // TN + optimizer epilogue: the tensor's fp16x2 weight images (mlpimg.h; null pointers: none)
 };
 
 extern std::atomic<unsigned long long*> g_forward_stamps;    // developer probe, see tonic_debug_forward_stamps

@@ -466,6 +466,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
   }
   stamp(4);                                         // folded, optimizer operands requested
   // D layout: lane (column index i, group kg), register r <-> row index 4 kg + r of the MFMA tile
+  float newp[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, newt[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // -> the weight images
 #pragma unroll
   for (int jm = 0; jm < 2; ++jm) {
     const int m = m0 + 2 * (4 * kg + w) + jm;
@@ -493,6 +494,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
       const float p = adam_element(sum[e], pm[jm][0][e], mo, vo, fold, consts);
       out[0][e] = p; out[1][e] = mo; out[2][e] = vo;
       out[3][e] = pm[jm][3][e] * fold.polyak_keep + fold.polyak_mix * p;
+      newp[jm][e] = p; newt[jm][e] = out[3][e];
     }
     float* to[4] = {fold.params + off, fold.exp_avg + off, fold.exp_avg_sq + off, fold.target + off};
 #pragma unroll
@@ -502,6 +504,37 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
         *reinterpret_cast<f32x2_dword*>(to[q]) = f32x2_dword{out[q][0], out[q][1]};
       } else if (cb < g.N) {
         to[q][0] = out[q][0];
+      }
+    }
+  }
+  // ---- the tensor's fp16x2 weight images (mlpimg.h) follow the parameters: the two rows x two columns this
+  //      lane has just stepped — the forward image pairs them along the columns (k), the transposed one along
+  //      the rows; what lies beyond the tensor stays zero.  Same conversion as build_images_kernel -> same bits.
+  const ImgTarget& im = g.img;
+  if (stepping && (im.fwd != nullptr || im.bwd != nullptr)) {       // uniform
+    const int r_even = m0 + 2 * (4 * kg + w);
+    const int64_t zoff = z * im.stride;
+    if (im.fwd != nullptr && cb < g.N) {
+#pragma unroll
+      for (int jm = 0; jm < 2; ++jm) {
+        if (r_even + jm >= g.M) continue;
+        const bool second = cb + 1 < g.N;
+        img_store_pair(im.fwd + zoff, im.fwd_chunks, r_even + jm, cb, newp[jm][0], second ? newp[jm][1] : 0.f);
+        if (polyak)
+          img_store_pair(im.fwd + zoff + im.target_delta, im.fwd_chunks, r_even + jm, cb, newt[jm][0],
+                         second ? newt[jm][1] : 0.f);
+      }
+    }
+    if (im.bwd != nullptr && r_even < g.M) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = cb + e - im.bwd_col0;
+        if (cb + e >= g.N || k < 0 || k >= im.bwd_cols) continue;
+        const bool second = r_even + 1 < g.M;
+        img_store_pair(im.bwd + zoff, im.bwd_chunks, k, r_even, newp[0][e], second ? newp[1][e] : 0.f);
+        if (polyak)
+          img_store_pair(im.bwd + zoff + im.target_delta, im.bwd_chunks, k, r_even, newt[0][e],
+                         second ? newt[1][e] : 0.f);
       }
     }
   }
@@ -607,6 +640,55 @@ int launch_gemm_group(char mode_a, char mode_b, const GemmArgs* list, int count,
   }
 #undef TONIC_GEMM_LAUNCH
   TONIC_CHECK_LAUNCH("gemm16_group");
+  return TONIC_OK;
+}
+
+// ------------------------------------------------------------------------------ weight images (mlpimg.h)
+// One workgroup = one (tile, k-chunk) block of one image, both terms: thread = (lane, pair of neighbouring k).
+__global__ __launch_bounds__(256) void build_images_kernel(ImgJobs J) {
+  int p = 0;
+  for (int q = 1; q < J.count; ++q) p += (int)blockIdx.x >= J.first[q] ? 1 : 0;
+  const ImgJob& j = J.job[p];
+  const int blk = (int)blockIdx.x - J.first[p];
+  const int c = blk % j.chunks, t = blk / j.chunks;
+  const int pair = threadIdx.x & 3, lane = threadIdx.x >> 2;
+  const int i = 16 * t + (lane & 15);                       // row of the A operand
+  const int kk = 32 * c + 8 * (lane >> 4) + 2 * pair;       // its (even) k
+  float w0 = 0.f, w1 = 0.f;
+  if (!j.transposed) {
+    if (i < j.rows) {
+      const float* row = j.src + (int64_t)i * j.ld;
+      if (kk < j.cols) w0 = row[kk];
+      if (kk + 1 < j.cols) w1 = row[kk + 1];
+    }
+  } else if (i < j.ncols) {
+    const float* col = j.src + j.col0 + i;
+    if (kk < j.rows) w0 = col[(int64_t)kk * j.ld];
+    if (kk + 1 < j.rows) w1 = col[(int64_t)(kk + 1) * j.ld];
+  }
+  unsigned hi, lo;
+  img_terms(w0, w1, hi, lo);
+  char* at = j.dst + ((int64_t)blk * 2 * 64 + lane) * 16 + 4 * pair;
+  *reinterpret_cast<unsigned*>(at) = hi;
+  *reinterpret_cast<unsigned*>(at + kImgTermBytes) = lo;
+}
+
+void ImgBuild::add(const float* src, int ld, int rows, int cols, char* block, ImgView v, bool transposed,
+                   int col0, int ncols) {
+  if (jobs.count >= kImgJobsMax) { jobs.count = kImgJobsMax + 1; return; }     // (launch_build_images refuses)
+  ImgJob& j = jobs.job[jobs.count];
+  j.src = src; j.ld = ld; j.rows = rows; j.cols = cols;
+  j.transposed = transposed ? 1 : 0; j.col0 = col0; j.ncols = ncols;
+  j.dst = block + v.off; j.tiles = v.tiles; j.chunks = v.chunks;
+  jobs.first[jobs.count + 1] = jobs.first[jobs.count] + v.tiles * v.chunks;
+  jobs.count += 1;
+}
+
+int launch_build_images(const ImgBuild& b, hipStream_t stream) {
+  TONIC_REQUIRE(b.jobs.count >= 1 && b.jobs.count <= kImgJobsMax, TONIC_ERR_INVALID_ARGUMENT,
+                "build_weight_images: %d conversions", b.jobs.count);
+  hipLaunchKernelGGL(build_images_kernel, dim3(b.jobs.first[b.jobs.count]), dim3(256), 0, stream, b.jobs);
+  TONIC_CHECK_LAUNCH("build_images_kernel");
   return TONIC_OK;
 }
 

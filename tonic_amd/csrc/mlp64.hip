@@ -485,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp64_grad_kernel(MlpAr
       const bool plain = a.plain != 0;                            // StochasticPolicyGradient
       const float g = (valid && (plain || !dead)) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
       if (counted) {
-        st0 += plain ? -(adv * logp) : -fminf(surr1, surr2);
+        st0 += plain ? -(adv * logp) : -(surr2 < surr1 ? surr2 : surr1);   // torch.min: a NaN ratio stays NaN (fminf drops it)
         st1 += old_lp - logp;
         st2 += (outside && !plain) ? 1.f : 0.f;
         st3 += 1.f;
@@ -898,6 +898,12 @@ extern "C" int tonic_set_tuning(const char* key, int32_t value) {
     g_q_chain = value;
     return TONIC_OK;
   }
+  if (strcmp(key, "q_images") == 0) {      // 0: the off-policy passes on float32 MFMAs from the parameter blocks
+    TONIC_REQUIRE(value == 0 || value == 1, TONIC_ERR_INVALID_ARGUMENT,
+                  "q_images must be 0 or 1, got %d", value);
+    g_q_images = value;
+    return TONIC_OK;
+  }
   if (strcmp(key, "gae_stream") == 0) {
     TONIC_REQUIRE(value >= 0 && value <= 4, TONIC_ERR_INVALID_ARGUMENT,
                   "gae_stream must be 0, 1, 2 (developer probe) or 3 (dword helpers), got %d", value);
@@ -918,6 +924,7 @@ extern "C" int tonic_get_tuning(const char* key, int32_t* value) {
   if (strcmp(key, "policy_tail") == 0) { *value = g_policy_tail; return TONIC_OK; }
   if (strcmp(key, "gae_stream") == 0) { *value = g_gae_stream; return TONIC_OK; }
   if (strcmp(key, "q_chain") == 0) { *value = g_q_chain; return TONIC_OK; }
+  if (strcmp(key, "q_images") == 0) { *value = g_q_images; return TONIC_OK; }
   set_error("tonic_get_tuning: unknown key '%s'", key);
   return TONIC_ERR_INVALID_ARGUMENT;
 }

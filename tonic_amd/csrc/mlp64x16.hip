@@ -959,7 +959,7 @@ __global__ __launch_bounds__(kWaves16 * 64, 2) void mlp64_grad16_kernel(MlpArgs 
         enter_unit(row_max16(fabsf(gl) * bsum * w3_bound));
         gl *= s_run;
       }
-      st0 += cw * (plain ? -(adv * logp) : -fminf(surr1, surr2));
+      st0 += cw * (plain ? -(adv * logp) : -(surr2 < surr1 ? surr2 : surr1));   // torch.min (actors.py:86): a NaN ratio stays NaN, fminf would drop it
       st1 += cw * (old_lp - logp);
       st2 += (counted && outside && !plain) ? 1.f : 0.f;
       st3 += cw;

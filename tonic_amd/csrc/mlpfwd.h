@@ -123,6 +123,7 @@ struct MlpFwdArgs {
                                 //   exchange lines, see ValueLines; null: none
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
+  FwdImages img;                // img.block != null: the products run on fp16x2 terms from weight images (mlpimg.h)
   // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
   // the second input — has a tail of its own with its own outputs (the fused learner iteration
   // runs the policy passes of the critic step AND of the actor step as one launch: SAC the online
@@ -178,6 +179,7 @@ struct MlpBwdArgs {
   float hb_alpha;
   unsigned* exchange_failed;    // chained launches: l_tq / l_q / hb_dxa* are exchange words (exchange_read), dxa is
                                 //   written with exchange_write; the word a reader sets when a value never came
+  BwdImages img;                // img.block != null: the products run on fp16x2 terms from weight images (mlpimg.h)
 };
 enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 
@@ -287,6 +289,8 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream);
 int launch_q_actor_step(const QActorStep& c, hipStream_t stream);
 extern std::atomic<int> g_chain_fault;
 extern std::atomic<int> g_q_chain;          // tuning key "q_chain": 0 keeps one launch per pass
+extern std::atomic<int> g_q_images;         // tuning key "q_images": 0 keeps the float32 passes (no weight images)
+bool mlp_image_pass_supported(int K1, int H);
 
 bool mlp_forward_supported(int H, int NH, int heads);
 bool mlp_policy_tail_supported(int H, int NH);

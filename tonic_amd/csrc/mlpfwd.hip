@@ -14,6 +14,7 @@
 #include "mlpfwd.h"
 
 #include <atomic>
+#include <vector>
 
 namespace tonic {
 
@@ -205,6 +206,121 @@ struct Layer {
   }
 };
 
+// What follows a policy's heads (sampling / target noise / dense copy, the critics' input rows), for the 16 rows
+// of this workgroup: thread = (row, action slot).  The head outputs are in LDS at a.tail_offset
+// ([2 heads][16 rows][kPostPitch], written by the head waves).  Shared by the float32 pass and the image pass.
+__device__ __forceinline__ void policy_tail(const MlpFwdArgs& a, const bool second, const int r0, float* lds) {
+  const int tid = threadIdx.x;
+  const int post = second ? a.tail2.post : a.post;
+  const float* post_eps = second ? a.tail2.eps : a.post_eps;
+  float* post_actions = second ? a.tail2.actions : a.post_actions;
+  float* post_sigma = second ? a.tail2.sigma : a.post_sigma;
+  float* post_logp = second ? a.tail2.logp : a.post_logp;
+  const float* enc_obs = second ? a.tail2.enc_obs : a.enc_obs;
+  float* enc_out = second ? a.tail2.enc_out : a.enc_out;
+  const float* enc_obs2 = second ? nullptr : a.enc_obs2;
+  const float* enc_act2 = second ? nullptr : a.enc_act2;
+  float* enc_out2 = second ? nullptr : a.enc_out2;
+  // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
+  const int prow = tid >> 4, slot = tid & 15, A = a.NH;
+  const int64_t grow = r0 + prow;
+  const bool ok = grow < a.B;
+  // The encoder's operands (raw observations, statistics: lines nobody has touched in this launch)
+  // are requested FIRST — they fly over the barrier and the sampling arithmetic below.
+  const int O = a.enc_O;
+  const int64_t src = min(grow, (int64_t)a.B - 1);
+  const bool pair = enc_out2 != nullptr;
+  float x[8], y[8], mean[8], sdev[8];
+  if (enc_out != nullptr) {                           // scalar
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = min(16 * u + slot, O - 1);
+      x[u] = enc_obs[src * O + c];
+      y[u] = pair ? enc_obs2[src * O + c] : 0.f;
+      mean[u] = a.enc_mean[c];
+      sdev[u] = a.enc_std[c];
+    }
+  }
+  __syncthreads();
+  const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
+  const int padded = (A + 15) / 16 * 16;
+  // this thread's log-probability terms: actions slot, slot + 16, slot + 32, slot + 48
+  float term4[kPostPitch / 16] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < kPostPitch / 16; ++u) {
+    const int aa = slot + 16 * u;
+    if (aa >= padded) break;                          // scalar
+    float action = 0.f;
+    if (aa < A) {
+      const float first = headbuf[prow * kPostPitch + aa];
+      if (post == POST_SQUASHED_SAMPLE) {
+        const bool has_eps = post_eps != nullptr;
+        const float eps = (has_eps && ok) ? post_eps[grow * A + aa] : 0.f;
+        const SquashedSample sm =
+            squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
+        term4[u] = sm.logp_term;
+        if (ok) {
+          post_actions[grow * A + aa] = sm.action;
+          if (post_sigma != nullptr) post_sigma[grow * A + aa] = sm.sigma;
+        }
+        action = sm.action;
+      } else if (ok) {
+        action = post == POST_TARGET_NOISE
+                     ? noisy_target_action(first, post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
+                     : first;
+        post_actions[grow * A + aa] = action;
+      }
+      if (ok && enc_out != nullptr) {               // the critics' input: action columns
+        enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
+        if (enc_out2 != nullptr)
+          enc_out2[grow * a.enc_ld + a.enc_O + aa] = enc_act2[grow * A + aa];
+      }
+    }
+  }
+  if (enc_out != nullptr) {
+    // ... and the normalised observation columns, eight 16-column strips at a time (the first
+    // eight were requested above): all loads first, through clamped addresses (a load under a
+    // lane-predicated branch waits for itself)
+    for (int c0 = 0; c0 < O; c0 += 8 * 16) {
+      if (c0 > 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = min(c0 + 16 * u + slot, O - 1);
+          x[u] = enc_obs[src * O + c];
+          y[u] = pair ? enc_obs2[src * O + c] : 0.f;
+          mean[u] = a.enc_mean[c];
+          sdev[u] = a.enc_std[c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 16 * u + slot;
+        if (ok && c < O) {
+          enc_out[grow * a.enc_ld + c] =
+              __builtin_amdgcn_fmed3f((x[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
+          if (pair)
+            enc_out2[grow * a.enc_ld + c] =
+                __builtin_amdgcn_fmed3f((y[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
+        }
+      }
+    }
+  }
+  if (post != POST_SQUASHED_SAMPLE || post_logp == nullptr) return;
+  // The fold of sac_sample_kernel, re-played on the registers of the row's 16 threads: there G
+  // lanes (G = sample_group(A) <= 32) hold one sample, lane j sums terms j, j + G, ... in turn,
+  // then a xor tree runs (lane j adds lane j ^ off).  Thread `slot` holds the terms of lanes slot
+  // and slot + 16 (and what the first loop adds to them): the tree's level 16 is one addition in
+  // the thread, the levels below are shuffles among the row's 16 lanes — the same additions with
+  // the same operands in the same order, no LDS, no second barrier.
+  const int G = sample_group(A);
+  float lo = term4[0], hi = term4[1];
+  if (slot + 32 < A) lo = lo + term4[2];              // (first loop: v[aa % 32] += v[aa], A > 32)
+  if (slot + 48 < A) hi = hi + term4[3];
+  float val = G == 32 ? lo + hi : lo;                 // (level 16)
+  for (int off = min(G, 16) >> 1; off >= 1; off >>= 1) val = val + __shfl_xor(val, off, 16);
+  if (slot == 0 && ok) post_logp[grow] = val;
+}
+
 // The pass of workgroup (bx, net): 16 batch rows of one network.  A kernel of its own
 // (mlp_forward_kernel) or one stage of q_chain_kernel.
 __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int net, const int bx,
@@ -232,15 +348,6 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
   // selects on a scalar condition, not indexing (a runtime index into the kernel arguments would
   // go to scratch)
   const int post = second ? a.tail2.post : a.post;
-  const float* post_eps = second ? a.tail2.eps : a.post_eps;
-  float* post_actions = second ? a.tail2.actions : a.post_actions;
-  float* post_sigma = second ? a.tail2.sigma : a.post_sigma;
-  float* post_logp = second ? a.tail2.logp : a.post_logp;
-  const float* enc_obs = second ? a.tail2.enc_obs : a.enc_obs;
-  float* enc_out = second ? a.tail2.enc_out : a.enc_out;
-  const float* enc_obs2 = second ? nullptr : a.enc_obs2;
-  const float* enc_act2 = second ? nullptr : a.enc_act2;
-  float* enc_out2 = second ? nullptr : a.enc_out2;
   const int64_t poff = net * a.stride_params + (second ? a.second_params : 0);
   const float* W1 = a.W1 + poff;
   const float* b1 = a.b1 + poff;
@@ -411,111 +518,10 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
   stamp(6);
   if (post == POST_NONE) return;                    // scalar
 
-  // ---- what follows the heads, for the 16 rows of this workgroup: thread = (row, action slot)
-  const int prow = tid >> 4, slot = tid & 15, A = a.NH;
-  const int64_t grow = r0 + prow;
-  const bool ok = grow < a.B;
-  // The encoder's operands (raw observations, statistics: lines nobody has touched in this launch)
-  // are requested FIRST — they fly over the barrier and the sampling arithmetic below.
-  const int O = a.enc_O;
-  const int64_t src = min(grow, (int64_t)a.B - 1);
-  const bool pair = enc_out2 != nullptr;
-  float x[8], y[8], mean[8], sdev[8];
-  if (enc_out != nullptr) {                           // scalar
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = min(16 * u + slot, O - 1);
-      x[u] = enc_obs[src * O + c];
-      y[u] = pair ? enc_obs2[src * O + c] : 0.f;
-      mean[u] = a.enc_mean[c];
-      sdev[u] = a.enc_std[c];
-    }
-  }
-  __syncthreads();
-  const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
-  const int padded = (A + 15) / 16 * 16;
-  // this thread's log-probability terms: actions slot, slot + 16, slot + 32, slot + 48
-  float term4[kPostPitch / 16] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < kPostPitch / 16; ++u) {
-    const int aa = slot + 16 * u;
-    if (aa >= padded) break;                          // scalar
-    float action = 0.f;
-    if (aa < A) {
-      const float first = headbuf[prow * kPostPitch + aa];
-      if (post == POST_SQUASHED_SAMPLE) {
-        const bool has_eps = post_eps != nullptr;
-        const float eps = (has_eps && ok) ? post_eps[grow * A + aa] : 0.f;
-        const SquashedSample sm =
-            squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
-        term4[u] = sm.logp_term;
-        if (ok) {
-          post_actions[grow * A + aa] = sm.action;
-          if (post_sigma != nullptr) post_sigma[grow * A + aa] = sm.sigma;
-        }
-        action = sm.action;
-      } else if (ok) {
-        action = post == POST_TARGET_NOISE
-                     ? noisy_target_action(first, post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
-                     : first;
-        post_actions[grow * A + aa] = action;
-      }
-      if (ok && enc_out != nullptr) {               // the critics' input: action columns
-        enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
-        if (enc_out2 != nullptr)
-          enc_out2[grow * a.enc_ld + a.enc_O + aa] = enc_act2[grow * A + aa];
-      }
-    }
-  }
-  if (enc_out != nullptr) {
-    // ... and the normalised observation columns, eight 16-column strips at a time (the first
-    // eight were requested above): all loads first, through clamped addresses (a load under a
-    // lane-predicated branch waits for itself)
-    for (int c0 = 0; c0 < O; c0 += 8 * 16) {
-      if (c0 > 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int c = min(c0 + 16 * u + slot, O - 1);
-          x[u] = enc_obs[src * O + c];
-          y[u] = pair ? enc_obs2[src * O + c] : 0.f;
-          mean[u] = a.enc_mean[c];
-          sdev[u] = a.enc_std[c];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = c0 + 16 * u + slot;
-        if (ok && c < O) {
-          enc_out[grow * a.enc_ld + c] =
-              __builtin_amdgcn_fmed3f((x[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
-          if (pair)
-            enc_out2[grow * a.enc_ld + c] =
-                __builtin_amdgcn_fmed3f((y[u] - mean[u]) / sdev[u], -a.enc_clip, a.enc_clip);
-        }
-      }
-    }
-  }
-  if (post != POST_SQUASHED_SAMPLE || post_logp == nullptr) return;
-  // The fold of sac_sample_kernel, re-played on the registers of the row's 16 threads: there G
-  // lanes (G = sample_group(A) <= 32) hold one sample, lane j sums terms j, j + G, ... in turn,
-  // then a xor tree runs (lane j adds lane j ^ off).  Thread `slot` holds the terms of lanes slot
-  // and slot + 16 (and what the first loop adds to them): the tree's level 16 is one addition in
-  // the thread, the levels below are shuffles among the row's 16 lanes — the same additions with
-  // the same operands in the same order, no LDS, no second barrier.
-  const int G = sample_group(A);
-  float lo = term4[0], hi = term4[1];
-  if (slot + 32 < A) lo = lo + term4[2];              // (first loop: v[aa % 32] += v[aa], A > 32)
-  if (slot + 48 < A) hi = hi + term4[3];
-  float val = G == 32 ? lo + hi : lo;                 // (level 16)
-  for (int off = min(G, 16) >> 1; off >= 1; off >>= 1) val = val + __shfl_xor(val, off, 16);
-  if (slot == 0 && ok) post_logp[grow] = val;
+  policy_tail(a, second, r0, lds);
   stamp(7);
 }
 
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
-  mlp_forward_body(a, blockIdx.y, blockIdx.x, lds);
-}
 
 // Fused input-gradient chain of the same networks (the backward of mlp_forward_kernel without the
 // weight gradients, which contract over the batch and go out as one grouped GEMM launch):
@@ -845,9 +851,22 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
   if (a.loss != LOSS_GIVEN && co == nullptr && bx == 0 && net == 0) mlp_loss_stats(a);
 }
 
+
+#include "mlpimg_body.h"
+
+// IMG: the passes on fp16x2 terms from weight images (mlpimg_body.h); else the float32 passes above.
+template <bool IMG>
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // float32: two [16][H + 4] images; IMG: img_lds
+  if constexpr (IMG) mlp_forward_body_img(a, blockIdx.y, blockIdx.x, lds);
+  else mlp_forward_body(a, blockIdx.y, blockIdx.x, lds);
+}
+
+template <bool IMG>
 __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];     // two [16][H + 4] images
-  mlp_backward_body(a, blockIdx.y, blockIdx.x, lds);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if constexpr (IMG) mlp_backward_body_img(a, blockIdx.y, blockIdx.x, lds, 0);
+  else mlp_backward_body(a, blockIdx.y, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------ chained passes (mlpfwd.h)
@@ -865,6 +884,7 @@ __device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b) {
                                                       //  next iteration's first launch clears it)
 }
 
+template <bool IMG>
 __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int roles = 2 * c.nets;
@@ -875,12 +895,15 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
     return;
   }
   if (c.lose_first_target != 0 && blockIdx.x == 0) return;    // test hook: a workgroup that never answers
-  mlp_forward_body(c.fwd, role, tile, lds);           // (its values -> the tile's exchange lines)
+  if constexpr (IMG) mlp_forward_body_img(c.fwd, role, tile, lds);
+  else mlp_forward_body(c.fwd, role, tile, lds);      // (its values -> the tile's exchange lines)
   if (role < c.nets) return;                          // a target
   __syncthreads();                                    // (the forward's LDS images are free)
-  mlp_backward_body(c.bwd, role - c.nets, tile, lds);
+  if constexpr (IMG) mlp_backward_body_img(c.bwd, role - c.nets, tile, lds, c.fwd.K1);
+  else mlp_backward_body(c.bwd, role - c.nets, tile, lds);
 }
 
+template <bool IMG>
 __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int roles = c.used + 1;
@@ -891,18 +914,26 @@ __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
     return;
   }
   if (role == c.used) {                               // the actor: both critics' action columns
-    mlp_backward_body(c.actor, 0, tile, lds);
+    if constexpr (IMG) mlp_backward_body_img(c.actor, 0, tile, lds, c.fwd.K1);
+    else mlp_backward_body(c.actor, 0, tile, lds);
     return;
   }
-  mlp_forward_body(c.fwd, role, tile, lds);
-  __syncthreads();
-  mlp_backward_body(c.bwd, role, tile, lds);          // (the twin's q; dxa -> the exchange area)
+  if constexpr (IMG) {
+    mlp_forward_body_img(c.fwd, role, tile, lds);
+    __syncthreads();
+    mlp_backward_body_img(c.bwd, role, tile, lds, c.fwd.K1);
+  } else {
+    mlp_forward_body(c.fwd, role, tile, lds);
+    __syncthreads();
+    mlp_backward_body(c.bwd, role, tile, lds);        // (the twin's q; dxa -> the exchange area)
+  }
 }
 
 }  // namespace
 
 std::atomic<int> g_policy_tail{1};
 std::atomic<int> g_q_chain{1};
+std::atomic<int> g_q_images{1};
 std::atomic<int> g_chain_fault{0};     // tuning key "chain_fault": the NEXT critic step loses its first workgroup (test hook)
 
 // The tail's three [16][kPostPitch] images live in the first hidden image where they fit (H >= 188:
@@ -924,6 +955,26 @@ static std::atomic<unsigned> g_forward_launches{0};
 extern "C" int tonic_debug_forward_stamps(uint64_t* d_stamps) {
   g_forward_stamps.store(reinterpret_cast<unsigned long long*>(d_stamps));
   g_forward_launches.store(0);
+  return TONIC_OK;
+}
+
+// The image passes' LDS (img_lds) can exceed the 64 KB a kernel gets by default: raised once per kernel.
+static bool image_pass_supported(int K1, int H) {
+  return H >= 16 && H <= 16 * 4 * kMaxTiles && H % 16 == 0 && K1 >= 0 && img_lds(K1, H).total <= kImgLdsCap;
+}
+bool mlp_image_pass_supported(int K1, int H) { return image_pass_supported(K1, H); }
+
+template <typename Kernel>
+static int allow_image_lds(Kernel kernel, const char* what) {
+  static thread_local std::vector<const void*> configured;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  for (const void* known : configured) if (known == fn) return TONIC_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kImgLdsCap);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d B LDS): %s", what, kImgLdsCap, hipGetErrorString(e));
+    return TONIC_ERR_LAUNCH;
+  }
+  configured.push_back(fn);
   return TONIC_OK;
 }
 
@@ -967,8 +1018,20 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
   if (unsigned long long* base = g_forward_stamps.load()) {      // developer probe: ring of 8 launches
     launch.stamps = base + 16 * (g_forward_launches.fetch_add(1) % 8);
   }
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
-                     stream, launch);
+  if (a.img.block != nullptr) {
+    TONIC_REQUIRE(image_pass_supported(a.K1, a.H), TONIC_ERR_INVALID_ARGUMENT,
+                  "mlp_forward: K1=%d H=%d outside the image pass", a.K1, a.H);
+    const ImgLds L = img_lds(a.K1, a.H);
+    launch.tail_offset = L.off_f32 / 4;
+    launch.stamps = nullptr;
+    const int status = allow_image_lds(mlp_forward_kernel<true>, "mlp_forward_kernel");
+    if (status != TONIC_OK) return status;
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), L.total,
+                       stream, launch);
+  } else {
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
+                       stream, launch);
+  }
   TONIC_CHECK_LAUNCH("mlp_forward_kernel");
   return TONIC_OK;
 }
@@ -992,8 +1055,17 @@ int launch_mlp_backward(const MlpBwdArgs& a, int nets, hipStream_t stream) {
                 a.heads, a.NH);
   const size_t lds = (2 * (size_t)kRows * (a.H + 4) +
                       (a.hb_dxa0 != nullptr ? 2 * (size_t)kRows * kHeadPitch : 0)) * sizeof(float);
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
-                     stream, a);
+  if (a.img.block != nullptr) {
+    TONIC_REQUIRE(image_pass_supported(0, a.H), TONIC_ERR_INVALID_ARGUMENT,
+                  "mlp_backward: H=%d outside the image pass", a.H);
+    const int status = allow_image_lds(mlp_backward_kernel<true>, "mlp_backward_kernel");
+    if (status != TONIC_OK) return status;
+    hipLaunchKernelGGL(mlp_backward_kernel<true>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256),
+                       img_lds(0, a.H).total, stream, a);
+  } else {
+    hipLaunchKernelGGL(mlp_backward_kernel<false>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
+                       stream, a);
+  }
   TONIC_CHECK_LAUNCH("mlp_backward_kernel");
   return TONIC_OK;
 }
@@ -1013,8 +1085,18 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
   const int tiles = (f.B + kRows - 1) / kRows;
   QCriticStep launch = c;
   launch.lose_first_target = g_chain_fault.exchange(0);      // (one launch, then off again)
-  hipLaunchKernelGGL(q_critic_step_kernel, dim3(tiles * 2 * c.nets + 1), dim3(256),
-                     chain_lds_bytes(f.H), stream, launch);
+  const bool images = f.img.block != nullptr;
+  TONIC_REQUIRE(images == (c.bwd.img.block != nullptr) && (!images || image_pass_supported(f.K1, f.H)),
+                TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: weight images for one half only (K1=%d H=%d)", f.K1, f.H);
+  if (images) {
+    const int status = allow_image_lds(q_critic_step_kernel<true>, "q_critic_step_kernel");
+    if (status != TONIC_OK) return status;
+    hipLaunchKernelGGL(q_critic_step_kernel<true>, dim3(tiles * 2 * c.nets + 1), dim3(256),
+                       img_lds(f.K1, f.H).total, stream, launch);
+  } else {
+    hipLaunchKernelGGL(q_critic_step_kernel<false>, dim3(tiles * 2 * c.nets + 1), dim3(256),
+                       chain_lds_bytes(f.H), stream, launch);
+  }
   TONIC_CHECK_LAUNCH("q_critic_step_kernel");
   return TONIC_OK;
 }
@@ -1032,8 +1114,19 @@ int launch_q_actor_step(const QActorStep& c, hipStream_t stream) {
                     mlp_backward_supported(f.H, c.actor.NH, c.actor.heads, c.actor.xa_count),
                 TONIC_ERR_INVALID_ARGUMENT, "q_actor_step: used=%d H=%d", c.used, f.H);
   const int tiles = (f.B + kRows - 1) / kRows;
-  hipLaunchKernelGGL(q_actor_step_kernel, dim3(tiles * (c.used + 1) + 1), dim3(256),
-                     chain_lds_bytes(f.H), stream, c);
+  const bool images = f.img.block != nullptr;
+  TONIC_REQUIRE(images == (c.bwd.img.block != nullptr) && images == (c.actor.img.block != nullptr) &&
+                    (!images || image_pass_supported(f.K1, f.H)),
+                TONIC_ERR_INVALID_ARGUMENT, "q_actor_step: weight images for some roles only (K1=%d H=%d)", f.K1, f.H);
+  if (images) {
+    const int status = allow_image_lds(q_actor_step_kernel<true>, "q_actor_step_kernel");
+    if (status != TONIC_OK) return status;
+    hipLaunchKernelGGL(q_actor_step_kernel<true>, dim3(tiles * (c.used + 1) + 1), dim3(256),
+                       img_lds(f.K1, f.H).total, stream, c);
+  } else {
+    hipLaunchKernelGGL(q_actor_step_kernel<false>, dim3(tiles * (c.used + 1) + 1), dim3(256),
+                       chain_lds_bytes(f.H), stream, c);
+  }
   TONIC_CHECK_LAUNCH("q_actor_step_kernel");
   return TONIC_OK;
 }

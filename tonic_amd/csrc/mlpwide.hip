@@ -491,7 +491,8 @@ __global__ __launch_bounds__(kWideThreads) void ppo_loss_kernel(PpoLossArgs a) {
     const bool dead = (ratio > a.clip_hi && adv > 0.f) || (ratio < a.clip_lo && adv < 0.f);
     const bool plain = a.plain != 0;
     const float gl = (plain || !dead) ? -(adv * (plain ? 1.f : ratio)) : 0.f;
-    st0 += plain ? -(double)(adv * logp) : -(double)fminf(adv * ratio, adv * clipped);
+    st0 += plain ? -(double)(adv * logp)
+                 : -(double)(adv * clipped < adv * ratio ? adv * clipped : adv * ratio);   // torch.min: NaN stays NaN
     st1 += (double)(old_lp - logp);
     st2 += (outside && !plain) ? 1.0 : 0.0;
     st3 += 1.0;

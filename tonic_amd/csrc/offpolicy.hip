@@ -683,6 +683,45 @@ GemmArgs gemm(const float* A, int lda, const float* B, int ldb, float* C, int ld
     if (rc__ != TONIC_OK) return rc__; \
   } while (0)
 
+// The fp16x2 weight images of a network (mlpimg.h): `block` = this network's (the first of `nets` critics,
+// the others `v.bytes` on), `target` = its polyak target's (where the optimizer epilogue keeps those up to date),
+// `second` = the images of a launch's second parameter set (critics_forward's params2).  Null block = float32 passes.
+struct ActorImg { char* block; char* target; ActorImages v; };
+struct CriticImg { char* block; char* target; char* second; CriticImages v; };
+
+// build_weight_images: every image of one actor / of `nets` critics from the float32 parameters
+void add_actor_images(ImgBuild& b, const float* params, ActorShape s, const ActorImg& img) {
+  const ActorBlock<const float> p(params, s);
+  b.add(p.W1, p.ld1, s.H, s.O, img.block, img.v.f1);
+  b.add(p.W2, p.ldH, s.H, s.H, img.block, img.v.f2);
+  b.add(p.W2, p.ldH, s.H, s.H, img.block, img.v.t2, true, 0, s.H);
+  for (int h = 0; h < s.heads; ++h) {
+    b.add(p.head_w(h), p.ldO, s.A, s.H, img.block, img.v.fh[h]);
+    b.add(p.head_w(h), p.ldO, s.A, s.H, img.block, img.v.th[h], true, 0, s.H);
+  }
+}
+void add_critic_images(ImgBuild& b, const float* params, CriticShape s, int nets, char* block,
+                       const CriticImages& v) {
+  const CriticOffsets o(s);
+  for (int z = 0; z < nets; ++z) {
+    const float* p = params + z * o.count;
+    char* at = block + z * v.bytes;
+    b.add(p + o.W1, o.ld1, s.H, s.O + s.A, at, v.f1);
+    b.add(p + o.W2, o.ldH, s.H, s.H, at, v.f2);
+    b.add(p + o.W2, o.ldH, s.H, s.H, at, v.t2, true, 0, s.H);
+    b.add(p + o.W1, o.ld1, s.H, s.O + s.A, at, v.t1a, true, s.O, s.A);
+  }
+}
+int64_t images_floats(int O, int A, int H, int heads) {
+  // [actor | target actor | two critics | two target critics], 256-byte slots
+  return 2 * round_up(actor_images(O, H, A, heads).bytes, 256) / 4 +
+         2 * round_up(2 * critic_images(O, A, H).bytes, 256) / 4;
+}
+bool images_serve(int O, int A, int H) {
+  return g_q_images.load() != 0 && H >= 16 && H <= 256 && H % 16 == 0 && A <= 64 &&
+         mlp_image_pass_supported(O + A, H);
+}
+
 // actor torso + heads: h1, h2 [Bp, H]; head h -> out_h [Bp, ldh] (pre-activation unless `tanh_head`)
 // What follows the heads (sampling / target noise / dense copy); folded into the forward launch
 // when the fused kernel can (then *tail_done = true), else the caller launches its own kernel.
@@ -703,7 +742,7 @@ struct PolicyTail {
 int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
                   hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr,
-                  int ldx = 0) {
+                  int ldx = 0, const ActorImg* img = nullptr) {
   ActorParams p(params, s);
   if (ldx <= 0) ldx = s.O;                      // dense observation rows unless told otherwise
   if (tail_done != nullptr) *tail_done = false;
@@ -719,6 +758,8 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.out[0] = head0; f.out[1] = s.heads == 2 ? head1 : head0; f.ldo = ldh;
     f.act[0] = tanh_head ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
     f.B = B; f.H = s.H; f.split = 1 << 30;
+    if (img != nullptr && img->block != nullptr)
+      f.img = FwdImages{img->block, img->v.f1, img->v.f2, {img->v.fh[0], img->v.fh[s.heads - 1]}, 0, 0};
     if (tail != nullptr && g_policy_tail != 0 && mlp_policy_tail_supported(s.H, s.A)) {
       f.post = tail->post; f.post_eps = tail->eps; f.post_actions = tail->actions;
       f.post_sigma = tail->sigma; f.post_logp = tail->logp;
@@ -753,7 +794,8 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
 // The fused form's arguments (mlp_forward_supported(H, 1, 1)); *launch_nets = networks in the launch.
 MlpFwdArgs critics_forward_args(const float* params, CriticShape s, int nets, const float* X,
                                 int ldx, int B, int Bp, float* h1, float* h2, float* q,
-                                const float* params2, const float* X2, int* launch_nets) {
+                                const float* params2, const float* X2, int* launch_nets,
+                                const CriticImg* img = nullptr) {
   const CriticOffsets o(s);
   const int HP = weight_ld(s.H);
   MlpFwdArgs f{};
@@ -773,12 +815,17 @@ MlpFwdArgs critics_forward_args(const float* params, CriticShape s, int nets, co
     f.X2 = X2;
     *launch_nets = 2 * nets;
   }
+  if (img != nullptr && img->block != nullptr) {
+    f.img = FwdImages{img->block, img->v.f1, img->v.f2, {ImgView{}, ImgView{}}, img->v.bytes, 0};
+    if (params2 != nullptr) f.img.second = (img->second - img->block) - (int64_t)nets * img->v.bytes;
+  }
   return f;
 }
 
 int critics_forward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                     int Bp, float* h1, float* h2, float* q, hipStream_t st,
-                    const float* params2 = nullptr, const float* X2 = nullptr) {
+                    const float* params2 = nullptr, const float* X2 = nullptr,
+                    const CriticImg* img = nullptr) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
   const int HP = s.hp(), H2 = s.h2();
@@ -786,7 +833,7 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
   if (s.plain() && mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
     int launch_nets = 0;
     const MlpFwdArgs f = critics_forward_args(params, s, nets, X, ldx, B, Bp, h1, h2, q, params2,
-                                              X2, &launch_nets);
+                                              X2, &launch_nets, img);
     return launch_mlp_forward(f, launch_nets, st);
   }
   if (params2 != nullptr) {            // unfused path: one pass per parameter set
@@ -825,7 +872,7 @@ struct StepLoss {
 // The one-launch chain's arguments (mlp_backward_supported(H, 1, 0, dxa ? A : 0)).
 MlpBwdArgs critics_chain_args(const float* params, CriticShape s, int nets, int B, int Bp,
                               const float* h1, const float* h2, float* dq, float* dh2, float* dh1,
-                              float* dxa, const StepLoss* loss) {
+                              float* dxa, const StepLoss* loss, const CriticImg* img = nullptr) {
   const CriticOffsets o(s);
   const int HP = weight_ld(s.H), ldxa = pad16(s.A);
   MlpBwdArgs b{};
@@ -843,6 +890,8 @@ MlpBwdArgs critics_chain_args(const float* params, CriticShape s, int nets, int 
   b.ldxa = ldxa;
   b.stride_params = o.count; b.stride_hidden = (int64_t)Bp * HP; b.stride_dq = Bp;
   b.stride_dxa = (int64_t)Bp * ldxa;
+  if (img != nullptr && img->block != nullptr)
+    b.img = BwdImages{img->block, img->v.t2, {ImgView{}, ImgView{}}, img->v.t1a, img->v.bytes};
   return b;
 }
 
@@ -850,7 +899,8 @@ MlpBwdArgs critics_chain_args(const float* params, CriticShape s, int nets, int 
 //   dw3[1,H] = dq^T h2, db3 = sum dq ; dW2[H,H] = dz2^T h1, db2 ; dW1[H,in] = dz1^T X, db1
 int critics_weight_gradients(CriticShape s, int nets, const float* X, int ldx, int B, int Bp,
                              const float* h1, const float* h2, const float* dq, const float* dh2,
-                             const float* dh1, float* grads, hipStream_t st, const AdamFold* fold) {
+                             const float* dh1, float* grads, hipStream_t st, const AdamFold* fold,
+                             const CriticImg* img = nullptr) {
   const CriticOffsets o(s);
   const int in = s.O + s.A;
   const int HP = s.hp(), H2 = s.h2();
@@ -865,13 +915,22 @@ int critics_weight_gradients(CriticShape s, int nets, const float* X, int ldx, i
   w[2] = gemm(dh1, HP, X, ldx, grads + o.W1, o.ld1, s.H, in, B);
   w[2].colsum = grads + o.b1; w[2].strideColsum = o.count;
   w[2].strideA = hs; w[2].strideC = o.count;
+  if (fold != nullptr && img != nullptr && img->block != nullptr) {
+    // the optimizer epilogue keeps the stepped tensors' weight images (and their targets') up to date
+    const int64_t to_target = img->target != nullptr ? img->target - img->block : 0;
+    w[1].img = ImgTarget{img->block + img->v.f2.off, img->v.f2.chunks, img->block + img->v.t2.off,
+                         img->v.t2.chunks, 0, s.H, img->v.bytes, to_target};
+    w[2].img = ImgTarget{img->block + img->v.f1.off, img->v.f1.chunks, img->block + img->v.t1a.off,
+                         img->v.t1a.chunks, s.O, s.A, img->v.bytes, to_target};
+  }
   return launch_gemm_group('s', 's', w, 3, nets, st, fold);
 }
 
 int critics_backward(const float* params, CriticShape s, int nets, const float* X, int ldx, int B,
                      int Bp, const float* h1, const float* h2, float* dq, float* dh2,
                      float* dh1, float* grads, float* dxa, hipStream_t st,
-                     const StepLoss* loss = nullptr, const AdamFold* fold = nullptr) {
+                     const StepLoss* loss = nullptr, const AdamFold* fold = nullptr,
+                     const CriticImg* img = nullptr) {
   const CriticOffsets o(s);
   const bool one_launch = s.plain() && mlp_backward_supported(s.H, 1, 0, dxa ? s.A : 0);
   if (loss && !one_launch) {
@@ -890,7 +949,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
   GemmArgs g;
   // the input-gradient chain first ...
   if (one_launch) {                                               // ... in ONE launch
-    const MlpBwdArgs b = critics_chain_args(params, s, nets, B, Bp, h1, h2, dq, dh2, dh1, dxa, loss);
+    const MlpBwdArgs b = critics_chain_args(params, s, nets, B, Bp, h1, h2, dq, dh2, dh1, dxa, loss, img);
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
@@ -910,7 +969,7 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
     }
   }
   if (grads)       // ... then the three weight gradients in ONE launch
-    TRY(critics_weight_gradients(s, nets, X, ldx, B, Bp, h1, h2, dq, dh2, dh1, grads, st, fold));
+    TRY(critics_weight_gradients(s, nets, X, ldx, B, Bp, h1, h2, dq, dh2, dh1, grads, st, fold, img));
   return TONIC_OK;
 }
 
@@ -924,12 +983,36 @@ struct Workspace {
   }
 };
 
+// The six networks' image blocks, carved from the END of a workspace's takes (so that nothing else moves).
+struct ImageSet {
+  ActorImg actor, target_actor;
+  CriticImg critics, target_critics;       // (critics.second / .target = the targets and vice versa, as needed)
+  bool on;
+};
+ImageSet take_images(Workspace& ws, int O, int A, int H, int heads, bool on) {
+  ImageSet im{};
+  im.on = on;
+  if (!on) return im;
+  const ActorImages av = actor_images(O, H, A, heads);
+  const CriticImages cv = critic_images(O, A, H);
+  char* a0 = reinterpret_cast<char*>(ws.take(round_up(av.bytes, 256) / 4));
+  char* a1 = reinterpret_cast<char*>(ws.take(round_up(av.bytes, 256) / 4));
+  char* c0 = reinterpret_cast<char*>(ws.take(round_up(2 * cv.bytes, 256) / 4));
+  char* c1 = reinterpret_cast<char*>(ws.take(round_up(2 * cv.bytes, 256) / 4));
+  im.actor = ActorImg{a0, a1, av};
+  im.target_actor = ActorImg{a1, nullptr, av};
+  im.critics = CriticImg{c0, c1, nullptr, cv};
+  im.target_critics = CriticImg{c1, nullptr, c0, cv};
+  return im;
+}
+
 int64_t offpolicy_workspace_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = hidden_pitch(H);
   // actor h1,h2 + 2 heads + act + sigma + logp ; X ; critics h1,h2,q,dq,dh2,dh1 (x2) ; dX ; dloc,dspre,dah2,dah1
   return 2 * Bp * HP + 2 * Bp * ldh + 2 * Bp * A + Bp + Bp * ldx + 2 * (4 * Bp * HP + 2 * Bp) +
          Bp * ldx + 2 * Bp * ldh + 2 * Bp * HP + 2 * Bp * ldh + 64 * 16 +
-         4 * Bp * HP + Bp * ldx + 4 * Bp;                 // second input + four-network forward
+         4 * Bp * HP + Bp * ldx + 4 * Bp +                // second input + four-network forward
+         (hidden_plain(H) ? images_floats(O, A, H, 2) : 0);     // the weight images (mlpimg.h)
 }
 
 }  // namespace
@@ -1046,6 +1129,18 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
 
   // ---- targets (no grad)
   const ActorShape as = actor_shape(O, H, A, kind == 1 ? 2 : 1);
+  // the fused passes' weight images (mlpimg.h), formed from the float32 parameters by THIS call: the policy's,
+  // the target critics' and the critics' — the same conversion as the fused iteration's, so the same bits
+  ImageSet im = take_images(ws, O, A, H, as.heads, hidden_plain(H) && images_serve(O, A, H) &&
+                                                    mlp_forward_supported(H, A, as.heads) &&
+                                                    mlp_backward_supported(H, 1, 0, 0));
+  if (im.on) {
+    ImgBuild build;
+    add_actor_images(build, d_policy_params, as, im.actor);
+    add_critic_images(build, d_critics, cs, nets, im.critics.block, im.critics.v);
+    add_critic_images(build, d_target_critics, cs, nets, im.target_critics.block, im.target_critics.v);
+    TRY(launch_build_images(build, st));
+  }
   // the policy's tail also encodes both critic inputs: (s', a') from its own actions -> X, the
   // stored (s, a) -> X2
   PolicyTail tail{};
@@ -1057,7 +1152,7 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
   tail.enc_out = X; tail.enc_out2 = X2; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_policy_params, as, d_next_observations, B, a_h1, a_h2, head0, head1, ldh,
-                    kind != 1, st, &tail, &tail_done));
+                    kind != 1, st, &tail, &tail_done, 0, im.on ? &im.actor : nullptr));
   if (tail_done) {
   } else if (kind == 0) {
     hipLaunchKernelGGL(td3_target_action_kernel, dim3((B * A + threads - 1) / threads),
@@ -1080,11 +1175,11 @@ extern "C" int tonic_twin_q_grad(int32_t kind, const float* d_policy_params,
                        clip_bound(norm_clip), X, B, O, A, ldx, d_observations, d_actions, X2);
   }
   TRY(critics_forward(d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
-                      d_critics, X2));
+                      d_critics, X2, im.on ? &im.target_critics : nullptr));
   const StepLoss td{LOSS_TD, d_rewards, d_discounts, tq, kind == 1 ? logp : (const float*)nullptr,
                     (float)entropy_coeff, q, d_grad_sums + nets * Pc};
   TRY(critics_backward(d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, d_grad_sums,
-                       nullptr, st, &td));
+                       nullptr, st, &td, nullptr, im.on ? &im.critics : nullptr));
   TONIC_CHECK_LAUNCH("tonic_twin_q_grad");
   return TONIC_OK;
 }
@@ -1098,7 +1193,7 @@ namespace {
 MlpBwdArgs actor_chain_args(const float* params, ActorShape as, int B, const float* a_h1,
                             const float* a_h2, const float* dloc, const float* dspre, int ldh,
                             float* da_h2, float* da_h1, float* dxa, int xa_first, int xa_count,
-                            const MlpBwdArgs* head_fold) {
+                            const MlpBwdArgs* head_fold, const ActorImg* img = nullptr) {
   const int H = as.H, A = as.A, HP = as.hp();
   ActorParams p(params, as);
   MlpBwdArgs b{};
@@ -1115,6 +1210,8 @@ MlpBwdArgs actor_chain_args(const float* params, ActorShape as, int B, const flo
     b.hb_act = head_fold->hb_act; b.hb_eps = head_fold->hb_eps; b.hb_sigma = head_fold->hb_sigma;
     b.hb_spre = head_fold->hb_spre; b.hb_sac = head_fold->hb_sac; b.hb_alpha = head_fold->hb_alpha;
   }
+  if (img != nullptr && img->block != nullptr && b.xa_count == 0)     // (no image of W1^T's columns for actors)
+    b.img = BwdImages{img->block, img->v.t2, {img->v.th[0], img->v.th[as.heads - 1]}, ImgView{}, 0};
   return b;
 }
 
@@ -1123,19 +1220,28 @@ MlpBwdArgs actor_chain_args(const float* params, ActorShape as, int B, const flo
 int actor_weight_gradients(ActorShape as, const float* X, int ldx, int B, const float* a_h1,
                            const float* a_h2, const float* dloc, const float* dspre, int ldh,
                            const float* da_h2, const float* da_h1, float* grads, hipStream_t st,
-                           const AdamFold* fold) {
+                           const AdamFold* fold, const ActorImg* img = nullptr) {
   const int H = as.H, A = as.A, HP = as.hp(), H2 = as.h2();
   const ActorBlock<float> gp(grads, as);               // the gradient sums share the layout
   GemmArgs w[4];
   int count = 0;
+  const bool images = fold != nullptr && img != nullptr && img->block != nullptr;
+  const int64_t to_target = images && img->target != nullptr ? img->target - img->block : 0;
   for (int h = 0; h < as.heads; ++h) {
     const float* dhead = h == 0 ? dloc : dspre;
     w[count] = gemm(dhead, ldh, a_h2, HP, gp.head_w(h), gp.ldO, A, H2, B);
+    if (images)
+      w[count].img = ImgTarget{img->block + img->v.fh[h].off, img->v.fh[h].chunks, img->block + img->v.th[h].off,
+                               img->v.th[h].chunks, 0, H2, 0, to_target};
     w[count++].colsum = gp.head_b(h);
   }
   w[count] = gemm(da_h2, HP, a_h1, HP, gp.W2, gp.ldH, H2, H, B);
+  if (images)
+    w[count].img = ImgTarget{img->block + img->v.f2.off, img->v.f2.chunks, img->block + img->v.t2.off,
+                             img->v.t2.chunks, 0, H, 0, to_target};
   w[count++].colsum = gp.b2;
   w[count] = gemm(da_h1, HP, X, ldx, gp.W1, gp.ld1, H, as.O, B);
+  if (images) w[count].img = ImgTarget{img->block + img->v.f1.off, img->v.f1.chunks, nullptr, 0, 0, 0, 0, to_target};
   w[count++].colsum = gp.b1;
   return launch_gemm_group('s', 's', w, count, 1, st, fold);
 }
@@ -1144,14 +1250,15 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
                           const float* a_h1, const float* a_h2, const float* dloc,
                           const float* dspre, int ldh, float* da_h2, float* da_h1, float* grads,
                           float* dxa, int xa_first, int xa_count, hipStream_t st,
-                          const MlpBwdArgs* head_fold = nullptr, const AdamFold* fold = nullptr) {
+                          const MlpBwdArgs* head_fold = nullptr, const AdamFold* fold = nullptr,
+                          const ActorImg* img = nullptr) {
   const int H = as.H, A = as.A, HP = as.hp(), H2 = as.h2();
   ActorParams p(params, as);
   GemmArgs g;
   // the input-gradient chain first: dz2 = (dloc Wloc [+ dspre Wscale]) * act'(h2) ; dz1
   if (as.plain() && mlp_backward_supported(H, A, as.heads, xa_count)) {
     const MlpBwdArgs b = actor_chain_args(params, as, B, a_h1, a_h2, dloc, dspre, ldh, da_h2, da_h1,
-                                          dxa, xa_first, xa_count, head_fold);
+                                          dxa, xa_first, xa_count, head_fold, img);
     TRY(launch_mlp_backward(b, 1, st));
   } else {
     for (int h = 0; h < as.heads; ++h) {
@@ -1170,7 +1277,7 @@ int actor_shaped_backward(const float* params, ActorShape as, const float* X, in
   }
   if (grads == nullptr) return TONIC_OK;
   return actor_weight_gradients(as, X, ldx, B, a_h1, a_h2, dloc, dspre, ldh, da_h2, da_h1, grads, st,
-                                fold);
+                                fold, img);
 }
 
 }  // namespace
@@ -1212,7 +1319,8 @@ int64_t q_iteration_floats(int B, int O, int A, int H) {
          + 2 * Bp * ldh + 2 * Bp * ldh              // dxa (two critics), dloc, dspre
          + 2 * Bp * HP                              // actor dz2, dz1
          + kChainSyncArea                           // the chained launches' failure word (first)
-         + (Bp / 16) * kExchangeTileFloats;         // their value lines
+         + (Bp / 16) * kExchangeTileFloats          // their value lines
+         + images_floats(O, A, H, 2);               // the six networks' weight images (mlpimg.h)
 }
 
 }  // namespace
@@ -1278,6 +1386,21 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   float* dh2 = ws.take(2 * hs); float* dh1 = ws.take(2 * hs);
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take(hs); float* da_h1 = ws.take(hs);
+  // the weight images of the six networks (mlpimg.h): rebuilt from the float32 parameters when the caller says
+  // they may have changed since this workspace last saw them (the first iteration of an update call; every call
+  // in phases, where the caller's own optimizer launches step the parameters), kept up to date by the optimizer
+  // epilogues of this call otherwise
+  ImageSet im = take_images(ws, O, A, H, heads, images_serve(O, A, H));
+  if (im.on && (a.refresh_images != 0 || phase != 0)) {
+    ImgBuild build;
+    add_actor_images(build, a.d_actor, as, im.actor);
+    add_actor_images(build, a.d_target_actor, as, im.target_actor);
+    add_critic_images(build, a.d_critics, cs, nets, im.critics.block, im.critics.v);
+    add_critic_images(build, a.d_target_critics, cs, nets, im.target_critics.block, im.target_critics.v);
+    TRY(launch_build_images(build, st));
+  }
+  const ActorImg* actor_img = im.on ? &im.actor : nullptr;
+  const CriticImg* critics_img = im.on ? &im.critics : nullptr;
 
   // ---- 1: the policy passes
   if (phase != 2) {
@@ -1313,6 +1436,11 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
       f.tail2.logp = kind == 1 ? logp : nullptr;
       f.tail2.enc_obs = a.d_observations; f.tail2.enc_out = X3;
     }
+    if (im.on) {
+      const ActorImg& pi = kind == 1 ? im.actor : im.target_actor;
+      f.img = FwdImages{pi.block, pi.v.f1, pi.v.f2, {pi.v.fh[0], pi.v.fh[heads - 1]}, 0,
+                        due ? im.actor.block - pi.block : 0};
+    }
     TRY(launch_mlp_forward(f, due ? 2 : 1, st));
   }
   // ---- 2: targets on (s', a') and online critics on (s, a)
@@ -1341,21 +1469,22 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     QCriticStep step{};
     int launch_nets = 0;
     step.fwd = critics_forward_args(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all,
-                                    q_all, a.d_critics, X2, &launch_nets);
+                                    q_all, a.d_critics, X2, &launch_nets, im.on ? &im.target_critics : nullptr);
     step.fwd.xq = xq;
-    step.bwd = critics_chain_args(a.d_critics, cs, nets, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, &td);
+    step.bwd = critics_chain_args(a.d_critics, cs, nets, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, &td,
+                                  critics_img);
     step.bwd.exchange_failed = failed;   // targets: lines 0, 1 of the tile; the online critics: lines 2, 3
     step.bwd.l_tq = xq; step.bwd.l_tq_at = ValueLines{32, kExchangeTileFloats};
     step.bwd.l_q = xq + 64; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
     step.nets = nets;
     TRY(launch_q_critic_step(step, st));
     TRY(critics_weight_gradients(cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
-                                 a.critic.d_grad_sums, st, critic_fold));
+                                 a.critic.d_grad_sums, st, critic_fold, critics_img));
   } else {
     TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
-                        a.d_critics, X2));
+                        a.d_critics, X2, im.on ? &im.target_critics : nullptr));
     TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
-                         a.critic.d_grad_sums, nullptr, st, &td, critic_fold));
+                         a.critic.d_grad_sums, nullptr, st, &td, critic_fold, critics_img));
   }
   if (!due || phase == 1) {
     TONIC_CHECK_LAUNCH("tonic_q_iteration");
@@ -1387,27 +1516,27 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     QActorStep step{};
     int launch_nets = 0;
     step.fwd = critics_forward_args(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, nullptr,
-                                    nullptr, &launch_nets);
+                                    nullptr, &launch_nets, critics_img);
     step.fwd.xq = xq + 128;              // the critics' q: lines 4, 5 of the tile
     step.bwd = critics_chain_args(a.d_critics, cs, used, B, Bp, c_h1, c_h2, dq, dh2, dh1, dxa,
-                                  &objective);
+                                  &objective, critics_img);
     step.bwd.exchange_failed = failed;
     step.bwd.l_q = xq + 128; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
     step.actor = actor_chain_args(a.d_actor, as, B, p_h1 + hs, p_h2 + hs, dloc,
-                                  kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, nullptr, 0, 0, &hb);
+                                  kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, nullptr, 0, 0, &hb, actor_img);
     step.actor.exchange_failed = failed;
     step.used = used;
     TRY(launch_q_actor_step(step, st));
     TRY(actor_weight_gradients(as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
                                kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
-                               st, actor_fold));
+                               st, actor_fold, actor_img));
   } else {
-    TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st));
+    TRY(critics_forward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, q, st, nullptr, nullptr, critics_img));
     TRY(critics_backward(a.d_critics, cs, used, X3, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr,
-                         dxa, st, &objective));
+                         dxa, st, &objective, nullptr, critics_img));
     TRY(actor_shaped_backward(a.d_actor, as, a.d_observations, O, B, p_h1 + hs, p_h2 + hs, dloc,
                               kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, a.actor.d_grad_sums,
-                              nullptr, 0, 0, st, &hb, actor_fold));
+                              nullptr, 0, 0, st, &hb, actor_fold, actor_img));
   }
   TONIC_CHECK_LAUNCH("tonic_q_iteration");
   return TONIC_OK;
@@ -1745,6 +1874,17 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   float* dxa = ws.take(2LL * Bp * ldh);         // action columns of the critics' input gradients
   float* dloc = ws.take((int64_t)Bp * ldh); float* dspre = ws.take((int64_t)Bp * ldh);
   float* da_h2 = ws.take((int64_t)Bp * HP); float* da_h1 = ws.take((int64_t)Bp * HP);
+  // the weight images of the actor and the critics (mlpimg.h), formed by this call (see tonic_twin_q_grad)
+  ImageSet im = take_images(ws, O, A, H, as.heads, hidden_plain(H) && images_serve(O, A, H) &&
+                                                    mlp_forward_supported(H, A, as.heads) &&
+                                                    mlp_backward_supported(H, A, as.heads, 0) &&
+                                                    mlp_backward_supported(H, 1, 0, A));
+  if (im.on) {
+    ImgBuild build;
+    add_actor_images(build, d_actor_params, as, im.actor);
+    add_critic_images(build, d_critics, cs, nets, im.critics.block, im.critics.v);
+    TRY(launch_build_images(build, st));
+  }
 
   PolicyTail tail{};                             // the tail also encodes the critics' input (s, a)
   tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = d_eps; tail.actions = act;
@@ -1754,7 +1894,7 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
   tail.enc_out = X; tail.enc_ld = ldx;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, as, d_observations, B, a_h1, a_h2, head0, head1, ldh,
-                    kind == 0, st, &tail, &tail_done));
+                    kind == 0, st, &tail, &tail_done, 0, im.on ? &im.actor : nullptr));
   if (tail_done) {
   } else if (kind == 0) {
     hipLaunchKernelGGL(copy_actions_kernel, dim3((B * A + threads - 1) / threads), dim3(threads),
@@ -1770,18 +1910,19 @@ extern "C" int tonic_actor_q_grad(int32_t kind, const float* d_actor_params,
                        0, st, d_observations, act, d_norm_mean, d_norm_std, clip_bound(norm_clip), X,
                        B, O, A, ldx);
   }
-  TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st));
+  TRY(critics_forward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, q, st, nullptr, nullptr,
+                      im.on ? &im.critics : nullptr));
   const StepLoss objective{LOSS_ACTOR, nullptr, nullptr, nullptr, logp, (float)entropy_coeff, q,
                            d_grad_sums + Pa};
   TRY(critics_backward(d_critics, cs, nets, X, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, dxa,
-                       st, &objective));
+                       st, &objective, nullptr, im.on ? &im.critics : nullptr));
   hipLaunchKernelGGL(actor_head_backward_kernel, dim3((B * A + threads - 1) / threads),
                      dim3(threads), 0, st, dxa, nets == 2 ? dxa + (int64_t)Bp * ldh : (float*)nullptr,
                      ldh, act, d_eps, sigma, head1, ldh,
                      (float)entropy_coeff, kind == 1 ? 1 : 0, dloc, dspre, B, A);
   TRY(actor_shaped_backward(d_actor_params, as, d_observations, O, B, a_h1, a_h2, dloc,
                             kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, d_grad_sums, nullptr,
-                            0, 0, st));
+                            0, 0, st, nullptr, nullptr, im.on ? &im.actor : nullptr));
   TONIC_CHECK_LAUNCH("tonic_actor_q_grad");
   return TONIC_OK;
 }

@@ -1573,7 +1573,10 @@ class DDPG(Agent):
                              self._static_adam[iteration, 0] if phase == 0 else None),
             actor=optimizer(actor, self._infos[1, iteration],
                             self._static_adam[iteration, 1] if phase == 0 else None),
-            d_workspace=p(ws), workspace_bytes=ws.numel(), phase=phase)
+            d_workspace=p(ws), workspace_bytes=ws.numel(), phase=phase,
+            # the workspace's fp16x2 weight images follow the optimizer epilogues INSIDE an update call; between
+            # calls anybody may have written parameters (load_state_dict, another path): rebuilt on iteration 0
+            refresh_images=int(iteration == 0 or phase != 0))
         _lib.check(self.lib.tonic_q_iteration(ctypes.byref(args), _lib.current_stream()),
                    'tonic_q_iteration')
 
