@@ -54,7 +54,7 @@ const char* tonic_last_error(void);
  * tonic_value_regression_grad, 7 = tonic_stream_gate, 8 = the tonic_*_torso entries, tonic_mlp_hidden, `min_log_dual` of the MPO entries,  tonic_q_iteration_t.phase,
  * 9 = collector transport 3 + tonic_collector_transport, 10 = tonic_q_iteration_t.refresh_images (fp16x2 weight
  * images of the off-policy passes in the workspaces: tonic_offpolicy_workspace_bytes / tonic_q_iteration_workspace_bytes
- * grow), tonic_mlp_hidden packs with bit 30 set (plain widths of any size pass as they are))
+ * grow), tonic_mlp_hidden packs with bit 30 set (plain widths of any size pass as they are), tonic_collector_q_act)
  * and the gfx target the kernels were built for.  TONIC_ABI_VERSION is what a binding was compiled against:
  * tonic_amd/_fastcall (csrc/fastcall.c) and tonic_amd/_lib.py compare it with the loaded library's answer. */
 #define TONIC_ABI_VERSION 10
@@ -711,6 +711,25 @@ int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32
 /* 1 when tonic_q_iteration serves these shapes (heads: 1 deterministic, 2 Gaussian policy) */
 int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads);
 int tonic_q_iteration(const tonic_q_iteration_t* iteration, void* stream);
+
+/* ---- off-policy acting on a collector block --------------------------------------------------------------
+ * replaces: tonic/torch/agents/ddpg.py:45-52 (`_greedy_actions`), sac.py:40-51 (`_stochastic_actions` /
+ *   `_greedy_actions`) for observations that the environment has written into a collector block (tonic_collector_*
+ *   above; tonic_amd.environments do): ONE launch on `stream` reads the block's W observation rows in place
+ *   (page-locked host memory), runs the policy of tonic_policy_forward (kind 0: deterministic tanh head, 1: squashed
+ *   Gaussian — eps_slot 0: the block's first noise field holds the host's standard-normal draws, -1: the greedy loc),
+ *   writes the actions into the block's SECOND noise field (TONIC_COLLECTOR_EPS1: host-visible) and one completion
+ *   word per 16 rows at system scope; tonic_collector_wait_actions is the wait.  d_rows_out [W, O] (may be NULL)
+ *   receives a device copy of the observation rows (Buffer.store of the transition runs after the environment's
+ *   step has overwritten the block's).  d_workspace: tonic_offpolicy_workspace_bytes(W, O, A, H).  The forward runs
+ *   on the actor's fp16x2 weight images (csrc/mlpimg.h; the input rows are fetched over PCIe in ONE round trip):
+ *   d_actor_images = tonic_mlp_actor_image_bytes(O, H, A, heads) bytes owned by the caller, rebuild_images = 1
+ *   whenever the parameters changed since the last call (after every learner update).  Shapes with 0 image bytes:
+ *   TONIC_ERR_UNSUPPORTED_SHAPE (callers keep tonic_policy_forward for those). */
+int64_t tonic_mlp_actor_image_bytes(int32_t O, int32_t H, int32_t A, int32_t heads);   /* 0: not served */
+int tonic_collector_q_act(tonic_collector_t* collector, const float* d_actor_params, void* d_actor_images,
+                          int32_t rebuild_images, int32_t kind, int32_t H, int32_t eps_slot, float* d_rows_out,
+                          void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- D4PG: distributional critic (tonic/torch/models/critics.py:23-66, agents/d4pg.py).
  *   The critic is an actor-shaped network on the encoded input [normalised observation | action]:

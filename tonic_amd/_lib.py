@@ -131,6 +131,8 @@ SIGNATURES = {
     'tonic_collector_ring': (ctypes.c_int, [c_vp]),
     'tonic_collector_block_carry_over': (ctypes.c_int, [c_vp, c_i32]),
     'tonic_collector_arm': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
+    'tonic_collector_q_act': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    'tonic_mlp_actor_image_bytes': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'tonic_collector_claim': (ctypes.c_int, [c_vp]),
     'tonic_collector_worker_wait': (c_i64, [c_vp, c_i64, c_f64]),
     'tonic_collector_worker_done': (ctypes.c_int, [c_vp]),

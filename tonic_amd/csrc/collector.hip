@@ -36,6 +36,7 @@
 #include <new>
 
 #include "collect16.h"
+#include "collector_q.h"
 
 namespace tonic {
 namespace {
@@ -374,6 +375,7 @@ struct tonic_collector {
   double park_us;
   unsigned long long* d_stamps;   // developer probe (TONIC_AMD_COLLECTOR_STAMPS=1)
   unsigned long long launches, relaunches;
+  int q_words;                    // > 0: the step in flight is an off-policy acting launch with that many completion words
 };
 
 namespace {
@@ -924,7 +926,7 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
   const double deadline = now_s() + timeout_s;
   const uint32_t* flags = reinterpret_cast<const uint32_t*>(
       reinterpret_cast<const char*>(c->host) + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
-  const int words = c->wide ? wide_collect_words(c->W) : collect16_blocks(c->W);
+  const int words = c->q_words > 0 ? c->q_words : c->wide ? wide_collect_words(c->W) : collect16_blocks(c->W);
   int arrived = 0;                                   // words [0, arrived) already carry c->seq
   for (uint64_t spins = 0;; ++spins) {
     bool done;
@@ -988,8 +990,36 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
     }
   }
   c->waiting = false;
+  c->q_words = 0;
   return TONIC_OK;
 }
+
+namespace tonic {
+void collector_shape(tonic_collector_t* c, int64_t* W, int* O, int* A) { *W = c->W; *O = c->O; *A = c->A; }
+
+int collector_begin_q_step(tonic_collector_t* c, int eps_slot, CollectorStep* out) {
+  TONIC_REQUIRE(c != nullptr && out != nullptr && eps_slot >= -1 && eps_slot <= 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_q_act: bad argument (noise slot %d)", eps_slot);
+  TONIC_REQUIRE(!c->waiting && !c->live && !c->armed, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_q_act: another step of this collector is in flight");
+  const int words = (int)((c->W + 15) / 16);
+  // (the block's completion field: collect16_blocks(W) words, rounded up to 256 bytes)
+  TONIC_REQUIRE(words <= 64 || words <= collect16_blocks(c->W), TONIC_ERR_UNSUPPORTED_SHAPE,
+                "tonic_collector_q_act: %d completion words do not fit the block", words);
+  c->seq += 1;
+  __atomic_store_n(&c->host->act_seq, c->seq, __ATOMIC_RELEASE);
+  out->W = c->W; out->O = c->O; out->A = c->A;
+  auto mapped = [&](int f) { return reinterpret_cast<float*>(c->mapped + c->host->offset[f]); };
+  out->observations = mapped(TONIC_COLLECTOR_OBSERVATIONS);
+  out->eps = eps_slot < 0 ? nullptr : mapped(TONIC_COLLECTOR_EPS0);
+  out->actions_out = mapped(TONIC_COLLECTOR_EPS1);
+  out->done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
+  out->seq = c->seq;
+  c->q_words = words;
+  c->waiting = true;
+  return TONIC_OK;
+}
+}  // namespace tonic
 
 extern "C" int tonic_collector_end_rollout(tonic_collector_t* c, int64_t last_row,
                                            void* learner_stream) {

@@ -124,6 +124,12 @@ struct MlpFwdArgs {
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
   FwdImages img;                // img.block != null: the products run on fp16x2 terms from weight images (mlpimg.h)
+  // acting on a collector's block (tonic_collector_q_act): every workgroup copies its 16 input rows (K1 columns)
+  // to rows_out (rows_ld apart; null: no copy), releases its stores to the SYSTEM (the tail wrote the actions into
+  // mapped host memory) and then writes done_seq into done_flags[blockIdx.x] at system scope — the host polls
+  // these words (tonic_collector_wait_actions).  Null done_flags: none of this.
+  unsigned* done_flags; unsigned done_seq;
+  float* rows_out; int rows_ld;
   // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
   // the second input — has a tail of its own with its own outputs (the fused learner iteration
   // runs the policy passes of the critic step AND of the actor step as one launch: SAC the online

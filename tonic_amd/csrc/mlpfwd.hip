@@ -860,6 +860,20 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];     // float32: two [16][H + 4] images; IMG: img_lds
   if constexpr (IMG) mlp_forward_body_img(a, blockIdx.y, blockIdx.x, lds);
   else mlp_forward_body(a, blockIdx.y, blockIdx.x, lds);
+  if (a.done_flags != nullptr) {                      // scalar: a step of a collector's block (see MlpFwdArgs)
+    if (!IMG && a.rows_out != nullptr) {              // (the image pass wrote them from its input registers)
+      const int r0 = blockIdx.x * kRows;
+      for (int i = threadIdx.x; i < kRows * a.K1; i += blockDim.x) {
+        const int r = i / a.K1, k = i - r * a.K1;
+        if (r0 + r < a.B) a.rows_out[(int64_t)(r0 + r) * a.rows_ld + k] = a.X[(int64_t)(r0 + r) * a.ldx + k];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // this wave's stores (the actions) -> the system
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(a.done_flags + blockIdx.x, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 template <bool IMG>

@@ -273,6 +273,11 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
         if (u >= U) break;
         const int c0 = 64 * u + 4 * slot;
         if (c0 < KP1) store4(c0, xv[u][0], xv[u][1], xv[u][2], xv[u][3], unit);
+        if (a.rows_out != nullptr && r0 + prow < a.B) {       // (scalar pointer: a collector step's device copy)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < K1) a.rows_out[(int64_t)(r0 + prow) * a.rows_ld + c0 + e] = xv[u][e];
+        }
       }
     } else {                                          // wide inputs: two passes over the row (L2 hits)
       float amax = 0.f;
@@ -284,7 +289,14 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
       const float unit = img_pow2(kActTop - ex);
       for (int u = 0; u < U; ++u) {
         const int c0 = 64 * u + 4 * slot;
-        if (c0 < KP1) store4(c0, element(c0), element(c0 + 1), element(c0 + 2), element(c0 + 3), unit);
+        const float x0 = element(c0), x1 = element(c0 + 1), x2 = element(c0 + 2), x3 = element(c0 + 3);
+        if (c0 < KP1) store4(c0, x0, x1, x2, x3, unit);
+        if (a.rows_out != nullptr && r0 + prow < a.B) {
+          const float xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < K1) a.rows_out[(int64_t)(r0 + prow) * a.rows_ld + c0 + e] = xs[e];
+        }
       }
     }
     if (slot == 0) desc[prow] = img_pow2(ex - kActTop - kImgScaleExp);

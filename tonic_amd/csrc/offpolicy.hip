@@ -18,6 +18,7 @@
 // tonic_adam_step / an RCCL all-reduce consume them exactly like the PPO path.
 #include "gemm16.h"
 #include "mlpfwd.h"
+#include "collector_q.h"
 
 namespace tonic {
 
@@ -742,7 +743,8 @@ struct PolicyTail {
 int actor_forward(const float* params, ActorShape s, const float* obs, int B, float* h1,
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
                   hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr,
-                  int ldx = 0, const ActorImg* img = nullptr) {
+                  int ldx = 0, const ActorImg* img = nullptr, const CollectorStep* step = nullptr,
+                  float* rows_out = nullptr) {
   ActorParams p(params, s);
   if (ldx <= 0) ldx = s.O;                      // dense observation rows unless told otherwise
   if (tail_done != nullptr) *tail_done = false;
@@ -760,6 +762,9 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
     f.B = B; f.H = s.H; f.split = 1 << 30;
     if (img != nullptr && img->block != nullptr)
       f.img = FwdImages{img->block, img->v.f1, img->v.f2, {img->v.fh[0], img->v.fh[s.heads - 1]}, 0, 0};
+    if (step != nullptr) {       // a step of a collector's block: completion words, the rows' device copy
+      f.done_flags = step->done_flags; f.done_seq = step->seq; f.rows_out = rows_out; f.rows_ld = s.O;
+    }
     if (tail != nullptr && g_policy_tail != 0 && mlp_policy_tail_supported(s.H, s.A)) {
       f.post = tail->post; f.post_eps = tail->eps; f.post_actions = tail->actions;
       f.post_sigma = tail->sigma; f.post_logp = tail->logp;
@@ -1082,6 +1087,61 @@ extern "C" int tonic_policy_forward(const float* d_actor_params, const float* d_
                        sample_group(A));
   }
   TONIC_CHECK_LAUNCH("tonic_policy_forward");
+  return TONIC_OK;
+}
+
+// Acting on a collector's block (the off-policy agents' step when the environment writes its observations into a
+// shared pinned block, tonic_amd/collector.py): ONE launch reads the W observation rows in place (page-locked host
+// memory, no staging copy), runs the policy of tonic_policy_forward (kind 0 deterministic tanh head, 1 squashed
+// Gaussian: eps_slot 0 = the block's first noise field holds the standard-normal draws, -1 = the greedy loc), writes
+// the actions into the block's second noise field (host-visible) and one completion word per 16 rows at system
+// scope; the host waits with tonic_collector_wait_actions — no event, no copy back.  d_rows_out [W, O] (may be
+// NULL): a device copy of the observation rows for the transition the agent stores after the environment's step
+// (the block's own rows are overwritten by then).  replaces: tonic/torch/agents/ddpg.py:45-52,
+// sac.py:40-51 (`_policy` / `_greedy_actions`) for observations that live in a collector block.
+extern "C" int64_t tonic_mlp_actor_image_bytes(int32_t O, int32_t H, int32_t A, int32_t heads) {
+  if (!hidden_plain(H) || heads < 1 || heads > 2 || !images_serve(O, A, H) || !mlp_forward_supported(H, A, heads))
+    return 0;
+  return round_up(actor_images(O, H, A, heads).bytes, 256);
+}
+
+extern "C" int tonic_collector_q_act(tonic_collector_t* collector, const float* d_actor_params,
+                                     void* d_actor_images, int32_t rebuild_images, int32_t kind,
+                                     int32_t H, int32_t eps_slot, float* d_rows_out, void* d_workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  TONIC_REQUIRE(collector && d_actor_params && d_actor_images && d_workspace && (kind == 0 || kind == 1),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_q_act: bad argument");
+  TONIC_REQUIRE(kind == 1 || eps_slot < 0, TONIC_ERR_INVALID_ARGUMENT,
+                "tonic_collector_q_act: the deterministic policy takes no noise");
+  int64_t W; int O, A;
+  collector_shape(collector, &W, &O, &A);      // (shapes first: nothing is opened before the arguments are known good)
+  const ActorShape s = actor_shape(O, H, A, kind == 0 ? 1 : 2);
+  TONIC_REQUIRE(tonic_mlp_actor_image_bytes(O, H, A, s.heads) > 0 && mlp_policy_tail_supported(s.H, s.A) &&
+                    g_policy_tail != 0 && mlp_image_pass_supported(O, s.H),
+                TONIC_ERR_UNSUPPORTED_SHAPE, "tonic_collector_q_act: O=%d H=%d A=%d outside the fused forward", O, H, A);
+  TONIC_REQUIRE(workspace_bytes >= tonic_offpolicy_workspace_bytes((int32_t)W, O, A, H), TONIC_ERR_WORKSPACE,
+                "tonic_collector_q_act: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int B = (int)W, Bp = pad16(B), ldh = pad16(A), HP = hidden_pitch(H);
+  Workspace ws{static_cast<char*>(d_workspace), 0, workspace_bytes};
+  float* h1 = ws.take((int64_t)Bp * HP); float* h2 = ws.take((int64_t)Bp * HP);
+  float* head0 = ws.take((int64_t)Bp * ldh); float* head1 = ws.take((int64_t)Bp * ldh);
+  // the actor's weight images (mlpimg.h): the caller's buffer, rebuilt here when it says the parameters moved
+  const ActorImg img{static_cast<char*>(d_actor_images), nullptr, actor_images(O, s.H, A, s.heads)};
+  if (rebuild_images != 0) {
+    ImgBuild build;
+    add_actor_images(build, d_actor_params, s, img);
+    TRY(launch_build_images(build, st));
+  }
+  CollectorStep step{};
+  TRY(collector_begin_q_step(collector, eps_slot, &step));
+  PolicyTail tail{};
+  tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = step.eps; tail.actions = step.actions_out;
+  bool tail_done = false;
+  TRY(actor_forward(d_actor_params, s, step.observations, B, h1, h2, head0, head1, ldh, kind == 0, st, &tail,
+                    &tail_done, 0, &img, &step, d_rows_out));
+  TONIC_REQUIRE(tail_done, TONIC_ERR_UNSUPPORTED_SHAPE, "tonic_collector_q_act: the policy tail did not fuse");
+  TONIC_CHECK_LAUNCH("tonic_collector_q_act");
   return TONIC_OK;
 }
 

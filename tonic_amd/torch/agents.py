@@ -50,6 +50,20 @@ _SIDE_STREAMS = {}
 _ARMED_GATES = weakref.WeakSet()      # agents whose critic chain waits behind a tonic_stream_gate
 
 
+class _DevicePointer:
+    """A raw device address where the entry-point wrappers expect a contiguous float32 tensor (`_lib.ptr`): fields
+    of a page-locked collector block as the GPU addresses them."""
+
+    def __init__(self, address, shape):
+        self.address, self.shape = address, tuple(shape)
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.address
+
+
 def _side_stream(name):
     """One stream per purpose and device for the whole process, not one per agent: HIP maps the
     streams of a process onto a handful of hardware queues in creation order, and two streams on one
@@ -1245,6 +1259,10 @@ class DDPG(Agent):
         self._replicate([self.model.flat_online, self.model.flat_target], own_noise=False)
         self._workers = None
         self._policy_io = {}
+        self._q_blocks = {}
+        self._actor_images = None             # the acting launch's weight images of the actor (tonic_collector_q_act)
+        self._actor_images_stale = True
+        self._actor_images_version = -1
         self._graph, self._static_key = None, None       # a re-initialised agent re-captures
 
     def close(self):
@@ -1254,7 +1272,74 @@ class DDPG(Agent):
             parallel.release_affinity()
 
     # ------------------------------------------------------------------ acting
+    def _block_of(self, observations, kind):
+        """The collector block these observations live in when the policy can act on it in place
+        (tonic_collector_q_act: the environments of tonic_amd.environments hand out views of their shared block;
+        plain torsos the fused forward holds; one process per block's GPU handle) — None: the staged copies."""
+        if kind not in (0, 1) or self.hidden is None or os.environ.get('TONIC_AMD_Q_BLOCK', '1') == '0':
+            return None
+        if self._actor_images is None:          # (once: does the fused forward on weight images serve this policy?)
+            need = self.lib.tonic_mlp_actor_image_bytes(self.observation_size, self.hidden, self.action_size,
+                                                        2 if kind == 1 else 1)
+            self._actor_images = torch.zeros(need, dtype=torch.uint8, device=self.device) if need > 0 else False
+            self._actor_images_stale = True
+        if self._actor_images is False:
+            return None
+        if not isinstance(observations, np.ndarray):
+            return None
+        block = Block.owner_of(observations)
+        if block is None:
+            return None
+        state = self._q_blocks.get(id(block))
+        if state is None:
+            W = block.workers
+            need = self.lib.tonic_offpolicy_workspace_bytes(W, self.observation_size, self.action_size, self.hidden)
+            state = dict(block=block, collector=Collector.for_block(block, 0),
+                         workspace=torch.empty(need, dtype=torch.uint8, device=self.device),
+                         rows=torch.zeros(W, self.observation_size, device=self.device), usable=True)
+            # the block's fields as the GPU sees them (page-locked by the collector): the store reads them in place
+            def mapped(view, shape):
+                address = self.lib.tonic_host_device_pointer(view.ctypes.data)
+                return _DevicePointer(address, shape) if address else None
+            W, O, A = block.workers, self.observation_size, self.action_size
+            state['fields'] = dict(actions=mapped(block.actions, (W, A)),
+                                   next_observations=mapped(block.next_observations, (W, O)),
+                                   rewards=mapped(block.rewards, (W,)), resets=mapped(block.resets, (W,)),
+                                   terminations=mapped(block.terminations, (W,)))
+            if any(v is None for v in state['fields'].values()):
+                state['usable'] = False
+            self._q_blocks[id(block)] = state
+        return state if state['usable'] else None
+
+    def _act_on_block(self, state, kind, stochastic):
+        """One launch on the environment's block, no copies: ddpg.py:45-52 / sac.py:40-51 (tonic_collector_q_act)."""
+        block, collector = state['block'], state['collector']
+        W = block.workers
+        if stochastic:          # Normal.sample() of sac.py:43 == loc + scale * randn (SURVEY A.7)
+            np.copyto(block.eps[0], self._randn(W, self.action_size).numpy())
+        workspace = state['workspace']
+        # the images follow the float32 parameters: rebuilt after every learner update (raw-pointer writes: the
+        # flag) and whenever torch has written the flat block in place since (load_state_dict, an optimizer of the
+        # caller's: the tensor's version counter, which every in-place operation on a view of it advances)
+        flat = self.model.flat_online
+        stale = self._actor_images_stale or flat._version != self._actor_images_version
+        self._actor_images_version = flat._version
+        _lib.check(self.lib.tonic_collector_q_act(
+            collector.handle, _lib.ptr(self.model.flat_actor.flat), _lib.ptr(self._actor_images),
+            int(stale), kind, self.hidden, 0 if stochastic else -1,
+            _lib.ptr(state['rows']), _lib.ptr(workspace), workspace.numel(), _lib.current_stream()),
+            'tonic_collector_q_act')
+        self._actor_images_stale = False
+        collector.wait_actions()
+        state['rows_of'] = block          # the device copy of these observation rows: for the next store
+        return block.eps[1].copy()
+
     def _forward_policy(self, observations, kind, stochastic):
+        state = self._block_of(observations, kind)
+        if state is not None:
+            actions = self._act_on_block(state, kind, stochastic)
+            if actions is not None:
+                return actions
         observations = np.asarray(observations, np.float32)
         W = observations.shape[0]
         io = self._policy_io.get(W)
@@ -1311,16 +1396,68 @@ class DDPG(Agent):
         return self._greedy_actions(observations)
 
     def step(self, observations, steps):
+        for state in self._q_blocks.values():
+            state['rows_of'] = state['actions_of'] = None
         actions = self.exploration(observations, steps)
         self.last_observations = observations.copy()
         self.last_actions = actions.copy()
+        self._stepped_on = observations
+        state = self._block_of(observations, self.policy_kind)
+        if state is not None:
+            block = state['block']
+            if state.get('store_pending') and state['rows_of'] is not block:
+                # the last store launch reads the block in place and no acting launch was waited for behind it
+                # (warm-up: uniform actions): it must be through before the environment overwrites the block
+                torch.cuda.current_stream().synchronize()
+            state['store_pending'] = False
+            # the executed actions go into the environment's block (where the store launch reads them); policy
+            # actions (float32) are handed out as the block's own view — value-identical, and the environments of
+            # tonic_amd.environments take their one-call step then — the warm-up's float64 draws as they are
+            np.copyto(block.actions, actions)
+            state['actions_of'] = block
+            if actions.dtype == np.float32:
+                return block.out_actions
         return actions
 
     def test_step(self, observations, steps):
         return self._greedy_actions(observations)
 
     # ---------------------------------------------------------------- learning
+    def _store_from_block(self, observations, rewards):
+        """The transition straight from the environment's block (Buffer.store, buffers.py:33-56): next observations,
+        outcome and the executed actions are read by the store launch IN PLACE (page-locked block), the observations
+        from the device copy the acting launch made — or, when the policy did not act on this step (warm-up), from one
+        staged copy.  False: not this step's layout (foreign arrays, another block): the staged path."""
+        block = Block.owner_of(getattr(self, '_stepped_on', None)) if isinstance(
+            getattr(self, '_stepped_on', None), np.ndarray) else None
+        if block is None or observations is not block.out_next_observations or rewards is not block.out_rewards:
+            return False
+        state = self._block_of(self._stepped_on, self.policy_kind)
+        if state is None or state.get('actions_of') is not block:      # (step() put the executed actions there)
+            return False
+        if state.get('rows_of') is block:
+            rows = state['rows']
+        else:                                   # (warm-up: uniform actions, the policy never saw these rows)
+            staged = state.setdefault('staged_rows', torch.zeros(
+                block.workers, self.observation_size, dtype=torch.float32).pin_memory())
+            torch.cuda.current_stream().synchronize()        # (the previous store may still read it)
+            staged.numpy()[:] = self.last_observations
+            rows = state['rows']
+            rows.copy_(staged, non_blocking=True)
+        self.replay.store(normalizer=self.model.observation_normalizer, observations=rows, **state['fields'])
+        state['store_pending'] = True
+        return True
+
     def update(self, observations, rewards, resets, terminations, steps):
+        if self._store_from_block(observations, rewards):
+            if self.model.return_normalizer:
+                raise NotImplementedError('return normalisers are not supported')
+            if self.replay.ready(steps):
+                self._update(steps)          # (ends with a read-back: the store launch is through)
+                for state in self._q_blocks.values():
+                    state['store_pending'] = False
+            self.exploration.update(resets)
+            return
         W = len(rewards)
         if self._workers != W:
             self._workers = W
@@ -1362,6 +1499,7 @@ class DDPG(Agent):
         grouped weight-gradient launches, Adam + polyak: 13 per SAC iteration — is captured once into a hipGraph
         reading fixed index / noise buffers and replayed on later calls."""
         iterations, global_batch = indices.shape
+        self._actor_images_stale = True          # (the acting launch rebuilds its weight images after an update)
         world = self.critic_updater.world_size
         counts = None
         if world > 1:
