@@ -487,6 +487,50 @@ def test_fused_iteration_equals_the_split_entry_points(lib, monkeypatch, kind, O
                                       got[first] if first else None, want[first] if first else None))
 
 
+@pytest.mark.parametrize('kind', ['sac', 'td3'])
+def test_update_call_in_chunks_is_bit_identical(lib, monkeypatch, kind):
+    """DDPG._update draws the index and noise streams of an update call chunk by chunk (10 iterations per captured
+    graph, two alternating sets of graph inputs) so that the host's draws run under the GPU's work: the same draws in
+    the same order — parameters, targets, moments, step counters and every logged statistic of two update calls of
+    40 iterations are bit-identical with the one-graph call (TONIC_AMD_UPDATE_CHUNK=0), and the generators end up
+    in the same state."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    O, A, W, B, rows, iterations = (23, 5, 2, 64, 40, 40)
+    rng = np.random.RandomState(21)
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    results = {}
+    for mode, chunk in (('one graph', '0'), ('chunks', '10')):
+        monkeypatch.setenv('TONIC_AMD_UPDATE_CHUNK', chunk)
+        replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B)
+        agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3)[kind](replay=replay)
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+        assert (agent._update_chunk(iterations) == 10) == (mode == 'chunks')
+        norm = agent.model.observation_normalizer
+        for t in range(rows):
+            replay.store(normalizer=norm, **{k: dev(v[t]) for k, v in host.items()})
+        infos = []
+        for call in range(2):
+            agent._update(steps=100000 + 50 * call)
+            infos.append(agent.last_infos.copy())
+            for t in range(3):               # (the normaliser's update wants new records every time)
+                replay.store(normalizer=norm, **{k: dev(v[t]) for k, v in host.items()})
+        results[mode] = dict(
+            infos0=infos[0], infos1=infos[1], online=agent.model.flat_online.cpu().numpy(),
+            target=agent.model.flat_target.cpu().numpy(),
+            critic_m=agent.critic_updater.exp_avg.cpu().numpy(), actor_v=agent.actor_updater.exp_avg_sq.cpu().numpy(),
+            steps=np.array([int(agent.critic_updater.state[0]), int(agent.actor_updater.state[0])]),
+            next_index=replay.np_random.randint(1 << 30, size=4), next_noise=torch.randn(4).numpy())
+    assert list(results['chunks']['steps']) == [2 * iterations, 2 * iterations // (2 if kind == 'td3' else 1)]
+    for key, want in results['one graph'].items():
+        got = results['chunks'][key]
+        assert np.array_equal(got, want, equal_nan=True), (key, np.abs(got - want).max())
+
+
 @pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100), ('ddpg', 17, 6, 4, 100)])
 def test_fused_iteration_in_phases_equals_the_split_entry_points(lib, monkeypatch, kind, O, A, W, B):
     """Whenever something must see the complete gradient sums between gradients and step — here a gradient-norm

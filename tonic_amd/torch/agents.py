@@ -1264,6 +1264,7 @@ class DDPG(Agent):
         self._actor_images_stale = True
         self._actor_images_version = -1
         self._graph, self._static_key = None, None       # a re-initialised agent re-captures
+        self._slots, self._slot_index = {}, 0
 
     def close(self):
         """Gives back what the agent holds beyond its tensors (the process's CPU binding: parallel.bind_near_gpu)."""
@@ -1735,11 +1736,54 @@ class DDPG(Agent):
         # DeterministicQLearning / DeterministicPolicyGradient draw nothing (one unused slot)
         return np.zeros((iterations, 1, self.replay.batch_size, self.action_size), np.float32)
 
+    # -- an update call in chunks: the host draws chunk k + 1's index and noise streams while the GPU runs chunk k
+    _SLOT_FIELDS = ('_static_key', '_static_indices', '_static_eps', '_infos', '_graph', '_static_adam')
+
+    def _select_slot(self, index):
+        """Two sets of everything a captured update graph reads (index / noise / step-constant buffers, the
+        statistics rows, the graph itself): one is being replayed while the host fills the other."""
+        current = getattr(self, '_slot_index', 0)
+        if index == current:
+            return
+        slots = self.__dict__.setdefault('_slots', {})
+        slots[current] = {f: getattr(self, f, None) for f in self._SLOT_FIELDS}
+        chosen = slots.get(index, {})
+        for f in self._SLOT_FIELDS:
+            setattr(self, f, chosen.get(f))
+        self._slot_index = index
+
+    def _update_chunk(self, iterations):
+        """How many iterations one graph of a chunked update holds (0: one graph for the whole call).  The streams
+        are drawn in the reference's order either way (indices: the Buffer's RandomState, noise: torch's CPU
+        generator, both only consumed by this call while it runs) — chunking only moves WHEN the host draws them:
+        7.6 -> ~6 ms per SAC update call of 50 iterations, whose 2 ms of host draws ran in front of 5.4 ms of GPU
+        work (profiles/r06_offpolicy_pmc.md).  Needs the fused iteration in a hipGraph on one rank; chunks hold a
+        whole number of actor delays.  TONIC_AMD_UPDATE_CHUNK=0: off; =n: n iterations per chunk."""
+        chunk = int(os.environ.get('TONIC_AMD_UPDATE_CHUNK', '10'))
+        delay = int(getattr(self, 'delay_steps', 1) or 1)
+        if (chunk <= 0 or iterations < 2 * chunk or iterations % chunk or chunk % delay
+                or type(self)._update is not DDPG._update or type(self).enqueue_update is not DDPG.enqueue_update
+                or os.environ.get('TONIC_AMD_NO_GRAPH', '0') == '1' or parallel.exchanging()
+                or self.critic_updater.world_size > 1 or self._fused_kind() is None or self._fused_in_phases()):
+            return 0
+        return chunk
+
     def _update(self, steps):
         replay = self.replay
-        indices = replay.sample_indices()
-        eps = self._draw_noise(indices.shape[0])
-        infos = self.enqueue_update(indices, eps).cpu().numpy()
+        chunk = self._update_chunk(replay.batch_iterations)
+        if chunk:
+            parts = []
+            for k in range(replay.batch_iterations // chunk):
+                indices = replay.sample_indices(chunk)         # (host: while the GPU runs the chunk before)
+                eps = self._draw_noise(chunk)
+                self._select_slot(k & 1)
+                parts.append(self.enqueue_update(indices, eps).clone())
+            self._select_slot(0)
+            infos = torch.cat(parts, dim=1).cpu().numpy()
+        else:
+            indices = replay.sample_indices()
+            eps = self._draw_noise(indices.shape[0])
+            infos = self.enqueue_update(indices, eps).cpu().numpy()
         parallel.check_one_shot()
         if getattr(self, '_phased_update', False) and int(self._fused_workspace[:4].view(torch.int32)[0]):
             # (in phases the steps are the updaters' own launches: nothing held them back)
