@@ -78,7 +78,7 @@ def pmc_traffic(prefix):
     collected from inside the timed run, so the summary of the same kernels is quoted (the newest
     round's file that has the kernel)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
+    for name in ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 table = json.load(f)['kernels']
@@ -95,7 +95,7 @@ def rocprof_us(prefix):
     `python bench.py` (profiles/rNN_kernel_us.json, written by scripts/kernel_us.py from the
     stats csv of the same round; the newest round's), next to the HIP-event figure measured live."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r05_kernel_us.json', 'r04_kernel_us.json'):
+    for name in ('r06_kernel_us.json', 'r05_kernel_us.json', 'r04_kernel_us.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 table = json.load(f)['kernels']
@@ -252,7 +252,7 @@ def kernel_rooflines(agent):
                                                   ms=sweep[1]['ms']),
                     sweep_top=dict(achieved=top['achieved'], frac=top['frac'],
                                    at=dict(T=top['T'], W=top['W'], chunks=top['chunks'])),
-                    sweep=sweep, **pmc_traffic('gae_scan_kernel'),
+                    sweep=sweep, **pmc_traffic('gae_onepass_kernel'),
                     note='the headline figure is the metric\'s own size (T=4096, W=256: 29 MB, inside '
                          'the Infinity Cache: launch- and latency-bound, not bandwidth-bound); the kernel '
                          'reaches its HBM fraction on the sweep (sweep_top: W = 65 536, 1.9 GB)')

@@ -38,6 +38,13 @@ for _ in range(3):
         p(small[0]), p(small[1]), p(rs2), p(tm2), p(small[2]), p(ret2), p(adv2), p(stats), None,
         T2, W2, 0.99, 0.97, 1, p(ws2), ws2.numel(), None), 'gae small')
 torch.cuda.synchronize()
+# ... and the Segment's default there since round 6: the one-pass form (gae_onepass_kernel, chunks = 0)
+ws3 = torch.empty(max(lib.tonic_gae_workspace_bytes(T2, W2, 0), 16), dtype=torch.uint8, device='cuda')
+for _ in range(3):
+    _lib.check(lib.tonic_gae_lambda_returns(
+        p(small[0]), p(small[1]), p(rs2), p(tm2), p(small[2]), p(ret2), p(adv2), p(stats), None,
+        T2, W2, 0.99, 0.97, 0, p(ws3), ws3.numel(), None), 'gae small, one pass')
+torch.cuda.synchronize()
 
 O, A, n = 17, 6, 4096 * 256
 P = lib.tonic_ppo_actor_param_count(O, A)

@@ -15,6 +15,7 @@ Pa, Pc = 64 * O + 64 + 4096 + 64 + A + 64 * A + A, 64 * O + 64 + 4096 + 64 + 64 
 ALGORITHMIC = {      # bytes per launch
     'gae_scan_kernel': ('gae_scan_kernel@T=4096,W=65536', 28 * T * W),
     'gae_stream16_kernel': ('gae_stream16_kernel@T=4096,W=256', 28 * T2 * W2),
+    'gae_onepass_kernel': ('gae_onepass_kernel@T=4096,W=256', 28 * T2 * W2),
     'actor': ('mlp64_grad16_kernel<actor>@N=1048576', N * (O + A + 2) * 4 + 256 * (Pa + 8 + 55) // 64 * 64 * 4),
     'critic': ('mlp64_grad16_kernel<critic>@N=1048576', N * (O + 1) * 4 + 256 * (Pc + 8 + 55) // 64 * 64 * 4),
     'values': ('mlp64_grad16_kernel<values>@N=1048576', N * (O + 1) * 4),
@@ -26,6 +27,8 @@ def short(name):
     m = re.match(r'mlp64_grad16_kernel<\d+, \d+, \d+, \d+, (true|false), (true|false), \d+, (true|false)(?:, (true|false))?>', name)
     if m:
         return 'values' if m.group(4) == 'true' else 'actor' if m.group(1) == 'true' else 'critic'
+    if name.startswith('gae_onepass_kernel'):
+        return 'gae_onepass_kernel'
     return name.split('<')[0] if name.startswith(('gae_', 'reduce_')) and '<' not in name else name
 
 
