@@ -726,10 +726,24 @@ int tonic_q_iteration(const tonic_q_iteration_t* iteration, void* stream);
  *   d_actor_images = tonic_mlp_actor_image_bytes(O, H, A, heads) bytes owned by the caller, rebuild_images = 1
  *   whenever the parameters changed since the last call (after every learner update).  Shapes with 0 image bytes:
  *   TONIC_ERR_UNSUPPORTED_SHAPE (callers keep tonic_policy_forward for those). */
+/* store (may be NULL): the transition of the step BEFORE rides in the same launch — one more workgroup runs
+ *   tonic_buffer_store's body (Buffer.store + MeanStd.record, replays/buffers.py:33-52, mean_stds.py:44-48) with the
+ *   block's outcome fields (executed actions, next observations, rewards, resets, terminations: read in place) and
+ *   d_observations = the device copy of that step's observation rows (the d_rows_out of ITS acting call: callers
+ *   alternate two buffers), into row `row` of the HBM Buffer; its completion word follows the tiles'.  The
+ *   environment may overwrite the block once tonic_collector_wait_actions has returned. */
+typedef struct tonic_q_store_t {
+  float* d_buf_observations; float* d_buf_actions; float* d_buf_next_observations; float* d_buf_rewards;
+  float* d_buf_resets; float* d_buf_terminations; float* d_buf_discounts;
+  const float* d_observations;   /* [W, O] */
+  float* d_norm_acc;             /* MeanStd running sums [2 O] (may be NULL) */
+  int64_t row;
+  double discount_factor;
+} tonic_q_store_t;
 int64_t tonic_mlp_actor_image_bytes(int32_t O, int32_t H, int32_t A, int32_t heads);   /* 0: not served */
 int tonic_collector_q_act(tonic_collector_t* collector, const float* d_actor_params, void* d_actor_images,
                           int32_t rebuild_images, int32_t kind, int32_t H, int32_t eps_slot, float* d_rows_out,
-                          void* d_workspace, int64_t workspace_bytes, void* stream);
+                          const tonic_q_store_t* store, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- D4PG: distributional critic (tonic/torch/models/critics.py:23-66, agents/d4pg.py).
  *   The critic is an actor-shaped network on the encoded input [normalised observation | action]:

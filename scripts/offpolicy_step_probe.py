@@ -39,9 +39,9 @@ def probe(kind, o_dim, a_dim, batch, workers, count=2000):
         if stochastic:
             np.copyto(block.eps[0], agent._randn(workers, a_dim).numpy())
         t2 = clock()
-        _lib.check(agent.lib.tonic_collector_q_act(
+        _lib.check(agent._q_act(
             collector.handle, _lib.ptr(agent.model.flat_actor.flat), _lib.ptr(agent._actor_images), 0, kind_code,
-            agent.hidden, 0 if stochastic else -1, _lib.ptr(state['rows']), _lib.ptr(state['workspace']),
+            agent.hidden, 0 if stochastic else -1, _lib.ptr(state['rows'][0]), None, _lib.ptr(state['workspace']),
             state['workspace'].numel(), _lib.current_stream()), 'q_act')
         t3 = clock()
         collector.wait_actions()
@@ -64,7 +64,7 @@ def probe(kind, o_dim, a_dim, batch, workers, count=2000):
     # the store launch alone
     t0 = clock()
     for _ in range(count):
-        replay.store(normalizer=agent.model.observation_normalizer, observations=state['rows'], **state['fields'])
+        replay.store(normalizer=agent.model.observation_normalizer, observations=state['rows'][0], **state['fields'])
     out['store_call_us'] = round((clock() - t0) / count * 1e6, 2)
     torch.cuda.synchronize()
     return out

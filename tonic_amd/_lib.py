@@ -20,6 +20,14 @@ class QOptimizer(ctypes.Structure):
                 ('lr', c_f64), ('beta1', c_f64), ('beta2', c_f64), ('eps', c_f64)]
 
 
+class QStore(ctypes.Structure):
+    """tonic_q_store_t of include/tonic_hip.h (field for field)."""
+    _fields_ = [('d_buf_observations', c_vp), ('d_buf_actions', c_vp), ('d_buf_next_observations', c_vp),
+                ('d_buf_rewards', c_vp), ('d_buf_resets', c_vp), ('d_buf_terminations', c_vp),
+                ('d_buf_discounts', c_vp), ('d_observations', c_vp), ('d_norm_acc', c_vp),
+                ('row', c_i64), ('discount_factor', c_f64)]
+
+
 class QIteration(ctypes.Structure):
     """tonic_q_iteration_t of include/tonic_hip.h (field for field)."""
     _fields_ = [('kind', c_i32), ('actor_due', c_i32),
@@ -131,7 +139,7 @@ SIGNATURES = {
     'tonic_collector_ring': (ctypes.c_int, [c_vp]),
     'tonic_collector_block_carry_over': (ctypes.c_int, [c_vp, c_i32]),
     'tonic_collector_arm': (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32]),
-    'tonic_collector_q_act': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    'tonic_collector_q_act': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'tonic_mlp_actor_image_bytes': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'tonic_collector_claim': (ctypes.c_int, [c_vp]),
     'tonic_collector_worker_wait': (c_i64, [c_vp, c_i64, c_f64]),

@@ -997,12 +997,12 @@ extern "C" int tonic_collector_wait_actions(tonic_collector_t* c, double timeout
 namespace tonic {
 void collector_shape(tonic_collector_t* c, int64_t* W, int* O, int* A) { *W = c->W; *O = c->O; *A = c->A; }
 
-int collector_begin_q_step(tonic_collector_t* c, int eps_slot, CollectorStep* out) {
+int collector_begin_q_step(tonic_collector_t* c, int eps_slot, int extra_words, CollectorStep* out) {
   TONIC_REQUIRE(c != nullptr && out != nullptr && eps_slot >= -1 && eps_slot <= 0, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_q_act: bad argument (noise slot %d)", eps_slot);
   TONIC_REQUIRE(!c->waiting && !c->live && !c->armed, TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_collector_q_act: another step of this collector is in flight");
-  const int words = (int)((c->W + 15) / 16);
+  const int words = (int)((c->W + 15) / 16) + extra_words;
   // (the block's completion field: collect16_blocks(W) words, rounded up to 256 bytes)
   TONIC_REQUIRE(words <= 64 || words <= collect16_blocks(c->W), TONIC_ERR_UNSUPPORTED_SHAPE,
                 "tonic_collector_q_act: %d completion words do not fit the block", words);
@@ -1013,6 +1013,11 @@ int collector_begin_q_step(tonic_collector_t* c, int eps_slot, CollectorStep* ou
   out->observations = mapped(TONIC_COLLECTOR_OBSERVATIONS);
   out->eps = eps_slot < 0 ? nullptr : mapped(TONIC_COLLECTOR_EPS0);
   out->actions_out = mapped(TONIC_COLLECTOR_EPS1);
+  out->actions = mapped(TONIC_COLLECTOR_ACTIONS);
+  out->next_observations = mapped(TONIC_COLLECTOR_NEXT_OBSERVATIONS);
+  out->rewards = mapped(TONIC_COLLECTOR_REWARDS);
+  out->resets = mapped(TONIC_COLLECTOR_RESETS);
+  out->terminations = mapped(TONIC_COLLECTOR_TERMINATIONS);
   out->done_flags = reinterpret_cast<unsigned*>(c->mapped + c->host->offset[TONIC_COLLECTOR_DONE_FLAGS]);
   out->seq = c->seq;
   c->q_words = words;

@@ -24,12 +24,15 @@ typedef int (*wait_actions_fn)(void*, double);
 typedef int (*arm_fn)(void*, int64_t, int32_t, int32_t);
 typedef int (*claim_fn)(void*);
 typedef int (*ring_fn)(void*);
+typedef int (*q_act_fn)(void*, const float*, void*, int32_t, int32_t, int32_t, int32_t, float*, const void*, void*,
+                        int64_t, void*);
 
 static synthetic_step_fn p_synthetic_step;
 static wait_actions_fn p_wait_actions;
 static arm_fn p_arm, p_ppo_step;
 static claim_fn p_claim;
 static ring_fn p_ring;
+static q_act_fn p_q_act;
 
 /* int or None -> pointer (None: NULL); -1 + exception on anything else */
 static int as_pointer(PyObject* o, void** out) {
@@ -59,7 +62,8 @@ static PyObject* bind(PyObject* self, PyObject* arg) {
   p_ppo_step = (arm_fn)dlsym(lib, "tonic_collector_ppo_step");
   p_claim = (claim_fn)dlsym(lib, "tonic_collector_claim");
   p_ring = (ring_fn)dlsym(lib, "tonic_collector_ring");
-  if (!p_synthetic_step || !p_wait_actions || !p_arm || !p_ppo_step || !p_claim || !p_ring) {
+  p_q_act = (q_act_fn)dlsym(lib, "tonic_collector_q_act");
+  if (!p_synthetic_step || !p_wait_actions || !p_arm || !p_ppo_step || !p_claim || !p_ring || !p_q_act) {
     PyErr_Format(PyExc_RuntimeError, "%s lacks a tonic_collector_* entry", path);
     return NULL;
   }
@@ -133,6 +137,27 @@ static PyObject* ring(PyObject* self, PyObject* arg) {
   return PyLong_FromLong(p_ring(block));
 }
 
+/* tonic_collector_q_act(collector, actor_params, actor_images, rebuild_images, kind, H, eps_slot, rows_out,
+ *                        store | None (address of a tonic_q_store_t), workspace, workspace_bytes, stream) */
+static PyObject* q_act(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  REQUIRE_ARGS(12, "tonic_collector_q_act")
+  void *collector, *params, *images, *rows_out, *store, *workspace, *stream;
+  if (as_pointer(args[0], &collector) || as_pointer(args[1], &params) || as_pointer(args[2], &images) ||
+      as_pointer(args[7], &rows_out) || as_pointer(args[8], &store) || as_pointer(args[9], &workspace) ||
+      as_pointer(args[11], &stream))
+    return NULL;
+  long small[4];
+  for (int i = 0; i < 4; ++i) {
+    small[i] = PyLong_AsLong(args[3 + i]);
+    if (small[i] == -1 && PyErr_Occurred()) return NULL;
+  }
+  const long long bytes = PyLong_AsLongLong(args[10]);
+  if (bytes == -1 && PyErr_Occurred()) return NULL;
+  return PyLong_FromLong(p_q_act(collector, (const float*)params, images, (int32_t)small[0], (int32_t)small[1],
+                                 (int32_t)small[2], (int32_t)small[3], (float*)rows_out, store, workspace,
+                                 (int64_t)bytes, stream));
+}
+
 static PyMethodDef methods[] = {
     {"bind", bind, METH_O, "bind(path of the loaded libtonic_hip.so): resolves the entries below"},
     {"tonic_collector_synthetic_step", (PyCFunction)(void (*)(void))synthetic_step, METH_FASTCALL, NULL},
@@ -141,6 +166,7 @@ static PyMethodDef methods[] = {
     {"tonic_collector_ppo_step", (PyCFunction)(void (*)(void))ppo_step, METH_FASTCALL, NULL},
     {"tonic_collector_claim", claim, METH_O, NULL},
     {"tonic_collector_ring", ring, METH_O, NULL},
+    {"tonic_collector_q_act", (PyCFunction)(void (*)(void))q_act, METH_FASTCALL, NULL},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_fastcall",

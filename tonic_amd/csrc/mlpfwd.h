@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include "gemm16.h"
+#include "bufstore.h"
 
 namespace tonic {
 
@@ -130,6 +131,11 @@ struct MlpFwdArgs {
   // these words (tonic_collector_wait_actions).  Null done_flags: none of this.
   unsigned* done_flags; unsigned done_seq;
   float* rows_out; int rows_ld;
+  // ... and (store_on) ONE more workgroup behind the row tiles stores the PREVIOUS step's transition (bufstore.h:
+  // Buffer.store + MeanStd.record; its sources are the block's outcome fields, read in place, and the device copy
+  // of that step's observation rows) and writes the completion word behind the tiles' — the environment may
+  // overwrite the block once every word is out.  lds_floats: the launch's dynamic LDS, the record's staging tile.
+  BufferStoreArgs store; int store_on; int lds_floats;
   // tail2.post != POST_NONE (two networks, split == 1): network 1 — the second parameter set on
   // the second input — has a tail of its own with its own outputs (the fused learner iteration
   // runs the policy passes of the critic step AND of the actor step as one launch: SAC the online

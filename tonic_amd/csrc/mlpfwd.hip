@@ -858,6 +858,14 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
 template <bool IMG>
 __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];     // float32: two [16][H + 4] images; IMG: img_lds
+  if (a.store_on != 0 && blockIdx.x == gridDim.x - 1) {           // scalar: the store role of a collector step
+    buffer_store_body(a.store, lds, a.lds_floats, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // its reads of the block have returned
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(a.done_flags + blockIdx.x, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   if constexpr (IMG) mlp_forward_body_img(a, blockIdx.y, blockIdx.x, lds);
   else mlp_forward_body(a, blockIdx.y, blockIdx.x, lds);
   if (a.done_flags != nullptr) {                      // scalar: a step of a collector's block (see MlpFwdArgs)
@@ -1038,11 +1046,15 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
     const ImgLds L = img_lds(a.K1, a.H);
     launch.tail_offset = L.off_f32 / 4;
     launch.stamps = nullptr;
+    launch.lds_floats = L.total / 4;
+    TONIC_REQUIRE(a.store_on == 0 || (nets == 1 && a.done_flags != nullptr && a.store.O <= L.total / 4),
+                  TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: a store role needs a single-network collector step");
     const int status = allow_image_lds(mlp_forward_kernel<true>, "mlp_forward_kernel");
     if (status != TONIC_OK) return status;
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), L.total,
-                       stream, launch);
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3((a.B + kRows - 1) / kRows + (a.store_on != 0 ? 1 : 0), nets),
+                       dim3(256), L.total, stream, launch);
   } else {
+    TONIC_REQUIRE(a.store_on == 0, TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: the store role rides on the image pass");
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((a.B + kRows - 1) / kRows, nets), dim3(256), lds,
                        stream, launch);
   }

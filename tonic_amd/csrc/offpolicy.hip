@@ -19,6 +19,7 @@
 #include "gemm16.h"
 #include "mlpfwd.h"
 #include "collector_q.h"
+#include "bufstore.h"
 
 namespace tonic {
 
@@ -588,48 +589,10 @@ __global__ __launch_bounds__(256) void buffer_nstep_kernel(NStepArgs a) {
   }
 }
 
-// Buffer.store row write (buffers.py:33-52) + MeanStd.record (mean_stds.py:44-48).
-struct BufferStoreArgs {
-  float* b_obs; float* b_act; float* b_next; float* b_rew; float* b_rst; float* b_term; float* b_disc;
-  const float* obs; const float* act; const float* next; const float* rew; const float* rst;
-  const float* term;
-  float* norm_acc;
-  int64_t row, W;
-  int O, A;
-  float discount;
-};
-
+// Buffer.store row write (buffers.py:33-52) + MeanStd.record (mean_stds.py:44-48): bufstore.h
 __global__ __launch_bounds__(1024) void buffer_store_kernel(BufferStoreArgs a) {
   __shared__ float tile[16384];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n_obs = a.W * a.O, n_act = a.W * a.A;
-  for (int64_t i = tid; i < n_obs; i += stride) {
-    a.b_obs[a.row * n_obs + i] = a.obs[i];
-    a.b_next[a.row * n_obs + i] = a.next[i];
-  }
-  for (int64_t i = tid; i < n_act; i += stride) a.b_act[a.row * n_act + i] = a.act[i];
-  for (int64_t i = tid; i < a.W; i += stride) {
-    a.b_rew[a.row * a.W + i] = a.rew[i];
-    a.b_rst[a.row * a.W + i] = a.rst[i];
-    a.b_term[a.row * a.W + i] = a.term[i];
-    a.b_disc[a.row * a.W + i] = (1.f - a.term[i]) * a.discount;     // buffers.py:34-36
-  }
-  if (a.norm_acc == nullptr || blockIdx.x != gridDim.x - 1) return;
-  const int k = threadIdx.x;
-  float sum = 0.f, sum_sq = 0.f;
-  if (k < a.O) { sum = a.norm_acc[k]; sum_sq = a.norm_acc[a.O + k]; }
-  const int64_t rows_per_chunk = 16384 / a.O;
-  for (int64_t w0 = 0; w0 < a.W; w0 += rows_per_chunk) {
-    const int64_t rows = min(rows_per_chunk, a.W - w0);
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < rows * a.O; i += blockDim.x) tile[i] = a.obs[w0 * a.O + i];
-    __syncthreads();
-    if (k < a.O) {
-      record_rows(tile + k, a.O, (int)rows, sum, sum_sq);
-    }
-  }
-  if (k < a.O) { a.norm_acc[k] = sum; a.norm_acc[a.O + k] = sum_sq; }
+  buffer_store_body(a, tile, 16384, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------- host helpers
@@ -744,7 +707,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
                   float* h2, float* head0, float* head1, int ldh, bool tanh_head,
                   hipStream_t st, const PolicyTail* tail = nullptr, bool* tail_done = nullptr,
                   int ldx = 0, const ActorImg* img = nullptr, const CollectorStep* step = nullptr,
-                  float* rows_out = nullptr) {
+                  float* rows_out = nullptr, const BufferStoreArgs* store = nullptr) {
   ActorParams p(params, s);
   if (ldx <= 0) ldx = s.O;                      // dense observation rows unless told otherwise
   if (tail_done != nullptr) *tail_done = false;
@@ -764,6 +727,7 @@ int actor_forward(const float* params, ActorShape s, const float* obs, int B, fl
       f.img = FwdImages{img->block, img->v.f1, img->v.f2, {img->v.fh[0], img->v.fh[s.heads - 1]}, 0, 0};
     if (step != nullptr) {       // a step of a collector's block: completion words, the rows' device copy
       f.done_flags = step->done_flags; f.done_seq = step->seq; f.rows_out = rows_out; f.rows_ld = s.O;
+      if (store != nullptr) { f.store = *store; f.store_on = 1; }
     }
     if (tail != nullptr && g_policy_tail != 0 && mlp_policy_tail_supported(s.H, s.A)) {
       f.post = tail->post; f.post_eps = tail->eps; f.post_actions = tail->actions;
@@ -1107,7 +1071,8 @@ extern "C" int64_t tonic_mlp_actor_image_bytes(int32_t O, int32_t H, int32_t A, 
 
 extern "C" int tonic_collector_q_act(tonic_collector_t* collector, const float* d_actor_params,
                                      void* d_actor_images, int32_t rebuild_images, int32_t kind,
-                                     int32_t H, int32_t eps_slot, float* d_rows_out, void* d_workspace,
+                                     int32_t H, int32_t eps_slot, float* d_rows_out,
+                                     const tonic_q_store_t* store, void* d_workspace,
                                      int64_t workspace_bytes, void* stream) {
   TONIC_REQUIRE(collector && d_actor_params && d_actor_images && d_workspace && (kind == 0 || kind == 1),
                 TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_q_act: bad argument");
@@ -1133,13 +1098,26 @@ extern "C" int tonic_collector_q_act(tonic_collector_t* collector, const float* 
     add_actor_images(build, d_actor_params, s, img);
     TRY(launch_build_images(build, st));
   }
+  TONIC_REQUIRE(store == nullptr ||
+                    (store->d_buf_observations && store->d_buf_actions && store->d_buf_next_observations &&
+                     store->d_buf_rewards && store->d_buf_resets && store->d_buf_terminations &&
+                     store->d_buf_discounts && store->d_observations && store->row >= 0),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_collector_q_act: bad store argument");
   CollectorStep step{};
-  TRY(collector_begin_q_step(collector, eps_slot, &step));
+  TRY(collector_begin_q_step(collector, eps_slot, store != nullptr ? 1 : 0, &step));
+  BufferStoreArgs st_args{};
+  if (store != nullptr) {      // the previous step's transition: the block's outcome fields, read in place
+    st_args = BufferStoreArgs{store->d_buf_observations, store->d_buf_actions, store->d_buf_next_observations,
+                              store->d_buf_rewards, store->d_buf_resets, store->d_buf_terminations,
+                              store->d_buf_discounts, store->d_observations, step.actions, step.next_observations,
+                              step.rewards, step.resets, step.terminations, store->d_norm_acc, store->row, W, O, A,
+                              (float)store->discount_factor};
+  }
   PolicyTail tail{};
   tail.post = kind == 0 ? POST_COPY : POST_SQUASHED_SAMPLE; tail.eps = step.eps; tail.actions = step.actions_out;
   bool tail_done = false;
   TRY(actor_forward(d_actor_params, s, step.observations, B, h1, h2, head0, head1, ldh, kind == 0, st, &tail,
-                    &tail_done, 0, &img, &step, d_rows_out));
+                    &tail_done, 0, &img, &step, d_rows_out, store != nullptr ? &st_args : nullptr));
   TONIC_REQUIRE(tail_done, TONIC_ERR_UNSUPPORTED_SHAPE, "tonic_collector_q_act: the policy tail did not fuse");
   TONIC_CHECK_LAUNCH("tonic_collector_q_act");
   return TONIC_OK;

@@ -94,6 +94,40 @@ class Buffer:
         self.index = (self.index + 1) % self.max_size
         self.size = min(self.size + 1, self.max_size)
 
+    def reserve_row(self, normalizer=None):
+        """The host half of `store` for a transition whose device write is issued later (the off-policy agents'
+        acting launch carries it: tonic_collector_q_act): the row it will occupy, the circular index and the size
+        advanced (buffers.py:54-56), the normaliser's record count noted.  Needs an allocated Buffer and
+        return_steps == 1 (the n-step accumulation reads the stored row right away)."""
+        assert self.buffers is not None and self.return_steps == 1
+        row = self.index
+        if normalizer is not None:
+            normalizer.note_device_rows(self.num_workers)
+        self.index = (self.index + 1) % self.max_size
+        self.size = min(self.size + 1, self.max_size)
+        return row
+
+    def store_at(self, row, normalizer=None, **kwargs):
+        """The device half of a reserved transition on its own (tonic_buffer_store into `row`): what the acting
+        launch would have carried, when no acting launch follows (an update is due first, the policy sits out)."""
+        b, p = self.buffers, _lib.ptr
+        sums = normalizer.device_sums if normalizer is not None else None
+        _lib.check(self.lib.tonic_buffer_store(
+            p(b['observations']), p(b['actions']), p(b['next_observations']), p(b['rewards']),
+            p(b['resets']), p(b['terminations']), p(b['discounts']), p(kwargs['observations']),
+            p(kwargs['actions']), p(kwargs['next_observations']), p(kwargs['rewards']),
+            p(kwargs['resets']), p(kwargs['terminations']), p(sums), row,
+            self.num_workers, self.observation_size, self.action_size,
+            float(self.discount_factor), _lib.current_stream()), 'tonic_buffer_store')
+
+    def store_arguments(self, row, observations, normalizer=None):
+        """tonic_q_store_t for `row` (see reserve_row): the Buffer's arrays, the observation rows' device copy."""
+        b, p = self.buffers, _lib.ptr
+        sums = normalizer.device_sums if normalizer is not None else None
+        return _lib.QStore(p(b['observations']), p(b['actions']), p(b['next_observations']), p(b['rewards']),
+                           p(b['resets']), p(b['terminations']), p(b['discounts']), p(observations), p(sums),
+                           row, float(self.discount_factor))
+
     def sample_indices(self, iterations=None):
         """The index stream of `iterations` successive Buffer.get draws (buffers.py:85-86)."""
         total = self.size * self.global_workers

@@ -1260,6 +1260,8 @@ class DDPG(Agent):
         self._workers = None
         self._policy_io = {}
         self._q_blocks = {}
+        self._q_last = None
+        self._q_act = _lib.hot('tonic_collector_q_act')      # (per environment step: the vectorcall shim if built)
         self._actor_images = None             # the acting launch's weight images of the actor (tonic_collector_q_act)
         self._actor_images_stale = True
         self._actor_images_version = -1
@@ -1267,7 +1269,9 @@ class DDPG(Agent):
         self._slots, self._slot_index = {}, 0
 
     def close(self):
-        """Gives back what the agent holds beyond its tensors (the process's CPU binding: parallel.bind_near_gpu)."""
+        """Stores what is still deferred; gives back what the agent holds beyond its tensors (the process's CPU
+        binding: parallel.bind_near_gpu)."""
+        self.settle()
         if getattr(self, '_holds_affinity', False):
             self._holds_affinity = False
             parallel.release_affinity()
@@ -1277,6 +1281,15 @@ class DDPG(Agent):
         """The collector block these observations live in when the policy can act on it in place
         (tonic_collector_q_act: the environments of tonic_amd.environments hand out views of their shared block;
         plain torsos the fused forward holds; one process per block's GPU handle) — None: the staged copies."""
+        cached = self._q_last                      # (three look-ups per loop iteration: the same view each time)
+        if cached is not None and cached[0] is observations and cached[1] == kind:
+            return cached[2]
+        state = self._find_block(observations, kind)
+        if isinstance(observations, np.ndarray):
+            self._q_last = (observations, kind, state)
+        return state
+
+    def _find_block(self, observations, kind):
         if kind not in (0, 1) or self.hidden is None or os.environ.get('TONIC_AMD_Q_BLOCK', '1') == '0':
             return None
         if self._actor_images is None:          # (once: does the fused forward on weight images serve this policy?)
@@ -1297,7 +1310,8 @@ class DDPG(Agent):
             need = self.lib.tonic_offpolicy_workspace_bytes(W, self.observation_size, self.action_size, self.hidden)
             state = dict(block=block, collector=Collector.for_block(block, 0),
                          workspace=torch.empty(need, dtype=torch.uint8, device=self.device),
-                         rows=torch.zeros(W, self.observation_size, device=self.device), usable=True)
+                         rows=[torch.zeros(W, self.observation_size, device=self.device) for _ in range(2)],
+                         turn=0, deferred=None, rows_of=None, actions_of=None, store_pending=False, usable=True)
             # the block's fields as the GPU sees them (page-locked by the collector): the store reads them in place
             def mapped(view, shape):
                 address = self.lib.tonic_host_device_pointer(view.ctypes.data)
@@ -1325,15 +1339,49 @@ class DDPG(Agent):
         flat = self.model.flat_online
         stale = self._actor_images_stale or flat._version != self._actor_images_version
         self._actor_images_version = flat._version
-        _lib.check(self.lib.tonic_collector_q_act(
+        # the transition of the step before (reserved by update(), its sources still in the block) rides in this
+        # launch: one more workgroup stores it while the tiles compute these actions
+        deferred, store = state['deferred'], None
+        if deferred is not None:
+            held = state.get('store_struct')        # (one tonic_q_store_t per block: two fields change per step)
+            if held is None or state.get('store_struct_of') is not self.replay.buffers:
+                held = state['store_struct'] = self.replay.store_arguments(
+                    0, state['rows'][0], self.model.observation_normalizer)
+                state['store_struct_of'] = self.replay.buffers
+                state['store_struct_rows'] = [_lib.ptr(r) for r in state['rows']]
+            held.row = deferred['row']
+            held.d_observations = state['store_struct_rows'][deferred['turn']]
+            store = ctypes.addressof(held)
+        turn = state['turn'] ^ 1          # (these rows' device copy: the buffer the pending store does not read)
+        status = self._q_act(
             collector.handle, _lib.ptr(self.model.flat_actor.flat), _lib.ptr(self._actor_images),
             int(stale), kind, self.hidden, 0 if stochastic else -1,
-            _lib.ptr(state['rows']), _lib.ptr(workspace), workspace.numel(), _lib.current_stream()),
-            'tonic_collector_q_act')
+            _lib.ptr(state['rows'][turn]), store, _lib.ptr(workspace), workspace.numel(), _lib.current_stream())
+        if status != 0:
+            _lib.check(status, 'tonic_collector_q_act')
         self._actor_images_stale = False
-        collector.wait_actions()
-        state['rows_of'] = block          # the device copy of these observation rows: for the next store
+        collector.wait_actions()          # (every completion word, the store's included)
+        state['deferred'], state['store_pending'] = None, False
+        state['turn'], state['rows_of'] = turn, block
         return block.eps[1].copy()
+
+    def _flush_store(self, state):
+        """A reserved transition goes out as a launch of its own (no acting launch will carry it in time)."""
+        deferred = state['deferred']
+        if deferred is None:
+            return
+        self.replay.store_at(deferred['row'], self.model.observation_normalizer,
+                             observations=state['rows'][deferred['turn']], **state['fields'])
+        state['deferred'], state['store_pending'] = None, True
+
+    def settle(self):
+        """Everything this agent has deferred is on the device: reserved transitions stored, their launches through
+        (readers of `replay.buffers` between two steps call this; `close` does)."""
+        for state in getattr(self, '_q_blocks', {}).values():
+            self._flush_store(state)
+            if state['store_pending']:
+                torch.cuda.current_stream().synchronize()
+                state['store_pending'] = False
 
     def _forward_policy(self, observations, kind, stochastic):
         state = self._block_of(observations, kind)
@@ -1406,10 +1454,13 @@ class DDPG(Agent):
         state = self._block_of(observations, self.policy_kind)
         if state is not None:
             block = state['block']
-            if state.get('store_pending') and state['rows_of'] is not block:
-                # the last store launch reads the block in place and no acting launch was waited for behind it
-                # (warm-up: uniform actions): it must be through before the environment overwrites the block
-                torch.cuda.current_stream().synchronize()
+            if state['rows_of'] is not block:
+                # the policy sat this step out (warm-up: uniform actions): no acting launch carried the reserved
+                # transition or was waited for behind a store launch — they read the block in place and must be
+                # through before the environment overwrites it
+                self._flush_store(state)
+                if state['store_pending']:
+                    torch.cuda.current_stream().synchronize()
             state['store_pending'] = False
             # the executed actions go into the environment's block (where the store launch reads them); policy
             # actions (float32) are handed out as the block's own view — value-identical, and the environments of
@@ -1436,16 +1487,20 @@ class DDPG(Agent):
         state = self._block_of(self._stepped_on, self.policy_kind)
         if state is None or state.get('actions_of') is not block:      # (step() put the executed actions there)
             return False
-        if state.get('rows_of') is block:
-            rows = state['rows']
-        else:                                   # (warm-up: uniform actions, the policy never saw these rows)
+        normalizer = self.model.observation_normalizer
+        if state['rows_of'] is block and self.replay.buffers is not None and self.replay.return_steps == 1:
+            # the usual step: the row is reserved now (Buffer bookkeeping, buffers.py:54-56) and written by the next
+            # acting launch, which reads the block before the environment's next step can touch it
+            state['deferred'] = dict(row=self.replay.reserve_row(normalizer), turn=state['turn'])
+            return True
+        rows = state['rows'][state['turn']]
+        if state['rows_of'] is not block:       # (warm-up: uniform actions, the policy never saw these rows)
             staged = state.setdefault('staged_rows', torch.zeros(
                 block.workers, self.observation_size, dtype=torch.float32).pin_memory())
             torch.cuda.current_stream().synchronize()        # (the previous store may still read it)
             staged.numpy()[:] = self.last_observations
-            rows = state['rows']
             rows.copy_(staged, non_blocking=True)
-        self.replay.store(normalizer=self.model.observation_normalizer, observations=rows, **state['fields'])
+        self.replay.store(normalizer=normalizer, observations=rows, **state['fields'])
         state['store_pending'] = True
         return True
 
@@ -1454,7 +1509,9 @@ class DDPG(Agent):
             if self.model.return_normalizer:
                 raise NotImplementedError('return normalisers are not supported')
             if self.replay.ready(steps):
-                self._update(steps)          # (ends with a read-back: the store launch is through)
+                for state in self._q_blocks.values():
+                    self._flush_store(state)         # the update samples this transition too
+                self._update(steps)          # (ends with a read-back: the store launches are through)
                 for state in self._q_blocks.values():
                     state['store_pending'] = False
             self.exploration.update(resets)
