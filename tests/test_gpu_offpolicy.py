@@ -360,18 +360,24 @@ def test_offpolicy_full_size_iteration_vs_oracle(lib, kind, O, A, W, B, support)
         np.testing.assert_allclose(got, value - state['pre/' + key], rtol=0, atol=1e-5, err_msg=key)
 
 
-@pytest.mark.parametrize('kind', ['sac', 'td3'])
-def test_plain_torsos_of_1024_units_stay_on_the_hip_entries(lib, kind):
-    """two ReLU layers of 1024 units are a PLAIN width of the C ABI's `H` argument (tonic_mlp_hidden
-    packs only unequal / non-ReLU torsos, bit 30 set) and run on the HIP entries layer by layer (csrc/gemm16.hip)
-    — not on stock torch operators: `updater.stock is False`, and two learner iterations agree with the torch-CPU
-    oracle from identical parameters, buffer, indices and noise."""
+@pytest.mark.parametrize('kind,O,A,hidden,B', [
+    ('sac', 17, 6, 1024, 64), ('td3', 17, 6, 1024, 64),
+    # the corners of the image passes (csrc/mlpimg_body.h): inputs wider than 256 columns (two passes over the
+    # row, Humanoid-v3's 376 + 17), widths of 16 mod 32 (the zeroed upper half of the last k-chunk), more than 32
+    # actions (two k-chunks per head in the actor's chain), batches that are no multiple of 16
+    ('sac', 376, 17, 48, 40), ('td3', 300, 6, 80, 33), ('sac', 60, 30, 256, 50), ('td3', 9, 33, 112, 100)])
+def test_plain_torsos_of_other_widths_vs_oracle(lib, kind, O, A, hidden, B):
+    """Equal-width ReLU torsos other than the default 256 on the HIP entries — never on stock torch operators:
+    `updater.stock is False`.  1 024 units (a PLAIN width of the C ABI's `H` argument, tonic_mlp_hidden
+    packs only unequal / non-ReLU torsos, bit 30 set) run layer by layer (csrc/gemm16.hip); widths up to 256 on
+    the fused passes and their fp16x2 weight images, here at the shapes' corners.  Two learner iterations agree with
+    the torch-CPU oracle from identical parameters, buffer, indices and noise."""
     import tonic_amd
     import tonic_amd.torch as tt
     import torch_port
     from tonic_amd.environments import Box
     assert lib.tonic_mlp_hidden(1024, 1024, 1) == 1024 and lib.tonic_mlp_hidden(400, 300, 1) & (1 << 30)
-    O, A, W, B, rows, hidden = 17, 6, 2, 64, 48, 1024
+    W, rows = 2, 48
     rng = np.random.RandomState(17)
     relu = torch.nn.ReLU
     head = (tt.models.GaussianPolicyHead(loc_activation=torch.nn.Identity,
@@ -387,7 +393,7 @@ def test_plain_torsos_of_1024_units_stay_on_the_hip_entries(lib, kind):
     agent = dict(sac=tt.agents.SAC, td3=tt.agents.TD3)[kind](model=model, replay=replay)
     agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
     assert agent.critic_updater.stock is False and agent.actor_updater.stock is False
-    assert agent.hidden == hidden
+    assert agent.hidden == hidden and (agent._fused_kind() is not None) == (hidden <= 256)
     state = {'pre/' + k: v.detach().cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
     host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
                 next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
@@ -407,10 +413,12 @@ def test_plain_torsos_of_1024_units_stay_on_the_hip_entries(lib, kind):
     for key, value in oracle.state().items():
         got = after[key].detach().cpu().numpy() - state['pre/' + key]
         diff = np.abs(got - (value - state['pre/' + key]))
-        # Adam's first steps move every element by ~lr whatever its gradient's size: one element in a million whose
-        # gradient is at float32 rounding level (1 of 1 048 576 in actor.torso.model.2.weight, td3) takes a step
-        # of its own — 1.6e-5 here; the reference itself does that when its summation order changes
-        assert (diff <= 1e-5).mean() >= 0.99999 and diff.max() <= 2 * lr, (key, diff.max(), (diff > 1e-5).sum())
+        # Adam's first steps move every element by ~lr whatever its gradient's size: an element whose gradient is at
+        # float32 rounding level takes a step of its own (seen: 1 of 1 048 576 in actor.torso.model.2.weight at 1 024
+        # units, 1.6e-5; 1 of 12 544 in critic_1.torso.model.2.weight at 112 units, 6.2e-5); the reference itself does
+        # that when its summation order changes.  At most one such element per tensor (1e-5 of a large one)
+        violations = int((diff > 1e-5).sum())
+        assert violations <= max(1, int(1e-5 * diff.size)) and diff.max() <= 2 * lr, (key, diff.max(), violations)
 
 
 @pytest.mark.parametrize('kind,O,A,W,B,hidden', [

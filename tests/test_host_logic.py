@@ -52,6 +52,37 @@ def test_library_exports_every_declared_symbol():
     assert status == -1 and b'unknown key' in loaded.tonic_last_error()
 
 
+def test_offpolicy_size_queries_and_hidden_codes():
+    """Host-side queries of the off-policy entries (no GPU work): the `H` argument carries a plain width of any size
+    as it is and packs every other two-layer torso with bit 30 set (plain widths of 1 024 and more used to
+    fall off the kernels); the workspaces hold the fp16x2 weight images of the networks (csrc/mlpimg.h: [16-feature
+    tiles][32-wide k-chunks][hi, lo] blocks of 1 KB per term) where the image passes serve the shape, and none where
+    they do not."""
+    from tonic_amd import _lib
+    lib = _lib.load()
+    for width in (16, 256, 1023, 1024, 4000):
+        assert lib.tonic_mlp_hidden(width, width, 1) == width
+    packed = lib.tonic_mlp_hidden(400, 300, 1)
+    assert packed & (1 << 30) and packed & 4095 == 400 and (packed >> 12) & 4095 == 300 and (packed >> 24) & 7 == 1
+    assert lib.tonic_mlp_hidden(256, 256, 2) & (1 << 30)          # Tanh: not the plain torso
+    assert lib.tonic_mlp_hidden(4096, 256, 1) == -1 and lib.tonic_mlp_hidden(256, 256, 4) == -1
+
+    def image_bytes(M, K):
+        return ((M + 15) // 16) * ((K + 31) // 32) * 2 * 1024
+    O, A, H = 111, 8, 256
+    # SAC actor: W1, W2, W2^T, and per head Wh, Wh^T
+    want = image_bytes(H, O) + 2 * image_bytes(H, H) + 2 * (image_bytes(A, H) + image_bytes(H, A))
+    assert lib.tonic_mlp_actor_image_bytes(O, H, A, 2) == (want + 255) // 256 * 256
+    assert lib.tonic_mlp_actor_image_bytes(O, H, A, 1) < lib.tonic_mlp_actor_image_bytes(O, H, A, 2)
+    assert lib.tonic_mlp_actor_image_bytes(O, 400, A, 1) == 0      # wider than the fused passes hold
+    assert lib.tonic_mlp_actor_image_bytes(O, packed, A, 1) == 0   # not a plain torso
+    critic = image_bytes(H, O + A) + 2 * image_bytes(H, H) + image_bytes(A, H)
+    images = 2 * lib.tonic_mlp_actor_image_bytes(O, H, A, 2) + 2 * ((2 * critic + 255) // 256 * 256)
+    assert lib.tonic_q_iteration_workspace_bytes(1024, O, A, H) >= images
+    assert lib.tonic_offpolicy_workspace_bytes(1024, O, A, H) >= images
+    assert lib.tonic_q_iteration_supported(O, H, A, 2) == 1 and lib.tonic_q_iteration_supported(O, packed, A, 2) == 0
+
+
 def test_agents_fail_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
