@@ -1385,6 +1385,11 @@ class DDPG(Agent):
 
     def _forward_policy(self, observations, kind, stochastic):
         state = self._block_of(observations, kind)
+        for other in self._q_blocks.values():
+            # a transition reserved on ANOTHER block (test episodes between training steps, a second environment)
+            # does not wait for that block's next acting launch
+            if other is not state and other['deferred'] is not None:
+                self._flush_store(other)
         if state is not None:
             actions = self._act_on_block(state, kind, stochastic)
             if actions is not None:
