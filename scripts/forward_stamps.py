@@ -29,7 +29,7 @@ raw = stamps.cpu().numpy()
 both, tn = raw[:128].reshape(8, 16), raw[128:].reshape(8, 8)
 s, cycles = both[:, :8], both[:, 8:]
 names = ['target actor', 'four critics', 'online actor', 'two critics'] * 2
-labels = ['loads issued', 'layer 1', 'epilogue+barrier', 'layer 2', 'epilogue+barrier', 'heads/out', 'tail']
+labels = ['inputs->LDS', 'layer 1', 'epilogue 1', 'layer 2', 'epilogue 2', 'heads/out', 'tail']
 print('B', B)
 for i in range(8):
     t = s[i]

@@ -125,6 +125,9 @@ struct MlpFwdArgs {
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
   unsigned long long* stamps;   // developer probe (tonic_debug_forward_stamps): null in the product path
   FwdImages img;                // img.block != null: the products run on fp16x2 terms from weight images (mlpimg.h)
+  int hidden_from;              // image pass: h1 / h2 go to HBM only for networks >= hidden_from (a network without a
+                                //   backward — the targets, the critic step's policy — has no reader for them: at
+                                //   B = 1 024 a quarter of the fused iteration's HBM writes)
   // acting on a collector's block (tonic_collector_q_act): every workgroup copies its 16 input rows (K1 columns)
   // to rows_out (rows_ld apart; null: no copy), releases its stores to the SYSTEM (the tail wrote the actions into
   // mapped host memory) and then writes done_seq into done_flags[blockIdx.x] at system scope — the host polls
@@ -192,6 +195,7 @@ struct MlpBwdArgs {
   unsigned* exchange_failed;    // chained launches: l_tq / l_q / hb_dxa* are exchange words (exchange_read), dxa is
                                 //   written with exchange_write; the word a reader sets when a value never came
   BwdImages img;                // img.block != null: the products run on fp16x2 terms from weight images (mlpimg.h)
+  int skip_dz;                  // image pass: dz2 / dz1 stay out of HBM (a frozen network's chain: no weight gradients)
 };
 enum MlpBwdLoss : int { LOSS_GIVEN = 0, LOSS_TD = 1, LOSS_ACTOR = 2 };
 

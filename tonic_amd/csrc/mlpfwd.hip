@@ -1045,7 +1045,6 @@ int launch_mlp_forward(const MlpFwdArgs& a, int nets, hipStream_t stream) {
                   "mlp_forward: K1=%d H=%d outside the image pass", a.K1, a.H);
     const ImgLds L = img_lds(a.K1, a.H);
     launch.tail_offset = L.off_f32 / 4;
-    launch.stamps = nullptr;
     launch.lds_floats = L.total / 4;
     TONIC_REQUIRE(a.store_on == 0 || (nets == 1 && a.done_flags != nullptr && a.store.O <= L.total / 4),
                   TONIC_ERR_INVALID_ARGUMENT, "mlp_forward: a store role needs a single-network collector step");

@@ -144,8 +144,9 @@ __device__ __forceinline__ void img_publish(const ImgPublish& p, const float (&v
     const int f = 16 * p.tile_of[j] + 4 * p.g;
 #pragma unroll
     for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[j][e]));
-    if (p.row_ok) *reinterpret_cast<f32x4_dword*>(global + (int64_t)(p.r0 + p.m) * ld + f) =
-        f32x4_dword{v[j][0], v[j][1], v[j][2], v[j][3]};
+    if (p.row_ok && global != nullptr)                  // (null: nobody reads this row from HBM)
+      *reinterpret_cast<f32x4_dword*>(global + (int64_t)(p.r0 + p.m) * ld + f) =
+          f32x4_dword{v[j][0], v[j][1], v[j][2], v[j][3]};
   }
   if (!operand) return;                                 // scalar
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -191,10 +192,21 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
   const int post = second ? a.tail2.post : a.post;
   const int64_t poff = net * a.stride_params + (second ? a.second_params : 0);
   const char* images = a.img.block + net * a.img.stride + (second ? a.img.second : 0);
+  // developer probe (tonic_debug_forward_stamps): wall-clock stamps (10 ns ticks) of workgroup (0, 0)
+  const bool probe = a.stamps != nullptr && bx == 0 && net == 0 && tid == 0;
+  auto stamp = [&](int i) {
+    if (probe) {
+      __builtin_amdgcn_sched_barrier(0);
+      a.stamps[i] = wall_clock64();
+      a.stamps[8 + i] = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
   const float* b1 = a.b1 + poff;
   const float* b2 = a.b2 + poff;
-  float* h1g = a.h1 + net * a.stride_hidden;
-  float* h2g = a.h2 + net * a.stride_hidden;
+  float* h1g = net >= a.hidden_from ? a.h1 + net * a.stride_hidden : nullptr;      // (scalar)
+  float* h2g = net >= a.hidden_from ? a.h2 + net * a.stride_hidden : nullptr;
   _Float16* A_hi = reinterpret_cast<_Float16*>(lds + L.off_a);
   _Float16* A_lo = A_hi + kRows * L.pa;
   _Float16* B_hi = reinterpret_cast<_Float16*>(lds + L.off_b);
@@ -214,6 +226,23 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) tile_of[j] = min(wave + 4 * j, tiles - 1);
 
+  // The input rows are requested FIRST (thread = (row, 4-column slot)): a wave's loads return in issue order, and
+  // the split below waits for these — behind the weight blocks and biases they cost 1 us more per pass
+  // (profiles/r06_forward_stamps_images.txt: inputs -> LDS 2.5 us against 1.4 us of entry for the float32 pass).
+  const int prow = tid >> 4, slot = tid & 15;
+  const float* xrow = (second ? a.X2 : a.X) + (int64_t)min(r0 + prow, a.B - 1) * a.ldx;
+  const int U = (KP1 + 63) / 64;                      // scalar: 64-column strips
+  auto element = [&](int c) { const float v = xrow[min(c, K1 - 1)]; return c < K1 ? v : 0.f; };
+  float xv[4][4];                                     // (K1 <= 256: the row's share stays in registers)
+  if (U <= 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u >= U) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[u][e] = element(64 * u + 4 * slot + e);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // layer 1's first weight blocks, then everything else that does not depend on activations
   ImgLayer<kMaxTiles> l1;
   l1.start(images + a.img.f1.off, a.img.f1.chunks, tile_of, lane);
@@ -240,12 +269,8 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
 #pragma unroll
   for (int e = 0; e < 4; ++e) hbias[e] = bh[min(16 * head_tile + 4 * g + e, a.NH - 1)];
 
-  // ---- the 16 input rows -> region A as hi / lo terms in each row's own unit: thread = (row, 4-column slot)
+  // ---- the 16 input rows -> region A as hi / lo terms in each row's own unit
   {
-    const int prow = tid >> 4, slot = tid & 15;
-    const float* xrow = (second ? a.X2 : a.X) + (int64_t)min(r0 + prow, a.B - 1) * a.ldx;
-    const int U = (KP1 + 63) / 64;                    // scalar: 64-column strips
-    auto element = [&](int c) { const float v = xrow[min(c, K1 - 1)]; return c < K1 ? v : 0.f; };
     auto store4 = [&](int c0, float x0, float x1, float x2, float x3, float unit) {
       unsigned h0, l0, h1, l1;
       img_split(x0 * unit, x1 * unit, h0, l0);
@@ -254,17 +279,13 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
       *reinterpret_cast<img_u32x2*>(A_lo + prow * L.pa + c0) = img_u32x2{l0, l1};
     };
     int ex;
-    if (U <= 4) {                                     // (K1 <= 256: the row's share stays in registers)
-      float xv[4][4];
+    if (U <= 4) {
       float amax = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u >= U) break;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xv[u][e] = element(64 * u + 4 * slot + e);
-          amax = fmaxf(amax, fabsf(xv[u][e]));
-        }
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(xv[u][e]));
       }
       ex = row_exponent(img_row_max16(amax));
       const float unit = img_pow2(kActTop - ex);
@@ -302,12 +323,14 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
     if (slot == 0) desc[prow] = img_pow2(ex - kActTop - kImgScaleExp);
   }
   __syncthreads();
+  stamp(1);                                           // input rows fetched, split, published
 
   const ImgPublish pub{rowmax, desc, wave, m, g, tiles, H, r0, row_ok, tile_of};
   f32x4 acc[kMaxTiles];
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   l1.run(acc, A_hi + m * L.pa + 8 * g, A_lo + m * L.pa + 8 * g);
+  stamp(2);                                           // layer 1's products
   ImgLayer<kMaxTiles> l2;
   l2.start(images + a.img.f2.off, a.img.f2.chunks, tile_of, lane);     // W2's first blocks fly over the epilogue
   {
@@ -319,10 +342,12 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
       for (int e = 0; e < 4; ++e) h[j][e] = fmaxf(fmaf(acc[j][e], dsc, bias1[j][e]), 0.f);
     img_publish(pub, h, h1g, a.ldh, true, B_hi, B_lo, L.pb, 1);
   }
+  stamp(3);                                           // layer 1's epilogue: h1 to HBM, unit, split, two barriers
 
 #pragma unroll
   for (int j = 0; j < kMaxTiles; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   l2.run(acc, B_hi + m * L.pb + 8 * g, B_lo + m * L.pb + 8 * g);
+  stamp(4);                                           // layer 2's products
   // a head tile is one short chain on one wave: all of its weight blocks are requested here, over the second
   // layer's epilogue and its barriers
   img_u32x4 wh[kImgMaxChunks][2];
@@ -370,9 +395,11 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
         exchange_write(a.xq + (int64_t)bx * kExchangeTileFloats + slot + m, q);
       }
     }
+    stamp(5);                                         // value head out
     return;
   }
   img_publish(pub, h2, h2g, a.ldh, true, A_hi, A_lo, L.pa, 0);
+  stamp(5);                                           // layer 2's epilogue
 
   // heads: one [16 outputs][16 rows] tile per head wave
   if (head_wave) {
@@ -406,8 +433,10 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
       }
     }
   }
+  stamp(6);                                           // heads
   if (post == POST_NONE) return;                    // scalar
   policy_tail(a, second, r0, lds_f);                  // (a.tail_offset = L.off_f32 / 4: set by the launcher)
+  stamp(7);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -426,8 +455,8 @@ __device__ __forceinline__ void mlp_backward_body_img(const MlpBwdArgs& a, const
   const char* images = a.img.block + net * a.img.stride;
   const float* h1g = a.h1 + net * a.stride_hidden;
   const float* h2g = a.h2 + net * a.stride_hidden;
-  float* dz2g = a.dz2 + net * a.stride_hidden;
-  float* dz1g = a.dz1 + net * a.stride_hidden;
+  float* dz2g = a.skip_dz ? nullptr : a.dz2 + net * a.stride_hidden;                 // (scalar)
+  float* dz1g = a.skip_dz ? nullptr : a.dz1 + net * a.stride_hidden;
   _Float16* A_hi = reinterpret_cast<_Float16*>(lds + L.off_a);
   _Float16* A_lo = A_hi + kRows * L.pa;
   _Float16* B_hi = reinterpret_cast<_Float16*>(lds + L.off_b);

@@ -801,8 +801,9 @@ int critics_forward(const float* params, CriticShape s, int nets, const float* X
   const int64_t hs = (int64_t)Bp * HP;
   if (s.plain() && mlp_forward_supported(s.H, 1, 1)) {              // one launch for all `nets` critics
     int launch_nets = 0;
-    const MlpFwdArgs f = critics_forward_args(params, s, nets, X, ldx, B, Bp, h1, h2, q, params2,
-                                              X2, &launch_nets, img);
+    MlpFwdArgs f = critics_forward_args(params, s, nets, X, ldx, B, Bp, h1, h2, q, params2,
+                                        X2, &launch_nets, img);
+    if (params2 != nullptr) f.hidden_from = nets;   // (the first set = the targets: forward only)
     return launch_mlp_forward(f, launch_nets, st);
   }
   if (params2 != nullptr) {            // unfused path: one pass per parameter set
@@ -918,7 +919,8 @@ int critics_backward(const float* params, CriticShape s, int nets, const float* 
   GemmArgs g;
   // the input-gradient chain first ...
   if (one_launch) {                                               // ... in ONE launch
-    const MlpBwdArgs b = critics_chain_args(params, s, nets, B, Bp, h1, h2, dq, dh2, dh1, dxa, loss, img);
+    MlpBwdArgs b = critics_chain_args(params, s, nets, B, Bp, h1, h2, dq, dh2, dh1, dxa, loss, img);
+    b.skip_dz = grads == nullptr ? 1 : 0;          // (a frozen critic's chain: only its action columns are read)
     TRY(launch_mlp_backward(b, nets, st));
   } else {
     // dz2 = (dq w3) * relu'(h2)
@@ -1478,6 +1480,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
       const ActorImg& pi = kind == 1 ? im.actor : im.target_actor;
       f.img = FwdImages{pi.block, pi.v.f1, pi.v.f2, {pi.v.fh[0], pi.v.fh[heads - 1]}, 0,
                         due ? im.actor.block - pi.block : 0};
+      f.hidden_from = 1;             // (net 0, the critic step's policy, has no backward)
     }
     TRY(launch_mlp_forward(f, due ? 2 : 1, st));
   }
@@ -1509,6 +1512,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     step.fwd = critics_forward_args(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all,
                                     q_all, a.d_critics, X2, &launch_nets, im.on ? &im.target_critics : nullptr);
     step.fwd.xq = xq;
+    step.fwd.hidden_from = nets;     // (the targets: forward only)
     step.bwd = critics_chain_args(a.d_critics, cs, nets, B, Bp, c_h1, c_h2, dq, dh2, dh1, nullptr, &td,
                                   critics_img);
     step.bwd.exchange_failed = failed;   // targets: lines 0, 1 of the tile; the online critics: lines 2, 3
@@ -1559,6 +1563,7 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     step.bwd = critics_chain_args(a.d_critics, cs, used, B, Bp, c_h1, c_h2, dq, dh2, dh1, dxa,
                                   &objective, critics_img);
     step.bwd.exchange_failed = failed;
+    step.bwd.skip_dz = 1;            // (the critics are frozen in the actor step: only dxa leaves their chain)
     step.bwd.l_q = xq + 128; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
     step.actor = actor_chain_args(a.d_actor, as, B, p_h1 + hs, p_h2 + hs, dloc,
                                   kind == 1 ? dspre : nullptr, ldh, da_h2, da_h1, nullptr, 0, 0, &hb, actor_img);
