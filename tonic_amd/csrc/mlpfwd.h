@@ -235,13 +235,34 @@ __device__ __forceinline__ void exchange_write(float* p, float v) {
 __device__ __forceinline__ float shared_value(const float* p, unsigned* exchange) {
   return exchange != nullptr ? exchange_read(p, exchange) : *p;
 }
+// N exchanged values at once: all N loads are issued TOGETHER (one L2 round trip when the writers are done — the
+// usual case for everything but the first), and only a word that is still empty is polled.  exchange_read one
+// after the other is a round trip EACH (its spin loop is control flow on the loaded value: nothing overlaps):
+// eight of them stood at the head of the actor role's chain (round 6).  Same values, same arithmetic.
+template <int N>
+__device__ __forceinline__ void shared_values(const float* const (&p)[N], float (&v)[N], unsigned* exchange) {
+  if (exchange == nullptr) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = *p[i];
+    return;
+  }
+  unsigned bits[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    bits[i] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    v[i] = bits[i] == kExchangeEmpty ? exchange_read(p[i], exchange) : __uint_as_float(bits[i]);
+}
 __device__ __forceinline__ float td_target(const float* rewards, const float* discounts,
                                            const float* tq, const float* logp_next, float alpha,
                                            int m, ValueLines at, int nets,
                                            unsigned* coherent = nullptr) {
   if (nets == 1) return rewards[m] + discounts[m] * shared_value(tq + at.index(0, m), coherent);
-  float next = fminf(shared_value(tq + at.index(0, m), coherent),
-                     shared_value(tq + at.index(1, m), coherent));
+  const float* const where[2] = {tq + at.index(0, m), tq + at.index(1, m)};
+  float both[2];
+  shared_values(where, both, coherent);
+  float next = fminf(both[0], both[1]);
   if (logp_next) next = next - alpha * logp_next[m];
   return rewards[m] + discounts[m] * next;
 }
@@ -250,8 +271,10 @@ __device__ __forceinline__ float td_target(const float* rewards, const float* di
 __device__ __forceinline__ float actor_dq(const float* q, int m, ValueLines at, int twin, int z,
                                           unsigned* coherent = nullptr) {
   if (!twin) return -1.f;
-  const float q1 = shared_value(q + at.index(0, m), coherent),
-              q2 = shared_value(q + at.index(1, m), coherent);
+  const float* const where[2] = {q + at.index(0, m), q + at.index(1, m)};
+  float both[2];
+  shared_values(where, both, coherent);
+  const float q1 = both[0], q2 = both[1];
   if (z == 0) return q1 < q2 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
   return q2 < q1 ? -1.f : (q1 == q2 ? -0.5f : 0.f);
 }

@@ -241,6 +241,16 @@ __device__ __forceinline__ void policy_tail(const MlpFwdArgs& a, const bool seco
       sdev[u] = a.enc_std[c];
     }
   }
+  // ... and so are this thread's noise draws and stored actions (round 6: loaded inside the action loop, under
+  // lane-predicated branches, each waited for where it was used: 1.8 us of the tail's 3.6 for two actions per
+  // thread, profiles/r06_forward_stamps_images.txt); clamped addresses, selected below
+  float eps4[kPostPitch / 16], act4[kPostPitch / 16];
+#pragma unroll
+  for (int u = 0; u < kPostPitch / 16; ++u) {
+    const int64_t at = src * A + min(slot + 16 * u, A - 1);
+    eps4[u] = post_eps != nullptr ? post_eps[at] : 0.f;                         // (scalar conditions)
+    act4[u] = (enc_out != nullptr && enc_out2 != nullptr) ? enc_act2[at] : 0.f;
+  }
   __syncthreads();
   const float* headbuf = lds + a.tail_offset;         // [2 heads][16 rows][kPostPitch]
   const int padded = (A + 15) / 16 * 16;
@@ -255,7 +265,7 @@ __device__ __forceinline__ void policy_tail(const MlpFwdArgs& a, const bool seco
       const float first = headbuf[prow * kPostPitch + aa];
       if (post == POST_SQUASHED_SAMPLE) {
         const bool has_eps = post_eps != nullptr;
-        const float eps = (has_eps && ok) ? post_eps[grow * A + aa] : 0.f;
+        const float eps = (has_eps && ok) ? eps4[u] : 0.f;
         const SquashedSample sm =
             squashed_sample(first, headbuf[(kRows + prow) * kPostPitch + aa], eps, has_eps);
         term4[u] = sm.logp_term;
@@ -266,14 +276,14 @@ __device__ __forceinline__ void policy_tail(const MlpFwdArgs& a, const bool seco
         action = sm.action;
       } else if (ok) {
         action = post == POST_TARGET_NOISE
-                     ? noisy_target_action(first, post_eps[grow * A + aa], a.noise_scale, a.noise_clip)
+                     ? noisy_target_action(first, eps4[u], a.noise_scale, a.noise_clip)
                      : first;
         post_actions[grow * A + aa] = action;
       }
       if (ok && enc_out != nullptr) {               // the critics' input: action columns
         enc_out[grow * a.enc_ld + a.enc_O + aa] = action;
         if (enc_out2 != nullptr)
-          enc_out2[grow * a.enc_ld + a.enc_O + aa] = enc_act2[grow * A + aa];
+          enc_out2[grow * a.enc_ld + a.enc_O + aa] = act4[u];
       }
     }
   }
@@ -687,12 +697,17 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
       const int A = a.NH;
       const int64_t src = min((int64_t)r0 + hb_row, (int64_t)a.B - 1);
       const float* dxa1 = a.hb_dxa1 != nullptr ? a.hb_dxa1 : a.hb_dxa0;
+      const float* where[2 * kHeadSlots];
+      float got[2 * kHeadSlots];
 #pragma unroll
       for (int u = 0; u < kHeadSlots; ++u) {
         const int aa = min(hb_slot + 16 * u, A - 1);
-        hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
-        hb_second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+        where[2 * u] = a.hb_dxa0 + src * a.hb_ldxa + aa;
+        where[2 * u + 1] = dxa1 + src * a.hb_ldxa + aa;
       }
+      shared_values(where, got, co);                   // (all in flight together: one round trip, not eight)
+#pragma unroll
+      for (int u = 0; u < kHeadSlots; ++u) { hb_da[u] = got[2 * u]; hb_second[u] = got[2 * u + 1]; }
     }
   }
   if (formed && a.hb_dxa1 != nullptr) {

@@ -529,12 +529,17 @@ __device__ __forceinline__ void mlp_backward_body_img(const MlpBwdArgs& a, const
     const int A = a.NH;
     const int64_t src = min((int64_t)r0 + hb_row, (int64_t)a.B - 1);
     const float* dxa1 = a.hb_dxa1 != nullptr ? a.hb_dxa1 : a.hb_dxa0;
+    const float* where[2 * kHeadSlots];
+    float got[2 * kHeadSlots];
 #pragma unroll
     for (int u = 0; u < kHeadSlots; ++u) {
       const int aa = min(hb_slot + 16 * u, A - 1);
-      hb_da[u] = load_shared(a.hb_dxa0 + src * a.hb_ldxa + aa, co);
-      hb_second[u] = load_shared(dxa1 + src * a.hb_ldxa + aa, co);
+      where[2 * u] = a.hb_dxa0 + src * a.hb_ldxa + aa;
+      where[2 * u + 1] = dxa1 + src * a.hb_ldxa + aa;
     }
+    shared_values(where, got, co);                   // (all in flight together: one round trip, not eight)
+#pragma unroll
+    for (int u = 0; u < kHeadSlots; ++u) { hb_da[u] = got[2 * u]; hb_second[u] = got[2 * u + 1]; }
   }
   if (formed && a.hb_dxa1 != nullptr) {
 #pragma unroll
