@@ -419,6 +419,29 @@ def test_late_rows_reach_the_logger_before_it_reduces_an_epoch():
     assert len(logger._before_dump) == count - 1
 
 
+def test_logger_keeps_its_own_copy_of_step_views(tmp_path):
+    """`agent.step` / `environment.step` hand out persistent views of the collector block, overwritten in
+    place by the next step (deviation 2).  The trainer stores every step's actions for the
+    epoch's statistics (trainer.py:71): the logger must reduce what each step held, not N copies of the last
+    one — arrays that own their memory are kept as they are, like the reference does."""
+    from tonic_amd.utils import logger
+    log = logger.Logger(path=str(tmp_path / 'run'))
+    block = np.zeros((4, 2), np.float32)
+    view = block.view()
+    view.setflags(write=False)
+    for step in range(3):
+        block[:] = step
+        log.store('train/action', view, stats=True)
+    owned = np.ones(3)
+    log.store('other', owned)
+    assert log.epoch_dict['other'][0] is owned
+    kept = log.epoch_dict['train/action']
+    assert [float(k[0, 0]) for k in kept] == [0.0, 1.0, 2.0]
+    log._reduce()
+    assert log.epoch_dict['train/action/mean'] == 1.0
+    assert log.epoch_dict['train/action/min'] == 0.0 and log.epoch_dict['train/action/max'] == 2.0
+
+
 def test_environments_promise_carry_over_rows(monkeypatch):
     """Sequential / Parallel / SyntheticBatch write `observations` of step t + 1 = `next_observations`
     of step t for every worker that did not reset (distributed.py:41-57) and say so in the block's

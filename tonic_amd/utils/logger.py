@@ -58,7 +58,14 @@ class Logger:
         self.start_time = time.time()
 
     def store(self, key, value, stats=False):
-        """Keeps named values during an epoch (logger.py:51-59)."""
+        """Keeps named values during an epoch (logger.py:51-59).
+
+        The reference keeps the object it is given; its agents and environments return fresh
+        arrays every step.  Here a step's outputs may be persistent views of the collector block
+        (deviation 2), overwritten in place by the next step: an array that does not
+        own its memory is kept as a copy, so an epoch's statistics are those of every step."""
+        if isinstance(value, np.ndarray) and not value.flags.owndata:
+            value = value.copy()
         bucket = self.epoch_dict.get(key)
         if bucket is None:
             self.epoch_dict[key] = [value]
