@@ -1,5 +1,6 @@
 // Shared host/device helpers for libtonic_hip.so (gfx950 only).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -144,6 +145,32 @@ __device__ __forceinline__ void add_rows32(const float* column, int rows, float&
     __builtin_amdgcn_sched_barrier(0);
   }
   for (int w = 16 * full; w < rows; ++w) acc = acc + column[w * kPitch];
+}
+
+// Every 64-byte line of the kernel's argument segment requested at the kernel's entry, as one batch of scalar
+// loads.  The latency-chain kernels of the off-policy learner take 1 - 2 KB of arguments; the compiler fetches a
+// field where it is first used (there are not enough SGPRs to hold them), and a field on a line nobody has
+// touched is a miss of the scalar cache in the middle of a dependent chain — one trip here instead (the entry
+// waits for its first arguments anyway), hits afterwards.  The loads' one destination register is dead.
+// (each load has a destination of its own, kept alive past the wait: a register the allocator had handed to
+//  something else would be overwritten when the load returns)
+template <int OFF, typename Args>
+__device__ __forceinline__ unsigned kernarg_line(Args args) {
+  unsigned sink;
+  asm volatile("s_load_dword %0, %1, %2" : "=&s"(sink) : "s"(args), "n"(OFF) : "memory");
+  return sink;
+}
+__device__ __forceinline__ void kernarg_sink(unsigned v) { asm volatile("" :: "s"(v)); }
+template <int... LINE>
+__device__ __forceinline__ void kernarg_lines(std::integer_sequence<int, LINE...>) {
+  auto args = __builtin_amdgcn_kernarg_segment_ptr();
+  const unsigned sink[] = {kernarg_line<64 * LINE>(args)...};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  (kernarg_sink(sink[LINE]), ...);
+}
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+  kernarg_lines(std::make_integer_sequence<int, (BYTES + 63) / 64>{});
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

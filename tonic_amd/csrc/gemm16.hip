@@ -543,6 +543,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmArgs& g, int tm, int tn, 
 
 __global__ __launch_bounds__(64 * kTnWaves) void gemm_tn_group_kernel(GemmGroup G) {
   __shared__ float part[kTnWaves * 64 * kTnPart];
+  kernarg_prefetch<sizeof(GemmGroup)>();
   int p = 0;
 #pragma unroll
   for (int q = 1; q < kGemmGroupMax; ++q) p += (q < G.count && (int)blockIdx.x >= G.first[q]) ? 1 : 0;

@@ -873,6 +873,7 @@ __device__ __forceinline__ void mlp_backward_body(const MlpBwdArgs& a, const int
 template <bool IMG>
 __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];     // float32: two [16][H + 4] images; IMG: img_lds
+  kernarg_prefetch<sizeof(MlpFwdArgs)>();
   if (a.store_on != 0 && blockIdx.x == gridDim.x - 1) {           // scalar: the store role of a collector step
     buffer_store_body(a.store, lds, a.lds_floats, 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // its reads of the block have returned
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpFwdArgs a) {
 template <bool IMG>
 __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  kernarg_prefetch<sizeof(MlpBwdArgs)>();
   if constexpr (IMG) mlp_backward_body_img(a, blockIdx.y, blockIdx.x, lds, 0);
   else mlp_backward_body(a, blockIdx.y, blockIdx.x, lds);
 }
@@ -924,6 +926,7 @@ __device__ __forceinline__ void chain_stats_role(const MlpBwdArgs& b) {
 template <bool IMG>
 __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  kernarg_prefetch<sizeof(QCriticStep)>();
   const int roles = 2 * c.nets;
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
 template <bool IMG>
 __global__ __launch_bounds__(256) void q_actor_step_kernel(QActorStep c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  kernarg_prefetch<sizeof(QActorStep)>();
   const int roles = c.used + 1;
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
