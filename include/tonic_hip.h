@@ -57,7 +57,7 @@ const char* tonic_last_error(void);
  * grow), tonic_mlp_hidden packs with bit 30 set (plain widths of any size pass as they are), tonic_collector_q_act)
  * and the gfx target the kernels were built for.  TONIC_ABI_VERSION is what a binding was compiled against:
  * tonic_amd/_fastcall (csrc/fastcall.c) and tonic_amd/_lib.py compare it with the loaded library's answer. */
-#define TONIC_ABI_VERSION 10
+#define TONIC_ABI_VERSION 11
 int32_t tonic_abi_version(void);
 const char* tonic_target_arch(void);
 
@@ -705,11 +705,24 @@ typedef struct tonic_q_iteration_t {
                                   written by anything but this entry's own optimizer epilogues since the workspace
                                   last served (the phases always rebuild); 0 = the images the previous iteration's
                                   epilogues left (they follow every Adam / polyak write).                          */
+  int32_t stage;               /* 0: the whole iteration; 2: everything BEHIND the policy passes (launch 1), which the
+                                  previous call has run ahead (see `ahead`): their outputs are in set `slot`.  phase 0. */
+  int32_t slot;                /* 0 / 1: which of the workspace's two sets of launch-1 outputs, exchange area and
+                                  failure word this iteration works on                                              */
+  const struct tonic_q_iteration_t* ahead;   /* NULL, or (host memory) the NEXT iteration's arguments: its policy
+                                  passes — they read the actor, the target actor, ITS batch and noise, none of which
+                                  a critic step writes — run as more workgroups of THIS iteration's critic-step
+                                  launch, into set ahead->slot (the other one).  Only when this iteration does not
+                                  step the actor (actor_due = 0: delayed updates, td3.py:43-46) and
+                                  tonic_q_iteration_ahead_supported says so; the next call then passes stage = 2.   */
 } tonic_q_iteration_t;
 
 int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H);
 /* 1 when tonic_q_iteration serves these shapes (heads: 1 deterministic, 2 Gaussian policy) */
 int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads);
+/* 1 when the next iteration's `passes` (1, 2 = it steps the actor) policy passes fit beside a critic step of `nets`
+ * twin / single critics on B rows (the image passes, every workgroup of the launch resident at once) */
+int tonic_q_iteration_ahead_supported(int32_t B, int32_t O, int32_t H, int32_t A, int32_t nets, int32_t passes);
 int tonic_q_iteration(const tonic_q_iteration_t* iteration, void* stream);
 
 /* ---- off-policy acting on a collector block --------------------------------------------------------------

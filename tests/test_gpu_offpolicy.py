@@ -539,6 +539,89 @@ def test_update_call_in_chunks_is_bit_identical(lib, monkeypatch, kind):
         assert np.array_equal(got, want, equal_nan=True), (key, np.abs(got - want).max())
 
 
+def test_capture_holds_the_garbage_collector_off(lib):
+    """A cyclic collection that starts inside a stream capture may finalize an OLDER captured graph that earlier
+    work left behind in a reference cycle: hipGraphExecDestroy while a stream captures throws from ~CUDAGraph, i.e.
+    terminates the process (scripts/capture_gc_probe.py; seen as `Fatal Python error: Aborted ... Garbage-collecting`
+    in the middle of a test session).  `_lib.capturing` — every capture of the package — collects first and keeps
+    the collector off until the capture has ended."""
+    import gc
+    import weakref
+    from tonic_amd import _lib
+    x = torch.zeros(64, device='cuda')
+
+    class Holder:
+        pass
+    holder = Holder()
+    holder.me = holder
+    holder.graph = torch.cuda.CUDAGraph()
+    with _lib.capturing(holder.graph):
+        x.add_(1)
+    holder.graph.replay()
+    torch.cuda.synchronize()
+    gone = weakref.ref(holder)
+    del holder
+    assert gc.isenabled()
+    graph = torch.cuda.CUDAGraph()
+    with _lib.capturing(graph):
+        assert not gc.isenabled() and gone() is None       # collected BEFORE the capture began
+        junk = [[i] for i in range(5000)]                  # (allocations that would have started a collection)
+        x.add_(1)
+    del junk
+    assert gc.isenabled()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 3.0
+
+
+@pytest.mark.parametrize('graph', [True, False])
+@pytest.mark.parametrize('O,A,W,B,delay,rides', [(67, 21, 64, 100, 2, True), (23, 5, 2, 64, 3, True),
+                                                 (111, 8, 1, 1024, 2, False)])
+def test_policy_passes_ahead_are_bit_identical(lib, monkeypatch, graph, O, A, W, B, delay, rides):
+    """TD3 steps its actor every `delay_steps` iterations (td3.py:43-46): the policy passes of iteration k + 1 read
+    nothing a critic step writes, so they ride as more workgroups in the critic-step launch of an iteration k that
+    leaves the actor alone (tonic_q_iteration_t.ahead: the workspace's other set of launch-1 outputs, exchange area
+    and failure word; iteration k + 1 starts behind them) — when the launch still fits the chip at once
+    (tonic_q_iteration_ahead_supported: not at B = 1 024).  The same kernels' code on the same inputs: parameters,
+    targets, moments, step counters and every logged statistic of two update calls are bit-identical with every
+    iteration by itself (TONIC_AMD_POLICY_AHEAD=0), replayed from a hipGraph and eager."""
+    import tonic_amd
+    import tonic_amd.torch as tt
+    from tonic_amd.environments import Box
+    rows, iterations = 40, 12
+    rng = np.random.RandomState(33)
+    host = dict(observations=rng.normal(size=(rows, W, O)), actions=rng.uniform(-1, 1, (rows, W, A)),
+                next_observations=rng.normal(size=(rows, W, O)), rewards=rng.normal(size=(rows, W)),
+                resets=rng.uniform(size=(rows, W)) < 0.1, terminations=rng.uniform(size=(rows, W)) < 0.05)
+    host = {k: np.asarray(v, np.float32) for k, v in host.items()}
+    monkeypatch.setenv('TONIC_AMD_UPDATE_CHUNK', '0')
+    assert bool(lib.tonic_q_iteration_ahead_supported(B, O, 256, A, 2, 2)) == rides
+    results = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TONIC_AMD_POLICY_AHEAD', mode)
+        replay = tonic_amd.replays.Buffer(size=rows * W, batch_iterations=iterations, batch_size=B)
+        agent = tt.agents.TD3(replay=replay, delay_steps=delay)
+        agent.initialize(Box(-np.inf, np.inf, (O,)), Box(-1, 1, (A,)), seed=5)
+        norm = agent.model.observation_normalizer
+        for t in range(rows):
+            replay.store(normalizer=norm, **{k: dev(v[t]) for k, v in host.items()})
+        infos = []
+        for call in range(2):
+            indices = replay.sample_indices()
+            eps = agent._draw_noise(indices.shape[0])
+            infos.append(agent.enqueue_update(indices, eps, graph=graph).cpu().numpy().copy())
+        results[mode] = dict(
+            infos0=infos[0], infos1=infos[1], online=agent.model.flat_online.cpu().numpy(),
+            target=agent.model.flat_target.cpu().numpy(),
+            critic_m=agent.critic_updater.exp_avg.cpu().numpy(), actor_v=agent.actor_updater.exp_avg_sq.cpu().numpy(),
+            steps=np.array([int(agent.critic_updater.state[0]), int(agent.actor_updater.state[0])]))
+    assert list(results['1']['steps']) == [2 * iterations, 2 * iterations // delay]
+    assert np.isfinite(results['1']['infos1'][0, :, 0]).all()
+    for key, want in results['0'].items():
+        got = results['1'][key]
+        assert np.array_equal(got, want, equal_nan=True), (key, np.abs(got - want).max())
+
+
 @pytest.mark.parametrize('kind,O,A,W,B', [('sac', 111, 8, 1, 1024), ('td3', 67, 21, 64, 100), ('ddpg', 17, 6, 4, 100)])
 def test_fused_iteration_in_phases_equals_the_split_entry_points(lib, monkeypatch, kind, O, A, W, B):
     """Whenever something must see the complete gradient sums between gradients and step — here a gradient-norm

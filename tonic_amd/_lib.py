@@ -43,7 +43,7 @@ class QIteration(ctypes.Structure):
                 ('noise_scale', c_f64), ('noise_clip', c_f64), ('target_coeff', c_f64),
                 ('critic', QOptimizer), ('actor', QOptimizer),
                 ('d_workspace', c_vp), ('workspace_bytes', c_i64), ('phase', c_i32),
-                ('refresh_images', c_i32)]
+                ('refresh_images', c_i32), ('stage', c_i32), ('slot', c_i32), ('ahead', ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/tonic_hip.h one to one.
@@ -98,6 +98,7 @@ SIGNATURES = {
                                                                     c_vp]),
     'tonic_q_iteration_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'tonic_q_iteration_supported': (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    'tonic_q_iteration_ahead_supported': (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
     'tonic_q_iteration': (ctypes.c_int, [c_vp, c_vp]),
     'tonic_polyak_update': (ctypes.c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
     'tonic_adam_polyak_step': (ctypes.c_int, [c_vp] * 5 + [c_i64] * 3 + [c_f64] * 5 + [c_i32, c_vp, c_vp,
@@ -174,7 +175,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 10       # include/tonic_hip.h: tonic_abi_version()
+ABI_VERSION = 11       # include/tonic_hip.h: tonic_abi_version()
 
 
 class TonicHipError(RuntimeError):
@@ -252,3 +253,29 @@ def ptr(tensor):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def capturing(graph, **kwargs):
+    """``torch.cuda.graph(graph)`` with Python's cyclic garbage collector held off while the stream captures.  A
+    collection that starts inside the capture may finalize device objects that earlier work left behind — tensors,
+    events, an older captured graph: hipFree / hipGraphExecDestroy while a stream is capturing is an error, raised
+    from a destructor, i.e. an abort (seen as a rare `Fatal Python error: Aborted ... Garbage-collecting` of a whole
+    test session, never with the collector off).  Default error mode `thread_local`: calls of OTHER threads (a
+    collective's watchdog, the noise helper) do not invalidate this thread's capture."""
+    import torch
+    kwargs.setdefault('capture_error_mode', 'thread_local')
+    enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kwargs):
+            yield
+    finally:
+        if enabled:
+            gc.enable()
+

@@ -120,6 +120,9 @@ struct MlpFwdArgs {
   int enc_O, enc_ld;
   float* reset_area; int64_t reset_floats;   // the launch AHEAD of the chained ones: fill with kExchangeEmpty
   unsigned* reset_failed;                    //   ... and clear their failure word
+  int reset_blocks;                          //   workgroups that share the fill, numbered net * tiles + tile (0: the
+                                             //   whole grid of a launch of its own; set where the pass rides in
+                                             //   another launch: QCriticStep::ahead)
   float* xq;                    // chained launches: the value head's outputs ALSO go (agent-scope stores) to the launch's
                                 //   exchange lines, see ValueLines; null: none
   int tail_offset;              // set by launch_mlp_forward: where the tail's LDS images start (floats)
@@ -314,6 +317,12 @@ struct QCriticStep {
   MlpBwdArgs bwd;            // the online critics' chain, loss = LOSS_TD
   int nets;
   int lose_first_target;     // test hook (tuning key "chain_fault"): workgroup 0 returns without a word
+  // ahead_nets > 0 (image passes): `ahead_nets` x tiles MORE workgroups behind the step's own run the policy passes
+  // (launch 1) of the NEXT iteration — with delayed actor updates (td3.py:43-46) a critic step that is not followed
+  // by an actor step leaves everything those passes read alone; they exchange nothing with the step's roles and
+  // write another set of buffers (tonic_q_iteration_t.slot), and at B = 100 the step fills a ninth of the chip.
+  MlpFwdArgs ahead;
+  int ahead_nets;
 };
 // Actor step: roles [critic_0 .. critic_{used-1} | actor] — the critics' forward on (s, a_new), the
 // actor objective (the twin critics exchange q), their chain down to the action columns, then the

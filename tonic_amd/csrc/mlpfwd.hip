@@ -370,8 +370,9 @@ __device__ __forceinline__ void mlp_forward_body(const MlpFwdArgs& a, const int 
   if (a.reset_area != nullptr) {
     // the launch AHEAD of the chained ones empties their exchange area (kExchangeEmpty everywhere):
     // plain stores, published by the kernel boundary
-    const int64_t first = ((int64_t)net * gridDim.x + bx) * blockDim.x + tid;
-    const int64_t stride = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+    const int row_tiles = (a.B + kRows - 1) / kRows;
+    const int64_t first = ((int64_t)net * (a.reset_blocks > 0 ? row_tiles : (int)gridDim.x) + bx) * blockDim.x + tid;
+    const int64_t stride = (int64_t)(a.reset_blocks > 0 ? a.reset_blocks : (int)(gridDim.x * gridDim.y)) * blockDim.x;
     unsigned* area = reinterpret_cast<unsigned*>(a.reset_area);
     for (int64_t i = first; i < a.reset_floats; i += stride) area[i] = kExchangeEmpty;
     if (first == 0 && a.reset_failed != nullptr) *a.reset_failed = 0u;   // (and their failure word)
@@ -930,8 +931,16 @@ __global__ __launch_bounds__(256) void q_critic_step_kernel(QCriticStep c) {
   const int roles = 2 * c.nets;
   const int tile = blockIdx.x / roles, role = blockIdx.x - tile * roles;      // scalar
   const int tiles = (c.fwd.B + kRows - 1) / kRows;
-  if (tile == tiles) {                                // the extra workgroup: the logged sums
+  const int own = tiles * roles;                      // scalar
+  if ((int)blockIdx.x == own) {                       // the extra workgroup: the logged sums
     chain_stats_role(c.bwd);
+    return;
+  }
+  if ((int)blockIdx.x > own) {                        // behind it: the NEXT iteration's policy passes (QCriticStep)
+    if constexpr (IMG) {
+      const int j = (int)blockIdx.x - own - 1;
+      mlp_forward_body_img(c.ahead, j / tiles, j - (j / tiles) * tiles, lds);
+    }
     return;
   }
   if (c.lose_first_target != 0 && blockIdx.x == 0) return;    // test hook: a workgroup that never answers
@@ -1132,10 +1141,24 @@ int launch_q_critic_step(const QCriticStep& c, hipStream_t stream) {
   const bool images = f.img.block != nullptr;
   TONIC_REQUIRE(images == (c.bwd.img.block != nullptr) && (!images || image_pass_supported(f.K1, f.H)),
                 TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: weight images for one half only (K1=%d H=%d)", f.K1, f.H);
+  TONIC_REQUIRE(c.ahead_nets == 0 ||
+                    (images && c.ahead_nets <= 2 && c.ahead.img.block != nullptr && c.ahead.B == f.B &&
+                     c.ahead.H == f.H && c.ahead.K1 <= f.K1 && c.ahead.post != POST_NONE &&
+                     c.ahead.done_flags == nullptr && c.ahead.store_on == 0 &&
+                     (c.ahead_nets == 1 || (c.ahead.split == 1 && c.ahead.tail2.post != POST_NONE))),
+                TONIC_ERR_INVALID_ARGUMENT, "q_critic_step: %d policy passes ahead (images %d)", c.ahead_nets,
+                (int)images);
+  if (c.ahead_nets > 0) {                               // (what launch_mlp_forward sets for a launch of its own)
+    const ImgLds L = img_lds(c.ahead.K1, c.ahead.H);
+    launch.ahead.tail_offset = L.off_f32 / 4;
+    launch.ahead.lds_floats = L.total / 4;
+    launch.ahead.stamps = nullptr;
+    launch.ahead.reset_blocks = tiles * c.ahead_nets;
+  }
   if (images) {
     const int status = allow_image_lds(q_critic_step_kernel<true>, "q_critic_step_kernel");
     if (status != TONIC_OK) return status;
-    hipLaunchKernelGGL(q_critic_step_kernel<true>, dim3(tiles * 2 * c.nets + 1), dim3(256),
+    hipLaunchKernelGGL(q_critic_step_kernel<true>, dim3(tiles * 2 * c.nets + 1 + tiles * c.ahead_nets), dim3(256),
                        img_lds(f.K1, f.H).total, stream, launch);
   } else {
     hipLaunchKernelGGL(q_critic_step_kernel<false>, dim3(tiles * 2 * c.nets + 1), dim3(256),

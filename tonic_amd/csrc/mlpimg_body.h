@@ -216,8 +216,9 @@ __device__ __forceinline__ void mlp_forward_body_img(const MlpFwdArgs& a, const 
   float* desc = partial + 64;
   if (a.reset_area != nullptr) {
     // the launch AHEAD of the chained ones empties their exchange area (kExchangeEmpty everywhere)
-    const int64_t first = ((int64_t)net * gridDim.x + bx) * blockDim.x + tid;
-    const int64_t stride = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+    const int row_tiles = (a.B + kRows - 1) / kRows;
+    const int64_t first = ((int64_t)net * (a.reset_blocks > 0 ? row_tiles : (int)gridDim.x) + bx) * blockDim.x + tid;
+    const int64_t stride = (int64_t)(a.reset_blocks > 0 ? a.reset_blocks : (int)(gridDim.x * gridDim.y)) * blockDim.x;
     unsigned* area = reinterpret_cast<unsigned*>(a.reset_area);
     for (int64_t i = first; i < a.reset_floats; i += stride) area[i] = kExchangeEmpty;
     if (first == 0 && a.reset_failed != nullptr) *a.reset_failed = 0u;

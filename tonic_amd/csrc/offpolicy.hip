@@ -1351,22 +1351,33 @@ constexpr int64_t kChainSyncArea = 64;               // floats
 
 int64_t q_iteration_floats(int B, int O, int A, int H) {
   const int64_t Bp = pad16(B), ldx = pitch16(O + A), ldh = pad16(A), HP = weight_ld(H);
-  return 2 * (2 * Bp * HP + 2 * Bp * ldh)           // policy passes: h1, h2, two head outputs, x2
-         + 3 * Bp * A + 2 * Bp                      // next actions, new actions, sigma, two log-probs
-         + 3 * Bp * ldx                             // X (s', a'), X2 (s, a), X3 (s, a_new)
+  // what the policy passes (launch 1) write and the chained launches exchange: two sets (tonic_q_iteration_t.slot)
+  const int64_t set = 2 * (2 * Bp * HP + 2 * Bp * ldh)   // policy passes: h1, h2, two head outputs, x2
+                      + 3 * Bp * A + 2 * Bp              // next actions, new actions, sigma, two log-probs
+                      + 3 * Bp * ldx                     // X (s', a'), X2 (s, a), X3 (s, a_new)
+                      + 2 * Bp * ldh                     // dxa (two critics)
+                      + (Bp / 16) * kExchangeTileFloats; // the chained launches' value lines
+  return 2 * set
          + 2 * 4 * Bp * HP + 4 * Bp                 // four-critic forward: h1, h2, values
          + 2 * Bp + 2 * 2 * Bp * HP                 // dq, dz2, dz1 of two critics
-         + 2 * Bp * ldh + 2 * Bp * ldh              // dxa (two critics), dloc, dspre
+         + 2 * Bp * ldh                             // dloc, dspre
          + 2 * Bp * HP                              // actor dz2, dz1
-         + kChainSyncArea                           // the chained launches' failure word (first)
-         + (Bp / 16) * kExchangeTileFloats          // their value lines
+         + kChainSyncArea                           // the chained launches' failure words (first)
          + images_floats(O, A, H, 2);               // the six networks' weight images (mlpimg.h)
 }
 
 }  // namespace
 
 extern "C" int64_t tonic_q_iteration_workspace_bytes(int32_t B, int32_t O, int32_t A, int32_t H) {
-  return (q_iteration_floats(B, O, A, H) + 64 * 40) * 4;
+  return (q_iteration_floats(B, O, A, H) + 64 * 64) * 4;       // (+ the 256-byte rounding of every take)
+}
+
+extern "C" int tonic_q_iteration_ahead_supported(int32_t B, int32_t O, int32_t H, int32_t A, int32_t nets,
+                                                 int32_t passes) {
+  if (B <= 0 || nets < 1 || nets > 2 || passes < 1 || passes > 2) return 0;
+  if (g_q_chain.load() == 0 || !hidden_plain(H) || !images_serve(O, A, H) || !mlp_image_pass_supported(O, H)) return 0;
+  const int tiles = (B + 15) / 16;
+  return tiles * (2 * nets + passes) + 1 <= 256;      // one workgroup per compute unit: all of them at once
 }
 
 extern "C" int tonic_q_iteration_supported(int32_t O, int32_t H, int32_t A, int32_t heads) {
@@ -1383,6 +1394,18 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const int phase = a.phase;                 // 0 whole iteration | 1 critic half | 2 actor half (sums only)
   TONIC_REQUIRE(phase >= 0 && phase <= 2 && (phase != 2 || due), TONIC_ERR_INVALID_ARGUMENT,
                 "tonic_q_iteration: phase %d (actor_due %d)", phase, (int)due);
+  const int stage = a.stage, slot = a.slot;  // 0 whole | 2 behind the policy passes; the set of launch-1 outputs
+  TONIC_REQUIRE((stage == 0 || stage == 2) && (stage == 0 || phase == 0) && (slot == 0 || slot == 1),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_q_iteration: stage %d, slot %d (phase %d)", stage, slot, phase);
+  const tonic_q_iteration_t* next = a.ahead;           // the iteration whose policy passes ride in this critic step
+  TONIC_REQUIRE(next == nullptr ||
+                    (phase == 0 && !due && next->kind == kind && next->B == B && next->O == O && next->H == H &&
+                     next->A == A && next->slot == (slot ^ 1) && next->d_workspace == a.d_workspace &&
+                     next->d_actor == a.d_actor && next->d_target_actor == a.d_target_actor &&
+                     next->d_next_observations && next->d_observations && next->d_actions &&
+                     (next->d_eps_critic || kind == 2) && (next->d_eps_actor || kind != 1 || !next->actor_due) &&
+                     tonic_q_iteration_ahead_supported(B, O, H, A, kind == 2 ? 1 : 2, next->actor_due ? 2 : 1)),
+                TONIC_ERR_INVALID_ARGUMENT, "tonic_q_iteration: policy passes ahead (actor_due %d)", (int)due);
   TONIC_REQUIRE(kind >= 0 && kind <= 2 && B > 0 && a.d_actor && a.d_critics && a.d_target_actor &&
                     a.d_target_critics && a.d_norm_mean && a.d_norm_std && a.d_observations &&
                     a.d_actions && a.d_next_observations && a.d_rewards && a.d_discounts &&
@@ -1403,21 +1426,35 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const ActorShape as{O, H, A, heads};
   const int64_t Pc = critic_count(cs), Pa = actor_count(as), hs = (int64_t)Bp * HP;
   Workspace ws{static_cast<char*>(a.d_workspace), 0, a.workspace_bytes};
-  unsigned* failed = reinterpret_cast<unsigned*>(ws.take(kChainSyncArea));
-  // the chained launches' exchange area: the value lines of the tiles, then the critics' action-
-  // column gradients — ONE span, emptied by the policy launch (launch 1) of every iteration
-  float* xq = ws.take((int64_t)(Bp / 16) * kExchangeTileFloats);
-  float* dxa = ws.take(2LL * Bp * ldh);
-  float* exchange_end = ws.take(0);
+  // (one failure word per set: the passes that run ahead clear THEIR iteration's word while this one's launches may set theirs)
+  unsigned* failed_words = reinterpret_cast<unsigned*>(ws.take(kChainSyncArea));
+  unsigned* failed = failed_words + slot;
+  // Everything launch 1 writes — the chained launches' exchange area (the value lines of the tiles, then the
+  // critics' action-column gradients: ONE span, emptied by the policy launch of every iteration), the policy
+  // passes' activations and head outputs [net 0 | net 1], the actions / log-probabilities, the critics' input
+  // rows — twice: an iteration works on set `slot`, the passes it runs ahead for the next one on the other
+  struct PolicySet {
+    float *xq, *dxa, *exchange_end, *p_h1, *p_h2, *head0, *head1, *next_act, *logp_next, *act, *sigma, *logp,
+        *X, *X2, *X3;
+  } sets[2];
+  for (int set = 0; set < 2; ++set) {
+    PolicySet& t = sets[set];
+    t.xq = ws.take((int64_t)(Bp / 16) * kExchangeTileFloats);
+    t.dxa = ws.take(2LL * Bp * ldh);
+    t.exchange_end = ws.take(0);
+    t.p_h1 = ws.take(2 * hs); t.p_h2 = ws.take(2 * hs);
+    t.head0 = ws.take(2LL * Bp * ldh); t.head1 = ws.take(2LL * Bp * ldh);
+    t.next_act = ws.take((int64_t)Bp * A); t.logp_next = ws.take(Bp);
+    t.act = ws.take((int64_t)Bp * A); t.sigma = ws.take((int64_t)Bp * A);
+    t.logp = ws.take(Bp);
+    t.X = ws.take((int64_t)Bp * ldx); t.X2 = ws.take((int64_t)Bp * ldx);
+    t.X3 = ws.take((int64_t)Bp * ldx);
+  }
+  const PolicySet& mine = sets[slot];
+  float *xq = mine.xq, *dxa = mine.dxa, *p_h1 = mine.p_h1, *p_h2 = mine.p_h2, *head1 = mine.head1,
+        *logp_next = mine.logp_next, *act = mine.act, *sigma = mine.sigma, *logp = mine.logp, *X = mine.X,
+        *X2 = mine.X2, *X3 = mine.X3;
   const bool chain = g_q_chain.load() != 0;
-  // policy passes [net 0 | net 1]
-  float* p_h1 = ws.take(2 * hs); float* p_h2 = ws.take(2 * hs);
-  float* head0 = ws.take(2LL * Bp * ldh); float* head1 = ws.take(2LL * Bp * ldh);
-  float* next_act = ws.take((int64_t)Bp * A); float* logp_next = ws.take(Bp);
-  float* act = ws.take((int64_t)Bp * A); float* sigma = ws.take((int64_t)Bp * A);
-  float* logp = ws.take(Bp);
-  float* X = ws.take((int64_t)Bp * ldx); float* X2 = ws.take((int64_t)Bp * ldx);
-  float* X3 = ws.take((int64_t)Bp * ldx);
   float* h1_all = ws.take(4 * hs); float* h2_all = ws.take(4 * hs);
   float* q_all = ws.take(4LL * Bp);
   float* c_h1 = h1_all + nets * hs; float* c_h2 = h2_all + nets * hs;
@@ -1442,48 +1479,50 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
   const ActorImg* actor_img = im.on ? &im.actor : nullptr;
   const CriticImg* critics_img = im.on ? &im.critics : nullptr;
 
-  // ---- 1: the policy passes
-  if (phase != 2) {
-    const float* policy = kind == 1 ? a.d_actor : a.d_target_actor;
+  // ---- 1: the policy passes (of iteration `it` into set `t`: this one's, or the next one's ahead of time)
+  auto policy_passes = [&](const tonic_q_iteration_t& it, const PolicySet& t, unsigned* failed_word) {
+    const bool it_due = it.actor_due != 0;
+    const float* policy = kind == 1 ? it.d_actor : it.d_target_actor;
     ActorParams p(policy, as);
     MlpFwdArgs f{};
-    f.X = a.d_next_observations; f.ldx = O; f.K1 = O;
+    f.X = it.d_next_observations; f.ldx = O; f.K1 = O;
     f.W1 = p.W1; f.b1 = p.b1; f.W2 = p.W2; f.b2 = p.b2; f.ldw1 = p.ld1; f.ldw2 = p.ldH;
     f.Wh[0] = p.head_w(0); f.bh[0] = p.head_b(0);
     f.Wh[1] = p.head_w(heads - 1); f.bh[1] = p.head_b(heads - 1);
     f.heads = heads; f.NH = A;
-    f.h1 = p_h1; f.h2 = p_h2; f.ldh = HP;
-    f.out[0] = head0; f.out[1] = heads == 2 ? head1 : head0; f.ldo = ldh;
+    f.h1 = t.p_h1; f.h2 = t.p_h2; f.ldh = HP;
+    f.out[0] = t.head0; f.out[1] = heads == 2 ? t.head1 : t.head0; f.ldo = ldh;
     f.act[0] = kind != 1 ? ACT_TANH : ACT_NONE; f.act[1] = ACT_NONE;
     f.B = B; f.H = H; f.split = 1 << 30;
     f.stride_hidden = hs; f.stride_out = (int64_t)Bp * ldh;
     f.post = kind == 0 ? POST_TARGET_NOISE : kind == 2 ? POST_COPY : POST_SQUASHED_SAMPLE;
-    f.post_eps = a.d_eps_critic; f.post_actions = next_act;
-    f.post_logp = kind == 1 ? logp_next : nullptr;
-    f.noise_scale = (float)a.noise_scale; f.noise_clip = (float)a.noise_clip;
-    f.enc_obs = a.d_next_observations; f.enc_obs2 = a.d_observations; f.enc_act2 = a.d_actions;
-    f.enc_mean = a.d_norm_mean; f.enc_std = a.d_norm_std; f.enc_clip = clip_bound(a.norm_clip);
-    f.enc_out = X; f.enc_out2 = X2; f.enc_O = O; f.enc_ld = ldx;
+    f.post_eps = it.d_eps_critic; f.post_actions = t.next_act;
+    f.post_logp = kind == 1 ? t.logp_next : nullptr;
+    f.noise_scale = (float)it.noise_scale; f.noise_clip = (float)it.noise_clip;
+    f.enc_obs = it.d_next_observations; f.enc_obs2 = it.d_observations; f.enc_act2 = it.d_actions;
+    f.enc_mean = it.d_norm_mean; f.enc_std = it.d_norm_std; f.enc_clip = clip_bound(it.norm_clip);
+    f.enc_out = t.X; f.enc_out2 = t.X2; f.enc_O = O; f.enc_ld = ldx;
     // (phases: the failure word is the caller's to clear — it stands for the whole update)
-    if (chain) { f.reset_area = xq; f.reset_floats = exchange_end - xq; f.reset_failed = phase == 0 ? failed : nullptr; }
-    if (due) {
+    if (chain) { f.reset_area = t.xq; f.reset_floats = t.exchange_end - t.xq; f.reset_failed = phase == 0 ? failed_word : nullptr; }
+    if (it_due) {
       f.split = 1;
-      f.second_params = a.d_actor - policy;            // (0 for SAC: the same network on s)
-      f.X2 = a.d_observations;
+      f.second_params = it.d_actor - policy;           // (0 for SAC: the same network on s)
+      f.X2 = it.d_observations;
       f.tail2.post = kind == 1 ? POST_SQUASHED_SAMPLE : POST_COPY;
-      f.tail2.eps = kind == 1 ? a.d_eps_actor : nullptr;
-      f.tail2.actions = act; f.tail2.sigma = kind == 1 ? sigma : nullptr;
-      f.tail2.logp = kind == 1 ? logp : nullptr;
-      f.tail2.enc_obs = a.d_observations; f.tail2.enc_out = X3;
+      f.tail2.eps = kind == 1 ? it.d_eps_actor : nullptr;
+      f.tail2.actions = t.act; f.tail2.sigma = kind == 1 ? t.sigma : nullptr;
+      f.tail2.logp = kind == 1 ? t.logp : nullptr;
+      f.tail2.enc_obs = it.d_observations; f.tail2.enc_out = t.X3;
     }
     if (im.on) {
       const ActorImg& pi = kind == 1 ? im.actor : im.target_actor;
       f.img = FwdImages{pi.block, pi.v.f1, pi.v.f2, {pi.v.fh[0], pi.v.fh[heads - 1]}, 0,
-                        due ? im.actor.block - pi.block : 0};
+                        it_due ? im.actor.block - pi.block : 0};
       f.hidden_from = 1;             // (net 0, the critic step's policy, has no backward)
     }
-    TRY(launch_mlp_forward(f, due ? 2 : 1, st));
-  }
+    return f;
+  };
+  if (phase != 2 && stage != 2) TRY(launch_mlp_forward(policy_passes(a, mine, failed), due ? 2 : 1, st));
   // ---- 2: targets on (s', a') and online critics on (s, a)
   // ---- 3 + 4: TD loss, backward chain, weight gradients + Adam (+ polyak of the critics)
   const float grad_scale = (float)(1.0 / (a.global_batch > 0 ? a.global_batch : B));
@@ -1519,10 +1558,15 @@ extern "C" int tonic_q_iteration(const tonic_q_iteration_t* it, void* stream) {
     step.bwd.l_tq = xq; step.bwd.l_tq_at = ValueLines{32, kExchangeTileFloats};
     step.bwd.l_q = xq + 64; step.bwd.l_q_at = ValueLines{32, kExchangeTileFloats};
     step.nets = nets;
+    if (next != nullptr) {            // the next iteration's policy passes: more workgroups of this launch
+      step.ahead = policy_passes(*next, sets[slot ^ 1], failed_words + (slot ^ 1));
+      step.ahead_nets = next->actor_due ? 2 : 1;
+    }
     TRY(launch_q_critic_step(step, st));
     TRY(critics_weight_gradients(cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,
                                  a.critic.d_grad_sums, st, critic_fold, critics_img));
   } else {
+    TONIC_REQUIRE(next == nullptr, TONIC_ERR_INVALID_ARGUMENT, "tonic_q_iteration: passes ahead need the chained launches");
     TRY(critics_forward(a.d_target_critics, cs, nets, X, ldx, B, Bp, h1_all, h2_all, q_all, st,
                         a.d_critics, X2, im.on ? &im.target_critics : nullptr));
     TRY(critics_backward(a.d_critics, cs, nets, X2, ldx, B, Bp, c_h1, c_h2, dq, dh2, dh1,

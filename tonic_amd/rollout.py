@@ -113,7 +113,7 @@ class DeviceRollout:
                 # run polling its events) must not invalidate this thread's capture.
                 graph = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    with _lib.capturing(graph):
                         self._enqueue()
                     self.graph = graph
                 except RuntimeError as error:       # still the HIP path, just launched eagerly

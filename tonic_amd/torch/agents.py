@@ -1626,6 +1626,9 @@ class DDPG(Agent):
             # the store does not change during an update: the batches of ALL its iterations are
             # gathered by one launch (the rows a rank does not own are padding, never read)
             batches = self.replay.gather_many(self._static_indices)
+            if fused is not None and not phased and counts is None:
+                self._enqueue_fused_iterations(fused, batches, iterations)
+                return
             for it in range(iterations):
                 c = global_batch if counts is None else int(counts[it])
                 n_global = None if counts is None else global_batch
@@ -1666,7 +1669,7 @@ class DDPG(Agent):
                 self._fused_workspace_for(batch_size)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with _lib.capturing(self._graph):
                 enqueue()
         self._graph.replay()
         self._step_mirror_valid = fused is not None and not phased
@@ -1740,7 +1743,41 @@ class DDPG(Agent):
             self._enqueue_fused(kind, batch, iteration, actor_due, phase=2)
             actor._step(n, self._infos[1, iteration], targets=targets)
 
+    def _enqueue_fused_iterations(self, kind, batches, iterations):
+        """The fused iterations of one update call.  With delayed actor updates (td3.py:43-46) the policy passes
+        (launch 1) of iteration k + 1 — they read the actor, the target actor, ITS batch and noise, none of which a
+        critic step writes — ride as more workgroups in the critic-step launch of an iteration k that does not step
+        the actor (tonic_q_iteration_t.ahead: the workspace's other set of launch-1 outputs; iteration k + 1 then
+        starts behind them, stage 2).  At B = 100 a launch fills a ninth of the chip: one launch and its dispatch
+        less per pair of iterations.  Same kernels' code on the same inputs: the same bits
+        (TONIC_AMD_POLICY_AHEAD=0: every iteration by itself; the tests compare)."""
+        due = [bool(self._actor_due(it)) for it in range(iterations)]
+        B = batches['observations'].shape[1]
+        nets = 1 if kind == 2 else 2
+        ahead_on = os.environ.get('TONIC_AMD_POLICY_AHEAD', '1') != '0' and not all(due)
+        args = [None] * iterations
+        slot, riding = 0, False          # riding: this iteration's policy passes ran in the previous critic step
+        for it in range(iterations):
+            args[it] = self._fused_arguments(kind, {k: v[it] for k, v in batches.items()}, it, due[it],
+                                             stage=2 if riding else 0, slot=slot)
+            riding = (ahead_on and not due[it] and it + 1 < iterations and bool(
+                self.lib.tonic_q_iteration_ahead_supported(B, self.observation_size, self.hidden, self.action_size,
+                                                           nets, 2 if due[it + 1] else 1)))
+            if riding:
+                slot ^= 1
+            args[it].rides_next = riding
+        for it in range(iterations):
+            if args[it].rides_next:
+                args[it].ahead = ctypes.cast(ctypes.pointer(args[it + 1]), ctypes.c_void_p)
+            _lib.check(self.lib.tonic_q_iteration(ctypes.byref(args[it]), _lib.current_stream()),
+                       'tonic_q_iteration')
+
     def _enqueue_fused(self, kind, batch, iteration, actor_due, phase=0):
+        _lib.check(self.lib.tonic_q_iteration(
+            ctypes.byref(self._fused_arguments(kind, batch, iteration, actor_due, phase)), _lib.current_stream()),
+            'tonic_q_iteration')
+
+    def _fused_arguments(self, kind, batch, iteration, actor_due, phase=0, stage=0, slot=0):
         critic, actor, model, p = self.critic_updater, self.actor_updater, self.model, _lib.ptr
         B = batch['observations'].shape[0]
         ws = self._fused_workspace_for(B)
@@ -1753,7 +1790,7 @@ class DDPG(Agent):
             return _lib.QOptimizer(p(updater.grad_sums), p(updater.exp_avg), p(updater.exp_avg_sq),
                                    p(updater.state), p(info_row), p(constants), h['lr'],
                                    h['betas'][0], h['betas'][1], h['eps'])
-        args = _lib.QIteration(
+        return _lib.QIteration(
             kind=kind, actor_due=int(bool(actor_due)), B=B, O=self.observation_size, H=self.hidden,
             A=self.action_size, global_batch=B,
             d_actor=p(model.flat_actor.flat), d_critics=p(model.flat_critics.flat),
@@ -1774,12 +1811,10 @@ class DDPG(Agent):
                              self._static_adam[iteration, 0] if phase == 0 else None),
             actor=optimizer(actor, self._infos[1, iteration],
                             self._static_adam[iteration, 1] if phase == 0 else None),
-            d_workspace=p(ws), workspace_bytes=ws.numel(), phase=phase,
+            d_workspace=p(ws), workspace_bytes=ws.numel(), phase=phase, stage=stage, slot=slot,
             # the workspace's fp16x2 weight images follow the optimizer epilogues INSIDE an update call; between
             # calls anybody may have written parameters (load_state_dict, another path): rebuilt on iteration 0
             refresh_images=int(iteration == 0 or phase != 0))
-        _lib.check(self.lib.tonic_q_iteration(ctypes.byref(args), _lib.current_stream()),
-                   'tonic_q_iteration')
 
     def _graph_signature(self):
         parts = []
