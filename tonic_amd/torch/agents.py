@@ -1755,20 +1755,19 @@ class DDPG(Agent):
         B = batches['observations'].shape[1]
         nets = 1 if kind == 2 else 2
         ahead_on = os.environ.get('TONIC_AMD_POLICY_AHEAD', '1') != '0' and not all(due)
-        args = [None] * iterations
-        slot, riding = 0, False          # riding: this iteration's policy passes ran in the previous critic step
+        args, rides = [], []             # rides[it]: iteration it + 1's policy passes run in it's critic step
+        slot = 0
         for it in range(iterations):
-            args[it] = self._fused_arguments(kind, {k: v[it] for k, v in batches.items()}, it, due[it],
-                                             stage=2 if riding else 0, slot=slot)
-            riding = (ahead_on and not due[it] and it + 1 < iterations and bool(
+            args.append(self._fused_arguments(kind, {k: v[it] for k, v in batches.items()}, it, due[it],
+                                              stage=2 if it and rides[it - 1] else 0, slot=slot))
+            rides.append(ahead_on and not due[it] and it + 1 < iterations and bool(
                 self.lib.tonic_q_iteration_ahead_supported(B, self.observation_size, self.hidden, self.action_size,
                                                            nets, 2 if due[it + 1] else 1)))
-            if riding:
-                slot ^= 1
-            args[it].rides_next = riding
+            if rides[it]:
+                slot ^= 1                # (the passes ahead write the other set: the next iteration's)
         for it in range(iterations):
-            if args[it].rides_next:
-                args[it].ahead = ctypes.cast(ctypes.pointer(args[it + 1]), ctypes.c_void_p)
+            if rides[it]:
+                args[it].ahead = ctypes.addressof(args[it + 1])      # (read during this call only; `args` lives on)
             _lib.check(self.lib.tonic_q_iteration(ctypes.byref(args[it]), _lib.current_stream()),
                        'tonic_q_iteration')
 
