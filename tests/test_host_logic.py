@@ -82,6 +82,27 @@ def test_offpolicy_size_queries_and_hidden_codes():
     assert lib.tonic_offpolicy_workspace_bytes(1024, O, A, H) >= images
     assert lib.tonic_q_iteration_supported(O, H, A, 2) == 1 and lib.tonic_q_iteration_supported(O, packed, A, 2) == 0
 
+    # the next iteration's policy passes riding in a critic-step launch (tonic_q_iteration_t.ahead): only while every
+    # workgroup of the launch is resident at once — tiles x (2 critics x 2 + passes) + 1 <= 256
+    assert lib.tonic_q_iteration_ahead_supported(100, 67, 256, 21, 2, 2) == 1        # cfg 4: 7 x 6 + 1
+    assert lib.tonic_q_iteration_ahead_supported(672, 67, 256, 21, 2, 2) == 1        # 42 x 6 + 1 = 253
+    assert lib.tonic_q_iteration_ahead_supported(673, 67, 256, 21, 2, 2) == 0
+    assert lib.tonic_q_iteration_ahead_supported(1024, 111, 256, 8, 2, 1) == 0       # cfg 3's batch: 64 x 5 + 1
+    assert lib.tonic_q_iteration_ahead_supported(100, 67, packed, 21, 2, 2) == 0     # not on the image passes
+    assert lib.tonic_q_iteration_ahead_supported(100, 67, 256, 21, 2, 3) == 0
+    # ... and argument errors come back before anything touches a device: a stage other than 0 / 2, a third slot,
+    # passes ahead of an iteration that steps the actor itself
+    import ctypes                                   # (TONIC_ERR_INVALID_ARGUMENT = -1)
+    def call(**fields):
+        args = _lib.QIteration(kind=0, actor_due=0, B=100, O=67, H=256, A=21, **fields)
+        return lib.tonic_q_iteration(ctypes.byref(args), None)
+    assert call(stage=1) == -1 and 'stage 1' in lib.tonic_last_error().decode()
+    assert call(slot=2) == -1
+    follower = _lib.QIteration(kind=0, actor_due=1, B=100, O=67, H=256, A=21, slot=1)
+    args = _lib.QIteration(kind=0, actor_due=1, B=100, O=67, H=256, A=21, ahead=ctypes.addressof(follower))
+    assert lib.tonic_q_iteration(ctypes.byref(args), None) == -1
+    assert 'policy passes ahead' in lib.tonic_last_error().decode()
+
 
 def test_agents_fail_loudly_without_gpu():
     import torch
